@@ -1,0 +1,414 @@
+"""CPU ORACLE for the Sub-GC hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain PyTorch-CPU fp32 (+ numpy for the integer work) restatement of the algorithm of the
+reference's `models/AttModel.py`, `models/lib/{gcn_backbone,graph_conv,graph_conv_unit,gpn}.py`,
+`models/loss_wrapper.py` and `misc/utils.py:LanguageModelCriterion`, written op-for-op the way
+the reference computes it (dense 0/1 incidence `bmm`, x5 expansion copies, python step loop,
+python-set NMS).  Each function cites the reference lines it follows.
+
+PARITY PIN: this file is checked against golden vectors produced by running the reference
+itself (tests/golden/make_golden.py -> tests/golden/*.npz; tests/test_oracle_golden.py), for
+train (outputs, losses, every intermediate, every parameter gradient), greedy / top-k / sct /
+return_att decode, NMS and the Full-GC (BatchNorm) variant.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module, and only as the checker / the timed CPU baseline.  Nothing under `sub-gc_amd/` imports it.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- options
+def opt_get(opt, name, default=None):
+    return getattr(opt, name, default) if not isinstance(opt, dict) else opt.get(name, default)
+
+
+class Cfg:
+    """The option fields the model reads (AttModel.py:44-69,96-98)."""
+
+    def __init__(self, opt):
+        g = lambda n, d=None: opt_get(opt, n, d)
+        self.vocab = g("vocab_size"); self.R = g("rnn_size"); self.E_in = g("input_encoding_size")
+        self.p_lm = g("drop_prob_lm", 0.5)
+        self.seq_length = g("max_length") or g("seq_length")           # AttModel.py:49
+        self.L = g("gcn_dim"); self.A = g("att_hid_size")
+        self.gpn = g("use_gpn", 1) == 1
+        self.noun_fuse = g("noun_fuse", 1) == 1
+        self.pred_emb_type = g("pred_emb_type", 1)
+        self.layers = g("gcn_layers", 2); self.residual = g("gcn_residual", 2)
+        self.bn = g("gcn_bn", 0) != 0
+        self.test_lstm = g("test_LSTM", 0) != 0
+        self.topk = g("use_topk_sampling", 0) != 0
+        self.topk_temp = g("topk_temp", 0.6); self.the_k = g("the_k", 3)
+        self.sct = g("sct", 0) != 0
+        self.nms_thres = g("gpn_nms_thres", 0.75); self.max_subg = g("gpn_max_subg", 1)
+        self.use_score = g("use_gt_subg", 0) == 0
+        self.ss_prob = g("sampling_prob", 0.0)
+        self.p_gpn = g("gpn_drop_prob", 0.5)      # nn.Dropout(0.5) in gpn_fc (gpn.py:27); tests pin it to 0
+
+
+def _drop(x, p, training, mask):
+    """nn.Dropout with an optionally injected keep-mask (1 = keep), scale 1/(1-p)."""
+    if not training or p == 0.0:
+        return x
+    if mask is None:
+        return F.dropout(x, p, True)
+    return x * mask.to(x.dtype) * (1.0 / (1.0 - p))
+
+
+# ----------------------------------------------------------------------------- encoder
+def feat_fusion(P, cfg, obj_dist, att_feats, pred_dist):
+    """AttModel.py:370-387."""
+    n_obj = obj_dist.size(-1); n_pred = pred_dist.size(-1)
+    if cfg.noun_fuse:
+        cls = obj_dist.reshape(-1, n_obj)[:, 1:].max(1)[1] + 1                      # :376
+        emb = F.linear(F.embedding(cls, P["sg_obj_embed.weight"]), P["obj_emb_proj.weight"], P["obj_emb_proj.bias"])
+        x = F.linear(att_feats, P["obj_v_proj.weight"], P["obj_v_proj.bias"])        # :377
+        x = torch.relu(x + emb.view(obj_dist.size(0), obj_dist.size(1), -1))        # :378
+    else:
+        x = F.linear(att_feats, P["obj_v_proj.weight"], P["obj_v_proj.bias"])        # :380
+    flat = pred_dist.reshape(-1, n_pred)
+    pc = flat[:, 1:].max(1)[1] + 1 if cfg.pred_emb_type == 1 else flat.max(1)[1]    # :383,:385
+    p = F.linear(F.embedding(pc, P["sg_pred_embed.weight"]), P["pred_emb_prj.weight"], P["pred_emb_prj.bias"])
+    return x, p.view(pred_dist.size(0), pred_dist.size(1), -1)
+
+
+def make_map(b, N, K, rel_ind, like):
+    """gcn_backbone.py:55-67: map[b, n, k, role] = 1 iff rel_ind[b, k, role] == n."""
+    maps = []
+    for role in (0, 1):
+        m = like.new_zeros(b, N, K)
+        for i in range(b):
+            m[i].scatter_(0, rel_ind[i, :, role].contiguous().view(1, K), like.new_ones(1, K))
+        maps.append(m)
+    return maps
+
+
+def collect_unit(P, pre, cfg, source, adj, bn_state, training):
+    """graph_conv_unit.py:28-36 (one _Collection_Unit)."""
+    out = F.linear(F.linear(source, P[pre + "fc_lft.weight"], P[pre + "fc_lft.bias"]),
+                   P[pre + "fc_rgt.weight"], P[pre + "fc_rgt.bias"])
+    if cfg.bn:
+        dim = out.size(-1)
+        out = F.batch_norm(out.view(-1, dim), bn_state[pre + "bn.running_mean"], bn_state[pre + "bn.running_var"],
+                           P[pre + "bn.weight"], P[pre + "bn.bias"], training, 0.1, 1e-5).view(source.shape[0], source.shape[1], dim)
+    collect = torch.bmm(adj, out)
+    return torch.relu(collect / (adj.sum(2).view(collect.size(0), collect.size(1), 1) + 1e-7))
+
+
+def gcn_backbone(P, cfg, x_obj, x_pred, rel_ind, bn_state=None, training=False, tap=None):
+    """gcn_backbone.py:29-53 + graph_conv.py:15-34; returns the x5-expanded features."""
+    b, N, L = x_obj.shape; K = x_pred.size(1)
+    skip_x, skip_p = x_obj, x_pred
+    if cfg.layers:
+        m_s, m_o = make_map(b, N, K, rel_ind, x_obj.detach())
+        for l in range(cfg.layers):
+            pre = f"gcn_backbone.gcn.{l}.gcn_collect.collect_units."
+            u = lambda i, src, adj: collect_unit(P, f"{pre}{i}.", cfg, src, adj, bn_state, training)
+            new_x = (u(0, x_pred, m_s) + u(1, x_pred, m_o)) / 2                      # graph_conv.py:24-26
+            new_p = (u(2, x_obj, m_s.transpose(1, 2)) + u(3, x_obj, m_o.transpose(1, 2))) / 2   # :29-33
+            x_obj, x_pred = new_x, new_p
+            if tap is not None:
+                tap[f"gcn_x_layer{l}"] = x_obj; tap[f"gcn_p_layer{l}"] = x_pred
+            if (l + 1) % cfg.residual == 0:                                          # gcn_backbone.py:43-47
+                x_obj = x_obj + skip_x; skip_x = x_obj
+                x_pred = x_pred + skip_p; skip_p = x_pred
+    x5 = x_obj.view(b, 1, N, L).expand(b, 5, N, L).contiguous().view(-1, N, L)      # :50-51
+    p5 = x_pred.view(b, 1, K, L).expand(b, 5, K, L).contiguous().view(-1, K, L)
+    return x5, p5
+
+
+# ----------------------------------------------------------------------------- sGPN
+def extract_subgraph_feats(b, N, L, att_feats, gpn_obj_ind):
+    """gpn.py:152-172 (node half; the predicate half is gathered by the reference but unused)."""
+    hb = gpn_obj_ind.size(-2)
+    bi = torch.arange(b).view(b, 1).expand(b, N * hb).contiguous().view(-1)
+    pos = att_feats[bi, gpn_obj_ind[:, 0].contiguous().view(-1)]
+    neg = att_feats[bi, gpn_obj_ind[:, 1].contiguous().view(-1)]
+    return torch.cat((pos.view(-1, N, L), neg.view(-1, N, L)), 0)
+
+
+def graph_pooling(N, gpn_att, gpn_pool_mtx, att_masks):
+    """gpn.py:174-185."""
+    each = gpn_pool_mtx.transpose(0, 1).contiguous().view(-1, N, N)
+    clean = torch.bmm(each, gpn_att)
+    mx = clean.max(1)[0]
+    mean = clean.sum(1) / att_masks.transpose(0, 1).sum(-1).view(-1, 1)
+    return torch.cat((mx, mean), -1)
+
+
+def cal_node_iou(a, b):
+    """gpn.py:140-150."""
+    if a.shape[0] == 0 or b.shape[0] == 0:
+        a = np.arange(a.shape[0])
+    sa, sb = set(a.tolist()), set(b.tolist())
+    return len(sa & sb) / float(len(sa | sb))
+
+
+def subgraph_nms(score, obj_ind, masks, thres, max_subgraphs, sort_kind=None):
+    """gpn.py:108-138.  `sort_kind=None` is numpy's default argsort exactly as the reference
+    calls it (unstable on ties); 'stable' gives the documented tie rule (larger index first)."""
+    score = np.asarray(score); obj_ind = np.asarray(obj_ind); masks = np.asarray(masks)
+    order = (np.argsort(score) if sort_kind is None else np.argsort(score, kind=sort_kind))[::-1]
+    sets = [np.unique(obj_ind[i][masks[i].nonzero()[0]]) for i in order]
+    keep = np.ones(len(order))
+    for i in range(len(order)):
+        if keep[i] == 0:
+            continue
+        for j in range(i + 1, len(order)):
+            if cal_node_iou(sets[i], sets[j]) > thres:
+                keep[j] = 0
+    kept_sorted = order[keep == 1]
+    flag = np.zeros(len(order))
+    flag[kept_sorted[:max_subgraphs]] = 1
+    return flag.nonzero()[0]
+
+
+def gpn_layer(P, cfg, b, N, L, gpn_obj_ind, gpn_pool_mtx, att_feats, att_masks, training, masks=None, tap=None,
+              nms_sort_kind=None):
+    """gpn.py:41-106 (both branches)."""
+    hb = gpn_obj_ind.size(-2)
+    gpn_att = extract_subgraph_feats(b, N, L, att_feats, gpn_obj_ind)
+    gb = gpn_att.size(0)
+    read_out = graph_pooling(N, gpn_att, gpn_pool_mtx, att_masks)
+    if tap is not None:
+        tap["read_out"] = read_out
+    if cfg.use_score:
+        hid = torch.relu(F.linear(read_out, P["gpn_layer.gpn_fc.0.weight"], P["gpn_layer.gpn_fc.0.bias"]))
+        hid = _drop(hid, cfg.p_gpn, training, None if masks is None else masks.get("gpn_hid"))
+        score = torch.sigmoid(F.linear(hid, P["gpn_layer.gpn_fc.3.weight"], P["gpn_layer.gpn_fc.3.bias"]))
+        target = torch.cat((score.new_ones(gb // 2, 1), score.new_zeros(gb // 2, 1)), 0)
+        gpn_loss = F.binary_cross_entropy(score, target)
+    else:
+        score = read_out.new_ones(gb, 1); gpn_loss = None
+    rop = lambda r: F.linear(F.linear(r, P["gpn_layer.read_out_proj.0.weight"], P["gpn_layer.read_out_proj.0.bias"]),
+                             P["gpn_layer.read_out_proj.1.weight"], P["gpn_layer.read_out_proj.1.bias"])
+    if not cfg.test_lstm:                                                             # gpn.py:64-81
+        sel = score.squeeze().view(2, b, hb)[0].argmax(-1)
+        bi = torch.arange(b)
+        sub_idx = gpn_obj_ind[:, 0][bi, sel, :].view(-1)
+        att = att_feats[torch.arange(b).view(b, 1).expand(b, N).contiguous().view(-1), sub_idx, :].view(b, N, L)
+        m = att_masks[:, 0][bi, sel, :]
+        fc = rop(read_out.view(2, b, hb, -1)[0][bi, sel, :].detach())
+        if tap is not None:
+            tap.update(sel_slot=sel, att_sel=att, mask_sel=m, fc_sel=fc)
+        return gpn_loss, score, att, fc, m
+    assert b == 5                                                                     # gpn.py:84
+    s = score.squeeze().view(2, b, hb).transpose(0, 1)[0].contiguous().view(-1)
+    all_idx = gpn_obj_ind[0].contiguous().view(-1, N)
+    att = att_feats[0][all_idx.view(-1), :].view(s.size(0), N, L)
+    m = att_masks[0].contiguous().view(-1, N)
+    fc = rop(read_out.view(2, b, hb, -1).transpose(0, 1)[0].contiguous().view(-1, read_out.size(-1)))
+    keep = torch.arange(s.size(0))
+    if not cfg.sct:                                                                   # use_nms (AttModel.py:95)
+        keep = torch.from_numpy(subgraph_nms(s.detach().numpy(), all_idx.numpy(), m.numpy(), cfg.nms_thres,
+                                             cfg.max_subg, nms_sort_kind)).long()
+        s, att, fc, m = s[keep], att[keep], fc[keep], m[keep]
+    return gpn_loss, s, att, fc, m, keep
+
+
+# ----------------------------------------------------------------------------- decoder
+def prepare_feature(P, cfg, fc, att, mask, training, masks=None):
+    """AttModel.py:348-368 (+ pack_wrapper :28-36: att_embed on valid rows only, pads = 0)."""
+    n_max = int(mask.long().sum(1).max())
+    att = att[:, :n_max].contiguous(); mask = mask[:, :n_max].contiguous()
+    g = lambda k: None if masks is None else masks.get(k)
+    f = torch.relu(F.linear(fc, P["fc_embed.0.weight"], P["fc_embed.0.bias"]))
+    f = _drop(torch.relu(F.linear(f, P["fc_embed.2.weight"], P["fc_embed.2.bias"])), cfg.p_lm, training, g("fc"))
+    v = _drop(torch.relu(F.linear(att, P["att_embed.0.weight"], P["att_embed.0.bias"])), cfg.p_lm, training,
+              None if g("att") is None else g("att")[:, :n_max])
+    valid = (torch.arange(n_max).view(1, -1) < mask.long().sum(1, keepdim=True)).to(v.dtype).unsqueeze(-1)
+    v = v * valid                                                                     # packed rows only; pads are 0
+    u = F.linear(v, P["ctx2att.weight"], P["ctx2att.bias"])
+    return f, v, u, mask
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """nn.LSTMCell: gate order i, f, g, o."""
+    i, f, g, o = (F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)).chunk(4, 1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    return torch.sigmoid(o) * torch.tanh(c2), c2
+
+
+def attention(P, h, v, u, mask):
+    """AttModel.py:445-471."""
+    att_h = F.linear(h, P["core.attention.h2att.weight"], P["core.attention.h2att.bias"])
+    dot = torch.tanh(u + att_h.unsqueeze(1))
+    e = F.linear(dot, P["core.attention.alpha_net.weight"], P["core.attention.alpha_net.bias"]).squeeze(-1)
+    w = F.softmax(e, dim=1)
+    w = w * mask.float()
+    w = w / w.sum(1, keepdim=True)
+    return torch.bmm(w.unsqueeze(1), v).squeeze(1), w
+
+
+def core_step(P, cfg, it, f, v, u, mask, state, training, xt_mask=None, out_mask=None, tap=None):
+    """AttModel.py:328-341 + TopDownCore :400-431."""
+    (h1, h2), (c1, c2) = state
+    xt = _drop(torch.relu(F.embedding(it, P["embed.0.weight"])), cfg.p_lm, training, xt_mask)
+    h1, c1 = lstm_cell(torch.cat([h2, f, xt], 1), h1, c1, P["core.att_lstm.weight_ih"], P["core.att_lstm.weight_hh"],
+                       P["core.att_lstm.bias_ih"], P["core.att_lstm.bias_hh"])
+    ctx, w = attention(P, h1, v, u, mask)
+    h2, c2 = lstm_cell(torch.cat([ctx, h1], 1), h2, c2, P["core.lang_lstm.weight_ih"], P["core.lang_lstm.weight_hh"],
+                       P["core.lang_lstm.bias_ih"], P["core.lang_lstm.bias_hh"])
+    out = _drop(h2, cfg.p_lm, training, out_mask)
+    logp = F.log_softmax(F.linear(out, P["logit.weight"], P["logit.bias"]), dim=1)
+    if tap is not None:
+        for k, t in (("h_att", h1), ("c_att", c1), ("h_lang", h2), ("c_lang", c2), ("alpha", w), ("ctx", ctx), ("logp", logp)):
+            tap.setdefault("step_" + k, []).append(t)
+    return logp, ((h1, h2), (c1, c2)), w
+
+
+def _zeros_state(n, R, like):
+    z = lambda: like.new_zeros(n, R)
+    return ((z(), z()), (z(), z()))
+
+
+def _encode(P, cfg, args, bn_state, training, masks, tap, nms_sort_kind=None):
+    """Everything before the step loop (AttModel.py:128-155 / :249-276)."""
+    fc_feats, att_feats, att_masks, obj_dist, rel_ind, pred_dist, gpn_obj_ind, gpn_pool_mtx = args
+    x, p = feat_fusion(P, cfg, obj_dist, att_feats, pred_dist)
+    if tap is not None:
+        tap["fusion_x"] = x; tap["fusion_p"] = p
+    b, N, L = x.shape
+    x5, p5 = gcn_backbone(P, cfg, x, p, rel_ind, bn_state, training, tap)
+    if tap is not None:
+        tap["x_obj_out"] = x5[::5]
+    b5 = x5.size(0)
+    keep = None
+    if cfg.gpn:
+        r = gpn_layer(P, cfg, b5, N, L, gpn_obj_ind, gpn_pool_mtx, x5, att_masks, training, masks, tap, nms_sort_kind)
+        gpn_loss, score, att, fc, m = r[:5]
+        keep = r[5] if len(r) > 5 else None
+    else:                                                                             # AttModel.py:140-149 / :261-271
+        gpn_loss = None; score = None
+        rop = lambda r_: F.linear(F.linear(r_, P["read_out_proj.0.weight"], P["read_out_proj.0.bias"]),
+                                  P["read_out_proj.1.weight"], P["read_out_proj.1.bias"])
+        if cfg.sample_mode:
+            att = x5[0:1]
+            fc = rop(att.mean(1))
+            m = att_masks[0:1, 0, 0]; m[:, :36].fill_(1.0)
+            keep = torch.arange(1)
+            score = torch.ones(1)
+        else:
+            att = x5
+            fc = rop(att.mean(1).detach())
+            m = att_masks[:, 0, 0]; m[:, :36].fill_(1.0)                              # in place on the caller's tensor
+    return gpn_loss, score, att, fc, m, keep
+
+
+class Oracle:
+    """Functional model over a {reference state_dict key: tensor} parameter dict."""
+
+    def __init__(self, opt, params, requires_grad=False):
+        self.cfg = Cfg(opt)
+        self.P = {}
+        self.buffers = {}
+        for k, v in params.items():
+            t = torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
+            t = t.clone()
+            if "running_" in k or "num_batches" in k:
+                self.buffers[k] = t
+            else:
+                self.P[k] = t.float().requires_grad_(requires_grad)
+        self.training = False
+
+    # -- train ---------------------------------------------------------------
+    def forward(self, fc_feats, att_feats, seq, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
+                pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None,
+                masks=None, tap=None):
+        """AttModel._forward (AttModel.py:122-177); `masks` optionally injects dropout keep-masks."""
+        P, cfg = self.P, self.cfg
+        cfg.sample_mode = False
+        gpn_loss, score, att, fc, m, _ = _encode(P, cfg, (fc_feats, att_feats, att_masks, obj_dist, rel_ind, pred_dist,
+                                                          gpn_obj_ind, gpn_pool_mtx), self.buffers, self.training, masks, tap)
+        n = fc.size(0)
+        state = _zeros_state(n, cfg.R, fc)
+        outputs = fc.new_zeros(n, seq.size(1) - 1, cfg.vocab + 1)
+        f, v, u, mk = prepare_feature(P, cfg, fc, att, m, self.training, masks)
+        if tap is not None:
+            tap.update(p_fc=f, p_att=v, pp_att=u, p_mask=mk)
+        g = lambda k, i: None if masks is None or masks.get(k) is None else masks[k][:, i]
+        for i in range(seq.size(1) - 1):
+            it = seq[:, i].clone()                                                    # ss_prob == 0 path (:168-169)
+            if i >= 1 and seq[:, i].sum() == 0:                                       # :171-172
+                break
+            logp, state, _ = core_step(P, cfg, it, f, v, u, mk, state, self.training, g("xt", i), g("out", i), tap)
+            outputs[:, i] = logp
+        return outputs, gpn_loss, score
+
+    # -- decode --------------------------------------------------------------
+    def sample(self, fc_feats, att_feats, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
+               pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None,
+               opt=None, uniforms=None, forced=None, tap=None, nms_sort_kind=None):
+        """AttModel._sample (AttModel.py:236-326), beam_size == 1.  Top-k sampling draws from
+        `uniforms[n, T]` by inverse CDF over the k renormalised probabilities in top-k order
+        (the reference draws with torch.multinomial, which cannot be reproduced elsewhere);
+        `forced[n, T]` makes the loop follow a given token path (used to pin the top-k maths)."""
+        P, cfg = self.P, self.cfg
+        opt = opt or {}
+        return_att = opt.get("return_att", 0) == 1
+        cfg.sample_mode = True
+        with torch.no_grad():
+            _, score, att, fc, m, keep = _encode(P, cfg, (fc_feats, att_feats, att_masks, obj_dist, rel_ind, pred_dist,
+                                                           gpn_obj_ind, gpn_pool_mtx), self.buffers, False, None, tap, nms_sort_kind)
+            n = fc.size(0)
+            state = _zeros_state(n, cfg.R, fc)
+            f, v, u, mk = prepare_feature(P, cfg, fc, att, m, False)
+            T = cfg.seq_length
+            seq = torch.zeros(n, T, dtype=torch.long); lps = fc.new_zeros(n, T)
+            it = torch.zeros(n, dtype=torch.long)
+            atts, unfinished = [], None
+            for t in range(T + 1):
+                logp, state, w = core_step(P, cfg, it, f, v, u, mk, state, False, tap=tap)
+                atts.append(w)
+                if t == T:
+                    break
+                if cfg.topk:                                                          # AttModel.py:295-303
+                    lp = F.log_softmax(logp / float(cfg.topk_temp), dim=1)
+                    top, idx = torch.topk(lp, cfg.the_k, dim=1)
+                    if tap is not None:
+                        tap.setdefault("topk_idx", []).append(idx); tap.setdefault("topk_lp", []).append(top)
+                    if forced is not None:
+                        it = forced[:, t].clone()
+                        slp = lp.gather(1, it.unsqueeze(1)).view(-1)
+                    else:
+                        pr = torch.exp(top - torch.logsumexp(top, 1, keepdim=True))   # Categorical(logits=) renormalises
+                        cdf = pr.cumsum(1)
+                        uu = uniforms[:, t:t + 1] if uniforms is not None else torch.rand(n, 1)
+                        pick = (uu >= cdf).sum(1).clamp(max=cfg.the_k - 1)
+                        it = idx.gather(1, pick.unsqueeze(1)).view(-1)
+                        slp = top.gather(1, pick.unsqueeze(1)).view(-1)
+                else:
+                    slp, it = torch.max(logp, 1)                                      # :306 (first max)
+                    if forced is not None:
+                        it = forced[:, t].clone(); slp = logp.gather(1, it.unsqueeze(1)).view(-1)
+                unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
+                it = it * unfinished.type_as(it)
+                seq[:, t] = it
+                lps[:, t] = slp                                                       # un-masked after EOS (:316)
+                if unfinished.sum() == 0:
+                    break
+        out = (seq, lps, score, keep)
+        return out + (torch.stack(atts, 1),) if return_att else out
+
+
+def lm_criterion(outputs, target, mask):
+    """misc/utils.py:115-124."""
+    target = target[:, :outputs.size(1)]; mask = mask[:, :outputs.size(1)]
+    out = -outputs.gather(2, target.unsqueeze(2)).squeeze(2) * mask
+    return out.sum() / mask.sum()
+
+
+def loss_wrapper(oracle, batch, masks=None, tap=None):
+    """models/loss_wrapper.py:14-27 -> {'lang_loss', 'gpn_loss'}."""
+    from_keys = ("fc_feats", "att_feats", "labels", "att_masks", None, "obj_dist", None, "rel_ind", None, "pred_dist",
+                 "gpn_obj_ind", "gpn_pred_ind", "gpn_nrel_ind", "gpn_pool_mtx")
+    args = [None if k is None else batch[k] for k in from_keys]
+    outputs, gpn_loss, score = oracle.forward(*args, masks=masks, tap=tap)
+    lang = lm_criterion(outputs, batch["labels"][:, 1:], batch["masks"][:, 1:])
+    return {"lang_loss": lang, "gpn_loss": gpn_loss, "outputs": outputs, "subgraph_score": score}

@@ -1,0 +1,60 @@
+"""pytest wiring: `gpu` marker, import paths, golden-fixture loader."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (os.path.join(ROOT, "sub-gc_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+class Golden:
+    """One golden case: meta + lazily loaded npz groups (weights / inputs / out / grads / bn_after)."""
+
+    def __init__(self, name):
+        self.name = name
+        with open(os.path.join(GOLDEN, "meta.json")) as f:
+            self.meta = json.load(f)[name]
+
+    def group(self, g):
+        path = os.path.join(GOLDEN, f"{self.name}_{g}.npz")
+        if not os.path.exists(path):
+            return None
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}
+
+    def opt(self, **over):
+        o = dict(self.meta["opt"])
+        o.update(over)
+        o.setdefault("obj_name_path", None)
+        o.setdefault("rel_name_path", None)
+        return argparse.Namespace(**o)
+
+    def tensors(self, g):
+        d = self.group(g)
+        return None if d is None else {k: torch.from_numpy(v) for k, v in d.items()}
+
+
+@pytest.fixture
+def golden():
+    return Golden

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (CPU, fp32).
+
+Runs only where /root/reference exists (the build container).  The reference's Python is
+imported from where it lies, never copied; what is committed is data: weights, inputs,
+expected outputs and intermediates of a tiny configuration that walks the same code as
+Sub_GC_Kar / Full_GC_Kar (N=37 nodes, K=65 relations so the hard-coded 36-isms are hit).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz + meta.json
+
+Recipe: a scratch cwd with a stub `data/glove.6B.<dim>d.pt` so that
+`misc/utils.py:348-422` finds "word vectors" (all class embeddings then come from the seeded
+`normal_`), `sys.path[0] = /root/reference`, an argparse.Namespace with the fields the model
+reads, synthetic inputs from subgc.synthetic.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "sub-gc_amd"))
+from subgc import synthetic  # noqa: E402
+
+TINY = dict(rnn_size=48, input_encoding_size=48, att_feat_size=64, gcn_dim=32, fc_feat_size=40,
+            att_hid_size=24, vocab_size=50, embed_dim=20, seq_length=16, max_length=20)
+
+
+def ref_opt(**over):
+    o = dict(caption_model="topdown", num_layers=1, drop_prob_lm=0.0, use_bn=0, sampling_prob=0.0,
+             use_gpn=1, noun_fuse=1, pred_emb_type=1, gcn_layers=2, gcn_residual=2, gcn_bn=0,
+             obj_name_path=os.path.join(REF, "data/object_names_1600-0-20.npy"),
+             rel_name_path=os.path.join(REF, "data/predicate_names_1600-0-20.npy"), **TINY)
+    o.update(over)
+    return argparse.Namespace(**o)
+
+
+def enter_scratch():
+    d = tempfile.mkdtemp(prefix="subgc_golden_")
+    os.makedirs(os.path.join(d, "data"))
+    for dim in (TINY["embed_dim"], 300):
+        torch.save(({"the": 0}, torch.zeros(1, dim), dim), os.path.join(d, "data", f"glove.6B.{dim}d.pt"))
+    os.chdir(d)
+    sys.path.insert(0, REF)
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def build(opt, seed, gcn_scale):
+    from models.AttModel import TopDownModel
+    torch.manual_seed(seed)
+    m = TopDownModel(opt)
+    with torch.no_grad():  # make the GCN numerically visible (default init is N(0,1e-3^2))
+        for n, p in m.named_parameters():
+            if "gcn_collect" in n and ("fc_lft.weight" in n or "fc_rgt.weight" in n):
+                p.mul_(gcn_scale)
+            if "gcn_collect" in n and n.endswith("bias") and ".bn." not in n:
+                p.normal_(0, 0.05)
+        if hasattr(m, "gpn_layer") and hasattr(m.gpn_layer, "gpn_fc"):
+            m.gpn_layer.gpn_fc[2].p = 0.0
+            m.gpn_layer.gpn_fc[0].weight.mul_(4.0)   # spread the sGPN scores
+            m.gpn_layer.gpn_fc[3].weight.mul_(4.0)
+        # default init decodes one constant token for ever: sharpen the decoder so greedy paths
+        # vary, some reach EOS (token 0) early and the unfinished-masking is exercised
+        for n, p in m.named_parameters():
+            if n.startswith("core.") and "lstm" in n and "weight" in n:
+                p.mul_(3.0)
+            if n in ("logit.weight", "core.attention.h2att.weight", "core.attention.alpha_net.weight", "ctx2att.weight"):
+                p.mul_(8.0)
+        m.logit.bias[0] += 1.0
+    return m
+
+
+class Tap:
+    """Capture intermediates of one reference call without touching its source."""
+
+    def __init__(self, model):
+        self.m, self.rec, self.hooks = model, {}, []
+        self.steps = dict(h_att=[], c_att=[], h_lang=[], c_lang=[], alpha=[], ctx=[], logp=[])
+        m = model
+        self._wrap(m, "feat_fusion", lambda out: self.rec.update(fusion_x=np_(out[0]), fusion_p=np_(out[1])))
+        self._wrap(m, "_prepare_feature", lambda out: self.rec.update(
+            p_fc=np_(out[0]), p_att=np_(out[1]), pp_att=np_(out[2]), p_mask=np_(out[3])))
+        for l, layer in enumerate(m.gcn_backbone.gcn):
+            self.hooks.append(layer.register_forward_hook(
+                lambda mod, i, o, l=l: self.rec.update({f"gcn_x_layer{l}": np_(o[0]), f"gcn_p_layer{l}": np_(o[1])})))
+        self.hooks.append(m.gcn_backbone.register_forward_hook(
+            lambda mod, i, o: self.rec.update(x_obj_out=np_(o[0][::5]), x_pred_out=np_(o[1][::5]))))
+        if m.gpn:
+            self._wrap(m.gpn_layer, "graph_pooling", lambda out: self.rec.update(read_out=np_(out)))
+            self.hooks.append(m.gpn_layer.register_forward_hook(self._gpn_out))
+        self.hooks.append(m.core.attention.register_forward_hook(self._att))
+        self.hooks.append(m.core.register_forward_hook(self._core))
+        self._wrap(m, "get_logprobs_state", lambda out: self.steps["logp"].append(np_(out[0])))
+
+    def _wrap(self, obj, name, fn):
+        orig = getattr(obj, name)
+
+        def w(*a, **k):
+            out = orig(*a, **k)
+            fn(out)
+            return out
+        setattr(obj, name, w)
+
+    def _gpn_out(self, mod, i, o):
+        self.rec.update(subgraph_score_raw=np_(o[1]), att_sel=np_(o[2]), fc_sel=np_(o[3]), mask_sel=np_(o[4]))
+        if o[0] is not None:
+            self.rec["gpn_loss"] = np_(o[0])
+        if len(o) > 5:
+            self.rec["keep_ind"] = np_(o[5])
+
+    def _att(self, mod, i, o):
+        with torch.no_grad():
+            h, att_feats, p_att, masks = i[:4] if len(i) >= 4 else (tuple(i) + (None,))[:4]
+            _, w = type(mod).forward(mod, h, att_feats, p_att, masks, return_att=True)
+        self.steps["alpha"].append(np_(w))
+        self.steps["ctx"].append(np_(o[0] if isinstance(o, tuple) else o))
+
+    def _core(self, mod, i, o):
+        st = o[1]
+        self.steps["h_att"].append(np_(st[0][0])); self.steps["h_lang"].append(np_(st[0][1]))
+        self.steps["c_att"].append(np_(st[1][0])); self.steps["c_lang"].append(np_(st[1][1]))
+
+    def done(self):
+        for h in self.hooks:
+            h.remove()
+        for k, v in self.steps.items():
+            if v:
+                self.rec["step_" + k] = np.stack(v, 0)
+        return self.rec
+
+
+def save(name, **groups):
+    for g, d in groups.items():
+        np.savez_compressed(os.path.join(HERE, f"{name}_{g}.npz"), **d)
+
+
+def run_train(name, opt, seed, B, gcn_scale, meta):
+    from misc.utils import LanguageModelCriterion
+    model = build(opt, seed, gcn_scale)
+    model.train()
+    batch = synthetic.make_train_batch(B, D=opt.att_feat_size, vocab=opt.vocab_size, seq_length=opt.seq_length,
+                                       seed=seed + 100, fc_size=opt.att_feat_size)
+    weights = {k: np_(v) for k, v in model.state_dict().items()}
+    tap = Tap(model)
+    args = synthetic.forward_args({k: v.clone() for k, v in batch.items()})
+    outputs, gpn_loss, score = model(*args)
+    lang_loss = LanguageModelCriterion()(outputs, batch["labels"][:, 1:], batch["masks"][:, 1:])
+    loss = lang_loss + (gpn_loss if gpn_loss is not None else 0.0)
+    loss.backward()
+    rec = tap.done()
+    rec.update(outputs=np_(outputs), lang_loss=np_(lang_loss), loss=np_(loss))
+    if score is not None:
+        rec["subgraph_score"] = np_(score)
+    grads = {k: np_(p.grad) for k, p in model.named_parameters() if p.grad is not None}
+    meta[name] = dict(kind="train", B=B, seed=seed, gcn_scale=gcn_scale, opt={k: v for k, v in vars(opt).items() if "path" not in k},
+                      dead_params=[k for k, p in model.named_parameters() if p.grad is None],
+                      buffers_after={})
+    # BN running stats after this one training forward (Full-GC): part of the contract
+    after = {k: np_(v) for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    save(name, weights=weights, inputs={k: v.numpy() for k, v in batch.items()}, out=rec, grads=grads, **({"bn_after": after} if after else {}))
+    return model, weights
+
+
+def run_sample(name, opt, weights, seed, M, sample_opt, meta, node_pool=None, keys=None):
+    from models.AttModel import TopDownModel
+    torch.manual_seed(seed)
+    model = TopDownModel(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.eval()
+    batch = synthetic.make_test_batch(M, D=opt.att_feat_size, seed=seed + 200, fc_size=opt.att_feat_size, node_pool=node_pool)
+    tap = Tap(model)
+    args = synthetic.sample_args({k: v.clone() for k, v in batch.items()})
+    torch.manual_seed(seed + 7)
+    with torch.no_grad():
+        ret = model(*args, opt=dict(sample_opt), mode="sample")
+    rec = tap.done()
+    rec.update(seq=np_(ret[0]), seqLogprobs=np_(ret[1]), subgraph_score=np_(ret[2]), keep_ind=np_(ret[3]))
+    if len(ret) > 4:
+        rec["att2_weights"] = np_(ret[4])
+    if keys is not None:
+        rec = {k: v for k, v in rec.items() if k in keys}
+    meta[name] = dict(kind="sample", M=M, seed=seed, sample_opt=sample_opt, node_pool=node_pool,
+                      opt={k: v for k, v in vars(opt).items() if "path" not in k})
+    save(name, inputs={k: v.numpy() for k, v in batch.items()}, out=rec)
+
+
+def main():
+    assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
+    enter_scratch()
+    torch.set_num_threads(1)
+    meta = dict(torch=torch.__version__, numpy=np.__version__, reference="YiwuZhong/Sub-GC @ v1",
+                tolerances=dict(fp32_atol=1e-4, fp32_rtol=1e-4, indices="exact"))
+    # 1. Sub-GC: train (grads), then decode with the same weights
+    _, w = run_train("subgc_train", ref_opt(), seed=1, B=3, gcn_scale=50.0, meta=meta)
+    t = dict(test_LSTM=1, gpn_nms_thres=0.75, gpn_max_subg=10)
+    run_sample("subgc_greedy", ref_opt(**t), w, seed=2, M=24, sample_opt=dict(sample_max=1, beam_size=1, return_att=1), meta=meta, node_pool=14)
+    run_sample("subgc_greedy_nms55", ref_opt(**dict(t, gpn_nms_thres=0.55, gpn_max_subg=1000)), w, seed=3, M=40,
+               sample_opt=dict(sample_max=1, beam_size=1), meta=meta, node_pool=10,
+               keys=("seq", "seqLogprobs", "subgraph_score", "keep_ind", "subgraph_score_raw", "read_out"))
+    run_sample("subgc_sct", ref_opt(**dict(t, sct=1)), w, seed=4, M=6, sample_opt=dict(sample_max=1, beam_size=1), meta=meta)
+    run_sample("subgc_topk", ref_opt(**dict(t, use_topk_sampling=1, topk_temp=0.6, the_k=3)), w, seed=5, M=12,
+               sample_opt=dict(sample_max=1, beam_size=1), meta=meta)
+    # 2. ground-truth sub-graphs (use_gt_subg: no sGPN score / loss)
+    run_train("subgc_gtsubg_train", ref_opt(use_gt_subg=1), seed=6, B=2, gcn_scale=50.0, meta=meta)
+    # 3. Full-GC baseline: 4 layers, residual every layer, BatchNorm in the GCN, no sGPN
+    fo = dict(use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1)
+    _, wf = run_train("fullgc_train", ref_opt(**fo), seed=7, B=3, gcn_scale=50.0, meta=meta)
+    run_sample("fullgc_greedy", ref_opt(**fo), wf, seed=8, M=2, sample_opt=dict(sample_max=1, beam_size=1), meta=meta)
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True, default=str)
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print("golden written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")), f"{tot/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
