@@ -1,0 +1,288 @@
+/*
+ * subgc_hip.h -- C ABI of libsubgc_hip.so: the MI355X (gfx950) kernels of the Sub-GC hot path.
+ *
+ * The reference (YiwuZhong/Sub-GC) has no FFI layer: its hot path is ATen calls made from
+ * models/AttModel.py, models/lib/{gcn_backbone,graph_conv,graph_conv_unit,gpn}.py and
+ * misc/utils.py.  Each entry point below replaces the op site cited next to it (file:line in
+ * /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Contract for EVERY function:
+ *   - returns 0 (SUBGC_OK) or a negative SUBGC_E* code; never throws, never allocates device
+ *     memory, never synchronises the device; all work is enqueued on `stream` (a hipStream_t
+ *     passed as void*; NULL = the legacy default stream);
+ *   - all pointers are BORROWED device pointers owned by the caller (e.g. tensor.data_ptr());
+ *     outputs / scratch are caller-allocated; row-major, fp32 unless noted, indices int64 where
+ *     the reference uses LongTensor inputs and int32 for internal index structures;
+ *   - re-entrant per stream; subgc_last_error() returns a thread-local message for the last
+ *     failing call on the calling thread.
+ */
+#ifndef SUBGC_HIP_H
+#define SUBGC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUBGC_OK 0
+#define SUBGC_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
+#define SUBGC_ELAUNCH (-2)  /* hipLaunch / runtime error, see subgc_last_error() */
+#define SUBGC_EALIGN (-3)   /* pointer / leading dimension violates a documented alignment */
+
+#define SUBGC_ABI_VERSION 1
+int subgc_version(void);
+const char* subgc_last_error(void);
+/* name of the gfx target the kernels were compiled for ("gfx950") */
+const char* subgc_arch(void);
+
+/* ---- profiling hook used by bench.py (HIP events on the launch stream) -------------------
+ * While enabled, every launch of kernel family `family` (see SUBGC_FAM_*) is bracketed by a
+ * pair of hipEvents recorded on its stream.  subgc_prof_collect() synchronises those events,
+ * returns the number of launches and their summed duration (ms) and summed `work` units the
+ * launches reported (flops for GEMM, bytes for the HBM-bound families), then clears the log. */
+#define SUBGC_FAM_GEMM 1
+#define SUBGC_FAM_ATTN 2
+#define SUBGC_FAM_LSTM 3
+#define SUBGC_FAM_GCN 4
+#define SUBGC_FAM_POOL 5
+#define SUBGC_FAM_SOFTMAX 6
+int subgc_prof_enable(int family, int on);
+int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* total_work);
+
+/* ======================================================================================
+ * Dense contractions (MFMA v_mfma_f32_32x32x2_f32; exact fp32)
+ * replaces: every nn.Linear / LSTMCell matmul on the path -- AttModel.py:363-366,376-377,386,
+ *           411-413,421-423,336,340,453; graph_conv_unit.py:29-30; gpn.py:54,79 -- and their
+ *           autograd backward.
+ *
+ *   C[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )
+ *   transA = 0: A stored [M,K] (lda >= K)      transA = 1: A stored [K,M] (lda >= M)
+ *   transB = 0: B stored [K,N] (ldb >= N)      transB = 1: B stored [N,K] (ldb >= K)  (nn.Linear weight)
+ *   epilogue, in this order:  v = acc
+ *        + bias[n]                       (bias  != NULL)
+ *        + add[row, n]                   (add   != NULL, leading dim ldadd)
+ *        v = max(v, 0)                   (flags & SUBGC_GEMM_RELU)
+ *        v *= keep[row, n] * keep_scale  (keep  != NULL: uint8 dropout keep-mask, ld = ldc)
+ *        v += C[row, n]                  (flags & SUBGC_GEMM_ACCUM)
+ *        C[row, n] = v
+ *   a_rows (int32[M], transA = 0 only): row m of op(A) is A[a_rows[m], :]; a negative index
+ *        reads a zero row.   c_rows (int32[M]): `row` above is c_rows[m] instead of m (rows with
+ *        a negative c_rows[m] are not written).   m_dev (int32*, device): the number of valid
+ *        ROWS OF THE STORED A matrix, read on the device so ragged row sets need no host round
+ *        trip: with transA = 0 the effective M is min(M, *m_dev); with transA = 1 (A stored
+ *        [K,M], the weight-gradient form dW = dY^T X over a ragged row set) the effective K is
+ *        min(K, *m_dev).
+ */
+#define SUBGC_GEMM_RELU 1
+#define SUBGC_GEMM_ACCUM 2
+int subgc_gemm_f32(int transA, int transB, int M, int N, int K,
+                   const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                   const float* bias, const float* add, int64_t ldadd,
+                   const uint8_t* keep, float keep_scale, int flags,
+                   const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m, n]  -- bias gradients.  accumulate != 0 adds to out. */
+int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
+                     const int32_t* m_dev, void* stream);
+
+/* ======================================================================================
+ * Index kernels (bit-exact)
+ * row_argmax: out[r] = add + argmax_{c >= skip} X[r, c] - 0 ... first maximum wins.
+ * replaces AttModel.py:376,383,385 (class argmax, `skip`=1,`add`=0 keeps the +1 of the
+ * reference because indices are reported in the un-skipped frame), gpn.py:66 (slot select),
+ * AttModel.py:306 (greedy token; also returns the max value when val != NULL).          */
+int subgc_row_argmax_f32(const float* X, int64_t ldx, int rows, int cols, int skip,
+                         int64_t* idx, float* val, void* stream);
+
+/* CSR of the scene graph by subject and by object (replaces gcn_backbone.py:55-67 make_map).
+ * rel_ind int64 [B,K,2]; for role r in {0,1}: ptr[r][b, 0..N] (int32, [2,B,N+1]) and
+ * edges[r][b, 0..K-1] (int32, [2,B,K]) with the relations of node n at
+ * edges[r][b, ptr[r][b,n] .. ptr[r][b,n+1]) in ascending k.  Returns SUBGC_EINVAL on the
+ * host for bad sizes; out-of-range node ids are clamped to N-1 on the device.           */
+int subgc_csr_build(const int64_t* rel_ind, int B, int K, int N, int32_t* ptr, int32_t* edges, void* stream);
+
+/* ======================================================================================
+ * GCN aggregation (replaces graph_conv_unit.py:34-36 bmm + normalise + ReLU, graph_conv.py:26,33
+ * averaging and gcn_backbone.py:43-47 residual).
+ *
+ * nodes <- relations (units 0,1):
+ *   X'[b,n,:] = 1/2 relu( sum_{k: s_k=n} F0[b,k,:] / (cnt_s[n] + 1e-7) )
+ *             + 1/2 relu( sum_{k: o_k=n} F1[b,k,:] / (cnt_o[n] + 1e-7) )  (+ skip[b,n,:])
+ *   act (uint8 [B,N,L], bit0: subject-role pre-activation > 0, bit1: object-role) is saved for
+ *   the backward:  dF0[b,k,:] = 1/2 [act&1](b,s_k,:) dX'[b,s_k,:] / (cnt_s[s_k] + 1e-7), same for F1.
+ * relations <- nodes (units 2,3), c = fp32(1 + 1e-7):
+ *   P'[b,k,:] = 1/2 relu(F2[b,s_k,:] / c) + 1/2 relu(F3[b,o_k,:] / c)  (+ skip[b,k,:])
+ *   dF2[b,n,:] = 1/2 [F2[b,n,:] > 0] / c * sum_{k: s_k=n} dP'[b,k,:], same for F3 with o_k.
+ */
+int subgc_gcn_nodes_fwd(const float* F0, const float* F1, const int32_t* ptr, const int32_t* edges,
+                        const float* skip, float* Xout, uint8_t* act, int B, int N, int K, int L, void* stream);
+int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int64_t* rel_ind, const int32_t* ptr,
+                        float* dF0, float* dF1, int B, int N, int K, int L, void* stream);
+int subgc_gcn_edges_fwd(const float* F2, const float* F3, const int64_t* rel_ind, const float* skip,
+                        float* Pout, int B, int N, int K, int L, void* stream);
+int subgc_gcn_edges_bwd(const float* dP, const float* F2, const float* F3, const int32_t* ptr,
+                        const int32_t* edges, float* dF2, float* dF3, int B, int N, int K, int L, void* stream);
+
+/* BatchNorm1d over the rows of X[M,C] (graph_conv_unit.py:31-32; Full-GC only).
+ * training != 0: batch statistics (biased variance for the normalisation, unbiased for the
+ * running_var update, momentum 0.1, eps 1e-5), saves mean / rstd [C] for the backward.   */
+int subgc_bn_fwd(const float* X, float* Y, int M, int C, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float* save_mean, float* save_rstd,
+                 int training, float momentum, float eps, void* stream);
+int subgc_bn_bwd(const float* dY, const float* X, const float* gamma, const float* save_mean,
+                 const float* save_rstd, float* dX, float* dgamma, float* dbeta, int M, int C, void* stream);
+
+/* ======================================================================================
+ * sGPN (replaces gpn.py:152-185 gather + diagonal bmm + max/mean pooling, never materialising
+ * the gathered [G,N,L] tensor).  For sub-graph g (image img[g]) with node list idx[g,0..N) and
+ * per-slot weights w[g,i] (the diagonal of gpn_pool_mtx) and denom[g] (sum of att_masks):
+ *   out[g, 0:L]  = max_i  w[g,i] * X[img[g], idx[g,i], :]      (all N slots, zeros included)
+ *   out[g, L:2L] = sum_i  w[g,i] * X[img[g], idx[g,i], :] / denom[g]
+ * argmax (int32 [G,L]) records the first maximising slot for the backward, which scatter-adds
+ * into dX with fp32 atomics (node rows are shared between sub-graphs).
+ * idx is read with element stride 1 and row stride idx_stride (int64 elements); w is read as
+ * w[g*w_gstride + i*w_istride] so the diagonal of the caller's [.,N,N] pool matrix can be used
+ * in place (w_gstride = N*N, w_istride = N+1).                                              */
+int subgc_subgraph_pool_fwd(const float* X, const int64_t* idx, int64_t idx_stride, const float* w,
+                            int64_t w_gstride, int64_t w_istride, const float* denom, const int32_t* img,
+                            float* out, int32_t* argmax, int G, int N, int L, void* stream);
+int subgc_subgraph_pool_bwd(const float* dout, const int64_t* idx, int64_t idx_stride, const float* w,
+                            int64_t w_gstride, int64_t w_istride, const float* denom, const int32_t* img,
+                            const int32_t* argmax, float* dX, int G, int N, int L, void* stream);
+
+/* score head tail (gpn.py:54-57): z = <hid[g,:] * keep[g,:] * keep_scale, w2> + b2,
+ * score = sigmoid(z), loss = mean BCE(score, target) with target[g] = g < G/2 (log clamped at
+ * -100 like nn.BCELoss).  loss may be NULL.  bwd: dz, dhid (through the dropout mask), dw2, db2. */
+int subgc_gpn_score_fwd(const float* hid, const uint8_t* keep, float keep_scale, const float* w2,
+                        const float* b2, float* score, float* loss, int G, int H, void* stream);
+int subgc_gpn_score_bwd(const float* hid, const uint8_t* keep, float keep_scale, const float* w2,
+                        const float* score, const float* dloss, float* dhid, float* dw2, float* db2,
+                        int G, int H, void* stream);
+
+/* sub-graph NMS by node-set IoU (replaces gpn.py:108-150, O(M^2) python sets).
+ * score [M], idx int64 [M,N] (row stride idx_stride), len int32 [M] (valid prefix length).
+ * order: score descending, ties -> larger index first.  A sub-graph is dropped when an earlier
+ * kept one has |A∩B|/|A∪B| > thres (evaluated in double like the reference).  The first
+ * max_keep survivors are returned ASCENDING in original index: keep[0..*n_keep).  Node ids
+ * must be < 64*SUBGC_NMS_WORDS.  scratch: M * (SUBGC_NMS_WORDS*8 + 8) bytes.                 */
+#define SUBGC_NMS_WORDS 4
+int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t idx_stride, const int32_t* len,
+                       int M, int N, double thres, int max_keep, int64_t* keep, int32_t* n_keep,
+                       void* scratch, size_t scratch_bytes, void* stream);
+
+/* ======================================================================================
+ * Decoder kernels
+ */
+/* ragged attention layout: off[s] = exclusive prefix sum of len[s] (len = int32 valid nodes of
+ * sentence s), total -> *total.  Also emits for every packed row m in [off[s], off[s]+len[s]):
+ * src_row[m] = img[s]*N + idx[s, m-off[s]]  (the X_out row feeding att_embed) and
+ * sent_of[m] = s.  Rows m >= total get src_row = -1.  (replaces AttModel.py:348-354 clip_att and
+ * :16-36 sort/pack/unpack.)  idx int64 [S,N] with row stride idx_stride.                      */
+int subgc_pack_rows(const int32_t* len, const int64_t* idx, int64_t idx_stride, const int32_t* img,
+                    int S, int N, int32_t* off, int32_t* total, int32_t* src_row, int32_t* sent_of,
+                    void* stream);
+
+/* xt = dropout(relu(Emb[tok])) for a block of tokens (AttModel.py:332 over all teacher-forced
+ * steps at once).  tok int64 [n] (tok_stride elements apart); out [n,E].  bwd scatter-adds
+ * dEmb[tok] += dxt * [Emb[tok] > 0] * keep * scale with fp32 atomics.                         */
+int subgc_embed_fwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep,
+                    float keep_scale, float* out, int n, int E, int vocab_rows, void* stream);
+int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep,
+                    float keep_scale, const float* dout, float* dtable, int n, int E, int vocab_rows,
+                    void* stream);
+
+/* fused LSTM cell pointwise (nn.LSTMCell, gate order i,f,g,o; AttModel.py:413,423):
+ *   pre = g0 + g1 + g2 + b0 + b1   (g1, g2, b0, b1 may be NULL; each g* is [S,4R] with its own ld)
+ *   c = sig(f) c_prev + sig(i) tanh(g);  h = sig(o) tanh(c);  gates[S,4R] keeps the activated
+ *   i,f,g,o for the backward (may be NULL at inference).  h is written with leading dim ldh so
+ *   it can land inside the next GEMM's concatenated operand; h2 (optional) receives a second copy
+ *   (ldh2), hdrop (optional) the dropout-masked copy used by the logit layer.                  */
+int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int64_t ld1, const float* g2, int64_t ld2,
+                   const float* b0, const float* b1, const float* c_prev, float* c, float* h, int64_t ldh,
+                   float* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd,
+                   float* gates, int S, int R, void* stream);
+/* dh (up to two sources summed: dh_a, dh_b, either may be NULL) and dc (may be NULL) ->
+ * dpre [S,4R] and dc_prev.  dh_drop (optional) is a gradient that arrives through the dropout
+ * mask (keep/keep_scale).                                                                    */
+int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda,
+                   const float* dh_b, int64_t ldb, const float* dh_drop, int64_t ldd, const uint8_t* keep,
+                   float keep_scale, const float* dc, float* dpre, float* dc_prev, int S, int R, void* stream);
+
+/* one attention step over the ragged node sets (AttModel.py:453-466):
+ *   e_i = <w_a, tanh(u[m,:] + ah[s,:])> + b_a ; alpha = softmax over the sentence's valid rows
+ *   (== softmax-then-mask-then-renormalise of the reference up to rounding) ;
+ *   ctx[s,:] = sum_i alpha_i v[m,:],  m = off[s]+i.
+ * u [rows,A], v [rows,R] packed; ah [S,A]; alpha_out [S,n_stride] (entries i >= len are 0);
+ * ctx written with leading dim ldctx.                                                        */
+int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a,
+                   const int32_t* off, const int32_t* len, float* ctx, int64_t ldctx, float* alpha,
+                   int n_stride, int S, int A, int R, void* stream);
+/* backward of one step: dctx [S,R] (ld lddctx) -> dah [S,A]; du, dv ACCUMULATE (+=) over steps;
+ * dw_a [A] and db_a [1] accumulate with atomics.                                             */
+int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off,
+                   const int32_t* len, const float* alpha, int n_stride, const float* dctx, int64_t lddctx,
+                   float* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R,
+                   void* stream);
+
+/* in-place row log-softmax of logits[rows, V] (AttModel.py:336,340).  active (int32 [rows] or
+ * NULL): rows with active == 0 are written as zeros (the reference leaves `outputs` rows of the
+ * steps after its early break at zero, AttModel.py:152,171-172).                              */
+int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, const int32_t* active, void* stream);
+/* dlogits = dout - exp(logp) * sum(dout); dlogits may alias dout (in place).                 */
+int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, float* dlogits, int64_t ld, int rows,
+                               int V, const int32_t* active, void* stream);
+/* LanguageModelCriterion (misc/utils.py:115-124): num = -sum mask*logp[target], den = sum mask,
+ * loss = num/den.  logp [S,T,V]; target, mask are [S,T] views of the [S,T+1] label/mask tensors
+ * shifted by one (row strides t_stride / m_stride).  bwd writes dlogp (dense, zero elsewhere). */
+int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask,
+                         int64_t m_stride, float* loss, float* scratch2, int S, int T, int V, void* stream);
+int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
+                         const float* scratch2, const float* dloss, float* dlogp, int S, int T, int V,
+                         void* stream);
+/* step_active[t] = 1 for t = 0 and for t >= 1 while no earlier step had all labels[:, t] == 0
+ * (AttModel.py:171-172), expanded to rows: active[s*T + t].                                  */
+int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream);
+
+/* greedy / top-k token choice of one decode step (AttModel.py:295-316).
+ * greedy (k == 0): it = first argmax, lp = max.  top-k: lp' = log_softmax(logp/temp), keep the
+ * k largest (ties -> smaller index), renormalise, draw by inverse CDF with uniform u[s];
+ * lp = lp'[it].  Then unfinished &= it > 0; it *= unfinished; seq[s, t] = it; seqlp[s, t] = lp
+ * (un-masked, like the reference); next_tok[s] = it; *n_unfinished accumulates the live count.
+ * prev_count (device int32*, may be NULL): the live count after the previous step; when it is 0
+ * the kernel writes nothing -- the reference has broken out of its loop (AttModel.py:318-319) --
+ * so the whole decode loop runs without a host round trip.                                     */
+int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int k, float temp, const float* u,
+                      int t, int64_t* seq, float* seqlp, int T, int64_t* next_tok, int32_t* unfinished,
+                      int32_t* n_unfinished, const int32_t* prev_count, void* stream);
+
+/* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
+int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* small utilities */
+/* dz = dy * scale * [y > 0]   (backward of y = relu(z) * keep * scale: y > 0 <=> z > 0 and kept) */
+int subgc_relu_bwd(const float* dy, const float* y, float scale, float* dz, int64_t n, void* stream);
+/* dst[m, :] = src[rows[m], :] for m < min(M, *m_dev); negative rows give zero rows               */
+int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, float* dst, int64_t ldd,
+                      int M, int L, const int32_t* m_dev, void* stream);
+int subgc_fill_f32(float* x, int64_t n, float value, void* stream);
+/* y[rows, cols] (ldy) += / = x[rows, cols] (ldx) */
+int subgc_copy2d_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, int accumulate,
+                     void* stream);
+/* dX[rows[m], :] += src[m, :] for m < min(M, *m_dev) (fp32 atomics; negative rows skipped) */
+int subgc_scatter_add_rows(const float* src, int64_t lds, const int32_t* rows, float* dX, int64_t ldx,
+                           int M, int L, const int32_t* m_dev, void* stream);
+
+/* fused global-norm clip + Adam over one flat fp32 bucket (misc/utils.py:174-200,234-235):
+ * pass 1 accumulates sum(g^2) into *sumsq (caller zeroes it), pass 2 applies
+ * g *= max_norm / max(sqrt(sumsq), max_norm) (utils.py:193) and the torch.optim.Adam update. */
+int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* stream);
+int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
+                         float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBGC_HIP_H */

@@ -1,0 +1,79 @@
+// Shared host-side plumbing of libsubgc_hip.so: error codes, thread-local error text,
+// launch checking and the HIP-event profiling hook declared in include/subgc_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/subgc_hip.h"
+
+#define SUBGC_API extern "C" __attribute__((visibility("default")))
+
+namespace subgc {
+
+void set_error(const char* fmt, ...);
+
+// RAII bracket: records a hipEvent pair around a launch when profiling of `family` is on.
+struct ProfScope {
+    ProfScope(int family, hipStream_t s, double work);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return SUBGC_ELAUNCH;
+    }
+    return SUBGC_OK;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace subgc
+
+#define SUBGC_REQUIRE(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            subgc::set_error(__VA_ARGS__); \
+            return SUBGC_EINVAL;          \
+        }                                 \
+    } while (0)
+
+// ---- device helpers ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum through LDS scratch (>= 16 floats); every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sm[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, sm[i]);
+    return r;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

@@ -1,0 +1,93 @@
+// Host-side plumbing: version, thread-local error text, HIP-event profiling hook.
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace subgc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+constexpr int kFamilies = 8;
+struct Rec {
+    hipEvent_t a, b;
+    double work;
+};
+struct Family {
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<Rec> pool;  // recycled event pairs
+};
+Family g_fam[kFamilies];
+std::mutex g_mu;
+}  // namespace
+
+ProfScope::ProfScope(int family, hipStream_t s, double work) : slot(-1), stream(s) {
+    if (family <= 0 || family >= kFamilies || !g_fam[family].on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Family& f = g_fam[family];
+    Rec r;
+    if (!f.pool.empty()) {
+        r = f.pool.back();
+        f.pool.pop_back();
+    } else {
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    }
+    r.work = work;
+    (void)hipEventRecord(r.a, s);
+    f.recs.push_back(r);
+    slot = family * 1000000 + (int)f.recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Family& f = g_fam[slot / 1000000];
+    (void)hipEventRecord(f.recs[slot % 1000000].b, stream);
+}
+
+}  // namespace subgc
+
+SUBGC_API int subgc_version(void) { return SUBGC_ABI_VERSION; }
+SUBGC_API const char* subgc_last_error(void) { return subgc::g_err; }
+SUBGC_API const char* subgc_arch(void) { return "gfx950"; }
+
+SUBGC_API int subgc_prof_enable(int family, int on) {
+    using namespace subgc;
+    SUBGC_REQUIRE(family > 0 && family < kFamilies, "prof_enable: bad family %d", family);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_fam[family].on = on != 0;
+    return SUBGC_OK;
+}
+
+SUBGC_API int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* total_work) {
+    using namespace subgc;
+    SUBGC_REQUIRE(family > 0 && family < kFamilies, "prof_collect: bad family %d", family);
+    std::lock_guard<std::mutex> lk(g_mu);
+    Family& f = g_fam[family];
+    double ms = 0, work = 0;
+    for (Rec& r : f.recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) {
+            set_error("prof_collect: hipEventSynchronize failed");
+            return SUBGC_ELAUNCH;
+        }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        ms += t;
+        work += r.work;
+        f.pool.push_back(r);
+    }
+    if (launches) *launches = (int64_t)f.recs.size();
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    f.recs.clear();
+    return SUBGC_OK;
+}

@@ -1,0 +1,703 @@
+// Decoder-side kernels of the Sub-GC hot path: ragged attention layout, word-embedding gather,
+// fused LSTM gate math, the per-step attention (scores + softmax + context) as a wavefront-
+// primitive kernel, row log-softmax / masked NLL, greedy / top-k token choice, dropout masks and
+// the fused clip + Adam step over a flat bucket.  All HBM- or latency-bound; fp32.
+//
+// Reference op sites: AttModel.py:16-36,348-354 (clip/pack), :332 (embed), :411-413,421-423
+// (LSTMCell), :445-471 (Attention), :336,340 (log_softmax), :295-316 (token choice),
+// misc/utils.py:115-124 (criterion), :174-200,234-235 (clip-norm, Adam).
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+// ------------------------------------------------------------------ ragged rows (pack)
+__global__ __launch_bounds__(1024) void pack_rows_kernel(const int32_t* __restrict__ len, const int64_t* __restrict__ idx,
+                                                         int64_t idx_stride, const int32_t* __restrict__ img, int S, int N,
+                                                         int32_t* __restrict__ off, int32_t* __restrict__ total,
+                                                         int32_t* __restrict__ src_row, int32_t* __restrict__ sent_of) {
+    __shared__ int part[1024];
+    __shared__ int carry_s;
+    const int t = threadIdx.x;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < S; base += 1024) {
+        const int s = base + t;
+        const int l = s < S ? max(0, min(len[s], N)) : 0;
+        part[t] = l;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
+            const int v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        const int excl = carry_s + part[t] - l;
+        if (s < S) off[s] = excl;
+        __syncthreads();
+        if (t == 1023) carry_s += part[1023];
+        __syncthreads();
+    }
+    const int tot = carry_s;
+    if (t == 0) total[0] = tot;
+    // rows: one thread per (sentence, slot)
+    for (int64_t q = t; q < (int64_t)S * N; q += 1024) {
+        const int s = (int)(q / N), i = (int)(q % N);
+        const int l = max(0, min(len[s], N));
+        if (i < l) {
+            int64_t n = idx[(int64_t)s * idx_stride + i];
+            n = n < 0 ? 0 : (n >= N ? N - 1 : n);
+            const int m = off[s] + i;
+            src_row[m] = img[s] * N + (int)n;
+            sent_of[m] = s;
+        }
+        if (q >= tot) { src_row[q] = -1; sent_of[q] = -1; }
+    }
+}
+
+// ------------------------------------------------------------------ embedding (+ReLU +dropout)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
+                                                        int64_t tok_stride, const uint8_t* __restrict__ keep, float scale,
+                                                        float* __restrict__ out, int n, int E, int rows) {
+    const int r = blockIdx.x;
+    int64_t w = tok[(int64_t)r * tok_stride];
+    w = w < 0 ? 0 : (w >= rows ? rows - 1 : w);
+    for (int c = threadIdx.x; c < E; c += blockDim.x) {
+        float v = fmaxf(table[w * E + c], 0.f);
+        if (keep) v = keep[(int64_t)r * E + c] ? v * scale : 0.f;
+        out[(int64_t)r * E + c] = v;
+    }
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
+                                                        int64_t tok_stride, const uint8_t* __restrict__ keep, float scale,
+                                                        const float* __restrict__ dout, float* __restrict__ dtable, int n, int E,
+                                                        int rows) {
+    const int r = blockIdx.x;
+    int64_t w = tok[(int64_t)r * tok_stride];
+    w = w < 0 ? 0 : (w >= rows ? rows - 1 : w);
+    for (int c = threadIdx.x; c < E; c += blockDim.x) {
+        if (table[w * E + c] <= 0.f) continue;
+        float g = dout[(int64_t)r * E + c];
+        if (keep) g = keep[(int64_t)r * E + c] ? g * scale : 0.f;
+        if (g != 0.f) unsafeAtomicAdd(dtable + w * E + c, g);
+    }
+}
+
+// ------------------------------------------------------------------ LSTM gate math
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ g0, int64_t ld0, const float* __restrict__ g1,
+                                                       int64_t ld1, const float* __restrict__ g2, int64_t ld2,
+                                                       const float* __restrict__ b0, const float* __restrict__ b1,
+                                                       const float* __restrict__ c_prev, float* __restrict__ c,
+                                                       float* __restrict__ h, int64_t ldh, float* __restrict__ h2, int64_t ldh2,
+                                                       const uint8_t* __restrict__ keep, float scale, float* __restrict__ hdrop,
+                                                       int64_t ldhd, float* __restrict__ gates, int S, int R) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)S * R) return;
+    const int s = (int)(q / R), j = (int)(q % R);
+    float pre[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = k * R + j;
+        float v = g0[(int64_t)s * ld0 + col];
+        if (g1) v += g1[(int64_t)s * ld1 + col];
+        if (g2) v += g2[(int64_t)s * ld2 + col];
+        if (b0) v += b0[col];
+        if (b1) v += b1[col];
+        pre[k] = v;
+    }
+    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+    const float cp = c_prev ? c_prev[q] : 0.f;
+    const float cn = fg * cp + ig * gg;
+    const float hn = og * tanhf(cn);
+    c[q] = cn;
+    h[(int64_t)s * ldh + j] = hn;
+    if (h2) h2[(int64_t)s * ldh2 + j] = hn;
+    if (hdrop) hdrop[(int64_t)s * ldhd + j] = keep ? (keep[q] ? hn * scale : 0.f) : hn;
+    if (gates) {
+        float* gp = gates + (int64_t)s * 4 * R + j;
+        gp[0] = ig; gp[R] = fg; gp[2 * R] = gg; gp[3 * R] = og;
+    }
+}
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                       const float* __restrict__ c, const float* __restrict__ dh_a, int64_t lda,
+                                                       const float* __restrict__ dh_b, int64_t ldb, const float* __restrict__ dh_d,
+                                                       int64_t ldd, const uint8_t* __restrict__ keep, float scale,
+                                                       const float* __restrict__ dc, float* __restrict__ dpre,
+                                                       float* __restrict__ dc_prev, int S, int R) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)S * R) return;
+    const int s = (int)(q / R), j = (int)(q % R);
+    const float* gp = gates + (int64_t)s * 4 * R + j;
+    const float ig = gp[0], fg = gp[R], gg = gp[2 * R], og = gp[3 * R];
+    float dh = 0.f;
+    if (dh_a) dh += dh_a[(int64_t)s * lda + j];
+    if (dh_b) dh += dh_b[(int64_t)s * ldb + j];
+    if (dh_d) {
+        const float g = dh_d[(int64_t)s * ldd + j];
+        dh += keep ? (keep[q] ? g * scale : 0.f) : g;
+    }
+    const float tc = tanhf(c[q]);
+    float dct = dh * og * (1.f - tc * tc);
+    if (dc) dct += dc[q];
+    const float cp = c_prev ? c_prev[q] : 0.f;
+    float* dp = dpre + (int64_t)s * 4 * R + j;
+    dp[0] = dct * gg * ig * (1.f - ig);
+    dp[R] = dct * cp * fg * (1.f - fg);
+    dp[2 * R] = dct * ig * (1.f - gg * gg);
+    dp[3 * R] = dh * tc * og * (1.f - og);
+    dc_prev[q] = dct * fg;
+}
+
+// ------------------------------------------------------------------ attention step
+// one workgroup (256 threads = 4 waves) per sentence.  LDS: e/alpha [len].
+constexpr int MAXLEN = 512;
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                       const float* __restrict__ ah, const float* __restrict__ w_a,
+                                                       const float* __restrict__ b_a, const int32_t* __restrict__ off,
+                                                       const int32_t* __restrict__ len, float* __restrict__ ctx, int64_t ldctx,
+                                                       float* __restrict__ alpha, int n_stride, int S, int A, int R) {
+    __shared__ float e_s[MAXLEN];
+    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = min(len[s], MAXLEN), m0 = off[s];
+    const float* ahs = ah + (int64_t)s * A;
+    for (int i = wave; i < l; i += 4) {                 // one wave per node: dot over A with a wave reduction
+        const float* ur = u + (int64_t)(m0 + i) * A;
+        float acc = 0.f;
+        for (int a = lane; a < A; a += 64) acc += w_a[a] * tanhf(ur[a] + ahs[a]);
+        acc = wave_sum(acc);
+        if (lane == 0) e_s[i] = acc + b_a[0];
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int i = 0; i < l; ++i) mx = fmaxf(mx, e_s[i]);
+    float den = 0.f;
+    for (int i = 0; i < l; ++i) den += expf(e_s[i] - mx);
+    __syncthreads();
+    for (int i = threadIdx.x; i < l; i += blockDim.x) e_s[i] = expf(e_s[i] - mx) / den;
+    __syncthreads();
+    if (alpha)
+        for (int i = threadIdx.x; i < n_stride; i += blockDim.x) alpha[(int64_t)s * n_stride + i] = i < l ? e_s[i] : 0.f;
+    for (int c = threadIdx.x; c < R; c += blockDim.x) {
+        float acc = 0.f;
+        for (int i = 0; i < l; ++i) acc += e_s[i] * v[(int64_t)(m0 + i) * R + c];
+        ctx[(int64_t)s * ldctx + c] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                       const float* __restrict__ ah, const float* __restrict__ w_a,
+                                                       const int32_t* __restrict__ off, const int32_t* __restrict__ len,
+                                                       const float* __restrict__ alpha, int n_stride,
+                                                       const float* __restrict__ dctx, int64_t lddctx, float* __restrict__ dah,
+                                                       float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
+                                                       float* __restrict__ db_a, int S, int A, int R) {
+    __shared__ float al_s[MAXLEN];    // alpha, then de
+    __shared__ float da_s[MAXLEN];    // dalpha
+    __shared__ float red[16];
+    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = min(len[s], MAXLEN), m0 = off[s];
+    const float* dc = dctx + (int64_t)s * lddctx;
+    for (int i = threadIdx.x; i < l; i += blockDim.x) al_s[i] = alpha[(int64_t)s * n_stride + i];
+    __syncthreads();
+    // dalpha_i = <dctx, v_i> ; dv_i += alpha_i dctx
+    for (int i = wave; i < l; i += 4) {
+        const float a_i = al_s[i];
+        const float* vr = v + (int64_t)(m0 + i) * R;
+        float* dvr = dv + (int64_t)(m0 + i) * R;
+        float acc = 0.f;
+        for (int c = lane; c < R; c += 64) {
+            const float g = dc[c];
+            acc += g * vr[c];
+            dvr[c] += a_i * g;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) da_s[i] = acc;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int i = 0; i < l; ++i) dot += al_s[i] * da_s[i];
+    __syncthreads();
+    float desum = 0.f;
+    for (int i = threadIdx.x; i < l; i += blockDim.x) al_s[i] = al_s[i] * (da_s[i] - dot);   // de_i
+    __syncthreads();
+    for (int i = 0; i < l; ++i) desum += al_s[i];
+    if (threadIdx.x == 0 && db_a) unsafeAtomicAdd(db_a, desum);
+    // through tanh: thread per hidden unit a
+    const float* ahs = ah + (int64_t)s * A;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        const float wa = w_a[a], ha = ahs[a];
+        float dsum = 0.f, wsum = 0.f;
+        for (int i = 0; i < l; ++i) {
+            const int64_t o = (int64_t)(m0 + i) * A + a;
+            const float t = tanhf(u[o] + ha);
+            const float de = al_s[i];
+            const float dpre = de * wa * (1.f - t * t);
+            du[o] += dpre;
+            dsum += dpre;
+            wsum += de * t;
+        }
+        dah[(int64_t)s * A + a] = dsum;
+        unsafeAtomicAdd(dw_a + a, wsum);
+    }
+    (void)red;
+}
+
+// ------------------------------------------------------------------ log-softmax rows / NLL
+__global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x, int64_t ldx, int rows, int V,
+                                                          const int32_t* __restrict__ active) {
+    __shared__ float sm[16];
+    const int r = blockIdx.x;
+    float* p = x + (int64_t)r * ldx;
+    if (active && !active[r]) {
+        for (int c = threadIdx.x; c < V; c += blockDim.x) p[c] = 0.f;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) mx = fmaxf(mx, p[c]);
+    mx = block_max(mx, sm);
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) sum += expf(p[c] - mx);
+    sum = block_sum(sum, sm);
+    const float lse = mx + logf(sum);
+    for (int c = threadIdx.x; c < V; c += blockDim.x) p[c] = p[c] - lse;
+}
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ logp, const float* dout, float* dlogits,
+                                                              int64_t ld, int rows, int V, const int32_t* __restrict__ active) {
+    __shared__ float sm[16];
+    const int r = blockIdx.x;
+    const float* lp = logp + (int64_t)r * ld;
+    const float* d = dout + (int64_t)r * ld;
+    float* o = dlogits + (int64_t)r * ld;
+    if (active && !active[r]) {
+        for (int c = threadIdx.x; c < V; c += blockDim.x) o[c] = 0.f;
+        return;
+    }
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) sum += d[c];
+    sum = block_sum(sum, sm);
+    for (int c = threadIdx.x; c < V; c += blockDim.x) o[c] = d[c] - expf(lp[c]) * sum;
+}
+__global__ __launch_bounds__(1024) void nll_fwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
+                                                       int64_t t_stride, const float* __restrict__ mask, int64_t m_stride,
+                                                       float* __restrict__ loss, float* __restrict__ scratch2, int S, int T, int V) {
+    __shared__ float sm[16];
+    float num = 0.f, den = 0.f;
+    for (int q = threadIdx.x; q < S * T; q += blockDim.x) {
+        const int s = q / T, t = q % T;
+        const float m = mask[(int64_t)s * m_stride + t];
+        int64_t w = target[(int64_t)s * t_stride + t];
+        w = w < 0 ? 0 : (w >= V ? V - 1 : w);
+        num += -logp[(int64_t)q * V + w] * m;
+        den += m;
+    }
+    num = block_sum(num, sm);
+    den = block_sum(den, sm);
+    if (threadIdx.x == 0) { scratch2[0] = num; scratch2[1] = den; loss[0] = num / den; }
+}
+__global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* __restrict__ target, int64_t t_stride,
+                                                      const float* __restrict__ mask, int64_t m_stride,
+                                                      const float* __restrict__ scratch2, const float* __restrict__ dloss,
+                                                      float* __restrict__ dlogp, int S, int T, int V) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= S * T) return;
+    const int s = q / T, t = q % T;
+    int64_t w = target[(int64_t)s * t_stride + t];
+    w = w < 0 ? 0 : (w >= V ? V - 1 : w);
+    dlogp[(int64_t)q * V + w] = -mask[(int64_t)s * m_stride + t] / scratch2[1] * dloss[0];
+}
+__global__ __launch_bounds__(256) void step_active_kernel(const int64_t* __restrict__ labels, int64_t l_stride, int S, int T,
+                                                          int32_t* __restrict__ active) {
+    __shared__ int any_s[512];
+    __shared__ int sm_i[16];
+    for (int t = 0; t < T; ++t) {
+        int any = 0;
+        for (int s = threadIdx.x; s < S; s += blockDim.x) any |= labels[(int64_t)s * l_stride + t] != 0;
+        any = __any(any) ? 1 : 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm_i[threadIdx.x >> 6] = any;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int a = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a |= sm_i[w];
+            // the reference tests seq[:, i].sum() == 0 (labels are >= 0): "all zero" == "none non-zero"
+            any_s[t] = (t == 0) ? 1 : (a && any_s[t - 1]);
+        }
+        __syncthreads();
+    }
+    for (int q = threadIdx.x; q < S * T; q += blockDim.x) active[q] = any_s[q % T];
+}
+
+// ------------------------------------------------------------------ token choice (decode)
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* sv, int* si) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sv[w] = v; si[w] = i; }
+    __syncthreads();
+    v = sv[0]; i = si[0];
+    for (int k = 1; k < nw; ++k)
+        if (sv[k] > v || (sv[k] == v && si[k] < i)) { v = sv[k]; i = si[k]; }
+}
+constexpr int MAXK = 8;
+__global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restrict__ logp, int64_t ld, int n, int V, int k, float temp,
+                                                          const float* __restrict__ u, int t, int64_t* __restrict__ seq,
+                                                          float* __restrict__ seqlp, int T, int64_t* __restrict__ next_tok,
+                                                          int32_t* __restrict__ unfinished, int32_t* __restrict__ n_unfinished,
+                                                          const int32_t* __restrict__ prev_count) {
+    if (prev_count && *prev_count == 0) return;   // the reference has left its loop (AttModel.py:318-319)
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ float smf[16];
+    const int r = blockIdx.x;
+    const float* p = logp + (int64_t)r * ld;
+    int it; float lp;
+    if (k <= 0) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < V; c += blockDim.x) {
+            const float x = p[c];
+            if (x > bv || bi == 0x7fffffff) { bv = x; bi = c; }
+        }
+        block_argmax(bv, bi, sv, si);
+        it = bi; lp = bv;
+    } else {
+        // lp' = log_softmax(logp / temp)
+        float mx = -INFINITY;
+        for (int c = threadIdx.x; c < V; c += blockDim.x) mx = fmaxf(mx, p[c] / temp);
+        mx = block_max(mx, smf);
+        float sum = 0.f;
+        for (int c = threadIdx.x; c < V; c += blockDim.x) sum += expf(p[c] / temp - mx);
+        sum = block_sum(sum, smf);
+        const float lse = mx + logf(sum);
+        int top_i[MAXK]; float top_v[MAXK];
+        for (int j = 0; j < k; ++j) {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int c = threadIdx.x; c < V; c += blockDim.x) {
+                bool used = false;
+                for (int q = 0; q < j; ++q) used |= top_i[q] == c;
+                if (used) continue;
+                const float x = p[c] / temp - lse;
+                if (x > bv || bi == 0x7fffffff) { bv = x; bi = c; }
+            }
+            block_argmax(bv, bi, sv, si);
+            top_i[j] = bi; top_v[j] = bv;
+        }
+        // Categorical(logits=top): renormalise over the k, inverse CDF in top-k order
+        float m2 = top_v[0];
+        for (int j = 1; j < k; ++j) m2 = fmaxf(m2, top_v[j]);
+        float z = 0.f;
+        for (int j = 0; j < k; ++j) z += expf(top_v[j] - m2);
+        const float lz = m2 + logf(z);
+        const float uu = u ? u[r] : 0.f;
+        float cdf = 0.f; int pick = 0;
+        for (int j = 0; j < k; ++j) {
+            cdf += expf(top_v[j] - lz);
+            pick += uu >= cdf;
+        }
+        pick = min(pick, k - 1);
+        it = top_i[pick]; lp = top_v[pick];
+    }
+    if (threadIdx.x == 0) {
+        int unf = (t == 0) ? (it > 0) : (unfinished[r] && it > 0);
+        unfinished[r] = unf;
+        const int64_t w = unf ? it : 0;
+        seq[(int64_t)r * T + t] = w;
+        seqlp[(int64_t)r * T + t] = lp;
+        next_tok[r] = w;
+        if (unf && n_unfinished) atomicAdd(n_unfinished, 1);
+    }
+}
+
+// ------------------------------------------------------------------ dropout masks (Philox-4x32-10)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, int64_t n, float p, uint64_t seed,
+                                                           uint64_t offset) {
+    // one Philox block = 4 x u32 -> 16 mask bytes (each byte compared on its own 8-bit... no: use
+    // 4 words -> 4 uniforms; to stay cheap we draw 4 uniforms per counter and emit 4 bytes)
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset / 4 + (uint64_t)q;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = q * 4 + j;
+            if (i < n) keep[i] = ((c[j] >> 8) * (1.0f / 16777216.0f)) >= p ? 1 : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ utilities
+__global__ void fill_kernel(float* x, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+__global__ void copy2d_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int rows, int cols,
+                              int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)rows * cols; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i % cols;
+        const float v = x[r * ldx + c];
+        float* d = y + r * ldy + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ rows,
+                                                               float* __restrict__ dX, int64_t ldx, int M, int L,
+                                                               const int32_t* __restrict__ m_dev) {
+    if (m_dev) M = min(M, *m_dev);
+    const int m = blockIdx.x;
+    if (m >= M) return;
+    const int r = rows[m];
+    if (r < 0) return;
+    for (int c = threadIdx.x; c < L; c += blockDim.x) unsafeAtomicAdd(dX + (int64_t)r * ldx + c, src[(int64_t)m * lds_ + c]);
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float scale, float* __restrict__ dz, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ rows,
+                                                          float* __restrict__ dst, int64_t ldd, int M, int L,
+                                                          const int32_t* __restrict__ m_dev) {
+    if (m_dev) M = min(M, *m_dev);
+    const int m = blockIdx.x;
+    if (m >= M) return;
+    const int r = rows[m];
+    for (int c = threadIdx.x; c < L; c += blockDim.x) dst[(int64_t)m * ldd + c] = r >= 0 ? src[(int64_t)r * lds_ + c] : 0.f;
+}
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += g[i] * g[i];
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
+}
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n, const float* __restrict__ sumsq,
+                                                        float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                        float bc2) {
+    // misc/utils.py:193: coef = clip / max(total_norm, clip)
+    const float coef = max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]), max_norm) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * coef;
+        g[i] = gi;
+        if (wd != 0.f) gi += wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+inline int ew_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192)); }
+
+}  // namespace
+
+SUBGC_API int subgc_pack_rows(const int32_t* len, const int64_t* idx, int64_t idx_stride, const int32_t* img, int S, int N,
+                              int32_t* off, int32_t* total, int32_t* src_row, int32_t* sent_of, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && N > 0, "pack_rows: bad sizes");
+    SUBGC_REQUIRE(off && total && src_row && sent_of && (S == 0 || (len && idx && img)), "pack_rows: null pointer");
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, len, idx, idx_stride, img, S, N, off, total,
+                       src_row, sent_of);
+    return subgc::check_launch("subgc_pack_rows");
+}
+
+SUBGC_API int subgc_embed_fwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep, float keep_scale,
+                              float* out, int n, int E, int vocab_rows, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && E > 0 && vocab_rows > 0, "embed_fwd: bad sizes");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(table && tok && out, "embed_fwd: null pointer");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, tok, tok_stride, keep, keep_scale, out, n,
+                       E, vocab_rows);
+    return subgc::check_launch("subgc_embed_fwd");
+}
+SUBGC_API int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep, float keep_scale,
+                              const float* dout, float* dtable, int n, int E, int vocab_rows, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && E > 0 && vocab_rows > 0, "embed_bwd: bad sizes");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(table && tok && dout && dtable, "embed_bwd: null pointer");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, tok, tok_stride, keep, keep_scale, dout,
+                       dtable, n, E, vocab_rows);
+    return subgc::check_launch("subgc_embed_bwd");
+}
+
+SUBGC_API int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0,
+                             const float* b1, const float* c_prev, float* c, float* h, int64_t ldh, float* h2, int64_t ldh2,
+                             const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd, float* gates, int S, int R,
+                             void* stream) {
+    SUBGC_REQUIRE(S >= 0 && R > 0, "lstm_fwd: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(g0 && c && h, "lstm_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)S * R;
+    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12);
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev, c,
+                       h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R);
+    return subgc::check_launch("subgc_lstm_fwd");
+}
+SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda, const float* dh_b,
+                             int64_t ldb, const float* dh_drop, int64_t ldd, const uint8_t* keep, float keep_scale, const float* dc,
+                             float* dpre, float* dc_prev, int S, int R, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && R > 0, "lstm_bwd: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(gates && c && dpre && dc_prev, "lstm_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)S * R;
+    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 14);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
+                       dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R);
+    return subgc::check_launch("subgc_lstm_bwd");
+}
+
+SUBGC_API int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
+                             const int32_t* len, float* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R,
+                             void* stream) {
+    SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride >= 0 && n_stride <= MAXLEN, "attn_fwd: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(u && v && ah && w_a && b_a && off && len && ctx, "attn_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R);
+    return subgc::check_launch("subgc_attn_fwd");
+}
+SUBGC_API int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                             const float* alpha, int n_stride, const float* dctx, int64_t lddctx, float* dah, float* du, float* dv,
+                             float* dw_a, float* db_a, int S, int A, int R, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride > 0 && n_stride <= MAXLEN, "attn_bwd: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dv && dw_a, "attn_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv,
+                       dw_a, db_a, S, A, R);
+    return subgc::check_launch("subgc_attn_bwd");
+}
+
+SUBGC_API int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, const int32_t* active, void* stream) {
+    SUBGC_REQUIRE(rows >= 0 && V > 0 && ldx >= V, "log_softmax_rows: bad sizes");
+    if (rows == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(x, "log_softmax_rows: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * rows * (double)V * 2);
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
+    return subgc::check_launch("subgc_log_softmax_rows");
+}
+SUBGC_API int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, float* dlogits, int64_t ld, int rows, int V,
+                                         const int32_t* active, void* stream) {
+    SUBGC_REQUIRE(rows >= 0 && V > 0 && ld >= V, "log_softmax_rows_bwd: bad sizes");
+    if (rows == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(logp && dout && dlogits, "log_softmax_rows_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * rows * (double)V * 3);
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, s, logp, dout, dlogits, ld, rows, V, active);
+    return subgc::check_launch("subgc_log_softmax_rows_bwd");
+}
+SUBGC_API int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
+                                   float* loss, float* scratch2, int S, int T, int V, void* stream) {
+    SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "masked_nll_fwd: bad sizes");
+    SUBGC_REQUIRE(logp && target && mask && loss && scratch2, "masked_nll_fwd: null pointer");
+    hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, target, t_stride, mask, m_stride, loss,
+                       scratch2, S, T, V);
+    return subgc::check_launch("subgc_masked_nll_fwd");
+}
+SUBGC_API int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride, const float* scratch2,
+                                   const float* dloss, float* dlogp, int S, int T, int V, void* stream) {
+    SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "masked_nll_bwd: bad sizes");
+    SUBGC_REQUIRE(target && mask && scratch2 && dloss && dlogp, "masked_nll_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)S * T * V;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, s, dlogp, n, 0.f);
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3((S * T + 255) / 256), dim3(256), 0, s, target, t_stride, mask, m_stride, scratch2, dloss,
+                       dlogp, S, T, V);
+    return subgc::check_launch("subgc_masked_nll_bwd");
+}
+SUBGC_API int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream) {
+    SUBGC_REQUIRE(S > 0 && T > 0 && T <= 512, "step_active: bad sizes");
+    SUBGC_REQUIRE(labels && active, "step_active: null pointer");
+    hipLaunchKernelGGL(step_active_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, labels, l_stride, S, T, active);
+    return subgc::check_launch("subgc_step_active");
+}
+
+SUBGC_API int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int k, float temp, const float* u, int t, int64_t* seq,
+                                float* seqlp, int T, int64_t* next_tok, int32_t* unfinished, int32_t* n_unfinished,
+                                const int32_t* prev_count, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && V > 0 && k >= 0 && k <= MAXK && k <= V && t >= 0 && t < T, "decode_pick: bad sizes");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(logp && seq && seqlp && next_tok && unfinished, "decode_pick: null pointer");
+    SUBGC_REQUIRE(k == 0 || temp > 0.f, "decode_pick: temperature must be positive");
+    hipLaunchKernelGGL(decode_pick_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logp, ld, n, V, k, temp, u, t, seq, seqlp, T,
+                       next_tok, unfinished, n_unfinished, prev_count);
+    return subgc::check_launch("subgc_decode_pick");
+}
+
+SUBGC_API int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && p >= 0.f && p < 1.f && offset % 4 == 0, "dropout_mask: bad arguments");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(keep, "dropout_mask: null pointer");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, offset);
+    return subgc::check_launch("subgc_dropout_mask");
+}
+
+SUBGC_API int subgc_fill_f32(float* x, int64_t n, float value, void* stream) {
+    SUBGC_REQUIRE(n >= 0, "fill: bad size");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(x, "fill: null pointer");
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, value);
+    return subgc::check_launch("subgc_fill_f32");
+}
+SUBGC_API int subgc_copy2d_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, int accumulate, void* stream) {
+    SUBGC_REQUIRE(rows >= 0 && cols >= 0 && ldx >= cols && ldy >= cols, "copy2d: bad sizes");
+    if (rows == 0 || cols == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(x && y, "copy2d: null pointer");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols,
+                       accumulate);
+    return subgc::check_launch("subgc_copy2d_f32");
+}
+SUBGC_API int subgc_scatter_add_rows(const float* src, int64_t lds, const int32_t* rows, float* dX, int64_t ldx, int M, int L,
+                                     const int32_t* m_dev, void* stream) {
+    SUBGC_REQUIRE(M >= 0 && L > 0 && lds >= L && ldx >= L, "scatter_add_rows: bad sizes");
+    if (M == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(src && rows && dX, "scatter_add_rows: null pointer");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dX, ldx, M, L, m_dev);
+    return subgc::check_launch("subgc_scatter_add_rows");
+}
+SUBGC_API int subgc_relu_bwd(const float* dy, const float* y, float scale, float* dz, int64_t n, void* stream) {
+    SUBGC_REQUIRE(n >= 0, "relu_bwd: bad size");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(dy && y && dz, "relu_bwd: null pointer");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n);
+    return subgc::check_launch("subgc_relu_bwd");
+}
+SUBGC_API int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, float* dst, int64_t ldd, int M, int L,
+                                const int32_t* m_dev, void* stream) {
+    SUBGC_REQUIRE(M >= 0 && L > 0 && lds >= L && ldd >= L, "gather_rows: bad sizes");
+    if (M == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(src && rows && dst, "gather_rows: null pointer");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dst, ldd, M, L, m_dev);
+    return subgc::check_launch("subgc_gather_rows");
+}
+SUBGC_API int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* stream) {
+    SUBGC_REQUIRE(n >= 0, "sumsq: bad size");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(g && sumsq, "sumsq: null pointer");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(std::min(ew_grid(n), 1024)), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
+    return subgc::check_launch("subgc_sumsq_f32");
+}
+SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && step >= 1, "clip_adam_step: bad arguments");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(p && g && m && v && sumsq, "clip_adam_step: null pointer");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2);
+    return subgc::check_launch("subgc_clip_adam_step");
+}

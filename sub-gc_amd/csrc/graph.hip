@@ -1,0 +1,444 @@
+// Scene-graph kernels: class arg-max, CSR build, GCN neighbour aggregation (fwd + bwd), BatchNorm.
+// All are HBM-bound streaming kernels: threads run along the feature dimension L (coalesced
+// 256-float rows), indices live in LDS, node tiles are LDS-staged where rows are re-used.
+//
+// Reference op sites: AttModel.py:376,383,385 (argmax); gcn_backbone.py:55-67 (make_map, replaced
+// by CSR); graph_conv_unit.py:28-36 (bmm + normalise + ReLU, BatchNorm); graph_conv.py:24-33
+// (average of the two roles); gcn_backbone.py:43-47 (residual).
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+// ------------------------------------------------------------------ row arg-max (first max)
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ X, int64_t ldx, int rows,
+                                                         int cols, int skip, int64_t* __restrict__ idx,
+                                                         float* __restrict__ val) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = X + (int64_t)row * ldx;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = skip + lane; c < cols; c += 64) {
+        const float v = x[c];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = c; }   // strict >: first max inside a lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        idx[row] = bi;
+        if (val) val[row] = best;
+    }
+}
+
+// ------------------------------------------------------------------ CSR by subject / by object
+// grid (B, 2 roles); thread n owns node n: counts its relations, then lists them in ascending k.
+__global__ __launch_bounds__(256) void csr_build_kernel(const int64_t* __restrict__ rel_ind, int B, int K, int N,
+                                                        int32_t* __restrict__ ptr, int32_t* __restrict__ edges) {
+    extern __shared__ int sm_i[];
+    int* node_of = sm_i;          // [K]
+    int* start = sm_i + K;        // [N+1]
+    const int b = blockIdx.x, role = blockIdx.y;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int64_t v = rel_ind[((int64_t)b * K + k) * 2 + role];
+        node_of[k] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        int c = 0;
+        for (int k = 0; k < K; ++k) c += node_of[k] == n;
+        start[n + 1] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        start[0] = 0;
+        for (int n = 0; n < N; ++n) start[n + 1] += start[n];
+    }
+    __syncthreads();
+    int32_t* p = ptr + ((int64_t)role * B + b) * (N + 1);
+    int32_t* e = edges + ((int64_t)role * B + b) * K;
+    for (int n = threadIdx.x; n <= N; n += blockDim.x) p[n] = start[n];
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        int pos = start[n];
+        for (int k = 0; k < K; ++k)
+            if (node_of[k] == n) e[pos++] = k;
+    }
+}
+
+// ------------------------------------------------------------------ nodes <- relations
+// grid (L/256, B); thread = one feature column; CSR lists of the image in LDS.
+__global__ __launch_bounds__(256) void gcn_nodes_fwd_kernel(const float* __restrict__ F0, const float* __restrict__ F1,
+                                                            const int32_t* __restrict__ ptr,
+                                                            const int32_t* __restrict__ edges,
+                                                            const float* __restrict__ skip, float* __restrict__ Xout,
+                                                            uint8_t* __restrict__ act, int B, int N, int K, int L) {
+    extern __shared__ int sm_i[];
+    int* ps = sm_i;                 // [N+1] subject ptr
+    int* po = ps + (N + 1);         // [N+1] object ptr
+    int* es = po + (N + 1);         // [K]
+    int* eo = es + K;               // [K]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i <= N; i += blockDim.x) {
+        ps[i] = ptr[((int64_t)0 * B + b) * (N + 1) + i];
+        po[i] = ptr[((int64_t)1 * B + b) * (N + 1) + i];
+    }
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        es[i] = edges[((int64_t)0 * B + b) * K + i];
+        eo[i] = edges[((int64_t)1 * B + b) * K + i];
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= L) return;
+    const float* f0 = F0 + (int64_t)b * K * L + col;
+    const float* f1 = F1 + (int64_t)b * K * L + col;
+    for (int n = 0; n < N; ++n) {
+        float a = 0.f, c = 0.f;
+        const int s0 = ps[n], s1 = ps[n + 1], o0 = po[n], o1 = po[n + 1];
+        for (int j = s0; j < s1; ++j) a += f0[(int64_t)es[j] * L];
+        for (int j = o0; j < o1; ++j) c += f1[(int64_t)eo[j] * L];
+        a = a / ((float)(s1 - s0) + 1e-7f);
+        c = c / ((float)(o1 - o0) + 1e-7f);
+        const uint8_t bits = (a > 0.f ? 1 : 0) | (c > 0.f ? 2 : 0);
+        float v = (fmaxf(a, 0.f) + fmaxf(c, 0.f)) / 2.f;
+        const int64_t o = ((int64_t)b * N + n) * L + col;
+        if (skip) v += skip[o];
+        Xout[o] = v;
+        if (act) act[o] = bits;
+    }
+}
+
+// dF0[b,k,:] = 1/2 [bit0](b,s_k,:) dX[b,s_k,:] / (cnt_s[s_k] + 1e-7);  dF1 likewise with o_k / bit1
+__global__ __launch_bounds__(256) void gcn_nodes_bwd_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ act,
+                                                            const int64_t* __restrict__ rel_ind,
+                                                            const int32_t* __restrict__ ptr, float* __restrict__ dF0,
+                                                            float* __restrict__ dF1, int B, int N, int K, int L) {
+    extern __shared__ int sm_i[];
+    int* ns = sm_i;            // [K] subject node of k
+    int* no = ns + K;          // [K] object node of k
+    float* ds = reinterpret_cast<float*>(no + K);   // [N] cnt_s + 1e-7 denominators
+    float* dn_o = ds + N;
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int64_t s = rel_ind[((int64_t)b * K + k) * 2 + 0], o = rel_ind[((int64_t)b * K + k) * 2 + 1];
+        ns[k] = (int)(s < 0 ? 0 : (s >= N ? N - 1 : s));
+        no[k] = (int)(o < 0 ? 0 : (o >= N ? N - 1 : o));
+    }
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int32_t* p0 = ptr + ((int64_t)0 * B + b) * (N + 1);
+        const int32_t* p1 = ptr + ((int64_t)1 * B + b) * (N + 1);
+        ds[n] = (float)(p0[n + 1] - p0[n]) + 1e-7f;
+        dn_o[n] = (float)(p1[n + 1] - p1[n]) + 1e-7f;
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= L) return;
+    for (int k = 0; k < K; ++k) {
+        const int s = ns[k], o = no[k];
+        const int64_t is = ((int64_t)b * N + s) * L + col, io = ((int64_t)b * N + o) * L + col;
+        const float gs = (act[is] & 1) ? dX[is] * 0.5f / ds[s] : 0.f;
+        const float go = (act[io] & 2) ? dX[io] * 0.5f / dn_o[o] : 0.f;
+        const int64_t ok = ((int64_t)b * K + k) * L + col;
+        dF0[ok] = gs;
+        dF1[ok] = go;
+    }
+}
+
+// ------------------------------------------------------------------ relations <- nodes
+// grid (L/TC, B), TC = 128 columns; the image's F2/F3 node tiles [N x TC] are staged in LDS
+// (each node row is consumed by ~K/N relations per role), then every relation gathers from LDS.
+constexpr int TC = 128;
+__global__ __launch_bounds__(256) void gcn_edges_fwd_kernel(const float* __restrict__ F2, const float* __restrict__ F3,
+                                                            const int64_t* __restrict__ rel_ind,
+                                                            const float* __restrict__ skip, float* __restrict__ Pout,
+                                                            int B, int N, int K, int L) {
+    extern __shared__ __attribute__((aligned(16))) float sm_f[];
+    float* t2 = sm_f;                    // [N][TC]
+    float* t3 = sm_f + (size_t)N * TC;   // [N][TC]
+    int* ns = reinterpret_cast<int*>(t3 + (size_t)N * TC);   // [K]
+    int* no = ns + K;
+    const int b = blockIdx.y, c0 = blockIdx.x * TC;
+    const float cdiv1 = 1.f + 1e-7f;     // fp32(1 + 1e-7) = 1.00000012: rowsum of a 0/1 incidence row + 1e-7
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int64_t s = rel_ind[((int64_t)b * K + k) * 2 + 0], o = rel_ind[((int64_t)b * K + k) * 2 + 1];
+        ns[k] = (int)(s < 0 ? 0 : (s >= N ? N - 1 : s));
+        no[k] = (int)(o < 0 ? 0 : (o >= N ? N - 1 : o));
+    }
+    for (int i = threadIdx.x; i < N * (TC / 4); i += blockDim.x) {
+        const int n = i / (TC / 4), c4 = (i % (TC / 4)) * 4;
+        const int64_t g = ((int64_t)b * N + n) * L + c0 + c4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        if (c0 + c4 + 3 < L) {
+            a = *reinterpret_cast<const float4*>(F2 + g);
+            c = *reinterpret_cast<const float4*>(F3 + g);
+        } else {
+            float* pa = &a.x; float* pc = &c.x;
+            for (int j = 0; j < 4; ++j)
+                if (c0 + c4 + j < L) { pa[j] = F2[g + j]; pc[j] = F3[g + j]; }
+        }
+        // relu(x / c) is what every consumer needs: do it once per node element
+        a.x = fmaxf(a.x / cdiv1, 0.f); a.y = fmaxf(a.y / cdiv1, 0.f); a.z = fmaxf(a.z / cdiv1, 0.f); a.w = fmaxf(a.w / cdiv1, 0.f);
+        c.x = fmaxf(c.x / cdiv1, 0.f); c.y = fmaxf(c.y / cdiv1, 0.f); c.z = fmaxf(c.z / cdiv1, 0.f); c.w = fmaxf(c.w / cdiv1, 0.f);
+        *reinterpret_cast<float4*>(t2 + n * TC + c4) = a;
+        *reinterpret_cast<float4*>(t3 + n * TC + c4) = c;
+    }
+    __syncthreads();
+    const int cl = threadIdx.x & (TC - 1), half = threadIdx.x >> 7;   // 2 relation streams x 128 columns
+    const int col = c0 + cl;
+    if (col >= L) return;
+    for (int k = half; k < K; k += 2) {
+        float v = (t2[ns[k] * TC + cl] + t3[no[k] * TC + cl]) / 2.f;
+        const int64_t o = ((int64_t)b * K + k) * L + col;
+        if (skip) v += skip[o];
+        Pout[o] = v;
+    }
+}
+
+// dF2[b,n,:] = 1/2 [F2>0] / c * sum_{k in CSR_s(n)} dP[b,k,:]   (and F3 / CSR_o)
+__global__ __launch_bounds__(256) void gcn_edges_bwd_kernel(const float* __restrict__ dP, const float* __restrict__ F2,
+                                                            const float* __restrict__ F3, const int32_t* __restrict__ ptr,
+                                                            const int32_t* __restrict__ edges, float* __restrict__ dF2,
+                                                            float* __restrict__ dF3, int B, int N, int K, int L) {
+    extern __shared__ int sm_i[];
+    int* ps = sm_i; int* po = ps + (N + 1); int* es = po + (N + 1); int* eo = es + K;
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i <= N; i += blockDim.x) {
+        ps[i] = ptr[((int64_t)0 * B + b) * (N + 1) + i];
+        po[i] = ptr[((int64_t)1 * B + b) * (N + 1) + i];
+    }
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        es[i] = edges[((int64_t)0 * B + b) * K + i];
+        eo[i] = edges[((int64_t)1 * B + b) * K + i];
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= L) return;
+    const float cdiv1 = 1.f + 1e-7f;
+    const float* dp = dP + (int64_t)b * K * L + col;
+    for (int n = 0; n < N; ++n) {
+        float a = 0.f, c = 0.f;
+        for (int j = ps[n]; j < ps[n + 1]; ++j) a += dp[(int64_t)es[j] * L];
+        for (int j = po[n]; j < po[n + 1]; ++j) c += dp[(int64_t)eo[j] * L];
+        const int64_t o = ((int64_t)b * N + n) * L + col;
+        dF2[o] = (F2[o] / cdiv1 > 0.f) ? a * 0.5f / cdiv1 : 0.f;
+        dF3[o] = (F3[o] / cdiv1 > 0.f) ? c * 0.5f / cdiv1 : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm1d over rows
+// column statistics: grid (C/64, slabs); 4 waves stride rows; atomics merge slabs.
+__global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict__ X, int M, int C, const float* __restrict__ center,
+                                                        float* __restrict__ sum, int square, int rows_per_block) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const float mu = (center && col < C) ? center[col] : 0.f;
+    float acc = 0.f;
+    if (col < C)
+        for (int r = r0 + w; r < r1; r += 4) {
+            const float d = X[(int64_t)r * C + col] - mu;
+            acc += square ? d * d : d;
+        }
+    sm[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && col < C) atomicAdd(sum + col, sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane]);
+}
+// finalise: mean = s/M (pass 0)  |  var -> rstd, running stats (pass 1)
+__global__ void bn_finalize_kernel(float* __restrict__ mean_or_var, int M, int C, int pass, float* __restrict__ save_mean,
+                                   float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (pass == 0) {
+        const float m = mean_or_var[c] / (float)M;
+        save_mean[c] = m;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    } else {
+        const float ss = mean_or_var[c];
+        const float var_b = ss / (float)M;
+        save_rstd[c] = 1.f / sqrtf(var_b + eps);
+        if (running_var) {
+            const float var_u = M > 1 ? ss / (float)(M - 1) : var_b;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var_u;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t total, int C,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ rvar, float eps,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float rs = rstd ? rstd[c] : 1.f / sqrtf(rvar[c] + eps);
+        Y[i] = (X[i] - mean[c]) * rs * gamma[c] + beta[c];
+    }
+}
+// backward pass 1: dbeta = sum dy, dgamma = sum dy * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, const float* __restrict__ X, int M, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows_per_block) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float ag = 0.f, ab = 0.f;
+    if (col < C) {
+        const float mu = mean[col], rs = rstd[col];
+        for (int r = r0 + w; r < r1; r += 4) {
+            const float dy = dY[(int64_t)r * C + col];
+            ab += dy;
+            ag += dy * (X[(int64_t)r * C + col] - mu) * rs;
+        }
+    }
+    sg[w][lane] = ag; sb[w][lane] = ab;
+    __syncthreads();
+    if (w == 0 && col < C) {
+        atomicAdd(dgamma + col, sg[0][lane] + sg[1][lane] + sg[2][lane] + sg[3][lane]);
+        atomicAdd(dbeta + col, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dX,
+                                                           int64_t total, int M, int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    const float invM = 1.f / (float)M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float xh = (X[i] - mean[c]) * rstd[c];
+        dX[i] = gamma[c] * rstd[c] * (dY[i] - dbeta[c] * invM - xh * dgamma[c] * invM);
+    }
+}
+__global__ void zero_f32_kernel(float* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+inline int raise_lds(const void* fn, size_t bytes, const char* what) {
+    if (bytes <= 64 * 1024) return SUBGC_OK;
+    if (bytes > 160 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        subgc::set_error("%s: needs %zu bytes of LDS", what, bytes);
+        return SUBGC_EINVAL;
+    }
+    return SUBGC_OK;
+}
+
+}  // namespace
+
+SUBGC_API int subgc_row_argmax_f32(const float* X, int64_t ldx, int rows, int cols, int skip, int64_t* idx, float* val,
+                                   void* stream) {
+    SUBGC_REQUIRE(rows >= 0 && cols > skip && skip >= 0 && ldx >= cols, "row_argmax: bad sizes rows=%d cols=%d skip=%d", rows, cols, skip);
+    if (rows == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(X && idx, "row_argmax: null pointer");
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, cols, skip, idx, val);
+    return subgc::check_launch("subgc_row_argmax_f32");
+}
+
+SUBGC_API int subgc_csr_build(const int64_t* rel_ind, int B, int K, int N, int32_t* ptr, int32_t* edges, void* stream) {
+    SUBGC_REQUIRE(B >= 0 && K > 0 && N > 0, "csr_build: bad sizes");
+    if (B == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(rel_ind && ptr && edges, "csr_build: null pointer");
+    const size_t lds = sizeof(int) * (K + N + 1);
+    hipLaunchKernelGGL(csr_build_kernel, dim3(B, 2), dim3(128), lds, (hipStream_t)stream, rel_ind, B, K, N, ptr, edges);
+    return subgc::check_launch("subgc_csr_build");
+}
+
+SUBGC_API int subgc_gcn_nodes_fwd(const float* F0, const float* F1, const int32_t* ptr, const int32_t* edges, const float* skip,
+                                  float* Xout, uint8_t* act, int B, int N, int K, int L, void* stream) {
+    SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0, "gcn_nodes_fwd: bad sizes");
+    if (B == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(F0 && F1 && ptr && edges && Xout, "gcn_nodes_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + (skip ? 2.0 : 1.0) * N));
+    const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
+    hipLaunchKernelGGL(gcn_nodes_fwd_kernel, dim3((L + 255) / 256, B), dim3(256), lds, s, F0, F1, ptr, edges, skip, Xout, act, B, N, K, L);
+    return subgc::check_launch("subgc_gcn_nodes_fwd");
+}
+
+SUBGC_API int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int64_t* rel_ind, const int32_t* ptr, float* dF0,
+                                  float* dF1, int B, int N, int K, int L, void* stream) {
+    SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0, "gcn_nodes_bwd: bad sizes");
+    if (B == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(dX && act && rel_ind && ptr && dF0 && dF1, "gcn_nodes_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 2.0 * K));
+    const size_t lds = sizeof(int) * (2 * K) + sizeof(float) * 2 * N;
+    hipLaunchKernelGGL(gcn_nodes_bwd_kernel, dim3((L + 255) / 256, B), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
+    return subgc::check_launch("subgc_gcn_nodes_bwd");
+}
+
+SUBGC_API int subgc_gcn_edges_fwd(const float* F2, const float* F3, const int64_t* rel_ind, const float* skip, float* Pout, int B,
+                                  int N, int K, int L, void* stream) {
+    SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0, "gcn_edges_fwd: bad sizes");
+    if (B == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(F2 && F3 && rel_ind && Pout, "gcn_edges_fwd: null pointer");
+    SUBGC_REQUIRE(L % 4 == 0, "gcn_edges_fwd: L must be a multiple of 4 (got %d)", L);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = sizeof(float) * 2 * (size_t)N * TC + sizeof(int) * 2 * K;
+    int rc = raise_lds((const void*)gcn_edges_fwd_kernel, lds, "gcn_edges_fwd");
+    if (rc) return rc;
+    subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * N + (skip ? 2.0 : 1.0) * K));
+    hipLaunchKernelGGL(gcn_edges_fwd_kernel, dim3((L + TC - 1) / TC, B), dim3(256), lds, s, F2, F3, rel_ind, skip, Pout, B, N, K, L);
+    return subgc::check_launch("subgc_gcn_edges_fwd");
+}
+
+SUBGC_API int subgc_gcn_edges_bwd(const float* dP, const float* F2, const float* F3, const int32_t* ptr, const int32_t* edges,
+                                  float* dF2, float* dF3, int B, int N, int K, int L, void* stream) {
+    SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0, "gcn_edges_bwd: bad sizes");
+    if (B == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(dP && F2 && F3 && ptr && edges && dF2 && dF3, "gcn_edges_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 4.0 * N));
+    const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
+    hipLaunchKernelGGL(gcn_edges_bwd_kernel, dim3((L + 255) / 256, B), dim3(256), lds, s, dP, F2, F3, ptr, edges, dF2, dF3, B, N, K, L);
+    return subgc::check_launch("subgc_gcn_edges_bwd");
+}
+
+SUBGC_API int subgc_bn_fwd(const float* X, float* Y, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* save_mean, float* save_rstd, int training, float momentum, float eps,
+                           void* stream) {
+    SUBGC_REQUIRE(M > 0 && C > 0, "bn_fwd: bad sizes");
+    SUBGC_REQUIRE(X && Y && gamma && beta, "bn_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)M * C;
+    const int ew_blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    if (!training) {
+        SUBGC_REQUIRE(running_mean && running_var, "bn_fwd(eval): running stats required");
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks), dim3(256), 0, s, X, Y, total, C, running_mean, (const float*)nullptr,
+                           running_var, eps, gamma, beta);
+        return subgc::check_launch("subgc_bn_fwd");
+    }
+    SUBGC_REQUIRE(save_mean && save_rstd, "bn_fwd(train): save buffers required");
+    const int rpb = 512;
+    dim3 g((C + 63) / 64, (M + rpb - 1) / rpb);
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_mean, (int64_t)C);
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_rstd, (int64_t)C);
+    hipLaunchKernelGGL(bn_colsum_kernel, g, dim3(256), 0, s, X, M, C, (const float*)nullptr, save_mean, 0, rpb);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_mean, M, C, 0, save_mean, save_rstd,
+                       running_mean, running_var, momentum, eps);
+    hipLaunchKernelGGL(bn_colsum_kernel, g, dim3(256), 0, s, X, M, C, (const float*)save_mean, save_rstd, 1, rpb);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_rstd, M, C, 1, save_mean, save_rstd,
+                       running_mean, running_var, momentum, eps);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks), dim3(256), 0, s, X, Y, total, C, (const float*)save_mean,
+                       (const float*)save_rstd, (const float*)nullptr, eps, gamma, beta);
+    return subgc::check_launch("subgc_bn_fwd");
+}
+
+SUBGC_API int subgc_bn_bwd(const float* dY, const float* X, const float* gamma, const float* save_mean, const float* save_rstd,
+                           float* dX, float* dgamma, float* dbeta, int M, int C, void* stream) {
+    SUBGC_REQUIRE(M > 0 && C > 0, "bn_bwd: bad sizes");
+    SUBGC_REQUIRE(dY && X && gamma && save_mean && save_rstd && dX && dgamma && dbeta, "bn_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)M * C;
+    const int rpb = 512;
+    dim3 g((C + 63) / 64, (M + rpb - 1) / rpb);
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dgamma, (int64_t)C);
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dbeta, (int64_t)C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, dim3(256), 0, s, dY, X, M, C, save_mean, save_rstd, dgamma, dbeta, rpb);
+    const int ew_blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks), dim3(256), 0, s, dY, X, dX, total, M, C, save_mean, save_rstd, gamma,
+                       (const float*)dgamma, (const float*)dbeta);
+    return subgc::check_launch("subgc_bn_bwd");
+}

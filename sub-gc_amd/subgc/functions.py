@@ -1,0 +1,437 @@
+"""Autograd boundary of the HIP path: torch.autograd.Function wrappers whose forward AND backward
+are sequences of C-ABI launches (ops.py).  torch only owns the memory and the graph edges.
+
+Encoder side (few launches per call) is modular: LinearFn, GcnNodesFn, GcnEdgesFn, BatchNormFn,
+SubgraphPoolFn, GpnScoreFn, MaskedNLLFn.  The attention-LSTM decoder (the bulk of the FLOPs and of
+the launches) is ONE Function, DecoderFn, with a hand-written BPTT: loop-invariant contractions
+are hoisted out of the recurrence, every weight gradient is one batched-over-time GEMM, and the
+ragged attention sets are packed once (reference: AttModel.py:122-177,328-368,400-471).
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------- linear
+class LinearFn(Function):
+    """y = [dropout]([relu](x W^T + b [+ add])) on 2-D row-major x (any leading dim)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, add, keep, scale, relu):
+        y = torch.empty(x.size(0), W.size(0), device=x.device, dtype=torch.float32)
+        ops.gemm(x, W, y, tb=True, bias=b, add=add, keep=keep, keep_scale=scale, relu=relu)
+        ctx.relu, ctx.scale, ctx.has_add = relu, scale, add is not None
+        ctx.save_for_backward(x, W, y if (relu or keep is not None) else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        dz = ops.relu_bwd(dy, y, ctx.scale) if y is not None else dy
+        dx = dW = db = dadd = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.size(0), W.size(1), device=dy.device, dtype=torch.float32)
+            ops.gemm(dz, W, dx)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            ops.gemm(dz, x, dW, ta=True)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(dz)
+        if ctx.has_add and ctx.needs_input_grad[3]:
+            dadd = dz
+        return dx, dW, db, dadd, None, None, None
+
+
+def linear(x, W, b=None, add=None, keep=None, scale=1.0, relu=False):
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1]) if x.dim() != 2 else x
+    add2 = add.reshape(-1, add.shape[-1]) if add is not None and add.dim() != 2 else add
+    y = LinearFn.apply(x2, W, b, add2, keep, scale, relu)
+    return y.view(*shp[:-1], W.size(0)) if x.dim() != 2 else y
+
+
+class GatherRowsFn(Function):
+    """nn.Embedding lookup with int32 row ids (AttModel.py:376,383,385 class embeddings)."""
+
+    @staticmethod
+    def forward(ctx, table, rows):
+        out = torch.empty(rows.numel(), table.size(1), device=table.device, dtype=torch.float32)
+        ops.gather_rows(table, rows, out)
+        ctx.save_for_backward(rows)
+        ctx.shape = table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rows,) = ctx.saved_tensors
+        dt = ops.zeros(*ctx.shape, device=dout.device)
+        ops.scatter_add_rows(dout.contiguous(), rows, dt)
+        return dt, None
+
+
+# ------------------------------------------------------------------------------- GCN
+class GcnNodesFn(Function):
+    """nodes <- relations (graph_conv_unit.py:34-36 for units 0,1 + graph_conv.py:26 + residual)."""
+
+    @staticmethod
+    def forward(ctx, F0, F1, skip, rel_ind, ptr, edges, N):
+        B, K, L = F0.shape
+        F0, F1 = F0.contiguous(), F1.contiguous()
+        out, act = ops.gcn_nodes_fwd(F0, F1, ptr, edges, skip.contiguous() if skip is not None else None, B, N, K, L)
+        ctx.save_for_backward(act, rel_ind, ptr)
+        ctx.dims = (B, N, K, L)
+        ctx.has_skip = skip is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dX):
+        act, rel_ind, ptr = ctx.saved_tensors
+        B, N, K, L = ctx.dims
+        dX = dX.contiguous()
+        dF0, dF1 = ops.gcn_nodes_bwd(dX, act, rel_ind, ptr, B, N, K, L)
+        return dF0, dF1, (dX if ctx.has_skip else None), None, None, None, None
+
+
+class GcnEdgesFn(Function):
+    """relations <- nodes (units 2,3; LDS-staged gather)."""
+
+    @staticmethod
+    def forward(ctx, F2, F3, skip, rel_ind, ptr, edges, K):
+        B, N, L = F2.shape
+        F2, F3 = F2.contiguous(), F3.contiguous()
+        out = ops.gcn_edges_fwd(F2, F3, rel_ind, skip.contiguous() if skip is not None else None, B, N, K, L)
+        ctx.save_for_backward(F2, F3, ptr, edges)
+        ctx.dims = (B, N, K, L)
+        ctx.has_skip = skip is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dP):
+        F2, F3, ptr, edges = ctx.saved_tensors
+        B, N, K, L = ctx.dims
+        dP = dP.contiguous()
+        dF2, dF3 = ops.gcn_edges_bwd(dP, F2, F3, ptr, edges, B, N, K, L)
+        return dF2, dF3, (dP if ctx.has_skip else None), None, None, None, None
+
+
+class BatchNormFn(Function):
+    """nn.BatchNorm1d over rows (graph_conv_unit.py:31-32); running stats updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training):
+        x = x.contiguous()
+        y, sm, sr = ops.bn_fwd(x, gamma, beta, running_mean, running_var, training)
+        ctx.training = training
+        if training:
+            ctx.save_for_backward(x, gamma, sm, sr)
+        else:
+            ctx.save_for_backward(x, gamma, running_mean, running_var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, a, b = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("BatchNormFn: backward in eval mode is not part of the Sub-GC path")
+        dx, dg, db = ops.bn_bwd(dy.contiguous(), x, gamma, a, b)
+        return dx, dg, db, None, None, None
+
+
+# ------------------------------------------------------------------------------- sGPN
+class SubgraphPoolFn(Function):
+    """Fused gather + diagonal mask + max/mean pooling (gpn.py:152-185)."""
+
+    @staticmethod
+    def forward(ctx, X, idx, w, w_g, w_i, denom, img, N):
+        Bn, L = X.shape
+        G = idx.size(0)
+        X = X.contiguous()
+        out, am = ops.pool_fwd(X, idx, idx.stride(0), w, w_g, w_i, denom, img, G, N, L)
+        ctx.save_for_backward(idx, w, denom, img, am)
+        ctx.meta = (w_g, w_i, G, N, L, Bn)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, w, denom, img, am = ctx.saved_tensors
+        w_g, w_i, G, N, L, Bn = ctx.meta
+        dX = ops.zeros(Bn, L, device=dout.device)
+        ops.pool_bwd(dout.contiguous(), idx, idx.stride(0), w, w_g, w_i, denom, img, am, dX, G, N, L)
+        return dX, None, None, None, None, None, None, None
+
+
+class GpnScoreFn(Function):
+    """Linear(H->1) + sigmoid + BCE(mean) after the (ReLU, dropout) hidden layer (gpn.py:54-57)."""
+
+    @staticmethod
+    def forward(ctx, hid, w2, b2, keep, scale):
+        hid = hid.contiguous()
+        score, loss = ops.gpn_score_fwd(hid, keep, scale, w2, b2)
+        ctx.save_for_backward(hid, w2, score, keep)
+        ctx.scale = scale
+        ctx.mark_non_differentiable(score)
+        return score, loss
+
+    @staticmethod
+    def backward(ctx, dscore, dloss):
+        hid, w2, score, keep = ctx.saved_tensors
+        dhid, dw2, db2 = ops.gpn_score_bwd(hid, keep, ctx.scale, w2, score, dloss.contiguous())
+        return dhid, dw2, db2, None, None
+
+
+class MaskedNLLFn(Function):
+    """LanguageModelCriterion (misc/utils.py:115-124)."""
+
+    @staticmethod
+    def forward(ctx, logp, target, mask):
+        logp = logp.contiguous()
+        loss, scratch = ops.masked_nll_fwd(logp, target, mask)
+        ctx.save_for_backward(target, mask, scratch)
+        ctx.shape = logp.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        target, mask, scratch = ctx.saved_tensors
+        S, T, V = ctx.shape
+        return ops.masked_nll_bwd(target, mask, scratch, dloss.contiguous(), S, T, V), None, None
+
+
+# ------------------------------------------------------------------------------- decoder
+PARAM_ORDER = (
+    "fc_embed.0.weight", "fc_embed.0.bias", "fc_embed.2.weight", "fc_embed.2.bias",
+    "att_embed.0.weight", "att_embed.0.bias", "ctx2att.weight", "ctx2att.bias", "embed.0.weight",
+    "core.att_lstm.weight_ih", "core.att_lstm.weight_hh", "core.att_lstm.bias_ih", "core.att_lstm.bias_hh",
+    "core.lang_lstm.weight_ih", "core.lang_lstm.weight_hh", "core.lang_lstm.bias_ih", "core.lang_lstm.bias_hh",
+    "core.attention.h2att.weight", "core.attention.h2att.bias", "core.attention.alpha_net.weight",
+    "core.attention.alpha_net.bias", "logit.weight", "logit.bias",
+)
+
+
+class Prepared:
+    """Loop-invariant decoder state (AttModel._prepare_feature + pack): shared by train and decode."""
+
+    def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale):
+        (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b) = P[:8]
+        dev = fc_in.device
+        S = fc_in.size(0)
+        self.S, self.N = S, N
+        self.off, self.total, self.src_row, self.sent_of = ops.pack_rows(lens, idx, img, S, N)
+        self.lens = lens
+        MR = S * N
+        L = X_nodes.size(1)
+        self.Xg = torch.empty(MR, L, device=dev, dtype=torch.float32)
+        ops.gather_rows(X_nodes, self.src_row, self.Xg, m_dev=self.total)
+        self.f1 = torch.empty(S, fc0_w.size(0), device=dev, dtype=torch.float32)
+        ops.gemm(fc_in, fc0_w, self.f1, tb=True, bias=fc0_b, relu=True)
+        self.f = torch.empty(S, fc2_w.size(0), device=dev, dtype=torch.float32)
+        ops.gemm(self.f1, fc2_w, self.f, tb=True, bias=fc2_b, relu=True, keep=keep_fc, keep_scale=scale)
+        self.v = ops.zeros(MR, att_w.size(0), device=dev)
+        ops.gemm(self.Xg, att_w, self.v, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
+        self.u = torch.empty(MR, c2a_w.size(0), device=dev, dtype=torch.float32)
+        ops.gemm(self.v, c2a_w, self.u, tb=True, bias=c2a_b, m_dev=self.total)
+
+
+def _cat_weights(w_ih_part, w_hh):
+    """[W_ih(:, cols) | W_hh] as one K-contiguous operand so a recurrent step is ONE GEMM."""
+    R4, a = w_ih_part.shape
+    out = torch.empty(R4, a + w_hh.size(1), device=w_hh.device, dtype=torch.float32)
+    ops.copy2d(w_ih_part, out[:, :a])
+    ops.copy2d(w_hh, out[:, a:])
+    return out
+
+
+class DecoderFn(Function):
+    """Teacher-forced attention-LSTM decoder -> log-probabilities [S, T, V+1]."""
+
+    @staticmethod
+    def forward(ctx, meta, labels, fc_in, X_nodes, lens, idx, img, *P):
+        N, p_drop, masks = meta["N"], meta["p"], meta.get("masks") or {}
+        dev = fc_in.device
+        (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
+         h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
+        S, T = fc_in.size(0), labels.size(1) - 1
+        R, E, A, V1 = w1h.size(1), emb.size(1), h2a_w.size(0), lg_w.size(0)
+        scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        k_fc, k_att, k_xt, k_out = (masks.get(k) for k in ("fc", "att", "xt", "out"))
+        fc_in = fc_in.contiguous(); X_nodes = X_nodes.contiguous()
+        pr = Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale)
+
+        xt = torch.empty(T, S, E, device=dev, dtype=torch.float32)
+        for t in range(T):
+            ops.embed_fwd(emb, labels[:, t], labels.stride(0), None if k_xt is None else k_xt[t], scale, xt[t])
+        Gx = torch.empty(T * S, 4 * R, device=dev, dtype=torch.float32)
+        ops.gemm(xt.view(T * S, E), w1i[:, 2 * R:], Gx, tb=True)
+        Gf = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
+        ops.gemm(pr.f, w1i[:, R:2 * R], Gf, tb=True)
+        Wc1 = _cat_weights(w1i[:, :R], w1h)           # [4R, 2R]  x [h2_prev | h1_prev]
+        Wc2 = _cat_weights(w2i, w2h)                  # [4R, 3R]  x [ctx | h1 | h2_prev]
+
+        H1 = ops.zeros(T + 1, S, 2 * R, device=dev)
+        H2 = ops.zeros(T + 1, S, 3 * R, device=dev)
+        C1 = ops.zeros(T + 1, S, R, device=dev)
+        C2 = ops.zeros(T + 1, S, R, device=dev)
+        Hout = torch.empty(S, T, R, device=dev, dtype=torch.float32)
+        G1 = torch.empty(T, S, 4 * R, device=dev, dtype=torch.float32)
+        G2 = torch.empty(T, S, 4 * R, device=dev, dtype=torch.float32)
+        AH = torch.empty(T, S, A, device=dev, dtype=torch.float32)
+        AL = torch.empty(T, S, N, device=dev, dtype=torch.float32)
+        pre = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
+        Gx3 = Gx.view(T, S, 4 * R)
+        for t in range(T):
+            ops.gemm(H1[t], Wc1, pre, tb=True)
+            ops.lstm_fwd(pre, Gx3[t], Gf, b1i, b1h, C1[t], C1[t + 1], H2[t][:, R:2 * R], H1[t + 1][:, R:], None, 1.0, None, G1[t], S, R)
+            ops.gemm(H2[t][:, R:2 * R], h2a_w, AH[t], tb=True, bias=h2a_b)
+            ops.attn_fwd(pr.u, pr.v, AH[t], an_w, an_b, pr.off, lens, H2[t][:, :R], AL[t], S, A, R)
+            ops.gemm(H2[t], Wc2, pre, tb=True)
+            ops.lstm_fwd(pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
+                         None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
+        logits = torch.empty(S * T, V1, device=dev, dtype=torch.float32)
+        ops.gemm(Hout.view(S * T, R), lg_w, logits, tb=True, bias=lg_b)
+        active = ops.step_active(labels, T)
+        ops.log_softmax_rows_(logits, active)
+
+        ctx.meta = (N, scale, S, T, R, E, A, V1)
+        ctx.masks = (k_xt, k_out)
+        ctx.pr = pr
+        ctx.save_for_backward(labels, fc_in, X_nodes, lens, logits, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL, *P)
+        return logits.view(S, T, V1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, scale, S, T, R, E, A, V1 = ctx.meta
+        k_xt, k_out = ctx.masks
+        pr = ctx.pr
+        (labels, fc_in, X_nodes, lens, logp, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL, *P) = ctx.saved_tensors
+        (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
+         h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
+        dev = dout.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        zer = lambda *s: ops.zeros(*s, device=dev)
+
+        dlogits = new(S * T, V1)
+        ops.log_softmax_rows_bwd(logp, dout.contiguous().view(S * T, V1), dlogits, active)
+        Hout2 = Hout.view(S * T, R)
+        d_lg_w = new(V1, R); ops.gemm(dlogits, Hout2, d_lg_w, ta=True)
+        d_lg_b = ops.colsum(dlogits)
+        dHout = new(S, T, R); ops.gemm(dlogits, lg_w, dHout.view(S * T, R))
+        del dlogits
+
+        dP1, dP2, dAH = new(T, S, 4 * R), new(T, S, 4 * R), new(T, S, A)
+        du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
+        d_an_w, d_an_b = zer(1, A), zer(1)
+        dH1 = [zer(S, 2 * R), new(S, 2 * R)]          # [next, cur] ping-pong
+        dH2 = [zer(S, 3 * R), new(S, 3 * R)]
+        dC1 = [zer(S, R), new(S, R)]
+        dC2 = [zer(S, R), new(S, R)]
+        for t in range(T - 1, -1, -1):
+            nH1, cH1 = dH1; nH2, cH2 = dH2; nC1, cC1 = dC1; nC2, cC2 = dC2
+            ops.lstm_bwd(G2[t], C2[t], C2[t + 1], nH1[:, :R], nH2[:, 2 * R:], dHout[:, t, :], None if k_out is None else k_out[t],
+                         scale, nC2, dP2[t], cC2, S, R)
+            ops.gemm(dP2[t], Wc2, cH2)                                     # -> [dctx | dh1 | dh2_prev]
+            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, dv, d_an_w, d_an_b, S, A, R)
+            ops.gemm(dAH[t], h2a_w, cH2[:, R:2 * R], accum=True)          # h1 also feeds the attention query
+            ops.lstm_bwd(G1[t], C1[t], C1[t + 1], cH2[:, R:2 * R], nH1[:, R:], None, None, 1.0, nC1, dP1[t], cC1, S, R)
+            ops.gemm(dP1[t], Wc1, cH1)                                     # -> [dh2_prev | dh1_prev]
+            dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
+
+        P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
+        H1a, H2a = H1[:T].view(T * S, 2 * R), H2[:T].view(T * S, 3 * R)
+        d_w2i = new(4 * R, 2 * R); ops.gemm(P2, H2a[:, :2 * R], d_w2i, ta=True)
+        d_w2h = new(4 * R, R); ops.gemm(P2, H2a[:, 2 * R:], d_w2h, ta=True)
+        d_b2 = ops.colsum(P2)
+        d_w1i = new(4 * R, 2 * R + E)
+        ops.gemm(P1, H1a[:, :R], d_w1i[:, :R], ta=True)
+        dGf = ops.colsum(dP1.view(T, S * 4 * R)).view(S, 4 * R)
+        ops.gemm(dGf, pr.f, d_w1i[:, R:2 * R], ta=True)
+        ops.gemm(P1, xt.view(T * S, E), d_w1i[:, 2 * R:], ta=True)
+        d_w1h = new(4 * R, R); ops.gemm(P1, H1a[:, R:], d_w1h, ta=True)
+        d_b1 = ops.colsum(P1)
+        df = new(S, R); ops.gemm(dGf, w1i[:, R:2 * R], df)
+        dxt = new(T * S, E); ops.gemm(P1, w1i[:, 2 * R:], dxt)
+        d_emb = zer(V1, E)
+        dxt3 = dxt.view(T, S, E)
+        for t in range(T):
+            ops.embed_bwd(emb, labels[:, t], labels.stride(0), None if k_xt is None else k_xt[t], scale, dxt3[t], d_emb)
+        dAH2 = dAH.view(T * S, A)
+        d_h2a_w = new(A, R); ops.gemm(dAH2, H2a[:, R:2 * R], d_h2a_w, ta=True)
+        d_h2a_b = ops.colsum(dAH2)
+
+        tot = pr.total
+        ops.gemm(du, c2a_w, dv, accum=True, m_dev=tot)                     # u = v W_c^T + b_c
+        d_c2a_w = new(A, R); ops.gemm(du, pr.v, d_c2a_w, ta=True, m_dev=tot)
+        d_c2a_b = ops.colsum(du, m_dev=tot)
+        dzv = ops.relu_bwd(dv, pr.v, scale)
+        d_att_w = new(R, pr.Xg.size(1)); ops.gemm(dzv, pr.Xg, d_att_w, ta=True, m_dev=tot)
+        d_att_b = ops.colsum(dzv, m_dev=tot)
+        dX = None
+        if ctx.needs_input_grad[3]:
+            dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
+            dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
+            ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
+
+        dz2 = ops.relu_bwd(df, pr.f, scale)
+        d_fc2_w = new(fc2_w.shape); ops.gemm(dz2, pr.f1, d_fc2_w, ta=True)
+        d_fc2_b = ops.colsum(dz2)
+        df1 = new(S, pr.f1.size(1)); ops.gemm(dz2, fc2_w, df1)
+        dz1 = ops.relu_bwd(df1, pr.f1, 1.0)
+        d_fc0_w = new(fc0_w.shape); ops.gemm(dz1, fc_in, d_fc0_w, ta=True)
+        d_fc0_b = ops.colsum(dz1)
+        dfc_in = None
+        if ctx.needs_input_grad[2]:
+            dfc_in = new(S, fc_in.size(1)); ops.gemm(dz1, fc0_w, dfc_in)
+        ctx.pr = None
+        grads = (d_fc0_w, d_fc0_b, d_fc2_w, d_fc2_b, d_att_w, d_att_b, d_c2a_w, d_c2a_b, d_emb, d_w1i, d_w1h, d_b1, d_b1.clone(),
+                 d_w2i, d_w2h, d_b2, d_b2.clone(), d_h2a_w, d_h2a_b, d_an_w, d_an_b, d_lg_w, d_lg_b)
+        return (None, None, dfc_in, dX, None, None, None) + grads
+
+
+# ------------------------------------------------------------------------------- decode (no grad)
+class DecodeState:
+    """Step-wise decoder for sampling (AttModel._sample loop body): same kernels, batch n."""
+
+    def __init__(self, pr: Prepared, P, N, want_att):
+        (_, _, _, _, _, _, _, _, self.emb, w1i, w1h, self.b1i, self.b1h, w2i, w2h, self.b2i, self.b2h,
+         self.h2a_w, self.h2a_b, self.an_w, self.an_b, self.lg_w, self.lg_b) = P
+        self.pr, self.N = pr, N
+        dev = pr.f.device
+        S = pr.S
+        R, E = w1h.size(1), self.emb.size(1)
+        self.S, self.R, self.E, self.A, self.V1 = S, R, E, self.h2a_w.size(0), self.lg_w.size(0)
+        self.Wc1 = _cat_weights(w1i[:, :R], w1h)
+        self.Wc2 = _cat_weights(w2i, w2h)
+        self.W1x = w1i[:, 2 * R:]
+        self.Gf = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
+        ops.gemm(pr.f, w1i[:, R:2 * R], self.Gf, tb=True)
+        self.H1 = ops.zeros(S, 2 * R, device=dev)           # [h2 | h1]
+        self.H2 = ops.zeros(S, 3 * R, device=dev)           # [ctx | h1 | h2]
+        self.C1 = [ops.zeros(S, R, device=dev), torch.empty(S, R, device=dev)]
+        self.C2 = [ops.zeros(S, R, device=dev), torch.empty(S, R, device=dev)]
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        self.xt, self.Gx, self.pre, self.ah = new(S, E), new(S, 4 * R), new(S, 4 * R), new(S, self.A)
+        self.hout, self.logits = new(S, R), new(S, self.V1)
+        self.want_att = want_att
+
+    def step(self, it, alpha_out):
+        S, R, A = self.S, self.R, self.A
+        pr = self.pr
+        ops.embed_fwd(self.emb, it, 1, None, 1.0, self.xt)
+        ops.gemm(self.xt, self.W1x, self.Gx, tb=True)
+        ops.gemm(self.H1, self.Wc1, self.pre, tb=True)
+        ops.lstm_fwd(self.pre, self.Gx, self.Gf, self.b1i, self.b1h, self.C1[0], self.C1[1], self.H2[:, R:2 * R], self.H1[:, R:],
+                     None, 1.0, None, None, S, R)
+        self.C1.reverse()
+        ops.gemm(self.H2[:, R:2 * R], self.h2a_w, self.ah, tb=True, bias=self.h2a_b)
+        ops.attn_fwd(pr.u, pr.v, self.ah, self.an_w, self.an_b, pr.off, pr.lens, self.H2[:, :R], alpha_out, S, A, R)
+        ops.gemm(self.H2, self.Wc2, self.pre, tb=True)
+        ops.lstm_fwd(self.pre, None, None, self.b2i, self.b2h, self.C2[0], self.C2[1], self.H1[:, :R], self.H2[:, 2 * R:],
+                     None, 1.0, self.hout, None, S, R)
+        self.C2.reverse()
+        ops.gemm(self.hout, self.lg_w, self.logits, tb=True, bias=self.lg_b)
+        ops.log_softmax_rows_(self.logits)
+        return self.logits

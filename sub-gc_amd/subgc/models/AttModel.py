@@ -1,0 +1,498 @@
+"""`AttModel` / `TopDownModel`: the Sub-GC captioner behind the reference's model API, with every
+contraction, gather, reduction and activation running in libsubgc_hip.so (gfx950).
+
+Drop-in surface kept from reference `models/AttModel.py`:
+  * ctor reads the same `opt` fields (AttModel.py:44-69,96-98);
+  * `_forward(fc_feats, att_feats, seq, att_masks, trip_pred, obj_dist, obj_box, rel_ind, pred_fmap,
+    pred_dist, gpn_obj_ind, gpn_pred_ind, gpn_nrel_ind, gpn_pool_mtx)` -> (outputs, gpn_loss, score)
+    (AttModel.py:122-177) and `_sample(... , opt={})` -> (seq, seqLogprobs, score, keep_ind[, att])
+    (AttModel.py:236-326);
+  * attributes `.gpn .ss_prob .seq_length .vocab_size`, methods `init_hidden`;
+  * `state_dict()` keys and shapes are the reference's, so checkpoints interchange.
+
+What is different by design (MI355X-first):
+  * all parameters are views into ONE flat fp32 buffer (`self.flat_params`, gradients likewise in
+    `self.flat_grads`) so data-parallel training all-reduces one RCCL bucket (parallel.py) and the
+    fused clip+Adam kernel sweeps one array;
+  * the x5 "counterpart" expansion (gcn_backbone.py:50-51) and the gathered sub-graph tensor
+    (gpn.py:159-170) are never materialised: kernels index `sentence -> image` instead;
+  * dead GCN units (outputs that cannot reach any model output, SURVEY.md section 8a note) are skipped;
+    their parameters stay in the state_dict and simply receive no gradient, exactly as in the
+    reference;
+  * the attention sets are ragged-packed once; padded rows are never computed.
+
+Unsupported reference options fail loudly: `use_bn != 0` (BatchNorm inside att_embed, unused by
+every preset), scheduled sampling (`ss_prob > 0`), beam search.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functions as F_
+from .. import ops
+from .CaptionModel import CaptionModel
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted state_dict names."""
+
+
+def _attach(root, dotted, tensor, buffer=False):
+    *path, leaf = dotted.split(".")
+    mod = root
+    for p in path:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if buffer:
+        mod.register_buffer(leaf, tensor)
+    else:
+        mod.register_parameter(leaf, tensor)
+
+
+def _count_names(path, default):
+    if path and os.path.exists(path):
+        return int(np.load(path, encoding="latin1").shape[0])
+    return default
+
+
+class AttModel(CaptionModel):
+    def __init__(self, opt):
+        super().__init__()
+        g = lambda n, d=None: getattr(opt, n, d)
+        self.vocab_size = opt.vocab_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_size = opt.rnn_size
+        self.num_layers = g("num_layers", 1)
+        self.drop_prob_lm = g("drop_prob_lm", 0.5)
+        self.seq_length = g("max_length", None) or g("seq_length")
+        self.fc_feat_size = opt.fc_feat_size
+        self.att_feat_size = opt.att_feat_size
+        self.att_hid_size = opt.att_hid_size
+        self.use_bn = g("use_bn", 0)
+        self.ss_prob = g("sampling_prob", 0.0)
+        self.gpn = g("use_gpn", 1) == 1
+        self.embed_dim = g("embed_dim", 300)
+        self.GCN_dim = g("gcn_dim", 1024)
+        self.noun_fuse = g("noun_fuse", 1) == 1
+        self.pred_emb_type = g("pred_emb_type", 1)
+        self.GCN_layers = g("gcn_layers", 2)
+        self.GCN_residual = g("gcn_residual", 2)
+        self.GCN_use_bn = g("gcn_bn", 0) != 0
+        self.GCN_lr = 512                                     # graph_conv.py:11 (dim_lr is not plumbed)
+        self.test_LSTM = g("test_LSTM", 0) != 0
+        self.topk_sampling = g("use_topk_sampling", 0) != 0
+        self.topk_temp = g("topk_temp", 0.6)
+        self.the_k = g("the_k", 3)
+        self.sct = g("sct", 0) != 0
+        self.gpn_nms_thres = g("gpn_nms_thres", 0.75)
+        self.gpn_max_subg = g("gpn_max_subg", 1)
+        self.use_sGPN_score = g("use_gt_subg", 0) == 0
+        self.gpn_drop_prob = g("gpn_drop_prob", 0.5)          # nn.Dropout(0.5) of gpn_fc (gpn.py:27)
+        self.sg_obj_cnt = _count_names(g("obj_name_path"), g("sg_obj_cnt", 1599))
+        self.sg_pred_cnt = _count_names(g("rel_name_path"), g("sg_pred_cnt", 21))
+        if self.use_bn:
+            raise NotImplementedError("use_bn != 0 (BatchNorm inside att_embed) is not on the Sub-GC presets' path")
+        if self.gpn and self.att_feat_size != 2 * self.GCN_dim:
+            raise ValueError("att_feat_size must equal 2*gcn_dim: fc_embed consumes the [max|mean] read-out "
+                             "(reference AttModel.py:109 with gpn.py:35-36,79)")
+        self.dropout_seed = g("seed", 2019)
+        self._dropout_calls = 0
+        self.injected_masks = None       # tests inject {'fc','att','xt','out','gpn_hid'} keep-masks here
+        self._build_parameters()
+
+    # ------------------------------------------------------------------ parameters
+    def _specs(self):
+        """(name, shape, init) in flat-buffer order: encoder first, decoder last (its gradients
+        are complete first in the backward, so its bucket can be all-reduced while the encoder's
+        backward still runs)."""
+        L, D, A, R, E, V1 = self.GCN_dim, self.att_feat_size, self.att_hid_size, self.rnn_size, self.input_encoding_size, self.vocab_size + 1
+        Lr, Ew, FC = self.GCN_lr, self.embed_dim, self.fc_feat_size
+        lin = lambda o, i: [((o, i), ("uniform", 1 / math.sqrt(i))), ((o,), ("uniform", 1 / math.sqrt(i)))]
+        sp = []
+
+        def add_lin(name, o, i, bias_zero=False):
+            (ws, wi), (bs, bi) = lin(o, i)
+            sp.append((name + ".weight", ws, wi)); sp.append((name + ".bias", bs, ("zero",) if bias_zero else bi))
+
+        add_lin("obj_v_proj", L, D)
+        if self.noun_fuse:
+            sp.append(("sg_obj_embed.weight", (self.sg_obj_cnt, Ew), ("normal", 1.0)))
+            add_lin("obj_emb_proj", L, Ew)
+        sp.append(("sg_pred_embed.weight", (self.sg_pred_cnt, Ew), ("normal", 1.0)))
+        add_lin("pred_emb_prj", L, Ew)
+        for l in range(self.GCN_layers):
+            for u in range(4):
+                pre = f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}."
+                sp.append((pre + "fc_lft.weight", (Lr, L), ("normal", 0.001))); sp.append((pre + "fc_lft.bias", (Lr,), ("zero",)))
+                sp.append((pre + "fc_rgt.weight", (L, Lr), ("normal", 0.001))); sp.append((pre + "fc_rgt.bias", (L,), ("zero",)))
+                if self.GCN_use_bn:
+                    sp.append((pre + "bn.weight", (L,), ("one",))); sp.append((pre + "bn.bias", (L,), ("zero",)))
+        if self.gpn:
+            if self.use_sGPN_score:
+                add_lin("gpn_layer.gpn_fc.0", A, 2 * L, bias_zero=True)
+                add_lin("gpn_layer.gpn_fc.3", 1, A, bias_zero=True)
+            add_lin("gpn_layer.read_out_proj.0", A, 2 * L, bias_zero=True)
+            add_lin("gpn_layer.read_out_proj.1", 2 * L, A, bias_zero=True)
+        else:
+            add_lin("read_out_proj.0", A, L, bias_zero=True)
+            add_lin("read_out_proj.1", 2 * L, A, bias_zero=True)
+        self._decoder_first = len(sp)
+        add_lin("logit", V1, R)
+        sp.append(("embed.0.weight", (V1, E), ("normal", 1.0)))
+        add_lin("fc_embed.0", FC, D)
+        add_lin("fc_embed.2", R, FC)
+        add_lin("att_embed.0", R, L)
+        add_lin("ctx2att", A, R)
+        add_lin("core.attention.h2att", A, R)
+        add_lin("core.attention.alpha_net", 1, A)
+        k = 1 / math.sqrt(R)
+        for nm, i in (("core.att_lstm", E + 2 * R), ("core.lang_lstm", 2 * R)):
+            sp.append((nm + ".weight_ih", (4 * R, i), ("uniform", k))); sp.append((nm + ".weight_hh", (4 * R, R), ("uniform", k)))
+            sp.append((nm + ".bias_ih", (4 * R,), ("uniform", k))); sp.append((nm + ".bias_hh", (4 * R,), ("uniform", k)))
+        return sp
+
+    def _build_parameters(self):
+        specs = self._specs()
+        # 16-byte (4-float) aligned slots so every parameter can feed the vector GEMM path
+        offs, total = [], 0
+        for _, shape, _ in specs:
+            offs.append(total)
+            total += (int(np.prod(shape)) + 3) // 4 * 4
+        self.flat_params = torch.zeros(total, dtype=torch.float32)
+        self.flat_grads = None
+        self._slots = {}
+        for (name, shape, init), o in zip(specs, offs):
+            n = int(np.prod(shape))
+            view = self.flat_params[o:o + n].view(shape)
+            if init[0] == "uniform":
+                view.uniform_(-init[1], init[1])
+            elif init[0] == "normal":
+                view.normal_(0, init[1])
+            elif init[0] == "one":
+                view.fill_(1.0)
+            _attach(self, name, nn.Parameter(view))
+            self._slots[name] = (o, n, shape)
+        self.decoder_offset = offs[self._decoder_first]
+        if self.GCN_use_bn:
+            for l in range(self.GCN_layers):
+                for u in range(4):
+                    pre = f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}.bn."
+                    _attach(self, pre + "running_mean", torch.zeros(self.GCN_dim), buffer=True)
+                    _attach(self, pre + "running_var", torch.ones(self.GCN_dim), buffer=True)
+                    _attach(self, pre + "num_batches_tracked", torch.tensor(0, dtype=torch.long), buffer=True)
+        self._pmap = dict(self.named_parameters())
+        self._bmap = dict(self.named_buffers())
+
+    def _apply(self, fn, recurse=True):
+        """.cuda()/.to(): move the flat buffer once and re-point every parameter into it."""
+        new_flat = fn(self.flat_params)
+        moved = new_flat.device != self.flat_params.device or new_flat.dtype != self.flat_params.dtype
+        if not moved:
+            return super()._apply(fn, recurse)
+        self.flat_params = new_flat
+        self.flat_grads = None
+        for name, p in self._pmap.items():
+            o, n, shape = self._slots[name]
+            p.data = self.flat_params[o:o + n].view(shape)
+            p.grad = None
+        for mod in self.modules():
+            for k, b in mod._buffers.items():
+                if b is not None:
+                    mod._buffers[k] = fn(b)
+        self._bmap = dict(self.named_buffers())
+        return self
+
+    def flatten_grads(self):
+        """Point every .grad into one flat fp32 buffer (zeroed); dead parameters contribute zeros."""
+        if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
+            self.flat_grads = torch.zeros_like(self.flat_params)
+        else:
+            self.flat_grads.zero_()
+        for name, p in self._pmap.items():
+            o, n, shape = self._slots[name]
+            p.grad = self.flat_grads[o:o + n].view(shape)
+        return self.flat_grads
+
+    def P(self, name):
+        return self._pmap[name]
+
+    def init_hidden(self, bsz):
+        w = self.P("logit.weight")
+        return (w.new_zeros(self.num_layers, bsz, self.rnn_size), w.new_zeros(self.num_layers, bsz, self.rnn_size))
+
+    # ------------------------------------------------------------------ dropout masks
+    def _masks(self, shapes, device):
+        """keep-masks for one training forward: injected (tests) or Philox-generated on device."""
+        if not self.training:
+            return {}
+        if self.injected_masks is not None:
+            return self.injected_masks
+        out, off = {}, 0
+        self._dropout_calls += 1
+        seed = (self.dropout_seed * 1000003 + self._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        for k, (shape, p) in shapes.items():
+            if p > 0:
+                out[k] = ops.dropout_mask(shape, p, seed, off, device)
+                off += (int(np.prod(shape)) + 3) // 4 * 4
+        return out
+
+    # ------------------------------------------------------------------ encoder
+    def _gcn_liveness(self):
+        Ly, res = self.GCN_layers, self.GCN_residual
+        needX, needP = [False] * (Ly + 1), [False] * (Ly + 1)
+        live_nodes, live_edges = [False] * Ly, [False] * Ly
+        needX[Ly] = True                       # x_pred of the last layer is gathered by sGPN but never used
+        for l in range(Ly - 1, -1, -1):
+            live_nodes[l], live_edges[l] = needX[l + 1], needP[l + 1]
+            needP[l] |= live_nodes[l]
+            needX[l] |= live_edges[l]
+            if (l + 1) % res == 0:
+                s = (l // res) * res
+                needX[s] |= live_nodes[l]
+                needP[s] |= live_edges[l]
+        return needX, needP, live_nodes, live_edges
+
+    def _unit(self, l, u, src):
+        pre = f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}."
+        shp = src.shape
+        h = F_.linear(src.reshape(-1, shp[-1]), self.P(pre + "fc_lft.weight"), self.P(pre + "fc_lft.bias"))
+        y = F_.linear(h, self.P(pre + "fc_rgt.weight"), self.P(pre + "fc_rgt.bias"))
+        if self.GCN_use_bn:
+            y = F_.BatchNormFn.apply(y, self.P(pre + "bn.weight"), self.P(pre + "bn.bias"), self._bmap[pre + "bn.running_mean"],
+                                     self._bmap[pre + "bn.running_var"], self.training)
+            if self.training:
+                self._bmap[pre + "bn.num_batches_tracked"] += 1
+        return y.view(shp[0], shp[1], -1)
+
+    def _encode(self, att_feats, obj_dist, pred_dist, rel_ind):
+        """feat_fusion + GCN (AttModel.py:370-387, gcn_backbone.py:29-53) -> X_out [B, N, L]."""
+        B, N, D = att_feats.shape
+        K, L = rel_ind.size(1), self.GCN_dim
+        needX, needP, live_nodes, live_edges = self._gcn_liveness()
+        att2 = att_feats.reshape(B * N, D)
+        if self.noun_fuse:
+            cls = ops.row_argmax(obj_dist.reshape(B * N, -1), skip=1).to(torch.int32)
+            emb = F_.GatherRowsFn.apply(self.P("sg_obj_embed.weight"), cls)
+            e = F_.linear(emb, self.P("obj_emb_proj.weight"), self.P("obj_emb_proj.bias"))
+            x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), add=e, relu=True)
+        else:
+            x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"))
+        x = x.view(B, N, L)
+        p = None
+        if needP[0] or self.GCN_layers == 0:
+            pc = ops.row_argmax(pred_dist.reshape(B * K, -1), skip=1 if self.pred_emb_type == 1 else 0).to(torch.int32)
+            pe = F_.GatherRowsFn.apply(self.P("sg_pred_embed.weight"), pc)
+            p = F_.linear(pe, self.P("pred_emb_prj.weight"), self.P("pred_emb_prj.bias")).view(B, K, L)
+        if self.GCN_layers == 0:
+            return x
+        rel_ind = rel_ind.contiguous()
+        ptr, edges = ops.csr_build(rel_ind, N)
+        skip_x, skip_p = x, p
+        for l in range(self.GCN_layers):
+            res = (l + 1) % self.GCN_residual == 0
+            new_x = new_p = None
+            if live_nodes[l]:
+                new_x = F_.GcnNodesFn.apply(self._unit(l, 0, p), self._unit(l, 1, p), skip_x if res else None, rel_ind, ptr, edges, N)
+            if live_edges[l]:
+                new_p = F_.GcnEdgesFn.apply(self._unit(l, 2, x), self._unit(l, 3, x), skip_p if res else None, rel_ind, ptr, edges, K)
+            x, p = new_x, new_p
+            if res:
+                skip_x, skip_p = x, p
+        return x
+
+    # ------------------------------------------------------------------ sGPN
+    def _pool(self, X2, idx, w, denom, img, N):
+        return F_.SubgraphPoolFn.apply(X2, idx, w, w.stride(0), 1, denom, img, N)
+
+    def _read_out_proj(self, r, prefix):
+        h = F_.linear(r, self.P(prefix + "read_out_proj.0.weight"), self.P(prefix + "read_out_proj.0.bias"))
+        return F_.linear(h, self.P(prefix + "read_out_proj.1.weight"), self.P(prefix + "read_out_proj.1.bias"))
+
+    def _gpn_train(self, X, gpn_obj_ind, gpn_pool_mtx, att_masks, masks):
+        """gpn.py:41-81: score all (pos, neg) sub-graphs, pick the best positive one per sentence."""
+        B, N, L = X.shape
+        b5, _, hb, _ = gpn_obj_ind.shape
+        spi = b5 // B
+        dev = X.device
+        G = 2 * b5 * hb
+        idx = gpn_obj_ind.permute(1, 0, 2, 3).reshape(G, N)
+        w = gpn_pool_mtx.diagonal(dim1=-2, dim2=-1).permute(1, 0, 2, 3).reshape(G, N).contiguous()
+        denom = att_masks.permute(1, 0, 2, 3).reshape(G, N).sum(1)
+        sent = torch.arange(b5, device=dev, dtype=torch.int32)
+        img_s = torch.div(sent, spi, rounding_mode="floor").to(torch.int32)
+        img = img_s.repeat_interleave(hb).repeat(2)
+        read_out = self._pool(X.reshape(B * N, L), idx.contiguous(), w, denom.contiguous(), img.contiguous(), N)
+        if self.use_sGPN_score:
+            hid = F_.linear(read_out, self.P("gpn_layer.gpn_fc.0.weight"), self.P("gpn_layer.gpn_fc.0.bias"), relu=True)
+            p = self.gpn_drop_prob if self.training else 0.0
+            keep = masks.get("gpn_hid") if p > 0 else None
+            score, gpn_loss = F_.GpnScoreFn.apply(hid, self.P("gpn_layer.gpn_fc.3.weight"), self.P("gpn_layer.gpn_fc.3.bias"), keep,
+                                                  1.0 / (1.0 - p) if keep is not None else 1.0)
+        else:
+            score, gpn_loss = torch.ones(G, 1, device=dev), None
+        sel = ops.row_argmax(score.view(2, b5, hb)[0].contiguous())                       # gpn.py:66 (first max)
+        ar = torch.arange(b5, device=dev)
+        sel_idx = gpn_obj_ind[:, 0][ar, sel].contiguous()                                 # [b5, N]
+        mask_sel = att_masks[:, 0][ar, sel]
+        ro_sel = read_out.detach().view(2, b5, hb, 2 * L)[0][ar, sel].contiguous()        # gpn.py:78 (.detach())
+        fc = self._read_out_proj(ro_sel, "gpn_layer.")
+        return gpn_loss, score, sel_idx, mask_sel, fc, img_s
+
+    # ------------------------------------------------------------------ train forward
+    def _decoder_params(self):
+        return [self.P(n) for n in F_.PARAM_ORDER]
+
+    def _forward(self, fc_feats, att_feats, seq, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
+                 pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None):
+        if self.training and self.ss_prob > 0.0:
+            raise NotImplementedError("scheduled sampling (ss_prob > 0, AttModel.py:158-167) is not built on the HIP path")
+        B, N, _ = att_feats.shape
+        dev = att_feats.device
+        L, R, E = self.GCN_dim, self.rnn_size, self.input_encoding_size
+        b5, T = seq.size(0), seq.size(1) - 1
+        p = self.drop_prob_lm if self.training else 0.0
+        hb = gpn_obj_ind.size(2) if gpn_obj_ind is not None else 1
+        masks = self._masks({"fc": ((b5, R), p), "att": ((b5 * N, R), p), "xt": ((T, b5, E), p), "out": ((T, b5, R), p),
+                             "gpn_hid": ((2 * b5 * hb, self.att_hid_size), self.gpn_drop_prob if (self.gpn and self.use_sGPN_score) else 0.0)}, dev)
+        X = self._encode(att_feats, obj_dist, pred_dist, rel_ind)
+        if self.gpn:
+            gpn_loss, score, sel_idx, mask_sel, fc, img_s = self._gpn_train(X, gpn_obj_ind, gpn_pool_mtx, att_masks, masks)
+        else:                                                                             # AttModel.py:140-149
+            gpn_loss = score = None
+            spi = b5 // B
+            img_s = torch.div(torch.arange(b5, device=dev, dtype=torch.int32), spi, rounding_mode="floor").to(torch.int32)
+            ar = torch.arange(N, device=dev).view(1, N)
+            mean = self._pool(X.detach().reshape(B * N, L), ar.expand(B, N).contiguous(), torch.ones(B, N, device=dev),
+                              torch.full((B,), float(N), device=dev), torch.arange(B, device=dev, dtype=torch.int32), N)[:, L:]
+            mean5 = mean.index_select(0, img_s.long())
+            fc = self._read_out_proj(mean5, "")
+            mask_sel = att_masks[:, 0, 0]
+            mask_sel[:, :36].fill_(1.0)                                                   # in place on the caller's tensor
+            sel_idx = ar.expand(b5, N).contiguous()
+        lens = mask_sel.sum(1).to(torch.int32)
+        meta = {"N": N, "p": p, "masks": masks}
+        outputs = F_.DecoderFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx, img_s.contiguous(),
+                                     *self._decoder_params())
+        return outputs, gpn_loss, score
+
+    # ------------------------------------------------------------------ decode
+    def _sample_sentences(self, *args, **kwargs):
+        raise NotImplementedError("beam_size > 1 (reference AttModel.py:179-234) is not built on the HIP path yet")
+
+    @torch.no_grad()
+    def _sample(self, fc_feats, att_feats, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
+                pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None, opt={},
+                uniforms=None, forced=None):
+        """Greedy / top-k decode of one image (AttModel.py:236-326).  `uniforms[n, T]` (optional)
+        supplies the top-k sampler's random numbers; `forced[n, T]` makes the loop follow a given
+        token path (both exist so tests can pin the sampler)."""
+        if opt.get("beam_size", 1) > 1:
+            return self._sample_sentences()
+        return_att = opt.get("return_att", 0) == 1
+        B, N, _ = att_feats.shape
+        dev = att_feats.device
+        L = self.GCN_dim
+        X = self._encode(att_feats, obj_dist, pred_dist, rel_ind)
+        X2 = X.reshape(B * N, L).contiguous()
+        if self.gpn:
+            if gpn_obj_ind.size(0) != 5:
+                raise AssertionError("test branch of sGPN expects the 5 counterparts of ONE image (gpn.py:84)")
+            idx = gpn_obj_ind[0].reshape(-1, N).contiguous()                              # pos slots then neg slots
+            m_all = att_masks[0].reshape(-1, N)
+            w = gpn_pool_mtx[0].diagonal(dim1=-2, dim2=-1).reshape(-1, N).contiguous()
+            G = idx.size(0)
+            lens_all = m_all.sum(1)
+            img = torch.zeros(G, device=dev, dtype=torch.int32)
+            read_out, _ = ops.pool_fwd(X2, idx, idx.stride(0), w, w.stride(0), 1, lens_all.contiguous(), img, G, N, L, want_argmax=False)
+            if self.use_sGPN_score:
+                hid = torch.empty(G, self.att_hid_size, device=dev)
+                ops.gemm(read_out, self.P("gpn_layer.gpn_fc.0.weight"), hid, tb=True, bias=self.P("gpn_layer.gpn_fc.0.bias"), relu=True)
+                score, _ = ops.gpn_score_fwd(hid, None, 1.0, self.P("gpn_layer.gpn_fc.3.weight"), self.P("gpn_layer.gpn_fc.3.bias"), want_loss=False)
+                score = score.view(-1)
+            else:
+                score = torch.ones(G, device=dev)
+            lens_i = lens_all.to(torch.int32)
+            if not self.sct:                                                              # use_nms (AttModel.py:95)
+                keep_buf, n_keep = ops.subgraph_nms(score, idx, lens_i, self.gpn_nms_thres, self.gpn_max_subg)
+                keep = keep_buf[: int(n_keep.item())]
+            else:
+                keep = torch.arange(G, device=dev)
+            score = score[keep]
+            idx_k, lens_k = idx[keep].contiguous(), lens_i[keep].contiguous()
+            fc = torch.empty(keep.numel(), 2 * L, device=dev)
+            h = torch.empty(keep.numel(), self.att_hid_size, device=dev)
+            ops.gemm(read_out[keep].contiguous(), self.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=self.P("gpn_layer.read_out_proj.0.bias"))
+            ops.gemm(h, self.P("gpn_layer.read_out_proj.1.weight"), fc, tb=True, bias=self.P("gpn_layer.read_out_proj.1.bias"))
+        else:                                                                             # AttModel.py:261-271
+            ar = torch.arange(N, device=dev).view(1, N)
+            mean, _ = ops.pool_fwd(X2, ar.contiguous(), N, torch.ones(1, N, device=dev), N, 1, torch.full((1,), float(N), device=dev),
+                                   torch.zeros(1, device=dev, dtype=torch.int32), 1, N, L, want_argmax=False)
+            h = torch.empty(1, self.att_hid_size, device=dev); fc = torch.empty(1, 2 * L, device=dev)
+            ops.gemm(mean[:, L:], self.P("read_out_proj.0.weight"), h, tb=True, bias=self.P("read_out_proj.0.bias"))
+            ops.gemm(h, self.P("read_out_proj.1.weight"), fc, tb=True, bias=self.P("read_out_proj.1.bias"))
+            m = att_masks[0:1, 0, 0]
+            m[:, :36].fill_(1.0)
+            lens_k = m.sum(1).to(torch.int32)
+            idx_k = ar.contiguous()
+            keep = torch.arange(1, device=dev)
+            score = torch.ones(1, device=dev)
+        n = fc.size(0)
+        T = self.seq_length
+        seq = torch.zeros(n, T, device=dev, dtype=torch.long)
+        seqlp = torch.zeros(n, T, device=dev)
+        if n == 0:
+            return (seq, seqlp, score, keep) + ((torch.zeros(0, 0, 0, device=dev),) if return_att else ())
+        P = self._decoder_params()
+        pr = F_.Prepared(fc, X2, lens_k, idx_k, torch.zeros(n, device=dev, dtype=torch.int32), N, P, None, None, 1.0)
+        st = F_.DecodeState(pr, P, N, return_att)
+        it = torch.zeros(n, device=dev, dtype=torch.long)
+        unfinished = torch.zeros(n, device=dev, dtype=torch.int32)
+        counts = torch.zeros(T, device=dev, dtype=torch.int32)
+        AL = torch.zeros(T + 1, n, N, device=dev) if return_att else None
+        k = self.the_k if self.topk_sampling else 0
+        if k and uniforms is None and forced is None:
+            uniforms = torch.rand(n, T, device=dev)
+        for t in range(T + 1):
+            logp = st.step(it, AL[t] if return_att else None)
+            if t == T:
+                break
+            if forced is not None:
+                ops_forced_pick(logp, forced[:, t].contiguous(), k, self.topk_temp, t, seq, seqlp, it, unfinished, counts)
+            else:
+                ops.decode_pick(logp, k, self.topk_temp, None if uniforms is None else uniforms[:, t].contiguous(), t, seq, seqlp, it,
+                                unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None)
+        out = (seq, seqlp, score, keep)
+        if return_att:
+            c = counts.cpu()
+            dead = (c == 0).nonzero()
+            steps = int(dead[0]) + 1 if dead.numel() else T + 1
+            n_max = int(lens_k.max().item())
+            out = out + (AL[:steps, :, :n_max].permute(1, 0, 2).contiguous(),)
+        return out
+
+
+def ops_forced_pick(logp, tok, k, temp, t, seq, seqlp, it, unfinished, counts):
+    """Test hook: follow a given token path (plumbing in torch; never on the product path)."""
+    lp = torch.log_softmax(logp / temp, 1) if k else logp
+    slp = lp.gather(1, tok.view(-1, 1)).view(-1)
+    unf = (tok > 0) if t == 0 else (unfinished.bool() & (tok > 0))
+    unfinished.copy_(unf.int())
+    w = tok * unf.long()
+    seq[:, t] = w
+    seqlp[:, t] = slp
+    it.copy_(w)
+    counts[t] = unf.sum().int()
+
+
+class TopDownModel(AttModel):
+    """reference AttModel.py:476-480 (num_layers is forced to 2: att-LSTM + lang-LSTM)."""
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.num_layers = 2

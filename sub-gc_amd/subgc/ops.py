@@ -1,0 +1,307 @@
+"""Thin tensor-level wrappers over the C ABI (include/subgc_hip.h).
+
+Every function takes torch tensors that already live on the MI355X, hands their raw device
+pointers to libsubgc_hip.so on torch's CURRENT stream and returns torch tensors.  No autograd
+here (see functions.py) and no fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import SubgcError, call
+
+RELU, ACCUM = 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SubgcError("subgc ops need device tensors (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise SubgcError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def ld(t):
+    """Leading dimension of a 2-D row-major view with unit inner stride."""
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise SubgcError(f"need a 2-D tensor with unit inner stride, got {tuple(t.shape)} / {t.stride()}")
+    if t.size(0) > 1 and t.stride(0) < t.size(1):
+        raise SubgcError(f"overlapping rows: shape {tuple(t.shape)} stride {t.stride()}")
+    return max(t.stride(0), t.size(1))
+
+
+def gemm(a, b, out, *, ta=False, tb=False, bias=None, add=None, keep=None, keep_scale=1.0, relu=False,
+         accum=False, a_rows=None, c_rows=None, m_dev=None):
+    """out = epilogue(op(a) @ op(b));  a, b, out are 2-D row-major views (any leading dim)."""
+    M = a.size(1) if ta else a.size(0)
+    K = a.size(0) if ta else a.size(1)
+    N = b.size(0) if tb else b.size(1)
+    Kb = b.size(1) if tb else b.size(0)
+    if a_rows is not None:
+        M = a_rows.numel()
+    if K != Kb or (c_rows is None and out.size(0) < M) or out.size(1) != N:
+        raise SubgcError(f"gemm shape mismatch: op(a)=[{M},{K}] op(b)=[{Kb},{N}] out={tuple(out.shape)}")
+    call("subgc_gemm_f32", int(ta), int(tb), M, N, K, _ptr(a, torch.float32), ld(a), _ptr(b, torch.float32), ld(b),
+         _ptr(out, torch.float32), ld(out), _ptr(bias), _ptr(add), ld(add) if add is not None else 0,
+         _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0),
+         _ptr(a_rows, torch.int32), _ptr(c_rows, torch.int32), _ptr(m_dev, torch.int32), _stream())
+    return out
+
+
+def colsum(x, out=None, accumulate=False, m_dev=None):
+    out = torch.empty(x.size(1), device=x.device, dtype=torch.float32) if out is None else out
+    call("subgc_colsum_f32", _ptr(x, torch.float32), ld(x), x.size(0), x.size(1), _ptr(out), int(accumulate),
+         _ptr(m_dev, torch.int32), _stream())
+    return out
+
+
+def row_argmax(x, skip=0, want_val=False):
+    rows, cols = x.shape
+    idx = torch.empty(rows, device=x.device, dtype=torch.int64)
+    val = torch.empty(rows, device=x.device, dtype=torch.float32) if want_val else None
+    call("subgc_row_argmax_f32", _ptr(x, torch.float32), ld(x), rows, cols, skip, _ptr(idx), _ptr(val), _stream())
+    return (idx, val) if want_val else idx
+
+
+def csr_build(rel_ind, N):
+    B, K, _ = rel_ind.shape
+    rel_ind = rel_ind.contiguous()
+    ptr = torch.empty(2, B, N + 1, device=rel_ind.device, dtype=torch.int32)
+    edges = torch.empty(2, B, K, device=rel_ind.device, dtype=torch.int32)
+    call("subgc_csr_build", _ptr(rel_ind, torch.int64), B, K, N, _ptr(ptr), _ptr(edges), _stream())
+    return ptr, edges
+
+
+def gcn_nodes_fwd(F0, F1, ptr, edges, skip, B, N, K, L, want_act=True):
+    out = torch.empty(B, N, L, device=F0.device, dtype=torch.float32)
+    act = torch.empty(B, N, L, device=F0.device, dtype=torch.uint8) if want_act else None
+    call("subgc_gcn_nodes_fwd", _ptr(F0), _ptr(F1), _ptr(ptr), _ptr(edges), _ptr(skip), _ptr(out), _ptr(act), B, N, K, L, _stream())
+    return out, act
+
+
+def gcn_nodes_bwd(dX, act, rel_ind, ptr, B, N, K, L):
+    dF0 = torch.empty(B, K, L, device=dX.device, dtype=torch.float32)
+    dF1 = torch.empty_like(dF0)
+    call("subgc_gcn_nodes_bwd", _ptr(dX), _ptr(act), _ptr(rel_ind), _ptr(ptr), _ptr(dF0), _ptr(dF1), B, N, K, L, _stream())
+    return dF0, dF1
+
+
+def gcn_edges_fwd(F2, F3, rel_ind, skip, B, N, K, L):
+    out = torch.empty(B, K, L, device=F2.device, dtype=torch.float32)
+    call("subgc_gcn_edges_fwd", _ptr(F2), _ptr(F3), _ptr(rel_ind), _ptr(skip), _ptr(out), B, N, K, L, _stream())
+    return out
+
+
+def gcn_edges_bwd(dP, F2, F3, ptr, edges, B, N, K, L):
+    dF2 = torch.empty(B, N, L, device=dP.device, dtype=torch.float32)
+    dF3 = torch.empty_like(dF2)
+    call("subgc_gcn_edges_bwd", _ptr(dP), _ptr(F2), _ptr(F3), _ptr(ptr), _ptr(edges), _ptr(dF2), _ptr(dF3), B, N, K, L, _stream())
+    return dF2, dF3
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    M, C = x.shape
+    y = torch.empty_like(x)
+    sm = torch.empty(C, device=x.device, dtype=torch.float32) if training else None
+    sr = torch.empty(C, device=x.device, dtype=torch.float32) if training else None
+    call("subgc_bn_fwd", _ptr(x), _ptr(y), M, C, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+         _ptr(sm), _ptr(sr), int(training), float(momentum), float(eps), _stream())
+    return y, sm, sr
+
+
+def bn_bwd(dy, x, gamma, sm, sr):
+    M, C = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, device=x.device, dtype=torch.float32)
+    db = torch.empty_like(dg)
+    call("subgc_bn_bwd", _ptr(dy), _ptr(x), _ptr(gamma), _ptr(sm), _ptr(sr), _ptr(dx), _ptr(dg), _ptr(db), M, C, _stream())
+    return dx, dg, db
+
+
+def pool_fwd(X, idx, idx_stride, w, w_g, w_i, denom, img, G, N, L, want_argmax=True):
+    out = torch.empty(G, 2 * L, device=X.device, dtype=torch.float32)
+    am = torch.empty(G, L, device=X.device, dtype=torch.int32) if want_argmax else None
+    call("subgc_subgraph_pool_fwd", _ptr(X), _ptr(idx, torch.int64), idx_stride, _ptr(w, torch.float32), w_g, w_i,
+         _ptr(denom, torch.float32), _ptr(img, torch.int32), _ptr(out), _ptr(am), G, N, L, _stream())
+    return out, am
+
+
+def pool_bwd(dout, idx, idx_stride, w, w_g, w_i, denom, img, am, dX, G, N, L):
+    call("subgc_subgraph_pool_bwd", _ptr(dout), _ptr(idx, torch.int64), idx_stride, _ptr(w), w_g, w_i, _ptr(denom),
+         _ptr(img, torch.int32), _ptr(am, torch.int32), _ptr(dX), G, N, L, _stream())
+    return dX
+
+
+def gpn_score_fwd(hid, keep, scale, w2, b2, want_loss=True):
+    G, H = hid.shape
+    score = torch.empty(G, 1, device=hid.device, dtype=torch.float32)
+    loss = torch.empty((), device=hid.device, dtype=torch.float32) if want_loss else None
+    call("subgc_gpn_score_fwd", _ptr(hid), _ptr(keep, torch.uint8), float(scale), _ptr(w2), _ptr(b2), _ptr(score), _ptr(loss), G, H, _stream())
+    return score, loss
+
+
+def gpn_score_bwd(hid, keep, scale, w2, score, dloss):
+    G, H = hid.shape
+    dhid = torch.empty_like(hid)
+    dw2 = torch.empty(1, H, device=hid.device, dtype=torch.float32)
+    db2 = torch.empty(1, device=hid.device, dtype=torch.float32)
+    call("subgc_gpn_score_bwd", _ptr(hid), _ptr(keep, torch.uint8), float(scale), _ptr(w2), _ptr(score), _ptr(dloss), _ptr(dhid),
+         _ptr(dw2), _ptr(db2), G, H, _stream())
+    return dhid, dw2, db2
+
+
+NMS_WORDS = 4
+
+
+def subgraph_nms(score, idx, lens, thres, max_keep):
+    """-> (keep[int64, M] buffer, n_keep int32[1]) both on device; caller syncs to read n_keep."""
+    M, N = idx.shape
+    keep = torch.empty(max(M, 1), device=score.device, dtype=torch.int64)
+    n_keep = torch.zeros(1, device=score.device, dtype=torch.int32)
+    scratch = torch.empty(max(M, 1) * (NMS_WORDS * 8 + 8), device=score.device, dtype=torch.uint8)
+    call("subgc_subgraph_nms", _ptr(score, torch.float32), _ptr(idx, torch.int64), idx.stride(0), _ptr(lens, torch.int32), M, N,
+         float(thres), int(max_keep), _ptr(keep), _ptr(n_keep), _ptr(scratch), scratch.numel(), _stream())
+    return keep, n_keep
+
+
+def pack_rows(lens, idx, img, S, N):
+    dev = lens.device
+    off = torch.empty(S, device=dev, dtype=torch.int32)
+    total = torch.empty(1, device=dev, dtype=torch.int32)
+    src = torch.empty(S * N, device=dev, dtype=torch.int32)
+    sent = torch.empty(S * N, device=dev, dtype=torch.int32)
+    call("subgc_pack_rows", _ptr(lens, torch.int32), _ptr(idx, torch.int64), idx.stride(0), _ptr(img, torch.int32), S, N,
+         _ptr(off), _ptr(total), _ptr(src), _ptr(sent), _stream())
+    return off, total, src, sent
+
+
+def embed_fwd(table, tok, tok_stride, keep, scale, out):
+    n, E = out.shape
+    call("subgc_embed_fwd", _ptr(table), _ptr(tok, torch.int64), tok_stride, _ptr(keep, torch.uint8), float(scale), _ptr(out), n, E,
+         table.size(0), _stream())
+    return out
+
+
+def embed_bwd(table, tok, tok_stride, keep, scale, dout, dtable):
+    n, E = dout.shape
+    call("subgc_embed_bwd", _ptr(table), _ptr(tok, torch.int64), tok_stride, _ptr(keep, torch.uint8), float(scale), _ptr(dout),
+         _ptr(dtable), n, E, table.size(0), _stream())
+    return dtable
+
+
+def lstm_fwd(g0, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R):
+    L = lambda t: ld(t) if t is not None else 0
+    call("subgc_lstm_fwd", _ptr(g0), L(g0), _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c),
+         _ptr(h), L(h), _ptr(h2), L(h2), _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, _stream())
+
+
+def lstm_bwd(gates, c_prev, c, dh_a, dh_b, dh_drop, keep, scale, dc, dpre, dc_prev, S, R):
+    L = lambda t: ld(t) if t is not None else 0
+    call("subgc_lstm_bwd", _ptr(gates), _ptr(c_prev), _ptr(c), _ptr(dh_a), L(dh_a), _ptr(dh_b), L(dh_b), _ptr(dh_drop), L(dh_drop),
+         _ptr(keep, torch.uint8), float(scale), _ptr(dc), _ptr(dpre), _ptr(dc_prev), S, R, _stream())
+
+
+def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R):
+    call("subgc_attn_fwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32),
+         _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, _stream())
+
+
+def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R):
+    call("subgc_attn_bwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
+         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R, _stream())
+
+
+def log_softmax_rows_(x, active=None):
+    rows, V = x.shape
+    call("subgc_log_softmax_rows", _ptr(x), ld(x), rows, V, _ptr(active, torch.int32), _stream())
+    return x
+
+
+def log_softmax_rows_bwd(logp, dout, dlogits, active=None):
+    rows, V = logp.shape
+    call("subgc_log_softmax_rows_bwd", _ptr(logp), _ptr(dout), _ptr(dlogits), ld(logp), rows, V, _ptr(active, torch.int32), _stream())
+    return dlogits
+
+
+def masked_nll_fwd(logp, target, mask):
+    """logp [S,T,V] contiguous; target/mask are [S,T] views (unit inner stride) of the label tensors."""
+    S, T, V = logp.shape
+    loss = torch.empty((), device=logp.device, dtype=torch.float32)
+    scratch = torch.empty(2, device=logp.device, dtype=torch.float32)
+    call("subgc_masked_nll_fwd", _ptr(logp), _ptr(target, torch.int64), target.stride(0), _ptr(mask, torch.float32), mask.stride(0),
+         _ptr(loss), _ptr(scratch), S, T, V, _stream())
+    return loss, scratch
+
+
+def masked_nll_bwd(target, mask, scratch, dloss, S, T, V):
+    dlogp = torch.empty(S, T, V, device=mask.device, dtype=torch.float32)
+    call("subgc_masked_nll_bwd", _ptr(target, torch.int64), target.stride(0), _ptr(mask), mask.stride(0), _ptr(scratch), _ptr(dloss),
+         _ptr(dlogp), S, T, V, _stream())
+    return dlogp
+
+
+def step_active(labels, T):
+    S = labels.size(0)
+    active = torch.empty(S * T, device=labels.device, dtype=torch.int32)
+    call("subgc_step_active", _ptr(labels, torch.int64), labels.stride(0), S, T, _ptr(active), _stream())
+    return active
+
+
+def decode_pick(logp, k, temp, u, t, seq, seqlp, next_tok, unfinished, n_unf, prev_count=None):
+    n, V = logp.shape
+    call("subgc_decode_pick", _ptr(logp), ld(logp), n, V, int(k), float(temp), _ptr(u), int(t), _ptr(seq, torch.int64), _ptr(seqlp),
+         seq.size(1), _ptr(next_tok, torch.int64), _ptr(unfinished, torch.int32), _ptr(n_unf, torch.int32), _ptr(prev_count, torch.int32), _stream())
+
+
+def dropout_mask(shape, p, seed, offset, device):
+    keep = torch.empty(shape, device=device, dtype=torch.uint8)
+    call("subgc_dropout_mask", _ptr(keep), keep.numel(), float(p), int(seed), int(offset), _stream())
+    return keep
+
+
+def fill_(x, value):
+    call("subgc_fill_f32", _ptr(x, torch.float32), x.numel(), float(value), _stream())
+    return x
+
+
+def zeros(*shape, device):
+    return fill_(torch.empty(*shape, device=device, dtype=torch.float32), 0.0)
+
+
+def copy2d(x, y, accumulate=False):
+    call("subgc_copy2d_f32", _ptr(x), ld(x), _ptr(y), ld(y), x.size(0), x.size(1), int(accumulate), _stream())
+    return y
+
+
+def relu_bwd(dy, y, scale=1.0, out=None):
+    out = torch.empty_like(y) if out is None else out
+    call("subgc_relu_bwd", _ptr(dy), _ptr(y), float(scale), _ptr(out), y.numel(), _stream())
+    return out
+
+
+def gather_rows(src, rows, dst, m_dev=None):
+    call("subgc_gather_rows", _ptr(src), ld(src), _ptr(rows, torch.int32), _ptr(dst), ld(dst), dst.size(0), dst.size(1),
+         _ptr(m_dev, torch.int32), _stream())
+    return dst
+
+
+def scatter_add_rows(src, rows, dX, m_dev=None):
+    call("subgc_scatter_add_rows", _ptr(src), ld(src), _ptr(rows, torch.int32), _ptr(dX), ld(dX), src.size(0), src.size(1),
+         _ptr(m_dev, torch.int32), _stream())
+    return dX
+
+
+def sumsq(g, out):
+    call("subgc_sumsq_f32", _ptr(g), g.numel(), _ptr(out), _stream())
+    return out
+
+
+def clip_adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step):
+    call("subgc_clip_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(max_norm), float(lr),
+         float(beta1), float(beta2), float(eps), float(wd), int(step), _stream())

@@ -1,0 +1,56 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/subgc_hip.h declares, validates arguments on the host and fails loudly without a GPU."""
+import argparse
+import ctypes
+
+import pytest
+import torch
+
+from subgc import _lib, ops
+import subgc.models as models
+
+
+def test_header_symbols_all_exported():
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    L = _lib.lib()
+    for name in protos:
+        assert hasattr(L, name), name
+    assert L.subgc_version() == 1
+    assert L.subgc_arch() == b"gfx950"
+
+
+def test_host_side_argument_validation_needs_no_gpu():
+    L = _lib.lib()
+    rc = L.subgc_gemm_f32(0, 1, -1, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 1.0, 0, None, None, None, None)
+    assert rc == -1 and b"negative size" in L.subgc_last_error()
+    rc = L.subgc_gemm_f32(1, 1, 4, 4, 4, 1, 4, 1, 4, 1, 4, None, None, 0, None, 1.0, 0, None, None, None, None)
+    assert rc == -1 and b"transA && transB" in L.subgc_last_error()
+    rc = L.subgc_row_argmax_f32(None, 4, 2, 4, 4, None, None, None)
+    assert rc == -1
+    with pytest.raises(_lib.SubgcError):
+        _lib.call("subgc_decode_pick", None, 10, 1, 10, 9, 1.0, None, 0, None, None, 4, None, None, None, None, None)
+
+
+def test_product_path_refuses_cpu_tensors():
+    with pytest.raises(_lib.SubgcError):
+        ops.row_argmax(torch.zeros(2, 4))
+
+
+def test_model_api_surface(golden):
+    g = golden("subgc_train")
+    m = models.setup(g.opt(caption_model="topdown"))
+    assert m.gpn is True and m.ss_prob == 0.0 and m.seq_length == 20 and m.vocab_size == 50 and m.num_layers == 2
+    h, c = m.init_hidden(3)
+    assert h.shape == (2, 3, 48) and c.shape == (2, 3, 48)
+    w = g.group("weights")
+    assert set(m.state_dict().keys()) == set(w.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    # parameters are views of one flat bucket
+    base = m.flat_params.data_ptr()
+    for n, p in m.named_parameters():
+        assert base <= p.data_ptr() < base + m.flat_params.numel() * 4, n
+    with pytest.raises(Exception, match="Caption model not supported"):
+        models.setup(argparse.Namespace(caption_model="show_tell"))
+    with pytest.raises(NotImplementedError):
+        m(mode="sample_sentences")

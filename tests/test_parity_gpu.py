@@ -1,0 +1,232 @@
+"""Parity of the HIP path (through models.setup / CaptionModel.forward / LossWrapper, i.e. through
+the C ABI) with (1) golden vectors produced by the reference itself and (2) the CPU oracle on the
+same seeded inputs, incl. at the full Sub_GC_Kar dimensions.
+
+Tolerances (fp32, different summation order than MKL): log-probs / losses atol 1e-4 rtol 1e-4;
+gradients atol 2e-4 rtol 2e-3; indices (tokens, kept sub-graphs, attention arg-max) exact.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import subgc_oracle as O
+from subgc import synthetic
+import subgc.models as models
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, name, atol=1e-4, rtol=1e-4):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, err_msg=name)
+
+
+def build(g, weights, train, **over):
+    m = models.setup(g.opt(caption_model="topdown", gpn_drop_prob=0.0, **over))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    m = m.to(DEV)
+    m.train(train)
+    return m
+
+
+def run_train(m, batch):
+    lw = models.LossWrapper(m, None)
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    m.flatten_grads()
+    out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None,
+             b["rel_ind"], None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+    loss = out["lang_loss"] + (out["gpn_loss"] if out["gpn_loss"] is not None else 0.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    return out, loss
+
+
+@pytest.mark.parametrize("name", ["subgc_train", "subgc_gtsubg_train", "fullgc_train"])
+def test_train_matches_reference_golden(golden, name):
+    g = golden(name)
+    m = build(g, g.group("weights"), True)
+    batch = g.tensors("inputs")
+    ref = g.group("out")
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    outputs, gpn_loss, score = m(*synthetic.forward_args(b))
+    close(outputs, ref["outputs"], "outputs")
+    if "gpn_loss" in ref:
+        close(gpn_loss, ref["gpn_loss"], "gpn_loss")
+        close(score, ref["subgraph_score"], "subgraph_score", atol=1e-5)
+    out, loss = run_train(m, batch)
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(loss, ref["loss"], "loss")
+    grads, dead = g.group("grads"), set(g.meta["dead_params"])
+    for k, p in m.named_parameters():
+        if k in dead:
+            assert float(p.grad.abs().max()) == 0.0, k       # dead parameters: zeros in the flat bucket
+        else:
+            close(p.grad, grads[k], "grad " + k, atol=2e-4, rtol=2e-3)
+    bn_after = g.group("bn_after")
+    if bn_after:
+        live = [k for k in bn_after if "num_batches" not in k and not any(k.startswith(d.rsplit(".", 2)[0] + ".") for d in dead)]
+        assert live
+        sd = m.state_dict()
+        for k in live:
+            # two training forwards ran above (one bare, one through LossWrapper): replay the EMA
+            r0 = g.group("weights")[k]; once = bn_after[k]
+            batch_stat = (once - 0.9 * r0) / 0.1
+            close(sd[k], 0.9 * once + 0.1 * batch_stat, k, atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name,wf", [("subgc_greedy", "subgc_train"), ("subgc_greedy_nms55", "subgc_train"),
+                                      ("subgc_sct", "subgc_train"), ("fullgc_greedy", "fullgc_train")])
+def test_greedy_decode_token_identical_to_reference(golden, name, wf):
+    g = golden(name)
+    m = build(g, golden(wf).group("weights"), False)
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    ret = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample")
+    ref = g.group("out")
+    np.testing.assert_array_equal(ret[3].cpu().numpy(), ref["keep_ind"])
+    np.testing.assert_array_equal(ret[0].cpu().numpy(), ref["seq"])
+    close(ret[1], ref["seqLogprobs"], "seqLogprobs")
+    close(ret[2], ref["subgraph_score"], "score", atol=1e-5)
+    if "att2_weights" in ref:
+        assert tuple(ret[4].shape) == ref["att2_weights"].shape
+        close(ret[4], ref["att2_weights"], "att2_weights", atol=1e-5)
+        np.testing.assert_array_equal(ret[4].cpu().numpy().argmax(-1), ref["att2_weights"].argmax(-1))
+
+
+def test_topk_sampler_on_reference_path(golden):
+    g = golden("subgc_topk")
+    ref = g.group("out")
+    m = build(g, golden("subgc_train").group("weights"), False)
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    forced = torch.from_numpy(ref["seq"]).to(DEV)
+    ret = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample", forced=forced)
+    np.testing.assert_array_equal(ret[3].cpu().numpy(), ref["keep_ind"])
+    # along the reference's own sampled path our renormalised log-probs of its tokens match its seqLogprobs
+    alive = np.ones(ref["seq"].shape[0], bool)
+    ours = ret[1].cpu().numpy()
+    for t in range(ref["seq"].shape[1]):
+        sel = alive & (ref["seq"][:, t] > 0)
+        np.testing.assert_allclose(ours[sel, t], ref["seqLogprobs"][sel, t], atol=2e-4)
+        alive &= ref["seq"][:, t] > 0
+    # free-running with injected uniforms == oracle with the same uniforms
+    u = torch.rand(ref["seq"].shape[0], 20, generator=torch.Generator().manual_seed(11))
+    ret2 = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample", uniforms=u.to(DEV))
+    orc = O.Oracle(g.opt(), golden("subgc_train").group("weights"))
+    want = orc.sample(*synthetic.sample_args(g.tensors("inputs")), opt=g.meta["sample_opt"], uniforms=u)
+    np.testing.assert_array_equal(ret2[0].cpu().numpy(), want[0].numpy())
+    close(ret2[1], want[1], "topk seqLogprobs", atol=2e-4)
+
+
+def _oracle_masks(masks, off, lens, N, T):
+    """HIP mask layout (packed att rows, time-major xt/out) -> the oracle's padded layout."""
+    S = lens.numel()
+    att = torch.zeros(S, N, masks["att"].size(1), dtype=torch.uint8)
+    for s in range(S):
+        att[s, : int(lens[s])] = masks["att"][int(off[s]): int(off[s]) + int(lens[s])]
+    return {"fc": masks["fc"], "att": att, "xt": masks["xt"].permute(1, 0, 2), "out": masks["out"].permute(1, 0, 2),
+            "gpn_hid": masks["gpn_hid"]}
+
+
+def test_train_with_dropout_masks_injected_matches_oracle(golden):
+    g = golden("subgc_train")
+    w = g.group("weights")
+    p = 0.5
+    m = build(g, w, True, drop_prob_lm=p)
+    m.gpn_drop_prob = 0.5
+    batch = g.tensors("inputs")
+    S, T, N = batch["labels"].size(0), batch["labels"].size(1) - 1, 37
+    R, E, A = 48, 48, 24
+    gen = torch.Generator().manual_seed(5)
+    mk = lambda *s: (torch.rand(*s, generator=gen) >= p).to(torch.uint8)
+    masks = {"fc": mk(S, R), "att": mk(S * N, R), "xt": mk(T, S, E), "out": mk(T, S, R), "gpn_hid": mk(batch["gpn_obj_ind"][:, :, :, 0].numel(), A)}
+    m.injected_masks = {k: v.to(DEV) for k, v in masks.items()}
+    out, loss = run_train(m, batch)
+    # the packed att mask is laid out by the SELECTED sub-graph lengths, which depend only on the score
+    # head (gpn_hid mask): probe them with the LM dropout off
+    probe = O.Oracle(g.opt(drop_prob_lm=0.0, gpn_drop_prob=0.5), w); probe.training = True
+    tap2 = {}
+    with torch.no_grad():
+        O.loss_wrapper(probe, batch, masks={"gpn_hid": masks["gpn_hid"].float()}, tap=tap2)
+    lens = tap2["mask_sel"].sum(1).long()
+    off = torch.cumsum(lens, 0) - lens
+    om = _oracle_masks(masks, off, lens, N, T)
+    orc = O.Oracle(g.opt(drop_prob_lm=p, gpn_drop_prob=0.5), w, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch, masks={k: v.float() for k, v in om.items()})
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss (dropout)")
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss (dropout)")
+    for k, pp in m.named_parameters():
+        if orc.P[k].grad is not None:
+            close(pp.grad, orc.P[k].grad, "grad " + k, atol=2e-4, rtol=2e-3)
+
+
+KAR = dict(caption_model="topdown", vocab_size=9487, input_encoding_size=1000, rnn_size=1000, num_layers=1, drop_prob_lm=0.0,
+           max_length=20, seq_length=16, fc_feat_size=2048, att_feat_size=2048, att_hid_size=512, use_bn=0, sampling_prob=0.0,
+           use_gpn=1, embed_dim=300, gcn_dim=1024, noun_fuse=1, pred_emb_type=1, gcn_layers=2, gcn_residual=2, gcn_bn=0,
+           gpn_drop_prob=0.0, obj_name_path=None, rel_name_path=None)
+
+
+def _sharpen(sd, gen):
+    """same role as make_golden.py's build(): make the GCN visible and the decode paths vary."""
+    for k, v in sd.items():
+        if "gcn_collect" in k and "weight" in k and ".bn." not in k:
+            v.mul_(30.0)
+        if k.startswith("core.") and "lstm" in k and "weight" in k:
+            v.mul_(2.0)
+        if k in ("logit.weight",):
+            v.mul_(4.0)
+
+
+def test_full_size_subgc_kar_train_and_decode_match_oracle():
+    """Sub_GC_Kar dimensions (D=2048, L=1024, R=1000, V+1=9488, N=37, K=65), B=2 images."""
+    torch.manual_seed(0)
+    opt = argparse.Namespace(**KAR)
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(2, seed=3)
+    out, loss = run_train(m, batch)
+    orc = O.Oracle(opt, sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss")
+    outputs, _, score = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+    close(outputs, ref["outputs"], "outputs", atol=2e-4, rtol=1e-4)
+    close(score, ref["subgraph_score"], "score", atol=1e-5)
+    for k in ("logit.weight", "core.att_lstm.weight_ih", "core.lang_lstm.weight_hh", "embed.0.weight", "obj_v_proj.weight",
+              "gcn_backbone.gcn.0.gcn_collect.collect_units.2.fc_lft.weight", "gpn_layer.gpn_fc.0.weight", "att_embed.0.weight"):
+        close(m.P(k).grad, orc.P[k].grad, "grad " + k, atol=2e-5 + 2e-3 * float(orc.P[k].grad.abs().max()), rtol=5e-3)
+    # decode: greedy tokens identical
+    tb = synthetic.make_test_batch(30, seed=4, node_pool=16)
+    topt = argparse.Namespace(**dict(KAR, test_LSTM=1, gpn_nms_thres=0.55, gpn_max_subg=10))
+    mt = models.setup(topt); mt.load_state_dict(sd); mt = mt.to(DEV).eval()
+    ret = mt(*synthetic.sample_args({k: v.to(DEV) for k, v in tb.items()}), opt=dict(sample_max=1, beam_size=1, return_att=1), mode="sample")
+    want = O.Oracle(topt, sd).sample(*synthetic.sample_args(tb), opt=dict(sample_max=1, beam_size=1, return_att=1), nms_sort_kind="stable")
+    np.testing.assert_array_equal(ret[3].cpu().numpy(), want[3].numpy())
+    np.testing.assert_array_equal(ret[0].cpu().numpy(), want[0].numpy())
+    close(ret[1], want[1], "seqLogprobs", atol=2e-4)
+    close(ret[4], want[4], "att2_weights", atol=1e-5)
+
+
+def test_size_independent_properties_at_bench_size():
+    """B=128 (the bench workload): log-probs normalise, padded steps are zero, loss finite, dead params get no gradient."""
+    torch.manual_seed(1)
+    opt = argparse.Namespace(**dict(KAR, drop_prob_lm=0.5, gpn_drop_prob=0.5))
+    m = models.setup(opt).to(DEV).train()
+    batch = synthetic.make_train_batch(128, seed=0)
+    out, loss = run_train(m, batch)
+    assert torch.isfinite(loss)
+    with torch.no_grad():
+        outputs, _, score = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+    lse = torch.logsumexp(outputs, -1)
+    assert float(lse.abs().max()) < 1e-3
+    assert tuple(outputs.shape) == (640, 17, 9488) and tuple(score.shape) == (2560, 1)
+    for k in ("sg_pred_embed.weight", "gcn_backbone.gcn.0.gcn_collect.collect_units.0.fc_lft.weight"):
+        assert float(m.P(k).grad.abs().max()) == 0.0
+    assert float(m.P("logit.weight").grad.abs().max()) > 0
