@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Sub-GC hot path on MI355X: train fwd+bwd images/s (Sub_GC_Kar, BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One rank per GPU.  A step = one pass of the hot path over one synthetic batch that is already
+resident in HBM: LossWrapper forward (fusion -> GCN -> sGPN -> attention-LSTM decoder -> NLL),
+backward, and for N > 1 the RCCL all-reduce of the flat gradient bucket.  Per-GPU batch is fixed
+(weak scaling); `value` = images of all ranks / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
+
+`roofline`: the dominant kernel is the fp32 MFMA GEMM (gemm_f32_kernel): every launch inside the
+timed region is bracketed by HIP events on its own stream (C-ABI profiling hook), so
+achieved = exact algorithmic GEMM FLOPs of the K steps / summed GEMM kernel time, against the
+157.3 TFLOP/s fp32 matrix peak.  `cpu_baseline`: the CPU oracle (op-for-op restatement of the
+reference, `kind: "port"`) timed on this box's host cores on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "sub-gc_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from subgc import _lib, ops, parallel, synthetic  # noqa: E402
+import subgc.models as models  # noqa: E402
+
+KAR = dict(caption_model="topdown", vocab_size=9487, input_encoding_size=1000, rnn_size=1000, num_layers=1, drop_prob_lm=0.5,
+           max_length=20, seq_length=16, fc_feat_size=2048, att_feat_size=2048, att_hid_size=512, use_bn=0, sampling_prob=0.0,
+           use_gpn=1, embed_dim=300, gcn_dim=1024, noun_fuse=1, pred_emb_type=1, gcn_layers=2, gcn_residual=2, gcn_bn=0,
+           obj_name_path=None, rel_name_path=None)
+MFMA_F32_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+MODEL_GFLOP_PER_IMAGE = 22.0            # live-graph fwd 7.32 GFLOP x 3 (fwd+bwd)
+
+
+def lw_args(b):
+    return (b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None,
+            b["rel_ind"], None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+
+
+def cpu_train_baseline(images, iters):
+    """The oracle (CPU restatement of the reference) on the host cores: fwd+bwd images/s."""
+    from oracle import subgc_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    opt = argparse.Namespace(**KAR)
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in models.setup(opt).state_dict().items()}
+    orc = O.Oracle(opt, sd, requires_grad=True)
+    orc.training = True
+    batch = synthetic.make_train_batch(images, seed=77)
+    times = []
+    for i in range(iters + 1):
+        for p in orc.P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        out = O.loss_wrapper(orc, batch)
+        (out["lang_loss"] + out["gpn_loss"]).backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(images / t, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU restatement of the reference path), Sub_GC_Kar fp32 train fwd+bwd, B={images} images, "
+                      f"median of {iters} timed iterations after 1 warm-up, torch threads={cores}"}
+
+
+def decode_bench(model_sd, dev, images, M):
+    """Greedy decode (reference test path: one image per call, NMS 0.75, keep 10, 20 tokens)."""
+    opt = argparse.Namespace(**dict(KAR, test_LSTM=1, gpn_nms_thres=0.75, gpn_max_subg=10))
+    m = models.setup(opt)
+    m.load_state_dict(model_sd)
+    m = m.to(dev).eval()
+    batches = [{k: v.to(dev) for k, v in synthetic.make_test_batch(M, seed=500 + i).items()} for i in range(images)]
+    sopt = dict(sample_max=1, beam_size=1)
+    for b in batches[:2]:
+        m(*synthetic.sample_args(b), opt=sopt, mode="sample")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tokens = 0
+    for b in batches:
+        seq = m(*synthetic.sample_args(b), opt=sopt, mode="sample")[0]
+        tokens += seq.size(0) * seq.size(1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"decode_tokens_per_s": round(tokens / dt, 1), "decode_ms_per_image": round(1e3 * dt / images, 3),
+            "decode_config": f"greedy, {2 * M} candidate sub-graphs/image -> NMS 0.75 -> <=10 kept x 20 tokens, {images} images looped"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU (Sub_GC_Kar bench workload: 128)")
+    ap.add_argument("--cpu-images", type=int, default=16)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--with-optimizer", action="store_true", help="also time the fused clip+Adam step (reported separately)")
+    a = ap.parse_args()
+
+    rank, local, world = parallel.init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    _lib.lib()
+    torch.manual_seed(1234)                     # identical replicas on every rank
+    opt = argparse.Namespace(**KAR)
+    model = models.setup(opt).to(dev).train()
+    lw = models.LossWrapper(model, None)
+    batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=1000 + rank).items()}
+    red = parallel.GradBucketReducer(model)
+    adam = parallel.FlatAdam(model) if a.with_optimizer else None
+
+    def step():
+        red.prepare()
+        out = lw(*lw_args(batch))
+        loss = out["lang_loss"] + out["gpn_loss"]
+        loss.backward()
+        red.finish()
+        if adam is not None:
+            adam.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    if rank == 0:
+        _lib.prof_enable("gemm", True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        _lib.prof_enable("gemm", False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        n_launch, gemm_ms, _nominal = _lib.prof_collect("gemm")
+        ops.FLOPS["on"], ops.FLOPS["gemm"] = True, 0.0          # one untimed accounting step: exact (ragged-aware) GEMM FLOPs
+        step()
+        torch.cuda.synchronize()
+        ops.FLOPS["on"] = False
+        flops_step = ops.FLOPS["gemm"]
+        achieved = flops_step * a.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        ms_per_step = 1e3 * elapsed / a.steps
+        imgs = world * a.batch
+        res = {
+            "metric": "images/sec (training fwd+bwd), Sub_GC_Kar", "value": round(imgs * a.steps / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Sub_GC_Kar train fwd+bwd (BASELINE.json configs[1]): 128 images/GPU, 36+1 nodes, 64+1 relations, "
+                                   "2048-d region feats, 5 sentences/image, 2 pos + 2 neg sub-graphs/sentence, T=17, V+1=9488, dropout on",
+                       "images_per_gpu": a.batch, "global_images": imgs, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches_per_step": n_launch // max(a.steps, 1),
+                         "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
+                         "gemm_ms_per_step": round(gemm_ms / a.steps, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
+                         "whole_step_frac": round(MODEL_GFLOP_PER_IMAGE * a.batch / (ms_per_step * 1e-3) / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
+            "final_loss": round(final_loss, 4),
+        }
+        if world == 1 and not a.no_decode:
+            res.update(decode_bench(model.state_dict(), dev, images=8, M=50))
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_train_baseline(a.cpu_images, a.cpu_iters)
+            res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

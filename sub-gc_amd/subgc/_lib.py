@@ -12,6 +12,10 @@ import ctypes
 import os
 import re
 
+# torch bundles its own libamdhip64; it must be the HIP runtime of the process BEFORE
+# libsubgc_hip.so is dlopen'ed, so that streams and device pointers are shared with torch.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "subgc_hip.h")
 LIB_PATH = os.path.join(_HERE, "libsubgc_hip.so")

@@ -11,6 +11,7 @@ import torch
 from ._lib import SubgcError, call
 
 RELU, ACCUM = 1, 2
+FLOPS = {"on": False, "gemm": 0.0}
 
 
 def _stream():
@@ -47,6 +48,10 @@ def gemm(a, b, out, *, ta=False, tb=False, bias=None, add=None, keep=None, keep_
         M = a_rows.numel()
     if K != Kb or (c_rows is None and out.size(0) < M) or out.size(1) != N:
         raise SubgcError(f"gemm shape mismatch: op(a)=[{M},{K}] op(b)=[{Kb},{N}] out={tuple(out.shape)}")
+    if FLOPS["on"]:                      # bench.py's untimed accounting step: exact, ragged-aware algorithmic FLOPs
+        r = int(m_dev.item()) if m_dev is not None else None
+        me, ke = (M, min(K, r)) if (ta and r is not None) else ((min(M, r) if r is not None else M), K)
+        FLOPS["gemm"] += 2.0 * me * N * ke
     call("subgc_gemm_f32", int(ta), int(tb), M, N, K, _ptr(a, torch.float32), ld(a), _ptr(b, torch.float32), ld(b),
          _ptr(out, torch.float32), ld(out), _ptr(bias), _ptr(add), ld(add) if add is not None else 0,
          _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0),

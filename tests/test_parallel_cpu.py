@@ -1,0 +1,107 @@
+"""N>1 path on CPU: two `gloo` ranks shard one batch by image, compute their shard's gradients
+(with the CPU oracle standing in for the device compute), all-reduce the flat gradient bucket with
+GradBucketReducer (decoder slice from the post-accumulate hook, encoder slice at the end) and must
+end up with the mean of the per-shard gradients - DataParallel's semantics (train.py:96-98,154-156)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _shard_grads(opt, weights, batch, rank, world):
+    from oracle import subgc_oracle as O
+    from subgc import parallel
+    orc = O.Oracle(opt, weights, requires_grad=True)
+    orc.training = True
+    shard = parallel.shard_batch(batch, rank, world)
+    out = O.loss_wrapper(orc, shard)
+    (out["lang_loss"] + out["gpn_loss"]).backward()
+    return {k: (p.grad if p.grad is not None else None) for k, p in orc.P.items()}
+
+
+def _worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "sub-gc_amd"), ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from conftest import Golden
+    from subgc import parallel, synthetic
+    import subgc.models as models
+    r, _, w = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    g = Golden("subgc_train")
+    opt = g.opt(caption_model="topdown", gpn_drop_prob=0.0)
+    weights = g.group("weights")
+    model = models.setup(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    batch = synthetic.make_train_batch(4, D=opt.att_feat_size, vocab=opt.vocab_size, seed=9, fc_size=opt.att_feat_size)
+    red = parallel.GradBucketReducer(model)
+    red.prepare()
+    grads = _shard_grads(opt, weights, batch, rank, world)
+    # feed this rank's gradients through autograd so the post-accumulate hooks fire like in a real backward;
+    # decoder parameters first (that is the order a real backward produces them in)
+    names = [n for n, _ in model.named_parameters() if grads.get(n) is not None]
+    names.sort(key=lambda n: -model._slots[n][0])
+    loss = sum((model.P(n) * grads[n]).sum() for n in names)
+    loss.backward()
+    assert red._fired == red._n_decoder and len(red._pending) == 1      # decoder bucket already in flight
+    flat = red.finish().clone()
+    red.close()
+    q.put((rank, flat.numpy(), {k: (None if v is None else v.numpy()) for k, v in grads.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_bucket_allreduce_is_mean_of_shard_grads():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, flat0, g0), (_, flat1, g1) = res
+    np.testing.assert_array_equal(flat0, flat1)                          # identical averaged bucket on both ranks
+    sys.path.insert(0, os.path.join(ROOT, "sub-gc_amd"))
+    from conftest import Golden
+    import subgc.models as models
+    g = Golden("subgc_train")
+    model = models.setup(g.opt(caption_model="topdown"))
+    seen_dead = 0
+    for name, (o, n, shape) in model._slots.items():
+        got = flat0[o:o + n].reshape(shape)
+        if g0[name] is None:
+            assert g1[name] is None and float(np.abs(got).max()) == 0.0     # dead parameter: zeros everywhere
+            seen_dead += 1
+        else:
+            np.testing.assert_allclose(got, 0.5 * (g0[name] + g1[name]), rtol=1e-6, atol=1e-7, err_msg=name)
+    assert seen_dead == len(g.meta["dead_params"])
+
+
+def test_shard_batch_splits_every_leading_dim():
+    sys.path.insert(0, os.path.join(ROOT, "sub-gc_amd"))
+    from subgc import parallel, synthetic
+    b = synthetic.make_train_batch(8, D=16, vocab=20, n_obj_cls=10, seed=0)
+    parts = [parallel.shard_batch(b, r, 4) for r in range(4)]
+    for k, v in b.items():
+        torch.testing.assert_close(torch.cat([p[k] for p in parts], 0), v)
+    assert parts[0]["att_feats"].size(0) == 2 and parts[0]["labels"].size(0) == 10
+    with pytest.raises(ValueError):
+        parallel.shard_batch(b, 0, 3)
