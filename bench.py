@@ -46,10 +46,28 @@ def lw_args(b):
             b["rel_ind"], None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
 
 
+def effective_cores():
+    """Cores this process may really use: min(affinity, cgroup CPU quota) -- os.cpu_count() alone
+    reports the whole host (256 on the GPU box) while the container is capped at 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_train_baseline(images, iters):
     """The oracle (CPU restatement of the reference) on the host cores: fwd+bwd images/s."""
     from oracle import subgc_oracle as O
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     torch.set_num_threads(cores)
     opt = argparse.Namespace(**KAR)
     torch.manual_seed(0)
@@ -100,7 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (Sub_GC_Kar bench workload: 128)")
     ap.add_argument("--cpu-images", type=int, default=16)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--with-optimizer", action="store_true", help="also time the fused clip+Adam step (reported separately)")

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 --kernel-trace --stats output directory into a small text summary
+(per-kernel calls / total / average / share), the file that gets committed under profiles/."""
+import csv
+import glob
+import os
+import sys
+
+
+def main(d, out):
+    files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    if not files:
+        files = glob.glob(os.path.join(d, "**", "*stats*.csv"), recursive=True)
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append(r)
+    if not rows:
+        print("no stats csv under", d); return 1
+    keys = rows[0].keys()
+    name = next(k for k in keys if k.lower() in ("name", "kernelname", "kernel_name"))
+    calls = next(k for k in keys if "calls" in k.lower())
+    tot = next(k for k in keys if "total" in k.lower() and "dur" in k.lower())
+    avg = next(k for k in keys if "average" in k.lower())
+    agg = {}
+    for r in rows:
+        a = agg.setdefault(r[name], [0, 0.0])
+        a[0] += int(r[calls]); a[1] += float(r[tot])
+    total = sum(v[1] for v in agg.values())
+    with open(out, "w") as fh:
+        fh.write(f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(d)}); durations in ns\n")
+        fh.write(f"# total kernel time {total/1e6:.3f} ms over {sum(v[0] for v in agg.values())} launches\n")
+        fh.write(f"{'calls':>8} {'total_ms':>12} {'avg_us':>10} {'share':>7}  kernel\n")
+        for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            fh.write(f"{c:8d} {t/1e6:12.3f} {t/c/1e3:10.2f} {100*t/total:6.2f}%  {k[:160]}\n")
+    print(open(out).read())
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1], sys.argv[2]))
