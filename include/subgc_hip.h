@@ -83,6 +83,13 @@ int subgc_gemm_f32(int transA, int transB, int M, int N, int K,
                    const uint8_t* keep, float keep_scale, int flags,
                    const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev, void* stream);
 
+/* Optional scratch for the split-K form of subgc_gemm_f32 (used for shapes whose 128x128 tile count
+ * cannot fill the 256 CUs, e.g. the per-step recurrent GEMMs with M = 640): a caller-owned device
+ * buffer into which partial tiles are written and from which they are reduced, all stream-ordered on
+ * the GEMM's stream.  Without a workspace those shapes run with 64x64 tiles.  One stream at a time
+ * may issue GEMMs while a workspace is registered.  ptr = NULL, bytes = 0 unregisters.            */
+int subgc_set_workspace(void* ptr, size_t bytes);
+
 /* column sums: out[n] (+)= sum_m X[m, n]  -- bias gradients.  accumulate != 0 adds to out. */
 int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
                      const int32_t* m_dev, void* stream);

@@ -23,6 +23,10 @@
 // from a sequential loop, which fp32 tolerates: results are within rounding, not bit-equal).
 #include "common.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -57,53 +61,118 @@ __device__ __forceinline__ float4 load4_guard(const float* line, int i0, int n) 
 }
 
 // ---- staging of one operand tile --------------------------------------------------------
-// KC = K-contiguous image: ROWS x BK, LDS [ROWS][BK+KPAD]; per thread ROWS*BK/4/256 float4.
-// KM = K-major image:      BK x ROWS, LDS [BK][ROWS+KPAD].
+// K-contiguous image: ROWS x BK, LDS [ROWS][BK+KPAD]; per thread NV = ROWS*BK/4/256 float4.
+// K-major image:      BK x ROWS, LDS [BK][ROWS+KPAD].
+// Everything that does not depend on k (row pointers, row validity) is computed ONCE by init();
+// a per-tile load is then one 64-bit add + one global_load_dwordx4 per float4, so the VALU work
+// between MFMA groups stays small.  Out-of-range elements are loaded from a clamped (valid)
+// address and zeroed when the registers are written to LDS, so loads never wait early.
 template <int ROWS, bool KMAJOR>
 struct Stage {
     static constexpr int NV = ROWS * BK / 4 / 256;   // float4 per thread
     static constexpr int LDS_FLOATS = KMAJOR ? BK * (ROWS + KPAD) : ROWS * (BK + KPAD);
     float4 r[NV];
+    const float* base[NV];     // element (row, k = 0) [K-contiguous]  /  (k = kk_local, col) [K-major]
+    unsigned rowok;            // bit v: the row / column group of r[v] is inside the matrix
+    unsigned okmask;           // rowok & (k in range), decided per tile
+    int64_t ld_;
+    int extent;                // nrows (logical rows of this operand)
 
-    // src: operand base; ld: leading dim; row0: first tile row; k0: first k;
-    // nrows / K: logical extents; rows_idx: optional gather (K-contiguous only)
     template <bool VEC>
-    __device__ __forceinline__ void load(const float* src, int64_t ld, int row0, int k0, int nrows, int K,
-                                         const int32_t* rows_idx) {
+    __device__ __forceinline__ void init(const float* src, int64_t ld, int row0, int nrows, const int32_t* rows_idx) {
         const int t = threadIdx.x;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int f = t + v * 256;           // float4 id inside the tile
-            if (!KMAJOR) {
-                const int rr = f / (BK / 4), c4 = f % (BK / 4);
-                const int row = row0 + rr;
-                int64_t srow = row;
-                bool ok = row < nrows;
-                if (rows_idx != nullptr && ok) {
-                    const int g = rows_idx[row];
-                    ok = g >= 0;
-                    srow = g;
-                }
-                r[v] = ok ? load4_guard<VEC>(src + srow * ld, k0 + c4 * 4, K) : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int kk = f / (ROWS / 4), c4 = f % (ROWS / 4);
-                const int k = k0 + kk;
-                r[v] = (k < K) ? load4_guard<VEC>(src + (int64_t)k * ld, row0 + c4 * 4, nrows)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
-    __device__ __forceinline__ void store(float* lds) const {
-        const int t = threadIdx.x;
+        rowok = 0; ld_ = ld; extent = nrows;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int f = t + v * 256;
             if (!KMAJOR) {
                 const int rr = f / (BK / 4), c4 = f % (BK / 4);
-                *reinterpret_cast<float4*>(lds + rr * (BK + KPAD) + c4 * 4) = r[v];
+                const int row = row0 + rr;
+                bool ok = row < nrows;
+                int64_t srow = max(min(row, nrows - 1), 0);
+                if (rows_idx != nullptr) {
+                    const int g = rows_idx[srow];
+                    ok = ok && g >= 0;
+                    srow = max(g, 0);
+                }
+                base[v] = src + srow * ld + c4 * 4;
+                if (ok) rowok |= 1u << v;
             } else {
                 const int kk = f / (ROWS / 4), c4 = f % (ROWS / 4);
-                *reinterpret_cast<float4*>(lds + kk * (ROWS + KPAD) + c4 * 4) = r[v];
+                const int col = row0 + c4 * 4;
+                const bool ok = VEC ? col < nrows : true;      // scalar path guards per element
+                base[v] = src + (int64_t)kk * ld + (VEC ? (col < nrows ? col : 0) : col);
+                if (ok) rowok |= 1u << v;
+            }
+        }
+    }
+
+    template <bool VEC>
+    __device__ __forceinline__ void load(int row0, int k0, int K) {
+        const int t = threadIdx.x;
+        if (VEC && k0 + BK <= K) {                   // interior tile (wave-uniform test): no k checks at all
+            okmask = rowok;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) r[v] = ld4(base[v] + (KMAJOR ? (int64_t)k0 * ld_ : (int64_t)k0));
+            return;
+        }
+        okmask = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f = t + v * 256;
+            const bool rok = (rowok >> v) & 1u;
+            if (!KMAJOR) {
+                const int kk = k0 + (f % (BK / 4)) * 4;
+                if (VEC) {
+                    r[v] = ld4(base[v] - (f % (BK / 4)) * 4 + (kk < K ? kk : 0));   // k out of range: element 0 of the row
+                    if (rok && kk < K) okmask |= 1u << v;
+                } else {
+                    r[v] = rok ? load4_guard<false>(base[v] - (f % (BK / 4)) * 4, kk, K) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    okmask |= 1u << v;
+                }
+            } else {
+                const int k = k0 + f / (ROWS / 4);
+                if (VEC) {
+                    r[v] = ld4(base[v] + (int64_t)(k < K ? k0 : -(f / (ROWS / 4))) * ld_);   // k out of range: row 0
+                    if (rok && k < K) okmask |= 1u << v;
+                } else {
+                    const int col = row0 + (f % (ROWS / 4)) * 4;
+                    r[v] = (k < K) ? load4_guard<false>(base[v] - col + (int64_t)k0 * ld_, col, extent) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    okmask |= 1u << v;
+                }
+            }
+        }
+    }
+
+    // interior tile (all k in range), vector path only: branch-free
+    __device__ __forceinline__ void load_interior(int k0) {
+        okmask = rowok;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) r[v] = ld4(base[v] + (KMAJOR ? (int64_t)k0 * ld_ : (int64_t)k0));
+    }
+
+    __device__ __forceinline__ void store_raw(float* lds) const {      // no masking (see mainloop steady state)
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f = t + v * 256;
+            if (!KMAJOR) *reinterpret_cast<float4*>(lds + (f / (BK / 4)) * (BK + KPAD) + (f % (BK / 4)) * 4) = r[v];
+            else *reinterpret_cast<float4*>(lds + (f / (ROWS / 4)) * (ROWS + KPAD) + (f % (ROWS / 4)) * 4) = r[v];
+        }
+    }
+
+    __device__ __forceinline__ void store(float* lds) const {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f = t + v * 256;
+            const float4 q = (okmask >> v) & 1u ? r[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!KMAJOR) {
+                const int rr = f / (BK / 4), c4 = f % (BK / 4);
+                *reinterpret_cast<float4*>(lds + rr * (BK + KPAD) + c4 * 4) = q;
+            } else {
+                const int kk = f / (ROWS / 4), c4 = f % (ROWS / 4);
+                *reinterpret_cast<float4*>(lds + kk * (ROWS + KPAD) + c4 * 4) = q;
             }
         }
     }
@@ -123,77 +192,129 @@ __device__ __forceinline__ void frag(const float* lds, int r0, int c, int lane, 
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
-    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
-    constexpr bool A_KM = TA;        // A stored [K,M]  -> K-major image
-    constexpr bool B_KM = !TB;       // B stored [K,N]  -> K-major image
+// ---- one (tile, k-range) unit of work: acc += A[m0.., kt0*BK .. kt1*BK) * B[.., n0..] --------------
+// Software pipeline (one barrier per K-tile, no MFMA bubble around it):
+//   * global loads run TWO tiles ahead: tile kt+2 is requested in the middle of iteration kt, right
+//     after the staging registers were drained into the other LDS stage (so they have ~1.75
+//     iterations of MFMA work to land);
+//   * the staging registers of tile kt+1 are written to LDS[nxt] after the 2nd of the 4 k-chunks;
+//   * MFMA fragments are double-buffered: chunk c+1 is fetched from LDS before chunk c is multiplied;
+//   * the barrier sits BEFORE the last chunk's MFMAs and is immediately followed by the fetch of the
+//     next tile's first fragments, so the matrix pipe has a full chunk of work queued while the
+//     workgroup re-synchronises.
+template <int BM, int BN, bool TA, bool TB, bool VEC, int MT, int NT>
+__device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, int K, int m0, int n0, int kt0, int kt1,
+                                         f32x16 (&acc)[MT][NT]) {
+    constexpr int WM = BM / 2, WN = BN / 2, NC = BK / 8;
+    constexpr bool A_KM = TA, B_KM = !TB;
     using SA = Stage<BM, A_KM>;
     using SB = Stage<BN, B_KM>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const lA0 = smem;
     float* const lB0 = smem + 2 * SA::LDS_FLOATS;
-
-    // m_dev bounds the ROWS of the stored A: M when A is [M,K], K when A is stored transposed [K,M]
-    const int M = (p.m_dev && !TA) ? min(p.M, *p.m_dev) : p.M;
-    const int K = (p.m_dev && TA) ? min(p.K, *p.m_dev) : p.K;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if (m0 >= M) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
+    const int32_t* arows = TA ? nullptr : p.a_rows;
+    if (kt1 <= kt0) return;
     SA sa; SB sb;
-    const int nk = (K + BK - 1) / BK;
-    sa.template load<VEC>(p.A, p.lda, m0, 0, M, K, TA ? nullptr : p.a_rows);
-    sb.template load<VEC>(p.B, p.ldb, n0, 0, p.N, K, nullptr);
+    sa.template init<VEC>(p.A, p.lda, m0, M, arows);
+    sb.template init<VEC>(p.B, p.ldb, n0, p.N, nullptr);
+    sa.template load<VEC>(m0, kt0 * BK, K);
+    sb.template load<VEC>(n0, kt0 * BK, K);
     sa.store(lA0); sb.store(lB0);
+    if (kt0 + 1 < kt1) {
+        sa.template load<VEC>(m0, (kt0 + 1) * BK, K);
+        sb.template load<VEC>(n0, (kt0 + 1) * BK, K);
+    }
     __syncthreads();
+    float fa[2][MT][4], fb[2][NT][4];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) frag<BM, A_KM>(lA0, wm + a * 32, 0, lane, fa[0][a]);
+#pragma unroll
+    for (int b = 0; b < NT; ++b) frag<BN, B_KM>(lB0, wn + b * 32, 0, lane, fb[0][b]);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    // one K-tile; STEADY = tiles kt+1 and kt+2 exist and kt+2 is an interior tile: no branches, and the
+    // staging / fragment traffic is interleaved one-by-one with the MFMAs (sched_group_barrier), so a
+    // single wave keeps the matrix pipe busy by itself instead of alternating MFMA and memory phases.
+    auto ktile = [&](int kt, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int cur = (kt - kt0) & 1;
         const float* lAc = lA0 + cur * SA::LDS_FLOATS;
         const float* lBc = lB0 + cur * SB::LDS_FLOATS;
-        if (kt + 1 < nk) {
-            sa.template load<VEC>(p.A, p.lda, m0, (kt + 1) * BK, M, K, TA ? nullptr : p.a_rows);
-            sb.template load<VEC>(p.B, p.ldb, n0, (kt + 1) * BK, p.N, K, nullptr);
-        }
+        float* lAn = lA0 + (cur ^ 1) * SA::LDS_FLOATS;
+        float* lBn = lB0 + (cur ^ 1) * SB::LDS_FLOATS;
+        const bool has_next = STEADY || kt + 1 < kt1;
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            float fa[MT][4], fb[NT][4];
+        for (int c = 0; c < NC; ++c) {
+            const int fc = c & 1, fn = fc ^ 1;
+            if (c + 1 < NC) {                                    // fragments of the next chunk of this tile
 #pragma unroll
-            for (int a = 0; a < MT; ++a) frag<BM, A_KM>(lAc, wm + a * 32, c, lane, fa[a]);
+                for (int a = 0; a < MT; ++a) frag<BM, A_KM>(lAc, wm + a * 32, c + 1, lane, fa[fn][a]);
 #pragma unroll
-            for (int b = 0; b < NT; ++b) frag<BN, B_KM>(lBc, wn + b * 32, c, lane, fb[b]);
+                for (int b = 0; b < NT; ++b) frag<BN, B_KM>(lBc, wn + b * 32, c + 1, lane, fb[fn][b]);
+            }
+            if (c == 1 && has_next) {                            // drain staging regs -> other LDS stage, refill them
+                if (STEADY) { sa.store_raw(lAn); sb.store_raw(lBn); } else { sa.store(lAn); sb.store(lBn); }
+                if (STEADY) {
+                    sa.load_interior((kt + 2) * BK);
+                    sb.load_interior((kt + 2) * BK);
+                } else if (kt + 2 < kt1) {
+                    sa.template load<VEC>(m0, (kt + 2) * BK, K);
+                    sb.template load<VEC>(n0, (kt + 2) * BK, K);
+                }
+            }
+            if (c == NC - 1) {                                   // re-synchronise, then prefetch the next tile's first chunk
+                if (STEADY) {
+#pragma unroll
+                    for (int i = 0; i < (NC - 1) * 4 * MT * NT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+                    }
+                }
+                __syncthreads();
+                if (has_next) {
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) frag<BM, A_KM>(lAn, wm + a * 32, 0, lane, fa[fn][a]);
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) frag<BN, B_KM>(lBn, wn + b * 32, 0, lane, fb[fn][b]);
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][a][s], fb[fc][b][s], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-            sa.store(lA0 + (cur ^ 1) * SA::LDS_FLOATS); sb.store(lB0 + (cur ^ 1) * SB::LDS_FLOATS);
-        }
-        __syncthreads();
+    };
+    int kt = kt0;
+    if (VEC && arows == nullptr) {
+        // In the steady state nothing is masked: rows / columns beyond M / N are read from a clamped
+        // (valid) address and only feed accumulator rows / columns the epilogue never stores.
+        const int steady_end = min(kt1, K / BK) - 2;             // kt + 2 must be an interior tile of this unit
+        for (; kt < steady_end; ++kt) ktile(kt, std::true_type{});
     }
+    for (; kt < kt1; ++kt) ktile(kt, std::false_type{});
+    __syncthreads();      // a following unit (stream-K) re-uses the LDS stages
+}
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// ATOMIC = this unit holds only part of the K range (stream-K): fp32 atomic add, bias from the first part.
+template <int BM, int BN, int MT, int NT, bool ATOMIC>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, int M, int m0, int n0, bool first_part, f32x16 (&acc)[MT][NT]) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int col_l = lane & 31, hrow = 4 * (lane >> 5);
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int col = n0 + wn + b * 32 + col_l;
         if (col >= p.N) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
+        const float bias = (p.bias && first_part) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -201,21 +322,155 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
                 const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + hrow;
                 if (m >= M) continue;
                 int64_t row = m;
-                if (p.c_rows) {
+                if (!ATOMIC && p.c_rows) {
                     const int g = p.c_rows[m];
                     if (g < 0) continue;
                     row = g;
                 }
                 float v = acc[a][b][r] + bias;
-                if (p.add) v += p.add[row * p.ldadd + col];
-                if (relu) v = fmaxf(v, 0.f);
-                if (p.keep) v *= p.keep[row * p.ldc + col] ? p.keep_scale : 0.f;
                 float* dst = p.C + row * p.ldc + col;
-                if (accum) v += *dst;
-                *dst = v;
+                if (ATOMIC) {
+                    unsafeAtomicAdd(dst, v);
+                } else {
+                    if (p.add) v += p.add[row * p.ldadd + col];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (p.keep) v *= p.keep[row * p.ldc + col] ? p.keep_scale : 0.f;
+                    if (accum) v += *dst;
+                    *dst = v;
+                }
             }
         }
     }
+}
+
+// ---- workgroup -> tile mapping for L2 locality ------------------------------------------------------
+// Workgroup b is dispatched to XCD b % 8 and every XCD has its own 4 MiB L2.  (1) give each XCD a
+// CONTIGUOUS chunk of the tile sequence (bijective for any grid size), (2) order the sequence in
+// groups of GROUP_M tile-rows walked column by column, so the ~64 workgroups resident on one XCD
+// cover an ~8x8 patch of tiles: 8 A panels + 8 B panels, each k-slice fetched into that L2 once and
+// hit 7 more times.  (rocprof r01: 35 % TCC miss rate with the naive row-major mapping.)
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ int xcd_chunked_id(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int per_group = GROUP_M * tiles_n;
+    const int g = t / per_group, first_m = g * GROUP_M, in_g = t - g * per_group;
+    const int gsize = min(tiles_m - first_m, GROUP_M);
+    tm = first_m + in_g % gsize;
+    tn = in_g / gsize;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+}
+
+// data-parallel form: one workgroup per output tile
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
+    constexpr int MT = BM / 64, NT = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // m_dev bounds the ROWS of the stored A: M when A is [M,K], K when A is stored transposed [K,M]
+    const int M = (p.m_dev && !TA) ? min(p.M, *p.m_dev) : p.M;
+    const int K = (p.m_dev && TA) ? min(p.K, *p.m_dev) : p.K;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of(xcd_chunked_id(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= M) return;
+    f32x16 acc[MT][NT];
+    zero_acc(acc);
+    mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+    epilogue<BM, BN, MT, NT, false>(p, M, m0, n0, true, acc);
+}
+
+// split-K form for shapes whose tile count cannot fill 256 CUs (the per-step recurrent GEMMs, M = 640:
+// 160 tiles of 128x128).  The K range is cut into `splits` equal parts, workgroup (tile, part) writes
+// its raw partial tile to a caller-provided workspace ws[part][M][N] with plain stores (no atomics:
+// device-scope fp32 atomics are executed memory-side on this chip and cost more than the GEMM saves),
+// and splitk_reduce_kernel sums the parts and applies the (bias / accumulate) epilogue.  Both launches
+// are stream-ordered; the workspace is just-written and comes back out of L2 / Infinity Cache.
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
+    constexpr int MT = BM / 64, NT = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+    const int u = xcd_chunked_id(blockIdx.x, gridDim.x);         // parts of one tile stay on one XCD, back to back
+    const int tile = u / splits, part = u - tile * splits;
+    int tm, tn;
+    tile_of(tile, tiles_m, tiles_n, tm, tn);
+    (void)tiles;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt_all = (p.K + BK - 1) / BK;
+    const int kt0 = part * kt_per_split, kt1 = min(kt_all, kt0 + kt_per_split);
+    f32x16 acc[MT][NT];
+    zero_acc(acc);
+    mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, p.K, m0, n0, kt0, kt1, acc);
+    // raw partial tile -> ws[part][m][n]
+    constexpr int WM = BM / 2, WN = BN / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN, col_l = lane & 31, hrow = 4 * (lane >> 5);
+    float* out = ws + (size_t)part * p.M * p.N;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int col = n0 + wn + b * 32 + col_l;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+                if (m < p.M) out[(size_t)m * p.N + col] = acc[a][b][r];
+            }
+    }
+}
+
+// C = [C +] bias + sum_parts ws[part]   (float4 along N when N % 4 == 0 and C is 16-byte aligned)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ C,
+                                                            int64_t ldc, const float* __restrict__ bias, int accum, int vec) {
+    const size_t plane = (size_t)M * N;
+    if (vec) {
+        const int n4 = N >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = i / n4;
+            const int c4 = (int)(i - row * n4) * 4;
+            float4 v = bias ? *reinterpret_cast<const float4*>(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < splits; ++s) {
+                const float4 q = *reinterpret_cast<const float4*>(ws + s * plane + (size_t)row * N + c4);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            float4* d = reinterpret_cast<float4*>(C + row * ldc + c4);
+            if (accum) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *d = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * N; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = i / N;
+            const int col = (int)(i - row * N);
+            float v = bias ? bias[col] : 0.f;
+            for (int s = 0; s < splits; ++s) v += ws[s * plane + (size_t)i];
+            float* d = C + row * ldc + col;
+            *d = accum ? *d + v : v;
+        }
+    }
+}
+
+template <typename KernelT>
+int raise_lds(KernelT kernel, size_t lds, bool& done) {
+    if (done || lds <= 64 * 1024) return SUBGC_OK;    // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        subgc::set_error("gemm: cannot raise dynamic LDS limit to %zu", lds);
+        return SUBGC_ELAUNCH;
+    }
+    done = true;
+    return SUBGC_OK;
 }
 
 template <int BM, int BN, bool TA, bool TB, bool VEC>
@@ -223,25 +478,64 @@ int launch(const GemmArgs& a, hipStream_t s) {
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
     const size_t lds = sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
-    dim3 grid((unsigned)subgc::cdiv(a.N, BN), (unsigned)subgc::cdiv(a.M, BM));
-    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set && lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, TA, TB, VEC>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            subgc::set_error("gemm: cannot raise dynamic LDS limit to %zu", lds);
-            return SUBGC_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
+    static bool attr_set = false;
+    if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC>, lds, attr_set)) return rc;
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC>), grid, dim3(256), lds, s, a);
     return subgc::check_launch("subgc_gemm_f32");
 }
 
+// caller-provided scratch for the split-K partial tiles (subgc_set_workspace); one stream at a time
+float* g_ws = nullptr;
+size_t g_ws_bytes = 0;
+int g_splitk = 1;            // 0 disables the split-K form (SUBGC_SPLITK=0)
+
+// pick the number of K parts for 128x128 tiles so that tiles x parts fills the 512 workgroup slots
+// (2 per CU) in whole rounds; returns 1 when splitting does not pay
+inline int choose_splits(int tiles, int kt) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 8; ++s) {
+        const int per = (kt + s - 1) / s;
+        if (s > 1 && per < 12) break;                            // keep >= 384 of K per part
+        const int rounds = (tiles * s + 511) / 512;
+        const double cost = rounds * (per + 3.0) + 0.6 * (s > 1 ? s + 1 : 0);   // +3: prologue/epilogue, reduce pass
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+template <bool TA, bool TB, bool VEC>
+int launch_splitk(const GemmArgs& a, hipStream_t s, int splits) {
+    constexpr int BM = 128, BN = 128;
+    using SA = Stage<BM, TA>;
+    using SB = Stage<BN, !TB>;
+    const size_t lds = sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    const int tiles = (int)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM));
+    const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
+    static bool attr_set = false;
+    if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC>, lds, attr_set)) return rc;
+    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC>), dim3(tiles * splits), dim3(256), lds, s, a, g_ws, splits, per);
+    const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
+                    (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+    const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)g_ws,
+                       splits, a.M, a.N, a.C, a.ldc, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0, vec);
+    return subgc::check_launch("subgc_gemm_f32(split-K)");
+}
+
 template <bool TA, bool TB, bool VEC>
 int pick_tile(const GemmArgs& a, hipStream_t s) {
-    // 256 CUs: prefer the big tile only when it still yields >= ~1.5 workgroups per CU
+    // 256 CUs: the big tile when it yields >= ~1.5 workgroups per CU; otherwise split-K over big tiles
+    // when the epilogue is a plain (bias / accumulate) one and a workspace was registered; else small tiles.
     const int64_t big = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
     if (big >= 384) return launch<128, 128, TA, TB, VEC>(a, s);
+    const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && !a.m_dev;
+    if (plain && g_splitk && g_ws && big >= 16) {
+        const int splits = choose_splits((int)big, (a.K + BK - 1) / BK);
+        if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
+            return launch_splitk<TA, TB, VEC>(a, s, splits);
+    }
     return launch<64, 64, TA, TB, VEC>(a, s);
 }
 
@@ -260,16 +554,29 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     SUBGC_REQUIRE(!(transA && a_rows), "gemm: a_rows needs transA == 0");
     SUBGC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "gemm: leading dimension too small");
     SUBGC_REQUIRE(!add || ldadd >= N, "gemm: ldadd too small");
+    static bool env_read = false;
+    if (!env_read) {
+        if (const char* e = getenv("SUBGC_SPLITK")) g_splitk = atoi(e);
+        env_read = true;
+    }
     GemmArgs a{A, B, C, bias, add, keep, a_rows, c_rows, m_dev, lda, ldb, ldc, ldadd, M, N, K, flags, keep_scale};
     hipStream_t s = (hipStream_t)stream;
     // vector path: every staged line is read as aligned float4 and is all-in or all-out of range
     const bool vecA = aligned16(A) && lda % 4 == 0 && (transA ? M % 4 == 0 : K % 4 == 0);
-    const bool vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K % 4 == 0 && !(transA && m_dev) : N % 4 == 0);
+    const bool vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0);
     const bool vec = vecA && vecB;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
     if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);
     if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
     return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
+}
+
+SUBGC_API int subgc_set_workspace(void* ptr, size_t bytes) {
+    SUBGC_REQUIRE(ptr != nullptr || bytes == 0, "set_workspace: null pointer with non-zero size");
+    SUBGC_REQUIRE((reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "set_workspace: pointer must be 16-byte aligned");
+    g_ws = static_cast<float*>(ptr);
+    g_ws_bytes = bytes;
+    return SUBGC_OK;
 }
 
 // ---- column sums (bias gradients) -------------------------------------------------------

@@ -274,6 +274,7 @@ class AttModel(CaptionModel):
         """feat_fusion + GCN (AttModel.py:370-387, gcn_backbone.py:29-53) -> X_out [B, N, L]."""
         B, N, D = att_feats.shape
         K, L = rel_ind.size(1), self.GCN_dim
+        ops.ensure_workspace(att_feats.device)          # scratch for the split-K form of the M=5B recurrent GEMMs
         needX, needP, live_nodes, live_edges = self._gcn_liveness()
         att2 = att_feats.reshape(B * N, D)
         if self.noun_fuse:

@@ -18,6 +18,20 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_WS = {}
+
+
+def ensure_workspace(device, mbytes=96):
+    """Register a per-device scratch buffer for the split-K GEMM form (see subgc_set_workspace)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if _WS.get("dev") != key:
+        buf = torch.empty(mbytes << 20, dtype=torch.uint8, device=dev)
+        call("subgc_set_workspace", buf.data_ptr(), buf.numel())
+        _WS["dev"], _WS["buf"] = key, buf
+    return _WS["buf"]
+
+
 def _ptr(t, dtype=None):
     if t is None:
         return None

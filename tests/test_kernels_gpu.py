@@ -420,3 +420,23 @@ def test_clip_adam_matches_torch():
     ops.sumsq(g, ss)
     ops.clip_adam_step(p, g, m, v, ss, 10.0, 5e-4, 0.9, 0.999, 1e-8, 0.0, 1)
     close(g, pr.grad, atol=1e-6); close(p, pr.detach(), atol=1e-6)
+
+
+def test_gemm_splitk_plain_bias_and_accumulate():
+    """M = 640 recurrent shapes take the split-K form (workspace partials + reduce) once a workspace is
+    registered: same numbers as the tile form."""
+    ops.ensure_workspace(DEV)
+    M, N, K = 640, 3000, 4000
+    a = rnd(M, K, seed=1); w = rnd(N, K, seed=2); bias = rnd(N, seed=3)
+    ref = (a.double() @ w.double().t() + bias.double()).float()
+    out = torch.full((M, N), 3.0, device=DEV)
+    ops.gemm(a, w, out, tb=True, bias=bias)
+    close(out, ref, atol=2e-2, rtol=1e-4)
+    big = torch.ones(M, N + 8, device=DEV); view = big[:, 4:4 + N]
+    ops.gemm(a, w, view, tb=True, accum=True)
+    close(view, ref - bias + 1.0, atol=2e-2, rtol=1e-4)
+    assert float((big[:, :4] - 1).abs().max()) == 0 and float((big[:, 4 + N:] - 1).abs().max()) == 0
+    wn = rnd(K, 2000, seed=4)
+    out2 = torch.empty(M, 2000, device=DEV)
+    ops.gemm(a, wn, out2)
+    close(out2, (a.double() @ wn.double()).float(), atol=2e-2, rtol=1e-4)
