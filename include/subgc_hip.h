@@ -248,6 +248,12 @@ int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_str
 int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
                          const float* scratch2, const float* dloss, float* dlogp, int S, int T, int V,
                          void* stream);
+/* masked-NLL backward fused through the log-softmax (the criterion applied directly to the decoder's
+ * log-probabilities, as LossWrapper does): dlogits = dloss * mask/den * (softmax - onehot(target));
+ * never materialises the dense dlogp.  scratch2 is the {num, den} pair written by masked_nll_fwd.  */
+int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask,
+                             int64_t m_stride, const float* scratch2, const float* dloss, float* dlogits,
+                             int S, int T, int V, const int32_t* active, void* stream);
 /* step_active[t] = 1 for t = 0 and for t >= 1 while no earlier step had all labels[:, t] == 0
  * (AttModel.py:171-172), expanded to rows: active[s*T + t].                                  */
 int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream);

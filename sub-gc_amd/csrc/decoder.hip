@@ -305,6 +305,26 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* __restrict_
     w = w < 0 ? 0 : (w >= V ? V - 1 : w);
     dlogp[(int64_t)q * V + w] = -mask[(int64_t)s * m_stride + t] / scratch2[1] * dloss[0];
 }
+// fused backward of loss = -sum(mask * logp[target]) / sum(mask) through the log-softmax:
+// dlogits[r, c] = dloss * mask_r / den * (exp(logp[r, c]) - [c == target_r]); rows that are masked or inactive get zeros.
+__global__ __launch_bounds__(256) void nll_logsoftmax_bwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
+                                                                 int64_t t_stride, const float* __restrict__ mask, int64_t m_stride,
+                                                                 const float* __restrict__ scratch2, const float* __restrict__ dloss,
+                                                                 float* __restrict__ dlogits, int T, int V,
+                                                                 const int32_t* __restrict__ active) {
+    const int r = blockIdx.x, s = r / T, t = r % T;
+    const float m = mask[(int64_t)s * m_stride + t];
+    float* d = dlogits + (int64_t)r * V;
+    if (m == 0.f || (active && !active[r])) {
+        for (int c = threadIdx.x; c < V; c += blockDim.x) d[c] = 0.f;
+        return;
+    }
+    int64_t w = target[(int64_t)s * t_stride + t];
+    w = w < 0 ? 0 : (w >= V ? V - 1 : w);
+    const float g = dloss[0] * m / scratch2[1];
+    const float* lp = logp + (int64_t)r * V;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) d[c] = g * (expf(lp[c]) - (c == (int)w ? 1.f : 0.f));
+}
 __global__ __launch_bounds__(256) void step_active_kernel(const int64_t* __restrict__ labels, int64_t l_stride, int S, int T,
                                                           int32_t* __restrict__ active) {
     __shared__ int any_s[512];
@@ -618,6 +638,17 @@ SUBGC_API int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, cons
     hipLaunchKernelGGL(nll_bwd_kernel, dim3((S * T + 255) / 256), dim3(256), 0, s, target, t_stride, mask, m_stride, scratch2, dloss,
                        dlogp, S, T, V);
     return subgc::check_launch("subgc_masked_nll_bwd");
+}
+SUBGC_API int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
+                                       const float* scratch2, const float* dloss, float* dlogits, int S, int T, int V,
+                                       const int32_t* active, void* stream) {
+    SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "nll_logsoftmax_bwd: bad sizes");
+    SUBGC_REQUIRE(logp && target && mask && scratch2 && dloss && dlogits, "nll_logsoftmax_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * S * T * (double)V * 2);
+    hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3(S * T), dim3(256), 0, s, logp, target, t_stride, mask, m_stride, scratch2, dloss,
+                       dlogits, T, V, active);
+    return subgc::check_launch("subgc_nll_logsoftmax_bwd");
 }
 SUBGC_API int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream) {
     SUBGC_REQUIRE(S > 0 && T > 0 && T <= 512, "step_active: bad sizes");

@@ -203,6 +203,9 @@ class MaskedNLLFn(Function):
 
 
 # ------------------------------------------------------------------------------- decoder
+DIRECT_GRADS = True               # accumulate parameter gradients straight into existing .grad buffers
+on_decoder_grads_ready = None     # callback set by parallel.GradBucketReducer (decoder slice can be all-reduced)
+
 PARAM_ORDER = (
     "fc_embed.0.weight", "fc_embed.0.bias", "fc_embed.2.weight", "fc_embed.2.bias",
     "att_embed.0.weight", "att_embed.0.bias", "ctx2att.weight", "ctx2att.bias", "embed.0.weight",
@@ -296,35 +299,81 @@ class DecoderFn(Function):
         active = ops.step_active(labels, T)
         ops.log_softmax_rows_(logits, active)
 
+        crit = meta.get("crit")                      # (target [S,T] view, mask [S,T] view): criterion fused in
+        if crit is not None:
+            loss, nll_scratch = ops.masked_nll_fwd(logits.view(S, T, V1), crit[0], crit[1])
+        else:
+            loss, nll_scratch = torch.zeros((), device=dev), None
         ctx.meta = (N, scale, S, T, R, E, A, V1)
         ctx.masks = (k_xt, k_out)
         ctx.pr = pr
-        ctx.save_for_backward(labels, fc_in, X_nodes, lens, logits, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL, *P)
-        return logits.view(S, T, V1)
+        ctx.crit = crit
+        ctx.nll_scratch = nll_scratch
+        ctx.params = P
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(labels, fc_in, X_nodes, lens, logits, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
+        return logits.view(S, T, V1), loss
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dloss):
         N, scale, S, T, R, E, A, V1 = ctx.meta
         k_xt, k_out = ctx.masks
         pr = ctx.pr
-        (labels, fc_in, X_nodes, lens, logp, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL, *P) = ctx.saved_tensors
+        (labels, fc_in, X_nodes, lens, logp, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
+        P = ctx.params
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
          h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
-        dev = dout.device
+        dev = logp.device
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         zer = lambda *s: ops.zeros(*s, device=dev)
 
+        # Gradient destinations: when a parameter already owns a .grad buffer (the flat bucket of
+        # AttModel.flatten_grads) the kernels accumulate straight into it and autograd gets None --
+        # no temporary, no separate "+=" pass over 280 MB.
+        dst, acc, ret = [], [], []
+        for prm in P:
+            g = prm.grad if DIRECT_GRADS else None
+            ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == dev
+            dst.append(g if ok else None); acc.append(ok); ret.append(None)
+
+        def out_for(i, zero=False):
+            if dst[i] is None:
+                dst[i] = zer(*P[i].shape) if zero else new(*P[i].shape)
+                ret[i] = dst[i]
+            return dst[i]
+
+        def wgrad(i, dy, x, cols=None):                  # dW_i[:, cols] (+)= dy^T x
+            o = out_for(i)
+            ops.gemm(dy, x, o if cols is None else o[:, cols[0]:cols[1]], ta=True, accum=acc[i])
+
+        def bgrad(i, x, m_dev=None, also=None):          # db_i (+)= column sums of x  (also: a second bias with the same gradient)
+            if also is None:
+                ops.colsum(x, out=out_for(i), accumulate=acc[i], m_dev=m_dev)
+                return
+            tmp = ops.colsum(x, m_dev=m_dev).view(1, -1)
+            for j in (i, also):
+                ops.copy2d(tmp, out_for(j).view(1, -1), accumulate=acc[j])
+
         dlogits = new(S * T, V1)
-        ops.log_softmax_rows_bwd(logp, dout.contiguous().view(S * T, V1), dlogits, active)
+        if ctx.crit is not None and dloss is not None:
+            ops.nll_logsoftmax_bwd(logp, ctx.crit[0], ctx.crit[1], ctx.nll_scratch, dloss.contiguous(), dlogits, active, S, T, V1)
+            if dout is not None:                         # the log-probabilities were ALSO used elsewhere
+                extra = new(S * T, V1)
+                ops.log_softmax_rows_bwd(logp, dout.contiguous().view(S * T, V1), extra, active)
+                dlogits.add_(extra)
+        elif dout is not None:
+            ops.log_softmax_rows_bwd(logp, dout.contiguous().view(S * T, V1), dlogits, active)
+        else:
+            return (None,) * (7 + len(P))
         Hout2 = Hout.view(S * T, R)
-        d_lg_w = new(V1, R); ops.gemm(dlogits, Hout2, d_lg_w, ta=True)
-        d_lg_b = ops.colsum(dlogits)
+        wgrad(21, dlogits, Hout2)
+        bgrad(22, dlogits)
         dHout = new(S, T, R); ops.gemm(dlogits, lg_w, dHout.view(S * T, R))
         del dlogits
 
         dP1, dP2, dAH = new(T, S, 4 * R), new(T, S, 4 * R), new(T, S, A)
         du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
-        d_an_w, d_an_b = zer(1, A), zer(1)
+        d_an_w, d_an_b = out_for(19, zero=True), out_for(20, zero=True)
         dH1 = [zer(S, 2 * R), new(S, 2 * R)]          # [next, cur] ping-pong
         dH2 = [zer(S, 3 * R), new(S, 3 * R)]
         dC1 = [zer(S, R), new(S, R)]
@@ -334,7 +383,7 @@ class DecoderFn(Function):
             ops.lstm_bwd(G2[t], C2[t], C2[t + 1], nH1[:, :R], nH2[:, 2 * R:], dHout[:, t, :], None if k_out is None else k_out[t],
                          scale, nC2, dP2[t], cC2, S, R)
             ops.gemm(dP2[t], Wc2, cH2)                                     # -> [dctx | dh1 | dh2_prev]
-            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, dv, d_an_w, d_an_b, S, A, R)
+            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, dv, d_an_w.view(1, -1), d_an_b, S, A, R)
             ops.gemm(dAH[t], h2a_w, cH2[:, R:2 * R], accum=True)          # h1 also feeds the attention query
             ops.lstm_bwd(G1[t], C1[t], C1[t + 1], cH2[:, R:2 * R], nH1[:, R:], None, None, 1.0, nC1, dP1[t], cC1, S, R)
             ops.gemm(dP1[t], Wc1, cH1)                                     # -> [dh2_prev | dh1_prev]
@@ -342,33 +391,32 @@ class DecoderFn(Function):
 
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
         H1a, H2a = H1[:T].view(T * S, 2 * R), H2[:T].view(T * S, 3 * R)
-        d_w2i = new(4 * R, 2 * R); ops.gemm(P2, H2a[:, :2 * R], d_w2i, ta=True)
-        d_w2h = new(4 * R, R); ops.gemm(P2, H2a[:, 2 * R:], d_w2h, ta=True)
-        d_b2 = ops.colsum(P2)
-        d_w1i = new(4 * R, 2 * R + E)
-        ops.gemm(P1, H1a[:, :R], d_w1i[:, :R], ta=True)
+        wgrad(13, P2, H2a[:, :2 * R])
+        wgrad(14, P2, H2a[:, 2 * R:])
+        bgrad(15, P2, also=16)
+        wgrad(9, P1, H1a[:, :R], cols=(0, R))
         dGf = ops.colsum(dP1.view(T, S * 4 * R)).view(S, 4 * R)
-        ops.gemm(dGf, pr.f, d_w1i[:, R:2 * R], ta=True)
-        ops.gemm(P1, xt.view(T * S, E), d_w1i[:, 2 * R:], ta=True)
-        d_w1h = new(4 * R, R); ops.gemm(P1, H1a[:, R:], d_w1h, ta=True)
-        d_b1 = ops.colsum(P1)
+        wgrad(9, dGf, pr.f, cols=(R, 2 * R))
+        wgrad(9, P1, xt.view(T * S, E), cols=(2 * R, 2 * R + E))
+        wgrad(10, P1, H1a[:, R:])
+        bgrad(11, P1, also=12)
         df = new(S, R); ops.gemm(dGf, w1i[:, R:2 * R], df)
         dxt = new(T * S, E); ops.gemm(P1, w1i[:, 2 * R:], dxt)
-        d_emb = zer(V1, E)
+        d_emb = out_for(8, zero=True)
         dxt3 = dxt.view(T, S, E)
         for t in range(T):
             ops.embed_bwd(emb, labels[:, t], labels.stride(0), None if k_xt is None else k_xt[t], scale, dxt3[t], d_emb)
         dAH2 = dAH.view(T * S, A)
-        d_h2a_w = new(A, R); ops.gemm(dAH2, H2a[:, R:2 * R], d_h2a_w, ta=True)
-        d_h2a_b = ops.colsum(dAH2)
+        wgrad(17, dAH2, H2a[:, R:2 * R])
+        bgrad(18, dAH2)
 
         tot = pr.total
         ops.gemm(du, c2a_w, dv, accum=True, m_dev=tot)                     # u = v W_c^T + b_c
-        d_c2a_w = new(A, R); ops.gemm(du, pr.v, d_c2a_w, ta=True, m_dev=tot)
-        d_c2a_b = ops.colsum(du, m_dev=tot)
+        ops.gemm(du, pr.v, out_for(6), ta=True, accum=acc[6], m_dev=tot)
+        bgrad(7, du, m_dev=tot)
         dzv = ops.relu_bwd(dv, pr.v, scale)
-        d_att_w = new(R, pr.Xg.size(1)); ops.gemm(dzv, pr.Xg, d_att_w, ta=True, m_dev=tot)
-        d_att_b = ops.colsum(dzv, m_dev=tot)
+        ops.gemm(dzv, pr.Xg, out_for(4), ta=True, accum=acc[4], m_dev=tot)
+        bgrad(5, dzv, m_dev=tot)
         dX = None
         if ctx.needs_input_grad[3]:
             dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
@@ -376,19 +424,19 @@ class DecoderFn(Function):
             ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
 
         dz2 = ops.relu_bwd(df, pr.f, scale)
-        d_fc2_w = new(fc2_w.shape); ops.gemm(dz2, pr.f1, d_fc2_w, ta=True)
-        d_fc2_b = ops.colsum(dz2)
+        wgrad(2, dz2, pr.f1)
+        bgrad(3, dz2)
         df1 = new(S, pr.f1.size(1)); ops.gemm(dz2, fc2_w, df1)
         dz1 = ops.relu_bwd(df1, pr.f1, 1.0)
-        d_fc0_w = new(fc0_w.shape); ops.gemm(dz1, fc_in, d_fc0_w, ta=True)
-        d_fc0_b = ops.colsum(dz1)
+        wgrad(0, dz1, fc_in)
+        bgrad(1, dz1)
         dfc_in = None
         if ctx.needs_input_grad[2]:
             dfc_in = new(S, fc_in.size(1)); ops.gemm(dz1, fc0_w, dfc_in)
         ctx.pr = None
-        grads = (d_fc0_w, d_fc0_b, d_fc2_w, d_fc2_b, d_att_w, d_att_b, d_c2a_w, d_c2a_b, d_emb, d_w1i, d_w1h, d_b1, d_b1.clone(),
-                 d_w2i, d_w2h, d_b2, d_b2.clone(), d_h2a_w, d_h2a_b, d_an_w, d_an_b, d_lg_w, d_lg_b)
-        return (None, None, dfc_in, dX, None, None, None) + grads
+        if on_decoder_grads_ready is not None:           # data-parallel reducer: the decoder bucket is complete
+            on_decoder_grads_ready()
+        return (None, None, dfc_in, dX, None, None, None) + tuple(ret)
 
 
 # ------------------------------------------------------------------------------- decode (no grad)

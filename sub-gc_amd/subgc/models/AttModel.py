@@ -62,6 +62,8 @@ def _count_names(path, default):
 
 
 class AttModel(CaptionModel):
+    supports_fused_crit = True       # LossWrapper may pass fused_crit=(target, mask) to _forward
+
     def __init__(self, opt):
         super().__init__()
         g = lambda n, d=None: getattr(opt, n, d)
@@ -350,7 +352,11 @@ class AttModel(CaptionModel):
         return [self.P(n) for n in F_.PARAM_ORDER]
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
-                 pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None):
+                 pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None,
+                 fused_crit=None):
+        """`fused_crit=(target, mask)` (used by LossWrapper) also evaluates LanguageModelCriterion inside the
+        decoder Function, so its backward never materialises the dense d(log-probs); the value is left in
+        `self.fused_lang_loss`.  The returned tuple is the reference's either way."""
         if self.training and self.ss_prob > 0.0:
             raise NotImplementedError("scheduled sampling (ss_prob > 0, AttModel.py:158-167) is not built on the HIP path")
         B, N, _ = att_feats.shape
@@ -377,9 +383,10 @@ class AttModel(CaptionModel):
             mask_sel[:, :36].fill_(1.0)                                                   # in place on the caller's tensor
             sel_idx = ar.expand(b5, N).contiguous()
         lens = mask_sel.sum(1).to(torch.int32)
-        meta = {"N": N, "p": p, "masks": masks}
-        outputs = F_.DecoderFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx, img_s.contiguous(),
-                                     *self._decoder_params())
+        meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit}
+        outputs, lang_loss = F_.DecoderFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx, img_s.contiguous(),
+                                                *self._decoder_params())
+        self.fused_lang_loss = lang_loss if fused_crit is not None else None
         return outputs, gpn_loss, score
 
     # ------------------------------------------------------------------ decode

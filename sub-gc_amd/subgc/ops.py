@@ -265,6 +265,12 @@ def masked_nll_bwd(target, mask, scratch, dloss, S, T, V):
     return dlogp
 
 
+def nll_logsoftmax_bwd(logp, target, mask, scratch, dloss, dlogits, active, S, T, V):
+    call("subgc_nll_logsoftmax_bwd", _ptr(logp), _ptr(target, torch.int64), target.stride(0), _ptr(mask), mask.stride(0), _ptr(scratch),
+         _ptr(dloss), _ptr(dlogits), S, T, V, _ptr(active, torch.int32), _stream())
+    return dlogits
+
+
 def step_active(labels, T):
     S = labels.size(0)
     active = torch.empty(S * T, device=labels.device, dtype=torch.int32)

@@ -67,10 +67,13 @@ class GradBucketReducer:
         self.overlap = overlap and self.world > 1
         self._pending = []
         self._fired = 0
+        self._decoder_launched = False
         self._handles = []
         names = set(n for n in model._slots if model._slots[n][0] >= self.split)
         self._n_decoder = len(names)
         if self.overlap:
+            from . import functions as F_
+            F_.on_decoder_grads_ready = self._decoder_ready
             for n, p in model.named_parameters():
                 if n in names:
                     self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
@@ -78,13 +81,23 @@ class GradBucketReducer:
     def _hook(self, p):
         self._fired += 1
         if self._fired == self._n_decoder:
-            g = self.model.flat_grads[self.split:]
-            self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._decoder_ready()
+
+    def _decoder_ready(self):
+        """The decoder slice of the bucket is final: start its all-reduce now (once per step).  Called by
+        DecoderFn.backward (which writes its gradients straight into the bucket) or, on the generic
+        autograd path, by the post-accumulate-grad hooks."""
+        if self._decoder_launched or self.world == 1 or self.model.flat_grads is None:
+            return
+        self._decoder_launched = True
+        g = self.model.flat_grads[self.split:]
+        self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def prepare(self):
         """Call before forward: (re)binds every .grad into the zeroed flat bucket."""
         self._fired = 0
         self._pending = []
+        self._decoder_launched = False
         return self.model.flatten_grads()
 
     def finish(self):
@@ -104,6 +117,9 @@ class GradBucketReducer:
         return g
 
     def close(self):
+        from . import functions as F_
+        if F_.on_decoder_grads_ready == self._decoder_ready:
+            F_.on_decoder_grads_ready = None
         for h in self._handles:
             h.remove()
         self._handles = []
