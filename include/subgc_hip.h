@@ -265,10 +265,13 @@ int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int
  * (un-masked, like the reference); next_tok[s] = it; *n_unfinished accumulates the live count.
  * prev_count (device int32*, may be NULL): the live count after the previous step; when it is 0
  * the kernel writes nothing -- the reference has broken out of its loop (AttModel.py:318-319) --
- * so the whole decode loop runs without a host round trip.                                     */
+ * so the whole decode loop runs without a host round trip.
+ * raw_logits != 0: `logp` holds un-normalised logits; the kernel folds the log-softmax in (the greedy
+ * log-prob is -log sum exp(x - max); the top-k branch is shift-invariant), so decode never writes the
+ * normalised [n, V+1] row.                                                                      */
 int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int k, float temp, const float* u,
                       int t, int64_t* seq, float* seqlp, int T, int64_t* next_tok, int32_t* unfinished,
-                      int32_t* n_unfinished, const int32_t* prev_count, void* stream);
+                      int32_t* n_unfinished, const int32_t* prev_count, int raw_logits, void* stream);
 
 /* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);

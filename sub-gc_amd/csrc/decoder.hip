@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restric
                                                           const float* __restrict__ u, int t, int64_t* __restrict__ seq,
                                                           float* __restrict__ seqlp, int T, int64_t* __restrict__ next_tok,
                                                           int32_t* __restrict__ unfinished, int32_t* __restrict__ n_unfinished,
-                                                          const int32_t* __restrict__ prev_count) {
+                                                          const int32_t* __restrict__ prev_count, int raw) {
     if (prev_count && *prev_count == 0) return;   // the reference has left its loop (AttModel.py:318-319)
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -384,6 +384,12 @@ __global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restric
         }
         block_argmax(bv, bi, sv, si);
         it = bi; lp = bv;
+        if (raw) {                                // raw logits: log_softmax(x)[argmax] = -log sum exp(x - max)
+            float sum = 0.f;
+            for (int c = threadIdx.x; c < V; c += blockDim.x) sum += expf(p[c] - bv);
+            sum = block_sum(sum, smf);
+            lp = -logf(sum);
+        }
     } else {
         // lp' = log_softmax(logp / temp)
         float mx = -INFINITY;
@@ -659,13 +665,13 @@ SUBGC_API int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, 
 
 SUBGC_API int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int k, float temp, const float* u, int t, int64_t* seq,
                                 float* seqlp, int T, int64_t* next_tok, int32_t* unfinished, int32_t* n_unfinished,
-                                const int32_t* prev_count, void* stream) {
+                                const int32_t* prev_count, int raw_logits, void* stream) {
     SUBGC_REQUIRE(n >= 0 && V > 0 && k >= 0 && k <= MAXK && k <= V && t >= 0 && t < T, "decode_pick: bad sizes");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(logp && seq && seqlp && next_tok && unfinished, "decode_pick: null pointer");
     SUBGC_REQUIRE(k == 0 || temp > 0.f, "decode_pick: temperature must be positive");
     hipLaunchKernelGGL(decode_pick_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logp, ld, n, V, k, temp, u, t, seq, seqlp, T,
-                       next_tok, unfinished, n_unfinished, prev_count);
+                       next_tok, unfinished, n_unfinished, prev_count, raw_logits);
     return subgc::check_launch("subgc_decode_pick");
 }
 

@@ -465,7 +465,7 @@ class DecodeState:
         self.hout, self.logits = new(S, R), new(S, self.V1)
         self.want_att = want_att
 
-    def step(self, it, alpha_out):
+    def step(self, it, alpha_out, normalize=True):
         S, R, A = self.S, self.R, self.A
         pr = self.pr
         ops.embed_fwd(self.emb, it, 1, None, 1.0, self.xt)
@@ -481,5 +481,6 @@ class DecodeState:
                      None, 1.0, self.hout, None, S, R)
         self.C2.reverse()
         ops.gemm(self.hout, self.lg_w, self.logits, tb=True, bias=self.lg_b)
-        ops.log_softmax_rows_(self.logits)
+        if normalize:
+            ops.log_softmax_rows_(self.logits)
         return self.logits

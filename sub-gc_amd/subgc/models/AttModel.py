@@ -467,14 +467,14 @@ class AttModel(CaptionModel):
         if k and uniforms is None and forced is None:
             uniforms = torch.rand(n, T, device=dev)
         for t in range(T + 1):
-            logp = st.step(it, AL[t] if return_att else None)
+            logp = st.step(it, AL[t] if return_att else None, normalize=forced is not None)
             if t == T:
                 break
             if forced is not None:
                 ops_forced_pick(logp, forced[:, t].contiguous(), k, self.topk_temp, t, seq, seqlp, it, unfinished, counts)
             else:
                 ops.decode_pick(logp, k, self.topk_temp, None if uniforms is None else uniforms[:, t].contiguous(), t, seq, seqlp, it,
-                                unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None)
+                                unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
         out = (seq, seqlp, score, keep)
         if return_att:
             c = counts.cpu()

@@ -278,10 +278,10 @@ def step_active(labels, T):
     return active
 
 
-def decode_pick(logp, k, temp, u, t, seq, seqlp, next_tok, unfinished, n_unf, prev_count=None):
+def decode_pick(logp, k, temp, u, t, seq, seqlp, next_tok, unfinished, n_unf, prev_count=None, raw=False):
     n, V = logp.shape
     call("subgc_decode_pick", _ptr(logp), ld(logp), n, V, int(k), float(temp), _ptr(u), int(t), _ptr(seq, torch.int64), _ptr(seqlp),
-         seq.size(1), _ptr(next_tok, torch.int64), _ptr(unfinished, torch.int32), _ptr(n_unf, torch.int32), _ptr(prev_count, torch.int32), _stream())
+         seq.size(1), _ptr(next_tok, torch.int64), _ptr(unfinished, torch.int32), _ptr(n_unf, torch.int32), _ptr(prev_count, torch.int32), int(raw), _stream())
 
 
 def dropout_mask(shape, p, seed, offset, device):

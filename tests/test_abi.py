@@ -29,7 +29,7 @@ def test_host_side_argument_validation_needs_no_gpu():
     rc = L.subgc_row_argmax_f32(None, 4, 2, 4, 4, None, None, None)
     assert rc == -1
     with pytest.raises(_lib.SubgcError):
-        _lib.call("subgc_decode_pick", None, 10, 1, 10, 9, 1.0, None, 0, None, None, 4, None, None, None, None, None)
+        _lib.call("subgc_decode_pick", None, 10, 1, 10, 9, 1.0, None, 0, None, None, 4, None, None, None, None, 0, None)
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -440,3 +440,15 @@ def test_gemm_splitk_plain_bias_and_accumulate():
     out2 = torch.empty(M, 2000, device=DEV)
     ops.gemm(a, wn, out2)
     close(out2, (a.double() @ wn.double()).float(), atol=2e-2, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 9488, 1000), (10, 4000, 2000), (10, 4000, 3000), (16, 512, 1000), (7, 2048, 2048), (3, 64, 48), (10, 9488, 1000)])
+def test_gemm_skinny_weight_streaming_form(M, N, K):
+    """decode shapes (M = captions of one image <= 16): the weight-streaming kernel, incl. strided A, bias, relu"""
+    big = rnd(M, K + 8, seed=1); a = big[:, 4:4 + K] if (K % 4 == 0) else big[:, :K]
+    w = rnd(N, K, seed=2); bias = rnd(N, seed=3)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(a, w, out, tb=True, bias=bias, relu=True)
+    close(out, torch.relu(a.double() @ w.double().t() + bias.double()).float(), atol=2e-4 * K ** 0.5, rtol=1e-4)
+    ops.gemm(a, w, out, tb=True)
+    close(out, (a.double() @ w.double().t()).float(), atol=2e-4 * K ** 0.5, rtol=1e-4)
