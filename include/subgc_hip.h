@@ -205,11 +205,14 @@ int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, 
  *   c = sig(f) c_prev + sig(i) tanh(g);  h = sig(o) tanh(c);  gates[S,4R] keeps the activated
  *   i,f,g,o for the backward (may be NULL at inference).  h is written with leading dim ldh so
  *   it can land inside the next GEMM's concatenated operand; h2 (optional) receives a second copy
- *   (ldh2), hdrop (optional) the dropout-masked copy used by the logit layer.                  */
+ *   (ldh2), hdrop (optional) the dropout-masked copy used by the logit layer.  rows_h / rows_h2
+ *   (0 = all S) limit how many leading rows of h / h2 are written: with sentences sorted by length
+ *   the next step only consumes a prefix of them (packed decoder).                              */
 int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int64_t ld1, const float* g2, int64_t ld2,
                    const float* b0, const float* b1, const float* c_prev, float* c, float* h, int64_t ldh,
                    float* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd,
-                   float* gates, int S, int R, void* stream);
+                   float* gates, int S, int R, int rows_h, int rows_h2,
+                   void* stream);
 /* dh (up to two sources summed: dh_a, dh_b, either may be NULL) and dc (may be NULL) ->
  * dpre [S,4R] and dc_prev.  dh_drop (optional) is a gradient that arrives through the dropout
  * mask (keep/keep_scale).                                                                    */

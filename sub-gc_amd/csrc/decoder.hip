@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ c_prev, float* __restrict__ c,
                                                        float* __restrict__ h, int64_t ldh, float* __restrict__ h2, int64_t ldh2,
                                                        const uint8_t* __restrict__ keep, float scale, float* __restrict__ hdrop,
-                                                       int64_t ldhd, float* __restrict__ gates, int S, int R) {
+                                                       int64_t ldhd, float* __restrict__ gates, int S, int R, int rows_h, int rows_h2) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (int64_t)S * R) return;
     const int s = (int)(q / R), j = (int)(q % R);
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     const float cn = fg * cp + ig * gg;
     const float hn = og * tanhf(cn);
     c[q] = cn;
-    h[(int64_t)s * ldh + j] = hn;
-    if (h2) h2[(int64_t)s * ldh2 + j] = hn;
+    if (s < rows_h) h[(int64_t)s * ldh + j] = hn;
+    if (h2 && s < rows_h2) h2[(int64_t)s * ldh2 + j] = hn;
     if (hdrop) hdrop[(int64_t)s * ldhd + j] = keep ? (keep[q] ? hn * scale : 0.f) : hn;
     if (gates) {
         float* gp = gates + (int64_t)s * 4 * R + j;
@@ -558,15 +558,17 @@ SUBGC_API int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t to
 SUBGC_API int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0,
                              const float* b1, const float* c_prev, float* c, float* h, int64_t ldh, float* h2, int64_t ldh2,
                              const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd, float* gates, int S, int R,
-                             void* stream) {
+                             int rows_h, int rows_h2, void* stream) {
     SUBGC_REQUIRE(S >= 0 && R > 0, "lstm_fwd: bad sizes");
+    if (rows_h <= 0 || rows_h > S) rows_h = S;
+    if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(g0 && c && h, "lstm_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)S * R;
     subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12);
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev, c,
-                       h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R);
+                       h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2);
     return subgc::check_launch("subgc_lstm_fwd");
 }
 SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda, const float* dh_b,

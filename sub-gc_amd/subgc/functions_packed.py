@@ -1,0 +1,231 @@
+"""Packed (length-sorted) teacher-forced decoder + fused criterion: the LossWrapper fast path.
+
+The reference runs every sentence through every one of the T decoder steps (AttModel.py:157-175) and
+then multiplies most of that work by a zero mask in the criterion (misc/utils.py:115-124).  A step of a
+sentence whose mask is zero from there on can influence neither the loss nor any gradient, so this
+Function - used only when the caller wants the LOSS and not the log-probabilities, i.e. from
+LossWrapper - does what cuDNN-style packed sequences do:
+
+  * sentences are sorted by their number of live steps (descending); at step t only the first M_t rows
+    are computed (M_t is non-increasing), every per-step buffer is stored packed time-major
+    (offset ot[t], M_t rows), so the batched-over-time GEMMs (x_t -> gates, logits, every weight
+    gradient) run over sum_t M_t rows instead of T*S;
+  * the live counts come from the label masks with ONE small device->host read per step of training;
+  * loss and gradients are identical to the unpacked path (tests/test_parity_gpu.py compares both with
+    the reference's golden gradients); only the [S,T,V+1] `outputs` tensor is not produced.
+
+Same kernels, same C ABI calls as functions.DecoderFn; only the row bookkeeping differs.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import functions as F_
+from . import ops
+
+
+def live_plan(labels, mask_t):
+    """-> (perm int64 [S] device, M list[int] per step, den tensor): sentences sorted by live steps.
+    A step t of sentence s is live iff mask_t[s, t'] > 0 for some t' >= t and the reference's early break
+    (AttModel.py:171-172: stop at the first t >= 1 where labels[:, t] is all zero) has not happened."""
+    S, T = mask_t.shape
+    steps = torch.arange(1, T + 1, device=mask_t.device).view(1, T)
+    live = ((mask_t > 0) * steps).amax(1)                                  # last live step index + 1
+    any_tok = (labels[:, :T] != 0).any(0)
+    any_tok[0] = True
+    t_break = int(torch.cumprod(any_tok.to(torch.int32), 0).sum().item())   # host read #1 (tiny)
+    live = live.clamp(max=t_break)
+    order = torch.sort(live, descending=True, stable=True)
+    counts = (order.values.view(1, S) > torch.arange(T, device=mask_t.device).view(T, 1)).sum(1)
+    return order.indices, [int(c) for c in counts.tolist()], mask_t.sum()
+
+
+class PackedDecoderLossFn(Function):
+    """(labels, fc_in, X_nodes, lens, idx, img, params...) -> masked NLL (scalar)."""
+
+    @staticmethod
+    def forward(ctx, meta, labels, fc_in, X_nodes, lens, idx, img, *P):
+        N, p_drop, masks = meta["N"], meta["p"], meta.get("masks") or {}
+        target, mask_t = meta["crit"]
+        dev = fc_in.device
+        (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
+         h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
+        S, T = fc_in.size(0), labels.size(1) - 1
+        R, E, A, V1 = w1h.size(1), emb.size(1), h2a_w.size(0), lg_w.size(0)
+        scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        k_fc, k_att, k_xt, k_out = (masks.get(k) for k in ("fc", "att", "xt", "out"))
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+
+        perm, M, den = live_plan(labels, mask_t)
+        T_live = sum(1 for m in M if m > 0)
+        ot = [0]
+        for m in M:
+            ot.append(ot[-1] + m)
+        rows = ot[-1]
+        labels_p = labels.index_select(0, perm).contiguous()
+        lens_p = lens.index_select(0, perm).contiguous()
+        idx_p = idx.index_select(0, perm).contiguous()
+        img_p = img.index_select(0, perm).contiguous()
+        fc_p = fc_in.index_select(0, perm).contiguous()
+        X_nodes = X_nodes.contiguous()
+        pr = F_.Prepared(fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale)
+
+        xt = new(max(rows, 1), E)
+        for t in range(T_live):
+            ops.embed_fwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[ot[t]:ot[t + 1]])
+        Gx = new(max(rows, 1), 4 * R)
+        ops.gemm(xt[:rows], w1i[:, 2 * R:], Gx[:rows], tb=True)
+        Gf = new(S, 4 * R)
+        ops.gemm(pr.f, w1i[:, R:2 * R], Gf, tb=True)
+        Wc1 = F_._cat_weights(w1i[:, :R], w1h)
+        Wc2 = F_._cat_weights(w2i, w2h)
+
+        H1 = ops.zeros(rows + S, 2 * R, device=dev)            # packed [h2_{t-1} | h1_{t-1}], + S rows of slack after the last step
+        H2 = ops.zeros(rows + S, 3 * R, device=dev)            # packed [ctx_t | h1_t | h2_{t-1}]
+        C1 = ops.zeros(T + 1, S, R, device=dev)
+        C2 = ops.zeros(T + 1, S, R, device=dev)
+        Hout, G1, G2 = new(max(rows, 1), R), new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R)
+        AH, AL = new(max(rows, 1), A), new(max(rows, 1), N)
+        pre = new(S, 4 * R)
+        for t in range(T_live):
+            m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
+            o1 = ot[t + 1]
+            mn_ = max(mn, 1)                                    # row limit 0 means "all" in the C ABI: write 1 dummy row into the slack
+            ops.gemm(H1[o:o + m], Wc1, pre[:m], tb=True)
+            ops.lstm_fwd(pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R], H1[o1:o1 + mn_, R:],
+                         None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
+            ops.gemm(H2[o:o + m, R:2 * R], h2a_w, AH[o:o + m], tb=True, bias=h2a_b)
+            ops.attn_fwd(pr.u, pr.v, AH[o:o + m], an_w, an_b, pr.off, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R)
+            ops.gemm(H2[o:o + m], Wc2, pre[:m], tb=True)
+            ops.lstm_fwd(pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R], H2[o1:o1 + mn_, 2 * R:],
+                         None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R, rows_h=mn_, rows_h2=mn_)
+        logits = new(max(rows, 1), V1)
+        ops.gemm(Hout[:rows], lg_w, logits[:rows], tb=True, bias=lg_b)
+        ops.log_softmax_rows_(logits[:rows])
+        # criterion over the packed rows: row ot[t] + s  <->  (sentence perm[s], step t)
+        tgt_p = torch.cat([target.index_select(0, perm[:M[t]])[:, t] for t in range(T_live)]).contiguous().view(-1, 1)
+        msk_p = torch.cat([mask_t.index_select(0, perm[:M[t]])[:, t] for t in range(T_live)]).contiguous().view(-1, 1)
+        _, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p)
+        nll[1:2].copy_(den.view(1))                            # denominator = ALL mask entries (dead ones are zero anyway)
+        loss = nll[0] / nll[1]
+
+        ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
+        ctx.masks = (k_xt, k_out)
+        ctx.pr, ctx.params, ctx.aux = pr, P, (perm, labels_p, lens_p, tgt_p, msk_p, nll)
+        ctx.save_for_backward(fc_in, X_nodes, logits, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        N, scale, S, T, T_live, R, E, A, V1, M, ot, rows = ctx.meta
+        k_xt, k_out = ctx.masks
+        pr, P = ctx.pr, ctx.params
+        perm, labels_p, lens_p, tgt_p, msk_p, nll = ctx.aux
+        (fc_in, X_nodes, logp, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
+        (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
+         h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
+        dev = logp.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        zer = lambda *s: ops.zeros(*s, device=dev)
+        dst, acc, ret = [], [], []
+        for prm in P:                                           # accumulate straight into the flat gradient bucket when it exists
+            g = prm.grad if F_.DIRECT_GRADS else None
+            ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == dev
+            dst.append(g if ok else None); acc.append(ok); ret.append(None)
+
+        def out_for(i, zero=False):
+            if dst[i] is None:
+                dst[i] = zer(*P[i].shape) if zero else new(*P[i].shape)
+                ret[i] = dst[i]
+            return dst[i]
+
+        def wgrad(i, dy, x, cols=None):
+            o = out_for(i)
+            ops.gemm(dy, x, o if cols is None else o[:, cols[0]:cols[1]], ta=True, accum=acc[i])
+
+        def bgrad(i, x, m_dev=None, also=None):
+            if also is None:
+                ops.colsum(x, out=out_for(i), accumulate=acc[i], m_dev=m_dev)
+                return
+            tmp = ops.colsum(x, m_dev=m_dev).view(1, -1)
+            for j in (i, also):
+                ops.copy2d(tmp, out_for(j).view(1, -1), accumulate=acc[j])
+
+        dlogits = new(max(rows, 1), V1)
+        ops.nll_logsoftmax_bwd(logp[:rows], tgt_p, msk_p, nll, dloss.contiguous(), dlogits[:rows], None, rows, 1, V1)
+        wgrad(21, dlogits[:rows], Hout[:rows])
+        bgrad(22, dlogits[:rows])
+        dHout = new(max(rows, 1), R); ops.gemm(dlogits[:rows], lg_w, dHout[:rows])
+        del dlogits
+
+        dP1, dP2, dAH = new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R), new(max(rows, 1), A)
+        du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
+        d_an_w, d_an_b = out_for(19, zero=True), out_for(20, zero=True)
+        # rows that are dead at step t+1 but live at step t enter the recurrence with zero state-gradient:
+        # both ping-pong buffers start zeroed and a row >= M[t+1] is never written before step t reads it
+        dH1 = [zer(S, 2 * R), zer(S, 2 * R)]
+        dH2 = [zer(S, 3 * R), zer(S, 3 * R)]
+        dC1 = [zer(S, R), zer(S, R)]
+        dC2 = [zer(S, R), zer(S, R)]
+        dGf = zer(S, 4 * R)
+        for t in range(T_live - 1, -1, -1):
+            m, o = M[t], ot[t]
+            nH1, cH1 = dH1; nH2, cH2 = dH2; nC1, cC1 = dC1; nC2, cC2 = dC2
+            ops.lstm_bwd(G2[o:o + m], C2[t][:m], C2[t + 1][:m], nH1[:m, :R], nH2[:m, 2 * R:], dHout[o:o + m],
+                         None if k_out is None else k_out[t], scale, nC2[:m], dP2[o:o + m], cC2[:m], m, R)
+            ops.gemm(dP2[o:o + m], Wc2, cH2[:m])
+            ops.attn_bwd(pr.u, pr.v, AH[o:o + m], an_w, pr.off, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, dv, d_an_w.view(1, -1),
+                         d_an_b, m, A, R)
+            ops.gemm(dAH[o:o + m], h2a_w, cH2[:m, R:2 * R], accum=True)
+            ops.lstm_bwd(G1[o:o + m], C1[t][:m], C1[t + 1][:m], cH2[:m, R:2 * R], nH1[:m, R:], None, None, 1.0, nC1[:m], dP1[o:o + m],
+                         cC1[:m], m, R)
+            ops.gemm(dP1[o:o + m], Wc1, cH1[:m])
+            ops.copy2d(dP1[o:o + m], dGf[:m], accumulate=True)
+            dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
+
+        P1, P2, H1a, H2a = dP1[:rows], dP2[:rows], H1[:rows], H2[:rows]
+        wgrad(13, P2, H2a[:, :2 * R])
+        wgrad(14, P2, H2a[:, 2 * R:])
+        bgrad(15, P2, also=16)
+        wgrad(9, P1, H1a[:, :R], cols=(0, R))
+        wgrad(9, dGf, pr.f, cols=(R, 2 * R))
+        wgrad(9, P1, xt[:rows], cols=(2 * R, 2 * R + E))
+        wgrad(10, P1, H1a[:, R:])
+        bgrad(11, P1, also=12)
+        df = new(S, R); ops.gemm(dGf, w1i[:, R:2 * R], df)
+        dxt = new(max(rows, 1), E); ops.gemm(P1, w1i[:, 2 * R:], dxt[:rows])
+        d_emb = out_for(8, zero=True)
+        for t in range(T_live):
+            ops.embed_bwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, dxt[ot[t]:ot[t + 1]], d_emb)
+        wgrad(17, dAH[:rows], H2a[:, R:2 * R])
+        bgrad(18, dAH[:rows])
+
+        tot = pr.total
+        ops.gemm(du, c2a_w, dv, accum=True, m_dev=tot)
+        ops.gemm(du, pr.v, out_for(6), ta=True, accum=acc[6], m_dev=tot)
+        bgrad(7, du, m_dev=tot)
+        dzv = ops.relu_bwd(dv, pr.v, scale)
+        ops.gemm(dzv, pr.Xg, out_for(4), ta=True, accum=acc[4], m_dev=tot)
+        bgrad(5, dzv, m_dev=tot)
+        dX = None
+        if ctx.needs_input_grad[3]:
+            dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
+            dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
+            ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
+        dz2 = ops.relu_bwd(df, pr.f, scale)
+        wgrad(2, dz2, pr.f1)
+        bgrad(3, dz2)
+        df1 = new(S, pr.f1.size(1)); ops.gemm(dz2, fc2_w, df1)
+        dz1 = ops.relu_bwd(df1, pr.f1, 1.0)
+        fc_p = fc_in.index_select(0, perm)
+        wgrad(0, dz1, fc_p)
+        bgrad(1, dz1)
+        dfc_in = None
+        if ctx.needs_input_grad[2]:
+            dfc_p = new(S, fc_in.size(1)); ops.gemm(dz1, fc0_w, dfc_p)
+            dfc_in = torch.empty_like(dfc_p).index_copy_(0, perm, dfc_p)
+        ctx.pr = None
+        if F_.on_decoder_grads_ready is not None:
+            F_.on_decoder_grads_ready()
+        return (None, None, dfc_in, dX, None, None, None) + tuple(ret)

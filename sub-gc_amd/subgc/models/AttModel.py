@@ -63,6 +63,7 @@ def _count_names(path, default):
 
 class AttModel(CaptionModel):
     supports_fused_crit = True       # LossWrapper may pass fused_crit=(target, mask) to _forward
+    packed_decoder = True            # loss-only calls skip the masked-out decoder steps (functions_packed.py)
 
     def __init__(self, opt):
         super().__init__()
@@ -353,10 +354,11 @@ class AttModel(CaptionModel):
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
                  pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None,
-                 fused_crit=None):
+                 fused_crit=None, need_outputs=True):
         """`fused_crit=(target, mask)` (used by LossWrapper) also evaluates LanguageModelCriterion inside the
         decoder Function, so its backward never materialises the dense d(log-probs); the value is left in
-        `self.fused_lang_loss`.  The returned tuple is the reference's either way."""
+        `self.fused_lang_loss`.  The returned tuple is the reference's either way, except that with
+        `need_outputs=False` (LossWrapper only wants the loss) `outputs` is None and the decoder runs packed."""
         if self.training and self.ss_prob > 0.0:
             raise NotImplementedError("scheduled sampling (ss_prob > 0, AttModel.py:158-167) is not built on the HIP path")
         B, N, _ = att_feats.shape
@@ -384,6 +386,12 @@ class AttModel(CaptionModel):
             sel_idx = ar.expand(b5, N).contiguous()
         lens = mask_sel.sum(1).to(torch.int32)
         meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit}
+        if fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None:
+            # loss-only call (LossWrapper): length-sorted packed decoder, dead (masked-out) steps are never computed
+            from ..functions_packed import PackedDecoderLossFn
+            self.fused_lang_loss = PackedDecoderLossFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx,
+                                                             img_s.contiguous(), *self._decoder_params())
+            return None, gpn_loss, score
         outputs, lang_loss = F_.DecoderFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx, img_s.contiguous(),
                                                 *self._decoder_params())
         self.fused_lang_loss = lang_loss if fused_crit is not None else None

@@ -28,7 +28,7 @@ class LossWrapper(torch.nn.Module):
                 pred_fmap, pred_dist, gpn_obj_ind, gpn_pred_ind, gpn_nrel_ind, gpn_pool_mtx):
         T = labels.size(1) - 1
         fused = (labels[:, 1:], masks[:, 1:T + 1]) if getattr(self.model, "supports_fused_crit", False) else None
-        kw = {"fused_crit": fused} if fused is not None else {}
+        kw = {"fused_crit": fused, "need_outputs": False} if fused is not None else {}
         lang_output, gpn_loss, subgraph_score = self.model(fc_feats, att_feats, labels, att_masks, trip_pred, obj_dist, obj_box,
                                                            rel_ind, pred_fmap, pred_dist, gpn_obj_ind, gpn_pred_ind, gpn_nrel_ind,
                                                            gpn_pool_mtx, **kw)

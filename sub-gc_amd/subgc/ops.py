@@ -214,10 +214,11 @@ def embed_bwd(table, tok, tok_stride, keep, scale, dout, dtable):
     return dtable
 
 
-def lstm_fwd(g0, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R):
+def lstm_fwd(g0, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0):
     L = lambda t: ld(t) if t is not None else 0
     call("subgc_lstm_fwd", _ptr(g0), L(g0), _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c),
-         _ptr(h), L(h), _ptr(h2), L(h2), _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, _stream())
+         _ptr(h), L(h), _ptr(h2), L(h2), _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h),
+         int(rows_h2), _stream())
 
 
 def lstm_bwd(gates, c_prev, c, dh_a, dh_b, dh_drop, keep, scale, dc, dpre, dc_prev, S, R):
