@@ -198,6 +198,30 @@ def main():
                          "whole_step_frac": round(MODEL_GFLOP_PER_IMAGE * a.batch / (ms_per_step * 1e-3) / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
             "final_loss": round(final_loss, 4),
         }
+        if world == 1:
+            # the same step with the loss-only packing switched off (every sentence runs all T steps, `outputs`
+            # is materialised exactly like the reference does): reported beside the default for comparison
+            model.packed_decoder = False
+            for _ in range(2):
+                step()
+            fence()
+            _lib.prof_enable("gemm", True)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            fence()
+            dt = time.perf_counter() - t0
+            _lib.prof_enable("gemm", False)
+            _, ms2, _ = _lib.prof_collect("gemm")
+            ops.FLOPS["on"], ops.FLOPS["gemm"] = True, 0.0
+            step()
+            torch.cuda.synchronize()
+            ops.FLOPS["on"] = False
+            ach2 = ops.FLOPS["gemm"] * a.steps / (ms2 * 1e-3) / 1e12
+            res["unpacked_decoder"] = {"value": round(imgs * a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3),
+                                       "gemm_gflop_per_step": round(ops.FLOPS["gemm"] / 1e9, 2), "gemm_achieved_tflops": round(ach2, 2),
+                                       "gemm_frac_of_peak": round(ach2 / MFMA_F32_PEAK_TFLOPS, 4)}
+            model.packed_decoder = True
         if world == 1 and not a.no_decode:
             res.update(decode_bench(model.state_dict(), dev, images=8, M=50))
         if world == 1 and not a.no_cpu_baseline:

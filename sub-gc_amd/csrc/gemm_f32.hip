@@ -505,9 +505,8 @@ inline int choose_splits(int tiles, int kt) {
     return best;
 }
 
-template <bool TA, bool TB, bool VEC>
+template <int BM, int BN, bool TA, bool TB, bool VEC>
 int launch_splitk(const GemmArgs& a, hipStream_t s, int splits) {
-    constexpr int BM = 128, BN = 128;
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
     const size_t lds = sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
@@ -534,7 +533,16 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     if (plain && g_splitk && g_ws && big >= 16) {
         const int splits = choose_splits((int)big, (a.K + BK - 1) / BK);
         if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
-            return launch_splitk<TA, TB, VEC>(a, s, splits);
+            return launch_splitk<128, 128, TA, TB, VEC>(a, s, splits);
+    }
+    if (plain && g_splitk && g_ws) {
+        // small contractions (the per-step h2att projection and its data gradient): split K over 64x64 tiles
+        // until ~2 workgroups per CU exist; each part keeps >= 4 K-tiles
+        const int small = (int)(subgc::cdiv(a.M, 64) * subgc::cdiv(a.N, 64)), kt = (a.K + BK - 1) / BK;
+        int splits = 1;
+        while (small * (splits + 1) <= 768 && kt / (splits + 1) >= 4 && splits < 8) ++splits;
+        if (splits > 1 && small * splits >= 128 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
+            return launch_splitk<64, 64, TA, TB, VEC>(a, s, splits);
     }
     return launch<64, 64, TA, TB, VEC>(a, s);
 }

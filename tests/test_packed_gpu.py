@@ -1,0 +1,62 @@
+"""The loss-only fast path (length-sorted packed decoder, functions_packed.py) must give the SAME loss and
+the SAME gradients as the full path that also produces `outputs` (functions.DecoderFn), including when
+the reference's early break triggers and when a batch contains very short and very long sentences."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from subgc import synthetic
+import subgc.models as models
+from subgc.functions_packed import live_plan
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+OPT = dict(caption_model="topdown", vocab_size=300, input_encoding_size=128, rnn_size=128, num_layers=1, drop_prob_lm=0.0,
+           max_length=20, seq_length=16, fc_feat_size=96, att_feat_size=256, att_hid_size=64, use_bn=0, sampling_prob=0.0,
+           use_gpn=1, embed_dim=20, gcn_dim=128, noun_fuse=1, pred_emb_type=1, gcn_layers=2, gcn_residual=2, gcn_bn=0,
+           gpn_drop_prob=0.0, obj_name_path=None, rel_name_path=None, sg_obj_cnt=60, sg_pred_cnt=21)
+
+
+def grads_of(model, batch, packed):
+    model.packed_decoder = packed
+    lw = models.LossWrapper(model, None)
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    model.flatten_grads()
+    out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
+             None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+    (out["lang_loss"] + out["gpn_loss"]).backward()
+    torch.cuda.synchronize()
+    return float(out["lang_loss"]), model.flat_grads.clone()
+
+
+@pytest.mark.parametrize("min_len,max_len", [(5, 16), (1, 16), (2, 6)])
+def test_packed_equals_unpacked(min_len, max_len):
+    torch.manual_seed(0)
+    m = models.setup(argparse.Namespace(**OPT))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "gcn_collect" in n and "weight" in n:
+                p.mul_(30.0)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(6, D=256, vocab=300, n_obj_cls=60, seed=5, fc_size=256, min_len=min_len, max_len=max_len)
+    l0, g0 = grads_of(m, batch, packed=False)
+    l1, g1 = grads_of(m, batch, packed=True)
+    assert abs(l0 - l1) < 2e-5 * max(1.0, abs(l0))
+    scale = float(g0.abs().max())
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=2e-5 * scale + 1e-7, rtol=2e-4)
+
+
+def test_live_plan_counts_and_early_break():
+    labels = torch.zeros(5, 8, dtype=torch.long)
+    for s, n in enumerate([3, 1, 5, 2, 5]):
+        labels[s, 1:n + 1] = 7
+    mask = (torch.arange(8).view(1, -1) < torch.tensor([5, 3, 7, 4, 7]).view(-1, 1)).float()   # len + 2 ones
+    perm, M, den = live_plan(labels.to(DEV), mask[:, 1:].to(DEV))
+    # step t is live for sentence s while t <= len_s; the longest sentences have 5 tokens -> steps 0..5, then all labels are
+    # zero from t = 6 on (early break at t = 6)
+    assert M == [5, 5, 4, 3, 2, 2, 0]
+    assert float(den) == float(mask[:, 1:].sum())
+    assert sorted(perm.tolist()[:2]) == [2, 4]
