@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--packed-only", action="store_true", help="skip the extra unpacked-decoder leg (clean profiles)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time the fused clip+Adam step (reported separately)")
     a = ap.parse_args()
 
@@ -198,7 +199,7 @@ def main():
                          "whole_step_frac": round(MODEL_GFLOP_PER_IMAGE * a.batch / (ms_per_step * 1e-3) / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
             "final_loss": round(final_loss, 4),
         }
-        if world == 1:
+        if world == 1 and not a.packed_only:
             # the same step with the loss-only packing switched off (every sentence runs all T steps, `outputs`
             # is materialised exactly like the reference does): reported beside the default for comparison
             model.packed_decoder = False

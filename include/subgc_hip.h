@@ -230,7 +230,9 @@ int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float*
                    const int32_t* off, const int32_t* len, float* ctx, int64_t ldctx, float* alpha,
                    int n_stride, int S, int A, int R, void* stream);
 /* backward of one step: dctx [S,R] (ld lddctx) -> dah [S,A]; du, dv ACCUMULATE (+=) over steps;
- * dw_a [A] and db_a [1] accumulate with atomics.                                             */
+ * dw_a [S,A] and db_a [S] receive PER-SENTENCE partial gradients of w_a / b_a (plain stores; the
+ * caller column-sums them once over all steps: 640 workgroups x 512 same-address atomics per step
+ * cost more than the rest of the kernel).                                                    */
 int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off,
                    const int32_t* len, const float* alpha, int n_stride, const float* dctx, int64_t lddctx,
                    float* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R,

@@ -1,0 +1,216 @@
+// Vectorised (float4) forms of the per-step attention kernels, used when A % 4 == 0, R % 4 == 0 and all
+// row starts are 16-byte aligned (every Sub-GC preset); decoder.hip keeps the scalar forms as fallback.
+//
+// One workgroup (256 threads = 4 waves) per sentence.  The sets are tiny (<= 11 nodes on Sub_GC_Kar), so
+// the kernels are latency-bound: everything is arranged so that each thread issues ALL of its loads for a
+// phase before it consumes any of them (full unrolling over float4 chunks), instead of one dependent
+// global round trip per loop iteration.
+// Reference: AttModel.py:453-466 (forward), its autograd backward.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXLEN = 512;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// CA = ceil(A/4 / 64): float4 chunks of a score row per lane;  CR = ceil(R/4 / 256): float4 chunks of a value row per thread
+template <int CA, int CR>
+__global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ ah, const float* __restrict__ w_a,
+                                                           const float* __restrict__ b_a, const int32_t* __restrict__ off,
+                                                           const int32_t* __restrict__ len, float* __restrict__ ctx, int64_t ldctx,
+                                                           float* __restrict__ alpha, int n_stride, int A, int R) {
+    __shared__ float e_s[MAXLEN];
+    const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l = min(len[s], MAXLEN), m0 = off[s];
+    const int A4 = A >> 2, R4 = R >> 2;
+    // scores: one wave per node; the query slice and w_a of this lane are loaded once
+    float4 q[CA], w[CA];
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+        const int a4 = lane + c * 64;
+        const bool ok = a4 < A4;
+        q[c] = ok ? ld4(ah + (int64_t)s * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        w[c] = ok ? ld4(w_a + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = wave; i < l; i += 4) {
+        const float* ur = u + (int64_t)(m0 + i) * A;
+        float4 x[CA];
+#pragma unroll
+        for (int c = 0; c < CA; ++c) x[c] = (lane + c * 64 < A4) ? ld4(ur + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CA; ++c)
+            acc += w[c].x * tanhf(x[c].x + q[c].x) + w[c].y * tanhf(x[c].y + q[c].y) + w[c].z * tanhf(x[c].z + q[c].z) +
+                   w[c].w * tanhf(x[c].w + q[c].w);
+        acc = wave_sum(acc);
+        if (lane == 0) e_s[i] = acc + b_a[0];
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int i = 0; i < l; ++i) mx = fmaxf(mx, e_s[i]);
+    float den = 0.f;
+    for (int i = 0; i < l; ++i) den += expf(e_s[i] - mx);
+    __syncthreads();
+    for (int i = t; i < l; i += 256) e_s[i] = expf(e_s[i] - mx) / den;
+    __syncthreads();
+    if (alpha)
+        for (int i = t; i < n_stride; i += 256) alpha[(int64_t)s * n_stride + i] = i < l ? e_s[i] : 0.f;
+    // context: thread = float4 column chunk; 4 node rows in flight at a time
+#pragma unroll
+    for (int c = 0; c < CR; ++c) {
+        const int r4 = t + c * 256;
+        if (r4 >= R4) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* vp = v + (int64_t)m0 * R + r4 * 4;
+        int i = 0;
+        for (; i + 4 <= l; i += 4) {
+            const float4 x0 = ld4(vp + (int64_t)(i + 0) * R), x1 = ld4(vp + (int64_t)(i + 1) * R);
+            const float4 x2 = ld4(vp + (int64_t)(i + 2) * R), x3 = ld4(vp + (int64_t)(i + 3) * R);
+            const float a0 = e_s[i], a1 = e_s[i + 1], a2 = e_s[i + 2], a3 = e_s[i + 3];
+            acc.x += a0 * x0.x; acc.y += a0 * x0.y; acc.z += a0 * x0.z; acc.w += a0 * x0.w;
+            acc.x += a1 * x1.x; acc.y += a1 * x1.y; acc.z += a1 * x1.z; acc.w += a1 * x1.w;
+            acc.x += a2 * x2.x; acc.y += a2 * x2.y; acc.z += a2 * x2.z; acc.w += a2 * x2.w;
+            acc.x += a3 * x3.x; acc.y += a3 * x3.y; acc.z += a3 * x3.z; acc.w += a3 * x3.w;
+        }
+        for (; i < l; ++i) {
+            const float4 x0 = ld4(vp + (int64_t)i * R);
+            const float a0 = e_s[i];
+            acc.x += a0 * x0.x; acc.y += a0 * x0.y; acc.z += a0 * x0.z; acc.w += a0 * x0.w;
+        }
+        st4(ctx + (int64_t)s * ldctx + r4 * 4, acc);
+    }
+}
+
+template <int CA, int CR64>
+__global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ ah, const float* __restrict__ w_a,
+                                                           const int32_t* __restrict__ off, const int32_t* __restrict__ len,
+                                                           const float* __restrict__ alpha, int n_stride,
+                                                           const float* __restrict__ dctx, int64_t lddctx, float* __restrict__ dah,
+                                                           float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
+                                                           float* __restrict__ db_a, int A, int R) {
+    __shared__ float al_s[MAXLEN];    // alpha, then de
+    __shared__ float da_s[MAXLEN];    // dalpha
+    __shared__ float4 part_d[128], part_w[128];
+    const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l = min(len[s], MAXLEN), m0 = off[s];
+    const int A4 = A >> 2, R4 = R >> 2;
+    for (int i = t; i < l; i += 256) al_s[i] = alpha[(int64_t)s * n_stride + i];
+    // dalpha_i = <dctx, v_i>,  dv_i += alpha_i dctx : wave per node; this lane's dctx chunks are loaded once
+    float4 g[CR64];
+#pragma unroll
+    for (int c = 0; c < CR64; ++c) g[c] = (lane + c * 64 < R4) ? ld4(dctx + (int64_t)s * lddctx + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int i = wave; i < l; i += 4) {
+        const float a_i = al_s[i];
+        const float* vr = v + (int64_t)(m0 + i) * R;
+        float* dvr = dv + (int64_t)(m0 + i) * R;
+        float4 x[CR64], y[CR64];
+#pragma unroll
+        for (int c = 0; c < CR64; ++c) {
+            const bool ok = lane + c * 64 < R4;
+            x[c] = ok ? ld4(vr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y[c] = ok ? ld4(dvr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CR64; ++c) {
+            acc += g[c].x * x[c].x + g[c].y * x[c].y + g[c].z * x[c].z + g[c].w * x[c].w;
+            y[c].x += a_i * g[c].x; y[c].y += a_i * g[c].y; y[c].z += a_i * g[c].z; y[c].w += a_i * g[c].w;
+            if (lane + c * 64 < R4) st4(dvr + (lane + c * 64) * 4, y[c]);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) da_s[i] = acc;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int i = 0; i < l; ++i) dot += al_s[i] * da_s[i];
+    __syncthreads();
+    for (int i = t; i < l; i += 256) al_s[i] = al_s[i] * (da_s[i] - dot);     // de_i
+    __syncthreads();
+    if (t == 0 && db_a) {
+        float desum = 0.f;
+        for (int i = 0; i < l; ++i) desum += al_s[i];
+        db_a[s] = desum;
+    }
+    // through tanh: 2 thread groups x 128 float4 chunks of the hidden dimension; group g takes nodes i = g, g+2, ...
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+        const int a4 = (t & 127) + c * 128, grp = t >> 7;
+        float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f), wsum = dsum;
+        if (a4 < A4) {
+            const float4 wa = ld4(w_a + a4 * 4), ha = ld4(ah + (int64_t)s * A + a4 * 4);
+            for (int i = grp; i < l; i += 2) {
+                const int64_t o = (int64_t)(m0 + i) * A + a4 * 4;
+                const float4 x = ld4(u + o);
+                float4 d = ld4(du + o);
+                const float de = al_s[i];
+                const float t0 = tanhf(x.x + ha.x), t1 = tanhf(x.y + ha.y), t2 = tanhf(x.z + ha.z), t3 = tanhf(x.w + ha.w);
+                const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
+                const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
+                d.x += p0; d.y += p1; d.z += p2; d.w += p3;
+                st4(du + o, d);
+                dsum.x += p0; dsum.y += p1; dsum.z += p2; dsum.w += p3;
+                wsum.x += de * t0; wsum.y += de * t1; wsum.z += de * t2; wsum.w += de * t3;
+            }
+        }
+        __syncthreads();
+        if (grp == 1 && (t & 127) < 128) { part_d[t & 127] = dsum; part_w[t & 127] = wsum; }
+        __syncthreads();
+        if (grp == 0 && a4 < A4) {
+            const float4 od = part_d[t & 127], ow = part_w[t & 127];
+            dsum.x += od.x; dsum.y += od.y; dsum.z += od.z; dsum.w += od.w;
+            wsum.x += ow.x; wsum.y += ow.y; wsum.z += ow.z; wsum.w += ow.w;
+            st4(dah + (int64_t)s * A + a4 * 4, dsum);
+            st4(dw_a + (int64_t)s * A + a4 * 4, wsum);      // per-sentence partial; the caller column-sums once over all steps
+        }
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+namespace subgc {
+
+// return -100 when the vector form does not apply
+int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
+                 const int32_t* len, float* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, hipStream_t s) {
+    if (A % 4 || R % 4 || ldctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(ctx)) return -100;
+    const int ca = (A / 4 + 63) / 64, cr = (R / 4 + 255) / 256;
+    if (ca > 2 || cr > 2) return -100;
+#define SUBGC_ATT_FWD(CA_, CR_)                                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_vec_kernel<CA_, CR_>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, \
+                       n_stride, A, R)
+    if (ca == 1 && cr == 1) SUBGC_ATT_FWD(1, 1);
+    else if (ca == 2 && cr == 1) SUBGC_ATT_FWD(2, 1);
+    else if (ca == 1 && cr == 2) SUBGC_ATT_FWD(1, 2);
+    else SUBGC_ATT_FWD(2, 2);
+#undef SUBGC_ATT_FWD
+    return check_launch("subgc_attn_fwd(vec)");
+}
+
+int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                 const float* alpha, int n_stride, const float* dctx, int64_t lddctx, float* dah, float* du, float* dv, float* dw_a,
+                 float* db_a, int S, int A, int R, hipStream_t s) {
+    if (A % 4 || R % 4 || lddctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
+        !al16(dv) || !al16(dw_a))
+        return -100;
+    const int ca = (A / 4 + 127) / 128, cr = (R / 4 + 63) / 64;
+    if (ca > 2 || cr > 8) return -100;
+#define SUBGC_ATT_BWD(CA_, CR_)                                                                                                     \
+    hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, \
+                       dah, du, dv, dw_a, db_a, A, R)
+    if (ca == 1) {
+        if (cr <= 1) SUBGC_ATT_BWD(1, 1); else if (cr <= 2) SUBGC_ATT_BWD(1, 2); else if (cr <= 4) SUBGC_ATT_BWD(1, 4); else SUBGC_ATT_BWD(1, 8);
+    } else {
+        if (cr <= 1) SUBGC_ATT_BWD(2, 1); else if (cr <= 2) SUBGC_ATT_BWD(2, 2); else if (cr <= 4) SUBGC_ATT_BWD(2, 4); else SUBGC_ATT_BWD(2, 8);
+    }
+#undef SUBGC_ATT_BWD
+    return check_launch("subgc_attn_bwd(vec)");
+}
+
+}  // namespace subgc

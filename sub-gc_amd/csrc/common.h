@@ -39,6 +39,13 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N,
                    int K, int relu, hipStream_t stream);
 
+// attention_vec.hip: float4 forms of the per-step attention kernels; return -100 when they do not apply
+int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
+                 const int32_t* len, float* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, hipStream_t s);
+int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                 const float* alpha, int n_stride, const float* dctx, int64_t lddctx, float* dah, float* du, float* dv, float* dw_a,
+                 float* db_a, int S, int A, int R, hipStream_t s);
+
 }  // namespace subgc
 
 #define SUBGC_REQUIRE(cond, ...)          \

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < l; i += blockDim.x) al_s[i] = al_s[i] * (da_s[i] - dot);   // de_i
     __syncthreads();
     for (int i = 0; i < l; ++i) desum += al_s[i];
-    if (threadIdx.x == 0 && db_a) unsafeAtomicAdd(db_a, desum);
+    if (threadIdx.x == 0 && db_a) db_a[s] = desum;
     // through tanh: thread per hidden unit a
     const float* ahs = ah + (int64_t)s * A;
     for (int a = threadIdx.x; a < A; a += blockDim.x) {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             wsum += de * t;
         }
         dah[(int64_t)s * A + a] = dsum;
-        unsafeAtomicAdd(dw_a + a, wsum);
+        dw_a[(int64_t)s * A + a] = wsum;
     }
     (void)red;
 }
@@ -593,6 +593,7 @@ SUBGC_API int subgc_attn_fwd(const float* u, const float* v, const float* ah, co
     SUBGC_REQUIRE(u && v && ah && w_a && b_a && off && len && ctx, "attn_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    if (const int rc = subgc::attn_fwd_vec(u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R, s); rc != -100) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R);
     return subgc::check_launch("subgc_attn_fwd");
 }
@@ -604,6 +605,9 @@ SUBGC_API int subgc_attn_bwd(const float* u, const float* v, const float* ah, co
     SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dv && dw_a, "attn_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, s);
+        rc != -100)
+        return rc;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv,
                        dw_a, db_a, S, A, R);
     return subgc::check_launch("subgc_attn_bwd");

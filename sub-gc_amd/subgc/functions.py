@@ -373,7 +373,7 @@ class DecoderFn(Function):
 
         dP1, dP2, dAH = new(T, S, 4 * R), new(T, S, 4 * R), new(T, S, A)
         du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
-        d_an_w, d_an_b = out_for(19, zero=True), out_for(20, zero=True)
+        dWa, dBa = new(T, S, A), new(T, S)                     # per-(step, sentence) partials of alpha_net's gradient
         dH1 = [zer(S, 2 * R), new(S, 2 * R)]          # [next, cur] ping-pong
         dH2 = [zer(S, 3 * R), new(S, 3 * R)]
         dC1 = [zer(S, R), new(S, R)]
@@ -383,7 +383,7 @@ class DecoderFn(Function):
             ops.lstm_bwd(G2[t], C2[t], C2[t + 1], nH1[:, :R], nH2[:, 2 * R:], dHout[:, t, :], None if k_out is None else k_out[t],
                          scale, nC2, dP2[t], cC2, S, R)
             ops.gemm(dP2[t], Wc2, cH2)                                     # -> [dctx | dh1 | dh2_prev]
-            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, dv, d_an_w.view(1, -1), d_an_b, S, A, R)
+            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, dv, dWa[t], dBa[t], S, A, R)
             ops.gemm(dAH[t], h2a_w, cH2[:, R:2 * R], accum=True)          # h1 also feeds the attention query
             ops.lstm_bwd(G1[t], C1[t], C1[t + 1], cH2[:, R:2 * R], nH1[:, R:], None, None, 1.0, nC1, dP1[t], cC1, S, R)
             ops.gemm(dP1[t], Wc1, cH1)                                     # -> [dh2_prev | dh1_prev]
@@ -409,6 +409,8 @@ class DecoderFn(Function):
         dAH2 = dAH.view(T * S, A)
         wgrad(17, dAH2, H2a[:, R:2 * R])
         bgrad(18, dAH2)
+        ops.colsum(dWa.view(T * S, A), out=out_for(19).view(-1), accumulate=acc[19])
+        ops.colsum(dBa.view(T * S, 1), out=out_for(20).view(-1), accumulate=acc[20])
 
         tot = pr.total
         ops.gemm(du, c2a_w, dv, accum=True, m_dev=tot)                     # u = v W_c^T + b_c

@@ -161,7 +161,7 @@ class PackedDecoderLossFn(Function):
 
         dP1, dP2, dAH = new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R), new(max(rows, 1), A)
         du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
-        d_an_w, d_an_b = out_for(19, zero=True), out_for(20, zero=True)
+        dWa, dBa = new(max(rows, 1), A), new(max(rows, 1))     # per-(step, sentence) partials of alpha_net's gradient
         # rows that are dead at step t+1 but live at step t enter the recurrence with zero state-gradient:
         # both ping-pong buffers start zeroed and a row >= M[t+1] is never written before step t reads it
         dH1 = [zer(S, 2 * R), zer(S, 2 * R)]
@@ -175,8 +175,8 @@ class PackedDecoderLossFn(Function):
             ops.lstm_bwd(G2[o:o + m], C2[t][:m], C2[t + 1][:m], nH1[:m, :R], nH2[:m, 2 * R:], dHout[o:o + m],
                          None if k_out is None else k_out[t], scale, nC2[:m], dP2[o:o + m], cC2[:m], m, R)
             ops.gemm(dP2[o:o + m], Wc2, cH2[:m])
-            ops.attn_bwd(pr.u, pr.v, AH[o:o + m], an_w, pr.off, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, dv, d_an_w.view(1, -1),
-                         d_an_b, m, A, R)
+            ops.attn_bwd(pr.u, pr.v, AH[o:o + m], an_w, pr.off, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, dv, dWa[o:o + m],
+                         dBa[o:o + m], m, A, R)
             ops.gemm(dAH[o:o + m], h2a_w, cH2[:m, R:2 * R], accum=True)
             ops.lstm_bwd(G1[o:o + m], C1[t][:m], C1[t + 1][:m], cH2[:m, R:2 * R], nH1[:m, R:], None, None, 1.0, nC1[:m], dP1[o:o + m],
                          cC1[:m], m, R)
@@ -200,6 +200,8 @@ class PackedDecoderLossFn(Function):
             ops.embed_bwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, dxt[ot[t]:ot[t + 1]], d_emb)
         wgrad(17, dAH[:rows], H2a[:, R:2 * R])
         bgrad(18, dAH[:rows])
+        ops.colsum(dWa[:rows], out=out_for(19).view(-1), accumulate=acc[19])
+        ops.colsum(dBa[:rows].view(-1, 1), out=out_for(20).view(-1), accumulate=acc[20])
 
         tot = pr.total
         ops.gemm(du, c2a_w, dv, accum=True, m_dev=tot)

@@ -326,11 +326,11 @@ def test_attention_step_fwd_bwd_equals_softmax_mask_renorm():
     close(ctx_h[:, :R], ctx, atol=1e-5); close(al[:, :n_max], wgt, atol=1e-6)
     assert float(al[:, n_max:].abs().max()) == 0
     dah = torch.empty(S, A, device=DEV); du = torch.ones(rows, A, device=DEV); dv = torch.ones(rows, R, device=DEV)
-    dwa = torch.zeros(1, A, device=DEV); dba = torch.zeros(1, device=DEV)
+    dwa = torch.zeros(S, A, device=DEV); dba = torch.zeros(S, device=DEV)
     gbuf = torch.zeros(S, 3 * R, device=DEV); gbuf[:, :R] = f(gctx)
     ops.attn_bwd(f(u), f(v), f(ah), f(wa), off.to(DEV), lens.to(DEV), al, gbuf[:, :R], dah, du, dv, dwa, dba, S, A, R)
     close(dah, ah.grad, atol=1e-5); close(du - 1, u.grad, atol=1e-5); close(dv - 1, v.grad, atol=1e-5)
-    close(dwa, wa.grad, atol=1e-4); close(dba, ba.grad, atol=1e-5)
+    close(dwa.sum(0, keepdim=True), wa.grad, atol=1e-4); close(dba.sum().view(1), ba.grad, atol=1e-5)
 
 
 def test_log_softmax_nll_step_active():
