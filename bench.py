@@ -190,13 +190,18 @@ def main():
             "config": {"workload": "Sub_GC_Kar train fwd+bwd (BASELINE.json configs[1]): 128 images/GPU, 36+1 nodes, 64+1 relations, "
                                    "2048-d region feats, 5 sentences/image, 2 pos + 2 neg sub-graphs/sentence, T=17, V+1=9488, dropout on",
                        "images_per_gpu": a.batch, "global_images": imgs, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "decoder": "packed (length-sorted, loss-only: masked-out steps skipped; identical loss and gradients)",
                        "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                          "traffic": None, "launches_per_step": n_launch // max(a.steps, 1),
                          "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
                          "gemm_ms_per_step": round(gemm_ms / a.steps, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
-                         "whole_step_frac": round(MODEL_GFLOP_PER_IMAGE * a.batch / (ms_per_step * 1e-3) / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
+                         # whole step (all kernels + gaps) against the MFMA peak: with the GEMM FLOPs actually executed, and with
+                         # the reference's nominal live-graph FLOPs (22.0 GFLOP/image; includes the masked-out decoder
+                         # steps that the packed loss-only path never computes)
+                         "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "whole_step_frac_nominal": round(MODEL_GFLOP_PER_IMAGE * a.batch / (ms_per_step * 1e-3) / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
             "final_loss": round(final_loss, 4),
         }
         if world == 1 and not a.packed_only:
