@@ -1,0 +1,102 @@
+"""Two ranks on the one MI355X of the test box (both on cuda:0; `gloo` carries the CUDA tensors because RCCL
+refuses two ranks on one device): the REAL model runs LossWrapper fwd+bwd on its image shard through the HIP
+path, DecoderFn's backward fires the reducer callback from the autograd thread, the flat bucket is reduced in
+two slices, and both ranks must end with the mean of the per-shard gradients computed in a single process."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+OPT = dict(caption_model="topdown", vocab_size=200, input_encoding_size=64, rnn_size=64, num_layers=1, drop_prob_lm=0.0,
+           max_length=20, seq_length=16, fc_feat_size=48, att_feat_size=128, att_hid_size=32, use_bn=0, sampling_prob=0.0,
+           use_gpn=1, embed_dim=20, gcn_dim=64, noun_fuse=1, pred_emb_type=1, gcn_layers=2, gcn_residual=2, gcn_bn=0,
+           gpn_drop_prob=0.0, obj_name_path=None, rel_name_path=None, sg_obj_cnt=40, sg_pred_cnt=21)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup_paths():
+    for p in (os.path.join(ROOT, "sub-gc_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _model_and_batch():
+    import argparse
+    from subgc import synthetic
+    import subgc.models as models
+    torch.manual_seed(3)
+    m = models.setup(argparse.Namespace(**OPT))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "gcn_collect" in n and "weight" in n:
+                p.mul_(30.0)
+    batch = synthetic.make_train_batch(4, D=128, vocab=200, n_obj_cls=40, seed=11, fc_size=128)
+    return m.to("cuda:0").train(), batch, models
+
+
+def _shard_step(m, models, shard, reducer=None):
+    lw = models.LossWrapper(m, None)
+    b = {k: v.to("cuda:0") for k, v in shard.items()}
+    (reducer.prepare() if reducer is not None else m.flatten_grads())
+    out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
+             None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+    (out["lang_loss"] + out["gpn_loss"]).backward()
+    if reducer is not None:
+        launched_early = reducer._decoder_launched and len(reducer._pending) == 1
+        flat = reducer.finish()
+        torch.cuda.synchronize()
+        return flat.clone(), launched_early
+    torch.cuda.synchronize()
+    return m.flat_grads.clone(), False
+
+
+def _worker(rank, world, port, q):
+    _setup_paths()
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from subgc import parallel
+    torch.cuda.set_device(0)
+    parallel.init_distributed("gloo")
+    m, batch, models = _model_and_batch()
+    red = parallel.GradBucketReducer(m)
+    flat, early = _shard_step(m, models, parallel.shard_batch(batch, rank, world), red)
+    red.close()
+    q.put((rank, flat.cpu().numpy(), early))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_bucket_reduction_matches_mean_of_shards():
+    _setup_paths()
+    from subgc import parallel
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    m, batch, models = _model_and_batch()
+    shard_grads = [_shard_step(m, models, parallel.shard_batch(batch, r, world))[0].cpu().numpy() for r in range(world)]
+    want = 0.5 * (shard_grads[0] + shard_grads[1])
+    scale = float(np.abs(want).max())
+    for rank, flat, early in res:
+        assert early, "decoder slice must be in flight before the encoder backward ends"
+        np.testing.assert_allclose(flat, want, atol=3e-5 * scale + 1e-8, rtol=1e-4)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
