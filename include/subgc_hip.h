@@ -278,6 +278,13 @@ int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int k, float 
                       int t, int64_t* seq, float* seqlp, int T, int64_t* next_tok, int32_t* unfinished,
                       int32_t* n_unfinished, const int32_t* prev_count, int raw_logits, void* stream);
 
+/* Beam search (CaptionModel.py:60 `torch.sort(logprobsf, 1, True)`, of which beam_step :62-72 reads only the
+ * leading `beam` columns): vals[r, :k], idx[r, :k] = the k largest entries of row r of x[rows, cols] in
+ * (value descending, index ascending) order.  log_softmax != 0: x holds raw logits and vals are
+ * x - logsumexp(x) (AttModel.py:340 folded in).  k <= 32, cols <= 16384.                          */
+int subgc_row_topk_f32(const float* x, int64_t ld, int rows, int cols, int k, int log_softmax, float* vals,
+                       int32_t* idx, void* stream);
+
 /* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 

@@ -397,6 +397,121 @@ class Oracle:
         return out + (torch.stack(atts, 1),) if return_att else out
 
 
+    def sample_beam(self, fc_feats, att_feats, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
+                    pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None,
+                    opt=None, nms_sort_kind=None):
+        """AttModel._sample_sentences (AttModel.py:179-234): one beam search per kept sub-graph.
+        Returns (seq, seqLogprobs, score, keep, done_beams)."""
+        P, cfg = self.P, self.cfg
+        opt = opt or {}
+        beam = opt.get("beam_size", 10)
+        cfg.sample_mode = True
+        with torch.no_grad():
+            _, score, att, fc, m, keep = _encode(P, cfg, (fc_feats, att_feats, att_masks, obj_dist, rel_ind, pred_dist,
+                                                           gpn_obj_ind, gpn_pool_mtx), self.buffers, False, None, None, nms_sort_kind)
+            f, v, u, mk = prepare_feature(P, cfg, fc, att, m, False)
+            n, T = fc.size(0), cfg.seq_length
+            seq = torch.zeros(n, T, dtype=torch.long); lps = fc.new_zeros(n, T)
+            done = []
+            for k in range(n):
+                fk, vk, uk = f[k:k + 1].expand(beam, -1), v[k:k + 1].expand(beam, -1, -1), u[k:k + 1].expand(beam, -1, -1)
+                mkk = mk[k:k + 1].expand(beam, -1) if mk is not None else None
+
+                def step(it, state, fk=fk, vk=vk, uk=uk, mkk=mkk):
+                    r0, r1 = state["rows"]
+                    h, c = state["s"]
+                    logp, (hh, cc), _ = core_step(P, cfg, it, fk[r0:r1], vk[r0:r1], uk[r0:r1], None if mkk is None else mkk[r0:r1],
+                                                  ((h[0], h[1]), (c[0], c[1])), False)
+                    return logp, {"s": (torch.stack(hh), torch.stack(cc)), "rows": (r0, r1)}
+                z = fc.new_zeros(2, beam, cfg.R)
+                logp0, st0 = step(torch.zeros(beam, dtype=torch.long), {"s": (z, z.clone()), "rows": (0, beam)})
+                beams = beam_search(step, st0, logp0, T, opt)
+                done.append(beams)
+                seq[k], lps[k] = beams[0]["seq"], beams[0]["logps"]
+        return seq, lps, score, keep, done
+
+
+def length_penalty_fn(cfg):
+    """misc/utils.py:145-171 (`''` -> identity, `wu_a` -> GNMT length normalisation, `avg_a` -> mean)."""
+    if cfg == "":
+        return lambda length, lp: lp
+    kind, alpha = cfg.split("_")
+    alpha = float(alpha)
+    return {"wu": lambda length, lp: lp / (((5 + length) ** alpha) / ((5 + 1) ** alpha)),
+            "avg": lambda length, lp: lp / length}[kind]
+
+
+def beam_search(step, init_state, init_logprobs, T, opt):
+    """CaptionModel.beam_search (CaptionModel.py:28-176), restated for one sub-graph.
+
+    `step(it, state) -> (logprobs, state)` is get_logprobs_state for the rows of one group; a state is
+    {"s": (h[2, rows, R], c[2, rows, R]), "rows": (first, last)}.  Every group g runs its own classical
+    beam search `g` steps behind group 0; before a group sorts, the words the earlier groups hold at the
+    same position are pushed down by diversity_lambda once per holder (:33-40); the UNK column is pushed
+    down by 1000 (:137) and, with decoding_constraint, the previous word is removed (:134-135)."""
+    beam = opt.get("beam_size", 10)
+    G = opt.get("group_size", 1)
+    lam = opt.get("diversity_lambda", 0.5)
+    constraint = opt.get("decoding_constraint", 0)
+    penalty = length_penalty_fn(opt.get("length_penalty", ""))
+    bd = beam // G
+    seqs = [torch.zeros(T, bd, dtype=torch.long) for _ in range(G)]
+    lpss = [torch.zeros(T, bd) for _ in range(G)]
+    sums = [torch.zeros(bd) for _ in range(G)]
+    finished = [[] for _ in range(G)]
+    h0, c0 = init_state["s"]
+    states = [{"s": (h0[:, g * bd:(g + 1) * bd].clone(), c0[:, g * bd:(g + 1) * bd].clone()), "rows": (g * bd, (g + 1) * bd)}
+              for g in range(G)]
+    logps = [init_logprobs[g * bd:(g + 1) * bd].clone().float() for g in range(G)]
+    for t in range(T + G - 1):
+        for g in range(G):
+            tau = t - g
+            if tau < 0 or tau > T - 1:
+                continue
+            lp = logps[g]
+            if constraint and tau > 0:
+                lp.scatter_(1, seqs[g][tau - 1].unsqueeze(1), float("-inf"))
+            lp[:, -1] = lp[:, -1] - 1000
+            raw = lp.clone()
+            for pg in range(g):
+                held = seqs[pg][tau]
+                for b in range(bd):
+                    for j in range(bd):
+                        lp[b][held[j]] = lp[b][held[j]] - lam
+            # ---- one classical step (:44-94)
+            ys, ix = torch.sort(lp, 1, True)
+            cand = []
+            for c in range(min(bd, ys.size(1))):
+                for q in range(1 if tau == 0 else bd):
+                    cand.append(dict(c=ix[q, c], q=q, p=sums[g][q] + ys[q, c].item(), r=raw[q, ix[q, c]]))
+            cand = sorted(cand, key=lambda x: -x["p"])
+            h, c_ = states[g]["s"]
+            nh, nc = h.clone(), c_.clone()
+            old_seq, old_lps = seqs[g][:tau].clone(), lpss[g][:tau].clone()
+            for vix in range(bd):
+                v = cand[vix]
+                if tau >= 1:
+                    seqs[g][:tau, vix] = old_seq[:, v["q"]]
+                    lpss[g][:tau, vix] = old_lps[:, v["q"]]
+                nh[:, vix] = h[:, v["q"]]
+                nc[:, vix] = c_[:, v["q"]]
+                seqs[g][tau, vix] = v["c"]
+                lpss[g][tau, vix] = v["r"]
+                sums[g][vix] = v["p"]
+            for vix in range(bd):
+                if seqs[g][tau, vix] == 0 or tau == T - 1:
+                    fin = dict(seq=seqs[g][:, vix].clone(), logps=lpss[g][:, vix].clone(), unaug_p=lpss[g][:, vix].sum().item(),
+                               p=penalty(tau + 1, sums[g][vix].item()))
+                    finished[g].append(fin)
+                    sums[g][vix] = -1000
+            logps[g], states[g] = step(seqs[g][tau], {"s": (nh, nc), "rows": states[g]["rows"]})
+            logps[g] = logps[g].float()
+    out = []
+    for g in range(G):
+        out += sorted(finished[g], key=lambda x: -x["p"])[:bd]
+    return out
+
+
 def lm_criterion(outputs, target, mask):
     """misc/utils.py:115-124."""
     target = target[:, :outputs.size(1)]; mask = mask[:, :outputs.size(1)]

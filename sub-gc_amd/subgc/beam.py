@@ -1,0 +1,163 @@
+"""Beam search / diverse beam search on the HIP decode path.
+
+Reference: CaptionModel.beam_search (models/CaptionModel.py:28-176) driven per sub-graph by
+AttModel._sample_sentences (models/AttModel.py:179-234).  The reference walks the sub-graphs one by
+one, sorts a [beam, V+1] matrix on the CPU-visible side every step and forks Python lists of states.
+
+Here every sub-graph and every beam of one image is a row of ONE decode batch (rows = n_subgraphs x beam):
+the attention rows of a sub-graph are shared by its beams through the (offset, length) table, a step is
+the same kernel sequence as greedy decode, `subgc_row_topk_f32` hands back the leading beam+2 log-probs of
+every row, the candidate bookkeeping (tiny: beam^2 numbers per sub-graph) runs on the host in the
+reference's exact order and arithmetic (fp32 sums, stable sort over the column-major candidate list), and
+the fork "beam q -> slot vix" is one row gather of the recurrent state.
+
+Why beam+2 columns are enough: a group's augmented row differs from the raw one only at the UNK column
+(-1000, CaptionModel.py:137), at the previous word (decoding_constraint, :134-135) and at the <= beam-bdash
+distinct words the earlier groups picked (:33-40), all of which only move DOWN; the top bdash of the
+augmented row therefore lie within the top (bdash + those) <= beam+2 of the raw row.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import functions as F_
+from . import ops
+
+_F32 = np.float32
+
+
+def penalty_builder(cfg):
+    """misc/utils.py:145-171."""
+    if cfg == "":
+        return lambda length, logprob: logprob
+    kind, alpha = cfg.split("_")
+    alpha = float(alpha)
+    if kind == "wu":
+        return lambda length, logprob: logprob / (((5 + length) ** alpha) / ((5 + 1) ** alpha))
+    if kind == "avg":
+        return lambda length, logprob: logprob / length
+    raise ValueError(f"unknown length_penalty {cfg!r} (expected '', 'wu_<alpha>' or 'avg_<alpha>')")
+
+
+class _Group:
+    """One beam group of one sub-graph: the tables of CaptionModel.py:106-108."""
+    __slots__ = ("seq", "lps", "sums", "done")
+
+    def __init__(self, T, bd):
+        self.seq = np.zeros((T, bd), np.int64)
+        self.lps = np.zeros((T, bd), _F32)
+        self.sums = np.zeros(bd, _F32)
+        self.done = []
+
+
+def _beam_step(grp, vals, idx, tau, bd, unk, constraint, earlier, lam):
+    """CaptionModel.py:44-94 on the leading columns.  vals/idx: [bd, kk] raw log-probs (descending) and
+    their word ids.  Returns the source beam of every new slot."""
+    vals = vals.copy()
+    if constraint and tau > 0:                                                   # :134-135
+        vals[idx == grp.seq[tau - 1][:, None]] = -np.inf
+    vals[idx == unk] -= _F32(1000)                                               # :137
+    unaug = vals.copy()
+    for prev in earlier:                                                         # add_diversity, :33-40
+        for tok in prev.seq[tau]:
+            vals[idx == tok] -= lam
+    order = np.argsort(-vals, axis=1, kind="stable")
+    rows = 1 if tau == 0 else bd
+    cols = min(bd, vals.shape[1])
+    cands = []
+    for c in range(cols):
+        for q in range(rows):
+            j = order[q, c]
+            cands.append((_F32(grp.sums[q] + vals[q, j]), q, int(idx[q, j]), unaug[q, j]))
+    cands.sort(key=lambda x: -x[0])                                              # stable, like sorted() at :73
+    prev_seq, prev_lps = grp.seq[:tau].copy(), grp.lps[:tau].copy()
+    src = []
+    for vix in range(bd):
+        p, q, tok, r = cands[vix]
+        grp.seq[:tau, vix] = prev_seq[:, q]
+        grp.lps[:tau, vix] = prev_lps[:, q]
+        grp.seq[tau, vix] = tok
+        grp.lps[tau, vix] = r
+        grp.sums[vix] = p
+        src.append(q)
+    return src
+
+
+@torch.no_grad()
+def beam_decode(pr, P, N, T, opt):
+    """Decode every sub-graph of `pr` (an F_.Prepared) with beam search.
+    Returns (seq [n, T] int64, seqLogprobs [n, T] fp32, done_beams) -- CPU tensors, as the reference's are."""
+    beam = int(opt.get("beam_size", 10))
+    G = int(opt.get("group_size", 1))
+    lam = opt.get("diversity_lambda", 0.5)
+    constraint = opt.get("decoding_constraint", 0)
+    length_penalty = penalty_builder(opt.get("length_penalty", ""))
+    if G < 1 or beam % G:
+        raise ValueError(f"beam_size {beam} must be a multiple of group_size {G}")
+    lam = _F32(lam)
+    bd = beam // G
+    n, dev = pr.S, pr.f.device
+    rows = n * beam
+    rep = torch.arange(n, device=dev).repeat_interleave(beam)
+    prb = SimpleNamespace(S=rows, N=N, f=pr.f.index_select(0, rep).contiguous(), u=pr.u, v=pr.v,
+                          off=pr.off.index_select(0, rep).contiguous(), lens=pr.lens.index_select(0, rep).contiguous())
+    st = F_.DecodeState(prb, P, N, False)
+    V1 = st.V1
+    unk = V1 - 1
+    kk = min(V1, beam + 2)
+    if bd > kk:
+        raise ValueError("beam wider than the vocabulary")
+    vals_d = torch.empty(rows, kk, device=dev, dtype=torch.float32)
+    idx_d = torch.empty(rows, kk, device=dev, dtype=torch.int32)
+    it = torch.zeros(rows, device=dev, dtype=torch.long)
+
+    def advance(tokens):
+        ops.row_topk(st.step(tokens, None, normalize=False), kk, vals_d, idx_d, log_softmax=True)
+        return vals_d.cpu().numpy().reshape(n, G, bd, kk), idx_d.cpu().numpy().reshape(n, G, bd, kk)
+
+    tv, ti = advance(it)                                                         # <bos>, AttModel.py:223-227
+    tv, ti = tv.copy(), ti.copy()
+    init = [x.clone() for x in st.recurrent()] if G > 1 else None
+    groups = [[_Group(T, bd) for _ in range(G)] for _ in range(n)]
+    base = np.arange(rows, dtype=np.int32).reshape(n, G, bd)
+    for t in range(T + G - 1):
+        live = [g for g in range(G) if g <= t <= T + g - 1]
+        src = base.copy()
+        tok = np.zeros((n, G, bd), np.int64)
+        for g in live:
+            tau = t - g
+            for s in range(n):
+                grp = groups[s][g]
+                q = _beam_step(grp, tv[s, g], ti[s, g], tau, bd, unk, constraint, groups[s][:g], lam)
+                src[s, g] = base[s, g][q]
+                for vix in range(bd):                                            # :150-166
+                    if grp.seq[tau, vix] == 0 or t == T + g - 1:
+                        final = {"seq": grp.seq[:, vix].copy(), "logps": grp.lps[:, vix].copy(),
+                                 "unaug_p": float(grp.lps[:, vix].sum(dtype=_F32)), "p": float(grp.sums[vix])}
+                        final["p"] = length_penalty(tau + 1, final["p"])
+                        grp.done.append(final)
+                        grp.sums[vix] = -1000
+                tok[s, g] = grp.seq[tau]
+        if not any(g <= t + 1 <= T + g - 1 for g in range(G)):
+            break                                                                # the reference's last step (:170-171) feeds nothing
+        if G > 1 and 0 < t < G:                                                  # group t starts now: give it the post-<bos> state
+            sel = torch.from_numpy(base[:, t].reshape(-1).astype(np.int64)).to(dev)
+            for cur, saved in zip(st.recurrent(), init):
+                cur[sel] = saved[sel]
+        st.reorder(torch.from_numpy(src.reshape(-1)).to(dev))
+        nv, ni = advance(torch.from_numpy(tok.reshape(-1)).to(dev))
+        for g in live:
+            tv[:, g], ti[:, g] = nv[:, g], ni[:, g]
+    seq = torch.zeros(n, T, dtype=torch.long)
+    seqlp = torch.zeros(n, T, dtype=torch.float32)
+    done_beams = []
+    for s in range(n):
+        beams = []
+        for g in range(G):
+            beams += sorted(groups[s][g].done, key=lambda x: -x["p"])[:bd]       # :174-175
+        for b in beams:
+            b["seq"], b["logps"] = torch.from_numpy(b["seq"]), torch.from_numpy(b["logps"])
+        done_beams.append(beams)
+        seq[s], seqlp[s] = beams[0]["seq"], beams[0]["logps"]
+    return seq, seqlp, done_beams

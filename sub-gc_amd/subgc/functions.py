@@ -466,6 +466,26 @@ class DecodeState:
         self.xt, self.Gx, self.pre, self.ah = new(S, E), new(S, 4 * R), new(S, 4 * R), new(S, self.A)
         self.hout, self.logits = new(S, R), new(S, self.V1)
         self.want_att = want_att
+        self._alt = None
+
+    # -- beam search support (CaptionModel.py:76-90 "rearrange recurrent states") -------------------
+    def recurrent(self):
+        """The tensors that carry state between steps: [h2|h1], the h2 slot of the lang-LSTM operand, c1, c2."""
+        R = self.R
+        return [self.H1, self.H2[:, 2 * R:], self.C1[0], self.C2[0]]
+
+    def reorder(self, src):
+        """state[row] <- state[src[row]] for every row (src: int32 [S] on the device)."""
+        if self._alt is None:
+            self._alt = [torch.empty_like(self.H1), torch.empty_like(self.H2), torch.empty_like(self.C1[0]), torch.empty_like(self.C2[0])]
+        a1, a2, ac1, ac2 = self._alt
+        R = self.R
+        ops.gather_rows(self.H1, src, a1)
+        ops.gather_rows(self.H2[:, 2 * R:], src, a2[:, 2 * R:])
+        ops.gather_rows(self.C1[0], src, ac1)
+        ops.gather_rows(self.C2[0], src, ac2)
+        self._alt = [self.H1, self.H2, self.C1[0], self.C2[0]]
+        self.H1, self.H2, self.C1[0], self.C2[0] = a1, a2, ac1, ac2
 
     def step(self, it, alpha_out, normalize=True):
         S, R, A = self.S, self.R, self.A

@@ -33,6 +33,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import beam
 from .. import functions as F_
 from .. import ops
 from .CaptionModel import CaptionModel
@@ -399,7 +400,11 @@ class AttModel(CaptionModel):
 
     # ------------------------------------------------------------------ decode
     def _sample_sentences(self, *args, **kwargs):
-        raise NotImplementedError("beam_size > 1 (reference AttModel.py:179-234) is not built on the HIP path yet")
+        """Beam search (reference AttModel.py:179-234): same entry as `_sample`, which routes here on beam_size > 1."""
+        opt = dict(kwargs.pop("opt", {}))
+        if opt.get("beam_size", 10) <= 1:
+            raise ValueError("_sample_sentences needs beam_size > 1")
+        return self._sample(*args, opt=opt, **kwargs)
 
     @torch.no_grad()
     def _sample(self, fc_feats, att_feats, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
@@ -408,8 +413,7 @@ class AttModel(CaptionModel):
         """Greedy / top-k decode of one image (AttModel.py:236-326).  `uniforms[n, T]` (optional)
         supplies the top-k sampler's random numbers; `forced[n, T]` makes the loop follow a given
         token path (both exist so tests can pin the sampler)."""
-        if opt.get("beam_size", 1) > 1:
-            return self._sample_sentences()
+        beam_size = opt.get("beam_size", 1)
         return_att = opt.get("return_att", 0) == 1
         B, N, _ = att_feats.shape
         dev = att_feats.device
@@ -466,6 +470,9 @@ class AttModel(CaptionModel):
             return (seq, seqlp, score, keep) + ((torch.zeros(0, 0, 0, device=dev),) if return_att else ())
         P = self._decoder_params()
         pr = F_.Prepared(fc, X2, lens_k, idx_k, torch.zeros(n, device=dev, dtype=torch.int32), N, P, None, None, 1.0)
+        if beam_size > 1:                                                                 # AttModel.py:245-246 -> :179-234
+            seq, seqlp, self.done_beams = beam.beam_decode(pr, P, N, T, opt)
+            return seq, seqlp, score, keep
         st = F_.DecodeState(pr, P, N, return_att)
         it = torch.zeros(n, device=dev, dtype=torch.long)
         unfinished = torch.zeros(n, device=dev, dtype=torch.int32)

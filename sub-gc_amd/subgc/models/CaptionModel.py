@@ -2,8 +2,8 @@
 
 Mirrors reference `models/CaptionModel.py:21-26`: `model(*args, mode='sample', **kw)` calls
 `self._sample(*args, **kw)`, the default mode is `'forward'` (-> `self._forward`).  The diverse
-beam search of `CaptionModel.py:28-175` is a "next" row of SURVEY.md section 8(f) and is not
-built yet: asking for it fails loudly instead of silently decoding greedily.
+beam search of `CaptionModel.py:28-175` lives in `subgc/beam.py` (all sub-graphs and beams of an image in
+one decode batch) and is reached through `mode='sample'` with `opt['beam_size'] > 1`, as in the reference.
 """
 from __future__ import annotations
 
@@ -20,5 +20,5 @@ class CaptionModel(nn.Module):
 
     def beam_search(self, init_state, init_logprobs, *args, **kwargs):
         raise NotImplementedError(
-            "beam search (reference CaptionModel.py:28-175) is not part of the round-1 HIP path; "
-            "decode with beam_size=1 (greedy / top-k sampling)")
+            "CaptionModel.beam_search(state, logprobs, ...) takes the reference's Python-side LSTM states; the HIP path keeps "
+            "them on the device -- call model(..., opt={'beam_size': b}, mode='sample') (subgc/beam.py) instead")

@@ -285,6 +285,12 @@ def decode_pick(logp, k, temp, u, t, seq, seqlp, next_tok, unfinished, n_unf, pr
          seq.size(1), _ptr(next_tok, torch.int64), _ptr(unfinished, torch.int32), _ptr(n_unf, torch.int32), _ptr(prev_count, torch.int32), int(raw), _stream())
 
 
+def row_topk(x, k, vals, idx, log_softmax=True):
+    """vals/idx[r, :k] = the k largest of row r (value desc, index asc); raw logits -> log-probs when log_softmax."""
+    call("subgc_row_topk_f32", _ptr(x), ld(x), x.size(0), x.size(1), int(k), int(log_softmax), _ptr(vals), _ptr(idx, torch.int32), _stream())
+    return vals, idx
+
+
 def dropout_mask(shape, p, seed, offset, device):
     keep = torch.empty(shape, device=device, dtype=torch.uint8)
     call("subgc_dropout_mask", _ptr(keep), keep.numel(), float(p), int(seed), int(offset), _stream())

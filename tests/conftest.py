@@ -34,7 +34,7 @@ class Golden:
     def __init__(self, name):
         self.name = name
         with open(os.path.join(GOLDEN, "meta.json")) as f:
-            self.meta = json.load(f)[name]
+            self.meta = json.load(f).get(name, {})          # weight-only groups (e.g. subgc_beam) have no meta entry
 
     def group(self, g):
         path = os.path.join(GOLDEN, f"{self.name}_{g}.npz")

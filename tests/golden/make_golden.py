@@ -134,7 +134,7 @@ class Tap:
         for h in self.hooks:
             h.remove()
         for k, v in self.steps.items():
-            if v:
+            if v and len({x.shape for x in v}) == 1:            # diverse beam search steps groups of different widths
                 self.rec["step_" + k] = np.stack(v, 0)
         return self.rec
 
@@ -185,6 +185,10 @@ def run_sample(name, opt, weights, seed, M, sample_opt, meta, node_pool=None, ke
         ret = model(*args, opt=dict(sample_opt), mode="sample")
     rec = tap.done()
     rec.update(seq=np_(ret[0]), seqLogprobs=np_(ret[1]), subgraph_score=np_(ret[2]), keep_ind=np_(ret[3]))
+    if sample_opt.get("beam_size", 1) > 1:                      # every finished beam the reference keeps (AttModel.py:229)
+        rec["done_seq"] = np.stack([np.stack([np_(b["seq"]) for b in beams]) for beams in model.done_beams])
+        rec["done_logps"] = np.stack([np.stack([np_(b["logps"]) for b in beams]) for beams in model.done_beams])
+        rec["done_p"] = np.array([[float(b["p"]) for b in beams] for beams in model.done_beams], np.float64)
     if len(ret) > 4:
         rec["att2_weights"] = np_(ret[4])
     if keys is not None:
@@ -194,10 +198,46 @@ def run_sample(name, opt, weights, seed, M, sample_opt, meta, node_pool=None, ke
     save(name, inputs={k: v.numpy() for k, v in batch.items()}, out=rec)
 
 
+BEAM_KEYS = ("seq", "seqLogprobs", "subgraph_score", "keep_ind", "done_seq", "done_logps", "done_p")
+
+
+def beam_cases(w, meta):
+    """Beam search (CaptionModel.py:28-176).  The reference moves the chosen words with `.cuda()` (:135,171);
+    on this CPU-only box that call is made the identity for the duration of the run."""
+    t = dict(test_LSTM=1, gpn_nms_thres=0.75, gpn_max_subg=10)
+    w = {k: v.copy() for k, v in w.items()}
+    w["logit.weight"][0] *= 6.0                                  # a state-dependent <eos>: beams end at 0, 1, 3, 7, ... 20 words
+    w["logit.bias"][0] -= 1.0
+    save("subgc_beam", weights=w)
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        run_sample("subgc_beam3", ref_opt(**t), w, seed=12, M=16, sample_opt=dict(sample_max=1, beam_size=3), meta=meta, node_pool=14,
+                   keys=BEAM_KEYS)
+        run_sample("subgc_beam2_wu", ref_opt(**t), w, seed=13, M=10, sample_opt=dict(sample_max=1, beam_size=2, length_penalty="wu_0.7"),
+                   meta=meta, node_pool=12, keys=BEAM_KEYS)
+        run_sample("subgc_beam4_div", ref_opt(**t), w, seed=14, M=12,
+                   sample_opt=dict(sample_max=1, beam_size=4, group_size=2, diversity_lambda=0.5, decoding_constraint=1,
+                                   length_penalty="avg_1.0"), meta=meta, node_pool=12, keys=BEAM_KEYS)
+        run_sample("subgc_beam6_div3", ref_opt(**t), w, seed=15, M=8,
+                   sample_opt=dict(sample_max=1, beam_size=6, group_size=3, diversity_lambda=0.3), meta=meta, node_pool=12, keys=BEAM_KEYS)
+    finally:
+        torch.Tensor.cuda = orig
+
+
 def main():
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     enter_scratch()
     torch.set_num_threads(1)
+    if "--only-beam" in sys.argv:                               # add the beam cases without rewriting the others
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        with np.load(os.path.join(HERE, "subgc_train_weights.npz")) as z:
+            w = {k: z[k] for k in z.files}
+        beam_cases(w, meta)
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        return
     meta = dict(torch=torch.__version__, numpy=np.__version__, reference="YiwuZhong/Sub-GC @ v1",
                 tolerances=dict(fp32_atol=1e-4, fp32_rtol=1e-4, indices="exact"))
     # 1. Sub-GC: train (grads), then decode with the same weights
@@ -216,6 +256,8 @@ def main():
     fo = dict(use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1)
     _, wf = run_train("fullgc_train", ref_opt(**fo), seed=7, B=3, gcn_scale=50.0, meta=meta)
     run_sample("fullgc_greedy", ref_opt(**fo), wf, seed=8, M=2, sample_opt=dict(sample_max=1, beam_size=1), meta=meta)
+    # 4. beam search / diverse beam search
+    beam_cases(w, meta)
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True, default=str)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

@@ -52,5 +52,7 @@ def test_model_api_surface(golden):
         assert base <= p.data_ptr() < base + m.flat_params.numel() * 4, n
     with pytest.raises(Exception, match="Caption model not supported"):
         models.setup(argparse.Namespace(caption_model="show_tell"))
-    with pytest.raises(NotImplementedError):
-        m(mode="sample_sentences")
+    with pytest.raises(ValueError):                             # beam search proper is entered through mode="sample"
+        m(None, None, opt={"beam_size": 1}, mode="sample_sentences")
+    with pytest.raises(NotImplementedError):                    # the state-passing helper is not a public entry here
+        m.beam_search(None, None)

@@ -452,3 +452,22 @@ def test_gemm_skinny_weight_streaming_form(M, N, K):
     close(out, torch.relu(a.double() @ w.double().t() + bias.double()).float(), atol=2e-4 * K ** 0.5, rtol=1e-4)
     ops.gemm(a, w, out, tb=True)
     close(out, (a.double() @ w.double().t()).float(), atol=2e-4 * K ** 0.5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("rows,cols,k", [(1, 50, 5), (7, 9488, 12), (33, 1000, 32), (4, 16384, 3), (5, 300, 8)])
+def test_row_topk_matches_sorted_log_softmax(rows, cols, k):
+    """subgc_row_topk_f32 == the leading k columns of torch.sort(log_softmax(x), descending) (CaptionModel.py:60);
+    ties resolve to the smaller index; a strided (ld > cols) input is honoured."""
+    torch.manual_seed(rows * 131 + cols)
+    buf = torch.randn(rows, cols + 3, device=DEV) * 3
+    x = buf[:, :cols]
+    x[:, 5] = x[:, 2]                                            # exact ties
+    vals = torch.empty(rows, k, device=DEV)
+    idx = torch.empty(rows, k, device=DEV, dtype=torch.int32)
+    ops.row_topk(x, k, vals, idx, log_softmax=True)
+    lp = torch.log_softmax(x.double(), 1)
+    order = torch.argsort(-lp, dim=1, stable=True)[:, :k]
+    np.testing.assert_array_equal(idx.cpu().numpy(), order.cpu().numpy())
+    np.testing.assert_allclose(vals.cpu().numpy(), lp.gather(1, order).float().cpu().numpy(), atol=2e-6, rtol=1e-6)
+    ops.row_topk(x, k, vals, idx, log_softmax=False)
+    np.testing.assert_array_equal(vals.cpu().numpy(), x.gather(1, order).cpu().numpy())

@@ -230,3 +230,15 @@ def test_size_independent_properties_at_bench_size():
     for k in ("sg_pred_embed.weight", "gcn_backbone.gcn.0.gcn_collect.collect_units.0.fc_lft.weight"):
         assert float(m.P(k).grad.abs().max()) == 0.0
     assert float(m.P("logit.weight").grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("name", ["subgc_beam3", "subgc_beam2_wu", "subgc_beam4_div", "subgc_beam6_div3"])
+def test_beam_search_identical_to_reference(golden, name):
+    """beam_size > 1 (AttModel.py:179-234 + CaptionModel.py:28-176): every kept beam of every sub-graph, not only the best."""
+    from test_beam_oracle import check_beams
+    g = golden(name)
+    m = build(g, golden("subgc_beam").group("weights"), False)
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    ret = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample")
+    check_beams(ret, m.done_beams, g.group("out"), atol=1e-4)
+    close(ret[2], g.group("out")["subgraph_score"], "score", atol=1e-5)
