@@ -1,0 +1,109 @@
+"""Parity at the OTHER BASELINE.json shapes (they are parity cases, not bench lines): the Flickr stress shape
+(config 5: N=101 nodes, K=301 relations, D=4096, L=2048, V+1=7001, sub-graphs of up to 30 nodes) and the
+Full_GC_Kar architecture at full width (config 3: 4 GCN layers with BatchNorm, residual every layer, no sGPN,
+attention over all 36 nodes).  Both run in fp32 -- the path's arithmetic type -- against the CPU oracle on the
+same seeded inputs.  Tolerances as in test_parity_gpu.py; tokens / kept sub-graphs / attention arg-max exact."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import subgc_oracle as O
+from subgc import synthetic
+import subgc.models as models
+from test_parity_gpu import DEV, KAR, _sharpen, close, run_train
+
+pytestmark = pytest.mark.gpu
+
+FLICKR = dict(KAR, vocab_size=7000, fc_feat_size=4096, att_feat_size=4096, gcn_dim=2048)
+FLICKR_DATA = dict(N=101, K=301, D=4096, n_edges=300, max_nodes=30)
+FULLGC = dict(KAR, use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1)
+
+
+def grads_close(m, orc, keys):
+    for k in keys:
+        g = orc.P[k].grad
+        close(m.P(k).grad, g, "grad " + k, atol=2e-5 + 2e-3 * float(g.abs().max()), rtol=5e-3)
+
+
+@pytest.mark.timeout(900)
+def test_flickr_stress_shape_train_and_decode_match_oracle():
+    torch.manual_seed(5)
+    opt = argparse.Namespace(**FLICKR)
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(2, vocab=7000, seed=6, **FLICKR_DATA)
+    out, loss = run_train(m, batch)
+    orc = O.Oracle(opt, sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss")
+    outputs, _, score = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+    assert tuple(outputs.shape) == (10, 17, 7001)
+    close(outputs, ref["outputs"], "outputs", atol=2e-4, rtol=1e-4)
+    close(score, ref["subgraph_score"], "score", atol=1e-5)
+    grads_close(m, orc, ("logit.weight", "core.att_lstm.weight_ih", "embed.0.weight", "obj_v_proj.weight", "obj_emb_proj.weight",
+                         "gcn_backbone.gcn.0.gcn_collect.collect_units.3.fc_rgt.weight",
+                         "gcn_backbone.gcn.1.gcn_collect.collect_units.0.fc_lft.weight", "gpn_layer.gpn_fc.0.weight",
+                         "att_embed.0.weight", "ctx2att.weight", "core.attention.alpha_net.weight"))
+    # decode: sct=1 (every candidate sub-graph, no NMS -- the only sample path the reference itself runs at N != 37) with return_att
+    tb = synthetic.make_test_batch(9, seed=7, **FLICKR_DATA)
+    sopt = dict(sample_max=1, beam_size=1, return_att=1)
+    topt = argparse.Namespace(**dict(FLICKR, test_LSTM=1, sct=1))
+    mt = models.setup(topt); mt.load_state_dict(sd); mt = mt.to(DEV).eval()
+    ret = mt(*synthetic.sample_args({k: v.to(DEV) for k, v in tb.items()}), opt=sopt, mode="sample")
+    want = O.Oracle(topt, sd).sample(*synthetic.sample_args(tb), opt=sopt)
+    assert ret[0].shape[0] == 18
+    np.testing.assert_array_equal(ret[0].cpu().numpy(), want[0].numpy())
+    close(ret[1], want[1], "seqLogprobs", atol=2e-4)
+    close(ret[2], want[2], "score", atol=1e-5)
+    assert tuple(ret[4].shape) == tuple(want[4].shape)
+    close(ret[4], want[4], "att2_weights", atol=1e-5)
+    # NMS generalised from the hard-coded 36 to N-1 (gpn.py:117-118): kept set == the oracle's set arithmetic on the same scores
+    nopt = argparse.Namespace(**dict(FLICKR, test_LSTM=1, gpn_nms_thres=0.4, gpn_max_subg=6))
+    mn = models.setup(nopt); mn.load_state_dict(sd); mn = mn.to(DEV).eval()
+    tb2 = synthetic.make_test_batch(40, seed=8, node_pool=45, **FLICKR_DATA)
+    r2 = mn(*synthetic.sample_args({k: v.to(DEV) for k, v in tb2.items()}), opt=dict(sample_max=1, beam_size=1), mode="sample")
+    w2 = O.Oracle(nopt, sd).sample(*synthetic.sample_args(tb2), opt=dict(sample_max=1, beam_size=1), nms_sort_kind="stable")
+    np.testing.assert_array_equal(r2[3].cpu().numpy(), w2[3].numpy())
+    np.testing.assert_array_equal(r2[0].cpu().numpy(), w2[0].numpy())
+    assert 0 < r2[3].numel() <= 6
+
+
+@pytest.mark.timeout(900)
+def test_full_gc_kar_full_width_train_and_decode_match_oracle():
+    torch.manual_seed(9)
+    opt = argparse.Namespace(**FULLGC)
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(3, seed=10)
+    out, loss = run_train(m, batch)
+    orc = O.Oracle(opt, sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    ref["lang_loss"].backward()
+    assert out["gpn_loss"] is None and ref["gpn_loss"] is None
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    grads_close(m, orc, ("logit.weight", "core.lang_lstm.weight_ih", "obj_v_proj.weight", "read_out_proj.0.weight",
+                         "gcn_backbone.gcn.0.gcn_collect.collect_units.1.fc_lft.weight",
+                         "gcn_backbone.gcn.2.gcn_collect.collect_units.2.fc_rgt.weight",
+                         "gcn_backbone.gcn.1.gcn_collect.collect_units.0.bn.weight", "att_embed.0.weight"))
+    msd = m.state_dict()
+    for k, v in orc.buffers.items():                                                    # BatchNorm running statistics after one step
+        dead = any(f"gcn.3.gcn_collect.collect_units.{u}." in k for u in (2, 3))      # output-irrelevant units are skipped
+        if "running_" in k and k in msd and not dead:
+            close(msd[k], v, k, atol=1e-5, rtol=1e-3)
+    mt = models.setup(opt); mt.load_state_dict(sd); mt = mt.to(DEV).eval()
+    tb = synthetic.make_test_batch(2, seed=11)
+    ret = mt(*synthetic.sample_args({k: v.to(DEV) for k, v in tb.items()}), opt=dict(sample_max=1, beam_size=1, return_att=1), mode="sample")
+    want = O.Oracle(opt, sd).sample(*synthetic.sample_args(tb), opt=dict(sample_max=1, beam_size=1, return_att=1))
+    np.testing.assert_array_equal(ret[0].cpu().numpy(), want[0].numpy())
+    close(ret[1], want[1], "seqLogprobs", atol=2e-4)
+    close(ret[4], want[4], "att2_weights", atol=1e-5)
