@@ -111,6 +111,19 @@ def decode_bench(model_sd, dev, images, M):
             "decode_config": f"greedy, {2 * M} candidate sub-graphs/image -> NMS 0.75 -> <=10 kept x 20 tokens, {images} images looped"}
 
 
+def pmc_traffic(a, world, launches_per_step):
+    """HBM bytes per GEMM launch from the committed PMC passes of THIS command (tools/pmc_traffic.sh -> profiles/): hardware
+    counters cannot be read from inside the timed run, so the figure is only reported when the profiled workload matches."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if world != 1 or a.batch != 128 or not os.path.exists(path):
+        return None, "no PMC profile for this configuration"
+    with open(path) as f:
+        p = json.load(f)
+    if p.get("gemm_launches_per_step") != launches_per_step:
+        return None, f"profiles/r01_pmc_traffic.json was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
+    return round(p["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,11 +188,13 @@ def main():
 
     if rank == 0:
         n_launch, gemm_ms, _nominal = _lib.prof_collect("gemm")
-        ops.FLOPS["on"], ops.FLOPS["gemm"] = True, 0.0          # one untimed accounting step: exact (ragged-aware) GEMM FLOPs
+        ops.FLOPS.update(on=True, gemm=0.0, gemm_bytes=0.0, gemm_calls=0)   # one untimed accounting step: exact (ragged-aware) GEMM FLOPs
         step()
         torch.cuda.synchronize()
         ops.FLOPS["on"] = False
         flops_step = ops.FLOPS["gemm"]
+        alg_bytes_launch = ops.FLOPS["gemm_bytes"] / max(ops.FLOPS["gemm_calls"], 1)
+        traffic, traffic_note = pmc_traffic(a, world, n_launch // max(a.steps, 1))
         achieved = flops_step * a.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         ms_per_step = 1e3 * elapsed / a.steps
         imgs = world * a.batch
@@ -194,7 +209,8 @@ def main():
                        "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                         "traffic": None, "launches_per_step": n_launch // max(a.steps, 1),
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
+                         "algorithmic_bytes_per_launch": round(alg_bytes_launch), "launches_per_step": n_launch // max(a.steps, 1),
                          "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
                          "gemm_ms_per_step": round(gemm_ms / a.steps, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
                          # whole step (all kernels + gaps) against the MFMA peak: with the GEMM FLOPs actually executed, and with

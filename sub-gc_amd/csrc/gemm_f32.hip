@@ -380,11 +380,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     // m_dev bounds the ROWS of the stored A: M when A is [M,K], K when A is stored transposed [K,M]
     const int M = (p.m_dev && !TA) ? min(p.M, *p.m_dev) : p.M;
     const int K = (p.m_dev && TA) ? min(p.K, *p.m_dev) : p.K;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    // The tile sequence is laid over the LIVE rows (device-side count): with a ragged row count the grid is sized
+    // for the allocation, and mapping it over p.M would put every live tile on the first one or two XCDs.
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, live = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= live) return;
     int tm, tn;
-    tile_of(xcd_chunked_id(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    tile_of(xcd_chunked_id(blockIdx.x, live), tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
-    if (m0 >= M) return;
     f32x16 acc[MT][NT];
     zero_acc(acc);
     mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
@@ -408,11 +410,15 @@ __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const GemmArgs p, 
     tile_of(tile, tiles_m, tiles_n, tm, tn);
     (void)tiles;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kt_all = (p.K + BK - 1) / BK;
-    const int kt0 = part * kt_per_split, kt1 = min(kt_all, kt0 + kt_per_split);
+    // a device-side row count bounds K of a transposed-A contraction (weight gradients over the ragged attention rows):
+    // the parts are then cut from the LIVE K range so that they stay balanced
+    const int K = (TA && p.m_dev) ? min(p.K, *p.m_dev) : p.K;
+    const int kt_all = (K + BK - 1) / BK;
+    if (TA && p.m_dev) kt_per_split = (kt_all + splits - 1) / splits;
+    const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
     f32x16 acc[MT][NT];
     zero_acc(acc);
-    mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, p.K, m0, n0, kt0, kt1, acc);
+    mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     // raw partial tile -> ws[part][m][n]
     constexpr int WM = BM / 2, WN = BN / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -529,7 +535,7 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     // when the epilogue is a plain (bias / accumulate) one and a workspace was registered; else small tiles.
     const int64_t big = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
     if (big >= 384) return launch<128, 128, TA, TB, VEC>(a, s);
-    const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && !a.m_dev;
+    const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && (!a.m_dev || TA);
     if (plain && g_splitk && g_ws && big >= 16) {
         const int splits = choose_splits((int)big, (a.K + BK - 1) / BK);
         if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)

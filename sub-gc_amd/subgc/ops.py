@@ -11,7 +11,7 @@ import torch
 from ._lib import SubgcError, call
 
 RELU, ACCUM = 1, 2
-FLOPS = {"on": False, "gemm": 0.0}
+FLOPS = {"on": False, "gemm": 0.0, "gemm_bytes": 0.0, "gemm_calls": 0}
 
 
 def _stream():
@@ -66,6 +66,9 @@ def gemm(a, b, out, *, ta=False, tb=False, bias=None, add=None, keep=None, keep_
         r = int(m_dev.item()) if m_dev is not None else None
         me, ke = (M, min(K, r)) if (ta and r is not None) else ((min(M, r) if r is not None else M), K)
         FLOPS["gemm"] += 2.0 * me * N * ke
+        # algorithmic HBM bytes of the same call: each operand read once, the result written once (+ read when accumulated into)
+        FLOPS["gemm_bytes"] += 4.0 * (me * ke + ke * N + me * N * (2 if (accum or add is not None) else 1))
+        FLOPS["gemm_calls"] += 1
     call("subgc_gemm_f32", int(ta), int(tb), M, N, K, _ptr(a, torch.float32), ld(a), _ptr(b, torch.float32), ld(b),
          _ptr(out, torch.float32), ld(out), _ptr(bias), _ptr(add), ld(add) if add is not None else 0,
          _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0),
