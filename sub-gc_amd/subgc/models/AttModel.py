@@ -33,9 +33,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import beam
 from .. import functions as F_
 from .. import ops
+from . import sampling
 from .CaptionModel import CaptionModel
 
 
@@ -413,104 +413,24 @@ class AttModel(CaptionModel):
         """Greedy / top-k decode of one image (AttModel.py:236-326).  `uniforms[n, T]` (optional)
         supplies the top-k sampler's random numbers; `forced[n, T]` makes the loop follow a given
         token path (both exist so tests can pin the sampler)."""
-        beam_size = opt.get("beam_size", 1)
-        return_att = opt.get("return_att", 0) == 1
         B, N, _ = att_feats.shape
-        dev = att_feats.device
-        L = self.GCN_dim
-        X = self._encode(att_feats, obj_dist, pred_dist, rel_ind)
-        X2 = X.reshape(B * N, L).contiguous()
-        if self.gpn:
-            if gpn_obj_ind.size(0) != 5:
-                raise AssertionError("test branch of sGPN expects the 5 counterparts of ONE image (gpn.py:84)")
-            idx = gpn_obj_ind[0].reshape(-1, N).contiguous()                              # pos slots then neg slots
-            m_all = att_masks[0].reshape(-1, N)
-            w = gpn_pool_mtx[0].diagonal(dim1=-2, dim2=-1).reshape(-1, N).contiguous()
-            G = idx.size(0)
-            lens_all = m_all.sum(1)
-            img = torch.zeros(G, device=dev, dtype=torch.int32)
-            read_out, _ = ops.pool_fwd(X2, idx, idx.stride(0), w, w.stride(0), 1, lens_all.contiguous(), img, G, N, L, want_argmax=False)
-            if self.use_sGPN_score:
-                hid = torch.empty(G, self.att_hid_size, device=dev)
-                ops.gemm(read_out, self.P("gpn_layer.gpn_fc.0.weight"), hid, tb=True, bias=self.P("gpn_layer.gpn_fc.0.bias"), relu=True)
-                score, _ = ops.gpn_score_fwd(hid, None, 1.0, self.P("gpn_layer.gpn_fc.3.weight"), self.P("gpn_layer.gpn_fc.3.bias"), want_loss=False)
-                score = score.view(-1)
-            else:
-                score = torch.ones(G, device=dev)
-            lens_i = lens_all.to(torch.int32)
-            if not self.sct:                                                              # use_nms (AttModel.py:95)
-                keep_buf, n_keep = ops.subgraph_nms(score, idx, lens_i, self.gpn_nms_thres, self.gpn_max_subg)
-                keep = keep_buf[: int(n_keep.item())]
-            else:
-                keep = torch.arange(G, device=dev)
-            score = score[keep]
-            idx_k, lens_k = idx[keep].contiguous(), lens_i[keep].contiguous()
-            fc = torch.empty(keep.numel(), 2 * L, device=dev)
-            h = torch.empty(keep.numel(), self.att_hid_size, device=dev)
-            ops.gemm(read_out[keep].contiguous(), self.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=self.P("gpn_layer.read_out_proj.0.bias"))
-            ops.gemm(h, self.P("gpn_layer.read_out_proj.1.weight"), fc, tb=True, bias=self.P("gpn_layer.read_out_proj.1.bias"))
-        else:                                                                             # AttModel.py:261-271
-            ar = torch.arange(N, device=dev).view(1, N)
-            mean, _ = ops.pool_fwd(X2, ar.contiguous(), N, torch.ones(1, N, device=dev), N, 1, torch.full((1,), float(N), device=dev),
-                                   torch.zeros(1, device=dev, dtype=torch.int32), 1, N, L, want_argmax=False)
-            h = torch.empty(1, self.att_hid_size, device=dev); fc = torch.empty(1, 2 * L, device=dev)
-            ops.gemm(mean[:, L:], self.P("read_out_proj.0.weight"), h, tb=True, bias=self.P("read_out_proj.0.bias"))
-            ops.gemm(h, self.P("read_out_proj.1.weight"), fc, tb=True, bias=self.P("read_out_proj.1.bias"))
-            m = att_masks[0:1, 0, 0]
-            m[:, :36].fill_(1.0)
-            lens_k = m.sum(1).to(torch.int32)
-            idx_k = ar.contiguous()
-            keep = torch.arange(1, device=dev)
-            score = torch.ones(1, device=dev)
-        n = fc.size(0)
-        T = self.seq_length
-        seq = torch.zeros(n, T, device=dev, dtype=torch.long)
-        seqlp = torch.zeros(n, T, device=dev)
-        if n == 0:
-            return (seq, seqlp, score, keep) + ((torch.zeros(0, 0, 0, device=dev),) if return_att else ())
-        P = self._decoder_params()
-        pr = F_.Prepared(fc, X2, lens_k, idx_k, torch.zeros(n, device=dev, dtype=torch.int32), N, P, None, None, 1.0)
-        if beam_size > 1:                                                                 # AttModel.py:245-246 -> :179-234
-            seq, seqlp, self.done_beams = beam.beam_decode(pr, P, N, T, opt)
-            return seq, seqlp, score, keep
-        st = F_.DecodeState(pr, P, N, return_att)
-        it = torch.zeros(n, device=dev, dtype=torch.long)
-        unfinished = torch.zeros(n, device=dev, dtype=torch.int32)
-        counts = torch.zeros(T, device=dev, dtype=torch.int32)
-        AL = torch.zeros(T + 1, n, N, device=dev) if return_att else None
-        k = self.the_k if self.topk_sampling else 0
-        if k and uniforms is None and forced is None:
-            uniforms = torch.rand(n, T, device=dev)
-        for t in range(T + 1):
-            logp = st.step(it, AL[t] if return_att else None, normalize=forced is not None)
-            if t == T:
-                break
-            if forced is not None:
-                ops_forced_pick(logp, forced[:, t].contiguous(), k, self.topk_temp, t, seq, seqlp, it, unfinished, counts)
-            else:
-                ops.decode_pick(logp, k, self.topk_temp, None if uniforms is None else uniforms[:, t].contiguous(), t, seq, seqlp, it,
-                                unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
-        out = (seq, seqlp, score, keep)
-        if return_att:
-            c = counts.cpu()
-            dead = (c == 0).nonzero()
-            steps = int(dead[0]) + 1 if dead.numel() else T + 1
-            n_max = int(lens_k.max().item())
-            out = out + (AL[:steps, :, :n_max].permute(1, 0, 2).contiguous(),)
-        return out
+        X2 = self._encode(att_feats, obj_dist, pred_dist, rel_ind).reshape(B * N, self.GCN_dim).contiguous()
+        image = [(0, gpn_obj_ind, att_masks, gpn_pool_mtx)]
+        sel = sampling.select_subgraphs(self, X2, N, image) if self.gpn else sampling.full_graph_rows(self, X2, N, image)
+        return sampling.decode(self, X2, N, sel, opt, uniforms, forced)[0]
 
-
-def ops_forced_pick(logp, tok, k, temp, t, seq, seqlp, it, unfinished, counts):
-    """Test hook: follow a given token path (plumbing in torch; never on the product path)."""
-    lp = torch.log_softmax(logp / temp, 1) if k else logp
-    slp = lp.gather(1, tok.view(-1, 1)).view(-1)
-    unf = (tok > 0) if t == 0 else (unfinished.bool() & (tok > 0))
-    unfinished.copy_(unf.int())
-    w = tok * unf.long()
-    seq[:, t] = w
-    seqlp[:, t] = slp
-    it.copy_(w)
-    counts[t] = unf.sum().int()
+    @torch.no_grad()
+    def sample_images(self, images, opt={}):
+        """Decode MANY images in one batch (not in the reference, whose loop is one image per call, eval_utils.py:98-104).
+        `images`: list of dicts with the test loader's keys (att_feats [1,N,D], obj_dist, pred_dist, rel_ind, att_masks,
+        gpn_obj_ind, gpn_pool_mtx -- the 5-counterpart layout of dataloader_test.py).  Returns one `_sample` tuple per image."""
+        att = torch.cat([im["att_feats"][:1] for im in images])
+        I, N, _ = att.shape
+        X2 = self._encode(att, torch.cat([im["obj_dist"][:1] for im in images]), torch.cat([im["pred_dist"][:1] for im in images]),
+                          torch.cat([im["rel_ind"][:1] for im in images])).reshape(I * N, self.GCN_dim).contiguous()
+        rows = [(i, im["gpn_obj_ind"], im["att_masks"], im["gpn_pool_mtx"]) for i, im in enumerate(images)]
+        sel = sampling.select_subgraphs(self, X2, N, rows) if self.gpn else sampling.full_graph_rows(self, X2, N, rows)
+        return sampling.decode(self, X2, N, sel, opt)
 
 
 class TopDownModel(AttModel):

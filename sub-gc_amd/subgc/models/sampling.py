@@ -1,0 +1,176 @@
+"""Decode-time sub-graph selection and the token loop, for one image (the reference's contract) or MANY.
+
+Reference: AttModel._sample (models/AttModel.py:236-326), gpn_layer test branch + subgraph_nms
+(models/lib/gpn.py:83-150), driven one image per call by misc/eval_utils.py:98-104 (the loader hands
+the 5 "counterparts" of a single image and gpn.py:84 asserts it).
+
+A decode step of <= 10 kept sub-graphs streams all 152 MB of decoder weights for ~10 rows of work
+(HBM weight-streaming bound below ~40 rows).  `sample_images` therefore scores the
+candidates of every image in one pool/score launch, runs the node-set NMS per image, and decodes the
+kept sub-graphs of ALL images as one batch; per-image results are cut back out, and everything the
+reference leaves untouched after an image's own early break (AttModel.py:318-319) is zeroed again, so each
+image's tuple equals what a one-image call returns.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import beam
+from .. import functions as F_
+from .. import ops
+
+
+def _forced_pick(logp, tok, k, temp, t, seq, seqlp, it, unfinished, counts):
+    """Test hook: follow a given token path (plumbing in torch; never on the product path)."""
+    lp = torch.log_softmax(logp / temp, 1) if k else logp
+    slp = lp.gather(1, tok.view(-1, 1)).view(-1)
+    unf = (tok > 0) if t == 0 else (unfinished.bool() & (tok > 0))
+    unfinished.copy_(unf.int())
+    w = tok * unf.long()
+    seq[:, t] = w
+    seqlp[:, t] = slp
+    it.copy_(w)
+    counts[t] = unf.sum().int()
+
+
+def select_subgraphs(m, X2, N, images):
+    """Score every candidate sub-graph of every image, keep the NMS survivors.
+
+    images: list of (image_row, gpn_obj_ind [5,2,M,N], att_masks [5,2,M,N], gpn_pool_mtx [5,2,M,N,N]) -- only
+    counterpart 0 is read, like gpn.py:86-96.  Returns a list of dicts(fc, lens, idx, img, score, keep)."""
+    dev, L = X2.device, m.GCN_dim
+    idx_l, w_l, len_l, img_l, sizes = [], [], [], [], []
+    for row, gpn_obj_ind, att_masks, gpn_pool_mtx in images:
+        if gpn_obj_ind.size(0) != 5:
+            raise AssertionError("test branch of sGPN expects the 5 counterparts of ONE image (gpn.py:84)")
+        idx = gpn_obj_ind[0].reshape(-1, N)                                            # pos slots then neg slots
+        idx_l.append(idx)
+        w_l.append(gpn_pool_mtx[0].diagonal(dim1=-2, dim2=-1).reshape(-1, N))
+        len_l.append(att_masks[0].reshape(-1, N).sum(1))
+        img_l.append(torch.full((idx.size(0),), row, device=dev, dtype=torch.int32))
+        sizes.append(idx.size(0))
+    idx, w = torch.cat(idx_l).contiguous(), torch.cat(w_l).contiguous()
+    lens_all, img = torch.cat(len_l).contiguous(), torch.cat(img_l)
+    G = idx.size(0)
+    read_out, _ = ops.pool_fwd(X2, idx, idx.stride(0), w, w.stride(0), 1, lens_all, img, G, N, L, want_argmax=False)
+    if m.use_sGPN_score:
+        hid = torch.empty(G, m.att_hid_size, device=dev)
+        ops.gemm(read_out, m.P("gpn_layer.gpn_fc.0.weight"), hid, tb=True, bias=m.P("gpn_layer.gpn_fc.0.bias"), relu=True)
+        score, _ = ops.gpn_score_fwd(hid, None, 1.0, m.P("gpn_layer.gpn_fc.3.weight"), m.P("gpn_layer.gpn_fc.3.bias"), want_loss=False)
+        score = score.view(-1)
+    else:
+        score = torch.ones(G, device=dev)
+    lens_i = lens_all.to(torch.int32)
+    keeps, g0 = [], 0
+    for n_i in sizes:                                                                  # node-set NMS is per image (gpn.py:108-138)
+        if not m.sct:                                                                  # use_nms (AttModel.py:95)
+            keeps.append(ops.subgraph_nms(score[g0:g0 + n_i], idx[g0:g0 + n_i], lens_i[g0:g0 + n_i], m.gpn_nms_thres, m.gpn_max_subg))
+        else:
+            keeps.append(None)
+        g0 += n_i
+    out, g0 = [], 0
+    for n_i, kb in zip(sizes, keeps):
+        keep = torch.arange(n_i, device=dev) if kb is None else kb[0][: int(kb[1].item())]
+        out.append(dict(keep=keep, glob=keep + g0))
+        g0 += n_i
+    glob = torch.cat([o["glob"] for o in out])
+    fc = torch.empty(glob.numel(), 2 * L, device=dev)
+    if glob.numel():
+        h = torch.empty(glob.numel(), m.att_hid_size, device=dev)
+        ops.gemm(read_out[glob].contiguous(), m.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
+        ops.gemm(h, m.P("gpn_layer.read_out_proj.1.weight"), fc, tb=True, bias=m.P("gpn_layer.read_out_proj.1.bias"))
+    r0 = 0
+    for o in out:
+        g, n = o.pop("glob"), o["keep"].numel()
+        o.update(fc=fc[r0:r0 + n], lens=lens_i[g].contiguous(), idx=idx[g].contiguous(), img=img[g].contiguous(), score=score[g])
+        r0 += n
+    return out
+
+
+def full_graph_rows(m, X2, N, images):
+    """Full-GC baseline (AttModel.py:261-271): one row per image, mean-pooled read-out, attention over the first 36 nodes."""
+    dev, L = X2.device, m.GCN_dim
+    n = len(images)
+    ar = torch.arange(N, device=dev).view(1, N).expand(n, N).contiguous()
+    img = torch.tensor([im[0] for im in images], device=dev, dtype=torch.int32)
+    mean, _ = ops.pool_fwd(X2, ar, N, torch.ones(n, N, device=dev), N, 1, torch.full((n,), float(N), device=dev), img, n, N, L, want_argmax=False)
+    h = torch.empty(n, m.att_hid_size, device=dev)
+    fc = torch.empty(n, 2 * L, device=dev)
+    ops.gemm(mean[:, L:], m.P("read_out_proj.0.weight"), h, tb=True, bias=m.P("read_out_proj.0.bias"))
+    ops.gemm(h, m.P("read_out_proj.1.weight"), fc, tb=True, bias=m.P("read_out_proj.1.bias"))
+    out = []
+    for i, (row, _g, att_masks, _p) in enumerate(images):
+        mk = att_masks[0:1, 0, 0]
+        mk[:, :36].fill_(1.0)                                                          # writes into the caller's tensor, like :148-149
+        out.append(dict(fc=fc[i:i + 1], lens=mk.sum(1).to(torch.int32), idx=ar[i:i + 1], img=img[i:i + 1],
+                        score=torch.ones(1, device=dev), keep=torch.arange(1, device=dev)))
+    return out
+
+
+@torch.no_grad()
+def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
+    """Greedy / top-k / beam decode of the selected sub-graphs of one or many images as ONE batch.
+    Returns one result tuple per image: (seq, seqLogprobs, score, keep[, att_weights])."""
+    dev = X2.device
+    T = m.seq_length
+    return_att = opt.get("return_att", 0) == 1
+    beam_size = opt.get("beam_size", 1)
+    sizes = [s["keep"].numel() for s in sel]
+    n = sum(sizes)
+    if n == 0:
+        z = lambda: (torch.zeros(0, T, device=dev, dtype=torch.long), torch.zeros(0, T, device=dev))
+        return [z() + (s["score"], s["keep"]) + ((torch.zeros(0, 0, 0, device=dev),) if return_att else ()) for s in sel]
+    cat = lambda k: torch.cat([s[k] for s in sel]).contiguous()
+    fc, lens_k, idx_k, img_k = cat("fc"), cat("lens"), cat("idx"), cat("img")
+    P = m._decoder_params()
+    pr = F_.Prepared(fc, X2, lens_k, idx_k, img_k, N, P, None, None, 1.0)
+    bounds = [0]
+    for s in sizes:
+        bounds.append(bounds[-1] + s)
+    if beam_size > 1:                                                                  # AttModel.py:245-246 -> :179-234
+        seq, seqlp, done = beam.beam_decode(pr, P, N, T, opt)
+        m.done_beams = done if len(sel) == 1 else [done[a:b] for a, b in zip(bounds, bounds[1:])]
+        return [(seq[a:b], seqlp[a:b], s["score"], s["keep"]) for s, a, b in zip(sel, bounds, bounds[1:])]
+    st = F_.DecodeState(pr, P, N, return_att)
+    seq = torch.zeros(n, T, device=dev, dtype=torch.long)
+    seqlp = torch.zeros(n, T, device=dev)
+    it = torch.zeros(n, device=dev, dtype=torch.long)
+    unfinished = torch.zeros(n, device=dev, dtype=torch.int32)
+    counts = torch.zeros(T, device=dev, dtype=torch.int32)
+    AL = torch.zeros(T + 1, n, N, device=dev) if return_att else None
+    k = m.the_k if m.topk_sampling else 0
+    if k and uniforms is None and forced is None:
+        uniforms = torch.rand(n, T, device=dev)
+    for t in range(T + 1):
+        logp = st.step(it, AL[t] if return_att else None, normalize=forced is not None)
+        if t == T:
+            break
+        if forced is not None:
+            _forced_pick(logp, forced[:, t].contiguous(), k, m.topk_temp, t, seq, seqlp, it, unfinished, counts)
+        else:
+            ops.decode_pick(logp, k, m.topk_temp, None if uniforms is None else uniforms[:, t].contiguous(), t, seq, seqlp, it,
+                            unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
+    if len(sel) == 1:
+        steps = None
+        if return_att:
+            dead = (counts.cpu() == 0).nonzero()
+            steps = [int(dead[0]) + 1 if dead.numel() else T + 1]
+    else:
+        # per-image early break: image i stops after the first step at which none of ITS rows is unfinished; the
+        # reference writes nothing (tokens, log-probs, attention rows) beyond that step
+        alive = (seq > 0).int().cumprod(1)                                             # [n, T] row still unfinished after step t
+        per = torch.stack([alive[a:b].sum(0) for a, b in zip(bounds, bounds[1:])])     # [I, T]
+        stopped = (per == 0).int()
+        brk = torch.where(stopped.any(1), stopped.argmax(1), torch.full_like(stopped[:, 0], T - 1).long())   # break step per image
+        tgrid = torch.arange(T, device=dev).view(1, T)
+        row_brk = torch.repeat_interleave(brk, torch.tensor(sizes, device=dev))
+        seqlp = seqlp * (tgrid <= row_brk.view(-1, 1))
+        steps = [min(int(b) + 1, T) + (1 if int(b) == T - 1 and not bool(s.any()) else 0) for b, s in zip(brk.cpu(), stopped.cpu())]
+    out = []
+    for i, (s, a, b) in enumerate(zip(sel, bounds, bounds[1:])):
+        r = (seq[a:b], seqlp[a:b], s["score"], s["keep"])
+        if return_att:
+            n_max = int(s["lens"].max().item()) if b > a else 0
+            r = r + (AL[:steps[i], a:b, :n_max].permute(1, 0, 2).contiguous(),)
+        out.append(r)
+    return out

@@ -242,3 +242,34 @@ def test_beam_search_identical_to_reference(golden, name):
     ret = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample")
     check_beams(ret, m.done_beams, g.group("out"), atol=1e-4)
     close(ret[2], g.group("out")["subgraph_score"], "score", atol=1e-5)
+
+
+@pytest.mark.parametrize("sample_opt", [dict(sample_max=1, beam_size=1, return_att=1), dict(sample_max=1, beam_size=3)])
+def test_sample_images_batch_equals_one_image_calls(golden, sample_opt):
+    """Cross-image decode batching: each image's tuple equals what the reference-shaped one-image call returns
+    (tokens / kept sub-graphs exact, incl. what is left zero after that image's own early break)."""
+    g = golden("subgc_greedy")
+    w = golden("subgc_beam").group("weights")                           # state-dependent <eos> ...
+    if sample_opt["beam_size"] == 1:
+        w["logit.bias"][0] += 2.0                                       # ... made likely enough that greedy images stop at steps 1, 17 and 21
+    m = build(g, w, False)
+    D = g.meta["opt"]["att_feat_size"]
+    ims = [synthetic.make_test_batch(M, D=D, seed=300 + i, fc_size=D, node_pool=pool) for i, (M, pool) in enumerate([(24, 14), (3, None), (40, 10), (9, 12), (1, None)])]
+    ims = [{k: v.to(DEV) for k, v in b.items()} for b in ims]
+    single = [m(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sample_opt, mode="sample") for b in ims]
+    batch = m.sample_images(ims, opt=sample_opt)
+    assert len(batch) == len(single)
+    lens = set()
+    for one, many in zip(single, batch):
+        np.testing.assert_array_equal(many[3].cpu().numpy(), one[3].cpu().numpy())
+        np.testing.assert_array_equal(many[0].cpu().numpy(), one[0].cpu().numpy())
+        close(many[1], one[1], "seqLogprobs", atol=2e-5)
+        close(many[2], one[2], "score", atol=1e-6)
+        if len(one) > 4:
+            assert tuple(many[4].shape) == tuple(one[4].shape)
+            close(many[4], one[4], "att2_weights", atol=1e-5)
+            lens.add(many[4].shape[1])
+    if sample_opt["beam_size"] > 1:
+        assert len(m.done_beams) == len(ims) and all(len(per) == r[0].shape[0] for per, r in zip(m.done_beams, batch))
+    else:
+        assert len(lens) > 1, "the images should stop at different steps for this test to mean something"
