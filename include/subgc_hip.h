@@ -285,6 +285,10 @@ int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int k, float 
 int subgc_row_topk_f32(const float* x, int64_t ld, int rows, int cols, int k, int log_softmax, float* vals,
                        int32_t* idx, void* stream);
 
+/* Eval loop (misc/eval_utils.py:106-108): order[r] = index of the r-th largest score (ties keep input order),
+ * sorted[r] = that score (may be NULL).  n <= 8192 (an image has at most 2M candidate sub-graphs).     */
+int subgc_rank_desc_f32(const float* score, int n, int64_t* order, float* sorted, void* stream);
+
 /* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 

@@ -527,3 +527,39 @@ def loss_wrapper(oracle, batch, masks=None, tap=None):
     outputs, gpn_loss, score = oracle.forward(*args, masks=masks, tap=tap)
     lang = lm_criterion(outputs, batch["labels"][:, 1:], batch["masks"][:, 1:])
     return {"lang_loss": lang, "gpn_loss": gpn_loss, "outputs": outputs, "subgraph_score": score}
+
+
+# --------------------------------------------------------------------------- eval glue (misc/eval_utils.py:105-141)
+_BAD_ENDINGS = ['with', 'in', 'on', 'of', 'a', 'at', 'to', 'for', 'an', 'this', 'his', 'her', 'that', 'the']   # misc/utils.py:16-17
+
+
+def decode_sequence(ix_to_word, seq, remove_bad_endings=0):
+    """misc/utils.py:59-81."""
+    out = []
+    for i in range(seq.size(0)):
+        txt = ''
+        for j in range(seq.size(1)):
+            ix = int(seq[i, j])
+            if ix <= 0:
+                break
+            txt = txt + (' ' if j >= 1 else '') + ix_to_word[str(ix)]
+        if remove_bad_endings:
+            flag, words = 0, txt.split(' ')
+            for j in range(len(words)):
+                if words[-j - 1] not in _BAD_ENDINGS:
+                    flag = -j
+                    break
+            txt = ' '.join(words[0:len(words) + flag])
+        out.append(txt)
+    return out
+
+
+def rank_subgraphs(gpn, seqq, subgraph_score, keep_nms_ind, sct_mode=False):
+    """misc/eval_utils.py:105-121."""
+    if sct_mode:
+        valid = int(subgraph_score.size(0) / 2)
+        return seqq[:valid], subgraph_score[:valid], keep_nms_ind[:valid], keep_nms_ind[:valid].long()
+    if gpn:
+        sorted_score, sort_ind = torch.sort(subgraph_score, descending=True, stable=True)
+        return seqq[sort_ind], sorted_score, keep_nms_ind[sort_ind], sort_ind
+    return seqq, subgraph_score, keep_nms_ind, torch.arange(subgraph_score.size(0)).type_as(keep_nms_ind)

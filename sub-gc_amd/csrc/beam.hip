@@ -90,3 +90,34 @@ SUBGC_API int subgc_row_topk_f32(const float* x, int64_t ld, int rows, int cols,
 #undef LAUNCH
     return subgc::check_launch("subgc_row_topk_f32");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Caption ranking of the eval loop (misc/eval_utils.py:106-108 `torch.sort(subgraph_score, descending=True)`):
+// order[r] = index of the r-th best score; equal scores keep their input order (stable).  n <= 8192: one
+// workgroup counts, for every element, how many elements precede it -- O(n^2) on a few hundred scores.
+namespace {
+__global__ __launch_bounds__(256) void rank_desc_kernel(const float* __restrict__ s, int n, int64_t* __restrict__ order,
+                                                        float* __restrict__ sorted) {
+    extern __shared__ float sh[];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sh[i] = s[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = sh[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) {
+            const float u = sh[j];
+            r += (u > v) || (u == v && j < i);
+        }
+        order[r] = i;
+        if (sorted) sorted[r] = v;
+    }
+}
+}  // namespace
+
+SUBGC_API int subgc_rank_desc_f32(const float* score, int n, int64_t* order, float* sorted, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && n <= 8192, "rank_desc: 0 <= n <= 8192");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(score && order, "rank_desc: null pointer");
+    hipLaunchKernelGGL(rank_desc_kernel, dim3(1), dim3(256), (size_t)n * sizeof(float), (hipStream_t)stream, score, n, order, sorted);
+    return subgc::check_launch("subgc_rank_desc_f32");
+}

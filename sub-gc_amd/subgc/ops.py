@@ -294,6 +294,15 @@ def row_topk(x, k, vals, idx, log_softmax=True):
     return vals, idx
 
 
+def rank_desc(score):
+    """(sorted scores, order): stable descending sort of a 1-D fp32 score vector (eval_utils.py:106)."""
+    score = score.contiguous()
+    order = torch.empty(score.numel(), device=score.device, dtype=torch.int64)
+    srt = torch.empty_like(score)
+    call("subgc_rank_desc_f32", _ptr(score, torch.float32), score.numel(), _ptr(order), _ptr(srt), _stream())
+    return srt, order
+
+
 def dropout_mask(shape, p, seed, offset, device):
     keep = torch.empty(shape, device=device, dtype=torch.uint8)
     call("subgc_dropout_mask", _ptr(keep), keep.numel(), float(p), int(seed), int(offset), _stream())

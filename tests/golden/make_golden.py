@@ -225,10 +225,37 @@ def beam_cases(w, meta):
         torch.Tensor.cuda = orig
 
 
+def eval_cases(meta):
+    """misc/utils.py:59-81 decode_sequence (with and without REMOVE_BAD_ENDINGS) on token rows that end in function words."""
+    import misc.utils as U
+    rng = np.random.default_rng(21)
+    words = list(U.bad_endings) + [f"w{i}" for i in range(40)]
+    vocab = {str(i + 1): w for i, w in enumerate(words)}
+    seq = rng.integers(1, len(words) + 1, size=(40, 12))
+    for r in range(40):
+        seq[r, rng.integers(0, 13):] = 0                          # random length incl. empty and full rows
+    seq[3, :4] = [20, 1, 2, 3]; seq[3, 4:] = 0                    # "w.. with in on": everything after the first word is stripped
+    seq[4, :3] = [1, 2, 14]; seq[4, 3:] = 0                       # only function words
+    out = {}
+    for flag in ("0", "1"):
+        os.environ["REMOVE_BAD_ENDINGS"] = flag
+        out["sents_" + flag] = np.array(U.decode_sequence(vocab, torch.from_numpy(seq)))
+    os.environ["REMOVE_BAD_ENDINGS"] = "0"
+    meta["eval_glue"] = dict(kind="eval", vocab=vocab)
+    save("eval_glue", out=dict(seq=seq, **out))
+
+
 def main():
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     enter_scratch()
     torch.set_num_threads(1)
+    if "--only-eval" in sys.argv:
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        eval_cases(meta)
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        return
     if "--only-beam" in sys.argv:                               # add the beam cases without rewriting the others
         with open(os.path.join(HERE, "meta.json")) as f:
             meta = json.load(f)
@@ -258,6 +285,7 @@ def main():
     run_sample("fullgc_greedy", ref_opt(**fo), wf, seed=8, M=2, sample_opt=dict(sample_max=1, beam_size=1), meta=meta)
     # 4. beam search / diverse beam search
     beam_cases(w, meta)
+    eval_cases(meta)
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True, default=str)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
