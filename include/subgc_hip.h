@@ -289,6 +289,23 @@ int subgc_row_topk_f32(const float* x, int64_t ld, int rows, int cols, int k, in
  * sorted[r] = that score (may be NULL).  n <= 8192 (an image has at most 2M candidate sub-graphs).     */
 int subgc_rank_desc_f32(const float* score, int n, int64_t* order, float* sorted, void* stream);
 
+/* ---- on-device batch assembly (dataloaders/dataloader.py:269-367) ----------------------------------------
+ * mask_compact (:276-308): row g of the 0/1 `mask [G, W]` -> ind[g, :] = ascending set positions, padded with `pad`
+ * (the dummy node / predicate index) to N columns; att_mask[g, i] = i < count (may be NULL); pool_mtx[g] = the
+ * N x N diagonal 0/1 matrix of :283,290 (may be NULL -- the model only reads its diagonal).  W <= 1024.          */
+int subgc_mask_compact(const uint8_t* mask, int64_t ld, int G, int W, int N, int64_t pad, int64_t* ind,
+                       float* att_mask, float* pool_mtx, void* stream);
+/* pad_rows (:336-354): image b owns rows off[b]..off[b+1] of the packed `src [sum, C]`; dst[b, r, :] = its r-th row
+ * for r < min(count, limit), else the padding row: one-hot(0) (onehot0 != 0; the class-0 rows of :341,350) or zeros
+ * (f32), `pad` (i64: the dummy endpoint obj_num-1 of :349).                                                       */
+int subgc_pad_rows_f32(const float* src, const int64_t* off, int B, int R, int C, int limit, int onehot0,
+                       float* dst, void* stream);
+int subgc_pad_rows_i64(const int64_t* src, const int64_t* off, int B, int R, int C, int limit, int64_t pad,
+                       int64_t* dst, void* stream);
+/* caption_labels (:356-363): labels[s] = [0, captions[s, :seq_length], 0]; masks[s, j] = j < nonzero(captions[s]) + 2 */
+int subgc_caption_labels(const int64_t* captions, int64_t ld, int S, int seq_length, int64_t* labels,
+                         float* masks, void* stream);
+
 /* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 

@@ -563,3 +563,46 @@ def rank_subgraphs(gpn, seqq, subgraph_score, keep_nms_ind, sct_mode=False):
         sorted_score, sort_ind = torch.sort(subgraph_score, descending=True, stable=True)
         return seqq[sort_ind], sorted_score, keep_nms_ind[sort_ind], sort_ind
     return seqq, subgraph_score, keep_nms_ind, torch.arange(subgraph_score.size(0)).type_as(keep_nms_ind)
+
+
+# --------------------------------------------------------------------------- batch assembly (dataloaders/dataloader.py:269-367)
+# PARITY UNPINNED for this block: the reference loader imports h5py and reads dataset files, neither of which
+# exists in the build container, so no golden vector could be produced by running it; this is a line-by-line
+# numpy restatement of the cited lines only.
+def assemble_image(object_fmap, object_dist, rel_ind, pred_dist, node_masks, pred_masks, captions, obj_num, rel_num):
+    """One image: node_masks [S, 2, hb, obj_num-1] bool, pred_masks [S, 2, hb, rel_num-1] bool, captions [S, seq_length]."""
+    S, _, hb, _ = node_masks.shape
+    gpn_obj_ind = np.full((S, 2, hb, obj_num), obj_num - 1)                                       # :276
+    gpn_att_mask = np.full((S, 2, hb, obj_num), 0).astype('float32')                              # :277
+    gpn_pred_ind = np.full((S, 2, hb, rel_num), rel_num - 1)                                      # :278
+    gpn_pool_mtx = np.zeros((S, 2, hb, obj_num, obj_num)).astype('float32')                       # :280
+    for i in range(S):
+        for k in range(hb):
+            for side in range(2):                                                                 # :283-301 (pos then neg)
+                tmp = node_masks[i, side, k].nonzero()[0]
+                if tmp.shape[0] != 0:
+                    gpn_obj_ind[i, side, k, :tmp.shape[0]] = tmp
+                gpn_att_mask[i, side, k, :tmp.shape[0]] = 1
+                gpn_pool_mtx[i, side, k, np.arange(tmp.shape[0]), np.arange(tmp.shape[0])] = 1
+                tmp = pred_masks[i, side, k].nonzero()[0]
+                if tmp.shape[0] != 0:
+                    gpn_pred_ind[i, side, k, :tmp.shape[0]] = tmp
+    pad_fmap = np.full((1, obj_num, object_fmap.shape[1]), 0).astype('float32')                   # :336
+    pad_dist = np.concatenate((np.ones((1, obj_num, 1)), np.zeros((1, obj_num, object_dist.shape[1] - 1))), axis=2).astype('float32')
+    fc_feat = np.full((1, object_fmap.shape[1]), 0).astype('float32')
+    pad_fmap[0, :obj_num - 1, :] = object_fmap                                                    # :340
+    pad_dist[0, :obj_num - 1, :] = object_dist
+    pad_rel = np.full((1, rel_num, rel_ind.shape[1]), obj_num - 1)                                # :349
+    pad_pred = np.concatenate((np.ones((1, rel_num, 1)), np.zeros((1, rel_num, pred_dist.shape[1] - 1))), axis=2).astype('float32')
+    n = min(rel_ind.shape[0], rel_num - 1)                                                        # :352
+    pad_pred[0, :n, :] = pred_dist[:n]
+    pad_rel[0, :n, :] = rel_ind[:n]
+    Lq = captions.shape[1]
+    label = np.zeros([S, Lq + 2], dtype='int64')                                                  # :356-357
+    label[:, 1:Lq + 1] = captions
+    nonzeros = np.array([(x != 0).sum() + 2 for x in label])
+    mask = np.zeros([S, Lq + 2], dtype='float32')
+    for idx in range(S):
+        mask[idx, :nonzeros[idx]] = 1
+    return dict(fc_feats=fc_feat, att_feats=pad_fmap, obj_dist=pad_dist, rel_ind=pad_rel, pred_dist=pad_pred, labels=label, masks=mask,
+                gpn_obj_ind=gpn_obj_ind, att_masks=gpn_att_mask, gpn_pred_ind=gpn_pred_ind, gpn_pool_mtx=gpn_pool_mtx)

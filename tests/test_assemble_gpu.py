@@ -1,0 +1,73 @@
+"""On-device batch assembly (dataloaders/dataloader.py:269-367) against the numpy restatement in the oracle
+(parity unpinned: the reference loader needs h5py + dataset files and cannot run in the build container).
+Integer outputs and the 0/1 float masks are compared bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import subgc_oracle as O
+from subgc import assemble
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("obj_num,rel_num,D", [(37, 65, 64), (101, 301, 32)])
+def test_assemble_train_batch_equals_loader_restatement(obj_num, rel_num, D):
+    rng = np.random.default_rng(obj_num)
+    B, S, hb, C, P, Lq = 3, 5, 2, 23, 21, 16
+    n_rel = [0, rel_num + 7, 11]                                  # empty, more than fits (truncated at rel_num-1), short
+    imgs, want = [], []
+    for b in range(B):
+        fmap = rng.standard_normal((obj_num - 1, D)).astype(np.float32)
+        dist = rng.random((obj_num - 1, C)).astype(np.float32)
+        rel = rng.integers(0, obj_num - 1, size=(n_rel[b], 2))
+        pred = rng.random((n_rel[b], P)).astype(np.float32)
+        nm = rng.random((S, 2, hb, obj_num - 1)) < 0.2
+        nm[0, 0, 0] = False                                       # an empty sub-graph
+        nm[1, 1, 1] = True                                        # a full one
+        pm = rng.random((S, 2, hb, rel_num - 1)) < 0.1
+        cap = rng.integers(1, 50, size=(S, Lq))
+        for s in range(S):
+            cap[s, rng.integers(0, Lq + 1):] = 0                  # lengths 0..Lq
+        imgs.append((fmap, dist, rel, pred, nm, pm, cap))
+        want.append(O.assemble_image(fmap, dist, rel, pred, nm, pm, cap, obj_num, rel_num))
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(DEV) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dt)
+    raw = dict(object_fmap=t(np.stack([i[0] for i in imgs])), object_dist=t(np.stack([i[1] for i in imgs])),
+               rel_ind=t(np.concatenate([i[2] for i in imgs]).astype(np.int64)), pred_dist=t(np.concatenate([i[3] for i in imgs])),
+               rel_off=t(np.concatenate([[0], np.cumsum(n_rel)]).astype(np.int64)),
+               node_mask=t(np.concatenate([i[4] for i in imgs]), torch.uint8), pred_mask=t(np.concatenate([i[5] for i in imgs]), torch.uint8),
+               captions=t(np.concatenate([i[6] for i in imgs]).astype(np.int64)))
+    got = assemble.assemble_train_batch(raw, obj_num, rel_num)
+    for k in want[0]:
+        w = np.concatenate([x[k] for x in want])
+        g = got[k].cpu().numpy()
+        assert g.shape == w.shape, k
+        np.testing.assert_array_equal(g, w.astype(g.dtype), err_msg=k)
+
+
+def test_assembled_batch_feeds_the_model(golden):
+    """The assembled dict is what LossWrapper takes: a batch rebuilt on the device from raw pieces of a synthetic
+    batch gives the same loss as the batch itself."""
+    import subgc.models as models
+    from subgc import synthetic
+    from test_parity_gpu import build, run_train
+    g = golden("subgc_train")
+    m = build(g, g.group("weights"), True)
+    batch = g.tensors("inputs")
+    ref_out, _ = run_train(m, batch)
+    N, K = batch["att_feats"].shape[1], batch["rel_ind"].shape[1]
+    B = batch["att_feats"].shape[0]
+    node_mask = torch.zeros(batch["gpn_obj_ind"].shape[:-1] + (N - 1,), dtype=torch.uint8)
+    for idx in np.ndindex(*batch["gpn_obj_ind"].shape[:-1]):
+        n = int(batch["att_masks"][idx].sum())
+        node_mask[idx][batch["gpn_obj_ind"][idx][:n]] = 1
+    raw = dict(object_fmap=batch["att_feats"][:, :N - 1], object_dist=batch["obj_dist"][:, :N - 1],
+               rel_ind=batch["rel_ind"][:, :K - 1].reshape(-1, 2), pred_dist=batch["pred_dist"][:, :K - 1].reshape(B * (K - 1), -1),
+               rel_off=torch.arange(B + 1) * (K - 1), node_mask=node_mask,
+               pred_mask=torch.zeros(batch["gpn_obj_ind"].shape[:-1] + (K - 1,), dtype=torch.uint8), captions=batch["labels"][:, 1:-1])
+    got = assemble.assemble_train_batch({k: v.contiguous().to(DEV) for k, v in raw.items()}, N, K)
+    for k in ("att_feats", "obj_dist", "rel_ind", "pred_dist", "labels", "masks", "gpn_obj_ind", "att_masks", "gpn_pool_mtx"):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), batch[k].numpy(), err_msg=k)
+    out, _ = run_train(m, {**{k: v for k, v in batch.items()}, **{k: v.cpu() for k, v in got.items()}})
+    assert float(out["lang_loss"]) == float(ref_out["lang_loss"])
