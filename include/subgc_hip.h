@@ -83,6 +83,13 @@ int subgc_gemm_f32(int transA, int transB, int M, int N, int K,
                    const uint8_t* keep, float keep_scale, int flags,
                    const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev, void* stream);
 
+/* GEMM arithmetic mode for the 128x128-tile forms (process-wide; also SUBGC_GEMM_X3=0|1 at first use):
+ *   0  v_mfma_f32_32x32x2_f32 on fp32 operands;
+ *   1  each fp32 operand is split EXACTLY into three bf16 planes and the product is formed from six
+ *      v_mfma_f32_32x32x16_bf16 terms accumulated in fp32 (csrc/gemm_x3.h): fp32-level accuracy at
+ *      2.67x the matrix-pipe rate.  Inputs, outputs and accumulation stay fp32 either way.          */
+int subgc_set_gemm_mode(int mode);
+
 /* Optional scratch for the split-K form of subgc_gemm_f32 (used for shapes whose 128x128 tile count
  * cannot fill the 256 CUs, e.g. the per-step recurrent GEMMs with M = 640): a caller-owned device
  * buffer into which partial tiles are written and from which they are reduced, all stream-ordered on
