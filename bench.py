@@ -258,28 +258,29 @@ def main():
                                        "gemm_gflop_per_step": round(ops.FLOPS["gemm"] / 1e9, 2), "gemm_achieved_tflops": round(ach2, 2),
                                        "gemm_frac_of_peak": round(ach2 / MFMA_F32_PEAK_TFLOPS, 4)}
             model.packed_decoder = True
-            # experimental, NOT the headline: the same packed step with the 128x128-tile GEMMs on the bf16 matrix pipe
-            # (fp32 operands split exactly into 3 bf16 planes, 6 MFMA terms, fp32 accumulate; csrc/gemm_x3.h)
-            _lib.call("subgc_set_gemm_mode", 1)
-            try:
-                for _ in range(2):
-                    step()
-                fence()
-                _lib.prof_enable("gemm", True)
-                t0 = time.perf_counter()
-                for _ in range(a.steps):
-                    loss3 = step()
-                fence()
-                dt = time.perf_counter() - t0
-                _lib.prof_enable("gemm", False)
-                _, ms3, _ = _lib.prof_collect("gemm")
-                res["experimental_bf16x3_split_gemm"] = {
-                    "value": round(imgs * a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3),
-                    "gemm_fp32_equivalent_tflops": round(flops_step * a.steps / (ms3 * 1e-3) / 1e12, 2),
-                    "final_loss": round(float(loss3.item()), 4),
-                    "note": "opt-in (subgc_set_gemm_mode(1)); error vs fp64 within 2x of the fp32-MFMA kernel (tests); not used for `value`"}
-            finally:
-                _lib.call("subgc_set_gemm_mode", 0)
+            # NOT the headline (fp32, above): the same packed step with the 128x128-tile GEMMs in the two other arithmetic
+            # modes of csrc/gemm_x3.h -- "bf16x3": fp32 operands split exactly into 3 bf16 planes, 6 bf16-MFMA terms, fp32
+            # accumulate (fp32-grade results); "bf16": operands rounded to bf16 (the compute type of BASELINE configs 3, 5)
+            notes = {"bf16x3": "opt-in; error vs fp64 within 2x of the fp32-MFMA kernel (tests); fp32-equivalent FLOPs",
+                     "bf16": "opt-in; bf16 operand rounding, fp32 accumulate/storage: a DIFFERENT precision than `value`'s fp32"}
+            res["other_gemm_modes"] = {}
+            for mode in ("bf16x3", "bf16"):
+                with ops.gemm_mode(mode):
+                    for _ in range(2):
+                        step()
+                    fence()
+                    _lib.prof_enable("gemm", True)
+                    t0 = time.perf_counter()
+                    for _ in range(a.steps):
+                        loss3 = step()
+                    fence()
+                    dt = time.perf_counter() - t0
+                    _lib.prof_enable("gemm", False)
+                    _, ms3, _ = _lib.prof_collect("gemm")
+                    res["other_gemm_modes"][mode] = {
+                        "value": round(imgs * a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3),
+                        "gemm_algorithmic_tflops": round(flops_step * a.steps / (ms3 * 1e-3) / 1e12, 2),
+                        "final_loss": round(float(loss3.item()), 4), "note": notes[mode]}
         if world == 1 and not a.no_decode:
             res.update(decode_bench(model.state_dict(), dev, images=64, M=50))
         if world == 1 and not a.no_cpu_baseline:

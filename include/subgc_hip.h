@@ -87,7 +87,9 @@ int subgc_gemm_f32(int transA, int transB, int M, int N, int K,
  *   0  v_mfma_f32_32x32x2_f32 on fp32 operands;
  *   1  each fp32 operand is split EXACTLY into three bf16 planes and the product is formed from six
  *      v_mfma_f32_32x32x16_bf16 terms accumulated in fp32 (csrc/gemm_x3.h): fp32-level accuracy at
- *      2.67x the matrix-pipe rate.  Inputs, outputs and accumulation stay fp32 either way.          */
+ *      2.67x the matrix-pipe rate;
+ *   2  bf16 compute (BASELINE configs 3 and 5): each fp32 operand is rounded to nearest-even bf16 on its way
+ *      to LDS, one v_mfma_f32_32x32x16_bf16 term.  Inputs, outputs and accumulation stay fp32 in every mode. */
 int subgc_set_gemm_mode(int mode);
 
 /* Optional scratch for the split-K form of subgc_gemm_f32 (used for shapes whose 128x128 tile count

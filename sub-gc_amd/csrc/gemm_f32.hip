@@ -375,7 +375,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 }
 
 // data-parallel form: one workgroup per output tile
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool X3 = false>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
     f32x16 acc[MT][NT];
     zero_acc(acc);
-    if constexpr (X3) mainloop_x3<BM, BN, TA, TB, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+    if constexpr (XM != 0) mainloop_x3<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
     else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
     epilogue<BM, BN, MT, NT, false>(p, M, m0, n0, true, acc);
 }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 // device-scope fp32 atomics are executed memory-side on this chip and cost more than the GEMM saves),
 // and splitk_reduce_kernel sums the parts and applies the (bias / accumulate) epilogue.  Both launches
 // are stream-ordered; the workspace is just-written and comes back out of L2 / Infinity Cache.
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool X3 = false>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
 __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const GemmArgs p, 
     const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
     f32x16 acc[MT][NT];
     zero_acc(acc);
-    if constexpr (X3) mainloop_x3<BM, BN, TA, TB, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
+    if constexpr (XM != 0) mainloop_x3<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     // raw partial tile -> ws[part][m][n]
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -483,15 +483,15 @@ int raise_lds(KernelT kernel, size_t lds, bool& done) {
     return SUBGC_OK;
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool X3 = false>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
 int launch(const GemmArgs& a, hipStream_t s) {
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
-    const size_t lds = X3 ? x3_lds_bytes(BM, BN) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    const size_t lds = XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
     static bool attr_set = false;
-    if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, X3>, lds, attr_set)) return rc;
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, X3>), grid, dim3(256), lds, s, a);
+    if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>), grid, dim3(256), lds, s, a);
     return subgc::check_launch("subgc_gemm_f32");
 }
 
@@ -499,7 +499,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
 int g_splitk = 1;            // 0 disables the split-K form (SUBGC_SPLITK=0)
-int g_x3 = 0;                // 1: 128x128 tiles run on the bf16 matrix pipe with 3-way split operands (subgc_set_gemm_mode)
+int g_x3 = 0;                // subgc_set_gemm_mode: 1 = 3-way split operands on the bf16 matrix pipe, 2 = operands rounded to bf16
 
 // pick the number of K parts for 128x128 tiles so that tiles x parts fills the 512 workgroup slots
 // (2 per CU) in whole rounds; returns 1 when splitting does not pay
@@ -516,16 +516,16 @@ inline int choose_splits(int tiles, int kt) {
     return best;
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool X3 = false>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
 int launch_splitk(const GemmArgs& a, hipStream_t s, int splits) {
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
-    const size_t lds = X3 ? x3_lds_bytes(BM, BN) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    const size_t lds = XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     const int tiles = (int)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM));
     const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
     static bool attr_set = false;
-    if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, X3>, lds, attr_set)) return rc;
-    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, X3>), dim3(tiles * splits), dim3(256), lds, s, a, g_ws, splits, per);
+    if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
+    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(256), lds, s, a, g_ws, splits, per);
     const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);
@@ -540,13 +540,15 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     // when the epilogue is a plain (bias / accumulate) one and a workspace was registered; else small tiles.
     const int64_t big = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
     // bf16x3-split form (gemm_x3.h): vector-addressable operands, no gathered A rows, 128x128 tiles
-    const bool x3 = VEC && g_x3 && !a.a_rows;
-    if (big >= 384) return x3 ? launch<128, 128, TA, TB, VEC, VEC>(a, s) : launch<128, 128, TA, TB, VEC>(a, s);
+    const int xm = (VEC && !a.a_rows) ? g_x3 : 0;
+    if (big >= 384) return xm == 1 ? launch<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s) : xm == 2 ? launch<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s)
+                                                                                                 : launch<128, 128, TA, TB, VEC>(a, s);
     const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && (!a.m_dev || TA);
     if (plain && g_splitk && g_ws && big >= 16) {
         const int splits = choose_splits((int)big, (a.K + BK - 1) / BK);
         if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
-            return x3 ? launch_splitk<128, 128, TA, TB, VEC, VEC>(a, s, splits) : launch_splitk<128, 128, TA, TB, VEC>(a, s, splits);
+            return xm == 1 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s, splits)
+                           : xm == 2 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s, splits) : launch_splitk<128, 128, TA, TB, VEC>(a, s, splits);
     }
     if (plain && g_splitk && g_ws) {
         // small contractions (the per-step h2att projection and its data gradient): split K over 64x64 tiles
@@ -598,7 +600,7 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
 }
 
 SUBGC_API int subgc_set_gemm_mode(int mode) {
-    SUBGC_REQUIRE(mode == 0 || mode == 1, "set_gemm_mode: 0 = fp32 matrix pipe, 1 = bf16 matrix pipe with 3-way split fp32 operands");
+    SUBGC_REQUIRE(mode >= 0 && mode <= 2, "set_gemm_mode: 0 = fp32 matrix pipe, 1 = bf16 pipe with 3-way split fp32 operands, 2 = bf16 operands");
     g_x3 = mode;
     return SUBGC_OK;
 }

@@ -28,9 +28,22 @@ __device__ __forceinline__ uint32_t x3_pack_hi(uint32_t hi_word, uint32_t lo_wor
     return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);   // (hi_word & 0xffff0000) | (lo_word >> 16)
 }
 
-// four consecutive-k fp32 values of one row -> 4 bf16 in each of the three planes
+// four consecutive-k fp32 values of one row -> 4 bf16 in each of the three planes.
+// TERMS == 1 is the plain bf16 mode (BASELINE configs 3 and 5: "bf16" compute, fp32 storage and accumulation):
+// ONE plane, rounded to nearest-even instead of truncated, one MFMA term.
+template <int TERMS>
 __device__ __forceinline__ void x3_split4(const float (&x)[4], uint2& p1, uint2& p2, uint2& p3) {
     uint32_t h[4], m[4], l[4];
+    if (TERMS == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t u = __float_as_uint(x[e]);
+            h[e] = u + 0x7fffu + ((u >> 16) & 1u);               // round to nearest even into the high half
+        }
+        p1.x = x3_pack_hi(h[1], h[0]); p1.y = x3_pack_hi(h[3], h[2]);
+        p2 = p1; p3 = p1;
+        return;
+    }
 #ifdef X3_FAKE_SPLIT
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h[e] = __float_as_uint(x[e]); m[e] = h[e]; l[e] = h[e]; }
@@ -50,9 +63,10 @@ __device__ __forceinline__ void x3_split4(const float (&x)[4], uint2& p1, uint2&
 }
 
 // Staging of one 128-row operand tile (VEC addressing only: ld % 4 == 0, 16-B aligned base, K % 4 == 0).
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, int TERMS>
 struct StageX3 {
     static_assert(ROWS == 128, "x3 path: 128-row tiles");
+    static constexpr int PLANES = TERMS == 1 ? 1 : 3;
     static constexpr int NV = 4;
     static constexpr int PLANE = ROWS * X3_ROW;              // bf16 elements per plane
     float4 rs[2][NV];                                        // TWO register sets: tile j lives in set (j - kt0) & 1
@@ -127,11 +141,13 @@ struct StageX3 {
             for (int v = 0; v < NV; ++v) {
                 const float x[4] = {r[v].x, r[v].y, r[v].z, r[v].w};
                 uint2 p1, p2, p3;
-                x3_split4(x, p1, p2, p3);
+                x3_split4<TERMS>(x, p1, p2, p3);
                 uint16_t* d = st + rr_[v] * X3_ROW + c4_ * 4;
                 *reinterpret_cast<uint2*>(d) = p1;
-                *reinterpret_cast<uint2*>(d + PLANE) = p2;
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                if (PLANES == 3) {
+                    *reinterpret_cast<uint2*>(d + PLANE) = p2;
+                    *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                }
             }
         } else {
             const float q[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
@@ -140,11 +156,13 @@ struct StageX3 {
             for (int e = 0; e < 4; ++e) {
                 const float x[4] = {q[0][e], q[1][e], q[2][e], q[3][e]};
                 uint2 p1, p2, p3;
-                x3_split4(x, p1, p2, p3);
+                x3_split4<TERMS>(x, p1, p2, p3);
                 uint16_t* d = st + (rg_ * 4 + e) * X3_ROW + kg_ * 4;
                 *reinterpret_cast<uint2*>(d) = p1;
-                *reinterpret_cast<uint2*>(d + PLANE) = p2;
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                if (PLANES == 3) {
+                    *reinterpret_cast<uint2*>(d + PLANE) = p2;
+                    *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                }
             }
         }
     }
@@ -160,11 +178,13 @@ struct StageX3 {
                 const bool in = ok != 0;
                 const float x[4] = {in ? r[v].x : 0.f, in ? r[v].y : 0.f, in ? r[v].z : 0.f, in ? r[v].w : 0.f};
                 uint2 p1, p2, p3;
-                x3_split4(x, p1, p2, p3);
+                x3_split4<TERMS>(x, p1, p2, p3);
                 uint16_t* d = st + rr_[v] * X3_ROW + c4_ * 4;
                 *reinterpret_cast<uint2*>(d) = p1;
-                *reinterpret_cast<uint2*>(d + PLANE) = p2;
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                if (PLANES == 3) {
+                    *reinterpret_cast<uint2*>(d + PLANE) = p2;
+                    *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                }
             }
         } else {
             const float q[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
@@ -175,33 +195,36 @@ struct StageX3 {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x[j] = ((ok >> j) & 1u) ? q[j][e] : 0.f;
                 uint2 p1, p2, p3;
-                x3_split4(x, p1, p2, p3);
+                x3_split4<TERMS>(x, p1, p2, p3);
                 uint16_t* d = st + (rg_ * 4 + e) * X3_ROW + kg_ * 4;
                 *reinterpret_cast<uint2*>(d) = p1;
-                *reinterpret_cast<uint2*>(d + PLANE) = p2;
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                if (PLANES == 3) {
+                    *reinterpret_cast<uint2*>(d + PLANE) = p2;
+                    *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                }
             }
         }
     }
 };
 
-template <int PLANE>
-__device__ __forceinline__ void x3_frag(const uint16_t* st, int r0, int kstep, int lane, bf16x8 (&out)[3]) {
+template <int PLANE, int PLANES>
+__device__ __forceinline__ void x3_frag(const uint16_t* st, int r0, int kstep, int lane, bf16x8 (&out)[PLANES]) {
     const uint16_t* p = st + (r0 + (lane & 31)) * X3_ROW + kstep * 16 + (lane >> 5) * 8;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) out[pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
+    for (int pl = 0; pl < PLANES; ++pl) out[pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
 }
 
-constexpr size_t x3_lds_bytes(int BM, int BN) { return (size_t)2 * 3 * (BM + BN) * X3_ROW * sizeof(uint16_t); }
+constexpr size_t x3_lds_bytes(int BM, int BN, int planes) { return (size_t)2 * planes * (BM + BN) * X3_ROW * sizeof(uint16_t); }
 
-template <int BM, int BN, bool TA, bool TB, int MT, int NT>
+template <int BM, int BN, bool TA, bool TB, int MT, int NT, int TERMS>
 __device__ __forceinline__ void mainloop_x3(const GemmArgs& p, float* smem_f, int M, int K, int m0, int n0, int kt0, int kt1,
                                             f32x16 (&acc)[MT][NT]) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr bool A_KM = TA, B_KM = !TB;
-    using SA = StageX3<BM, A_KM>;
-    using SB = StageX3<BN, B_KM>;
-    constexpr int STAGE = 3 * (SA::PLANE + SB::PLANE);
+    using SA = StageX3<BM, A_KM, TERMS>;
+    using SB = StageX3<BN, B_KM, TERMS>;
+    constexpr int PL = SA::PLANES;
+    constexpr int STAGE = PL * (SA::PLANE + SB::PLANE);
     uint16_t* const smem = reinterpret_cast<uint16_t*>(smem_f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
@@ -215,19 +238,19 @@ __device__ __forceinline__ void mainloop_x3(const GemmArgs& p, float* smem_f, in
         sa.template load<1>((kt0 + 1) * BK, K);
         sb.template load<1>((kt0 + 1) * BK, K);
     }
-    sa.template store<0>(smem); sb.template store<0>(smem + 3 * SA::PLANE);
+    sa.template store<0>(smem); sb.template store<0>(smem + PL * SA::PLANE);
     __syncthreads();
-    bf16x8 fa[2][MT][3], fb[2][NT][3];
+    bf16x8 fa[2][MT][PL], fb[2][NT][PL];
 #pragma unroll
-    for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE>(smem, wm + a * 32, 0, lane, fa[0][a]);
+    for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE, PL>(smem, wm + a * 32, 0, lane, fa[0][a]);
 #pragma unroll
-    for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE>(smem + 3 * SA::PLANE, wn + b * 32, 0, lane, fb[0][b]);
+    for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE, PL>(smem + PL * SA::PLANE, wn + b * 32, 0, lane, fb[0][b]);
 
     auto mfma6 = [&](int f) {
         // term order: smallest magnitude first.  Between two MFMAs on the same accumulator lie MT*NT-1 others.
         constexpr int TI[6] = {0, 2, 1, 0, 1, 0}, TJ[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = (TERMS == 1 ? 5 : 0); t < 6; ++t)
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -256,19 +279,19 @@ __device__ __forceinline__ void mainloop_x3(const GemmArgs& p, float* smem_f, in
             sb.template load<Q>((kt + 2) * BK, K);
         }
 #pragma unroll
-        for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE>(sc, wm + a * 32, 1, lane, fa[1][a]);
+        for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE, PL>(sc, wm + a * 32, 1, lane, fa[1][a]);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE>(sc + 3 * SA::PLANE, wn + b * 32, 1, lane, fb[1][b]);
+        for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE, PL>(sc + PL * SA::PLANE, wn + b * 32, 1, lane, fb[1][b]);
         mfma6(0);
         if (STEADY) {
 #ifndef X3_NO_STORE
-            sa.template store_interior<Q ^ 1>(sn); sb.template store_interior<Q ^ 1>(sn + 3 * SA::PLANE);
+            sa.template store_interior<Q ^ 1>(sn); sb.template store_interior<Q ^ 1>(sn + PL * SA::PLANE);
 #endif
         } else if (has_next) {
-            sa.template store<Q ^ 1>(sn); sb.template store<Q ^ 1>(sn + 3 * SA::PLANE);
+            sa.template store<Q ^ 1>(sn); sb.template store<Q ^ 1>(sn + PL * SA::PLANE);
         }
         mfma6(1);
-        if (STEADY) {
+        if (STEADY && TERMS == 6) {
             constexpr int NM = 2 * 6 * MT * NT, NR = 3 * (MT + NT), NW = 12, NL = 8;
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
@@ -285,9 +308,9 @@ __device__ __forceinline__ void mainloop_x3(const GemmArgs& p, float* smem_f, in
         __syncthreads();
         if (has_next) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE>(sn, wm + a * 32, 0, lane, fa[0][a]);
+            for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE, PL>(sn, wm + a * 32, 0, lane, fa[0][a]);
 #pragma unroll
-            for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE>(sn + 3 * SA::PLANE, wn + b * 32, 0, lane, fb[0][b]);
+            for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE, PL>(sn + PL * SA::PLANE, wn + b * 32, 0, lane, fb[0][b]);
         }
     };
     using Q0 = std::integral_constant<int, 0>;

@@ -32,6 +32,32 @@ def ensure_workspace(device, mbytes=96):
     return _WS["buf"]
 
 
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+class gemm_mode:
+    """`with ops.gemm_mode("bf16"): ...` -- arithmetic of the 128x128-tile GEMM forms (subgc_set_gemm_mode): "f32" (default),
+    "bf16x3" (fp32 operands split exactly into three bf16 planes, six MFMA terms) or "bf16" (operands rounded to bf16:
+    the compute type BASELINE configs 3 and 5 name).  Storage and accumulation are fp32 in every mode."""
+
+    current = "f32"
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = gemm_mode.current
+        set_gemm_mode(self.mode)
+
+    def __exit__(self, *exc):
+        set_gemm_mode(self.prev)
+
+
+def set_gemm_mode(mode):
+    call("subgc_set_gemm_mode", GEMM_MODES[mode])
+    gemm_mode.current = mode
+
+
 def _ptr(t, dtype=None):
     if t is None:
         return None

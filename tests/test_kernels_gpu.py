@@ -496,3 +496,22 @@ def test_gemm_bf16x3_split_mode_is_fp32_grade(mode, M, N, K):
     scale = float(ref.abs().max())
     assert errs[0] < 2e-5 * scale and errs[1] < 2e-5 * scale, errs
     assert errs[1] <= 2.0 * errs[0] + 1e-7 * scale, errs
+
+
+def test_gemm_bf16_mode_rounds_operands_only():
+    """mode "bf16": operands rounded to nearest-even bf16, fp32 accumulate -> equals an fp64 product of the ROUNDED operands
+    to fp32 accumulation accuracy, and differs from the exact product at the bf16 level."""
+    ops.ensure_workspace(DEV)
+    M, N, K = 2560, 4000, 1024                                   # >= 384 tiles of 128x128: the form the modes apply to
+    a, b = rnd(M, K, seed=8), rnd(N, K, seed=9)
+    out = torch.empty(M, N, device=DEV)
+    with ops.gemm_mode("bf16"):
+        ops.gemm(a, b, out, tb=True)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref_r = ar @ br.t()
+    ref = a.double() @ b.double().t()
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref_r).abs().max()) < 2e-5 * scale
+    err = float((out.double() - ref).abs().max())
+    assert 1e-4 * scale < err < 2e-2 * scale
+    assert ops.gemm_mode.current == "f32"

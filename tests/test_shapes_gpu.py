@@ -107,3 +107,36 @@ def test_full_gc_kar_full_width_train_and_decode_match_oracle():
     np.testing.assert_array_equal(ret[0].cpu().numpy(), want[0].numpy())
     close(ret[1], want[1], "seqLogprobs", atol=2e-4)
     close(ret[4], want[4], "att2_weights", atol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_full_gc_kar_bf16_compute_within_bf16_tolerance_of_fp32_oracle():
+    """BASELINE config 3 (Full_GC_Kar, bf16 compute / fp32 master): GEMM operands rounded to bf16 (ops.gemm_mode("bf16")),
+    everything else fp32.  Against the fp32 oracle: loss / log-probs atol 5e-2, and greedy tokens must agree
+    wherever the oracle's top-1/top-2 log-prob margin exceeds 2*atol."""
+    from subgc import ops
+    torch.manual_seed(9)
+    opt = argparse.Namespace(**FULLGC)
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(32, seed=12)                  # 160 sentences: the recurrent GEMMs reach the 128-row tiles
+    orc = O.Oracle(opt, sd); orc.training = True
+    with torch.no_grad():
+        ref = O.loss_wrapper(orc, batch)
+    with ops.gemm_mode("bf16"):
+        out, loss = run_train(m, batch)
+        with torch.no_grad():
+            outputs, _, _ = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+    assert torch.isfinite(loss)
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss", atol=5e-2, rtol=0)
+    close(outputs, ref["outputs"], "outputs", atol=5e-2, rtol=1e-2)
+    got = outputs.argmax(-1).cpu()
+    top2 = ref["outputs"].topk(2, -1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 0.1
+    live = ref["outputs"].abs().sum(-1) > 0
+    assert bool((got[sure & live] == ref["outputs"].argmax(-1)[sure & live]).all()) and int((sure & live).sum()) > 100
+    # and the bf16 mode really was in effect (fp32 mode matches ~100x tighter)
+    assert float((outputs.cpu() - ref["outputs"]).abs().max()) > 1e-4
