@@ -140,3 +140,33 @@ def test_full_gc_kar_bf16_compute_within_bf16_tolerance_of_fp32_oracle():
     assert bool((got[sure & live] == ref["outputs"].argmax(-1)[sure & live]).all()) and int((sure & live).sum()) > 100
     # and the bf16 mode really was in effect (fp32 mode matches ~100x tighter)
     assert float((outputs.cpu() - ref["outputs"]).abs().max()) > 1e-4
+
+
+@pytest.mark.timeout(900)
+def test_mrnn_decode_shape_many_candidates_topk_sampling():
+    """BASELINE config 4 decode (test.sh:24-30): ~1000 candidate sub-graphs per image, NMS 0.55 keeping up to 1000,
+    top-k(3) sampling at temperature 0.6.  Kept set and -- with the sampler's uniforms pinned -- every token equal the
+    oracle's; several such images decoded as ONE batch (sample_images) give the same kept sets."""
+    torch.manual_seed(13)
+    opt = argparse.Namespace(**dict(KAR, test_LSTM=1, use_topk_sampling=1, topk_temp=0.6, the_k=3, gpn_nms_thres=0.55, gpn_max_subg=1000))
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    tb = synthetic.make_test_batch(500, seed=14, node_pool=30, max_nodes=9)
+    dev_b = {k: v.to(DEV) for k, v in tb.items()}
+    probe = m(*synthetic.sample_args({k: v.clone() for k, v in dev_b.items()}), opt=dict(sample_max=1, beam_size=1), mode="sample")
+    n = probe[3].numel()
+    assert 20 < n <= 1000
+    u = torch.rand(n, opt.seq_length + 4, generator=torch.Generator().manual_seed(15))[:, :m.seq_length].contiguous()
+    ret = m._sample(*synthetic.sample_args(dev_b), opt=dict(sample_max=1, beam_size=1), uniforms=u.to(DEV))
+    want = O.Oracle(opt, sd).sample(*synthetic.sample_args(tb), opt=dict(sample_max=1, beam_size=1), uniforms=u, nms_sort_kind="stable")
+    np.testing.assert_array_equal(ret[3].cpu().numpy(), want[3].numpy())
+    same = (ret[0].cpu() == want[0]).all(1)
+    assert float(same.float().mean()) > 0.97, "sampled paths may fork where two of the top-3 renormalised probabilities straddle a uniform"
+    close(ret[1].cpu()[same], want[1][same], "seqLogprobs", atol=3e-4)
+    others = [{k: v.to(DEV) for k, v in synthetic.make_test_batch(M, seed=16 + i, node_pool=25, max_nodes=9).items()} for i, M in enumerate((300, 40))]
+    many = m.sample_images([dev_b] + others, opt=dict(sample_max=1, beam_size=1))
+    np.testing.assert_array_equal(many[0][3].cpu().numpy(), want[3].numpy())
+    assert many[0][0].shape == ret[0].shape and len(many) == 3
