@@ -376,7 +376,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 
 // data-parallel form: one workgroup per output tile
 template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(XM ? 512 : 256) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // m_dev bounds the ROWS of the stored A: M when A is [M,K], K when A is stored transposed [K,M]
@@ -391,8 +391,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
     f32x16 acc[MT][NT];
     zero_acc(acc);
-    if constexpr (XM != 0) mainloop_x3<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
-    else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+    if constexpr (XM != 0) {
+        mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+        if (threadIdx.x >= 256) return;                          // staging waves hold no accumulators
+    } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
     epilogue<BM, BN, MT, NT, false>(p, M, m0, n0, true, acc);
 }
 
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 // and splitk_reduce_kernel sums the parts and applies the (bias / accumulate) epilogue.  Both launches
 // are stream-ordered; the workspace is just-written and comes back out of L2 / Infinity Cache.
 template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
-__global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
+__global__ __launch_bounds__(XM ? 512 : 256) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
@@ -421,8 +423,10 @@ __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const GemmArgs p, 
     const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
     f32x16 acc[MT][NT];
     zero_acc(acc);
-    if constexpr (XM != 0) mainloop_x3<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
-    else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
+    if constexpr (XM != 0) {
+        mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
+        if (threadIdx.x >= 256) return;
+    } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     // raw partial tile -> ws[part][m][n]
     constexpr int WM = BM / 2, WN = BN / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -491,7 +495,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
     static bool attr_set = false;
     if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>), grid, dim3(XM ? 512 : 256), lds, s, a);
     return subgc::check_launch("subgc_gemm_f32");
 }
 
@@ -525,7 +529,7 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits) {
     const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
     static bool attr_set = false;
     if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
-    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(256), lds, s, a, g_ws, splits, per);
+    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, g_ws, splits, per);
     const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);

@@ -44,11 +44,6 @@ __device__ __forceinline__ void x3_split4(const float (&x)[4], uint2& p1, uint2&
         p2 = p1; p3 = p1;
         return;
     }
-#ifdef X3_FAKE_SPLIT
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { h[e] = __float_as_uint(x[e]); m[e] = h[e]; l[e] = h[e]; }
-    if (false)
-#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t u = __float_as_uint(x[e]);
@@ -77,7 +72,7 @@ struct StageX3 {
     int rr_[KMAJOR ? 1 : NV], c4_, kg_, rg_;
 
     __device__ __forceinline__ void init(const float* src, int64_t ld, int row0, int nrows, const int32_t* rows_idx) {
-        const int t = threadIdx.x;
+        const int t = threadIdx.x & 255;                     // producer waves of the specialised form are threads 256..511
         ld_ = ld;
         if (!KMAJOR) {
             c4_ = t & 7;
@@ -216,9 +211,18 @@ __device__ __forceinline__ void x3_frag(const uint16_t* st, int r0, int kstep, i
 
 constexpr size_t x3_lds_bytes(int BM, int BN, int planes) { return (size_t)2 * planes * (BM + BN) * X3_ROW * sizeof(uint16_t); }
 
+// ---- warp-specialised form: 512 threads = 4 MFMA waves + 4 staging waves ------------------------------------------
+// A single-role loop (one wave per SIMD interleaving ~250 staging instructions with 48 MFMAs in program order through
+// sched_group_barrier) was measured first: every latency (global load -> split -> ds_write -> barrier -> ds_read) lies
+// on its critical path and PMC showed the matrix pipe 36 % busy.  Here each SIMD hosts TWO waves with different jobs and
+// the hardware interleaves them (DESIGN.md 3.2 has the numbers of both):
+//   waves 0-3 (consumers): ds_read_b128 fragments + MFMAs of LDS stage Q, nothing else;
+//   waves 4-7 (producers): request tile kt+2 (global -> registers, two register sets), split tile kt+1 on the VALU and
+//                          write its bf16 planes into LDS stage Q^1.
+// One workgroup barrier per K-tile hands stage Q^1 to the consumers and stage Q back to the producers.
 template <int BM, int BN, bool TA, bool TB, int MT, int NT, int TERMS>
-__device__ __forceinline__ void mainloop_x3(const GemmArgs& p, float* smem_f, int M, int K, int m0, int n0, int kt0, int kt1,
-                                            f32x16 (&acc)[MT][NT]) {
+__device__ __forceinline__ void mainloop_x3_ws(const GemmArgs& p, float* smem_f, int M, int K, int m0, int n0, int kt0, int kt1,
+                                               f32x16 (&acc)[MT][NT]) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr bool A_KM = TA, B_KM = !TB;
     using SA = StageX3<BM, A_KM, TERMS>;
@@ -227,105 +231,74 @@ __device__ __forceinline__ void mainloop_x3(const GemmArgs& p, float* smem_f, in
     constexpr int STAGE = PL * (SA::PLANE + SB::PLANE);
     uint16_t* const smem = reinterpret_cast<uint16_t*>(smem_f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     if (kt1 <= kt0) return;
-    SA sa; SB sb;
-    sa.init(p.A, p.lda, m0, M, TA ? nullptr : p.a_rows);
-    sb.init(p.B, p.ldb, n0, p.N, nullptr);
-    sa.template load<0>(kt0 * BK, K);
-    sb.template load<0>(kt0 * BK, K);
-    if (kt0 + 1 < kt1) {
-        sa.template load<1>((kt0 + 1) * BK, K);
-        sb.template load<1>((kt0 + 1) * BK, K);
-    }
-    sa.template store<0>(smem); sb.template store<0>(smem + PL * SA::PLANE);
-    __syncthreads();
-    bf16x8 fa[2][MT][PL], fb[2][NT][PL];
-#pragma unroll
-    for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE, PL>(smem, wm + a * 32, 0, lane, fa[0][a]);
-#pragma unroll
-    for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE, PL>(smem + PL * SA::PLANE, wn + b * 32, 0, lane, fb[0][b]);
-
-    auto mfma6 = [&](int f) {
-        // term order: smallest magnitude first.  Between two MFMAs on the same accumulator lie MT*NT-1 others.
-        constexpr int TI[6] = {0, 2, 1, 0, 1, 0}, TJ[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-        for (int t = (TERMS == 1 ? 5 : 0); t < 6; ++t)
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][a][TI[t]], fb[f][b][TJ[t]], acc[a][b], 0, 0, 0);
-    };
-
-    // One K-tile; Q = (kt - kt0) & 1 names the LDS stage being multiplied and the register set that is FREE:
-    // tile kt+1 sits in set Q^1 (loaded one tile ago, split + written to LDS stage Q^1 now), tile kt+2 is requested
-    // into set Q at the top, a whole tile before it is needed.  STEADY (tiles kt+1, kt+2 exist and are interior): the
-    // tile is ONE scheduling region in which every MFMA is followed by its share of the other work -- with one wave
-    // per SIMD the matrix pipe only stays busy if the ~5 issue slots of each 32-cycle MFMA are filled in program order.
-    auto ktile = [&](int kt, auto q_tag, auto steady_tag) {
-        constexpr int Q = decltype(q_tag)::value;
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const uint16_t* sc = smem + Q * STAGE;
-        uint16_t* sn = smem + (Q ^ 1) * STAGE;
-        const bool has_next = STEADY || kt + 1 < kt1;
-        if (STEADY) {
-#ifndef X3_NO_VMEM
-            sa.template load_interior<Q>((kt + 2) * BK);
-            sb.template load_interior<Q>((kt + 2) * BK);
-#endif
-        } else if (kt + 2 < kt1) {
-            sa.template load<Q>((kt + 2) * BK, K);
-            sb.template load<Q>((kt + 2) * BK, K);
-        }
-#pragma unroll
-        for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE, PL>(sc, wm + a * 32, 1, lane, fa[1][a]);
-#pragma unroll
-        for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE, PL>(sc + PL * SA::PLANE, wn + b * 32, 1, lane, fb[1][b]);
-        mfma6(0);
-        if (STEADY) {
-#ifndef X3_NO_STORE
-            sa.template store_interior<Q ^ 1>(sn); sb.template store_interior<Q ^ 1>(sn + PL * SA::PLANE);
-#endif
-        } else if (has_next) {
-            sa.template store<Q ^ 1>(sn); sb.template store<Q ^ 1>(sn + PL * SA::PLANE);
-        }
-        mfma6(1);
-        if (STEADY && TERMS == 6) {
-            constexpr int NM = 2 * 6 * MT * NT, NR = 3 * (MT + NT), NW = 12, NL = 8;
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-                if (i < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // request tile kt+2
-                if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // fragment reads of k-step 1
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                       // split VALU
-                if (i >= 6 && (i & 1) == 0 && i < 6 + 2 * NW + 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // ds_write2 of finished rows
-            }
-        }
-#ifdef X3_NO_BARRIER
-        if (!STEADY)
-#endif
-        __syncthreads();
-        if (has_next) {
-#pragma unroll
-            for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE, PL>(sn, wm + a * 32, 0, lane, fa[0][a]);
-#pragma unroll
-            for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE, PL>(sn + PL * SA::PLANE, wn + b * 32, 0, lane, fb[0][b]);
-        }
-    };
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
-    int kt = kt0;
-    {
-        const int steady_end = min(kt1, K / BK) - 2;             // tiles kt+1, kt+2 must exist and be interior
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        SA sa; SB sb;
+        sa.init(p.A, p.lda, m0, M, TA ? nullptr : p.a_rows);
+        sb.init(p.B, p.ldb, n0, p.N, nullptr);
+        sa.template load<0>(kt0 * BK, K);
+        sb.template load<0>(kt0 * BK, K);
+        if (kt0 + 1 < kt1) {
+            sa.template load<1>((kt0 + 1) * BK, K);
+            sb.template load<1>((kt0 + 1) * BK, K);
+        }
+        sa.template store<0>(smem); sb.template store<0>(smem + PL * SA::PLANE);
+        __syncthreads();
+        auto ptile = [&](int kt, auto q_tag, auto steady_tag) {
+            constexpr int Q = decltype(q_tag)::value;
+            constexpr bool STEADY = decltype(steady_tag)::value;
+            uint16_t* sn = smem + (Q ^ 1) * STAGE;
+            if (STEADY) {
+                sa.template load_interior<Q>((kt + 2) * BK);
+                sb.template load_interior<Q>((kt + 2) * BK);
+                sa.template store_interior<Q ^ 1>(sn); sb.template store_interior<Q ^ 1>(sn + PL * SA::PLANE);
+            } else {
+                if (kt + 2 < kt1) {
+                    sa.template load<Q>((kt + 2) * BK, K);
+                    sb.template load<Q>((kt + 2) * BK, K);
+                }
+                if (kt + 1 < kt1) { sa.template store<Q ^ 1>(sn); sb.template store<Q ^ 1>(sn + PL * SA::PLANE); }
+            }
+            __syncthreads();
+        };
+        int kt = kt0;
+        const int steady_end = min(kt1, K / BK) - 2;
         for (; kt + 1 < steady_end; kt += 2) {
-            ktile(kt, Q0{}, std::true_type{});
-            ktile(kt + 1, Q1{}, std::true_type{});
+            ptile(kt, Q0{}, std::true_type{});
+            ptile(kt + 1, Q1{}, std::true_type{});
+        }
+        for (; kt < kt1; ++kt) {
+            if (((kt - kt0) & 1) == 0) ptile(kt, Q0{}, std::false_type{});
+            else ptile(kt, Q1{}, std::false_type{});
+        }
+    } else {
+        // ------------------------------------------------------------------ consumers
+        const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+        bf16x8 fa[2][MT][PL], fb[2][NT][PL];
+        constexpr int TI[6] = {0, 2, 1, 0, 1, 0}, TJ[6] = {2, 0, 1, 1, 0, 0};
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const uint16_t* sc = smem + ((kt - kt0) & 1) * STAGE;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) x3_frag<SA::PLANE, PL>(sc, wm + a * 32, f, lane, fa[f][a]);
+#pragma unroll
+                for (int b = 0; b < NT; ++b) x3_frag<SB::PLANE, PL>(sc + PL * SA::PLANE, wn + b * 32, f, lane, fb[f][b]);
+            }
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int t = (TERMS == 1 ? 5 : 0); t < 6; ++t)
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][a][TI[t]], fb[f][b][TJ[t]], acc[a][b], 0, 0, 0);
+            __syncthreads();
         }
     }
-    for (; kt < kt1; ++kt) {
-        if (((kt - kt0) & 1) == 0) ktile(kt, Q0{}, std::false_type{});
-        else ktile(kt, Q1{}, std::false_type{});
-    }
-    __syncthreads();
 }
