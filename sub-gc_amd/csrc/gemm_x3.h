@@ -34,13 +34,9 @@ __device__ __forceinline__ uint32_t x3_pack_hi(uint32_t hi_word, uint32_t lo_wor
 template <int TERMS>
 __device__ __forceinline__ void x3_split4(const float (&x)[4], uint2& p1, uint2& p2, uint2& p3) {
     uint32_t h[4], m[4], l[4];
-    if (TERMS == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t u = __float_as_uint(x[e]);
-            h[e] = u + 0x7fffu + ((u >> 16) & 1u);               // round to nearest even into the high half
-        }
-        p1.x = x3_pack_hi(h[1], h[0]); p1.y = x3_pack_hi(h[3], h[2]);
+    if (TERMS == 1) {                                            // v_cvt_pk_bf16_f32: two round-to-nearest-even conversions per instruction
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p1.x) : "v"(x[0]), "v"(x[1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p1.y) : "v"(x[2]), "v"(x[3]));
         p2 = p1; p3 = p1;
         return;
     }
