@@ -135,7 +135,7 @@ def pmc_traffic(a, world, launches_per_step):
         p = json.load(f)
     if p.get("gemm_launches_per_step") != launches_per_step:
         return None, f"profiles/r01_pmc_traffic.json was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
-    return round(p["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes"
+    return round(p["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (calibrated on this kernel, factor 1.0) + WRITE_SIZE, separate passes"
 
 
 def main():

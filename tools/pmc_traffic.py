@@ -5,8 +5,11 @@
            --steps-total 6 --launches-per-step 142 --alg-bytes-per-launch 5.1e7 > profiles/rNN_pmc_traffic.json
 
 Collected as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `--pmc` passes of the
-same bench command (tools/pmc_traffic.sh); rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE counts HALF the
-bytes of wide (16 B/lane) coalesced reads -- which is what every GEMM operand load here is -- so it is doubled;
+same bench command (tools/pmc_traffic.sh); rocprofv3 reports both in KiB.  The guide warns that on gfx950 FETCH_SIZE
+can count HALF the bytes of wide streaming reads and asks for a calibration on the kernel's own access pattern:
+tools/pmc_calibrate.sh runs one 128x128 tile over K = 262144 (each operand read exactly once: 268,435,456 B) and
+FETCH_SIZE reports 262,181..262,186 KiB = 268.47 MB for the NT, NN and TN forms alike -- for this kernel's loads
+(global_load_dwordx4 in 128-B row segments) the counter is exact, so NO correction factor is applied.
 WRITE_SIZE is uncalibrated and taken as reported.  A logical launch = one `subgc_gemm_f32` call = its main kernel
 plus, in split-K form, the reduce kernel (both are inside the HIP-event bracket that times it in bench.py).
 """
@@ -43,16 +46,16 @@ def main():
     a = ap.parse_args()
     f, fd = totals(a.fetch_csv, "FETCH_SIZE")
     w, wd = totals(a.write_csv, "WRITE_SIZE")
-    fetch = 2.0 * 1024.0 * sum(f.values())          # KiB -> B, x2 gfx950 wide-read correction
+    fetch = 1024.0 * sum(f.values())                # KiB -> B; calibrated factor 1.0 (see above)
     write = 1024.0 * sum(w.values())
     launches = a.steps_total * a.launches_per_step
     out = {
-        "counters": "FETCH_SIZE (x2, gfx950 wide coalesced reads) + WRITE_SIZE, separate --pmc passes, KiB",
+        "counters": "FETCH_SIZE (calibrated on this kernel: factor 1.0) + WRITE_SIZE, separate --pmc passes, KiB",
         "steps_profiled": a.steps_total, "gemm_launches_per_step": a.launches_per_step,
         "kernel_dispatches": fd,
         "fetch_bytes_per_step": fetch / a.steps_total, "write_bytes_per_step": write / a.steps_total,
         "traffic_bytes_per_launch": (fetch + write) / launches,
-        "per_kernel_bytes_per_dispatch": {k: {"fetch_x2": 2048.0 * f[k] / fd[k], "write": 1024.0 * w.get(k, 0.0) / max(wd.get(k, 1), 1)} for k in f},
+        "per_kernel_bytes_per_dispatch": {k: {"fetch": 1024.0 * f[k] / fd[k], "write": 1024.0 * w.get(k, 0.0) / max(wd.get(k, 1), 1)} for k in f},
     }
     if a.alg_bytes_per_launch:
         out["algorithmic_bytes_per_launch"] = a.alg_bytes_per_launch
