@@ -84,10 +84,88 @@ def _beam_step(grp, vals, idx, tau, bd, unk, constraint, earlier, lam):
     return src
 
 
+class _BatchEngine:
+    """All sub-graphs x beams of an image batch as rows of one DecodeState (the product path)."""
+
+    def __init__(self, pr, P, N, beam):
+        n, dev = pr.S, pr.f.device
+        self.n, self.rows, self.dev = n, n * beam, dev
+        rep = torch.arange(n, device=dev).repeat_interleave(beam)
+        prb = SimpleNamespace(S=self.rows, N=N, f=pr.f.index_select(0, rep).contiguous(), u=pr.u, v=pr.v,
+                              off=pr.off.index_select(0, rep).contiguous(), lens=pr.lens.index_select(0, rep).contiguous())
+        self.st = F_.DecodeState(prb, P, N, False)
+        self.V1 = self.st.V1
+
+    def _topk(self, logits, kk):
+        if not hasattr(self, "vals"):
+            self.vals = torch.empty(self.rows, kk, device=self.dev, dtype=torch.float32)
+            self.idx = torch.empty(self.rows, kk, device=self.dev, dtype=torch.int32)
+        ops.row_topk(logits, kk, self.vals, self.idx, log_softmax=True)
+        return self.vals.cpu().numpy(), self.idx.cpu().numpy()
+
+    def first(self, kk):                                                         # <bos>, AttModel.py:223-227
+        return self._topk(self.st.step(torch.zeros(self.rows, device=self.dev, dtype=torch.long), None, normalize=False), kk)
+
+    def advance(self, tok, kk):
+        return self._topk(self.st.step(torch.from_numpy(tok).to(self.dev), None, normalize=False), kk)
+
+    def reorder(self, src):
+        self.st.reorder(torch.from_numpy(src).to(self.dev))
+
+    def snapshot(self):
+        return [x.clone() for x in self.st.recurrent()]
+
+    def restore(self, rows, snap):
+        sel = torch.from_numpy(rows.astype(np.int64)).to(self.dev)
+        for cur, saved in zip(self.st.recurrent(), snap):
+            cur[sel] = saved[sel]
+
+
+class _StepEngine:
+    """The reference's own calling convention (CaptionModel.beam_search): a (h, c) state of shape [2, beam, R] that the
+    CALLER owns, advanced through `model.get_logprobs_state` -- one sub-graph, `beam` rows."""
+
+    def __init__(self, model, init_state, init_logprobs, args):
+        self.m, self.state, self.logp, self.args = model, tuple(init_state), init_logprobs, args
+        self.n, self.rows, self.dev, self.V1 = 1, init_logprobs.size(0), init_logprobs.device, init_logprobs.size(1)
+
+    def _topk(self, logp, kk):
+        vals = torch.empty(self.rows, kk, device=self.dev, dtype=torch.float32)
+        idx = torch.empty(self.rows, kk, device=self.dev, dtype=torch.int32)
+        ops.row_topk(logp.float().contiguous(), kk, vals, idx, log_softmax=False)
+        return vals.cpu().numpy(), idx.cpu().numpy()
+
+    def first(self, kk):
+        return self._topk(self.logp, kk)
+
+    def advance(self, tok, kk):
+        logp, self.state = self.m.get_logprobs_state(torch.from_numpy(tok).to(self.dev), *self.args, self.state)
+        return self._topk(logp, kk)
+
+    def reorder(self, src):
+        sel = torch.from_numpy(src.astype(np.int64)).to(self.dev)
+        self.state = tuple(s.index_select(1, sel) for s in self.state)
+
+    def snapshot(self):
+        return [s.clone() for s in self.state]
+
+    def restore(self, rows, snap):
+        sel = torch.from_numpy(rows.astype(np.int64)).to(self.dev)
+        self.state = tuple(s.clone() for s in self.state)
+        for cur, saved in zip(self.state, snap):
+            cur[:, sel] = saved[:, sel]
+
+
 @torch.no_grad()
 def beam_decode(pr, P, N, T, opt):
     """Decode every sub-graph of `pr` (an F_.Prepared) with beam search.
     Returns (seq [n, T] int64, seqLogprobs [n, T] fp32, done_beams) -- CPU tensors, as the reference's are."""
+    return search(_BatchEngine(pr, P, N, int(opt.get("beam_size", 10))), T, opt)
+
+
+@torch.no_grad()
+def search(eng, T, opt):
+    """The bookkeeping of CaptionModel.beam_search (:97-176) over an engine that owns the recurrent state."""
     beam = int(opt.get("beam_size", 10))
     G = int(opt.get("group_size", 1))
     lam = opt.get("diversity_lambda", 0.5)
@@ -97,28 +175,16 @@ def beam_decode(pr, P, N, T, opt):
         raise ValueError(f"beam_size {beam} must be a multiple of group_size {G}")
     lam = _F32(lam)
     bd = beam // G
-    n, dev = pr.S, pr.f.device
-    rows = n * beam
-    rep = torch.arange(n, device=dev).repeat_interleave(beam)
-    prb = SimpleNamespace(S=rows, N=N, f=pr.f.index_select(0, rep).contiguous(), u=pr.u, v=pr.v,
-                          off=pr.off.index_select(0, rep).contiguous(), lens=pr.lens.index_select(0, rep).contiguous())
-    st = F_.DecodeState(prb, P, N, False)
-    V1 = st.V1
+    n, rows, V1 = eng.n, eng.rows, eng.V1
+    if rows != n * beam:
+        raise ValueError(f"{rows} state rows for {n} sub-graph(s) x beam {beam}")
     unk = V1 - 1
     kk = min(V1, beam + 2)
     if bd > kk:
         raise ValueError("beam wider than the vocabulary")
-    vals_d = torch.empty(rows, kk, device=dev, dtype=torch.float32)
-    idx_d = torch.empty(rows, kk, device=dev, dtype=torch.int32)
-    it = torch.zeros(rows, device=dev, dtype=torch.long)
-
-    def advance(tokens):
-        ops.row_topk(st.step(tokens, None, normalize=False), kk, vals_d, idx_d, log_softmax=True)
-        return vals_d.cpu().numpy().reshape(n, G, bd, kk), idx_d.cpu().numpy().reshape(n, G, bd, kk)
-
-    tv, ti = advance(it)                                                         # <bos>, AttModel.py:223-227
-    tv, ti = tv.copy(), ti.copy()
-    init = [x.clone() for x in st.recurrent()] if G > 1 else None
+    shape = (n, G, bd, kk)
+    tv, ti = (x.reshape(shape).copy() for x in eng.first(kk))
+    init = eng.snapshot() if G > 1 else None
     groups = [[_Group(T, bd) for _ in range(G)] for _ in range(n)]
     base = np.arange(rows, dtype=np.int32).reshape(n, G, bd)
     for t in range(T + G - 1):
@@ -142,11 +208,9 @@ def beam_decode(pr, P, N, T, opt):
         if not any(g <= t + 1 <= T + g - 1 for g in range(G)):
             break                                                                # the reference's last step (:170-171) feeds nothing
         if G > 1 and 0 < t < G:                                                  # group t starts now: give it the post-<bos> state
-            sel = torch.from_numpy(base[:, t].reshape(-1).astype(np.int64)).to(dev)
-            for cur, saved in zip(st.recurrent(), init):
-                cur[sel] = saved[sel]
-        st.reorder(torch.from_numpy(src.reshape(-1)).to(dev))
-        nv, ni = advance(torch.from_numpy(tok.reshape(-1)).to(dev))
+            eng.restore(base[:, t].reshape(-1), init)
+        eng.reorder(src.reshape(-1))
+        nv, ni = (x.reshape(shape) for x in eng.advance(tok.reshape(-1), kk))
         for g in live:
             tv[:, g], ti[:, g] = nv[:, g], ni[:, g]
     seq = torch.zeros(n, T, dtype=torch.long)

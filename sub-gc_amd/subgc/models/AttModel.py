@@ -36,6 +36,7 @@ import torch.nn as nn
 from .. import functions as F_
 from .. import ops
 from . import sampling
+from . import stepapi
 from .CaptionModel import CaptionModel
 
 
@@ -229,6 +230,16 @@ class AttModel(CaptionModel):
     def init_hidden(self, bsz):
         w = self.P("logit.weight")
         return (w.new_zeros(self.num_layers, bsz, self.rnn_size), w.new_zeros(self.num_layers, bsz, self.rnn_size))
+
+    # ------------------------------------------------------------------ the reference's step-level methods (models/stepapi.py)
+    def _prepare_feature(self, fc_feats, att_feats, att_masks, sg_emb=None):
+        return stepapi.prepare_feature(self, fc_feats, att_feats, att_masks)
+
+    def get_logprobs_state(self, it, fc_feats, att_feats, p_att_feats, att_masks, state, sg_emb=None, p_sg_emb=None, return_att=False):
+        return stepapi.get_logprobs_state(self, it, fc_feats, att_feats, p_att_feats, att_masks, state, return_att)
+
+    def beam_search(self, init_state, init_logprobs, *args, **kwargs):
+        return stepapi.beam_search(self, init_state, init_logprobs, *args, **kwargs)
 
     # ------------------------------------------------------------------ dropout masks
     def _masks(self, shapes, device):

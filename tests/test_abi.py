@@ -54,5 +54,5 @@ def test_model_api_surface(golden):
         models.setup(argparse.Namespace(caption_model="show_tell"))
     with pytest.raises(ValueError):                             # beam search proper is entered through mode="sample"
         m(None, None, opt={"beam_size": 1}, mode="sample_sentences")
-    with pytest.raises(NotImplementedError):                    # the state-passing helper is not a public entry here
-        m.beam_search(None, None)
+    for name in ("_prepare_feature", "get_logprobs_state", "beam_search", "init_hidden", "sample_images"):
+        assert callable(getattr(m, name)), name
