@@ -315,6 +315,14 @@ int subgc_pad_rows_i64(const int64_t* src, const int64_t* off, int B, int R, int
 int subgc_caption_labels(const int64_t* captions, int64_t ld, int S, int seq_length, int64_t* labels,
                          float* masks, void* stream);
 
+/* Scheduled sampling (AttModel.py:157-167).  uniform: out[i] = uniform(seed, offset + i) in [0, 1), the same
+ * counter-based stream family as the dropout masks.  multinomial_rows: every row r with sel_u[r] < prob gets
+ * tok[r * tok_stride] = inverse-CDF draw (index order, u[r]) from softmax(logits[r, :V]); other rows keep their word.
+ * `logits` may be raw or log-normalised (the draw is shift-invariant).                                              */
+int subgc_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+int subgc_multinomial_rows(const float* logits, int64_t ld, int rows, int V, const float* u, const float* sel_u,
+                           float prob, int64_t* tok, int64_t tok_stride, void* stream);
+
 /* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 

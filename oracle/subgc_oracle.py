@@ -320,8 +320,11 @@ class Oracle:
     # -- train ---------------------------------------------------------------
     def forward(self, fc_feats, att_feats, seq, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
                 pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None,
-                masks=None, tap=None):
-        """AttModel._forward (AttModel.py:122-177); `masks` optionally injects dropout keep-masks."""
+                masks=None, tap=None, ss=None):
+        """AttModel._forward (AttModel.py:122-177); `masks` optionally injects dropout keep-masks.
+        `ss=(sel_u [T,n], u [T,n])` pins scheduled sampling (:157-167): row r of step i >= 1 is re-drawn iff
+        sel_u[i, r] < ss_prob (the reference's `sample_prob < self.ss_prob`), and the draw from exp(outputs[:, i-1]) is the
+        inverse CDF at u[i, r] in index order (the reference's torch.multinomial stream cannot be reproduced elsewhere)."""
         P, cfg = self.P, self.cfg
         cfg.sample_mode = False
         gpn_loss, score, att, fc, m, _ = _encode(P, cfg, (fc_feats, att_feats, att_masks, obj_dist, rel_ind, pred_dist,
@@ -335,6 +338,17 @@ class Oracle:
         g = lambda k, i: None if masks is None or masks.get(k) is None else masks[k][:, i]
         for i in range(seq.size(1) - 1):
             it = seq[:, i].clone()                                                    # ss_prob == 0 path (:168-169)
+            if self.training and i >= 1 and cfg.ss_prob > 0.0:                        # :157-167
+                if ss is None:
+                    raise ValueError("the oracle needs injected uniforms for scheduled sampling")
+                sample_mask = ss[0][i] < cfg.ss_prob
+                if sample_mask.sum() != 0:
+                    prob_prev = torch.exp(outputs[:, i - 1].detach())
+                    cdf = torch.cumsum(prob_prev, 1)
+                    draw = (cdf <= (ss[1][i] * cdf[:, -1]).unsqueeze(1)).sum(1).clamp(max=cdf.size(1) - 1)
+                    self.ss_tokens = getattr(self, "ss_tokens", {})
+                    it = torch.where(sample_mask, draw, it)
+                    self.ss_tokens[i] = it.clone()
             if i >= 1 and seq[:, i].sum() == 0:                                       # :171-172
                 break
             logp, state, _ = core_step(P, cfg, it, f, v, u, mk, state, self.training, g("xt", i), g("out", i), tap)
@@ -519,12 +533,12 @@ def lm_criterion(outputs, target, mask):
     return out.sum() / mask.sum()
 
 
-def loss_wrapper(oracle, batch, masks=None, tap=None):
+def loss_wrapper(oracle, batch, masks=None, tap=None, ss=None):
     """models/loss_wrapper.py:14-27 -> {'lang_loss', 'gpn_loss'}."""
     from_keys = ("fc_feats", "att_feats", "labels", "att_masks", None, "obj_dist", None, "rel_ind", None, "pred_dist",
                  "gpn_obj_ind", "gpn_pred_ind", "gpn_nrel_ind", "gpn_pool_mtx")
     args = [None if k is None else batch[k] for k in from_keys]
-    outputs, gpn_loss, score = oracle.forward(*args, masks=masks, tap=tap)
+    outputs, gpn_loss, score = oracle.forward(*args, masks=masks, tap=tap, ss=ss)
     lang = lm_criterion(outputs, batch["labels"][:, 1:], batch["masks"][:, 1:])
     return {"lang_loss": lang, "gpn_loss": gpn_loss, "outputs": outputs, "subgraph_score": score}
 

@@ -265,11 +265,17 @@ class DecoderFn(Function):
         fc_in = fc_in.contiguous(); X_nodes = X_nodes.contiguous()
         pr = Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale)
 
+        # scheduled sampling (AttModel.py:157-167): meta["ss"] = (prob, sel_u [T,S], u [T,S]); the input word of step
+        # t >= 1 then depends on step t-1's distribution, so embeddings / x->gates / logits are produced step by step.
+        # The sampled words are constants of the graph (the reference detaches them): the backward is unchanged.
+        ss = meta.get("ss")
+        tokens = labels if ss is None else labels[:, :T].clone()
         xt = torch.empty(T, S, E, device=dev, dtype=torch.float32)
-        for t in range(T):
-            ops.embed_fwd(emb, labels[:, t], labels.stride(0), None if k_xt is None else k_xt[t], scale, xt[t])
         Gx = torch.empty(T * S, 4 * R, device=dev, dtype=torch.float32)
-        ops.gemm(xt.view(T * S, E), w1i[:, 2 * R:], Gx, tb=True)
+        if ss is None:
+            for t in range(T):
+                ops.embed_fwd(emb, labels[:, t], labels.stride(0), None if k_xt is None else k_xt[t], scale, xt[t])
+            ops.gemm(xt.view(T * S, E), w1i[:, 2 * R:], Gx, tb=True)
         Gf = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
         ops.gemm(pr.f, w1i[:, R:2 * R], Gf, tb=True)
         Wc1 = _cat_weights(w1i[:, :R], w1h)           # [4R, 2R]  x [h2_prev | h1_prev]
@@ -286,7 +292,15 @@ class DecoderFn(Function):
         AL = torch.empty(T, S, N, device=dev, dtype=torch.float32)
         pre = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
         Gx3 = Gx.view(T, S, 4 * R)
+        logits = torch.empty(S * T, V1, device=dev, dtype=torch.float32)
+        logits3 = logits.view(S, T, V1)
         for t in range(T):
+            if ss is not None:
+                if t >= 1:
+                    ops.gemm(Hout[:, t - 1, :], lg_w, logits3[:, t - 1, :], tb=True, bias=lg_b)     # raw logits of the previous step
+                    ops.multinomial_rows_(logits3[:, t - 1, :], ss[2][t], ss[1][t], ss[0], tokens[:, t])
+                ops.embed_fwd(emb, tokens[:, t], tokens.stride(0), None if k_xt is None else k_xt[t], scale, xt[t])
+                ops.gemm(xt[t], w1i[:, 2 * R:], Gx3[t], tb=True)
             ops.gemm(H1[t], Wc1, pre, tb=True)
             ops.lstm_fwd(pre, Gx3[t], Gf, b1i, b1h, C1[t], C1[t + 1], H2[t][:, R:2 * R], H1[t + 1][:, R:], None, 1.0, None, G1[t], S, R)
             ops.gemm(H2[t][:, R:2 * R], h2a_w, AH[t], tb=True, bias=h2a_b)
@@ -294,8 +308,10 @@ class DecoderFn(Function):
             ops.gemm(H2[t], Wc2, pre, tb=True)
             ops.lstm_fwd(pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
                          None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
-        logits = torch.empty(S * T, V1, device=dev, dtype=torch.float32)
-        ops.gemm(Hout.view(S * T, R), lg_w, logits, tb=True, bias=lg_b)
+        if ss is None:
+            ops.gemm(Hout.view(S * T, R), lg_w, logits, tb=True, bias=lg_b)
+        else:
+            ops.gemm(Hout[:, T - 1, :], lg_w, logits3[:, T - 1, :], tb=True, bias=lg_b)
         active = ops.step_active(labels, T)
         ops.log_softmax_rows_(logits, active)
 
@@ -311,6 +327,7 @@ class DecoderFn(Function):
         ctx.nll_scratch = nll_scratch
         ctx.params = P
         ctx.set_materialize_grads(False)
+        ctx.tokens_used = tokens
         ctx.save_for_backward(labels, fc_in, X_nodes, lens, logits, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
         return logits.view(S, T, V1), loss
 
@@ -404,8 +421,9 @@ class DecoderFn(Function):
         dxt = new(T * S, E); ops.gemm(P1, w1i[:, 2 * R:], dxt)
         d_emb = out_for(8, zero=True)
         dxt3 = dxt.view(T, S, E)
+        toks = ctx.tokens_used                       # the words actually fed (ground truth, or scheduled-sampling draws)
         for t in range(T):
-            ops.embed_bwd(emb, labels[:, t], labels.stride(0), None if k_xt is None else k_xt[t], scale, dxt3[t], d_emb)
+            ops.embed_bwd(emb, toks[:, t], toks.stride(0), None if k_xt is None else k_xt[t], scale, dxt3[t], d_emb)
         dAH2 = dAH.view(T * S, A)
         wgrad(17, dAH2, H2a[:, R:2 * R])
         bgrad(18, dAH2)

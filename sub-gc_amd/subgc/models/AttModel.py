@@ -22,7 +22,8 @@ What is different by design (MI355X-first):
   * the attention sets are ragged-packed once; padded rows are never computed.
 
 Unsupported reference options fail loudly: `use_bn != 0` (BatchNorm inside att_embed, unused by
-every preset), scheduled sampling (`ss_prob > 0`), beam search.
+every preset).  Scheduled sampling (`ss_prob > 0`) runs through DecoderFn with per-step logits and its own
+counter-based RNG stream; beam search lives in `subgc/beam.py`.
 """
 from __future__ import annotations
 
@@ -109,6 +110,7 @@ class AttModel(CaptionModel):
         self.dropout_seed = g("seed", 2019)
         self._dropout_calls = 0
         self.injected_masks = None       # tests inject {'fc','att','xt','out','gpn_hid'} keep-masks here
+        self.injected_ss = None          # tests inject (selector uniforms [T,S], draw uniforms [T,S]) for scheduled sampling
         self._build_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -371,8 +373,6 @@ class AttModel(CaptionModel):
         decoder Function, so its backward never materialises the dense d(log-probs); the value is left in
         `self.fused_lang_loss`.  The returned tuple is the reference's either way, except that with
         `need_outputs=False` (LossWrapper only wants the loss) `outputs` is None and the decoder runs packed."""
-        if self.training and self.ss_prob > 0.0:
-            raise NotImplementedError("scheduled sampling (ss_prob > 0, AttModel.py:158-167) is not built on the HIP path")
         B, N, _ = att_feats.shape
         dev = att_feats.device
         L, R, E = self.GCN_dim, self.rnn_size, self.input_encoding_size
@@ -398,7 +398,17 @@ class AttModel(CaptionModel):
             sel_idx = ar.expand(b5, N).contiguous()
         lens = mask_sel.sum(1).to(torch.int32)
         meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit}
-        if fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None:
+        ss_on = self.training and self.ss_prob > 0.0
+        if ss_on:                                                                         # scheduled sampling, AttModel.py:157-167
+            if self.injected_ss is not None:
+                sel_u, u = self.injected_ss
+            else:
+                self._dropout_calls += 1
+                seed = (self.dropout_seed * 1000003 + self._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+                both = ops.uniform((2, T, b5), seed ^ 0x5C4ED51ED5A3B11F, 0, dev)
+                sel_u, u = both[0], both[1]
+            meta["ss"] = (float(self.ss_prob), sel_u.contiguous(), u.contiguous())
+        if fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None and not ss_on:
             # loss-only call (LossWrapper): length-sorted packed decoder, dead (masked-out) steps are never computed
             from ..functions_packed import PackedDecoderLossFn
             self.fused_lang_loss = PackedDecoderLossFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx,

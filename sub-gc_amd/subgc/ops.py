@@ -320,6 +320,20 @@ def row_topk(x, k, vals, idx, log_softmax=True):
     return vals, idx
 
 
+def uniform(shape, seed, offset, device):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("subgc_uniform_f32", _ptr(out), out.numel(), int(seed), int(offset), _stream())
+    return out
+
+
+def multinomial_rows_(logits, u, sel_u, prob, tok):
+    """tok[r] <- draw from softmax(logits[r]) where sel_u[r] < prob (in place; `tok` may be a strided column of int64)."""
+    rows, V = logits.shape
+    call("subgc_multinomial_rows", _ptr(logits, torch.float32), ld(logits), rows, V, _ptr(u, torch.float32), _ptr(sel_u, torch.float32),
+         float(prob), _ptr(tok, torch.int64), tok.stride(0) if tok.dim() else 1, _stream())
+    return tok
+
+
 def rank_desc(score):
     """(sorted scores, order): stable descending sort of a 1-D fp32 score vector (eval_utils.py:106)."""
     score = score.contiguous()
