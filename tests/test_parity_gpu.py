@@ -273,3 +273,44 @@ def test_sample_images_batch_equals_one_image_calls(golden, sample_opt):
         assert len(m.done_beams) == len(ims) and all(len(per) == r[0].shape[0] for per, r in zip(m.done_beams, batch))
     else:
         assert len(lens) > 1, "the images should stop at different steps for this test to mean something"
+
+
+def test_reference_style_training_loop_without_flat_bucket(golden):
+    """train.py:143-160 as written: torch Adam over model.parameters(), optimizer.zero_grad() (grads -> None), backward,
+    clip_gradient (misc/utils.py:174-178), step -- no flatten_grads(), no reducer.  Gradients must equal the flat-bucket
+    path's and the loss must go down."""
+    g = golden("subgc_train")
+    w = g.group("weights")
+    batch = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+
+    def loss_of(m):
+        out = models.LossWrapper(m, None)(batch["fc_feats"], batch["att_feats"], batch["labels"], batch["masks"], batch["att_masks"], None, None,
+                                          None, batch["obj_dist"], None, batch["rel_ind"], None, batch["pred_dist"], batch["gpn_obj_ind"],
+                                          batch["gpn_pred_ind"], batch["gpn_nrel_ind"], batch["gpn_pool_mtx"])
+        return out["lang_loss"].mean() + out["gpn_loss"].mean()
+
+    ref_m = build(g, w, True)
+    ref_m.flatten_grads()
+    loss_of(ref_m).backward()
+    m = build(g, w, True)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    losses = []
+    for it in range(4):
+        opt.zero_grad()
+        assert all(p.grad is None for p in m.parameters())
+        loss = loss_of(m)
+        loss.backward()
+        if it == 0:
+            for (n, p), (_, q) in zip(m.named_parameters(), ref_m.named_parameters()):
+                if q.grad is not None and float(q.grad.abs().max()) > 0:
+                    assert p.grad is not None, n
+                    close(p.grad, q.grad, "grad " + n, atol=1e-6, rtol=1e-5)
+        for group in opt.param_groups:                                  # utils.clip_gradient
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.grad.data.clamp_(-0.1, 0.1)
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(w.keys()) and all(torch.isfinite(v).all() for v in sd.values())
