@@ -152,7 +152,12 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true", help="also time the fused clip+Adam step (reported separately)")
     a = ap.parse_args()
 
-    rank, local, world = parallel.init_distributed()
+    # SUBGC_BENCH_REHEARSAL=1: run the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo carrying the tensors) --
+    # a functional rehearsal of the launch contract, not a measurement
+    rehearsal = os.environ.get("SUBGC_BENCH_REHEARSAL") == "1"
+    rank, local, world = parallel.init_distributed("gloo" if rehearsal else None)
+    if rehearsal:
+        local = 0
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", local)
@@ -200,12 +205,14 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss.item())
 
+    # one untimed accounting step: exact (ragged-aware) GEMM FLOPs.  EVERY rank runs it -- the step contains the gradient
+    # all-reduce, so a rank-0-only step would wait for its peers forever
+    ops.FLOPS.update(on=(rank == 0), gemm=0.0, gemm_bytes=0.0, gemm_calls=0)
+    step()
+    fence()
+    ops.FLOPS["on"] = False
     if rank == 0:
         n_launch, gemm_ms, _nominal = _lib.prof_collect("gemm")
-        ops.FLOPS.update(on=True, gemm=0.0, gemm_bytes=0.0, gemm_calls=0)   # one untimed accounting step: exact (ragged-aware) GEMM FLOPs
-        step()
-        torch.cuda.synchronize()
-        ops.FLOPS["on"] = False
         flops_step = ops.FLOPS["gemm"]
         alg_bytes_launch = ops.FLOPS["gemm_bytes"] / max(ops.FLOPS["gemm_calls"], 1)
         traffic, traffic_note = pmc_traffic(a, world, n_launch // max(a.steps, 1))
