@@ -314,3 +314,34 @@ def test_reference_style_training_loop_without_flat_bucket(golden):
     assert losses[-1] < losses[0]
     sd = m.state_dict()
     assert set(sd.keys()) == set(w.keys()) and all(torch.isfinite(v).all() for v in sd.values())
+
+
+def test_training_trajectory_matches_oracle_with_clip_norm_and_adam(golden):
+    """8 optimisation steps of train.py:151-166 (loss -> backward -> clip_gradient_norm(10) -> Adam 5e-4): the HIP model with
+    the fused FlatAdam sweep against the oracle parameters driven by torch.optim.Adam + the reference's norm clip."""
+    from subgc import parallel
+    g = golden("subgc_train")
+    w = g.group("weights")
+    batch = g.tensors("inputs")
+    m = build(g, w, True)
+    adam = parallel.FlatAdam(m, lr=5e-4)
+    orc = O.Oracle(g.opt(gpn_drop_prob=0.0), w, requires_grad=True)
+    orc.training = True
+    params = [p for p in orc.P.values() if p.requires_grad]
+    topt = torch.optim.Adam(params, 5e-4, (0.9, 0.999), 1e-8)
+    for it in range(8):
+        out, loss = run_train(m, batch)                               # flatten_grads() + fwd + bwd
+        adam.step()
+        topt.zero_grad()
+        ref = O.loss_wrapper(orc, batch)
+        rl = ref["lang_loss"] + ref["gpn_loss"]
+        rl.backward()
+        total = torch.sqrt(sum((p.grad.norm(2) ** 2 for p in params if p.grad is not None)))     # misc/utils.py:189-199
+        coef = 10.0 / max(float(total), 10.0)
+        for p in params:
+            if p.grad is not None:
+                p.grad.mul_(coef)
+        topt.step()
+        close(loss, rl, f"loss at step {it}", atol=2e-4, rtol=1e-4)
+    for k in ("logit.weight", "core.att_lstm.weight_ih", "obj_v_proj.weight", "gpn_layer.gpn_fc.0.weight"):
+        close(m.P(k), orc.P[k], "param " + k, atol=2e-5, rtol=1e-3)
