@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--packed-only", action="store_true", help="skip the extra unpacked-decoder leg (clean profiles)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time the fused clip+Adam step (reported separately)")
+    ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
 
     # SUBGC_BENCH_REHEARSAL=1: run the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo carrying the tensors) --
@@ -166,6 +167,7 @@ def main():
     torch.manual_seed(1234)                     # identical replicas on every rank
     opt = argparse.Namespace(**KAR)
     model = models.setup(opt).to(dev).train()
+    model.ss_prob = a.ss_prob
     lw = models.LossWrapper(model, None)
     batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=1000 + rank).items()}
     red = parallel.GradBucketReducer(model)
@@ -227,7 +229,8 @@ def main():
                                    "2048-d region feats, 5 sentences/image, 2 pos + 2 neg sub-graphs/sentence, T=17, V+1=9488, dropout on",
                        "images_per_gpu": a.batch, "global_images": imgs, "parallelism": f"dp{world}" if world > 1 else "single",
                        "decoder": "packed (length-sorted, loss-only: masked-out steps skipped; identical loss and gradients)",
-                       "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")},
+                       "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")
+                                   + (f" + scheduled sampling p={a.ss_prob} (per-step logits and draws)" if a.ss_prob > 0 else "")},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,

@@ -71,11 +71,18 @@ class PackedDecoderLossFn(Function):
         X_nodes = X_nodes.contiguous()
         pr = F_.Prepared(fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale)
 
+        # scheduled sampling (AttModel.py:157-167; see functions.DecoderFn): input words, x->gates and logits go step by step
+        ss = meta.get("ss")
+        tokens_p = labels_p
+        if ss is not None:
+            tokens_p = labels_p[:, :T].clone()
+            sel_p, u_p = ss[1].index_select(1, perm).contiguous(), ss[2].index_select(1, perm).contiguous()
         xt = new(max(rows, 1), E)
-        for t in range(T_live):
-            ops.embed_fwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[ot[t]:ot[t + 1]])
         Gx = new(max(rows, 1), 4 * R)
-        ops.gemm(xt[:rows], w1i[:, 2 * R:], Gx[:rows], tb=True)
+        if ss is None:
+            for t in range(T_live):
+                ops.embed_fwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[ot[t]:ot[t + 1]])
+            ops.gemm(xt[:rows], w1i[:, 2 * R:], Gx[:rows], tb=True)
         Gf = new(S, 4 * R)
         ops.gemm(pr.f, w1i[:, R:2 * R], Gf, tb=True)
         Wc1 = F_._cat_weights(w1i[:, :R], w1h)
@@ -88,10 +95,18 @@ class PackedDecoderLossFn(Function):
         Hout, G1, G2 = new(max(rows, 1), R), new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R)
         AH, AL = new(max(rows, 1), A), new(max(rows, 1), N)
         pre = new(S, 4 * R)
+        logits = new(max(rows, 1), V1)
         for t in range(T_live):
             m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
             o1 = ot[t + 1]
             mn_ = max(mn, 1)                                    # row limit 0 means "all" in the C ABI: write 1 dummy row into the slack
+            if ss is not None:
+                if t >= 1:                                      # raw logits of every row live at step t-1; draws for the rows still live now
+                    op, mp = ot[t - 1], M[t - 1]
+                    ops.gemm(Hout[op:op + mp], lg_w, logits[op:op + mp], tb=True, bias=lg_b)
+                    ops.multinomial_rows_(logits[op:op + m], u_p[t][:m], sel_p[t][:m], ss[0], tokens_p[:m, t])
+                ops.embed_fwd(emb, tokens_p[:, t], tokens_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[o:o + m])
+                ops.gemm(xt[o:o + m], w1i[:, 2 * R:], Gx[o:o + m], tb=True)
             ops.gemm(H1[o:o + m], Wc1, pre[:m], tb=True)
             ops.lstm_fwd(pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R], H1[o1:o1 + mn_, R:],
                          None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
@@ -100,8 +115,11 @@ class PackedDecoderLossFn(Function):
             ops.gemm(H2[o:o + m], Wc2, pre[:m], tb=True)
             ops.lstm_fwd(pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R], H2[o1:o1 + mn_, 2 * R:],
                          None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R, rows_h=mn_, rows_h2=mn_)
-        logits = new(max(rows, 1), V1)
-        ops.gemm(Hout[:rows], lg_w, logits[:rows], tb=True, bias=lg_b)
+        if ss is None:
+            ops.gemm(Hout[:rows], lg_w, logits[:rows], tb=True, bias=lg_b)
+        elif T_live > 0:
+            op = ot[T_live - 1]
+            ops.gemm(Hout[op:rows], lg_w, logits[op:rows], tb=True, bias=lg_b)
         ops.log_softmax_rows_(logits[:rows])
         # criterion over the packed rows: row ot[t] + s  <->  (sentence perm[s], step t)
         tgt_p = torch.cat([target.index_select(0, perm[:M[t]])[:, t] for t in range(T_live)]).contiguous().view(-1, 1)
@@ -112,7 +130,7 @@ class PackedDecoderLossFn(Function):
 
         ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
         ctx.masks = (k_xt, k_out)
-        ctx.pr, ctx.params, ctx.aux = pr, P, (perm, labels_p, lens_p, tgt_p, msk_p, nll)
+        ctx.pr, ctx.params, ctx.aux = pr, P, (perm, tokens_p, lens_p, tgt_p, msk_p, nll)      # tokens_p: the words actually fed
         ctx.save_for_backward(fc_in, X_nodes, logits, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
         return loss
 

@@ -408,7 +408,7 @@ class AttModel(CaptionModel):
                 both = ops.uniform((2, T, b5), seed ^ 0x5C4ED51ED5A3B11F, 0, dev)
                 sel_u, u = both[0], both[1]
             meta["ss"] = (float(self.ss_prob), sel_u.contiguous(), u.contiguous())
-        if fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None and not ss_on:
+        if fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None:
             # loss-only call (LossWrapper): length-sorted packed decoder, dead (masked-out) steps are never computed
             from ..functions_packed import PackedDecoderLossFn
             self.fused_lang_loss = PackedDecoderLossFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx,
