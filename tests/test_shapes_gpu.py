@@ -170,3 +170,31 @@ def test_mrnn_decode_shape_many_candidates_topk_sampling():
     many = m.sample_images([dev_b] + others, opt=dict(sample_max=1, beam_size=1))
     np.testing.assert_array_equal(many[0][3].cpu().numpy(), want[3].numpy())
     assert many[0][0].shape == ret[0].shape and len(many) == 3
+
+
+@pytest.mark.timeout(900)
+def test_soak_full_size_training_with_dropout_sampling_and_fused_adam():
+    """60 optimisation steps at the full Sub_GC_Kar width (B=16 images, dropout 0.5, scheduled sampling 0.25 from step 30,
+    fused clip+Adam): finite throughout, the loss falls well below its starting value on a fixed batch, and the flat
+    parameter buffer stays consistent with the state_dict views."""
+    from subgc import parallel
+    torch.manual_seed(21)
+    m = models.setup(argparse.Namespace(**dict(KAR, drop_prob_lm=0.5, gpn_drop_prob=0.5))).to(DEV).train()
+    lw = models.LossWrapper(m, None)
+    adam = parallel.FlatAdam(m, lr=5e-4)
+    b = {k: v.to(DEV) for k, v in synthetic.make_train_batch(16, seed=22).items()}
+    losses = []
+    for it in range(60):
+        m.ss_prob = 0.25 if it >= 30 else 0.0
+        m.flatten_grads()
+        out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
+                 None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+        loss = out["lang_loss"] + out["gpn_loss"]
+        loss.backward()
+        adam.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < 0.75 * np.mean(losses[:3]), (losses[:3], losses[-5:])
+    sd = m.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    assert sd["logit.weight"].data_ptr() == m.P("logit.weight").data_ptr()
