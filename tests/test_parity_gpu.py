@@ -345,3 +345,22 @@ def test_training_trajectory_matches_oracle_with_clip_norm_and_adam(golden):
         close(loss, rl, f"loss at step {it}", atol=2e-4, rtol=1e-4)
     for k in ("logit.weight", "core.att_lstm.weight_ih", "obj_v_proj.weight", "gpn_layer.gpn_fc.0.weight"):
         close(m.P(k), orc.P[k], "param " + k, atol=2e-5, rtol=1e-3)
+
+
+def test_images_without_candidate_subgraphs(golden):
+    """Empty inputs: an image with zero candidate sub-graphs decodes to empty tuples, alone or inside a batch, greedy or beam."""
+    g = golden("subgc_greedy")
+    m = build(g, golden("subgc_train").group("weights"), False)
+    D = g.meta["opt"]["att_feat_size"]
+    mk = lambda M, s: {k: v.to(DEV) for k, v in synthetic.make_test_batch(M, D=D, seed=s, fc_size=D).items()}
+    e, n = mk(0, 1), mk(5, 2)
+    r = m(*synthetic.sample_args(e), opt=dict(sample_max=1, beam_size=1, return_att=1), mode="sample")
+    assert [tuple(x.shape) for x in r] == [(0, 20), (0, 20), (0,), (0,), (0, 0, 0)]
+    r = m(*synthetic.sample_args(e), opt=dict(sample_max=1, beam_size=2), mode="sample")
+    assert tuple(r[0].shape) == (0, 20)
+    alone = m(*synthetic.sample_args({k: v.clone() for k, v in n.items()}), opt=dict(sample_max=1, beam_size=1), mode="sample")
+    rs = m.sample_images([e, n, e], opt=dict(sample_max=1, beam_size=1))
+    assert [r[0].shape[0] for r in rs] == [0, alone[0].shape[0], 0]
+    np.testing.assert_array_equal(rs[1][0].cpu().numpy(), alone[0].cpu().numpy())
+    rs = m.sample_images([e, n], opt=dict(sample_max=1, beam_size=3))
+    assert [len(d) for d in m.done_beams] == [0, rs[1][0].shape[0]]
