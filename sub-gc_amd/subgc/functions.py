@@ -474,8 +474,9 @@ class DecodeState:
         self.Wc1 = _cat_weights(w1i[:, :R], w1h)
         self.Wc2 = _cat_weights(w2i, w2h)
         self.W1x = w1i[:, 2 * R:]
+        self.W1f = w1i[:, R:2 * R]
         self.Gf = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
-        ops.gemm(pr.f, w1i[:, R:2 * R], self.Gf, tb=True)
+        ops.gemm(pr.f, self.W1f, self.Gf, tb=True)
         self.H1 = ops.zeros(S, 2 * R, device=dev)           # [h2 | h1]
         self.H2 = ops.zeros(S, 3 * R, device=dev)           # [ctx | h1 | h2]
         self.C1 = [ops.zeros(S, R, device=dev), torch.empty(S, R, device=dev)]
@@ -485,6 +486,12 @@ class DecodeState:
         self.hout, self.logits = new(S, R), new(S, self.V1)
         self.want_att = want_att
         self._alt = None
+
+    def reset(self):
+        """Start a new decode on the SAME buffers (hipGraph replay: `pr`'s tensors were overwritten in place)."""
+        ops.gemm(self.pr.f, self.W1f, self.Gf, tb=True)
+        for buf in (self.H1, self.H2, self.C1[0], self.C2[0]):
+            ops.fill_(buf, 0.0)
 
     # -- beam search support (CaptionModel.py:76-90 "rearrange recurrent states") -------------------
     def recurrent(self):

@@ -13,6 +13,8 @@ image's tuple equals what a one-image call returns.
 """
 from __future__ import annotations
 
+from types import SimpleNamespace
+
 import torch
 
 from .. import beam
@@ -107,6 +109,69 @@ def full_graph_rows(m, X2, N, images):
     return out
 
 
+class _GraphedLoop:
+    """The token loop of ONE image as a replayable hipGraph (torch.cuda.CUDAGraph over the C-ABI launches).
+
+    The reference-shaped call decodes <= 10 rows per step: ~12 kernels of 5-30 us each, 21 steps -- launch-bound.  For a
+    given row count the launch sequence is static (the early break is device-side), so it is captured once on buffers
+    of fixed address and replayed per image; the image's prepared features are copied into those buffers first.
+    Keyed by (rows, N, attention rows capacity, k, return_att) and by the version of the flat parameter buffer (the
+    K-concatenated LSTM weights inside DecodeState are snapshots of the parameters)."""
+
+    def __init__(self, m, n, N, k, return_att, P):
+        dev = m.flat_params.device
+        T, R, A = m.seq_length, m.rnn_size, m.att_hid_size
+        self.n, self.N, self.T, self.k, self.return_att = n, N, T, k, return_att
+        cap = n * N
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
+        self.st = F_.DecodeState(self.pr, P, N, return_att)
+        self.seq, self.seqlp = z(n, T, dt=torch.long), z(n, T)
+        self.it, self.unfinished, self.counts = z(n, dt=torch.long), z(n, dt=torch.int32), z(T, dt=torch.int32)
+        self.AL = z(T + 1, n, N) if return_att else None
+        self.u = z(T, n) if k else None
+        self.topk_temp = m.topk_temp
+        self._loop()                                                             # eager warm-up (sets kernel attributes, fills caches)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._loop()
+
+    def _loop(self):
+        T = self.T
+        self.st.reset()
+        for b in (self.seq, self.seqlp, self.it, self.unfinished, self.counts) + ((self.AL,) if self.AL is not None else ()):
+            b.zero_()
+        for t in range(T + 1):
+            logp = self.st.step(self.it, self.AL[t] if self.return_att else None, normalize=False)
+            if t == T:
+                break
+            ops.decode_pick(logp, self.k, self.topk_temp, None if self.u is None else self.u[t], t, self.seq, self.seqlp, self.it,
+                            self.unfinished, self.counts[t:t + 1], self.counts[t - 1:t] if t > 0 else None, raw=True)
+
+    def run(self, pr, uniforms):
+        rows = pr.u.size(0)
+        self.pr.f.copy_(pr.f)
+        self.pr.u[:rows].copy_(pr.u); self.pr.v[:rows].copy_(pr.v)
+        self.pr.off.copy_(pr.off); self.pr.lens.copy_(pr.lens)
+        if self.u is not None:
+            self.u.copy_(uniforms.t())
+        self.graph.replay()
+        return self.seq.clone(), self.seqlp.clone(), self.counts, (self.AL.clone() if self.AL is not None else None)
+
+
+def _graphed_loop(m, n, N, k, return_att, P):
+    key = (n, N, k, return_att, m.flat_params.data_ptr(), m.flat_params._version)
+    cache = m.__dict__.setdefault("_graph_cache", {})
+    if key not in cache:
+        for old in [q for q in cache if q[:4] == key[:4]]:                       # parameters changed: drop the stale snapshot
+            del cache[old]
+        if len(cache) >= 24:
+            cache.clear()
+        cache[key] = _GraphedLoop(m, n, N, k, return_att, P)
+    return cache[key]
+
+
 @torch.no_grad()
 def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     """Greedy / top-k / beam decode of the selected sub-graphs of one or many images as ONE batch.
@@ -131,25 +196,29 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
         seq, seqlp, done = beam.beam_decode(pr, P, N, T, opt)
         m.done_beams = done if len(sel) == 1 else [done[a:b] for a, b in zip(bounds, bounds[1:])]
         return [(seq[a:b], seqlp[a:b], s["score"], s["keep"]) for s, a, b in zip(sel, bounds, bounds[1:])]
-    st = F_.DecodeState(pr, P, N, return_att)
-    seq = torch.zeros(n, T, device=dev, dtype=torch.long)
-    seqlp = torch.zeros(n, T, device=dev)
-    it = torch.zeros(n, device=dev, dtype=torch.long)
-    unfinished = torch.zeros(n, device=dev, dtype=torch.int32)
-    counts = torch.zeros(T, device=dev, dtype=torch.int32)
-    AL = torch.zeros(T + 1, n, N, device=dev) if return_att else None
     k = m.the_k if m.topk_sampling else 0
     if k and uniforms is None and forced is None:
         uniforms = torch.rand(n, T, device=dev)
-    for t in range(T + 1):
-        logp = st.step(it, AL[t] if return_att else None, normalize=forced is not None)
-        if t == T:
-            break
-        if forced is not None:
-            _forced_pick(logp, forced[:, t].contiguous(), k, m.topk_temp, t, seq, seqlp, it, unfinished, counts)
-        else:
-            ops.decode_pick(logp, k, m.topk_temp, None if uniforms is None else uniforms[:, t].contiguous(), t, seq, seqlp, it,
-                            unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
+    if len(sel) == 1 and forced is None and n <= 16 and getattr(m, "decode_hipgraph", True):
+        # the reference-shaped call (one image, <= 10 rows): launch-bound, replayed as one hipGraph
+        seq, seqlp, counts, AL = _graphed_loop(m, n, N, k, return_att, P).run(pr, uniforms)
+    else:
+        st = F_.DecodeState(pr, P, N, return_att)
+        seq = torch.zeros(n, T, device=dev, dtype=torch.long)
+        seqlp = torch.zeros(n, T, device=dev)
+        it = torch.zeros(n, device=dev, dtype=torch.long)
+        unfinished = torch.zeros(n, device=dev, dtype=torch.int32)
+        counts = torch.zeros(T, device=dev, dtype=torch.int32)
+        AL = torch.zeros(T + 1, n, N, device=dev) if return_att else None
+        for t in range(T + 1):
+            logp = st.step(it, AL[t] if return_att else None, normalize=forced is not None)
+            if t == T:
+                break
+            if forced is not None:
+                _forced_pick(logp, forced[:, t].contiguous(), k, m.topk_temp, t, seq, seqlp, it, unfinished, counts)
+            else:
+                ops.decode_pick(logp, k, m.topk_temp, None if uniforms is None else uniforms[:, t].contiguous(), t, seq, seqlp, it,
+                                unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
     if len(sel) == 1:
         steps = None
         if return_att:
