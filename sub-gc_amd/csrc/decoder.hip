@@ -446,8 +446,7 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 }
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, int64_t n, float p, uint64_t seed,
                                                            uint64_t offset) {
-    // one Philox block = 4 x u32 -> 16 mask bytes (each byte compared on its own 8-bit... no: use
-    // 4 words -> 4 uniforms; to stay cheap we draw 4 uniforms per counter and emit 4 bytes)
+    // one Philox counter = 4 x u32 -> 4 uniforms (top 24 bits of each word) -> 4 mask bytes
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t ctr = offset / 4 + (uint64_t)q;
         uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
