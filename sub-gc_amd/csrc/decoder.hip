@@ -364,6 +364,10 @@ __device__ __forceinline__ void block_argmax(float& v, int& i, float* sv, int* s
         if (sv[k] > v || (sv[k] == v && si[k] < i)) { v = sv[k]; i = si[k]; }
 }
 constexpr int MAXK = 8;
+// One workgroup per row.  The row (<= 256*PER logits) is loaded into registers ONCE, with every load in flight together:
+// the first version walked the row two to k+3 times with dependent strided loads and cost 20 us for ten 38 KB rows --
+// the largest single kernel of the one-image decode step.
+template <int PER>
 __global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restrict__ logp, int64_t ld, int n, int V, int k, float temp,
                                                           const float* __restrict__ u, int t, int64_t* __restrict__ seq,
                                                           float* __restrict__ seqlp, int T, int64_t* __restrict__ next_tok,
@@ -375,42 +379,54 @@ __global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restric
     __shared__ float smf[16];
     const int r = blockIdx.x;
     const float* p = logp + (int64_t)r * ld;
+    float x[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = threadIdx.x + j * 256;
+        x[j] = c < V ? p[c] : -INFINITY;
+    }
     int it; float lp;
     if (k <= 0) {
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int c = threadIdx.x; c < V; c += blockDim.x) {
-            const float x = p[c];
-            if (x > bv || bi == 0x7fffffff) { bv = x; bi = c; }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int c = threadIdx.x + j * 256;
+            if (c < V && (x[j] > bv || bi == 0x7fffffff)) { bv = x[j]; bi = c; }
         }
         block_argmax(bv, bi, sv, si);
         it = bi; lp = bv;
         if (raw) {                                // raw logits: log_softmax(x)[argmax] = -log sum exp(x - max)
             float sum = 0.f;
-            for (int c = threadIdx.x; c < V; c += blockDim.x) sum += expf(p[c] - bv);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) sum += (threadIdx.x + j * 256 < V) ? expf(x[j] - bv) : 0.f;
             sum = block_sum(sum, smf);
             lp = -logf(sum);
         }
     } else {
         // lp' = log_softmax(logp / temp)
         float mx = -INFINITY;
-        for (int c = threadIdx.x; c < V; c += blockDim.x) mx = fmaxf(mx, p[c] / temp);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { x[j] = x[j] / temp; mx = fmaxf(mx, x[j]); }
         mx = block_max(mx, smf);
         float sum = 0.f;
-        for (int c = threadIdx.x; c < V; c += blockDim.x) sum += expf(p[c] / temp - mx);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) sum += (threadIdx.x + j * 256 < V) ? expf(x[j] - mx) : 0.f;
         sum = block_sum(sum, smf);
         const float lse = mx + logf(sum);
         int top_i[MAXK]; float top_v[MAXK];
-        for (int j = 0; j < k; ++j) {
+        float pv = INFINITY; int pi = -1;         // (value desc, index asc) is a total order: "after the previous pick" is one test
+        for (int q = 0; q < k; ++q) {
             float bv = -INFINITY; int bi = 0x7fffffff;
-            for (int c = threadIdx.x; c < V; c += blockDim.x) {
-                bool used = false;
-                for (int q = 0; q < j; ++q) used |= top_i[q] == c;
-                if (used) continue;
-                const float x = p[c] / temp - lse;
-                if (x > bv || bi == 0x7fffffff) { bv = x; bi = c; }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int c = threadIdx.x + j * 256;
+                const float v = x[j] - lse;
+                const bool after = v < pv || (v == pv && c > pi);
+                if (c < V && after && (v > bv || bi == 0x7fffffff)) { bv = v; bi = c; }
             }
             block_argmax(bv, bi, sv, si);
-            top_i[j] = bi; top_v[j] = bv;
+            top_i[q] = bi; top_v[q] = bv;
+            pv = bv; pi = bi;
         }
         // Categorical(logits=top): renormalise over the k, inverse CDF in top-k order
         float m2 = top_v[0];
@@ -675,8 +691,15 @@ SUBGC_API int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(logp && seq && seqlp && next_tok && unfinished, "decode_pick: null pointer");
     SUBGC_REQUIRE(k == 0 || temp > 0.f, "decode_pick: temperature must be positive");
-    hipLaunchKernelGGL(decode_pick_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logp, ld, n, V, k, temp, u, t, seq, seqlp, T,
-                       next_tok, unfinished, n_unfinished, prev_count, raw_logits);
+    SUBGC_REQUIRE(V <= 256 * 64, "decode_pick: at most %d columns", 256 * 64);
+    const int per = (V + 255) / 256;
+#define LAUNCH(P) hipLaunchKernelGGL(decode_pick_kernel<P>, dim3(n), dim3(256), 0, (hipStream_t)stream, logp, ld, n, V, k, temp, u, t, seq, \
+                                     seqlp, T, next_tok, unfinished, n_unfinished, prev_count, raw_logits)
+    if (per <= 4) LAUNCH(4);
+    else if (per <= 16) LAUNCH(16);
+    else if (per <= 40) LAUNCH(40);
+    else LAUNCH(64);
+#undef LAUNCH
     return subgc::check_launch("subgc_decode_pick");
 }
 
