@@ -243,6 +243,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ log-softmax rows / NLL
+// the row is held in registers between its single read and its single write (PER x 256 >= V)
+template <int PER>
 __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x, int64_t ldx, int rows, int V,
                                                           const int32_t* __restrict__ active) {
     __shared__ float sm[16];
@@ -252,14 +254,26 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x,
         for (int c = threadIdx.x; c < V; c += blockDim.x) p[c] = 0.f;
         return;
     }
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = threadIdx.x + j * 256;
+        v[j] = c < V ? p[c] : -INFINITY;
+    }
     float mx = -INFINITY;
-    for (int c = threadIdx.x; c < V; c += blockDim.x) mx = fmaxf(mx, p[c]);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) mx = fmaxf(mx, v[j]);
     mx = block_max(mx, sm);
     float sum = 0.f;
-    for (int c = threadIdx.x; c < V; c += blockDim.x) sum += expf(p[c] - mx);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sum += (threadIdx.x + j * 256 < V) ? expf(v[j] - mx) : 0.f;
     sum = block_sum(sum, sm);
     const float lse = mx + logf(sum);
-    for (int c = threadIdx.x; c < V; c += blockDim.x) p[c] = p[c] - lse;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < V) p[c] = v[j] - lse;
+    }
 }
 __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ logp, const float* dout, float* dlogits,
                                                               int64_t ld, int rows, int V, const int32_t* __restrict__ active) {
@@ -634,7 +648,12 @@ SUBGC_API int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, con
     SUBGC_REQUIRE(x, "log_softmax_rows: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * rows * (double)V * 2);
-    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
+    SUBGC_REQUIRE(V <= 256 * 64, "log_softmax_rows: at most %d columns", 256 * 64);
+    const int per = (V + 255) / 256;
+    if (per <= 4) hipLaunchKernelGGL(log_softmax_kernel<4>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
+    else if (per <= 16) hipLaunchKernelGGL(log_softmax_kernel<16>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
+    else if (per <= 40) hipLaunchKernelGGL(log_softmax_kernel<40>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
+    else hipLaunchKernelGGL(log_softmax_kernel<64>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
     return subgc::check_launch("subgc_log_softmax_rows");
 }
 SUBGC_API int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, float* dlogits, int64_t ld, int rows, int V,
