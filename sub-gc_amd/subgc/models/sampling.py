@@ -199,9 +199,17 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     k = m.the_k if m.topk_sampling else 0
     if k and uniforms is None and forced is None:
         uniforms = torch.rand(n, T, device=dev)
+    graphed = None
     if len(sel) == 1 and forced is None and n <= 16 and getattr(m, "decode_hipgraph", True):
         # the reference-shaped call (one image, <= 10 rows): launch-bound, replayed as one hipGraph
-        seq, seqlp, counts, AL = _graphed_loop(m, n, N, k, return_att, P).run(pr, uniforms)
+        try:
+            graphed = _graphed_loop(m, n, N, k, return_att, P)
+        except RuntimeError as e:                                                # capture unavailable here: same kernels, launched eagerly
+            import warnings
+            warnings.warn(f"hipGraph capture of the decode loop failed ({e}); decoding eagerly from now on")
+            m.decode_hipgraph = False
+    if graphed is not None:
+        seq, seqlp, counts, AL = graphed.run(pr, uniforms)
     else:
         st = F_.DecodeState(pr, P, N, return_att)
         seq = torch.zeros(n, T, device=dev, dtype=torch.long)
