@@ -70,9 +70,15 @@ def select_subgraphs(m, X2, N, images):
         else:
             keeps.append(None)
         g0 += n_i
-    out, g0 = [], 0
+    kept = [kb[1].view(1) for kb in keeps if kb is not None]
+    kept = torch.cat(kept).cpu().tolist() if kept else []                              # ONE host read for all images
+    out, g0, j = [], 0, 0
     for n_i, kb in zip(sizes, keeps):
-        keep = torch.arange(n_i, device=dev) if kb is None else kb[0][: int(kb[1].item())]
+        if kb is None:
+            keep = torch.arange(n_i, device=dev)
+        else:
+            keep = kb[0][: int(kept[j])]
+            j += 1
         out.append(dict(keep=keep, glob=keep + g0))
         g0 += n_i
     glob = torch.cat([o["glob"] for o in out])
