@@ -187,6 +187,14 @@ int subgc_gpn_score_bwd(const float* hid, const uint8_t* keep, float keep_scale,
 int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t idx_stride, const int32_t* len,
                        int M, int N, double thres, int max_keep, int64_t* keep, int32_t* n_keep,
                        void* scratch, size_t scratch_bytes, void* stream);
+/* The same NMS for MANY images in one launch (one workgroup per image): image b owns candidates
+ * offsets[b] .. offsets[b+1] (offsets int32 [images+1], total = offsets[images], max_m = the largest segment);
+ * keep[offsets[b] + i] = i-th kept candidate of image b (index RELATIVE to its segment), n_keep[b] its count.
+ * scratch: total * (SUBGC_NMS_WORDS*8 + 8) bytes.                                                              */
+int subgc_subgraph_nms_batched(const float* score, const int64_t* idx, int64_t idx_stride, const int32_t* len,
+                               const int32_t* offsets, int images, int total, int max_m, int N, double thres,
+                               int max_keep, int64_t* keep, int32_t* n_keep, void* scratch, size_t scratch_bytes,
+                               void* stream);
 
 /* ======================================================================================
  * Decoder kernels

@@ -153,10 +153,17 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ sco
                                                    int64_t idx_stride, const int32_t* __restrict__ len, int M, int N,
                                                    double thres, int max_keep, int64_t* __restrict__ keep,
                                                    int32_t* __restrict__ n_keep, uint64_t* __restrict__ masks,
-                                                   int32_t* __restrict__ order, int32_t* __restrict__ flag) {
+                                                   int32_t* __restrict__ order, int32_t* __restrict__ flag,
+                                                   const int32_t* __restrict__ offsets) {
     extern __shared__ unsigned char removed[];   // [M]
     __shared__ int kept_s;
     const int t = threadIdx.x, nt = blockDim.x;
+    if (offsets) {                               // batched form: workgroup b owns candidates offsets[b] .. offsets[b+1] of image b
+        const int g0 = offsets[blockIdx.x];
+        M = offsets[blockIdx.x + 1] - g0;
+        score += g0; idx += (int64_t)g0 * idx_stride; len += g0; keep += g0; n_keep += blockIdx.x;
+        masks += (int64_t)g0 * W; order += g0; flag += g0;
+    }
     for (int m = t; m < M; m += nt) {
         uint64_t bits[W] = {0};
         const int l = min(len[m], N);
@@ -271,6 +278,29 @@ SUBGC_API int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t
         return SUBGC_ELAUNCH;
     }
     hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), lds, s, score, idx, idx_stride, len, M, N, thres, max_keep, keep, n_keep, masks,
-                       order, flag);
+                       order, flag, (const int32_t*)nullptr);
     return subgc::check_launch("subgc_subgraph_nms");
+}
+
+SUBGC_API int subgc_subgraph_nms_batched(const float* score, const int64_t* idx, int64_t idx_stride, const int32_t* len,
+                                         const int32_t* offsets, int images, int total, int max_m, int N, double thres, int max_keep,
+                                         int64_t* keep, int32_t* n_keep, void* scratch, size_t scratch_bytes, void* stream) {
+    SUBGC_REQUIRE(images >= 0 && total >= 0 && max_m >= 0 && max_m <= 65536 && N > 0 && max_keep > 0, "subgraph_nms_batched: bad sizes");
+    if (images == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(offsets && keep && n_keep, "subgraph_nms_batched: null pointer");
+    SUBGC_REQUIRE(total == 0 || (score && idx && len && scratch), "subgraph_nms_batched: null pointer");
+    const size_t need = (size_t)total * (W * 8 + 8);
+    SUBGC_REQUIRE(scratch_bytes >= need, "subgraph_nms_batched: scratch too small (%zu < %zu)", scratch_bytes, need);
+    uint64_t* masks = (uint64_t*)scratch;
+    int32_t* order = (int32_t*)(masks + (size_t)total * W);
+    int32_t* flag = order + total;
+    const size_t lds = (size_t)((max_m + 15) / 16 * 16);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        subgc::set_error("subgraph_nms_batched: cannot get %zu bytes of LDS", lds);
+        return SUBGC_ELAUNCH;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(images), dim3(1024), lds, (hipStream_t)stream, score, idx, idx_stride, len, 0, N, thres, max_keep,
+                       keep, n_keep, masks, order, flag, offsets);
+    return subgc::check_launch("subgc_subgraph_nms_batched");
 }

@@ -63,24 +63,19 @@ def select_subgraphs(m, X2, N, images):
     else:
         score = torch.ones(G, device=dev)
     lens_i = lens_all.to(torch.int32)
-    keeps, g0 = [], 0
-    for n_i in sizes:                                                                  # node-set NMS is per image (gpn.py:108-138)
-        if not m.sct:                                                                  # use_nms (AttModel.py:95)
-            keeps.append(ops.subgraph_nms(score[g0:g0 + n_i], idx[g0:g0 + n_i], lens_i[g0:g0 + n_i], m.gpn_nms_thres, m.gpn_max_subg))
-        else:
-            keeps.append(None)
-        g0 += n_i
-    kept = [kb[1].view(1) for kb in keeps if kb is not None]
-    kept = torch.cat(kept).cpu().tolist() if kept else []                              # ONE host read for all images
-    out, g0, j = [], 0, 0
-    for n_i, kb in zip(sizes, keeps):
-        if kb is None:
+    out = []
+    if not m.sct:                                                                      # use_nms (AttModel.py:95); node-set NMS is per image (gpn.py:108-138)
+        keep_all, n_keep, offs = ops.subgraph_nms_batched(score, idx, lens_i, sizes, m.gpn_nms_thres, m.gpn_max_subg)
+        kept = n_keep.cpu().tolist()                                                   # ONE launch and ONE host read for all images
+        for b, g0 in enumerate(offs[:-1]):
+            keep = keep_all[g0:g0 + kept[b]]
+            out.append(dict(keep=keep, glob=keep + g0))
+    else:
+        g0 = 0
+        for n_i in sizes:
             keep = torch.arange(n_i, device=dev)
-        else:
-            keep = kb[0][: int(kept[j])]
-            j += 1
-        out.append(dict(keep=keep, glob=keep + g0))
-        g0 += n_i
+            out.append(dict(keep=keep, glob=keep + g0))
+            g0 += n_i
     glob = torch.cat([o["glob"] for o in out])
     fc = torch.empty(glob.numel(), 2 * L, device=dev)
     if glob.numel():

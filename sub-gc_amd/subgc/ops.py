@@ -218,6 +218,24 @@ def subgraph_nms(score, idx, lens, thres, max_keep):
     return keep, n_keep
 
 
+def subgraph_nms_batched(score, idx, lens, sizes, thres, max_keep):
+    """NMS of several images in ONE launch.  `sizes`: candidates per image (python ints, consecutive segments of score/idx/lens).
+    -> (keep int64 [total] with image b's kept indices (relative to its segment) at its segment start, n_keep int32 [images])."""
+    total, N = idx.shape
+    dev = score.device
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + int(n))
+    offsets = torch.tensor(offs, device=dev, dtype=torch.int32)
+    keep = torch.empty(max(total, 1), device=dev, dtype=torch.int64)
+    n_keep = torch.zeros(len(sizes), device=dev, dtype=torch.int32)
+    scratch = torch.empty(max(total, 1) * (NMS_WORDS * 8 + 8), device=dev, dtype=torch.uint8)
+    call("subgc_subgraph_nms_batched", _ptr(score, torch.float32), _ptr(idx, torch.int64), idx.stride(0), _ptr(lens, torch.int32),
+         _ptr(offsets), len(sizes), total, max(sizes) if sizes else 0, N, float(thres), int(max_keep), _ptr(keep), _ptr(n_keep),
+         _ptr(scratch), scratch.numel(), _stream())
+    return keep, n_keep, offs
+
+
 def pack_rows(lens, idx, img, S, N):
     dev = lens.device
     off = torch.empty(S, device=dev, dtype=torch.int32)

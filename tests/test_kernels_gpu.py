@@ -515,3 +515,20 @@ def test_gemm_bf16_mode_rounds_operands_only():
     err = float((out.double() - ref).abs().max())
     assert 1e-4 * scale < err < 2e-2 * scale
     assert ops.gemm_mode.current == "f32"
+
+
+def test_batched_nms_equals_per_image_nms():
+    torch.manual_seed(4)
+    sizes = [40, 1, 0, 200, 7]
+    N = 37
+    tot = sum(sizes)
+    score = torch.rand(tot, device=DEV)
+    score[5] = score[9]                                              # a tie
+    lens = torch.randint(1, 10, (tot,), device=DEV, dtype=torch.int32)
+    idx = torch.stack([torch.randperm(14, device=DEV)[:N - 23].repeat(3)[:N] for _ in range(tot)]).contiguous()
+    keep, n_keep, offs = ops.subgraph_nms_batched(score, idx, lens, sizes, 0.4, 8)
+    for b, (g0, n) in enumerate(zip(offs[:-1], sizes)):
+        k1, n1 = ops.subgraph_nms(score[g0:g0 + n], idx[g0:g0 + n], lens[g0:g0 + n], 0.4, 8)
+        c = int(n1.item()) if n else 0
+        assert int(n_keep[b]) == c
+        np.testing.assert_array_equal(keep[g0:g0 + c].cpu().numpy(), k1[:c].cpu().numpy())
