@@ -110,7 +110,7 @@ def decode_bench(model_sd, dev, images, M):
     out = {"decode_tokens_per_s": round(tokens / dt, 1), "decode_ms_per_image": round(1e3 * dt / images, 3),
            "decode_config": f"greedy, {2 * M} candidate sub-graphs/image -> NMS 0.75 -> <=10 kept x 20 tokens, {images} images looped"}
     # the same images, decoded `group` at a time as one batch (sample_images): same tokens per image, weights streamed once per step
-    group = 32
+    group = 64
     m.sample_images(batches[:group], opt=sopt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
