@@ -244,6 +244,29 @@ def main():
                          "whole_step_frac_nominal": round(MODEL_GFLOP_PER_IMAGE * a.batch / (ms_per_step * 1e-3) / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
             "final_loss": round(final_loss, 4),
         }
+        if world == 1:
+            # the HBM-bound kernel families of the same step (reported individually in GB/s against the 8 TB/s
+            # roof): two extra untimed steps with every family bracketed by HIP events on its launch stream; algorithmic
+            # bytes are counted by the entry points themselves (attention: sum of the ragged set sizes, counted here)
+            fams = ("gcn", "pool", "attn", "lstm", "softmax")
+            for f_ in fams:
+                _lib.prof_enable(f_, True)
+            ops.FLOPS.update(on=True, attn_bytes=0.0)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            ops.FLOPS["on"] = False
+            hbm = {}
+            for f_ in fams:
+                _lib.prof_enable(f_, False)
+                n_, ms_, work_ = _lib.prof_collect(f_)
+                if f_ == "attn":
+                    work_ = ops.FLOPS.get("attn_bytes", 0.0)
+                if n_ and ms_ > 0:
+                    gbps = work_ / (ms_ * 1e-3) / 1e9
+                    hbm[f_] = {"launches_per_step": n_ // 2, "ms_per_step": round(ms_ / 2, 3), "algorithmic_MB_per_step": round(work_ / 2 / 1e6, 1),
+                               "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)}
+            res["hbm_bound_kernels"] = hbm
         if world == 1 and not a.packed_only:
             # the same step with the loss-only packing switched off (every sentence runs all T steps, `outputs`
             # is materialised exactly like the reference does): reported beside the default for comparison

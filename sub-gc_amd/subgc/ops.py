@@ -274,12 +274,19 @@ def lstm_bwd(gates, c_prev, c, dh_a, dh_b, dh_drop, keep, scale, dc, dpre, dc_pr
          _ptr(keep, torch.uint8), float(scale), _ptr(dc), _ptr(dpre), _ptr(dc_prev), S, R, _stream())
 
 
+def _attn_account(lens, S, A, R, passes):
+    if FLOPS["on"]:                      # untimed accounting step: algorithmic bytes of the ragged attention sets
+        FLOPS["attn_bytes"] = FLOPS.get("attn_bytes", 0.0) + 4.0 * float(lens[:S].sum().item()) * (A + R) * passes
+
+
 def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R):
+    _attn_account(lens, S, A, R, 1)      # read u and v rows once
     call("subgc_attn_fwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32),
          _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, _stream())
 
 
 def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R):
+    _attn_account(lens, S, A, R, 3)      # read u, v; read-modify-write du, dv
     call("subgc_attn_bwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
          alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R, _stream())
 
