@@ -85,6 +85,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ LSTM gate math
+// VW = 4: a thread owns four consecutive hidden units (float4 loads / stores; every pointer 16-byte aligned, R and the
+// leading dimensions multiples of 4); VW = 1 is the unaligned fallback.  These kernels move 12-14 floats per hidden unit
+// and do ~10 transcendental ops: pure HBM streaming, so bytes in flight per thread is what sets their speed.
+template <int VW>
+__device__ __forceinline__ void ldv(const float* p, float (&o)[VW]) {
+    if (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); o[0] = t.x; o[1 % VW] = t.y; o[2 % VW] = t.z; o[3 % VW] = t.w; }
+    else o[0] = *p;
+}
+template <int VW>
+__device__ __forceinline__ void stv(float* p, const float (&o)[VW]) {
+    if (VW == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1 % VW], o[2 % VW], o[3 % VW]);
+    else *p = o[0];
+}
+template <int VW>
+__device__ __forceinline__ void ldk(const uint8_t* p, bool (&o)[VW]) {
+    if (VW == 4) { const uint32_t t = *reinterpret_cast<const uint32_t*>(p); o[0] = t & 0xffu; o[1 % VW] = t & 0xff00u; o[2 % VW] = t & 0xff0000u; o[3 % VW] = t & 0xff000000u; }
+    else o[0] = *p != 0;
+}
+
+template <int VW>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ g0, int64_t ld0, const float* __restrict__ g1,
                                                        int64_t ld1, const float* __restrict__ g2, int64_t ld2,
                                                        const float* __restrict__ b0, const float* __restrict__ b1,
@@ -92,61 +112,103 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ h, int64_t ldh, float* __restrict__ h2, int64_t ldh2,
                                                        const uint8_t* __restrict__ keep, float scale, float* __restrict__ hdrop,
                                                        int64_t ldhd, float* __restrict__ gates, int S, int R, int rows_h, int rows_h2) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (int64_t)S * R) return;
-    const int s = (int)(q / R), j = (int)(q % R);
-    float pre[4];
+    const int RV = R / VW;
+    const int64_t qv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qv >= (int64_t)S * RV) return;
+    const int s = (int)(qv / RV), j = (int)(qv % RV) * VW;
+    const int64_t q = (int64_t)s * R + j;
+    float pre[4][VW];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int col = k * R + j;
-        float v = g0[(int64_t)s * ld0 + col];
-        if (g1) v += g1[(int64_t)s * ld1 + col];
-        if (g2) v += g2[(int64_t)s * ld2 + col];
-        if (b0) v += b0[col];
-        if (b1) v += b1[col];
-        pre[k] = v;
+        float t[VW];
+        ldv<VW>(g0 + (int64_t)s * ld0 + col, pre[k]);
+        if (g1) { ldv<VW>(g1 + (int64_t)s * ld1 + col, t);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) pre[k][e] += t[e]; }
+        if (g2) { ldv<VW>(g2 + (int64_t)s * ld2 + col, t);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) pre[k][e] += t[e]; }
+        if (b0) { ldv<VW>(b0 + col, t);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) pre[k][e] += t[e]; }
+        if (b1) { ldv<VW>(b1 + col, t);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) pre[k][e] += t[e]; }
     }
-    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-    const float cp = c_prev ? c_prev[q] : 0.f;
-    const float cn = fg * cp + ig * gg;
-    const float hn = og * tanhf(cn);
-    c[q] = cn;
-    if (s < rows_h) h[(int64_t)s * ldh + j] = hn;
-    if (h2 && s < rows_h2) h2[(int64_t)s * ldh2 + j] = hn;
-    if (hdrop) hdrop[(int64_t)s * ldhd + j] = keep ? (keep[q] ? hn * scale : 0.f) : hn;
+    float cp[VW], cn[VW], hn[VW], ig[VW], fg[VW], gg[VW], og[VW];
+    if (c_prev) ldv<VW>(c_prev + q, cp);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+        ig[e] = sigmoidf_(pre[0][e]); fg[e] = sigmoidf_(pre[1][e]); gg[e] = tanhf(pre[2][e]); og[e] = sigmoidf_(pre[3][e]);
+        cn[e] = fg[e] * (c_prev ? cp[e] : 0.f) + ig[e] * gg[e];
+        hn[e] = og[e] * tanhf(cn[e]);
+    }
+    stv<VW>(c + q, cn);
+    if (s < rows_h) stv<VW>(h + (int64_t)s * ldh + j, hn);
+    if (h2 && s < rows_h2) stv<VW>(h2 + (int64_t)s * ldh2 + j, hn);
+    if (hdrop) {
+        float hd[VW];
+        bool kp[VW];
+        if (keep) ldk<VW>(keep + q, kp);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) hd[e] = keep ? (kp[e] ? hn[e] * scale : 0.f) : hn[e];
+        stv<VW>(hdrop + (int64_t)s * ldhd + j, hd);
+    }
     if (gates) {
         float* gp = gates + (int64_t)s * 4 * R + j;
-        gp[0] = ig; gp[R] = fg; gp[2 * R] = gg; gp[3 * R] = og;
+        stv<VW>(gp, ig); stv<VW>(gp + R, fg); stv<VW>(gp + 2 * R, gg); stv<VW>(gp + 3 * R, og);
     }
 }
+template <int VW>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                        const float* __restrict__ c, const float* __restrict__ dh_a, int64_t lda,
                                                        const float* __restrict__ dh_b, int64_t ldb, const float* __restrict__ dh_d,
                                                        int64_t ldd, const uint8_t* __restrict__ keep, float scale,
                                                        const float* __restrict__ dc, float* __restrict__ dpre,
                                                        float* __restrict__ dc_prev, int S, int R) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (int64_t)S * R) return;
-    const int s = (int)(q / R), j = (int)(q % R);
+    const int RV = R / VW;
+    const int64_t qv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qv >= (int64_t)S * RV) return;
+    const int s = (int)(qv / RV), j = (int)(qv % RV) * VW;
+    const int64_t q = (int64_t)s * R + j;
     const float* gp = gates + (int64_t)s * 4 * R + j;
-    const float ig = gp[0], fg = gp[R], gg = gp[2 * R], og = gp[3 * R];
-    float dh = 0.f;
-    if (dh_a) dh += dh_a[(int64_t)s * lda + j];
-    if (dh_b) dh += dh_b[(int64_t)s * ldb + j];
+    float ig[VW], fg[VW], gg[VW], og[VW], dh[VW], t[VW], cc[VW], cp[VW], dcv[VW];
+    ldv<VW>(gp, ig); ldv<VW>(gp + R, fg); ldv<VW>(gp + 2 * R, gg); ldv<VW>(gp + 3 * R, og);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) dh[e] = 0.f;
+    if (dh_a) { ldv<VW>(dh_a + (int64_t)s * lda + j, t);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) dh[e] += t[e]; }
+    if (dh_b) { ldv<VW>(dh_b + (int64_t)s * ldb + j, t);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) dh[e] += t[e]; }
     if (dh_d) {
-        const float g = dh_d[(int64_t)s * ldd + j];
-        dh += keep ? (keep[q] ? g * scale : 0.f) : g;
+        bool kp[VW];
+        ldv<VW>(dh_d + (int64_t)s * ldd + j, t);
+        if (keep) ldk<VW>(keep + q, kp);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) dh[e] += keep ? (kp[e] ? t[e] * scale : 0.f) : t[e];
     }
-    const float tc = tanhf(c[q]);
-    float dct = dh * og * (1.f - tc * tc);
-    if (dc) dct += dc[q];
-    const float cp = c_prev ? c_prev[q] : 0.f;
+    ldv<VW>(c + q, cc);
+    if (dc) ldv<VW>(dc + q, dcv);
+    if (c_prev) ldv<VW>(c_prev + q, cp);
+    float d0[VW], d1[VW], d2[VW], d3[VW], dcp[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+        const float tc = tanhf(cc[e]);
+        float dct = dh[e] * og[e] * (1.f - tc * tc);
+        if (dc) dct += dcv[e];
+        const float cpe = c_prev ? cp[e] : 0.f;
+        d0[e] = dct * gg[e] * ig[e] * (1.f - ig[e]);
+        d1[e] = dct * cpe * fg[e] * (1.f - fg[e]);
+        d2[e] = dct * ig[e] * (1.f - gg[e] * gg[e]);
+        d3[e] = dh[e] * tc * og[e] * (1.f - og[e]);
+        dcp[e] = dct * fg[e];
+    }
     float* dp = dpre + (int64_t)s * 4 * R + j;
-    dp[0] = dct * gg * ig * (1.f - ig);
-    dp[R] = dct * cp * fg * (1.f - fg);
-    dp[2 * R] = dct * ig * (1.f - gg * gg);
-    dp[3 * R] = dh * tc * og * (1.f - og);
-    dc_prev[q] = dct * fg;
+    stv<VW>(dp, d0); stv<VW>(dp + R, d1); stv<VW>(dp + 2 * R, d2); stv<VW>(dp + 3 * R, d3);
+    stv<VW>(dc_prev + q, dcp);
 }
 
 // ------------------------------------------------------------------ attention step
@@ -596,8 +658,16 @@ SUBGC_API int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int6
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)S * R;
     subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12);
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev, c,
-                       h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = R % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && ldh % 4 == 0 && ldh2 % 4 == 0 && ldhd % 4 == 0 && al(g0) &&
+                     al(g1) && al(g2) && al(b0) && al(b1) && al(c_prev) && al(c) && al(h) && al(h2) && al(hdrop) && al(gates) &&
+                     (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
+    if (vec)
+        hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev,
+                           c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2);
+    else
+        hipLaunchKernelGGL(lstm_fwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev, c,
+                           h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2);
     return subgc::check_launch("subgc_lstm_fwd");
 }
 SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda, const float* dh_b,
@@ -609,8 +679,15 @@ SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const floa
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)S * R;
     subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 14);
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
-                       dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = R % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldd % 4 == 0 && al(gates) && al(c_prev) && al(c) && al(dh_a) && al(dh_b) &&
+                     al(dh_drop) && al(dc) && al(dpre) && al(dc_prev) && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
+    if (vec)
+        hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
+                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R);
+    else
+        hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
+                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R);
     return subgc::check_launch("subgc_lstm_bwd");
 }
 
