@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void csr_build_kernel(const int64_t* __restric
 
 // ------------------------------------------------------------------ nodes <- relations
 // grid (L/256, B); thread = one feature column; CSR lists of the image in LDS.
+constexpr int GCN_ZSPLIT = 4;     // node / relation loop of the per-column kernels is strided over gridDim.z
 __global__ __launch_bounds__(256) void gcn_nodes_fwd_kernel(const float* __restrict__ F0, const float* __restrict__ F1,
                                                             const int32_t* __restrict__ ptr,
                                                             const int32_t* __restrict__ edges,
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void gcn_nodes_fwd_kernel(const float* __restr
     if (col >= L) return;
     const float* f0 = F0 + (int64_t)b * K * L + col;
     const float* f1 = F1 + (int64_t)b * K * L + col;
-    for (int n = 0; n < N; ++n) {
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {           // node chunks over gridDim.z: shorter dependent chains, 4x the loads in flight
         float a = 0.f, c = 0.f;
         const int s0 = ps[n], s1 = ps[n + 1], o0 = po[n], o1 = po[n + 1];
         for (int j = s0; j < s1; ++j) a += f0[(int64_t)es[j] * L];
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void gcn_nodes_bwd_kernel(const float* __restr
     __syncthreads();
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= L) return;
-    for (int k = 0; k < K; ++k) {
+    for (int k = blockIdx.z; k < K; k += gridDim.z) {
         const int s = ns[k], o = no[k];
         const int64_t is = ((int64_t)b * N + s) * L + col, io = ((int64_t)b * N + o) * L + col;
         const float gs = (act[is] & 1) ? dX[is] * 0.5f / ds[s] : 0.f;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void gcn_edges_bwd_kernel(const float* __restr
     if (col >= L) return;
     const float cdiv1 = 1.f + 1e-7f;
     const float* dp = dP + (int64_t)b * K * L + col;
-    for (int n = 0; n < N; ++n) {
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {
         float a = 0.f, c = 0.f;
         for (int j = ps[n]; j < ps[n + 1]; ++j) a += dp[(int64_t)es[j] * L];
         for (int j = po[n]; j < po[n + 1]; ++j) c += dp[(int64_t)eo[j] * L];
@@ -353,7 +354,7 @@ SUBGC_API int subgc_gcn_nodes_fwd(const float* F0, const float* F1, const int32_
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + (skip ? 2.0 : 1.0) * N));
     const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
-    hipLaunchKernelGGL(gcn_nodes_fwd_kernel, dim3((L + 255) / 256, B), dim3(256), lds, s, F0, F1, ptr, edges, skip, Xout, act, B, N, K, L);
+    hipLaunchKernelGGL(gcn_nodes_fwd_kernel, dim3((L + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, F0, F1, ptr, edges, skip, Xout, act, B, N, K, L);
     return subgc::check_launch("subgc_gcn_nodes_fwd");
 }
 
@@ -365,7 +366,7 @@ SUBGC_API int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 2.0 * K));
     const size_t lds = sizeof(int) * (2 * K) + sizeof(float) * 2 * N;
-    hipLaunchKernelGGL(gcn_nodes_bwd_kernel, dim3((L + 255) / 256, B), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
+    hipLaunchKernelGGL(gcn_nodes_bwd_kernel, dim3((L + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
     return subgc::check_launch("subgc_gcn_nodes_bwd");
 }
 
@@ -392,7 +393,7 @@ SUBGC_API int subgc_gcn_edges_bwd(const float* dP, const float* F2, const float*
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 4.0 * N));
     const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
-    hipLaunchKernelGGL(gcn_edges_bwd_kernel, dim3((L + 255) / 256, B), dim3(256), lds, s, dP, F2, F3, ptr, edges, dF2, dF3, B, N, K, L);
+    hipLaunchKernelGGL(gcn_edges_bwd_kernel, dim3((L + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, dP, F2, F3, ptr, edges, dF2, dF3, B, N, K, L);
     return subgc::check_launch("subgc_gcn_edges_bwd");
 }
 
