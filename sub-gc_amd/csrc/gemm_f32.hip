@@ -638,6 +638,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
         atomicAdd(out + col, v);
     }
 }
+// float4 form (N % 4 == 0, 16-byte aligned rows): a lane owns 4 adjacent columns, a wave reads 1 KB of a row per instruction
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ X, int64_t ldx, int M, int N,
+                                                         float* __restrict__ out, const int32_t* m_dev, int rows_per_block) {
+    __shared__ float4 sm[4][64];
+    if (m_dev) M = min(M, *m_dev);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < N)
+        for (int r = r0 + w; r < r1; r += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)r * ldx + col);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    sm[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && col < N) {
+        const float4 a = sm[0][lane], b = sm[1][lane], c = sm[2][lane], d = sm[3][lane];
+        atomicAdd(out + col, a.x + b.x + c.x + d.x);
+        atomicAdd(out + col + 1, a.y + b.y + c.y + d.y);
+        atomicAdd(out + col + 2, a.z + b.z + c.z + d.z);
+        atomicAdd(out + col + 3, a.w + b.w + c.w + d.w);
+    }
+}
 __global__ void zero_kernel(float* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.f;
@@ -653,6 +677,11 @@ SUBGC_API int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float*
     if (!accumulate) hipLaunchKernelGGL(zero_kernel, dim3((N + 255) / 256), dim3(256), 0, s, out, N);
     if (M == 0) return subgc::check_launch("subgc_colsum_f32");
     const int rows_per_block = 256;
+    if (N % 4 == 0 && ldx % 4 == 0 && aligned16(X)) {
+        dim3 grid((N / 4 + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block);
+        return subgc::check_launch("subgc_colsum_f32");
+    }
     dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, accumulate, m_dev, rows_per_block);
     return subgc::check_launch("subgc_colsum_f32");
