@@ -15,6 +15,13 @@ from torch.autograd import Function
 from . import ops
 
 
+def _direct(p, dev):
+    """The existing .grad buffer of a leaf parameter if gradients may be accumulated into it in place, else None."""
+    g = getattr(p, "grad", None) if (p is not None and DIRECT_GRADS) else None
+    ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == dev and p.is_leaf
+    return g if ok else None
+
+
 # ------------------------------------------------------------------------------- linear
 class LinearFn(Function):
     """y = [dropout]([relu](x W^T + b [+ add])) on 2-D row-major x (any leading dim)."""
@@ -26,6 +33,7 @@ class LinearFn(Function):
         ctx.relu, ctx.scale, ctx.has_add = relu, scale, add is not None
         ctx.save_for_backward(x, W, y if (relu or keep is not None) else None)
         ctx.has_b = b is not None
+        ctx.param_objs = (W, b)           # the leaf objects themselves: their .grad (a flat-bucket view) is written directly
         return y
 
     @staticmethod
@@ -37,11 +45,18 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x.size(0), W.size(1), device=dy.device, dtype=torch.float32)
             ops.gemm(dz, W, dx)
+        gW, gb = (_direct(p, dy.device) for p in ctx.param_objs)
         if ctx.needs_input_grad[1]:
-            dW = torch.empty_like(W)
-            ops.gemm(dz, x, dW, ta=True)
+            if gW is not None:            # accumulate in the GEMM epilogue: no temporary, no separate `+=` pass by autograd
+                ops.gemm(dz, x, gW, ta=True, accum=True)
+            else:
+                dW = torch.empty_like(W)
+                ops.gemm(dz, x, dW, ta=True)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = ops.colsum(dz)
+            if gb is not None:
+                ops.colsum(dz, out=gb, accumulate=True)
+            else:
+                db = ops.colsum(dz)
         if ctx.has_add and ctx.needs_input_grad[3]:
             dadd = dz
         return dx, dW, db, dadd, None, None, None
