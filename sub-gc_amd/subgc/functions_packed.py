@@ -79,9 +79,12 @@ class PackedDecoderLossFn(Function):
             sel_p, u_p = ss[1].index_select(1, perm).contiguous(), ss[2].index_select(1, perm).contiguous()
         xt = new(max(rows, 1), E)
         Gx = new(max(rows, 1), 4 * R)
-        if ss is None:
-            for t in range(T_live):
-                ops.embed_fwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[ot[t]:ot[t + 1]])
+        tok_flat = k_flat = None
+        if ss is None and rows > 0:
+            # all T steps' input words in packed order -> ONE embedding launch (and one in the backward) instead of one per step
+            tok_flat = torch.cat([labels_p[:M[t], t] for t in range(T_live)]).contiguous()
+            k_flat = None if k_xt is None else torch.cat([k_xt[t][:M[t]] for t in range(T_live)]).contiguous()
+            ops.embed_fwd(emb, tok_flat, 1, k_flat, scale, xt[:rows])
             ops.gemm(xt[:rows], w1i[:, 2 * R:], Gx[:rows], tb=True)
         Gf = new(S, 4 * R)
         ops.gemm(pr.f, w1i[:, R:2 * R], Gf, tb=True)
@@ -130,6 +133,7 @@ class PackedDecoderLossFn(Function):
 
         ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
         ctx.masks = (k_xt, k_out)
+        ctx.flat_tokens = (tok_flat, k_flat)
         ctx.pr, ctx.params, ctx.aux = pr, P, (perm, tokens_p, lens_p, tgt_p, msk_p, nll)      # tokens_p: the words actually fed
         ctx.save_for_backward(fc_in, X_nodes, logits, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
         return loss
@@ -138,6 +142,7 @@ class PackedDecoderLossFn(Function):
     def backward(ctx, dloss):
         N, scale, S, T, T_live, R, E, A, V1, M, ot, rows = ctx.meta
         k_xt, k_out = ctx.masks
+        tok_flat, k_flat = ctx.flat_tokens
         pr, P = ctx.pr, ctx.params
         perm, labels_p, lens_p, tgt_p, msk_p, nll = ctx.aux
         (fc_in, X_nodes, logp, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
@@ -215,7 +220,11 @@ class PackedDecoderLossFn(Function):
         dxt = new(max(rows, 1), E); ops.gemm(P1, w1i[:, 2 * R:], dxt[:rows])
         d_emb = out_for(8, zero=True)
         for t in range(T_live):
+            if tok_flat is not None:
+                break
             ops.embed_bwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, dxt[ot[t]:ot[t + 1]], d_emb)
+        if tok_flat is not None:
+            ops.embed_bwd(emb, tok_flat, 1, k_flat, scale, dxt[:rows], d_emb)
         wgrad(17, dAH[:rows], H2a[:, R:2 * R])
         bgrad(18, dAH[:rows])
         ops.colsum(dWa[:rows], out=out_for(19).view(-1), accumulate=acc[19])
