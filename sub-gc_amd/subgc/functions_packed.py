@@ -125,8 +125,9 @@ class PackedDecoderLossFn(Function):
             ops.gemm(Hout[op:rows], lg_w, logits[op:rows], tb=True, bias=lg_b)
         ops.log_softmax_rows_(logits[:rows])
         # criterion over the packed rows: row ot[t] + s  <->  (sentence perm[s], step t)
-        tgt_p = torch.cat([target.index_select(0, perm[:M[t]])[:, t] for t in range(T_live)]).contiguous().view(-1, 1)
-        msk_p = torch.cat([mask_t.index_select(0, perm[:M[t]])[:, t] for t in range(T_live)]).contiguous().view(-1, 1)
+        target_s, mask_s = target.index_select(0, perm), mask_t.index_select(0, perm)      # sorted once; the per-step prefixes are views
+        tgt_p = torch.cat([target_s[:M[t], t] for t in range(T_live)]).contiguous().view(-1, 1)
+        msk_p = torch.cat([mask_s[:M[t], t] for t in range(T_live)]).contiguous().view(-1, 1)
         _, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p)
         nll[1:2].copy_(den.view(1))                            # denominator = ALL mask entries (dead ones are zero anyway)
         loss = nll[0] / nll[1]
