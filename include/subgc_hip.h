@@ -331,6 +331,10 @@ int subgc_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, voi
 int subgc_multinomial_rows(const float* logits, int64_t ld, int rows, int V, const float* u, const float* sel_u,
                            float prob, int64_t* tok, int64_t tok_stride, void* stream);
 
+/* Packed (length-sorted) decoder: dst[s, :C] = sum_t src[offsets[t] + s, :C] over the steps t with s < offsets[t+1] - offsets[t]
+ * (offsets int32 [T+1] on the device, step sizes non-increasing).  The gradient of the loop-invariant fc->gates term. */
+int subgc_packed_time_sum(const float* src, const int32_t* offsets, int T, int S, int C, float* dst, void* stream);
+
 /* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 

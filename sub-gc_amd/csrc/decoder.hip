@@ -862,3 +862,36 @@ SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64
                        beta2, eps, weight_decay, bc1, bc2);
     return subgc::check_launch("subgc_clip_adam_step");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Packed decoder: dst[s, :] = sum over the time steps t at which sentence s is live of src[ot[t] + s, :]
+// (the gradient of the loop-invariant fc->gates term; replaces T accumulate-copies).  M_t = ot[t+1] - ot[t] is
+// non-increasing, so a row's live steps are a prefix of 0..T-1.
+namespace {
+__global__ __launch_bounds__(256) void packed_time_sum_kernel(const float* __restrict__ src, const int32_t* __restrict__ ot, int T, int S,
+                                                              int C4, float* __restrict__ dst) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)S * C4) return;
+    const int s = (int)(q / C4), c = (int)(q % C4) * 4;
+    const int64_t C = (int64_t)C4 * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+        const int o = ot[t];
+        if (s >= ot[t + 1] - o) break;
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(o + s) * C + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dst + (int64_t)s * C + c) = a;
+}
+}  // namespace
+
+SUBGC_API int subgc_packed_time_sum(const float* src, const int32_t* offsets, int T, int S, int C, float* dst, void* stream) {
+    SUBGC_REQUIRE(T >= 0 && S >= 0 && C > 0 && C % 4 == 0, "packed_time_sum: bad sizes (C % 4 == 0)");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(src && offsets && dst, "packed_time_sum: null pointer");
+    SUBGC_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "packed_time_sum: 16-byte alignment");
+    const int64_t n = (int64_t)S * (C / 4);
+    hipLaunchKernelGGL(packed_time_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, offsets, T, S, C / 4,
+                       dst);
+    return subgc::check_launch("subgc_packed_time_sum");
+}

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void bce_mean_kernel(const float* __restrict__
 // One workgroup per chunk of SB_CHUNK sub-graphs, threads along H: dw2[h] is accumulated in a register over the
 // chunk and leaves as ONE atomic per (chunk, h) -- G x H same-address atomics (one wave per sub-graph) cost 105 us
 // at G = 2560, H = 512, ten times the rest of the kernel.
-constexpr int SB_CHUNK = 64;
+constexpr int SB_CHUNK = 16;
 __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict__ hid, const uint8_t* __restrict__ keep, float scale,
                                                         const float* __restrict__ w2, const float* __restrict__ score,
                                                         const float* __restrict__ dloss, float* __restrict__ dhid,

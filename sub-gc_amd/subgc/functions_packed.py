@@ -192,7 +192,6 @@ class PackedDecoderLossFn(Function):
         dH2 = [zer(S, 3 * R), zer(S, 3 * R)]
         dC1 = [zer(S, R), zer(S, R)]
         dC2 = [zer(S, R), zer(S, R)]
-        dGf = zer(S, 4 * R)
         for t in range(T_live - 1, -1, -1):
             m, o = M[t], ot[t]
             nH1, cH1 = dH1; nH2, cH2 = dH2; nC1, cC1 = dC1; nC2, cC2 = dC2
@@ -205,7 +204,6 @@ class PackedDecoderLossFn(Function):
             ops.lstm_bwd(G1[o:o + m], C1[t][:m], C1[t + 1][:m], cH2[:m, R:2 * R], nH1[:m, R:], None, None, 1.0, nC1[:m], dP1[o:o + m],
                          cC1[:m], m, R)
             ops.gemm(dP1[o:o + m], Wc1, cH1[:m])
-            ops.copy2d(dP1[o:o + m], dGf[:m], accumulate=True)
             dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
 
         P1, P2, H1a, H2a = dP1[:rows], dP2[:rows], H1[:rows], H2[:rows]
@@ -213,6 +211,8 @@ class PackedDecoderLossFn(Function):
         wgrad(14, P2, H2a[:, 2 * R:])
         bgrad(15, P2, also=16)
         wgrad(9, P1, H1a[:, :R], cols=(0, R))
+        dGf = new(S, 4 * R)                                     # d(fc->gates) = sum over each sentence's live steps of dP1: one launch
+        ops.packed_time_sum(dP1, torch.tensor(ot[:T_live + 1], device=dev, dtype=torch.int32), T_live, S, dGf)
         wgrad(9, dGf, pr.f, cols=(R, 2 * R))
         wgrad(9, P1, xt[:rows], cols=(2 * R, 2 * R + E))
         wgrad(10, P1, H1a[:, R:])

@@ -359,6 +359,13 @@ def multinomial_rows_(logits, u, sel_u, prob, tok):
     return tok
 
 
+def packed_time_sum(src, offsets, T, S, dst):
+    """dst[s] = sum over live steps t of src[offsets[t] + s] (packed decoder; offsets int32 [T+1] on the device)."""
+    call("subgc_packed_time_sum", _ptr(src, torch.float32), _ptr(offsets, torch.int32), int(T), int(S), src.size(1), _ptr(dst, torch.float32),
+         _stream())
+    return dst
+
+
 def rank_desc(score):
     """(sorted scores, order): stable descending sort of a 1-D fp32 score vector (eval_utils.py:106)."""
     score = score.contiguous()
