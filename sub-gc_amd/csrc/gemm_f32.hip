@@ -503,6 +503,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
 int g_splitk = 1;            // 0 disables the split-K form (SUBGC_SPLITK=0)
+int g_ragged64 = 1;          // ragged launches use 64x64 tiles (SUBGC_RAGGED64=0 to compare)
 int g_x3 = 0;                // subgc_set_gemm_mode: 1 = 3-way split operands on the bf16 matrix pipe, 2 = operands rounded to bf16
 
 // pick the number of K parts for 128x128 tiles so that tiles x parts fills the 512 workgroup slots
@@ -545,6 +546,9 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     const int64_t big = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
     // bf16x3-split form (gemm_x3.h): vector-addressable operands, no gathered A rows, 128x128 tiles
     const int xm = (VEC && !a.a_rows) ? g_x3 : 0;
+    // a ragged launch (device-side row count) is sized for the allocation; its live tiles are usually few, and one 128x128
+    // workgroup alone on a CU cannot hide its own load latency: small tiles put several workgroups on every CU
+    if (a.m_dev && !TA && xm == 0 && g_ragged64) return launch<64, 64, TA, TB, VEC>(a, s);
     if (big >= 384) return xm == 1 ? launch<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s) : xm == 2 ? launch<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s)
                                                                                                  : launch<128, 128, TA, TB, VEC>(a, s);
     const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && (!a.m_dev || TA);
@@ -584,6 +588,7 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     static bool env_read = false;
     if (!env_read) {
         if (const char* e = getenv("SUBGC_SPLITK")) g_splitk = atoi(e);
+        if (const char* e = getenv("SUBGC_RAGGED64")) g_ragged64 = atoi(e);
         if (const char* e = getenv("SUBGC_GEMM_X3")) g_x3 = atoi(e);
         env_read = true;
     }
