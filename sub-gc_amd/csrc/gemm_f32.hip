@@ -549,6 +549,14 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     // a ragged launch (device-side row count) is sized for the allocation; its live tiles are usually few, and one 128x128
     // workgroup alone on a CU cannot hide its own load latency: small tiles put several workgroups on every CU
     if (a.m_dev && !TA && xm == 0 && g_ragged64) return launch<64, 64, TA, TB, VEC>(a, s);
+    // Between one and two rounds of 512 workgroup slots the second round is nearly empty and its tiles run alone on their CUs
+    // (the 600-tile logit weight gradient: 98 -> 111 TFLOP/s with two K parts); the same cost model decides.
+    if (big >= 384 && big < 1024 && g_splitk && xm == 0 && !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows &&
+        (!a.m_dev || TA) && g_ws && 2 * (size_t)a.M * a.N * sizeof(float) <= g_ws_bytes) {
+        const int kt = (a.K + BK - 1) / BK;
+        const double one = (double)((big + 511) / 512) * (kt + 3.0), two = (double)((2 * big + 511) / 512) * ((kt + 1) / 2 + 3.0) + 1.8;
+        if (kt >= 64 && two < 0.9 * one) return launch_splitk<128, 128, TA, TB, VEC>(a, s, 2);
+    }
     if (big >= 384) return xm == 1 ? launch<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s) : xm == 2 ? launch<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s)
                                                                                                  : launch<128, 128, TA, TB, VEC>(a, s);
     const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && (!a.m_dev || TA);
