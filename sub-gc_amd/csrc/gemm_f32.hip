@@ -503,6 +503,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
 int g_splitk = 1;            // 0 disables the split-K form (SUBGC_SPLITK=0)
+int g_smallm = 256;          // M <= this prefers the 64x64 split-K form: one 128x128 workgroup per CU is latency-bound (SUBGC_SMALLM)
 int g_ragged64 = 1;          // ragged launches use 64x64 tiles (SUBGC_RAGGED64=0 to compare)
 int g_x3 = 0;                // subgc_set_gemm_mode: 1 = 3-way split operands on the bf16 matrix pipe, 2 = operands rounded to bf16
 
@@ -560,7 +561,7 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     if (big >= 384) return xm == 1 ? launch<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s) : xm == 2 ? launch<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s)
                                                                                                  : launch<128, 128, TA, TB, VEC>(a, s);
     const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && (!a.m_dev || TA);
-    if (plain && g_splitk && g_ws && big >= 16) {
+    if (plain && g_splitk && g_ws && big >= 16 && a.M > g_smallm) {
         const int splits = choose_splits((int)big, (a.K + BK - 1) / BK);
         if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
             return xm == 1 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s, splits)
@@ -597,6 +598,7 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     if (!env_read) {
         if (const char* e = getenv("SUBGC_SPLITK")) g_splitk = atoi(e);
         if (const char* e = getenv("SUBGC_RAGGED64")) g_ragged64 = atoi(e);
+        if (const char* e = getenv("SUBGC_SMALLM")) g_smallm = atoi(e);
         if (const char* e = getenv("SUBGC_GEMM_X3")) g_x3 = atoi(e);
         env_read = true;
     }
