@@ -193,6 +193,7 @@ __device__ __forceinline__ void frag(const float* lds, int r0, int c, int lane, 
 }
 
 #include "gemm_x3.h"
+#include "gemm_x3_k16.h"
 
 // ---- one (tile, k-range) unit of work: acc += A[m0.., kt0*BK .. kt1*BK) * B[.., n0..] --------------
 // Software pipeline (one barrier per K-tile, no MFMA bubble around it):
@@ -376,7 +377,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 
 // data-parallel form: one workgroup per output tile
 template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
-__global__ __launch_bounds__(XM ? 512 : 256) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // m_dev bounds the ROWS of the stored A: M when A is [M,K], K when A is stored transposed [K,M]
@@ -391,7 +392,10 @@ __global__ __launch_bounds__(XM ? 512 : 256) void gemm_f32_kernel(const GemmArgs
     const int m0 = tm * BM, n0 = tn * BN;
     f32x16 acc[MT][NT];
     zero_acc(acc);
-    if constexpr (XM != 0) {
+    if constexpr (XM >= 3) {
+        mainloop_x16_ws<BM, BN, TA, TB, MT, NT, (XM == 3 ? 6 : 1)>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+        if (threadIdx.x >= 256) return;
+    } else if constexpr (XM != 0) {
         mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
         if (threadIdx.x >= 256) return;                          // staging waves hold no accumulators
     } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(XM ? 512 : 256) void gemm_f32_kernel(const GemmArgs
 // and splitk_reduce_kernel sums the parts and applies the (bias / accumulate) epilogue.  Both launches
 // are stream-ordered; the workspace is just-written and comes back out of L2 / Infinity Cache.
 template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
-__global__ __launch_bounds__(XM ? 512 : 256) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
+__global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
@@ -423,7 +427,10 @@ __global__ __launch_bounds__(XM ? 512 : 256) void gemm_f32_splitk_kernel(const G
     const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
     f32x16 acc[MT][NT];
     zero_acc(acc);
-    if constexpr (XM != 0) {
+    if constexpr (XM >= 3) {
+        mainloop_x16_ws<BM, BN, TA, TB, MT, NT, (XM == 3 ? 6 : 1)>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
+        if (threadIdx.x >= 256) return;
+    } else if constexpr (XM != 0) {
         mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
         if (threadIdx.x >= 256) return;
     } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
@@ -491,7 +498,7 @@ template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
 int launch(const GemmArgs& a, hipStream_t s) {
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
-    const size_t lds = XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
     static bool attr_set = false;
     if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
@@ -526,7 +533,7 @@ template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
 int launch_splitk(const GemmArgs& a, hipStream_t s, int splits) {
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
-    const size_t lds = XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     const int tiles = (int)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM));
     const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
     static bool attr_set = false;
@@ -558,13 +565,14 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
         const double one = (double)((big + 511) / 512) * (kt + 3.0), two = (double)((2 * big + 511) / 512) * ((kt + 1) / 2 + 3.0) + 1.8;
         if (kt >= 64 && two < 0.9 * one) return launch_splitk<128, 128, TA, TB, VEC>(a, s, 2);
     }
-    if (big >= 384) return xm == 1 ? launch<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s) : xm == 2 ? launch<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s)
+    // kernel variants: 3 = three-plane split with 16-deep stages (two workgroups per CU), 2 = single bf16 plane with 32-deep stages
+    if (big >= 384) return xm == 1 ? launch<128, 128, TA, TB, VEC, VEC ? 3 : 0>(a, s) : xm == 2 ? launch<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s)
                                                                                                  : launch<128, 128, TA, TB, VEC>(a, s);
     const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && (!a.m_dev || TA);
     if (plain && g_splitk && g_ws && big >= 16 && a.M > g_smallm) {
         const int splits = choose_splits((int)big, (a.K + BK - 1) / BK);
         if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
-            return xm == 1 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 1 : 0>(a, s, splits)
+            return xm == 1 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 3 : 0>(a, s, splits)
                            : xm == 2 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s, splits) : launch_splitk<128, 128, TA, TB, VEC>(a, s, splits);
     }
     if (plain && g_splitk && g_ws) {

@@ -13,6 +13,9 @@
 // instead of 512, i.e. 2.67x the fp32-pipe rate at fp32-level accuracy (tests: error vs fp64 is within 2x of the
 // fp32-MFMA kernel's on every GEMM shape of the path).
 //
+// (The three-plane mode runs the 16-deep-stage variant of this loop, gemm_x3_k16.h -- two workgroups per CU; the loop in
+// this file serves the single-plane bf16 mode, whose 41 KB LDS image already allows that.)
+//
 // Data path per K-tile (BK = 32): fp32 operands HBM -> registers (float4, exactly like the fp32 kernel),
 // split on the VALU (2 and, 2 sub per element + 1.5 perm to pack), written to LDS as three bf16 planes in a
 // K-CONTIGUOUS image [row][32 k + 8 pad] whatever the operand's memory layout: a K-major operand (A^T or a
