@@ -40,7 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch_csv")
     ap.add_argument("write_csv")
-    ap.add_argument("--steps-total", type=int, required=True, help="warmup + accounting + timed steps of the profiled command")
+    ap.add_argument("--steps-total", type=int, default=0, help="steps of the profiled command (default: inferred from the dispatch count)")
     ap.add_argument("--launches-per-step", type=int, required=True, help="subgc_gemm_f32 calls per step (bench.py roofline.launches_per_step)")
     ap.add_argument("--alg-bytes-per-launch", type=float, default=None)
     a = ap.parse_args()
@@ -48,6 +48,13 @@ def main():
     w, wd = totals(a.write_csv, "WRITE_SIZE")
     fetch = 1024.0 * sum(f.values())                # KiB -> B; calibrated factor 1.0 (see above)
     write = 1024.0 * sum(w.values())
+    mains = sum(v for k, v in fd.items() if k != "splitk_reduce_kernel")          # one main kernel per subgc_gemm_f32 call
+    if not a.steps_total:
+        if mains % a.launches_per_step:
+            raise SystemExit(f"{mains} GEMM dispatches are not a multiple of {a.launches_per_step} launches per step")
+        a.steps_total = mains // a.launches_per_step
+    elif mains != a.steps_total * a.launches_per_step:
+        raise SystemExit(f"{mains} GEMM dispatches != {a.steps_total} steps x {a.launches_per_step} launches")
     launches = a.steps_total * a.launches_per_step
     out = {
         "counters": "FETCH_SIZE (calibrated on this kernel: factor 1.0) + WRITE_SIZE, separate --pmc passes, KiB",
