@@ -144,8 +144,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (Sub_GC_Kar bench workload: 128)")
-    ap.add_argument("--cpu-images", type=int, default=16)
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=32)
+    ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--packed-only", action="store_true", help="skip the extra unpacked-decoder leg (clean profiles)")
