@@ -364,3 +364,23 @@ def test_images_without_candidate_subgraphs(golden):
     np.testing.assert_array_equal(rs[1][0].cpu().numpy(), alone[0].cpu().numpy())
     rs = m.sample_images([e, n], opt=dict(sample_max=1, beam_size=3))
     assert [len(d) for d in m.done_beams] == [0, rs[1][0].shape[0]]
+
+
+def test_single_gpu_dataparallel_wrap_like_train_py(golden):
+    """train.py:95-98 wraps the model and the LossWrapper in nn.DataParallel unconditionally; with one visible GPU that is a
+    pass-through and must give the plain call's loss (with several GPUs use one process per GPU)."""
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    g = golden("subgc_train")
+    m = build(g, g.group("weights"), True)
+    lw = models.LossWrapper(m, None)
+    dp = torch.nn.DataParallel(lw)
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    args = (b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"], None,
+            b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+    out = dp(*args)
+    loss = out["lang_loss"].mean() + out["gpn_loss"].mean()            # train.py:152-156
+    loss.backward()
+    ref = g.group("out")
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(m.P("logit.weight").grad, g.group("grads")["logit.weight"], "grad", atol=2e-4, rtol=2e-3)
