@@ -251,7 +251,7 @@ def main():
             fams = ("gcn", "pool", "attn", "lstm", "softmax")
             for f_ in fams:
                 _lib.prof_enable(f_, True)
-            ops.FLOPS.update(on=True, attn_bytes=0.0)
+            ops.FLOPS.update(on=True, attn_bytes=0.0, pool_bytes=0.0)
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
@@ -260,8 +260,8 @@ def main():
             for f_ in fams:
                 _lib.prof_enable(f_, False)
                 n_, ms_, work_ = _lib.prof_collect(f_)
-                if f_ == "attn":
-                    work_ = ops.FLOPS.get("attn_bytes", 0.0)
+                if f_ in ("attn", "pool"):                                          # ragged families: bytes counted on the host side
+                    work_ = ops.FLOPS.get(f_ + "_bytes", 0.0)
                 if n_ and ms_ > 0:
                     gbps = work_ / (ms_ * 1e-3) / 1e9
                     hbm[f_] = {"launches_per_step": n_ // 2, "ms_per_step": round(ms_ / 2, 3), "algorithmic_MB_per_step": round(work_ / 2 / 1e6, 1),

@@ -172,7 +172,15 @@ def bn_bwd(dy, x, gamma, sm, sr):
     return dx, dg, db
 
 
+def _pool_account(denom, G, L, fwd):
+    if FLOPS["on"]:                      # untimed accounting step: the valid node rows of every sub-graph, not the padded N
+        rows = float(denom[:G].sum().item())
+        # fwd: read the member rows, write [max | mean] (+ arg-max);  bwd: read d[max | mean] + arg-max, read-modify-write the member rows
+        FLOPS["pool_bytes"] = FLOPS.get("pool_bytes", 0.0) + 4.0 * ((rows * L + 3.0 * G * L) if fwd else (3.0 * G * L + 2.0 * rows * L))
+
+
 def pool_fwd(X, idx, idx_stride, w, w_g, w_i, denom, img, G, N, L, want_argmax=True):
+    _pool_account(denom, G, L, True)
     out = torch.empty(G, 2 * L, device=X.device, dtype=torch.float32)
     am = torch.empty(G, L, device=X.device, dtype=torch.int32) if want_argmax else None
     call("subgc_subgraph_pool_fwd", _ptr(X), _ptr(idx, torch.int64), idx_stride, _ptr(w, torch.float32), w_g, w_i,
@@ -181,6 +189,7 @@ def pool_fwd(X, idx, idx_stride, w, w_g, w_i, denom, img, G, N, L, want_argmax=T
 
 
 def pool_bwd(dout, idx, idx_stride, w, w_g, w_i, denom, img, am, dX, G, N, L):
+    _pool_account(denom, G, L, False)
     call("subgc_subgraph_pool_bwd", _ptr(dout), _ptr(idx, torch.int64), idx_stride, _ptr(w), w_g, w_i, _ptr(denom),
          _ptr(img, torch.int32), _ptr(am, torch.int32), _ptr(dX), G, N, L, _stream())
     return dX
