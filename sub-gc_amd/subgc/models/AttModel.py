@@ -22,7 +22,7 @@ What is different by design (MI355X-first):
   * the attention sets are ragged-packed once; padded rows are never computed.
 
 Unsupported reference options fail loudly: `use_bn != 0` (BatchNorm inside att_embed, unused by
-every preset).  Scheduled sampling (`ss_prob > 0`) runs through DecoderFn with per-step logits and its own
+every preset; the reference's own forward raises for it: BatchNorm1d(att_feat_size) on gcn_dim-channel rows, AttModel.py:115).  Scheduled sampling (`ss_prob > 0`) runs through DecoderFn with per-step logits and its own
 counter-based RNG stream; beam search lives in `subgc/beam.py`.
 """
 from __future__ import annotations
