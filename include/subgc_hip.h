@@ -217,6 +217,13 @@ int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, 
                     float keep_scale, const float* dout, float* dtable, int n, int E, int vocab_rows,
                     void* stream);
 
+/* out[r,:] = table[tok[r],:] -- plain token-row lookup, float4 when the rows allow it.  Decode only: with frozen weights
+ * the x->gates product of the attention LSTM, relu(Emb) . W_ih[:, 2R:]^T (AttModel.py:332 feeding :409-411), depends on the
+ * token alone, so the host builds that [V+1, 4R] table once per set of weights and each step looks rows up instead of
+ * running an [n,E]x[E,4R] GEMM.  tok int64 [n] (tok_stride apart, clamped to [0, vocab_rows)); table [vocab_rows, C].   */
+int subgc_token_rows_f32(const float* table, int64_t ldt, const int64_t* tok, int64_t tok_stride, float* out,
+                         int64_t ldo, int n, int C, int vocab_rows, void* stream);
+
 /* fused LSTM cell pointwise (nn.LSTMCell, gate order i,f,g,o; AttModel.py:413,423):
  *   pre = g0 + g1 + g2 + b0 + b1   (g1, g2, b0, b1 may be NULL; each g* is [S,4R] with its own ld)
  *   c = sig(f) c_prev + sig(i) tanh(g);  h = sig(o) tanh(c);  gates[S,4R] keeps the activated

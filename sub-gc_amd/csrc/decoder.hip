@@ -69,6 +69,22 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
         out[(int64_t)r * E + c] = v;
     }
 }
+// plain row lookup by token: out[r, :] = table[tok[r], :]  (decode-time x->gates table, see subgc_token_rows_f32)
+__global__ __launch_bounds__(256) void token_rows_kernel(const float* __restrict__ table, int64_t ldt, const int64_t* __restrict__ tok,
+                                                         int64_t tok_stride, float* __restrict__ out, int64_t ldo, int C, int rows,
+                                                         int vec) {
+    const int r = blockIdx.x;
+    int64_t w = tok[(int64_t)r * tok_stride];
+    w = w < 0 ? 0 : (w >= rows ? rows - 1 : w);
+    const float* src = table + w * ldt;
+    float* dst = out + (int64_t)r * ldo;
+    if (vec) {
+        for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4)
+            *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = src[c];
+    }
+}
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
                                                         int64_t tok_stride, const uint8_t* __restrict__ keep, float scale,
                                                         const float* __restrict__ dout, float* __restrict__ dtable, int n, int E,
@@ -635,6 +651,16 @@ SUBGC_API int subgc_embed_fwd(const float* table, const int64_t* tok, int64_t to
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, tok, tok_stride, keep, keep_scale, out, n,
                        E, vocab_rows);
     return subgc::check_launch("subgc_embed_fwd");
+}
+SUBGC_API int subgc_token_rows_f32(const float* table, int64_t ldt, const int64_t* tok, int64_t tok_stride, float* out, int64_t ldo,
+                                   int n, int C, int vocab_rows, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && C > 0 && vocab_rows > 0 && ldt >= C && ldo >= C, "token_rows: bad sizes");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(table && tok && out, "token_rows: null pointer");
+    const int vec = (C % 4 == 0 && ldt % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(token_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, ldt, tok, tok_stride, out, ldo, C,
+                       vocab_rows, vec);
+    return subgc::check_launch("subgc_token_rows_f32");
 }
 SUBGC_API int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep, float keep_scale,
                               const float* dout, float* dtable, int n, int E, int vocab_rows, void* stream) {

@@ -478,7 +478,10 @@ class DecoderFn(Function):
 class DecodeState:
     """Step-wise decoder for sampling (AttModel._sample loop body): same kernels, batch n."""
 
-    def __init__(self, pr: Prepared, P, N, want_att):
+    def __init__(self, pr: Prepared, P, N, want_att, xt_table=None):
+        """`xt_table` [V+1, 4R] (optional, frozen weights only): relu(Emb) . W_ih[:, 2R:]^T, one row per token -- the x->gates
+        product of the attention LSTM looked up instead of recomputed every step (AttModel.xt_gates_table)."""
+        self.xt_table = xt_table
         (_, _, _, _, _, _, _, _, self.emb, w1i, w1h, self.b1i, self.b1h, w2i, w2h, self.b2i, self.b2h,
          self.h2a_w, self.h2a_b, self.an_w, self.an_b, self.lg_w, self.lg_b) = P
         self.pr, self.N = pr, N
@@ -530,8 +533,11 @@ class DecodeState:
     def step(self, it, alpha_out, normalize=True):
         S, R, A = self.S, self.R, self.A
         pr = self.pr
-        ops.embed_fwd(self.emb, it, 1, None, 1.0, self.xt)
-        ops.gemm(self.xt, self.W1x, self.Gx, tb=True)
+        if self.xt_table is not None:
+            ops.token_rows(self.xt_table, it, self.Gx)
+        else:
+            ops.embed_fwd(self.emb, it, 1, None, 1.0, self.xt)
+            ops.gemm(self.xt, self.W1x, self.Gx, tb=True)
         ops.gemm(self.H1, self.Wc1, self.pre, tb=True)
         ops.lstm_fwd(self.pre, self.Gx, self.Gf, self.b1i, self.b1h, self.C1[0], self.C1[1], self.H2[:, R:2 * R], self.H1[:, R:],
                      None, 1.0, None, None, S, R)

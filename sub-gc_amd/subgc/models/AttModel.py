@@ -366,6 +366,36 @@ class AttModel(CaptionModel):
     def _decoder_params(self):
         return [self.P(n) for n in F_.PARAM_ORDER]
 
+    def weights_version(self):
+        """Changes whenever the decoder weights may have: the flat buffer's address and in-place version (fused optimizer
+        step, all-reduce) plus every decoder Parameter's own version counter (load_state_dict's `param.copy_`, torch.optim's
+        in-place updates -- a Parameter whose `.data` is a view keeps a counter of its own).  Keys the decode-time snapshots
+        (K-concatenated LSTM weights, hipGraphs, the x->gates table).  Writes through `p.data.<op>_()` bump neither counter:
+        call `model.invalidate_decode_caches()` after those."""
+        fp = self.flat_params
+        return (fp.data_ptr(), fp._version, self.__dict__.get("_cache_epoch", 0)) + tuple(p._version for p in self._decoder_params())
+
+    def invalidate_decode_caches(self):
+        self.__dict__["_cache_epoch"] = self.__dict__.get("_cache_epoch", 0) + 1
+
+    @torch.no_grad()
+    def xt_gates_table(self):
+        """[V+1, 4R] table relu(Emb) . W_ih_att[:, 2R:]^T for decoding with frozen weights (eval mode; dropout is the identity
+        there, AttModel.py:106-108): the word-input term of the attention LSTM's gates depends on the token alone, so decode
+        steps look a row up instead of running embed + GEMM (functions.DecodeState).  152 MB at V+1 = 9488, R = 1000; built by one
+        [V+1,E]x[E,4R] GEMM (~0.7 ms) and rebuilt whenever the flat parameter buffer changes (its version counter)."""
+        fp = self.flat_params
+        key = self.weights_version()
+        hit = self.__dict__.get("_xt_table")
+        if hit is None or hit[0] != key:
+            R = self.rnn_size
+            emb = torch.relu(self.P("embed.0.weight"))
+            tab = torch.empty(emb.size(0), 4 * R, device=fp.device, dtype=torch.float32)
+            ops.gemm(emb, self.P("core.att_lstm.weight_ih")[:, 2 * R:], tab, tb=True)
+            hit = (key, tab)
+            self.__dict__["_xt_table"] = hit
+        return hit[1]
+
     def _forward(self, fc_feats, att_feats, seq, att_masks=None, trip_pred=None, obj_dist=None, obj_box=None, rel_ind=None,
                  pred_fmap=None, pred_dist=None, gpn_obj_ind=None, gpn_pred_ind=None, gpn_nrel_ind=None, gpn_pool_mtx=None,
                  fused_crit=None, need_outputs=True):

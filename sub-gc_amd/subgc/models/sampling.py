@@ -15,6 +15,7 @@ from __future__ import annotations
 
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 
 from .. import beam
@@ -41,18 +42,16 @@ def select_subgraphs(m, X2, N, images):
     images: list of (image_row, gpn_obj_ind [5,2,M,N], att_masks [5,2,M,N], gpn_pool_mtx [5,2,M,N,N]) -- only
     counterpart 0 is read, like gpn.py:86-96.  Returns a list of dicts(fc, lens, idx, img, score, keep)."""
     dev, L = X2.device, m.GCN_dim
-    idx_l, w_l, len_l, img_l, sizes = [], [], [], [], []
-    for row, gpn_obj_ind, att_masks, gpn_pool_mtx in images:
+    for _, gpn_obj_ind, _, _ in images:
         if gpn_obj_ind.size(0) != 5:
             raise AssertionError("test branch of sGPN expects the 5 counterparts of ONE image (gpn.py:84)")
-        idx = gpn_obj_ind[0].reshape(-1, N)                                            # pos slots then neg slots
-        idx_l.append(idx)
-        w_l.append(gpn_pool_mtx[0].diagonal(dim1=-2, dim2=-1).reshape(-1, N))
-        len_l.append(att_masks[0].reshape(-1, N).sum(1))
-        img_l.append(torch.full((idx.size(0),), row, device=dev, dtype=torch.int32))
-        sizes.append(idx.size(0))
-    idx, w = torch.cat(idx_l).contiguous(), torch.cat(w_l).contiguous()
-    lens_all, img = torch.cat(len_l).contiguous(), torch.cat(img_l)
+    # per-image pieces are views (pos slots then neg slots; the pooling weights are the diagonal of gpn_pool_mtx); every
+    # device op below runs ONCE over the concatenation of all images, so the host cost does not grow with the image count
+    idx = torch.cat([g[0].reshape(-1, N) for _, g, _, _ in images]).contiguous()
+    w = torch.cat([p_[0].diagonal(dim1=-2, dim2=-1).reshape(-1, N) for _, _, _, p_ in images]).contiguous()
+    lens_all = torch.cat([a[0].reshape(-1, N) for _, _, a, _ in images]).sum(1)
+    sizes = [g.size(1) * g.size(2) for _, g, _, _ in images]
+    img = torch.from_numpy(np.repeat(np.asarray([r for r, _, _, _ in images], dtype=np.int32), sizes)).to(dev)
     G = idx.size(0)
     read_out, _ = ops.pool_fwd(X2, idx, idx.stride(0), w, w.stride(0), 1, lens_all, img, G, N, L, want_argmax=False)
     if m.use_sGPN_score:
@@ -63,30 +62,31 @@ def select_subgraphs(m, X2, N, images):
     else:
         score = torch.ones(G, device=dev)
     lens_i = lens_all.to(torch.int32)
-    out = []
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     if not m.sct:                                                                      # use_nms (AttModel.py:95); node-set NMS is per image (gpn.py:108-138)
-        keep_all, n_keep, offs = ops.subgraph_nms_batched(score, idx, lens_i, sizes, m.gpn_nms_thres, m.gpn_max_subg)
-        kept = n_keep.cpu().tolist()                                                   # ONE launch and ONE host read for all images
-        for b, g0 in enumerate(offs[:-1]):
-            keep = keep_all[g0:g0 + kept[b]]
-            out.append(dict(keep=keep, glob=keep + g0))
+        keep_all, n_keep, _ = ops.subgraph_nms_batched(score, idx, lens_i, sizes, m.gpn_nms_thres, m.gpn_max_subg)
+        kept = n_keep.cpu().numpy().astype(np.int64)                                   # ONE launch and ONE host read for all images
+        g0 = np.repeat(offs[:-1], kept)                                                # first candidate of the owning image, per survivor
+        slot = g0 + (np.arange(int(kept.sum())) - np.repeat(np.cumsum(kept) - kept, kept))
+        hs = torch.from_numpy(np.stack([slot, g0])).to(dev)                            # one small upload
+        keep = keep_all[hs[0]]                                                         # survivors, image-local indices in original order
+        glob = keep + hs[1]
     else:
-        g0 = 0
-        for n_i in sizes:
-            keep = torch.arange(n_i, device=dev)
-            out.append(dict(keep=keep, glob=keep + g0))
-            g0 += n_i
-    glob = torch.cat([o["glob"] for o in out])
-    fc = torch.empty(glob.numel(), 2 * L, device=dev)
-    if glob.numel():
-        h = torch.empty(glob.numel(), m.att_hid_size, device=dev)
-        ops.gemm(read_out[glob].contiguous(), m.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
+        kept = np.asarray(sizes, dtype=np.int64)
+        glob = torch.arange(G, device=dev)
+        keep = glob - torch.from_numpy(np.repeat(offs[:-1], kept)).to(dev)
+    n = glob.numel()
+    fc = torch.empty(n, 2 * L, device=dev)
+    if n:
+        h = torch.empty(n, m.att_hid_size, device=dev)
+        ops.gemm(read_out[glob], m.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
         ops.gemm(h, m.P("gpn_layer.read_out_proj.1.weight"), fc, tb=True, bias=m.P("gpn_layer.read_out_proj.1.bias"))
-    r0 = 0
-    for o in out:
-        g, n = o.pop("glob"), o["keep"].numel()
-        o.update(fc=fc[r0:r0 + n], lens=lens_i[g].contiguous(), idx=idx[g].contiguous(), img=img[g].contiguous(), score=score[g])
-        r0 += n
+    lens_g, idx_g, img_g, score_g = lens_i[glob], idx[glob], img[glob], score[glob]
+    out, r0 = [], 0
+    for k_ in kept.tolist():                                                           # per-image results are row slices (views)
+        r1 = r0 + k_
+        out.append(dict(keep=keep[r0:r1], fc=fc[r0:r1], lens=lens_g[r0:r1], idx=idx_g[r0:r1], img=img_g[r0:r1], score=score_g[r0:r1]))
+        r0 = r1
     return out
 
 
@@ -126,7 +126,7 @@ class _GraphedLoop:
         cap = n * N
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
-        self.st = F_.DecodeState(self.pr, P, N, return_att)
+        self.st = F_.DecodeState(self.pr, P, N, return_att, xt_table=m.xt_gates_table())
         self.seq, self.seqlp = z(n, T, dt=torch.long), z(n, T)
         self.it, self.unfinished, self.counts = z(n, dt=torch.long), z(n, dt=torch.int32), z(T, dt=torch.int32)
         self.AL = z(T + 1, n, N) if return_att else None
@@ -162,7 +162,7 @@ class _GraphedLoop:
 
 
 def _graphed_loop(m, n, N, k, return_att, P):
-    key = (n, N, k, return_att, m.flat_params.data_ptr(), m.flat_params._version)
+    key = (n, N, k, return_att) + m.weights_version()
     cache = m.__dict__.setdefault("_graph_cache", {})
     if key not in cache:
         for old in [q for q in cache if q[:4] == key[:4]]:                       # parameters changed: drop the stale snapshot
@@ -212,7 +212,7 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     if graphed is not None:
         seq, seqlp, counts, AL = graphed.run(pr, uniforms)
     else:
-        st = F_.DecodeState(pr, P, N, return_att)
+        st = F_.DecodeState(pr, P, N, return_att, xt_table=m.xt_gates_table())
         seq = torch.zeros(n, T, device=dev, dtype=torch.long)
         seqlp = torch.zeros(n, T, device=dev)
         it = torch.zeros(n, device=dev, dtype=torch.long)
@@ -237,11 +237,12 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
         # per-image early break: image i stops after the first step at which none of ITS rows is unfinished; the
         # reference writes nothing (tokens, log-probs, attention rows) beyond that step
         alive = (seq > 0).int().cumprod(1)                                             # [n, T] row still unfinished after step t
-        per = torch.stack([alive[a:b].sum(0) for a, b in zip(bounds, bounds[1:])])     # [I, T]
+        row_img = torch.from_numpy(np.repeat(np.arange(len(sizes)), sizes)).to(dev)    # owning image of every row
+        per = torch.zeros(len(sizes), T, device=dev, dtype=alive.dtype).index_add_(0, row_img, alive)   # [I, T] unfinished rows per image
         stopped = (per == 0).int()
         brk = torch.where(stopped.any(1), stopped.argmax(1), torch.full_like(stopped[:, 0], T - 1).long())   # break step per image
         tgrid = torch.arange(T, device=dev).view(1, T)
-        row_brk = torch.repeat_interleave(brk, torch.tensor(sizes, device=dev))
+        row_brk = brk[row_img]
         seqlp = seqlp * (tgrid <= row_brk.view(-1, 1))
         steps = [min(int(b) + 1, T) + (1 if int(b) == T - 1 and not bool(s.any()) else 0) for b, s in zip(brk.cpu(), stopped.cpu())]
     out = []

@@ -263,6 +263,13 @@ def embed_fwd(table, tok, tok_stride, keep, scale, out):
     return out
 
 
+def token_rows(table, tok, out, tok_stride=1):
+    """out[r] = table[tok[r]] (int64 tokens): the decode-time lookup into a per-token table (subgc_token_rows_f32)."""
+    call("subgc_token_rows_f32", _ptr(table, torch.float32), ld(table), _ptr(tok, torch.int64), tok_stride, _ptr(out, torch.float32), ld(out),
+         out.size(0), out.size(1), table.size(0), _stream())
+    return out
+
+
 def embed_bwd(table, tok, tok_stride, keep, scale, dout, dtable):
     n, E = dout.shape
     call("subgc_embed_bwd", _ptr(table), _ptr(tok, torch.int64), tok_stride, _ptr(keep, torch.uint8), float(scale), _ptr(dout),
