@@ -87,13 +87,13 @@ def _beam_step(grp, vals, idx, tau, bd, unk, constraint, earlier, lam):
 class _BatchEngine:
     """All sub-graphs x beams of an image batch as rows of one DecodeState (the product path)."""
 
-    def __init__(self, pr, P, N, beam):
+    def __init__(self, pr, P, N, beam, xt_table=None):
         n, dev = pr.S, pr.f.device
         self.n, self.rows, self.dev = n, n * beam, dev
         rep = torch.arange(n, device=dev).repeat_interleave(beam)
         prb = SimpleNamespace(S=self.rows, N=N, f=pr.f.index_select(0, rep).contiguous(), u=pr.u, v=pr.v,
                               off=pr.off.index_select(0, rep).contiguous(), lens=pr.lens.index_select(0, rep).contiguous())
-        self.st = F_.DecodeState(prb, P, N, False)
+        self.st = F_.DecodeState(prb, P, N, False, xt_table=xt_table)
         self.V1 = self.st.V1
 
     def _topk(self, logits, kk):
@@ -157,10 +157,10 @@ class _StepEngine:
 
 
 @torch.no_grad()
-def beam_decode(pr, P, N, T, opt):
+def beam_decode(pr, P, N, T, opt, xt_table=None):
     """Decode every sub-graph of `pr` (an F_.Prepared) with beam search.
     Returns (seq [n, T] int64, seqLogprobs [n, T] fp32, done_beams) -- CPU tensors, as the reference's are."""
-    return search(_BatchEngine(pr, P, N, int(opt.get("beam_size", 10))), T, opt)
+    return search(_BatchEngine(pr, P, N, int(opt.get("beam_size", 10)), xt_table), T, opt)
 
 
 @torch.no_grad()

@@ -194,7 +194,7 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     for s in sizes:
         bounds.append(bounds[-1] + s)
     if beam_size > 1:                                                                  # AttModel.py:245-246 -> :179-234
-        seq, seqlp, done = beam.beam_decode(pr, P, N, T, opt)
+        seq, seqlp, done = beam.beam_decode(pr, P, N, T, opt, xt_table=m.xt_gates_table())
         m.done_beams = done if len(sel) == 1 else [done[a:b] for a, b in zip(bounds, bounds[1:])]
         return [(seq[a:b], seqlp[a:b], s["score"], s["keep"]) for s, a, b in zip(sel, bounds, bounds[1:])]
     k = m.the_k if m.topk_sampling else 0

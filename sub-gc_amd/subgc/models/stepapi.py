@@ -59,7 +59,7 @@ def get_logprobs_state(m, it, fc_feats, att_feats, p_att_feats, att_masks, state
     pr = SimpleNamespace(S=b, N=n_max, f=fc_feats.contiguous(), u=p_att_feats.contiguous().view(b * n_max, -1),
                          v=att_feats.contiguous().view(b * n_max, R),
                          off=(torch.arange(b, device=dev, dtype=torch.int32) * n_max).contiguous(), lens=lens)
-    st = F_.DecodeState(pr, P, n_max, return_att)
+    st = F_.DecodeState(pr, P, n_max, return_att, xt_table=m.xt_gates_table())
     h, c = state
     st.H1[:, :R] = h[1]; st.H1[:, R:] = h[0]                                      # [h_lang | h_att]
     st.H2[:, 2 * R:] = h[1]
