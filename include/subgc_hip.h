@@ -217,6 +217,18 @@ int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, 
                     float keep_scale, const float* dout, float* dtable, int n, int E, int vocab_rows,
                     void* stream);
 
+/* One LSTMCell step (AttModel.py:411, :423 -> nn.LSTMCell) for a decode batch of S <= 16 rows in ONE launch: the gate
+ * GEMM x[S,K] . w_perm[4R,K]^T streams the weights through the matrix pipe and the cell update runs in its epilogue.
+ * w_perm is the K-concatenated gate matrix [W_ih | W_hh] with PERMUTED rows: row 16*b + 4*g + u holds gate g (i,f,g,o)
+ * of hidden unit 4*b + u, so a workgroup's 16 rows are everything four units need.  pre = x.w^T + b0 + b1
+ * + add1[tok ? tok[s] : s] + add2[s]  (add1/add2 [*,4R] in the UNpermuted gate order, optional; tok int64 [S] selects
+ * rows of a [tok_rows,4R] table);  c = f*c_prev + i*g;  h = o*tanh(c) is stored to every non-null h0/h1/h2 (row
+ * stride ldh*).  x must not alias any h destination (the caller ping-pongs its state buffers).  R % 4 == 0.          */
+int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R,
+                           const float* add1, int64_t ld1, const int64_t* tok, int tok_rows, const float* add2,
+                           int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c, float* h0,
+                           int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2, void* stream);
+
 /* out[r,:] = table[tok[r],:] -- plain token-row lookup, float4 when the rows allow it.  Decode only: with frozen weights
  * the x->gates product of the attention LSTM, relu(Emb) . W_ih[:, 2R:]^T (AttModel.py:332 feeding :409-411), depends on the
  * token alone, so the host builds that [V+1, 4R] table once per set of weights and each step looks rows up instead of

@@ -8,6 +8,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -72,6 +73,135 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_nt_kernel(const float*
     }
 }
 
+// ---- third version: the matrix pipe as a reduction engine -------------------------------------------------------------
+// Profiling the VALU form above in the one-image decode (21 us for the 38 MB logit matrix, 20 us for the 48 MB lang-LSTM
+// matrix: ~2 TB/s) showed a single-shot timeline -- stage A in LDS, barrier, wait for every W load, THEN 8 waves x
+// (120 ds_read_b128 + 120 ds_bpermute) on the one LDS port -- with nothing overlapped.  v_mfma_f32_16x16x4_f32 contracts
+// 16 W rows against <= 16 activation rows with NO cross-lane reduction and no LDS staging at all:
+//   * a workgroup owns 16 consecutive W rows; its WAVES waves interleave the K axis in 16-wide steps (wave w takes steps
+//     w, w+WAVES, ...), so together they walk 16 x (WAVES x 64 B) contiguous bytes per row and iteration;
+//   * lane l loads ONE float4 of W (row l%16, k = step*16 + (l/16)*4 .. +3) and ONE float4 of the activations (row l%16 = m,
+//     same k) per step; component j of both feeds the j-th of four MFMAs (the k-slot <-> address map only has to agree
+//     between the two operands).  The activations come straight from L2 (<= 192 KB, read by every workgroup);
+//   * loads run D steps ahead in a register ring, unconditional and clamped, so the compiler's vmcnt waits stay partial;
+//   * the WAVES partial 16x16 tiles are summed through 8 KB of LDS in a fixed order (deterministic), + bias, ReLU.
+// 37.5 % of the matrix pipe's columns are padding at M = 10 -- irrelevant: the pipe needs 2 us of the ~10 us the stream takes.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LSTM form (LSTM = true): W is the [4R, K] gate matrix with its rows PERMUTED so that a workgroup's 16 rows are the four
+// gates (i, f, g, o) of four consecutive hidden units (row 16*b + 4*g + u  <-  gate g of unit 4*b + u).  The cell update then
+// runs in the epilogue of the same launch -- c = f*c_prev + i*g, h = o*tanh(c), h stored to up to three places -- so a
+// decode step needs no separate pointwise kernel and the [S, 4R] pre-activations never reach memory.  The additive gate
+// terms (a per-token table row or a plain [S,4R] array, a second [S,4R] array, two bias vectors) and c_prev are fetched
+// by wave 0 BEFORE the K loop, so their latency hides behind the weight stream.
+struct LstmEpi {
+    const float* add1; int64_t ld1; const int64_t* tok; int tok_rows;       // add1 row = tok ? clamp(tok[m]) : m
+    const float* add2; int64_t ld2;
+    const float* b0; const float* b1;
+    const float* c_prev; float* c;
+    float* h0; int64_t ldh0; float* h1; int64_t ldh1; float* h2; int64_t ldh2;
+    int R;
+};
+
+template <int WAVES, int D, bool LSTM>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                                      int64_t ldb, float* __restrict__ C, int64_t ldc,
+                                                                      const float* __restrict__ bias, int M, int N, int K, int relu,
+                                                                      LstmEpi ep) {
+    __shared__ float part[WAVES][256];
+    __shared__ float tile[LSTM ? 256 : 1];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: uniform loop control
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const float* wrow = W + (int64_t)min(n0 + r16, N - 1) * ldb;            // rows past N: clamped, their results are not stored
+    const float* arow = A + (int64_t)min(r16, M - 1) * lda;              // columns m >= M of the tile: garbage, never stored
+    const int steps = (K + 15) >> 4, steps_full = K >> 4;                     // 16-wide K steps; only the last one can be partial
+    const int mine = steps > wave ? (steps - wave + WAVES - 1) / WAVES : 0;   // steps of this wave ...
+    const int mine_full = steps_full > wave ? (steps_full - wave + WAVES - 1) / WAVES : 0;   // ... that lie entirely inside K
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float4 wq[D], aq[D];
+    float gadd[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;                        // LSTM: wave 0, lane (u = lane/16, m = lane%16)
+    const int eu = lane >> 4, em = lane & 15, ej = blockIdx.x * 4 + eu;
+    const bool elive = LSTM && wave == 0 && em < M && ej < ep.R;
+    if (elive) {
+        int64_t row1 = em;
+        if (ep.tok) { const int64_t w = ep.tok[em]; row1 = w < 0 ? 0 : (w >= ep.tok_rows ? ep.tok_rows - 1 : w); }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = g * ep.R + ej;
+            float v = 0.f;
+            if (ep.b0) v += ep.b0[col];
+            if (ep.b1) v += ep.b1[col];
+            if (ep.add1) v += ep.add1[row1 * ep.ld1 + col];
+            if (ep.add2) v += ep.add2[(int64_t)em * ep.ld2 + col];
+            gadd[g] = v;
+        }
+        if (ep.c_prev) cprev = ep.c_prev[(int64_t)em * ep.R + ej];
+    }
+    auto k_of = [&](int i) { return ((wave + i * WAVES) << 4) + (kq << 2); };
+    auto issue = [&](int slot, int i) {                                       // i-th step of this wave -> ring slot (static index)
+        const int k = k_of(i);
+        const int kc = (i < mine && k < K) ? k : 0;                           // clamped address, never a predicated load
+        wq[slot] = ld4(wrow + kc);
+        aq[slot] = ld4(arow + kc);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, d);
+    int r = 0;
+    for (; (r + 1) * D <= mine_full; ++r) {                                   // steady state: no selects, partial vmcnt waits only
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float4 w = wq[d], a = aq[d];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc, 0, 0, 0);
+            issue(d, (r + 1) * D + d);
+        }
+    }
+    for (; r * D < mine; ++r) {                                               // tail: steps past this wave's share or past K add zeros
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = r * D + d;
+            const bool in = i < mine && k_of(i) < K;
+            const float4 w = wq[d], a = aq[d];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, in ? a.x : 0.f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, in ? a.y : 0.f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, in ? a.z : 0.f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, in ? a.w : 0.f, acc, 0, 0, 0);
+            issue(d, (r + 1) * D + d);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[wave][v * 64 + lane] = acc[v];
+    __syncthreads();
+    if (t < 256) {                                                            // element (row 4*(l/16)+v of the 16 W rows, m = l%16)
+        const int v = t >> 6, l = t & 63;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sum += part[w][v * 64 + l];
+        const int n = n0 + 4 * (l >> 4) + v, m = l & 15;
+        if (LSTM) tile[(4 * (l >> 4) + v) * 16 + m] = sum;                    // row 4*g + u of this workgroup, column m
+        else if (m < M && n < N) {
+            float o = sum + (bias ? bias[n] : 0.f);
+            if (relu) o = fmaxf(o, 0.f);
+            C[(int64_t)m * ldc + n] = o;
+        }
+    }
+    if (LSTM) {
+        __syncthreads();
+        if (elive) {
+            const float ig = sigmoidf_(tile[(0 + eu) * 16 + em] + gadd[0]), fg = sigmoidf_(tile[(4 + eu) * 16 + em] + gadd[1]);
+            const float gg = tanhf(tile[(8 + eu) * 16 + em] + gadd[2]), og = sigmoidf_(tile[(12 + eu) * 16 + em] + gadd[3]);
+            const float cn = fg * cprev + ig * gg, hn = og * tanhf(cn);
+            ep.c[(int64_t)em * ep.R + ej] = cn;
+            if (ep.h0) ep.h0[(int64_t)em * ep.ldh0 + ej] = hn;
+            if (ep.h1) ep.h1[(int64_t)em * ep.ldh1 + ej] = hn;
+            if (ep.h2) ep.h2[(int64_t)em * ep.ldh2 + ej] = hn;
+        }
+    }
+}
+
 template <int KPT4, int RB, int WAVES>
 int launch(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N, int K,
            int relu, hipStream_t s) {
@@ -109,6 +239,16 @@ namespace subgc {
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                    int relu, hipStream_t s) {
     if (M < 1 || M > 16) return -100;
+    static const int form = [] { const char* e = getenv("SUBGC_SKINNY"); return e ? atoi(e) : 1; }();   // 0: the VALU form (A/B timing)
+    if (form == 1) {
+        const int wgs = (N + 15) / 16;
+        const int per_wave = ((K + 15) / 16 + 7) / 8;                          // ring depth: the deeper one unless it leaves more idle slots
+        if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
+            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, false>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{});
+        else
+            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, false>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{});
+        return subgc::check_launch("subgc_gemm_f32(skinny)");
+    }
     const int k4 = (K + 3) / 4;                       // float4 per row; a wave covers 64 of them per KPT4 step
     if (k4 <= 64 * 4) return pick_rb<4>(A, lda, W, ldb, C, ldc, bias, M, N, K, relu, s);
     if (k4 <= 64 * 8) return pick_rb<8>(A, lda, W, ldb, C, ldc, bias, M, N, K, relu, s);
@@ -118,3 +258,26 @@ int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, flo
 }
 
 }  // namespace subgc
+
+// ---- C ABI: one LSTM cell step of a decode batch of <= 16 rows, gate GEMM and cell update in one launch ---------------------
+SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
+                                     int64_t ld1, const int64_t* tok, int tok_rows, const float* add2, int64_t ld2, const float* b0,
+                                     const float* b1, const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1,
+                                     float* h2, int64_t ldh2, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && S <= 16 && R > 0 && R % 4 == 0 && K > 0 && K % 4 == 0, "lstm_step_skinny: need S <= 16, R % 4 == 0, K % 4 == 0");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(x && w_perm && c && (h0 || h1 || h2), "lstm_step_skinny: null pointer");
+    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % 16) == 0,
+                  "lstm_step_skinny: x / w_perm rows must be 16-byte aligned float4 rows");
+    SUBGC_REQUIRE(!tok || (add1 && tok_rows > 0), "lstm_step_skinny: tok needs a table in add1");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
+    LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R};
+    const int N = 4 * R, wgs = N / 16;
+    const int per_wave = ((K + 15) / 16 + 7) / 8;
+    if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, true>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep);
+    else
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, true>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep);
+    return subgc::check_launch("subgc_lstm_step_skinny");
+}

@@ -478,10 +478,14 @@ class DecoderFn(Function):
 class DecodeState:
     """Step-wise decoder for sampling (AttModel._sample loop body): same kernels, batch n."""
 
-    def __init__(self, pr: Prepared, P, N, want_att, xt_table=None):
+    def __init__(self, pr: Prepared, P, N, want_att, xt_table=None, fuse_lstm=False):
         """`xt_table` [V+1, 4R] (optional, frozen weights only): relu(Emb) . W_ih[:, 2R:]^T, one row per token -- the x->gates
-        product of the attention LSTM looked up instead of recomputed every step (AttModel.xt_gates_table)."""
+        product of the attention LSTM looked up instead of recomputed every step (AttModel.xt_gates_table).
+        `fuse_lstm` (<= 16 rows, R % 4 == 0): each LSTM cell is ONE launch, gate GEMM + cell update (subgc_lstm_step_skinny) on
+        row-permuted weight snapshots; h is written into the OTHER buffer of an [H1, H1n] / [H2, H2n] pair, because the
+        launch that produces it is still reading the current one.  Not for callers that touch H1/H2 themselves (beam, step API)."""
         self.xt_table = xt_table
+        self.fused = bool(fuse_lstm) and pr.S <= 16 and P[10].size(1) % 4 == 0
         (_, _, _, _, _, _, _, _, self.emb, w1i, w1h, self.b1i, self.b1h, w2i, w2h, self.b2i, self.b2h,
          self.h2a_w, self.h2a_b, self.an_w, self.an_b, self.lg_w, self.lg_b) = P
         self.pr, self.N = pr, N
@@ -491,6 +495,10 @@ class DecodeState:
         self.S, self.R, self.E, self.A, self.V1 = S, R, E, self.h2a_w.size(0), self.lg_w.size(0)
         self.Wc1 = _cat_weights(w1i[:, :R], w1h)
         self.Wc2 = _cat_weights(w2i, w2h)
+        if self.fused:
+            perm = ops.lstm_gate_perm(R, dev)
+            self.Wc1, self.Wc2 = self.Wc1[perm].contiguous(), self.Wc2[perm].contiguous()    # only the permuted snapshots are kept
+            self.H1n, self.H2n = ops.zeros(S, 2 * R, device=dev), ops.zeros(S, 3 * R, device=dev)
         self.W1x = w1i[:, 2 * R:]
         self.W1f = w1i[:, R:2 * R]
         self.Gf = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
@@ -530,7 +538,32 @@ class DecodeState:
         self._alt = [self.H1, self.H2, self.C1[0], self.C2[0]]
         self.H1, self.H2, self.C1[0], self.C2[0] = a1, a2, ac1, ac2
 
+    def _step_fused(self, it, alpha_out, normalize):
+        S, R, A = self.S, self.R, self.A
+        pr = self.pr
+        if self.xt_table is not None:
+            add1, tok = self.xt_table, it
+        else:
+            ops.embed_fwd(self.emb, it, 1, None, 1.0, self.xt)
+            ops.gemm(self.xt, self.W1x, self.Gx, tb=True)
+            add1, tok = self.Gx, None
+        ops.lstm_step_skinny(self.H1, self.Wc1, self.C1[0], self.C1[1], [self.H2[:, R:2 * R], self.H1n[:, R:]], self.b1i, self.b1h,
+                             add1, tok, self.Gf)
+        self.C1.reverse()
+        ops.gemm(self.H2[:, R:2 * R], self.h2a_w, self.ah, tb=True, bias=self.h2a_b)
+        ops.attn_fwd(pr.u, pr.v, self.ah, self.an_w, self.an_b, pr.off, pr.lens, self.H2[:, :R], alpha_out, S, A, R)
+        ops.lstm_step_skinny(self.H2, self.Wc2, self.C2[0], self.C2[1], [self.H1n[:, :R], self.H2n[:, 2 * R:], self.hout], self.b2i, self.b2h)
+        self.C2.reverse()
+        self.H1, self.H1n = self.H1n, self.H1
+        self.H2, self.H2n = self.H2n, self.H2
+        ops.gemm(self.hout, self.lg_w, self.logits, tb=True, bias=self.lg_b)
+        if normalize:
+            ops.log_softmax_rows_(self.logits)
+        return self.logits
+
     def step(self, it, alpha_out, normalize=True):
+        if self.fused:
+            return self._step_fused(it, alpha_out, normalize)
         S, R, A = self.S, self.R, self.A
         pr = self.pr
         if self.xt_table is not None:

@@ -270,6 +270,27 @@ def token_rows(table, tok, out, tok_stride=1):
     return out
 
 
+def lstm_gate_perm(R, device):
+    """Row order of the permuted gate matrix subgc_lstm_step_skinny reads: row 16*b + 4*g + u <- gate g of unit 4*b + u."""
+    p = torch.arange(4 * R, device=device)
+    return (p % 16 // 4) * R + (p // 16) * 4 + p % 4
+
+
+def lstm_step_skinny(x, w_perm, c_prev, c, hs, b0=None, b1=None, add1=None, tok=None, add2=None):
+    """One LSTMCell step for <= 16 rows, GEMM + cell update in one launch (subgc_lstm_step_skinny).  `hs`: up to three 2-D
+    views that receive h (none may alias x)."""
+    S, K = x.shape
+    R = c.size(1)
+    hs = list(hs) + [None] * (3 - len(hs))
+    hp = []
+    for h_ in hs:
+        hp += [_ptr(h_, torch.float32), ld(h_) if h_ is not None else 0]
+    call("subgc_lstm_step_skinny", _ptr(x, torch.float32), ld(x), _ptr(w_perm, torch.float32), ld(w_perm), K, S, R,
+         _ptr(add1, torch.float32), ld(add1) if add1 is not None else 0, _ptr(tok, torch.int64), add1.size(0) if tok is not None else 0,
+         _ptr(add2, torch.float32), ld(add2) if add2 is not None else 0, _ptr(b0, torch.float32), _ptr(b1, torch.float32),
+         _ptr(c_prev, torch.float32), _ptr(c, torch.float32), *hp, _stream())
+
+
 def embed_bwd(table, tok, tok_stride, keep, scale, dout, dtable):
     n, E = dout.shape
     call("subgc_embed_bwd", _ptr(table), _ptr(tok, torch.int64), tok_stride, _ptr(keep, torch.uint8), float(scale), _ptr(dout),

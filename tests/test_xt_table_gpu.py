@@ -48,9 +48,9 @@ def test_decode_with_and_without_the_table(golden, name, monkeypatch):
     seen = []
     orig = F_.DecodeState.__init__
 
-    def no_table(self, pr, P, N, want_att, xt_table=None):
+    def no_table(self, pr, P, N, want_att, xt_table=None, **kw):
         seen.append(xt_table is not None)
-        orig(self, pr, P, N, want_att, None)
+        orig(self, pr, P, N, want_att, None, **kw)
 
     monkeypatch.setattr(F_.DecodeState, "__init__", no_table)
     m.__dict__.pop("_graph_cache", None)                                          # the cached hipGraph holds a table-backed state
@@ -76,3 +76,58 @@ def test_cached_decode_state_follows_load_state_dict(golden):
     assert torch.equal(again[0], fresh[0])
     torch.testing.assert_close(again[1], fresh[1], atol=1e-5, rtol=1e-5)
     assert not torch.allclose(first[1], again[1])
+
+
+@pytest.mark.parametrize("S,R,K", [(1, 48, 96), (10, 1000, 2000), (16, 1000, 3000), (7, 52, 1000)])
+def test_fused_lstm_step_equals_gemm_plus_cell(S, R, K):
+    """subgc_lstm_step_skinny (row-permuted weights, cell update in the GEMM epilogue) vs fp64 LSTMCell arithmetic."""
+    g = torch.Generator().manual_seed(S * 1000 + R)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    x, W = rnd(S, K), rnd(4 * R, K, sc=K ** -0.5)
+    b0, b1, add2, cp = rnd(4 * R, sc=0.3), rnd(4 * R, sc=0.3), rnd(S, 4 * R, sc=0.5), rnd(S, R)
+    table = rnd(23, 4 * R, sc=0.5)
+    tok = torch.randint(-1, 25, (S,), generator=g).to(DEV)
+    Wp = W[ops.lstm_gate_perm(R, DEV)].contiguous()
+    for use_tok in (True, False):
+        c = torch.empty(S, R, device=DEV)
+        wide = torch.full((S, 3 * R), 9.0, device=DEV)                              # h lands in column slices of wider buffers
+        h2 = torch.empty(S, R, device=DEV)
+        add1 = table if use_tok else table[tok.clamp(0, 22)].contiguous()
+        ops.lstm_step_skinny(x, Wp, cp, c, [wide[:, R:2 * R], h2], b0, b1, add1, tok if use_tok else None, add2)
+        pre = x.double() @ W.double().t() + b0.double() + b1.double() + table[tok.clamp(0, 22)].double() + add2.double()
+        i, f, gg, o = pre[:, :R].sigmoid(), pre[:, R:2 * R].sigmoid(), pre[:, 2 * R:3 * R].tanh(), pre[:, 3 * R:].sigmoid()
+        cn = f * cp.double() + i * gg
+        hn = o * cn.tanh()
+        torch.testing.assert_close(c.double(), cn, atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(h2.double(), hn, atol=2e-5, rtol=1e-5)
+        assert torch.equal(wide[:, R:2 * R], h2) and float(wide[:, :R].min()) == 9.0 and float(wide[:, 2 * R:].min()) == 9.0
+    c2 = torch.empty(S, R, device=DEV)                                               # no additive terms, no c_prev
+    ops.lstm_step_skinny(x, Wp, None, c2, [h2])
+    pre = x.double() @ W.double().t()
+    want = pre[:, :R].sigmoid() * pre[:, 2 * R:3 * R].tanh()
+    torch.testing.assert_close(c2.double(), want, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["subgc_greedy", "subgc_greedy_nms55", "subgc_sct"])
+def test_decode_with_fused_and_unfused_lstm_steps(golden, name, monkeypatch):
+    g = golden(name)
+    m = build(g, golden("subgc_train").group("weights"), False)
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    opt = g.meta["sample_opt"]
+    fused = m(*synthetic.sample_args(b), opt=opt, mode="sample")
+    used = []
+    orig = F_.DecodeState.__init__
+
+    def unfused(self, *a, fuse_lstm=False, **kw):
+        used.append(fuse_lstm)
+        orig(self, *a, fuse_lstm=False, **kw)
+
+    monkeypatch.setattr(F_.DecodeState, "__init__", unfused)
+    m.__dict__.pop("_graph_cache", None)
+    plain = m(*synthetic.sample_args(b), opt=opt, mode="sample")
+    assert used and all(used)                                                        # the product path asked for the fused steps
+    assert torch.equal(fused[0], plain[0])
+    torch.testing.assert_close(fused[1], plain[1], atol=1e-4, rtol=1e-4)
+    np.testing.assert_array_equal(fused[0].cpu().numpy(), g.group("out")["seq"])
+    if opt.get("return_att"):
+        torch.testing.assert_close(fused[4], plain[4], atol=1e-5, rtol=1e-4)
