@@ -617,8 +617,9 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     const bool vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0);
     const bool vec = vecA && vecB;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
-    if (!transA && transB && M <= 16 && vec && N >= 64 && !add && !keep && !(flags & SUBGC_GEMM_ACCUM) && !a_rows && !c_rows && !m_dev) {
-        const int rc = subgc::gemm_skinny_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, (flags & SUBGC_GEMM_RELU) ? 1 : 0, s);
+    if (!transA && transB && M <= 80 && vec && N >= 64 && !keep && !(flags & SUBGC_GEMM_ACCUM) && !a_rows && !c_rows && !m_dev &&
+        (!add || add != C)) {
+        const int rc = subgc::gemm_skinny_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, (flags & SUBGC_GEMM_RELU) ? 1 : 0, s, add, ldadd);
         if (rc != -100) return rc;      // -100: shape not covered by the weight-streaming form
     }
     if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);

@@ -103,23 +103,30 @@ struct LstmEpi {
     int R;
 };
 
-template <int WAVES, int D, bool LSTM>
+// MT > 1: the same stream against MT 16-row activation tiles (M <= 16*MT: the one-image encoder GEMMs, 37 node / 65 relation
+// rows) -- one W load, MT activation loads and 4*MT MFMAs per step; `add` [M,N] is an optional residual term of the epilogue.
+template <int WAVES, int D, bool LSTM, int MT>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                                       int64_t ldb, float* __restrict__ C, int64_t ldc,
                                                                       const float* __restrict__ bias, int M, int N, int K, int relu,
-                                                                      LstmEpi ep) {
-    __shared__ float part[WAVES][256];
+                                                                      LstmEpi ep, const float* __restrict__ add, int64_t ldadd) {
+    static_assert(!LSTM || MT == 1, "the fused cell update handles one 16-row activation tile");
+    __shared__ float part[WAVES][MT * 256];
     __shared__ float tile[LSTM ? 256 : 1];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: uniform loop control
     const int r16 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const float* wrow = W + (int64_t)min(n0 + r16, N - 1) * ldb;            // rows past N: clamped, their results are not stored
-    const float* arow = A + (int64_t)min(r16, M - 1) * lda;              // columns m >= M of the tile: garbage, never stored
+    const float* arow[MT];                                                 // columns m >= M of a tile: garbage, never stored
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (int64_t)min(mt * 16 + r16, M - 1) * lda;
     const int steps = (K + 15) >> 4, steps_full = K >> 4;                     // 16-wide K steps; only the last one can be partial
     const int mine = steps > wave ? (steps - wave + WAVES - 1) / WAVES : 0;   // steps of this wave ...
     const int mine_full = steps_full > wave ? (steps_full - wave + WAVES - 1) / WAVES : 0;   // ... that lie entirely inside K
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float4 wq[D], aq[D];
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 wq[D], aq[D][MT];
     float gadd[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;                        // LSTM: wave 0, lane (u = lane/16, m = lane%16)
     const int eu = lane >> 4, em = lane & 15, ej = blockIdx.x * 4 + eu;
     const bool elive = LSTM && wave == 0 && em < M && ej < ep.R;
@@ -143,7 +150,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
         const int k = k_of(i);
         const int kc = (i < mine && k < K) ? k : 0;                           // clamped address, never a predicated load
         wq[slot] = ld4(wrow + kc);
-        aq[slot] = ld4(arow + kc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aq[slot][mt] = ld4(arow[mt] + kc);
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) issue(d, d);
@@ -151,11 +159,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
     for (; (r + 1) * D <= mine_full; ++r) {                                   // steady state: no selects, partial vmcnt waits only
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const float4 w = wq[d], a = aq[d];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc, 0, 0, 0);
+            const float4 w = wq[d];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float4 a = aq[d][mt];
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc[mt], 0, 0, 0);
+            }
             issue(d, (r + 1) * D + d);
         }
     }
@@ -164,26 +176,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
         for (int d = 0; d < D; ++d) {
             const int i = r * D + d;
             const bool in = i < mine && k_of(i) < K;
-            const float4 w = wq[d], a = aq[d];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, in ? a.x : 0.f, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, in ? a.y : 0.f, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, in ? a.z : 0.f, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, in ? a.w : 0.f, acc, 0, 0, 0);
+            const float4 w = wq[d];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float4 a = aq[d][mt];
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, in ? a.x : 0.f, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, in ? a.y : 0.f, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, in ? a.z : 0.f, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, in ? a.w : 0.f, acc[mt], 0, 0, 0);
+            }
             issue(d, (r + 1) * D + d);
         }
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) part[wave][v * 64 + lane] = acc[v];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[wave][mt * 256 + v * 64 + lane] = acc[mt][v];
     __syncthreads();
-    if (t < 256) {                                                            // element (row 4*(l/16)+v of the 16 W rows, m = l%16)
-        const int v = t >> 6, l = t & 63;
+    for (int e = t; e < MT * 256; e += WAVES * 64) {                          // element (row 4*(l/16)+v of the 16 W rows, m = 16*mt + l%16)
+        const int mt = e >> 8, v = (e >> 6) & 3, l = e & 63;
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) sum += part[w][v * 64 + l];
-        const int n = n0 + 4 * (l >> 4) + v, m = l & 15;
+        for (int w = 0; w < WAVES; ++w) sum += part[w][e];
+        const int n = n0 + 4 * (l >> 4) + v, m = mt * 16 + (l & 15);
         if (LSTM) tile[(4 * (l >> 4) + v) * 16 + m] = sum;                    // row 4*g + u of this workgroup, column m
         else if (m < M && n < N) {
             float o = sum + (bias ? bias[n] : 0.f);
+            if (add) o += add[(int64_t)m * ldadd + n];
             if (relu) o = fmaxf(o, 0.f);
             C[(int64_t)m * ldc + n] = o;
         }
@@ -237,18 +256,32 @@ int pick_rb(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, 
 namespace subgc {
 
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N, int K,
-                   int relu, hipStream_t s) {
-    if (M < 1 || M > 16) return -100;
+                   int relu, hipStream_t s, const float* add, int64_t ldadd) {
+    if (M < 1 || M > 80) return -100;
     static const int form = [] { const char* e = getenv("SUBGC_SKINNY"); return e ? atoi(e) : 1; }();   // 0: the VALU form (A/B timing)
+    if (form == 1 && M > 16) {                                                 // 2..5 activation tiles, shallower ring
+        const int wgs = (N + 15) / 16, mt = (M + 15) / 16;
+#define SUBGC_SKINNY_MT(MT_, D_)                                                                                                            \
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, D_, false, MT_>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, \
+                       LstmEpi{}, add, ldadd)
+        if (mt == 2) SUBGC_SKINNY_MT(2, 8);
+        else if (mt == 3) SUBGC_SKINNY_MT(3, 4);
+        else if (mt == 4) SUBGC_SKINNY_MT(4, 4);
+        else SUBGC_SKINNY_MT(5, 4);
+#undef SUBGC_SKINNY_MT
+        return subgc::check_launch("subgc_gemm_f32(skinny)");
+    }
+    if (M > 16) return -100;
     if (form == 1) {
         const int wgs = (N + 15) / 16;
         const int per_wave = ((K + 15) / 16 + 7) / 8;                          // ring depth: the deeper one unless it leaves more idle slots
         if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
-            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, false>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{});
+            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, false, 1>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{}, add, ldadd);
         else
-            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, false>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{});
+            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, false, 1>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{}, add, ldadd);
         return subgc::check_launch("subgc_gemm_f32(skinny)");
     }
+    if (add) return -100;                             // the VALU form has no residual term
     const int k4 = (K + 3) / 4;                       // float4 per row; a wave covers 64 of them per KPT4 step
     if (k4 <= 64 * 4) return pick_rb<4>(A, lda, W, ldb, C, ldc, bias, M, N, K, relu, s);
     if (k4 <= 64 * 8) return pick_rb<8>(A, lda, W, ldb, C, ldc, bias, M, N, K, relu, s);
@@ -276,8 +309,8 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w
     const int N = 4 * R, wgs = N / 16;
     const int per_wave = ((K + 15) / 16 + 7) / 8;
     if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, true>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep);
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
     else
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, true>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep);
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
     return subgc::check_launch("subgc_lstm_step_skinny");
 }

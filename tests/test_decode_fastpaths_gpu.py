@@ -131,3 +131,18 @@ def test_decode_with_fused_and_unfused_lstm_steps(golden, name, monkeypatch):
     np.testing.assert_array_equal(fused[0].cpu().numpy(), g.group("out")["seq"])
     if opt.get("return_att"):
         torch.testing.assert_close(fused[4], plain[4], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(17, 1024, 2048), (37, 512, 1024), (65, 1024, 512), (80, 9488, 1000), (33, 72, 300), (10, 4000, 3000)])
+def test_weight_streaming_gemm_up_to_80_rows(M, N, K):
+    """The matrix-pipe weight-streaming form (one-image encoder GEMMs, 37 node / 65 relation rows): bias, residual, ReLU."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, W = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    bias, add = torch.randn(N, generator=g).to(DEV), torch.randn(M, N + 8, generator=g).to(DEV)[:, :N]
+    ref = x.double() @ W.double().t()
+    out = torch.full((M + 1, N), 5.0, device=DEV)
+    ops.gemm(x, W, out[:M], tb=True)
+    torch.testing.assert_close(out[:M].double(), ref, atol=2e-5, rtol=1e-5)
+    assert float(out[M].min()) == 5.0                                                # rows past M untouched
+    ops.gemm(x, W, out[:M], tb=True, bias=bias, add=add, relu=True)
+    torch.testing.assert_close(out[:M].double(), (ref + bias.double() + add.double()).clamp_min(0), atol=2e-5, rtol=1e-5)
