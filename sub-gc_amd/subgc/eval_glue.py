@@ -58,7 +58,7 @@ def rank_subgraphs(model, seqq, subgraph_score, keep_nms_ind, sct_mode=False):
 
 
 @torch.no_grad()
-def caption_images(model, images, infos, ix_to_word, eval_kwargs=None, group=64):
+def caption_images(model, images, infos, ix_to_word, eval_kwargs=None, group=256):
     """The testing branch of eval_split for a list of loader items: returns the `predictions` list
     (eval_utils.py:132-141): {'image_id', 'caption': [...], 'subgraph_score', 'sorted_subgraph_ind'} per image."""
     eval_kwargs = dict(eval_kwargs or {})
