@@ -321,6 +321,23 @@ int subgc_decode_pick(const float* logp, int64_t ld, int n, int V, int k, float 
 int subgc_row_topk_f32(const float* x, int64_t ld, int rows, int cols, int k, int log_softmax, float* vals,
                        int32_t* idx, void* stream);
 
+/* One step of (diverse) beam search for n sub-graphs at once (CaptionModel.py:28-94 beam_step + add_diversity, :126-166 the
+ * per-group loop body), one workgroup per sub-graph, the groups of a sub-graph in order.  Rows are laid out
+ * [n][G][bd] (bd = beam_size / group_size beams per group).  tv/ti [n][G][bd][kk]: the kk leading log-probs of every beam
+ * row in (value desc, index asc) order and their word ids (subgc_row_topk_f32; kk = beam+2 suffices, see subgc/beam.py).
+ * For every group that is live at global step t (g <= t <= T+g-1, local step tau = t-g) the kernel applies the
+ * decoding constraint (:134-135), the UNK penalty -1000 (:137) and the diversity penalty lam per earlier-group pick
+ * (:33-40), orders each row (stable, descending), forms the candidate list in (column, beam) order with fp32 sums
+ * (:62-72), keeps the leading bd of its stable sort, forks the token / log-prob history seq, lps [n][G][T][bd] and the
+ * running sums [n][G][bd] (:76-90), appends finished beams (word 0, or the last step) to done_* in finishing order
+ * (done_cnt [n][G]; done_seq/done_lps [n][G][cap][T]; done_p = the sum BEFORE the length penalty; done_len = tau+1) and
+ * sets their sum to -1000 (:150-166).  Outputs for the next decoder step: tok [n][G][bd] (0 for sleeping groups) and
+ * src [n][G][bd], the state row every slot continues from.  T <= 64, bd <= 16, kk <= 18.                          */
+int subgc_beam_step(const float* tv, const int32_t* ti, int32_t* seq, float* lps, float* sums, int32_t* done_cnt,
+                    int32_t* done_seq, float* done_lps, float* done_p, int32_t* done_len, int64_t* tok,
+                    int32_t* src, int n, int t, int T, int G, int bd, int kk, int unk, int constraint, float lam,
+                    int cap, void* stream);
+
 /* Eval loop (misc/eval_utils.py:106-108): order[r] = index of the r-th largest score (ties keep input order),
  * sorted[r] = that score (may be NULL).  n <= 8192 (an image has at most 2M candidate sub-graphs).     */
 int subgc_rank_desc_f32(const float* score, int n, int64_t* order, float* sorted, void* stream);

@@ -121,3 +121,134 @@ SUBGC_API int subgc_rank_desc_f32(const float* score, int n, int64_t* order, flo
     hipLaunchKernelGGL(rank_desc_kernel, dim3(1), dim3(256), (size_t)n * sizeof(float), (hipStream_t)stream, score, n, order, sorted);
     return subgc::check_launch("subgc_rank_desc_f32");
 }
+
+// ------------------------------------------------------------------ beam step (CaptionModel.py:28-94,126-166) on the device
+// One workgroup (one wave) per sub-graph walks its beam groups in order, exactly as the host bookkeeping in subgc/beam.py
+// (`_beam_step`, itself the restatement of the reference's beam_step) does: same fp32 sums, same stable orders.  With this
+// the search loop has no host round trip: top-k -> beam step -> state gather -> decode step, all queued on the stream.
+namespace {
+constexpr int BS_MAXB = 16, BS_MAXK = 18, BS_MAXT = 64;
+
+struct BeamStepArgs {
+    const float* tv; const int32_t* ti;                  // [n][G][bd][kk] leading log-probs / word ids of every beam row (desc)
+    int32_t* seq; float* lps; float* sums;               // [n][G][T][bd], [n][G][T][bd], [n][G][bd]
+    int32_t* done_cnt; int32_t* done_seq; float* done_lps; float* done_p; int32_t* done_len;   // finished beams, in finishing order
+    int64_t* tok; int32_t* src;                          // [n][G][bd]: next input word, source row of every slot
+    int t, T, G, bd, kk, unk, constraint, cap;
+    float lam;
+};
+
+__global__ __launch_bounds__(64) void beam_step_kernel(BeamStepArgs a) {
+    __shared__ float v[BS_MAXB * BS_MAXK], un[BS_MAXB * BS_MAXK];
+    __shared__ int32_t id[BS_MAXB * BS_MAXK], ord[BS_MAXB * BS_MAXK];
+    __shared__ float cp[BS_MAXB * BS_MAXB], cr[BS_MAXB * BS_MAXB];
+    __shared__ int32_t cq[BS_MAXB * BS_MAXB], ctok[BS_MAXB * BS_MAXB];
+    __shared__ int32_t sel_q[BS_MAXB], sel_tok[BS_MAXB];
+    __shared__ float sel_p[BS_MAXB], sel_r[BS_MAXB];
+    __shared__ int32_t tmp_seq[BS_MAXT * BS_MAXB];
+    __shared__ float tmp_lps[BS_MAXT * BS_MAXB];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int G = a.G, bd = a.bd, kk = a.kk, T = a.T;
+    for (int g = 0; g < G; ++g) {
+        const int64_t sg = (int64_t)s * G + g;
+        const int tau = a.t - g;
+        const bool live = g <= a.t && a.t <= T + g - 1;
+        if (!live) {                                                          // rows of a sleeping group: fed <bos>/0, left in place
+            if (lane < bd) { a.tok[sg * bd + lane] = 0; a.src[sg * bd + lane] = (int32_t)(sg * bd + lane); }
+            continue;
+        }
+        int32_t* seq = a.seq + sg * T * bd;
+        float* lps = a.lps + sg * T * bd;
+        float* sums = a.sums + sg * bd;
+        for (int e = lane; e < bd * kk; e += 64) {                            // augment (:134-137, add_diversity :33-40)
+            const int q = e / kk;
+            float val = a.tv[sg * bd * kk + e];
+            const int32_t w = a.ti[sg * bd * kk + e];
+            if (a.constraint && tau > 0 && w == seq[(tau - 1) * bd + q]) val = -INFINITY;
+            if (w == a.unk) val -= 1000.f;
+            const float u0 = val;
+            for (int g2 = 0; g2 < g; ++g2) {
+                const int32_t* pseq = a.seq + ((int64_t)s * G + g2) * T * bd + tau * bd;
+                for (int b = 0; b < bd; ++b)
+                    if (w == pseq[b]) val -= a.lam;
+            }
+            v[e] = val; un[e] = u0; id[e] = w;
+        }
+        for (int e = lane; e < tau * bd; e += 64) { tmp_seq[e] = seq[e]; tmp_lps[e] = lps[e]; }
+        __syncthreads();
+        if (lane < bd) {                                                      // stable descending order of the row (np.argsort(-vals, stable))
+            const int q = lane;
+            for (int j = 0; j < kk; ++j) ord[q * kk + j] = j;
+            for (int j = 1; j < kk; ++j) {
+                const int cur = ord[q * kk + j];
+                const float key = v[q * kk + cur];
+                int i = j - 1;
+                while (i >= 0 && v[q * kk + ord[q * kk + i]] < key) { ord[q * kk + i + 1] = ord[q * kk + i]; --i; }
+                ord[q * kk + i + 1] = cur;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const int rows = tau == 0 ? 1 : bd, cols = bd < kk ? bd : kk;
+            int nc = 0;
+            for (int c = 0; c < cols; ++c)
+                for (int q = 0; q < rows; ++q) {                              // candidate list in the reference's (column, beam) order
+                    const int j = ord[q * kk + c];
+                    cp[nc] = sums[q] + v[q * kk + j]; cq[nc] = q; ctok[nc] = id[q * kk + j]; cr[nc] = un[q * kk + j];
+                    ++nc;
+                }
+            for (int vix = 0; vix < bd; ++vix) {                              // leading bd of the stable sort by -p
+                int best = -1;
+                for (int c = 0; c < nc; ++c)
+                    if (cq[c] >= 0 && (best < 0 || cp[c] > cp[best])) best = c;
+                if (best < 0) best = 0;                                        // fewer candidates than slots cannot happen (cols*rows >= bd only when tau > 0 or bd == 1) -- keep memory safe
+                sel_q[vix] = cq[best] < 0 ? 0 : cq[best]; sel_tok[vix] = ctok[best]; sel_p[vix] = cp[best]; sel_r[vix] = cr[best];
+                cq[best] = -1 - cq[best];                                      // taken (q recoverable, never needed again)
+            }
+        }
+        __syncthreads();
+        for (int e = lane; e < tau * bd; e += 64) {                           // fork the history: column vix <- old column sel_q[vix]
+            const int r = e / bd, vix = e % bd;
+            seq[e] = tmp_seq[r * bd + sel_q[vix]];
+            lps[e] = tmp_lps[r * bd + sel_q[vix]];
+        }
+        if (lane < bd) {
+            seq[tau * bd + lane] = sel_tok[lane];
+            lps[tau * bd + lane] = sel_r[lane];
+            sums[lane] = sel_p[lane];
+            a.src[sg * bd + lane] = (int32_t)(sg * bd + sel_q[lane]);
+            a.tok[sg * bd + lane] = sel_tok[lane];
+        }
+        __syncthreads();
+        if (lane == 0) {                                                      // :150-166 finished beams, in slot order
+            for (int vix = 0; vix < bd; ++vix)
+                if (sel_tok[vix] == 0 || a.t == T + g - 1) {
+                    const int slot = a.done_cnt[sg];
+                    if (slot < a.cap) {
+                        for (int r = 0; r < T; ++r) {
+                            a.done_seq[(sg * a.cap + slot) * T + r] = r <= tau ? seq[r * bd + vix] : 0;
+                            a.done_lps[(sg * a.cap + slot) * T + r] = r <= tau ? lps[r * bd + vix] : 0.f;
+                        }
+                        a.done_p[sg * a.cap + slot] = sums[vix];
+                        a.done_len[sg * a.cap + slot] = tau + 1;
+                        a.done_cnt[sg] = slot + 1;
+                    }
+                    sums[vix] = -1000.f;
+                }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+SUBGC_API int subgc_beam_step(const float* tv, const int32_t* ti, int32_t* seq, float* lps, float* sums, int32_t* done_cnt,
+                              int32_t* done_seq, float* done_lps, float* done_p, int32_t* done_len, int64_t* tok, int32_t* src, int n,
+                              int t, int T, int G, int bd, int kk, int unk, int constraint, float lam, int cap, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && T > 0 && T <= BS_MAXT && G > 0 && bd > 0 && bd <= BS_MAXB && kk >= 1 && kk <= BS_MAXK && cap > 0 && t >= 0,
+                  "beam_step: need T <= 64, beams per group <= 16, kk <= 18");
+    if (n == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(tv && ti && seq && lps && sums && done_cnt && done_seq && done_lps && done_p && done_len && tok && src, "beam_step: null pointer");
+    BeamStepArgs a{tv, ti, seq, lps, sums, done_cnt, done_seq, done_lps, done_p, done_len, tok, src, t, T, G, bd, kk, unk, constraint, cap, lam};
+    hipLaunchKernelGGL(beam_step_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, a);
+    return subgc::check_launch("subgc_beam_step");
+}

@@ -157,10 +157,93 @@ class _StepEngine:
 
 
 @torch.no_grad()
-def beam_decode(pr, P, N, T, opt, xt_table=None):
+def beam_decode(pr, P, N, T, opt, xt_table=None, on_device=True):
     """Decode every sub-graph of `pr` (an F_.Prepared) with beam search.
-    Returns (seq [n, T] int64, seqLogprobs [n, T] fp32, done_beams) -- CPU tensors, as the reference's are."""
-    return search(_BatchEngine(pr, P, N, int(opt.get("beam_size", 10)), xt_table), T, opt)
+    Returns (seq [n, T] int64, seqLogprobs [n, T] fp32, done_beams) -- CPU tensors, as the reference's are.
+    `on_device` (default): the candidate bookkeeping runs in `subgc_beam_step`, the loop has no host round trip;
+    False keeps it on the host (`search`, the restatement the device kernel is tested against)."""
+    eng = _BatchEngine(pr, P, N, int(opt.get("beam_size", 10)), xt_table)
+    return search_device(eng, T, opt) if on_device else search(eng, T, opt)
+
+
+class DeviceTables:
+    """The tables of CaptionModel.py:106-109 for n sub-graphs x G groups, resident on the device."""
+
+    def __init__(self, n, G, T, bd, dev):
+        z = lambda *s, dt: torch.zeros(*s, device=dev, dtype=dt)
+        self.cap = bd * T                                                         # a group finishes at most bd beams per step
+        self.seq, self.lps, self.sums = z(n, G, T, bd, dt=torch.int32), z(n, G, T, bd, dt=torch.float32), z(n, G, bd, dt=torch.float32)
+        self.done_cnt = z(n, G, dt=torch.int32)
+        self.done_seq, self.done_lps = z(n, G, self.cap, T, dt=torch.int32), z(n, G, self.cap, T, dt=torch.float32)
+        self.done_p, self.done_len = z(n, G, self.cap, dt=torch.float32), z(n, G, self.cap, dt=torch.int32)
+
+
+def _check(opt, eng):
+    beam = int(opt.get("beam_size", 10))
+    G = int(opt.get("group_size", 1))
+    if G < 1 or beam % G:
+        raise ValueError(f"beam_size {beam} must be a multiple of group_size {G}")
+    bd = beam // G
+    if eng.rows != eng.n * beam:
+        raise ValueError(f"{eng.rows} state rows for {eng.n} sub-graph(s) x beam {beam}")
+    kk = min(eng.V1, beam + 2)
+    if bd > kk:
+        raise ValueError("beam wider than the vocabulary")
+    return beam, G, bd, kk
+
+
+@torch.no_grad()
+def search_device(eng, T, opt):
+    """`search` with the per-step bookkeeping in `subgc_beam_step`: every step is top-k -> beam step -> state gather ->
+    decoder step on the stream; the host reads the finished beams once, after the last step."""
+    beam, G, bd, kk = _check(opt, eng)
+    lam = float(_F32(opt.get("diversity_lambda", 0.5)))
+    constraint = opt.get("decoding_constraint", 0)
+    length_penalty = penalty_builder(opt.get("length_penalty", ""))
+    n, rows, dev = eng.n, eng.rows, eng.dev
+    unk = eng.V1 - 1
+    tb = DeviceTables(n, G, T, bd, dev)
+    tok = torch.zeros(rows, device=dev, dtype=torch.long)
+    src = torch.zeros(rows, device=dev, dtype=torch.int32)
+    tv = torch.empty(rows, kk, device=dev, dtype=torch.float32)
+    ti = torch.empty(rows, kk, device=dev, dtype=torch.int32)
+    ops.row_topk(eng.st.step(tok, None, normalize=False), kk, tv, ti, log_softmax=True)          # <bos>, AttModel.py:223-227
+    if G > 1:
+        init = eng.snapshot()
+        nv, ni = torch.empty_like(tv), torch.empty_like(ti)
+        base = np.arange(rows, dtype=np.int32).reshape(n, G, bd)
+        tv4, ti4, nv4, ni4 = (x.view(n, G, bd, kk) for x in (tv, ti, nv, ni))
+    for t in range(T + G - 1):
+        ops.beam_step(tv, ti, tb, tok, src, t, T, G, bd, kk, unk, constraint, lam)
+        if not any(g <= t + 1 <= T + g - 1 for g in range(G)):
+            break
+        if G > 1 and 0 < t < G:
+            eng.restore(base[:, t].reshape(-1), init)
+        eng.st.reorder(src)
+        logits = eng.st.step(tok, None, normalize=False)
+        if G == 1:
+            ops.row_topk(logits, kk, tv, ti, log_softmax=True)
+        else:
+            ops.row_topk(logits, kk, nv, ni, log_softmax=True)
+            for g in range(G):
+                if g <= t <= T + g - 1:                                           # only the groups that stepped take the new rows
+                    tv4[:, g], ti4[:, g] = nv4[:, g], ni4[:, g]
+    cnt = tb.done_cnt.cpu().numpy()
+    dseq, dlps = tb.done_seq.cpu().numpy().astype(np.int64), tb.done_lps.cpu().numpy()
+    dp, dlen = tb.done_p.cpu().numpy(), tb.done_len.cpu().numpy()
+    seq = torch.zeros(n, T, dtype=torch.long)
+    seqlp = torch.zeros(n, T, dtype=torch.float32)
+    done_beams = []
+    for s in range(n):
+        beams = []
+        for g in range(G):
+            done = [{"seq": torch.from_numpy(dseq[s, g, j].copy()), "logps": torch.from_numpy(dlps[s, g, j].copy()),
+                     "unaug_p": float(dlps[s, g, j].sum(dtype=_F32)), "p": length_penalty(int(dlen[s, g, j]), float(dp[s, g, j]))}
+                    for j in range(int(cnt[s, g]))]
+            beams += sorted(done, key=lambda x: -x["p"])[:bd]                     # :174-175
+        done_beams.append(beams)
+        seq[s], seqlp[s] = beams[0]["seq"], beams[0]["logps"]
+    return seq, seqlp, done_beams
 
 
 @torch.no_grad()

@@ -382,6 +382,15 @@ def row_topk(x, k, vals, idx, log_softmax=True):
     return vals, idx
 
 
+def beam_step(tv, ti, st, tok, src, t, T, G, bd, kk, unk, constraint, lam):
+    """One (diverse) beam-search step of every sub-graph on the device (subgc_beam_step).  `st`: the tables of beam.DeviceTables."""
+    n = st.sums.size(0)
+    call("subgc_beam_step", _ptr(tv, torch.float32), _ptr(ti, torch.int32), _ptr(st.seq, torch.int32), _ptr(st.lps, torch.float32),
+         _ptr(st.sums, torch.float32), _ptr(st.done_cnt, torch.int32), _ptr(st.done_seq, torch.int32), _ptr(st.done_lps, torch.float32),
+         _ptr(st.done_p, torch.float32), _ptr(st.done_len, torch.int32), _ptr(tok, torch.int64), _ptr(src, torch.int32), n, int(t), int(T),
+         int(G), int(bd), int(kk), int(unk), int(bool(constraint)), float(lam), st.cap, _stream())
+
+
 def uniform(shape, seed, offset, device):
     out = torch.empty(shape, device=device, dtype=torch.float32)
     call("subgc_uniform_f32", _ptr(out), out.numel(), int(seed), int(offset), _stream())

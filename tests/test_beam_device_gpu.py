@@ -1,0 +1,63 @@
+"""Beam search with the per-step bookkeeping on the device (subgc_beam_step) against the host bookkeeping of
+subgc/beam.py::search (the restatement of CaptionModel.py:28-176 that tests/test_beam_oracle.py pins on the reference's
+goldens): same engine, same decoder steps, every table compared bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from subgc import beam, synthetic
+from subgc import functions as F_
+from subgc.models import sampling
+from test_parity_gpu import DEV, build
+
+pytestmark = pytest.mark.gpu
+
+OPTS = [dict(beam_size=2), dict(beam_size=3, length_penalty="wu_0.7"), dict(beam_size=5, decoding_constraint=1),
+        dict(beam_size=4, group_size=2, diversity_lambda=0.5, decoding_constraint=1, length_penalty="avg_1.0"),
+        dict(beam_size=6, group_size=3, diversity_lambda=0.3), dict(beam_size=10)]
+
+
+def prepared(m, ims):
+    att = torch.cat([im["att_feats"][:1] for im in ims])
+    I, N, _ = att.shape
+    X2 = m._encode(att, torch.cat([im["obj_dist"][:1] for im in ims]), torch.cat([im["pred_dist"][:1] for im in ims]),
+                   torch.cat([im["rel_ind"][:1] for im in ims])).reshape(I * N, m.GCN_dim).contiguous()
+    sel = sampling.select_subgraphs(m, X2, N, [(i, im["gpn_obj_ind"], im["att_masks"], im["gpn_pool_mtx"]) for i, im in enumerate(ims)])
+    cat = lambda k: torch.cat([s[k] for s in sel]).contiguous()
+    P = m._decoder_params()
+    return F_.Prepared(cat("fc"), X2, cat("lens"), cat("idx"), cat("img"), N, P, None, None, 1.0), P, N
+
+
+@pytest.mark.parametrize("opt", OPTS, ids=lambda o: "-".join(f"{k[:4]}{v}" for k, v in o.items()))
+def test_device_beam_step_equals_host_bookkeeping(golden, opt):
+    g = golden("subgc_beam3")
+    m = build(g, golden("subgc_beam").group("weights"), False)
+    ims = [{k: v.to(DEV) for k, v in g.tensors("inputs").items()}]
+    pr, P, N = prepared(m, ims)
+    T = m.seq_length
+    with torch.no_grad():
+        dev_out = beam.beam_decode(pr, P, N, T, dict(opt), xt_table=m.xt_gates_table(), on_device=True)
+        host_out = beam.beam_decode(pr, P, N, T, dict(opt), xt_table=m.xt_gates_table(), on_device=False)
+    assert torch.equal(dev_out[0], host_out[0]) and torch.equal(dev_out[1], host_out[1])
+    assert len(dev_out[2]) == len(host_out[2]) == pr.S
+    ended_early = 0
+    for db, hb in zip(dev_out[2], host_out[2]):
+        assert len(db) == len(hb) == opt["beam_size"]
+        for d, h in zip(db, hb):
+            assert torch.equal(d["seq"], h["seq"]) and torch.equal(d["logps"], h["logps"])
+            assert d["p"] == h["p"] and abs(d["unaug_p"] - h["unaug_p"]) <= 1e-5 * max(1.0, abs(h["unaug_p"]))
+            ended_early += int((d["seq"] == 0).any())
+    assert ended_early > 0                                                       # the weights of this fixture do reach <eos>
+
+
+def test_product_path_uses_the_device_step_and_has_no_host_round_trip_per_step(golden, monkeypatch):
+    g = golden("subgc_beam3")
+    m = build(g, golden("subgc_beam").group("weights"), False)
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    calls = []
+    orig = beam.search_device
+    monkeypatch.setattr(beam, "search_device", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.setattr(beam, "search", lambda *a, **k: (_ for _ in ()).throw(AssertionError("host bookkeeping on the product path")))
+    ret = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample")
+    assert calls == [1]
+    np.testing.assert_array_equal(ret[0].cpu().numpy(), g.group("out")["seq"])
