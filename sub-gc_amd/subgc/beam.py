@@ -93,8 +93,16 @@ class _BatchEngine:
         rep = torch.arange(n, device=dev).repeat_interleave(beam)
         prb = SimpleNamespace(S=self.rows, N=N, f=pr.f.index_select(0, rep).contiguous(), u=pr.u, v=pr.v,
                               off=pr.off.index_select(0, rep).contiguous(), lens=pr.lens.index_select(0, rep).contiguous())
+        self.pr, self.prb, self.rep = pr, prb, rep
         self.st = F_.DecodeState(prb, P, N, False, xt_table=xt_table)
         self.V1 = self.st.V1
+
+    def refresh(self):
+        """Re-derive the per-beam rows from `pr` and restart the recurrent state (hipGraph replay: `pr` was overwritten in place)."""
+        torch.index_select(self.pr.f, 0, self.rep, out=self.prb.f)
+        torch.index_select(self.pr.off, 0, self.rep, out=self.prb.off)
+        torch.index_select(self.pr.lens, 0, self.rep, out=self.prb.lens)
+        self.st.reset()
 
     def _topk(self, logits, kk):
         if not hasattr(self, "vals"):
@@ -192,58 +200,91 @@ def _check(opt, eng):
     return beam, G, bd, kk
 
 
+class DeviceSearch:
+    """`search` with the per-step bookkeeping in `subgc_beam_step`: every step is top-k -> beam step -> state gather ->
+    decoder step on the stream (`loop`: launches only, no host read, so it can be captured in a hipGraph); the host reads
+    the finished beams once, after the last step (`collect`)."""
+
+    def __init__(self, eng, T, opt):
+        self.eng, self.T, self.opt = eng, T, dict(opt)
+        self.beam, self.G, self.bd, self.kk = _check(opt, eng)
+        self.lam = float(_F32(opt.get("diversity_lambda", 0.5)))
+        self.constraint = opt.get("decoding_constraint", 0)
+        n, rows, dev, G, bd, kk = eng.n, eng.rows, eng.dev, self.G, self.bd, self.kk
+        self.tb = DeviceTables(n, G, T, bd, dev)
+        self.tok = torch.zeros(rows, device=dev, dtype=torch.long)
+        self.src = torch.zeros(rows, device=dev, dtype=torch.int32)
+        self.tv = torch.empty(rows, kk, device=dev, dtype=torch.float32)
+        self.ti = torch.empty(rows, kk, device=dev, dtype=torch.int32)
+        if G > 1:
+            self.nv, self.ni = torch.empty_like(self.tv), torch.empty_like(self.ti)
+            base = torch.arange(rows, device=dev).view(n, G, bd)
+            self.group_rows = [base[:, g].reshape(-1).contiguous() for g in range(G)]
+
+    def loop(self, fresh_tables=False):
+        eng, T, G, bd, kk, tb = self.eng, self.T, self.G, self.bd, self.kk, self.tb
+        n, unk = eng.n, eng.V1 - 1
+        tv, ti, tok, src = self.tv, self.ti, self.tok, self.src
+        if not fresh_tables:
+            for x in (tb.seq, tb.lps, tb.sums, tb.done_cnt, tok):
+                x.zero_()
+        ops.row_topk(eng.st.step(tok, None, normalize=False), kk, tv, ti, log_softmax=True)      # <bos>, AttModel.py:223-227
+        if G > 1:
+            init = eng.snapshot()
+            tv4, ti4, nv4, ni4 = (x.view(n, G, bd, kk) for x in (tv, ti, self.nv, self.ni))
+        for t in range(T + G - 1):
+            ops.beam_step(tv, ti, tb, tok, src, t, T, G, bd, kk, unk, self.constraint, self.lam)
+            if not any(g <= t + 1 <= T + g - 1 for g in range(G)):
+                break
+            if G > 1 and 0 < t < G:                                               # group t starts now: give it the post-<bos> state
+                sel = self.group_rows[t]
+                for cur, saved in zip(eng.st.recurrent(), init):
+                    cur.index_copy_(0, sel, saved.index_select(0, sel))
+            eng.st.reorder(src)
+            logits = eng.st.step(tok, None, normalize=False)
+            if G == 1:
+                ops.row_topk(logits, kk, tv, ti, log_softmax=True)
+            else:
+                ops.row_topk(logits, kk, self.nv, self.ni, log_softmax=True)
+                for g in range(G):
+                    if g <= t <= T + g - 1:                                       # only the groups that stepped take the new rows
+                        tv4[:, g], ti4[:, g] = nv4[:, g], ni4[:, g]
+
+    def collect(self):
+        tb, T, G, bd, n, opt = self.tb, self.T, self.G, self.bd, self.eng.n, self.opt
+        length_penalty = penalty_builder(opt.get("length_penalty", ""))
+        # one read of the finished beams; ranking (:174-175) vectorised, python objects only for the beams that are kept
+        cnt = tb.done_cnt.cpu().numpy()
+        dseq, dlps = tb.done_seq.cpu().numpy(), tb.done_lps.cpu().numpy()
+        dp, dlen = tb.done_p.cpu().numpy(), tb.done_len.cpu().numpy()
+        valid = np.arange(tb.cap)[None, None, :] < cnt[:, :, None]
+        if opt.get("length_penalty", "") == "":
+            p = dp.astype(np.float64)
+        else:                                                                         # the reference's python-float arithmetic, entry by entry
+            p = np.zeros(dp.shape, np.float64)
+            for s_, g_, j_ in zip(*np.nonzero(valid)):
+                p[s_, g_, j_] = length_penalty(int(dlen[s_, g_, j_]), float(dp[s_, g_, j_]))
+        if n and int(cnt.min()) < bd:
+            raise RuntimeError("beam search ended with fewer finished beams than slots")   # the last step finishes every slot (:151)
+        order = np.argsort(np.where(valid, -p, np.inf), axis=-1, kind="stable")[:, :, :bd]
+        oi = order[..., None]                                                         # numpy gathers: single-threaded, no thread-pool wake-ups
+        top_seq = torch.from_numpy(np.take_along_axis(dseq, oi, 2).astype(np.int64))  # [n, G, bd, T]
+        top_lps = torch.from_numpy(np.take_along_axis(dlps, oi, 2))
+        top_p = np.take_along_axis(p, order, -1).reshape(-1).tolist()
+        top_un = np.take_along_axis(dlps.sum(-1, dtype=_F32), order, -1).reshape(-1).tolist()
+        rs, rl = top_seq.reshape(-1, T).unbind(0), top_lps.reshape(-1, T).unbind(0)
+        per = G * bd
+        done_beams = [[{"seq": rs[k], "logps": rl[k], "unaug_p": top_un[k], "p": top_p[k]} for k in range(s * per, (s + 1) * per)]
+                      for s in range(n)]
+        seq, seqlp = top_seq[:, 0, 0].clone(), top_lps[:, 0, 0].clone()
+        return seq, seqlp, done_beams
+
+
 @torch.no_grad()
 def search_device(eng, T, opt):
-    """`search` with the per-step bookkeeping in `subgc_beam_step`: every step is top-k -> beam step -> state gather ->
-    decoder step on the stream; the host reads the finished beams once, after the last step."""
-    beam, G, bd, kk = _check(opt, eng)
-    lam = float(_F32(opt.get("diversity_lambda", 0.5)))
-    constraint = opt.get("decoding_constraint", 0)
-    length_penalty = penalty_builder(opt.get("length_penalty", ""))
-    n, rows, dev = eng.n, eng.rows, eng.dev
-    unk = eng.V1 - 1
-    tb = DeviceTables(n, G, T, bd, dev)
-    tok = torch.zeros(rows, device=dev, dtype=torch.long)
-    src = torch.zeros(rows, device=dev, dtype=torch.int32)
-    tv = torch.empty(rows, kk, device=dev, dtype=torch.float32)
-    ti = torch.empty(rows, kk, device=dev, dtype=torch.int32)
-    ops.row_topk(eng.st.step(tok, None, normalize=False), kk, tv, ti, log_softmax=True)          # <bos>, AttModel.py:223-227
-    if G > 1:
-        init = eng.snapshot()
-        nv, ni = torch.empty_like(tv), torch.empty_like(ti)
-        base = np.arange(rows, dtype=np.int32).reshape(n, G, bd)
-        tv4, ti4, nv4, ni4 = (x.view(n, G, bd, kk) for x in (tv, ti, nv, ni))
-    for t in range(T + G - 1):
-        ops.beam_step(tv, ti, tb, tok, src, t, T, G, bd, kk, unk, constraint, lam)
-        if not any(g <= t + 1 <= T + g - 1 for g in range(G)):
-            break
-        if G > 1 and 0 < t < G:
-            eng.restore(base[:, t].reshape(-1), init)
-        eng.st.reorder(src)
-        logits = eng.st.step(tok, None, normalize=False)
-        if G == 1:
-            ops.row_topk(logits, kk, tv, ti, log_softmax=True)
-        else:
-            ops.row_topk(logits, kk, nv, ni, log_softmax=True)
-            for g in range(G):
-                if g <= t <= T + g - 1:                                           # only the groups that stepped take the new rows
-                    tv4[:, g], ti4[:, g] = nv4[:, g], ni4[:, g]
-    cnt = tb.done_cnt.cpu().numpy()
-    dseq, dlps = tb.done_seq.cpu().numpy().astype(np.int64), tb.done_lps.cpu().numpy()
-    dp, dlen = tb.done_p.cpu().numpy(), tb.done_len.cpu().numpy()
-    seq = torch.zeros(n, T, dtype=torch.long)
-    seqlp = torch.zeros(n, T, dtype=torch.float32)
-    done_beams = []
-    for s in range(n):
-        beams = []
-        for g in range(G):
-            done = [{"seq": torch.from_numpy(dseq[s, g, j].copy()), "logps": torch.from_numpy(dlps[s, g, j].copy()),
-                     "unaug_p": float(dlps[s, g, j].sum(dtype=_F32)), "p": length_penalty(int(dlen[s, g, j]), float(dp[s, g, j]))}
-                    for j in range(int(cnt[s, g]))]
-            beams += sorted(done, key=lambda x: -x["p"])[:bd]                     # :174-175
-        done_beams.append(beams)
-        seq[s], seqlp[s] = beams[0]["seq"], beams[0]["logps"]
-    return seq, seqlp, done_beams
+    ds = DeviceSearch(eng, T, opt)
+    ds.loop(fresh_tables=True)
+    return ds.collect()
 
 
 @torch.no_grad()

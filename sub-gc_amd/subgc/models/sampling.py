@@ -161,6 +161,51 @@ class _GraphedLoop:
         return self.seq.clone(), self.seqlp.clone(), self.counts, (self.AL.clone() if self.AL is not None else None)
 
 
+class _GraphedBeam:
+    """Beam search of ONE image (test.sh decodes Sub_GC_Kar with beam 2, Full-GC with beam 3) as a replayable hipGraph: with
+    the candidate bookkeeping on the device (`subgc_beam_step`) the whole search is a static launch sequence, ~16 launches per
+    step on <= 10 x beam rows, i.e. launch-bound when issued eagerly."""
+
+    def __init__(self, m, n, N, P, opt):
+        dev = m.flat_params.device
+        T, R, A = m.seq_length, m.rnn_size, m.att_hid_size
+        cap = n * N
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
+        self.eng = beam._BatchEngine(self.pr, P, N, int(opt.get("beam_size", 10)), m.xt_gates_table())
+        self.ds = beam.DeviceSearch(self.eng, T, opt)
+        self._loop()                                                             # eager warm-up
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._loop()
+
+    def _loop(self):
+        self.eng.refresh()
+        self.ds.loop()
+
+    def run(self, pr):
+        rows = pr.u.size(0)
+        self.pr.f.copy_(pr.f)
+        self.pr.u[:rows].copy_(pr.u); self.pr.v[:rows].copy_(pr.v)
+        self.pr.off.copy_(pr.off); self.pr.lens.copy_(pr.lens)
+        self.graph.replay()
+        return self.ds.collect()
+
+
+def _graphed_beam(m, n, N, P, opt):
+    okey = tuple(sorted((k, v) for k, v in opt.items() if k in ("beam_size", "group_size", "diversity_lambda", "decoding_constraint", "length_penalty")))
+    key = ("beam", n, N, okey) + m.weights_version()
+    cache = m.__dict__.setdefault("_graph_cache", {})
+    if key not in cache:
+        for old in [q for q in cache if q[:4] == key[:4]]:
+            del cache[old]
+        if len(cache) >= 24:
+            cache.clear()
+        cache[key] = _GraphedBeam(m, n, N, P, opt)
+    return cache[key]
+
+
 def _graphed_loop(m, n, N, k, return_att, P):
     key = (n, N, k, return_att) + m.weights_version()
     cache = m.__dict__.setdefault("_graph_cache", {})
@@ -194,7 +239,18 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     for s in sizes:
         bounds.append(bounds[-1] + s)
     if beam_size > 1:                                                                  # AttModel.py:245-246 -> :179-234
-        seq, seqlp, done = beam.beam_decode(pr, P, N, T, opt, xt_table=m.xt_gates_table())
+        graphed = None
+        if len(sel) == 1 and n * beam_size <= 128 and getattr(m, "decode_hipgraph", True):
+            try:
+                graphed = _graphed_beam(m, n, N, P, opt)
+            except RuntimeError as e:                                            # capture unavailable here: same kernels, launched eagerly
+                import warnings
+                warnings.warn(f"hipGraph capture of the beam search failed ({e}); searching eagerly from now on")
+                m.decode_hipgraph = False
+        if graphed is not None:
+            seq, seqlp, done = graphed.run(pr)
+        else:
+            seq, seqlp, done = beam.beam_decode(pr, P, N, T, opt, xt_table=m.xt_gates_table())
         m.done_beams = done if len(sel) == 1 else [done[a:b] for a, b in zip(bounds, bounds[1:])]
         return [(seq[a:b], seqlp[a:b], s["score"], s["keep"]) for s, a, b in zip(sel, bounds, bounds[1:])]
     k = m.the_k if m.topk_sampling else 0

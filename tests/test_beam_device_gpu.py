@@ -50,14 +50,22 @@ def test_device_beam_step_equals_host_bookkeeping(golden, opt):
     assert ended_early > 0                                                       # the weights of this fixture do reach <eos>
 
 
-def test_product_path_uses_the_device_step_and_has_no_host_round_trip_per_step(golden, monkeypatch):
+def test_product_path_never_uses_the_host_bookkeeping(golden, monkeypatch):
+    """One image: the search is captured once (hipGraph) and replayed; several images: launched eagerly.  Either way on the device."""
     g = golden("subgc_beam3")
     m = build(g, golden("subgc_beam").group("weights"), False)
     b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
-    calls = []
-    orig = beam.search_device
-    monkeypatch.setattr(beam, "search_device", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     monkeypatch.setattr(beam, "search", lambda *a, **k: (_ for _ in ()).throw(AssertionError("host bookkeeping on the product path")))
+    from test_beam_oracle import check_beams
+    for _ in range(3):                                                            # capture, then two replays
+        ret = m(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=g.meta["sample_opt"], mode="sample")
+        check_beams(ret, m.done_beams, g.group("out"), atol=1e-4)
+    assert any(k[0] == "beam" for k in m._graph_cache)
+    rs = m.sample_images([b, b], opt=g.meta["sample_opt"])
+    for r, per in zip(rs, m.done_beams):
+        check_beams(r, per, g.group("out"), atol=1e-4)
+    m.decode_hipgraph = False                                                     # eager one-image search: same result
+    m.__dict__.pop("_graph_cache")
     ret = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample")
-    assert calls == [1]
-    np.testing.assert_array_equal(ret[0].cpu().numpy(), g.group("out")["seq"])
+    check_beams(ret, m.done_beams, g.group("out"), atol=1e-4)
+    assert not m.__dict__.get("_graph_cache")
