@@ -121,6 +121,25 @@ def decode_bench(model_sd, dev, images, M):
                 tokens += r[0].size(0) * r[0].size(1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # test.sh decodes Sub_GC_Kar with --beam_size 2: the same images through beam search, one per call and batched
+    bopt = dict(sample_max=1, beam_size=2)
+    nb = min(images, 64)
+    for b in batches[:2]:
+        m(*synthetic.sample_args(b), opt=bopt, mode="sample")
+    torch.cuda.synchronize()
+    tb0 = time.perf_counter()
+    for b in batches[:nb]:
+        m(*synthetic.sample_args(b), opt=bopt, mode="sample")
+    torch.cuda.synchronize()
+    tb1 = time.perf_counter()
+    m.sample_images(batches[:nb], opt=bopt)
+    torch.cuda.synchronize()
+    tb2 = time.perf_counter()
+    m.sample_images(batches[:nb], opt=bopt)
+    torch.cuda.synchronize()
+    tb3 = time.perf_counter()
+    out.update({"decode_beam2_ms_per_image": round(1e3 * (tb1 - tb0) / nb, 3), "decode_beam2_batched_ms_per_image": round(1e3 * (tb3 - tb2) / nb, 3),
+                "decode_beam2_config": f"beam_size 2 (test.sh Sub_GC_Kar), candidate bookkeeping on the device; batched = {nb} images per search"})
     out.update({"decode_batched_tokens_per_s": round(tokens / dt, 1), "decode_batched_ms_per_image": round(1e3 * dt / (2 * images), 3),
                 "decode_batched_config": f"sample_images: {group} images per decode batch (<= {10 * group} sub-graph rows per step)"})
     return out
