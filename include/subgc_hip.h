@@ -217,7 +217,7 @@ int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, 
                     float keep_scale, const float* dout, float* dtable, int n, int E, int vocab_rows,
                     void* stream);
 
-/* One LSTMCell step (AttModel.py:411, :423 -> nn.LSTMCell) for a decode batch of S <= 16 rows in ONE launch: the gate
+/* One LSTMCell step (AttModel.py:411, :423 -> nn.LSTMCell) for a decode batch of S <= 32 rows in ONE launch: the gate
  * GEMM x[S,K] . w_perm[4R,K]^T streams the weights through the matrix pipe and the cell update runs in its epilogue.
  * w_perm is the K-concatenated gate matrix [W_ih | W_hh] with PERMUTED rows: row 16*b + 4*g + u holds gate g (i,f,g,o)
  * of hidden unit 4*b + u, so a workgroup's 16 rows are everything four units need.  pre = x.w^T + b0 + b1

@@ -110,9 +110,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
                                                                       int64_t ldb, float* __restrict__ C, int64_t ldc,
                                                                       const float* __restrict__ bias, int M, int N, int K, int relu,
                                                                       LstmEpi ep, const float* __restrict__ add, int64_t ldadd) {
-    static_assert(!LSTM || MT == 1, "the fused cell update handles one 16-row activation tile");
+    static_assert(!LSTM || MT <= 2, "the fused cell update handles up to two 16-row activation tiles (wave mt owns tile mt)");
     __shared__ float part[WAVES][MT * 256];
-    __shared__ float tile[LSTM ? 256 : 1];
+    __shared__ float tile[LSTM ? 256 * MT : 1];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: uniform loop control
     const int r16 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -127,9 +127,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 wq[D], aq[D][MT];
-    float gadd[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;                        // LSTM: wave 0, lane (u = lane/16, m = lane%16)
-    const int eu = lane >> 4, em = lane & 15, ej = blockIdx.x * 4 + eu;
-    const bool elive = LSTM && wave == 0 && em < M && ej < ep.R;
+    float gadd[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;                        // LSTM: wave mt < MT, lane (u = lane/16, m = 16*mt + lane%16)
+    const int eu = lane >> 4, em = wave * 16 + (lane & 15), ej = blockIdx.x * 4 + eu;
+    const bool elive = LSTM && wave < MT && em < M && ej < ep.R;
     if (elive) {
         int64_t row1 = em;
         if (ep.tok) { const int64_t w = ep.tok[em]; row1 = w < 0 ? 0 : (w >= ep.tok_rows ? ep.tok_rows - 1 : w); }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sum += part[w][e];
         const int n = n0 + 4 * (l >> 4) + v, m = mt * 16 + (l & 15);
-        if (LSTM) tile[(4 * (l >> 4) + v) * 16 + m] = sum;                    // row 4*g + u of this workgroup, column m
+        if (LSTM) tile[(4 * (l >> 4) + v) * (16 * MT) + m] = sum;             // row 4*g + u of this workgroup, column m
         else if (m < M && n < N) {
             float o = sum + (bias ? bias[n] : 0.f);
             if (add) o += add[(int64_t)m * ldadd + n];
@@ -210,8 +210,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
     if (LSTM) {
         __syncthreads();
         if (elive) {
-            const float ig = sigmoidf_(tile[(0 + eu) * 16 + em] + gadd[0]), fg = sigmoidf_(tile[(4 + eu) * 16 + em] + gadd[1]);
-            const float gg = tanhf(tile[(8 + eu) * 16 + em] + gadd[2]), og = sigmoidf_(tile[(12 + eu) * 16 + em] + gadd[3]);
+            constexpr int TW = 16 * MT;
+            const float ig = sigmoidf_(tile[(0 + eu) * TW + em] + gadd[0]), fg = sigmoidf_(tile[(4 + eu) * TW + em] + gadd[1]);
+            const float gg = tanhf(tile[(8 + eu) * TW + em] + gadd[2]), og = sigmoidf_(tile[(12 + eu) * TW + em] + gadd[3]);
             const float cn = fg * cprev + ig * gg, hn = og * tanhf(cn);
             ep.c[(int64_t)em * ep.R + ej] = cn;
             if (ep.h0) ep.h0[(int64_t)em * ep.ldh0 + ej] = hn;
@@ -297,7 +298,7 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w
                                      int64_t ld1, const int64_t* tok, int tok_rows, const float* add2, int64_t ld2, const float* b0,
                                      const float* b1, const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1,
                                      float* h2, int64_t ldh2, void* stream) {
-    SUBGC_REQUIRE(S >= 0 && S <= 16 && R > 0 && R % 4 == 0 && K > 0 && K % 4 == 0, "lstm_step_skinny: need S <= 16, R % 4 == 0, K % 4 == 0");
+    SUBGC_REQUIRE(S >= 0 && S <= 32 && R > 0 && R % 4 == 0 && K > 0 && K % 4 == 0, "lstm_step_skinny: need S <= 32, R % 4 == 0, K % 4 == 0");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(x && w_perm && c && (h0 || h1 || h2), "lstm_step_skinny: null pointer");
     SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % 16) == 0,
@@ -308,7 +309,9 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w
     LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R};
     const int N = 4 * R, wgs = N / 16;
     const int per_wave = ((K + 15) / 16 + 7) / 8;
-    if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
+    if (S > 16)                                                                // two activation tiles (beam search: <= 10 sub-graphs x 2-3 beams)
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, true, 2>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
+    else if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
         hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
     else
         hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);

@@ -94,7 +94,7 @@ class _BatchEngine:
         prb = SimpleNamespace(S=self.rows, N=N, f=pr.f.index_select(0, rep).contiguous(), u=pr.u, v=pr.v,
                               off=pr.off.index_select(0, rep).contiguous(), lens=pr.lens.index_select(0, rep).contiguous())
         self.pr, self.prb, self.rep = pr, prb, rep
-        self.st = F_.DecodeState(prb, P, N, False, xt_table=xt_table)
+        self.st = F_.DecodeState(prb, P, N, False, xt_table=xt_table, fuse_lstm=True)    # takes effect for <= 32 rows
         self.V1 = self.st.V1
 
     def refresh(self):

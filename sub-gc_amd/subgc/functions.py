@@ -481,11 +481,12 @@ class DecodeState:
     def __init__(self, pr: Prepared, P, N, want_att, xt_table=None, fuse_lstm=False):
         """`xt_table` [V+1, 4R] (optional, frozen weights only): relu(Emb) . W_ih[:, 2R:]^T, one row per token -- the x->gates
         product of the attention LSTM looked up instead of recomputed every step (AttModel.xt_gates_table).
-        `fuse_lstm` (<= 16 rows, R % 4 == 0): each LSTM cell is ONE launch, gate GEMM + cell update (subgc_lstm_step_skinny) on
+        `fuse_lstm` (<= 32 rows, R % 4 == 0): each LSTM cell is ONE launch, gate GEMM + cell update (subgc_lstm_step_skinny) on
         row-permuted weight snapshots; h is written into the OTHER buffer of an [H1, H1n] / [H2, H2n] pair, because the
-        launch that produces it is still reading the current one.  Not for callers that touch H1/H2 themselves (beam, step API)."""
+        launch that produces it is still reading the current one.  Beam search forks the state through `reorder`, which
+        gathers into a third buffer and so composes with the pairs; not for callers that write H1/H2 themselves (step API)."""
         self.xt_table = xt_table
-        self.fused = bool(fuse_lstm) and pr.S <= 16 and P[10].size(1) % 4 == 0
+        self.fused = bool(fuse_lstm) and pr.S <= 32 and P[10].size(1) % 4 == 0
         (_, _, _, _, _, _, _, _, self.emb, w1i, w1h, self.b1i, self.b1h, w2i, w2h, self.b2i, self.b2h,
          self.h2a_w, self.h2a_b, self.an_w, self.an_b, self.lg_w, self.lg_b) = P
         self.pr, self.N = pr, N

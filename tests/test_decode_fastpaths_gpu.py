@@ -78,7 +78,7 @@ def test_cached_decode_state_follows_load_state_dict(golden):
     assert not torch.allclose(first[1], again[1])
 
 
-@pytest.mark.parametrize("S,R,K", [(1, 48, 96), (10, 1000, 2000), (16, 1000, 3000), (7, 52, 1000)])
+@pytest.mark.parametrize("S,R,K", [(1, 48, 96), (10, 1000, 2000), (16, 1000, 3000), (7, 52, 1000), (17, 48, 144), (20, 1000, 2000), (30, 1000, 3000), (32, 52, 1000)])
 def test_fused_lstm_step_equals_gemm_plus_cell(S, R, K):
     """subgc_lstm_step_skinny (row-permuted weights, cell update in the GEMM epilogue) vs fp64 LSTMCell arithmetic."""
     g = torch.Generator().manual_seed(S * 1000 + R)
