@@ -69,3 +69,23 @@ def test_product_path_never_uses_the_host_bookkeeping(golden, monkeypatch):
     ret = m(*synthetic.sample_args(b), opt=g.meta["sample_opt"], mode="sample")
     check_beams(ret, m.done_beams, g.group("out"), atol=1e-4)
     assert not m.__dict__.get("_graph_cache")
+
+
+def test_full_gc_beam3_as_in_test_sh_matches_the_oracle(golden):
+    """test.sh decodes Full_GC_Kar with --beam_size 3: one row per image (no sub-graphs), 3 beams, replayed as a hipGraph."""
+    from oracle import subgc_oracle as O
+    g = golden("fullgc_greedy")
+    w = golden("fullgc_train").group("weights")
+    m = build(g, w, False)
+    orc = O.Oracle(g.opt(), w)
+    opt = dict(sample_max=1, beam_size=3)
+    b = g.tensors("inputs")
+    want = orc.sample_beam(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=opt)
+    for _ in range(2):                                                            # capture, replay
+        got = m(*synthetic.sample_args({k: v.clone().to(DEV) for k, v in b.items()}), opt=opt, mode="sample")
+        assert torch.equal(got[0].cpu(), want[0])
+        torch.testing.assert_close(got[1].cpu(), want[1], atol=1e-4, rtol=1e-4)
+        assert len(m.done_beams) == 1 and len(m.done_beams[0]) == 3
+        for d, h in zip(m.done_beams[0], want[4][0]):
+            assert torch.equal(d["seq"], h["seq"])
+            assert abs(d["p"] - h["p"]) < 2e-3
