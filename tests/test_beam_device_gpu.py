@@ -89,3 +89,22 @@ def test_full_gc_beam3_as_in_test_sh_matches_the_oracle(golden):
         for d, h in zip(m.done_beams[0], want[4][0]):
             assert torch.equal(d["seq"], h["seq"])
             assert abs(d["p"] - h["p"]) < 2e-3
+
+
+def test_sct_mode_with_beam2_as_in_test_sh(golden):
+    """test.sh's controllability runs: --sct 1 --beam_size 2 -- every candidate sub-graph is decoded (no NMS), two beams each."""
+    g = golden("subgc_sct")
+    m = build(g, golden("subgc_beam").group("weights"), False)
+    assert m.sct
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    opt = dict(sample_max=1, beam_size=2)
+    got = m(*synthetic.sample_args(b), opt=opt, mode="sample")
+    n = got[0].size(0)
+    assert n == b["gpn_obj_ind"].size(2) * 2 and len(m.done_beams) == n          # pos + neg slots, all kept
+    pr, P, N = prepared(m, [b])
+    with torch.no_grad():
+        host = beam.beam_decode(pr, P, N, m.seq_length, opt, xt_table=m.xt_gates_table(), on_device=False)
+    assert torch.equal(got[0].cpu(), host[0]) and torch.equal(got[1].cpu(), host[1])
+    for db, hb in zip(m.done_beams, host[2]):
+        for d, h in zip(db, hb):
+            assert torch.equal(d["seq"], h["seq"]) and d["p"] == h["p"]
