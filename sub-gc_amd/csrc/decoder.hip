@@ -630,6 +630,41 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
     }
 }
 
+// float4 forms (n % 4 == 0, 16-byte aligned buffers: the flat parameter bucket always is): 1 KB per wave instruction
+__global__ __launch_bounds__(256) void sumsq_vec_kernel(const float4* __restrict__ g, int64_t n4, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = g[i];
+        acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
+}
+__global__ __launch_bounds__(256) void clip_adam_vec_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                                            float4* __restrict__ v, int64_t n4, const float* __restrict__ sumsq,
+                                                            float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                            float bc2) {
+    const float coef = max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]), max_norm) : 1.f;
+    const float rs2 = sqrtf(bc2), step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 P = p[i], G = g[i], M = m[i], V = v[i];
+        float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                          // same arithmetic, element by element, as clip_adam_kernel
+            float gi = gg[e] * coef;
+            gg[e] = gi;
+            if (wd != 0.f) gi += wd * pp[e];
+            const float mi = b1 * mm[e] + (1.f - b1) * gi;
+            const float vi = b2 * vv[e] + (1.f - b2) * gi * gi;
+            mm[e] = mi; vv[e] = vi;
+            const float denom = sqrtf(vi) / rs2 + eps;
+            pp[e] = pp[e] - step * (mi / denom);
+        }
+        g[i] = G; m[i] = M; v[i] = V; p[i] = P;
+    }
+}
+
 inline int ew_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192)); }
 
 }  // namespace
@@ -875,6 +910,11 @@ SUBGC_API int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* str
     SUBGC_REQUIRE(n >= 0, "sumsq: bad size");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(g && sumsq, "sumsq: null pointer");
+    if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        hipLaunchKernelGGL(sumsq_vec_kernel, dim3(std::min(ew_grid(n / 4), 2048)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(g), n / 4, sumsq);
+        return subgc::check_launch("subgc_sumsq_f32");
+    }
     hipLaunchKernelGGL(sumsq_kernel, dim3(std::min(ew_grid(n), 1024)), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
     return subgc::check_launch("subgc_sumsq_f32");
 }
@@ -884,6 +924,13 @@ SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(p && g && m && v && sumsq, "clip_adam_step: null pointer");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (n % 4 == 0 && al(p) && al(g) && al(m) && al(v)) {
+        hipLaunchKernelGGL(clip_adam_vec_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(p),
+                           reinterpret_cast<float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n / 4, sumsq, max_norm, lr,
+                           beta1, beta2, eps, weight_decay, bc1, bc2);
+        return subgc::check_launch("subgc_clip_adam_step");
+    }
     hipLaunchKernelGGL(clip_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr, beta1,
                        beta2, eps, weight_decay, bc1, bc2);
     return subgc::check_launch("subgc_clip_adam_step");
