@@ -249,6 +249,16 @@ int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int64_t ld1, c
                    float* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd,
                    float* gates, int S, int R, int rows_h, int rows_h2,
                    void* stream);
+/* subgc_gemm_f32(x . w^T) + subgc_lstm_fwd in one call for the teacher-forced steps (S in the hundreds): when the product
+ * takes the split-K form its partial planes stay in the workspace and the cell kernel adds them while it reads the
+ * pre-activations (no reduce launch, no [S,4R] round trip); otherwise the product goes to `pre` [S, >= 4R] (scratch) and the
+ * two entry points run back to back.  w [4R, K] = [W_ih(cols) | W_hh] K-concatenated; remaining arguments as subgc_lstm_fwd.  */
+int subgc_lstm_fwd_gemm(const float* x, int64_t ldx, const float* w, int64_t ldw, int K, float* pre, int64_t ldpre,
+                        const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1,
+                        const float* c_prev, float* c, float* h, int64_t ldh, float* h2, int64_t ldh2,
+                        const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd, float* gates, int S, int R,
+                        int rows_h, int rows_h2, void* stream);
+
 /* dh (up to two sources summed: dh_a, dh_b, either may be NULL) and dc (may be NULL) ->
  * dpre [S,4R] and dc_prev.  dh_drop (optional) is a gradient that arrives through the dropout
  * mask (keep/keep_scale).                                                                    */

@@ -36,6 +36,7 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // gemm_skinny.hip: C[M,N] = act(A[M,K] W[N,K]^T + bias) for M <= 16 (weight-streaming bound); returns -100
 // when the shape is not covered (caller falls back to the tiled MFMA kernels).
+int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, hipStream_t s, const float** ws, int* splits);
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N,
                    int K, int relu, hipStream_t stream, const float* add = nullptr, int64_t ldadd = 0);
 

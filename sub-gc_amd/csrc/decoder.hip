@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ c_prev, float* __restrict__ c,
                                                        float* __restrict__ h, int64_t ldh, float* __restrict__ h2, int64_t ldh2,
                                                        const uint8_t* __restrict__ keep, float scale, float* __restrict__ hdrop,
-                                                       int64_t ldhd, float* __restrict__ gates, int S, int R, int rows_h, int rows_h2) {
+                                                       int64_t ldhd, float* __restrict__ gates, int S, int R, int rows_h, int rows_h2,
+                                                       int parts, int64_t plane) {
+    // parts > 1: g0 is a stack of split-K partial planes g0[p * plane + ...] (subgc_lstm_fwd_gemm): summed here, no reduce pass
     const int RV = R / VW;
     const int64_t qv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qv >= (int64_t)S * RV) return;
@@ -139,6 +141,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         const int col = k * R + j;
         float t[VW];
         ldv<VW>(g0 + (int64_t)s * ld0 + col, pre[k]);
+        for (int pt = 1; pt < parts; ++pt) {
+            ldv<VW>(g0 + pt * plane + (int64_t)s * ld0 + col, t);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) pre[k][e] += t[e];
+        }
         if (g1) { ldv<VW>(g1 + (int64_t)s * ld1 + col, t);
 #pragma unroll
             for (int e = 0; e < VW; ++e) pre[k][e] += t[e]; }
@@ -725,11 +732,41 @@ SUBGC_API int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int6
                      (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
     if (vec)
         hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev,
-                           c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2);
+                           c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, 1, 0);
     else
         hipLaunchKernelGGL(lstm_fwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev, c,
-                           h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2);
+                           h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, 1, 0);
     return subgc::check_launch("subgc_lstm_fwd");
+}
+// gate GEMM + cell update with the split-K reduce folded into the cell kernel (training steps, S in the hundreds)
+SUBGC_API int subgc_lstm_fwd_gemm(const float* x, int64_t ldx, const float* w, int64_t ldw, int K, float* pre, int64_t ldpre, const float* g1,
+                                  int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c,
+                                  float* h, int64_t ldh, float* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, float* hdrop,
+                                  int64_t ldhd, float* gates, int S, int R, int rows_h, int rows_h2, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && R > 0 && K > 0, "lstm_fwd_gemm: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(x && w && pre && c && h && ldpre >= 4 * R, "lstm_fwd_gemm: null pointer / scratch too narrow");
+    hipStream_t s = (hipStream_t)stream;
+    const float* ws = nullptr;
+    int parts = 0;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = R % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && ldh % 4 == 0 && ldh2 % 4 == 0 && ldhd % 4 == 0 && al(g1) && al(g2) && al(b0) &&
+                     al(b1) && al(c_prev) && al(c) && al(h) && al(h2) && al(hdrop) && al(gates) && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
+    int rc = vec ? subgc::gemm_nt_partials(x, ldx, w, ldw, S, 4 * R, K, s, &ws, &parts) : -100;
+    if (rc == -100)                                                               // not the split-K shape: plain product, then the cell kernel
+        return (rc = subgc_gemm_f32(0, 1, S, 4 * R, K, x, ldx, w, ldw, pre, ldpre, nullptr, nullptr, 0, nullptr, 1.f, 0, nullptr, nullptr, nullptr,
+                                    stream)) != SUBGC_OK
+                   ? rc
+                   : subgc_lstm_fwd(pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R,
+                                    rows_h, rows_h2, stream);
+    if (rc != SUBGC_OK) return rc;
+    if (rows_h <= 0 || rows_h > S) rows_h = S;
+    if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
+    const int64_t n = (int64_t)S * R;
+    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12);
+    hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ws, (int64_t)4 * R, g1, ld1, g2, ld2, b0, b1,
+                       c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, parts, (int64_t)S * 4 * R);
+    return subgc::check_launch("subgc_lstm_fwd_gemm");
 }
 SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda, const float* dh_b,
                              int64_t ldb, const float* dh_drop, int64_t ldd, const uint8_t* keep, float keep_scale, const float* dc,

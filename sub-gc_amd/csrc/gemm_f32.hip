@@ -530,7 +530,7 @@ inline int choose_splits(int tiles, int kt) {
 }
 
 template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
-int launch_splitk(const GemmArgs& a, hipStream_t s, int splits) {
+int launch_splitk(const GemmArgs& a, hipStream_t s, int splits, bool reduce = true) {
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
     const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
@@ -539,6 +539,7 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits) {
     static bool attr_set = false;
     if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
     hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, g_ws, splits, per);
+    if (!reduce) return subgc::check_launch("subgc_gemm_f32(split-K, partials)");   // the consumer sums the planes itself
     const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);
@@ -626,6 +627,25 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
     return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
 }
+
+namespace subgc {
+// x[M,K] . W[N,K]^T left as `splits` partial planes ws[part][M][N] in the registered workspace, WITHOUT the reduce pass: for a
+// consumer that reads the pre-activations exactly once and can add the planes on the way (the LSTM cell kernel).  Same tile
+// and split choice as subgc_gemm_f32 would make for the plain product; -100 when that choice is not the 128x128 split-K form.
+int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, hipStream_t s, const float** ws, int* splits) {
+    if (!(aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0) || !g_splitk || !g_ws || M <= g_smallm) return -100;
+    const int64_t big = cdiv(M, 128) * cdiv(N, 128);
+    if (big < 16 || big >= 384) return -100;
+    const int sp = choose_splits((int)big, (K + BK - 1) / BK);
+    if (sp <= 1 || big * sp < 200 || (size_t)sp * M * N * sizeof(float) > g_ws_bytes) return -100;
+    GemmArgs a{A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, M, N, K, 0, 1.f};
+    ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
+    const int rc = g_x3 == 1 ? launch_splitk<128, 128, false, true, true, 3>(a, s, sp, false)
+                 : g_x3 == 2 ? launch_splitk<128, 128, false, true, true, 2>(a, s, sp, false) : launch_splitk<128, 128, false, true, true>(a, s, sp, false);
+    *ws = g_ws; *splits = sp;
+    return rc;
+}
+}  // namespace subgc
 
 SUBGC_API int subgc_set_gemm_mode(int mode) {
     SUBGC_REQUIRE(mode >= 0 && mode <= 2, "set_gemm_mode: 0 = fp32 matrix pipe, 1 = bf16 pipe with 3-way split fp32 operands, 2 = bf16 operands");

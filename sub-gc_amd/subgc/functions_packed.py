@@ -110,14 +110,13 @@ class PackedDecoderLossFn(Function):
                     ops.multinomial_rows_(logits[op:op + m], u_p[t][:m], sel_p[t][:m], ss[0], tokens_p[:m, t])
                 ops.embed_fwd(emb, tokens_p[:, t], tokens_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[o:o + m])
                 ops.gemm(xt[o:o + m], w1i[:, 2 * R:], Gx[o:o + m], tb=True)
-            ops.gemm(H1[o:o + m], Wc1, pre[:m], tb=True)
-            ops.lstm_fwd(pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R], H1[o1:o1 + mn_, R:],
-                         None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
+            ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
+                              H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
             ops.gemm(H2[o:o + m, R:2 * R], h2a_w, AH[o:o + m], tb=True, bias=h2a_b)
             ops.attn_fwd(pr.u, pr.v, AH[o:o + m], an_w, an_b, pr.off, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R)
-            ops.gemm(H2[o:o + m], Wc2, pre[:m], tb=True)
-            ops.lstm_fwd(pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R], H2[o1:o1 + mn_, 2 * R:],
-                         None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R, rows_h=mn_, rows_h2=mn_)
+            ops.lstm_fwd_gemm(H2[o:o + m], Wc2, pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R],
+                              H2[o1:o1 + mn_, 2 * R:], None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R,
+                              rows_h=mn_, rows_h2=mn_)
         if ss is None:
             ops.gemm(Hout[:rows], lg_w, logits[:rows], tb=True, bias=lg_b)
         elif T_live > 0:

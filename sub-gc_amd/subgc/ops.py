@@ -305,6 +305,19 @@ def lstm_fwd(g0, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S,
          int(rows_h2), _stream())
 
 
+def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0):
+    """gemm(x, w^T) + lstm_fwd with the split-K reduce folded into the cell kernel (subgc_lstm_fwd_gemm); `pre` [S, 4R] is scratch."""
+    L = lambda t: ld(t) if t is not None else 0
+    K = x.size(1)
+    if FLOPS["on"]:                      # same accounting as ops.gemm: the product is the same launch family
+        FLOPS["gemm"] += 2.0 * S * 4 * R * K
+        FLOPS["gemm_bytes"] += 4.0 * (S * K + K * 4 * R + S * 4 * R)
+        FLOPS["gemm_calls"] += 1
+    call("subgc_lstm_fwd_gemm", _ptr(x, torch.float32), ld(x), _ptr(w, torch.float32), ld(w), K, _ptr(pre, torch.float32), ld(pre),
+         _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c), _ptr(h), L(h), _ptr(h2), L(h2),
+         _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h), int(rows_h2), _stream())
+
+
 def lstm_bwd(gates, c_prev, c, dh_a, dh_b, dh_drop, keep, scale, dc, dpre, dc_prev, S, R):
     L = lambda t: ld(t) if t is not None else 0
     call("subgc_lstm_bwd", _ptr(gates), _ptr(c_prev), _ptr(c), _ptr(dh_a), L(dh_a), _ptr(dh_b), L(dh_b), _ptr(dh_drop), L(dh_drop),

@@ -146,3 +146,26 @@ def test_weight_streaming_gemm_up_to_80_rows(M, N, K):
     assert float(out[M].min()) == 5.0                                                # rows past M untouched
     ops.gemm(x, W, out[:M], tb=True, bias=bias, add=add, relu=True)
     torch.testing.assert_close(out[:M].double(), (ref + bias.double() + add.double()).clamp_min(0), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("S,R,K", [(640, 1000, 2000), (384, 1000, 3000), (100, 1000, 2000), (640, 52, 104)])
+def test_lstm_fwd_gemm_equals_gemm_then_lstm_fwd(S, R, K):
+    """subgc_lstm_fwd_gemm: split-K partial planes summed inside the cell kernel (training steps) vs the two separate entry points."""
+    ops.ensure_workspace(DEV)
+    g = torch.Generator().manual_seed(S + R)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    x, W = rnd(S, K), rnd(4 * R, K, sc=K ** -0.5)
+    g1, g2, b0, b1, cp = rnd(S, 4 * R, sc=0.5), rnd(S, 4 * R, sc=0.5), rnd(4 * R, sc=0.3), rnd(4 * R, sc=0.3), rnd(S, R)
+    keep = (torch.rand(S, R, generator=g) > 0.5).to(torch.uint8).to(DEV)
+    new = lambda *s: torch.empty(*s, device=DEV)
+    outs = []
+    for fused in (True, False):
+        pre, c, h, h2, hd, gates = new(S, 4 * R), new(S, R), new(S, 2 * R), new(S, R), new(S, R), new(S, 4 * R)
+        if fused:
+            ops.lstm_fwd_gemm(x, W, pre, g1, g2, b0, b1, cp, c, h[:, R:], h2, keep, 2.0, hd, gates, S, R)
+        else:
+            ops.gemm(x, W, pre, tb=True)
+            ops.lstm_fwd(pre, g1, g2, b0, b1, cp, c, h[:, R:], h2, keep, 2.0, hd, gates, S, R)
+        outs.append((c, h[:, R:].clone(), h2, hd, gates))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, atol=2e-5, rtol=1e-5)
