@@ -390,6 +390,12 @@ int subgc_relu_bwd(const float* dy, const float* y, float scale, float* dz, int6
 /* dst[m, :] = src[rows[m], :] for m < min(M, *m_dev); negative rows give zero rows               */
 int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, float* dst, int64_t ldd,
                       int M, int L, const int32_t* m_dev, void* stream);
+/* the same gather for `count` (1..4) tensors in one launch: dst_k[m, :c_k] = src_k[rows[m], :c_k] -- the state fork of beam
+ * search (CaptionModel.py:76-90: h and c of both LSTMs follow the surviving beams), four tensors per step            */
+int subgc_gather_rows_multi(int count, const float* s0, int64_t lds0, float* d0, int64_t ldd0, int c0, const float* s1,
+                            int64_t lds1, float* d1, int64_t ldd1, int c1, const float* s2, int64_t lds2, float* d2,
+                            int64_t ldd2, int c2, const float* s3, int64_t lds3, float* d3, int64_t ldd3, int c3,
+                            const int32_t* rows, int M, void* stream);
 int subgc_fill_f32(float* x, int64_t n, float value, void* stream);
 /* y[rows, cols] (ldy) += / = x[rows, cols] (ldx) */
 int subgc_copy2d_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, int accumulate,

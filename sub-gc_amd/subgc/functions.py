@@ -532,10 +532,7 @@ class DecodeState:
             self._alt = [torch.empty_like(self.H1), torch.empty_like(self.H2), torch.empty_like(self.C1[0]), torch.empty_like(self.C2[0])]
         a1, a2, ac1, ac2 = self._alt
         R = self.R
-        ops.gather_rows(self.H1, src, a1)
-        ops.gather_rows(self.H2[:, 2 * R:], src, a2[:, 2 * R:])
-        ops.gather_rows(self.C1[0], src, ac1)
-        ops.gather_rows(self.C2[0], src, ac2)
+        ops.gather_rows_multi([(self.H1, a1), (self.H2[:, 2 * R:], a2[:, 2 * R:]), (self.C1[0], ac1), (self.C2[0], ac2)], src)
         self._alt = [self.H1, self.H2, self.C1[0], self.C2[0]]
         self.H1, self.H2, self.C1[0], self.C2[0] = a1, a2, ac1, ac2
 

@@ -466,6 +466,17 @@ def gather_rows(src, rows, dst, m_dev=None):
     return dst
 
 
+def gather_rows_multi(pairs, rows):
+    """dst[m] = src[rows[m]] for up to four (src, dst) pairs of 2-D views in one launch (subgc_gather_rows_multi)."""
+    if not 1 <= len(pairs) <= 4:
+        raise SubgcError("gather_rows_multi takes 1..4 (src, dst) pairs")
+    args = []
+    for src, dst in list(pairs) + [(None, None)] * (4 - len(pairs)):
+        args += [_ptr(src, torch.float32), ld(src) if src is not None else 0, _ptr(dst, torch.float32), ld(dst) if dst is not None else 0,
+                 dst.size(1) if dst is not None else 0]
+    call("subgc_gather_rows_multi", len(pairs), *args, _ptr(rows, torch.int32), pairs[0][1].size(0), _stream())
+
+
 def scatter_add_rows(src, rows, dX, m_dev=None):
     call("subgc_scatter_add_rows", _ptr(src), ld(src), _ptr(rows, torch.int32), _ptr(dX), ld(dX), src.size(0), src.size(1),
          _ptr(m_dev, torch.int32), _stream())
