@@ -469,9 +469,7 @@ class AttModel(CaptionModel):
         # weight-streaming form
         N = att_feats.size(1)
         X2 = self._encode(att_feats[:1], obj_dist[:1], pred_dist[:1], rel_ind[:1]).reshape(N, self.GCN_dim).contiguous()
-        image = [(0, gpn_obj_ind, att_masks, gpn_pool_mtx)]
-        sel = sampling.select_subgraphs(self, X2, N, image) if self.gpn else sampling.full_graph_rows(self, X2, N, image)
-        return sampling.decode(self, X2, N, sel, opt, uniforms, forced)[0]
+        return sampling.decode_one_image(self, X2, N, (0, gpn_obj_ind, att_masks, gpn_pool_mtx), opt, uniforms, forced)
 
     @torch.no_grad()
     def sample_images(self, images, opt={}):

@@ -36,11 +36,9 @@ def _forced_pick(logp, tok, k, temp, t, seq, seqlp, it, unfinished, counts):
     counts[t] = unf.sum().int()
 
 
-def select_subgraphs(m, X2, N, images):
-    """Score every candidate sub-graph of every image, keep the NMS survivors.
-
-    images: list of (image_row, gpn_obj_ind [5,2,M,N], att_masks [5,2,M,N], gpn_pool_mtx [5,2,M,N,N]) -- only
-    counterpart 0 is read, like gpn.py:86-96.  Returns a list of dicts(fc, lens, idx, img, score, keep)."""
+def score_candidates(m, X2, N, images):
+    """The launch-only half of `select_subgraphs`: pool + score every candidate sub-graph of every image and run the node-set
+    NMS; nothing is read back.  -> namespace(idx, lens_i, img, read_out, score, sizes, offs, keep_all, n_keep)."""
     dev, L = X2.device, m.GCN_dim
     for _, gpn_obj_ind, _, _ in images:
         if gpn_obj_ind.size(0) != 5:
@@ -63,9 +61,24 @@ def select_subgraphs(m, X2, N, images):
         score = torch.ones(G, device=dev)
     lens_i = lens_all.to(torch.int32)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    keep_all = n_keep = None
     if not m.sct:                                                                      # use_nms (AttModel.py:95); node-set NMS is per image (gpn.py:108-138)
         keep_all, n_keep, _ = ops.subgraph_nms_batched(score, idx, lens_i, sizes, m.gpn_nms_thres, m.gpn_max_subg)
-        kept = n_keep.cpu().numpy().astype(np.int64)                                   # ONE launch and ONE host read for all images
+    return SimpleNamespace(idx=idx, lens_i=lens_i, img=img, read_out=read_out, score=score, sizes=sizes, offs=offs, keep_all=keep_all,
+                           n_keep=n_keep, G=G)
+
+
+def select_subgraphs(m, X2, N, images, front=None, kept=None):
+    """Score every candidate sub-graph of every image, keep the NMS survivors.
+
+    images: list of (image_row, gpn_obj_ind [5,2,M,N], att_masks [5,2,M,N], gpn_pool_mtx [5,2,M,N,N]) -- only
+    counterpart 0 is read, like gpn.py:86-96.  Returns a list of dicts(fc, lens, idx, img, score, keep).
+    `front` / `kept`: the result of `score_candidates` and the survivor counts when the caller already has them."""
+    dev, L = X2.device, m.GCN_dim
+    fr = front if front is not None else score_candidates(m, X2, N, images)
+    idx, lens_i, img, read_out, score, sizes, offs, keep_all, G = fr.idx, fr.lens_i, fr.img, fr.read_out, fr.score, fr.sizes, fr.offs, fr.keep_all, fr.G
+    if not m.sct:
+        kept = fr.n_keep.cpu().numpy().astype(np.int64) if kept is None else np.asarray(kept, dtype=np.int64)   # ONE host read for all images
         g0 = np.repeat(offs[:-1], kept)                                                # first candidate of the owning image, per survivor
         slot = g0 + (np.arange(int(kept.sum())) - np.repeat(np.cumsum(kept) - kept, kept))
         hs = torch.from_numpy(np.stack([slot, g0])).to(dev)                            # one small upload
@@ -110,6 +123,52 @@ def full_graph_rows(m, X2, N, images):
     return out
 
 
+class _FrontBuffers:
+    """Fixed-address copies of what the selection phase of ONE image leaves for the decode graph (node states, read-outs,
+    scores, node sets, NMS survivors).  The copies are queued BEFORE the one host read of a call (the survivor count), so
+    after that read the host issues a single graph replay: the survivor gathers, the read-out projection and the attention-set
+    preparation (`F_.Prepared`) run inside the graph instead of as ~25 eager launches with the GPU idling between them."""
+
+    def __init__(self, m, G, N):
+        dev, L = m.flat_params.device, m.GCN_dim
+        self.G, self.N = G, N
+        self.X2, self.read_out = torch.empty(N, L, device=dev), torch.empty(G, 2 * L, device=dev)
+        self.keep, self.lens = torch.zeros(G, device=dev, dtype=torch.long), torch.zeros(G, device=dev, dtype=torch.int32)
+        self.idx, self.score = torch.zeros(G, N, device=dev, dtype=torch.long), torch.empty(G, device=dev)
+
+    def load(self, X2, fr):
+        self.X2.copy_(X2); self.read_out.copy_(fr.read_out); self.keep.copy_(fr.keep_all[:self.G])
+        self.lens.copy_(fr.lens_i); self.idx.copy_(fr.idx); self.score.copy_(fr.score)
+
+    def prepared(self, m, n, P):
+        """(inside the capture) the first n NMS survivors -> F_.Prepared, their scores and indices."""
+        dev, L = self.X2.device, m.GCN_dim
+        keep = self.keep[:n]
+        h, fc = torch.empty(n, m.att_hid_size, device=dev), torch.empty(n, 2 * L, device=dev)
+        ops.gemm(self.read_out[keep], m.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
+        ops.gemm(h, m.P("gpn_layer.read_out_proj.1.weight"), fc, tb=True, bias=m.P("gpn_layer.read_out_proj.1.bias"))
+        pr = F_.Prepared(fc, self.X2, self.lens[keep], self.idx[keep], torch.zeros(n, device=dev, dtype=torch.int32), self.N, P, None, None, 1.0)
+        return pr, self.score[keep], keep
+
+
+def _front_buffers(m, G, N):
+    cache = m.__dict__.setdefault("_front_cache", {})
+    key = (G, N, m.flat_params.data_ptr())
+    if key not in cache:
+        if len(cache) >= 8:
+            cache.clear()
+            m.__dict__.pop("_graph_cache", None)                                  # graphs captured on the dropped buffers go with them
+        cache[key] = _FrontBuffers(m, G, N)
+    return cache[key]
+
+
+def _load_prepared(dst, pr):
+    rows = pr.u.size(0)
+    dst.f.copy_(pr.f)
+    dst.u[:rows].copy_(pr.u); dst.v[:rows].copy_(pr.v)
+    dst.off.copy_(pr.off); dst.lens.copy_(pr.lens)
+
+
 class _GraphedLoop:
     """The token loop of ONE image as a replayable hipGraph (torch.cuda.CUDAGraph over the C-ABI launches).
 
@@ -119,10 +178,13 @@ class _GraphedLoop:
     Keyed by (rows, N, attention rows capacity, k, return_att) and by the version of the flat parameter buffer (the
     K-concatenated LSTM weights inside DecodeState are snapshots of the parameters)."""
 
-    def __init__(self, m, n, N, k, return_att, P):
+    def __init__(self, m, n, N, k, return_att, P, fb=None):
         dev = m.flat_params.device
         T, R, A = m.seq_length, m.rnn_size, m.att_hid_size
         self.n, self.N, self.T, self.k, self.return_att = n, N, T, k, return_att
+        self.m, self.P, self.fb = m, P, fb                                        # fb: the graph starts from the selection's static buffers
+        if fb is not None:
+            self.score_out, self.keep_out = torch.empty(n, device=dev), torch.zeros(n, device=dev, dtype=torch.long)
         cap = n * N
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
@@ -140,6 +202,10 @@ class _GraphedLoop:
 
     def _loop(self):
         T = self.T
+        if self.fb is not None:
+            pr, score, keep = self.fb.prepared(self.m, self.n, self.P)
+            _load_prepared(self.pr, pr)
+            self.score_out.copy_(score); self.keep_out.copy_(keep)
         self.st.reset()
         for b in (self.seq, self.seqlp, self.it, self.unfinished, self.counts) + ((self.AL,) if self.AL is not None else ()):
             b.zero_()
@@ -151,10 +217,8 @@ class _GraphedLoop:
                             self.unfinished, self.counts[t:t + 1], self.counts[t - 1:t] if t > 0 else None, raw=True)
 
     def run(self, pr, uniforms):
-        rows = pr.u.size(0)
-        self.pr.f.copy_(pr.f)
-        self.pr.u[:rows].copy_(pr.u); self.pr.v[:rows].copy_(pr.v)
-        self.pr.off.copy_(pr.off); self.pr.lens.copy_(pr.lens)
+        if pr is not None:
+            _load_prepared(self.pr, pr)
         if self.u is not None:
             self.u.copy_(uniforms.t())
         self.graph.replay()
@@ -166,9 +230,12 @@ class _GraphedBeam:
     the candidate bookkeeping on the device (`subgc_beam_step`) the whole search is a static launch sequence, ~16 launches per
     step on <= 10 x beam rows, i.e. launch-bound when issued eagerly."""
 
-    def __init__(self, m, n, N, P, opt):
+    def __init__(self, m, n, N, P, opt, fb=None):
         dev = m.flat_params.device
         T, R, A = m.seq_length, m.rnn_size, m.att_hid_size
+        self.m, self.n, self.P, self.fb = m, n, P, fb
+        if fb is not None:
+            self.score_out, self.keep_out = torch.empty(n, device=dev), torch.zeros(n, device=dev, dtype=torch.long)
         cap = n * N
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
@@ -181,41 +248,87 @@ class _GraphedBeam:
             self._loop()
 
     def _loop(self):
+        if self.fb is not None:
+            pr, score, keep = self.fb.prepared(self.m, self.n, self.P)
+            _load_prepared(self.pr, pr)
+            self.score_out.copy_(score); self.keep_out.copy_(keep)
         self.eng.refresh()
         self.ds.loop()
 
     def run(self, pr):
-        rows = pr.u.size(0)
-        self.pr.f.copy_(pr.f)
-        self.pr.u[:rows].copy_(pr.u); self.pr.v[:rows].copy_(pr.v)
-        self.pr.off.copy_(pr.off); self.pr.lens.copy_(pr.lens)
+        if pr is not None:
+            _load_prepared(self.pr, pr)
         self.graph.replay()
         return self.ds.collect()
 
 
-def _graphed_beam(m, n, N, P, opt):
+def _graphed_beam(m, n, N, P, opt, fb=None):
     okey = tuple(sorted((k, v) for k, v in opt.items() if k in ("beam_size", "group_size", "diversity_lambda", "decoding_constraint", "length_penalty")))
-    key = ("beam", n, N, okey) + m.weights_version()
+    key = ("beam", n, N, okey, None if fb is None else fb.G) + m.weights_version()
     cache = m.__dict__.setdefault("_graph_cache", {})
     if key not in cache:
-        for old in [q for q in cache if q[:4] == key[:4]]:
+        for old in [q for q in cache if q[:5] == key[:5]]:
             del cache[old]
         if len(cache) >= 24:
             cache.clear()
-        cache[key] = _GraphedBeam(m, n, N, P, opt)
+        cache[key] = _GraphedBeam(m, n, N, P, opt, fb)
     return cache[key]
 
 
-def _graphed_loop(m, n, N, k, return_att, P):
-    key = (n, N, k, return_att) + m.weights_version()
+def _graphed_loop(m, n, N, k, return_att, P, fb=None):
+    key = (n, N, k, return_att, None if fb is None else fb.G) + m.weights_version()
     cache = m.__dict__.setdefault("_graph_cache", {})
     if key not in cache:
-        for old in [q for q in cache if q[:4] == key[:4]]:                       # parameters changed: drop the stale snapshot
+        for old in [q for q in cache if q[:5] == key[:5]]:                       # parameters changed: drop the stale snapshot
             del cache[old]
         if len(cache) >= 24:
             cache.clear()
-        cache[key] = _GraphedLoop(m, n, N, k, return_att, P)
+        cache[key] = _GraphedLoop(m, n, N, k, return_att, P, fb)
     return cache[key]
+
+
+@torch.no_grad()
+def decode_one_image(m, X2, N, image, opt, uniforms=None, forced=None):
+    """The reference-shaped call (ONE image, sGPN + NMS): selection launches -> static buffers -> the one host read (how many
+    sub-graphs survived) -> ONE graph replay that gathers the survivors, prepares their attention sets and runs the token
+    loop / beam search.  Falls back to `select_subgraphs` + `decode` (same kernels, eager) whenever a graph does not apply."""
+    T = m.seq_length
+    beam_size = opt.get("beam_size", 1)
+    return_att = opt.get("return_att", 0) == 1
+    graphable = m.gpn and not m.sct and forced is None and getattr(m, "decode_hipgraph", True)
+    fr = score_candidates(m, X2, N, [image]) if m.gpn else None
+    if not graphable or fr.G == 0:
+        sel = select_subgraphs(m, X2, N, [image], front=fr) if m.gpn else full_graph_rows(m, X2, N, [image])
+        return decode(m, X2, N, sel, opt, uniforms, forced)[0]
+    fb = _front_buffers(m, fr.G, N)
+    fb.load(X2, fr)                                                               # queued before the host read below
+    n = int(fr.n_keep.item())
+    if n == 0 or (beam_size > 1 and n * beam_size > 128) or (beam_size <= 1 and n > 16):
+        return decode(m, X2, N, select_subgraphs(m, X2, N, [image], front=fr, kept=[n]), opt, uniforms, forced)[0]
+    P = m._decoder_params()
+    try:
+        if beam_size > 1:
+            g = _graphed_beam(m, n, N, P, opt, fb)
+            seq, seqlp, done = g.run(None)
+            m.done_beams = done
+            return (seq, seqlp, g.score_out.clone(), g.keep_out.clone())
+        k = m.the_k if m.topk_sampling else 0
+        if k and uniforms is None:
+            uniforms = torch.rand(n, T, device=X2.device)
+        g = _graphed_loop(m, n, N, k, return_att, P, fb)
+    except RuntimeError as e:                                                     # capture unavailable here: same kernels, launched eagerly
+        import warnings
+        warnings.warn(f"hipGraph capture of the decode loop failed ({e}); decoding eagerly from now on")
+        m.decode_hipgraph = False
+        return decode(m, X2, N, select_subgraphs(m, X2, N, [image], front=fr, kept=[n]), opt, uniforms, forced)[0]
+    seq, seqlp, counts, AL = g.run(None, uniforms)
+    r = (seq, seqlp, g.score_out.clone(), g.keep_out.clone())
+    if return_att:
+        dead = (counts.cpu() == 0).nonzero()
+        steps = int(dead[0]) + 1 if dead.numel() else T + 1
+        n_max = int(g.pr.lens.max().item())
+        r = r + (AL[:steps, :, :n_max].permute(1, 0, 2).contiguous(),)
+    return r
 
 
 @torch.no_grad()
