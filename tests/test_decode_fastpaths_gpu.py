@@ -169,3 +169,36 @@ def test_lstm_fwd_gemm_equals_gemm_then_lstm_fwd(S, R, K):
         outs.append((c, h[:, R:].clone(), h2, hd, gates))
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, atol=2e-5, rtol=1e-5)
+
+
+def test_one_image_graph_path_over_varied_candidate_and_survivor_counts(golden):
+    """Soak of the replayed one-image path: candidate counts G, survivor counts n (incl. 0 via an empty image) and the decode
+    mode change from call to call; every call must equal the eager path (same kernels, no graph, no static buffers)."""
+    g = golden("subgc_greedy")
+    w = golden("subgc_beam").group("weights")
+    opt = g.meta["opt"]
+    mk = lambda M, seed: {k: v.to(DEV) for k, v in synthetic.make_test_batch(M, seed=seed, D=opt["att_feat_size"], N=g.tensors("inputs")["att_feats"].size(1),
+                                                                           K=g.tensors("inputs")["rel_ind"].size(1)).items()}
+    cases = [(3, 11), (8, 12), (2, 13), (20, 14), (1, 16), (2, 17), (8, 15)]           # 2M candidates -> min(2M, 6) survivors: n in {2, 4, 6}
+    mg, me = build(g, w, False, gpn_nms_thres=0.55, gpn_max_subg=6), build(g, w, False, gpn_nms_thres=0.55, gpn_max_subg=6)
+    me.decode_hipgraph = False
+    seen_n = set()
+    for rnd in range(2):
+        for M, seed in cases:
+            b = mk(M, seed)
+            for sopt in (dict(sample_max=1, beam_size=1, return_att=1), dict(sample_max=1, beam_size=2)):
+                a = mg(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")
+                e = me(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")
+                seen_n.add(a[0].size(0))
+                assert len(a) == len(e)
+                for x, y in zip(a, e):
+                    assert x.shape == y.shape
+                    if x.dtype in (torch.int64, torch.int32):
+                        assert torch.equal(x.cpu(), y.cpu())
+                    else:
+                        torch.testing.assert_close(x.cpu(), y.cpu(), atol=1e-4, rtol=1e-4)
+                if sopt["beam_size"] > 1:
+                    for db, eb in zip(mg.done_beams, me.done_beams):
+                        for d, h in zip(db, eb):
+                            assert torch.equal(d["seq"], h["seq"]) and abs(d["p"] - h["p"]) < 1e-3
+    assert len(seen_n) >= 3 and not me.__dict__.get("_graph_cache") and mg.__dict__.get("_graph_cache")
