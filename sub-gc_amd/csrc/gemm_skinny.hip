@@ -265,21 +265,21 @@ int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, flo
 #define SUBGC_SKINNY_MT(MT_, D_)                                                                                                            \
     hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, D_, false, MT_>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, \
                        LstmEpi{}, add, ldadd)
-        if (mt == 2) SUBGC_SKINNY_MT(2, 8);
-        else if (mt == 3) SUBGC_SKINNY_MT(3, 4);
-        else if (mt == 4) SUBGC_SKINNY_MT(4, 4);
-        else SUBGC_SKINNY_MT(5, 4);
+        if (mt == 2) SUBGC_SKINNY_MT(2, 2);
+        else if (mt == 3) SUBGC_SKINNY_MT(3, 2);
+        else if (mt == 4) SUBGC_SKINNY_MT(4, 2);
+        else SUBGC_SKINNY_MT(5, 2);
 #undef SUBGC_SKINNY_MT
         return subgc::check_launch("subgc_gemm_f32(skinny)");
     }
     if (M > 16) return -100;
     if (form == 1) {
         const int wgs = (N + 15) / 16;
-        const int per_wave = ((K + 15) / 16 + 7) / 8;                          // ring depth: the deeper one unless it leaves more idle slots
-        if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
-            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, false, 1>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{}, add, ldadd);
-        else
-            hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, false, 1>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{}, add, ldadd);
+        // Ring depth 2.  Deeper rings were measured and are SLOWER (rocprofv3, 10 rows: logits 17.0 us at depth 8, 13.3 at 4, 11.9 at
+        // 2; depth 16: 31 us): the last steady-state round prefetches a full ring past the wave's share (clamped, useless loads --
+        // half of all load instructions at depth 8 when a wave owns 8 steps), and with ~50 VGPRs eight waves per SIMD hide the
+        // latency that the ring was meant to hide.
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{}, add, ldadd);
         return subgc::check_launch("subgc_gemm_f32(skinny)");
     }
     if (add) return -100;                             // the VALU form has no residual term
@@ -308,12 +308,9 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
     LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R};
     const int N = 4 * R, wgs = N / 16;
-    const int per_wave = ((K + 15) / 16 + 7) / 8;
     if (S > 16)                                                                // two activation tiles (beam search: <= 10 sub-graphs x 2-3 beams)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, true, 2>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
-    else if ((per_wave + 11) / 12 * 12 - per_wave <= (per_wave + 7) / 8 * 8 - per_wave)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 12, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 2>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
     else
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 8, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
     return subgc::check_launch("subgc_lstm_step_skinny");
 }
