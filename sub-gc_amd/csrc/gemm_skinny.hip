@@ -265,10 +265,12 @@ int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, flo
 #define SUBGC_SKINNY_MT(MT_, D_)                                                                                                            \
     hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, D_, false, MT_>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, \
                        LstmEpi{}, add, ldadd)
+        // 3..5 tiles = the one-image encoder GEMMs (37 / 65 rows, N = 512..1024: 32-64 workgroups, at most one per CU): there
+        // occupancy cannot hide the latency and the deeper (guarded) ring does
         if (mt == 2) SUBGC_SKINNY_MT(2, 2);
-        else if (mt == 3) SUBGC_SKINNY_MT(3, 2);
-        else if (mt == 4) SUBGC_SKINNY_MT(4, 2);
-        else SUBGC_SKINNY_MT(5, 2);
+        else if (mt == 3) SUBGC_SKINNY_MT(3, 4);
+        else if (mt == 4) SUBGC_SKINNY_MT(4, 4);
+        else SUBGC_SKINNY_MT(5, 4);
 #undef SUBGC_SKINNY_MT
         return subgc::check_launch("subgc_gemm_f32(skinny)");
     }
