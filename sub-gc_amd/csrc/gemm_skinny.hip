@@ -83,7 +83,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_nt_kernel(const float*
 //   * lane l loads ONE float4 of W (row l%16, k = step*16 + (l/16)*4 .. +3) and ONE float4 of the activations (row l%16 = m,
 //     same k) per step; component j of both feeds the j-th of four MFMAs (the k-slot <-> address map only has to agree
 //     between the two operands).  The activations come straight from L2 (<= 192 KB, read by every workgroup);
-//   * loads run D steps ahead in a register ring, unconditional and clamped, so the compiler's vmcnt waits stay partial;
+//   * loads run D steps ahead in a register ring with clamped (never predicated) addresses, so the compiler's vmcnt waits stay
+//     partial; the refill is guarded by the wave-uniform step count.  D = 2 where the launch fills the chip (eight waves per
+//     SIMD hide the latency; deeper rings measured slower, see the dispatch), D = 4 for the 32-64 workgroup encoder shapes;
 //   * the WAVES partial 16x16 tiles are summed through 8 KB of LDS in a fixed order (deterministic), + bias, ReLU.
 // 37.5 % of the matrix pipe's columns are padding at M = 10 -- irrelevant: the pipe needs 2 us of the ~10 us the stream takes.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +95,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // runs in the epilogue of the same launch -- c = f*c_prev + i*g, h = o*tanh(c), h stored to up to three places -- so a
 // decode step needs no separate pointwise kernel and the [S, 4R] pre-activations never reach memory.  The additive gate
 // terms (a per-token table row or a plain [S,4R] array, a second [S,4R] array, two bias vectors) and c_prev are fetched
-// by wave 0 BEFORE the K loop, so their latency hides behind the weight stream.
+// by wave mt (< MT) BEFORE the K loop, so their latency hides behind the weight stream.
 struct LstmEpi {
     const float* add1; int64_t ld1; const int64_t* tok; int tok_rows;       // add1 row = tok ? clamp(tok[m]) : m
     const float* add2; int64_t ld2;
