@@ -108,3 +108,23 @@ def test_sct_mode_with_beam2_as_in_test_sh(golden):
     for db, hb in zip(m.done_beams, host[2]):
         for d, h in zip(db, hb):
             assert torch.equal(d["seq"], h["seq"]) and d["p"] == h["p"]
+
+
+def test_gather_rows_multi_is_four_gathers():
+    from subgc import ops
+    g = torch.Generator().manual_seed(5)
+    S = 30
+    src = [torch.randn(S, c, generator=g).to(DEV) for c in (2000, 3000, 1000, 1000)]
+    views = [src[0], src[1][:, 2000:], src[2], src[3]]                            # one operand is a column slice, like the lang-LSTM slot
+    rows = torch.randint(0, S, (S,), generator=g).to(torch.int32).to(DEV)
+    rows[3] = -1                                                                  # negative row -> zeros, like subgc_gather_rows
+    dst = [torch.full_like(v, 3.0) for v in views]
+    dstv = [dst[0], dst[1], dst[2], dst[3]]
+    ops.gather_rows_multi(list(zip(views, dstv)), rows)
+    for v, d in zip(views, dstv):
+        want = v[rows.long().clamp_min(0)].clone()
+        want[3] = 0
+        assert torch.equal(d, want)
+    one = torch.empty_like(views[2])
+    ops.gather_rows_multi([(views[2], one)], rows)
+    assert torch.equal(one, dstv[2])
