@@ -316,13 +316,12 @@ class DecoderFn(Function):
                     ops.multinomial_rows_(logits3[:, t - 1, :], ss[2][t], ss[1][t], ss[0], tokens[:, t])
                 ops.embed_fwd(emb, tokens[:, t], tokens.stride(0), None if k_xt is None else k_xt[t], scale, xt[t])
                 ops.gemm(xt[t], w1i[:, 2 * R:], Gx3[t], tb=True)
-            ops.gemm(H1[t], Wc1, pre, tb=True)
-            ops.lstm_fwd(pre, Gx3[t], Gf, b1i, b1h, C1[t], C1[t + 1], H2[t][:, R:2 * R], H1[t + 1][:, R:], None, 1.0, None, G1[t], S, R)
+            ops.lstm_fwd_gemm(H1[t], Wc1, pre, Gx3[t], Gf, b1i, b1h, C1[t], C1[t + 1], H2[t][:, R:2 * R], H1[t + 1][:, R:], None, 1.0, None,
+                              G1[t], S, R)
             ops.gemm(H2[t][:, R:2 * R], h2a_w, AH[t], tb=True, bias=h2a_b)
             ops.attn_fwd(pr.u, pr.v, AH[t], an_w, an_b, pr.off, lens, H2[t][:, :R], AL[t], S, A, R)
-            ops.gemm(H2[t], Wc2, pre, tb=True)
-            ops.lstm_fwd(pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
-                         None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
+            ops.lstm_fwd_gemm(H2[t], Wc2, pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
+                              None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
         if ss is None:
             ops.gemm(Hout.view(S * T, R), lg_w, logits, tb=True, bias=lg_b)
         else:
