@@ -202,3 +202,17 @@ def test_one_image_graph_path_over_varied_candidate_and_survivor_counts(golden):
                         for d, h in zip(db, eb):
                             assert torch.equal(d["seq"], h["seq"]) and abs(d["p"] - h["p"]) < 1e-3
     assert len(seen_n) >= 3 and not me.__dict__.get("_graph_cache") and mg.__dict__.get("_graph_cache")
+
+
+def test_empty_batches_are_no_ops():
+    """S = 0 / n = 0 / M = 0 (an image without surviving sub-graphs): every new entry point returns without launching."""
+    R, K = 48, 96
+    e = lambda *s, dt=torch.float32: torch.empty(*s, device=DEV, dtype=dt)
+    ops.lstm_step_skinny(e(0, K), e(4 * R, K), None, e(0, R), [e(0, R)])
+    ops.lstm_fwd_gemm(e(0, K), e(4 * R, K), e(0, 4 * R), None, None, None, None, None, e(0, R), e(0, R), None, None, 1.0, None, None, 0, R)
+    ops.gather_rows_multi([(e(5, 8), e(0, 8))], e(0, dt=torch.int32))
+    assert ops.token_rows(e(7, 16), e(0, dt=torch.long), e(0, 16)).shape == (0, 16)
+    from subgc import beam
+    tb = beam.DeviceTables(0, 1, 20, 2, DEV)
+    ops.beam_step(e(0, 4), e(0, 4, dt=torch.int32), tb, e(0, dt=torch.long), e(0, dt=torch.int32), 0, 20, 1, 2, 4, 50, 0, 0.5)
+    torch.cuda.synchronize()
