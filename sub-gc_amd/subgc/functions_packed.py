@@ -192,10 +192,12 @@ class PackedDecoderLossFn(Function):
         dWa, dBa = new(max(rows, 1), A), new(max(rows, 1))     # per-(step, sentence) partials of alpha_net's gradient
         # rows that are dead at step t+1 but live at step t enter the recurrence with zero state-gradient:
         # both ping-pong buffers start zeroed and a row >= M[t+1] is never written before step t reads it
-        dH1 = [zer(S, 2 * R), zer(S, 2 * R)]
-        dH2 = [zer(S, 3 * R), zer(S, 3 * R)]
-        dC1 = [zer(S, R), zer(S, R)]
-        dC2 = [zer(S, R), zer(S, R)]
+        arena = zer(2 * S * 7 * R)                             # the eight ping-pong buffers below: one fill instead of eight
+        cut, pos = [], 0
+        for width in (2 * R, 2 * R, 3 * R, 3 * R, R, R, R, R):
+            cut.append(arena[pos:pos + S * width].view(S, width))
+            pos += S * width
+        dH1, dH2, dC1, dC2 = cut[0:2], cut[2:4], cut[4:6], cut[6:8]
         for t in range(T_live - 1, -1, -1):
             m, o = M[t], ot[t]
             nH1, cH1 = dH1; nH2, cH2 = dH2; nC1, cC1 = dC1; nC2, cC2 = dC2
