@@ -199,9 +199,9 @@ def main():
         out = lw(*lw_args(batch))
         loss = out["lang_loss"] + out["gpn_loss"]
         loss.backward()
-        red.finish()
+        red.finish(average=adam is None)                 # with the optimizer on, 1/world rides in its sweep
         if adam is not None:
-            adam.step()
+            adam.step(grad_scale=1.0 / world)
         return loss
 
     def timed_sampled(n_steps):

@@ -406,11 +406,13 @@ int subgc_scatter_add_rows(const float* src, int64_t lds, const int32_t* rows, f
 
 /* fused global-norm clip + Adam over one flat fp32 bucket (misc/utils.py:174-200,234-235):
  * pass 1 accumulates sum(g^2) into *sumsq (caller zeroes it), pass 2 applies
- * g *= max_norm / max(sqrt(sumsq), max_norm) (utils.py:193) and the torch.optim.Adam update. */
+ * g *= max_norm / max(sqrt(sumsq), max_norm) (utils.py:193) and the torch.optim.Adam update.  grad_scale (1 for one GPU,
+ * 1/world after a SUM all-reduce: DataParallel's mean of the replica losses, train.py:154-156) multiplies g first -- norm and
+ * update see the averaged gradient without a separate pass over the bucket; g is left scaled and clipped.            */
 int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* stream);
 int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         int step, void* stream);
+                         int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -632,9 +632,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, const float* __restrict__ sumsq,
                                                         float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                        float bc2) {
-    // misc/utils.py:193: coef = clip / max(total_norm, clip)
-    const float coef = max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]), max_norm) : 1.f;
+                                                        float bc2, float gscale) {
+    // misc/utils.py:193: coef = clip / max(total_norm, clip); gscale (1/world after a SUM all-reduce) is applied first
+    const float coef = gscale * (max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]) * gscale, max_norm) : 1.f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gi = g[i] * coef;
         g[i] = gi;
@@ -661,8 +661,8 @@ __global__ __launch_bounds__(256) void sumsq_vec_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void clip_adam_vec_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                             float4* __restrict__ v, int64_t n4, const float* __restrict__ sumsq,
                                                             float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                            float bc2) {
-    const float coef = max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]), max_norm) : 1.f;
+                                                            float bc2, float gscale) {
+    const float coef = gscale * (max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]) * gscale, max_norm) : 1.f);
     const float rs2 = sqrtf(bc2), step = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 P = p[i], G = g[i], M = m[i], V = v[i];
@@ -978,8 +978,8 @@ SUBGC_API int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* str
     return subgc::check_launch("subgc_sumsq_f32");
 }
 SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
-    SUBGC_REQUIRE(n >= 0 && step >= 1, "clip_adam_step: bad arguments");
+                                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    SUBGC_REQUIRE(n >= 0 && step >= 1 && grad_scale > 0.f, "clip_adam_step: bad arguments");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(p && g && m && v && sumsq, "clip_adam_step: null pointer");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
@@ -987,11 +987,11 @@ SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64
     if (n % 4 == 0 && al(p) && al(g) && al(m) && al(v)) {
         hipLaunchKernelGGL(clip_adam_vec_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(p),
                            reinterpret_cast<float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n / 4, sumsq, max_norm, lr,
-                           beta1, beta2, eps, weight_decay, bc1, bc2);
+                           beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
         return subgc::check_launch("subgc_clip_adam_step");
     }
     hipLaunchKernelGGL(clip_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2);
+                       beta2, eps, weight_decay, bc1, bc2, grad_scale);
     return subgc::check_launch("subgc_clip_adam_step");
 }
 

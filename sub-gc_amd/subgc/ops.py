@@ -488,6 +488,6 @@ def sumsq(g, out):
     return out
 
 
-def clip_adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step):
+def clip_adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     call("subgc_clip_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(max_norm), float(lr),
-         float(beta1), float(beta2), float(eps), float(wd), int(step), _stream())
+         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), _stream())

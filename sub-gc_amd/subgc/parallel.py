@@ -100,8 +100,9 @@ class GradBucketReducer:
         self._decoder_launched = False
         return self.model.flatten_grads()
 
-    def finish(self):
-        """Call after loss.backward(): completes the reduction and averages."""
+    def finish(self, average=True):
+        """Call after loss.backward(): completes the reduction and averages (`average=False`: leave the SUM and hand
+        `1 / world` to `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep)."""
         if self.world == 1:
             return self.model.flat_grads
         g = self.model.flat_grads
@@ -113,7 +114,8 @@ class GradBucketReducer:
         for w in self._pending:
             w.wait()
         self._pending = []
-        g.mul_(1.0 / self.world)
+        if average:
+            g.mul_(1.0 / self.world)
         return g
 
     def close(self):
@@ -136,10 +138,10 @@ class FlatAdam:
         self.sumsq = torch.zeros(1, device=model.flat_params.device)
         self.t = 0
 
-    def step(self):
+    def step(self, grad_scale=1.0):
         from . import ops
         self.t += 1
         ops.fill_(self.sumsq, 0.0)
         ops.sumsq(self.model.flat_grads, self.sumsq)
         ops.clip_adam_step(self.model.flat_params, self.model.flat_grads, self.m, self.v, self.sumsq, self.clip, self.lr,
-                           self.betas[0], self.betas[1], self.eps, self.wd, self.t)
+                           self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)

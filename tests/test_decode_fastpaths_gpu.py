@@ -216,3 +216,20 @@ def test_empty_batches_are_no_ops():
     tb = beam.DeviceTables(0, 1, 20, 2, DEV)
     ops.beam_step(e(0, 4), e(0, 4, dt=torch.int32), tb, e(0, dt=torch.long), e(0, dt=torch.int32), 0, 20, 1, 2, 4, 50, 0, 0.5)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n", [10007, 40000])                                    # scalar and float4 forms
+def test_clip_adam_grad_scale_equals_scaling_first(n):
+    """grad_scale = 1/world inside the fused sweep == averaging the summed gradient in a separate pass, then the plain step."""
+    g = torch.Generator().manual_seed(n)
+    p0, g0 = torch.randn(n, generator=g).to(DEV), (torch.randn(n, generator=g) * 9.0).to(DEV)
+    outs = []
+    for folded in (True, False):
+        p, gr, m, v, ss = p0.clone(), g0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(1, device=DEV)
+        if not folded:
+            gr.mul_(0.25)
+        ops.sumsq(gr, ss)
+        ops.clip_adam_step(p, gr, m, v, ss, 10.0, 5e-4, 0.9, 0.999, 1e-8, 0.01, 3, 0.25 if folded else 1.0)
+        outs.append((p, gr, m, v))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, atol=1e-6, rtol=1e-5)
