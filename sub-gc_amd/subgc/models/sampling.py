@@ -130,6 +130,8 @@ class _FrontBuffers:
     preparation (`F_.Prepared`) run inside the graph instead of as ~25 eager launches with the GPU idling between them."""
 
     def __init__(self, m, G, N):
+        """G: CAPACITY in candidate sub-graphs (a power of two): images with any smaller candidate count use the same buffers,
+        hence the same captured graphs -- the count varies from image to image on real data."""
         dev, L = m.flat_params.device, m.GCN_dim
         self.G, self.N = G, N
         self.X2, self.read_out = torch.empty(N, L, device=dev), torch.empty(G, 2 * L, device=dev)
@@ -137,8 +139,9 @@ class _FrontBuffers:
         self.idx, self.score = torch.zeros(G, N, device=dev, dtype=torch.long), torch.empty(G, device=dev)
 
     def load(self, X2, fr):
-        self.X2.copy_(X2); self.read_out.copy_(fr.read_out); self.keep.copy_(fr.keep_all[:self.G])
-        self.lens.copy_(fr.lens_i); self.idx.copy_(fr.idx); self.score.copy_(fr.score)
+        g = fr.G                                                                  # <= capacity; rows past g are never indexed (keep < g)
+        self.X2.copy_(X2); self.read_out[:g].copy_(fr.read_out); self.keep[:g].copy_(fr.keep_all[:g])
+        self.lens[:g].copy_(fr.lens_i); self.idx[:g].copy_(fr.idx); self.score[:g].copy_(fr.score)
 
     def prepared(self, m, n, P):
         """(inside the capture) the first n NMS survivors -> F_.Prepared, their scores and indices."""
@@ -153,6 +156,7 @@ class _FrontBuffers:
 
 def _front_buffers(m, G, N):
     cache = m.__dict__.setdefault("_front_cache", {})
+    G = max(128, 1 << (int(G) - 1).bit_length())                                  # capacity classes: 128, 256, 512, ...
     key = (G, N, m.flat_params.data_ptr())
     if key not in cache:
         if len(cache) >= 8:

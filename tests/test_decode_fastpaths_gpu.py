@@ -202,6 +202,8 @@ def test_one_image_graph_path_over_varied_candidate_and_survivor_counts(golden):
                         for d, h in zip(db, eb):
                             assert torch.equal(d["seq"], h["seq"]) and abs(d["p"] - h["p"]) < 1e-3
     assert len(seen_n) >= 3 and not me.__dict__.get("_graph_cache") and mg.__dict__.get("_graph_cache")
+    # candidate counts 2..40 share ONE capacity class of static buffers, so graphs are keyed by survivors and mode only
+    assert len(mg._front_cache) == 1 and len(mg._graph_cache) <= 2 * len(seen_n)
 
 
 def test_empty_batches_are_no_ops():
