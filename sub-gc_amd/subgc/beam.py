@@ -87,14 +87,14 @@ def _beam_step(grp, vals, idx, tau, bd, unk, constraint, earlier, lam):
 class _BatchEngine:
     """All sub-graphs x beams of an image batch as rows of one DecodeState (the product path)."""
 
-    def __init__(self, pr, P, N, beam, xt_table=None):
+    def __init__(self, pr, P, N, beam, xt_table=None, snapshots=None):
         n, dev = pr.S, pr.f.device
         self.n, self.rows, self.dev = n, n * beam, dev
         rep = torch.arange(n, device=dev).repeat_interleave(beam)
         prb = SimpleNamespace(S=self.rows, N=N, f=pr.f.index_select(0, rep).contiguous(), u=pr.u, v=pr.v,
                               off=pr.off.index_select(0, rep).contiguous(), lens=pr.lens.index_select(0, rep).contiguous())
         self.pr, self.prb, self.rep = pr, prb, rep
-        self.st = F_.DecodeState(prb, P, N, False, xt_table=xt_table, fuse_lstm=True)    # takes effect for <= 32 rows
+        self.st = F_.DecodeState(prb, P, N, False, xt_table=xt_table, fuse_lstm=True, snapshots=snapshots)    # fused for <= 32 rows
         self.V1 = self.st.V1
 
     def refresh(self):

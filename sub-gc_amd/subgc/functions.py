@@ -477,13 +477,15 @@ class DecoderFn(Function):
 class DecodeState:
     """Step-wise decoder for sampling (AttModel._sample loop body): same kernels, batch n."""
 
-    def __init__(self, pr: Prepared, P, N, want_att, xt_table=None, fuse_lstm=False):
+    def __init__(self, pr: Prepared, P, N, want_att, xt_table=None, fuse_lstm=False, snapshots=None):
         """`xt_table` [V+1, 4R] (optional, frozen weights only): relu(Emb) . W_ih[:, 2R:]^T, one row per token -- the x->gates
         product of the attention LSTM looked up instead of recomputed every step (AttModel.xt_gates_table).
         `fuse_lstm` (<= 32 rows, R % 4 == 0): each LSTM cell is ONE launch, gate GEMM + cell update (subgc_lstm_step_skinny) on
         row-permuted weight snapshots; h is written into the OTHER buffer of an [H1, H1n] / [H2, H2n] pair, because the
         launch that produces it is still reading the current one.  Beam search forks the state through `reorder`, which
-        gathers into a third buffer and so composes with the pairs; not for callers that write H1/H2 themselves (step API)."""
+        gathers into a third buffer and so composes with the pairs; not for callers that write H1/H2 themselves (step API).
+        `snapshots`: a dict shared by every state built on the same weights (AttModel.decode_snapshots): the K-concatenated
+        (and, fused, row-permuted) LSTM matrices are built once per set of weights, not once per state / captured graph."""
         self.xt_table = xt_table
         self.fused = bool(fuse_lstm) and pr.S <= 32 and P[10].size(1) % 4 == 0
         (_, _, _, _, _, _, _, _, self.emb, w1i, w1h, self.b1i, self.b1h, w2i, w2h, self.b2i, self.b2h,
@@ -493,11 +495,18 @@ class DecodeState:
         S = pr.S
         R, E = w1h.size(1), self.emb.size(1)
         self.S, self.R, self.E, self.A, self.V1 = S, R, E, self.h2a_w.size(0), self.lg_w.size(0)
-        self.Wc1 = _cat_weights(w1i[:, :R], w1h)
-        self.Wc2 = _cat_weights(w2i, w2h)
+        key = "perm" if self.fused else "cat"
+        if snapshots is not None and key in snapshots:
+            self.Wc1, self.Wc2 = snapshots[key]
+        else:
+            self.Wc1 = _cat_weights(w1i[:, :R], w1h)
+            self.Wc2 = _cat_weights(w2i, w2h)
+            if self.fused:
+                perm = ops.lstm_gate_perm(R, dev)
+                self.Wc1, self.Wc2 = self.Wc1[perm].contiguous(), self.Wc2[perm].contiguous()    # only the permuted snapshots are kept
+            if snapshots is not None:
+                snapshots[key] = (self.Wc1, self.Wc2)
         if self.fused:
-            perm = ops.lstm_gate_perm(R, dev)
-            self.Wc1, self.Wc2 = self.Wc1[perm].contiguous(), self.Wc2[perm].contiguous()    # only the permuted snapshots are kept
             self.H1n, self.H2n = ops.zeros(S, 2 * R, device=dev), ops.zeros(S, 3 * R, device=dev)
         self.W1x = w1i[:, 2 * R:]
         self.W1f = w1i[:, R:2 * R]

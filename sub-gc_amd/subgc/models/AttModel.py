@@ -375,6 +375,15 @@ class AttModel(CaptionModel):
         fp = self.flat_params
         return (fp.data_ptr(), fp._version, self.__dict__.get("_cache_epoch", 0)) + tuple(p._version for p in self._decoder_params())
 
+    def decode_snapshots(self):
+        """The dict of weight snapshots shared by every decode state built on the current weights (functions.DecodeState)."""
+        key = self.weights_version()
+        hit = self.__dict__.get("_decode_snapshots")
+        if hit is None or hit[0] != key:
+            hit = (key, {})
+            self.__dict__["_decode_snapshots"] = hit
+        return hit[1]
+
     def invalidate_decode_caches(self):
         self.__dict__["_cache_epoch"] = self.__dict__.get("_cache_epoch", 0) + 1
 

@@ -192,7 +192,7 @@ class _GraphedLoop:
         cap = n * N
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
-        self.st = F_.DecodeState(self.pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True)
+        self.st = F_.DecodeState(self.pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots())
         self.seq, self.seqlp = z(n, T, dt=torch.long), z(n, T)
         self.it, self.unfinished, self.counts = z(n, dt=torch.long), z(n, dt=torch.int32), z(T, dt=torch.int32)
         self.AL = z(T + 1, n, N) if return_att else None
@@ -243,7 +243,7 @@ class _GraphedBeam:
         cap = n * N
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
-        self.eng = beam._BatchEngine(self.pr, P, N, int(opt.get("beam_size", 10)), m.xt_gates_table())
+        self.eng = beam._BatchEngine(self.pr, P, N, int(opt.get("beam_size", 10)), m.xt_gates_table(), m.decode_snapshots())
         self.ds = beam.DeviceSearch(self.eng, T, opt)
         self._loop()                                                             # eager warm-up
         torch.cuda.synchronize()
@@ -273,7 +273,7 @@ def _graphed_beam(m, n, N, P, opt, fb=None):
     if key not in cache:
         for old in [q for q in cache if q[:5] == key[:5]]:
             del cache[old]
-        if len(cache) >= 24:
+        if len(cache) >= 64:                                                      # states share their weight snapshots: a graph is a few MB
             cache.clear()
         cache[key] = _GraphedBeam(m, n, N, P, opt, fb)
     return cache[key]
@@ -285,7 +285,7 @@ def _graphed_loop(m, n, N, k, return_att, P, fb=None):
     if key not in cache:
         for old in [q for q in cache if q[:5] == key[:5]]:                       # parameters changed: drop the stale snapshot
             del cache[old]
-        if len(cache) >= 24:
+        if len(cache) >= 64:                                                      # states share their weight snapshots: a graph is a few MB
             cache.clear()
         cache[key] = _GraphedLoop(m, n, N, k, return_att, P, fb)
     return cache[key]
@@ -385,7 +385,7 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     if graphed is not None:
         seq, seqlp, counts, AL = graphed.run(pr, uniforms)
     else:
-        st = F_.DecodeState(pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True)
+        st = F_.DecodeState(pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots())
         seq = torch.zeros(n, T, device=dev, dtype=torch.long)
         seqlp = torch.zeros(n, T, device=dev)
         it = torch.zeros(n, device=dev, dtype=torch.long)
