@@ -67,6 +67,9 @@ def caption_images(model, images, infos, ix_to_word, eval_kwargs=None, group=256
     was_training = model.training
     model.eval()
     predictions = []
+    # a decode batch holds up to group x gpn_max_subg sub-graph rows (x beam): keep it near 8 k rows -- 256 images at the
+    # Karpathy setting (10 sub-graphs), 8 at the MRNN setting (up to 1000), where one image already fills the chip
+    group = max(1, min(group, 8192 // max(1, int(getattr(model, "gpn_max_subg", 1)) * max(1, int(eval_kwargs.get("beam_size", 1))))))
     try:
         for i in range(0, len(images), group):
             results = model.sample_images(images[i:i + group], opt=eval_kwargs)
