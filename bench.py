@@ -132,14 +132,15 @@ def decode_bench(model_sd, dev, images, M):
         m(*synthetic.sample_args(b), opt=bopt, mode="sample")
     torch.cuda.synchronize()
     tb1 = time.perf_counter()
-    m.sample_images(batches[:nb], opt=bopt)
+    nbb = min(images, 256)
+    m.sample_images(batches[:nbb], opt=bopt)
     torch.cuda.synchronize()
     tb2 = time.perf_counter()
-    m.sample_images(batches[:nb], opt=bopt)
+    m.sample_images(batches[:nbb], opt=bopt)
     torch.cuda.synchronize()
     tb3 = time.perf_counter()
-    out.update({"decode_beam2_ms_per_image": round(1e3 * (tb1 - tb0) / nb, 3), "decode_beam2_batched_ms_per_image": round(1e3 * (tb3 - tb2) / nb, 3),
-                "decode_beam2_config": f"beam_size 2 (test.sh Sub_GC_Kar), candidate bookkeeping on the device; batched = {nb} images per search"})
+    out.update({"decode_beam2_ms_per_image": round(1e3 * (tb1 - tb0) / nb, 3), "decode_beam2_batched_ms_per_image": round(1e3 * (tb3 - tb2) / nbb, 3),
+                "decode_beam2_config": f"beam_size 2 (test.sh Sub_GC_Kar), candidate bookkeeping on the device; batched = {nbb} images per search"})
     out.update({"decode_batched_tokens_per_s": round(tokens / dt, 1), "decode_batched_ms_per_image": round(1e3 * dt / (2 * images), 3),
                 "decode_batched_config": f"sample_images: {group} images per decode batch (<= {10 * group} sub-graph rows per step)"})
     return out
