@@ -156,7 +156,6 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ sco
                                                    int32_t* __restrict__ order, int32_t* __restrict__ flag,
                                                    const int32_t* __restrict__ offsets) {
     extern __shared__ unsigned char removed[];   // [M]
-    __shared__ int kept_s;
     const int t = threadIdx.x, nt = blockDim.x;
     if (offsets) {                               // batched form: workgroup b owns candidates offsets[b] .. offsets[b+1] of image b
         const int g0 = offsets[blockIdx.x];
@@ -183,12 +182,13 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ sco
         flag[m] = 0;
         removed[m] = 0;
     }
-    if (t == 0) kept_s = 0;
     __syncthreads();
+    int kept = 0;                                // every thread counts the kept candidates itself: the value is uniform
     for (int i = 0; i < M; ++i) {
         if (removed[i]) continue;                // uniform: last writer of removed[] was followed by a barrier
         const int cur = order[i];
-        if (t == 0) { flag[cur] = 1; kept_s += 1; }
+        if (t == 0) flag[cur] = 1;
+        ++kept;
         uint64_t a[W];
         for (int w = 0; w < W; ++w) a[w] = masks[(int64_t)cur * W + w];
         for (int j = i + 1 + t; j < M; j += nt) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ sco
             if (iou_gt(a, masks + (int64_t)order[j] * W, thres)) removed[j] = 1;
         }
         __syncthreads();
-        if (kept_s >= max_keep) break;           // later survivors cannot enter the first max_keep
+        if (kept >= max_keep) break;             // later survivors cannot enter the first max_keep
     }
     __syncthreads();
     if (t == 0) {

@@ -244,6 +244,12 @@ class AttModel(CaptionModel):
         return stepapi.beam_search(self, init_state, init_logprobs, *args, **kwargs)
 
     # ------------------------------------------------------------------ dropout masks
+    def _rng_seed(self):
+        """Philox key of this forward: opt.seed, the call counter and the data-parallel RANK (one process per GPU: without
+        the rank every replica would draw the same masks / sampling uniforms for its different shard)."""
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        return ((self.dropout_seed * 1000003 + self._dropout_calls) ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
     def _masks(self, shapes, device):
         """keep-masks for one training forward: injected (tests) or Philox-generated on device."""
         if not self.training:
@@ -252,7 +258,7 @@ class AttModel(CaptionModel):
             return self.injected_masks
         out, off = {}, 0
         self._dropout_calls += 1
-        seed = (self.dropout_seed * 1000003 + self._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        seed = self._rng_seed()
         for k, (shape, p) in shapes.items():
             if p > 0:
                 out[k] = ops.dropout_mask(shape, p, seed, off, device)
@@ -294,6 +300,12 @@ class AttModel(CaptionModel):
         ops.ensure_workspace(att_feats.device)          # scratch for the split-K form of the M=5B recurrent GEMMs
         needX, needP, live_nodes, live_edges = self._gcn_liveness()
         att2 = att_feats.reshape(B * N, D)
+        # the reference's `.view(-1, sg_obj_cnt)` (AttModel.py:374,381) fails loudly on a width mismatch; here the class ids index
+        # the embedding tables on the device, so a wider distribution than the table would read / scatter out of bounds
+        if self.noun_fuse and obj_dist.size(-1) != self.sg_obj_cnt:
+            raise ValueError(f"obj_dist has {obj_dist.size(-1)} classes, sg_obj_embed has {self.sg_obj_cnt} rows")
+        if pred_dist is not None and pred_dist.size(-1) != self.sg_pred_cnt:
+            raise ValueError(f"pred_dist has {pred_dist.size(-1)} classes, sg_pred_embed has {self.sg_pred_cnt} rows")
         if self.noun_fuse:
             cls = ops.row_argmax(obj_dist.reshape(B * N, -1), skip=1).to(torch.int32)
             emb = F_.GatherRowsFn.apply(self.P("sg_obj_embed.weight"), cls)
@@ -367,11 +379,12 @@ class AttModel(CaptionModel):
         return [self.P(n) for n in F_.PARAM_ORDER]
 
     def weights_version(self):
-        """Changes whenever the decoder weights may have: the flat buffer's address and in-place version (fused optimizer
-        step, all-reduce) plus every decoder Parameter's own version counter (load_state_dict's `param.copy_`, torch.optim's
-        in-place updates -- a Parameter whose `.data` is a view keeps a counter of its own).  Keys the decode-time snapshots
-        (K-concatenated LSTM weights, hipGraphs, the x->gates table).  Writes through `p.data.<op>_()` bump neither counter:
-        call `model.invalidate_decode_caches()` after those."""
+        """Changes whenever the decoder weights may have: the flat buffer's address and in-place version (torch ops on it)
+        plus every decoder Parameter's own version counter (load_state_dict's `param.copy_`, torch.optim's in-place updates --
+        a Parameter whose `.data` is a view keeps a counter of its own) plus an explicit epoch.  Keys the decode-time snapshots
+        (K-concatenated LSTM weights, hipGraphs, the x->gates table).  Writes that torch cannot see bump no counter: the fused
+        optimizer step (`parallel.FlatAdam.step`, raw device pointers through the C ABI) therefore calls
+        `model.invalidate_decode_caches()` itself, and so must any other raw-pointer or `p.data.<op>_()` write."""
         fp = self.flat_params
         return (fp.data_ptr(), fp._version, self.__dict__.get("_cache_epoch", 0)) + tuple(p._version for p in self._decoder_params())
 
@@ -443,7 +456,7 @@ class AttModel(CaptionModel):
                 sel_u, u = self.injected_ss
             else:
                 self._dropout_calls += 1
-                seed = (self.dropout_seed * 1000003 + self._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+                seed = self._rng_seed()
                 both = ops.uniform((2, T, b5), seed ^ 0x5C4ED51ED5A3B11F, 0, dev)
                 sel_u, u = both[0], both[1]
             meta["ss"] = (float(self.ss_prob), sel_u.contiguous(), u.contiguous())

@@ -60,11 +60,14 @@ def shard_batch(batch, rank, world, sentences_per_image=5):
 class GradBucketReducer:
     """All-reduce `model.flat_grads` (decoder slice early, encoder slice at the end)."""
 
-    def __init__(self, model, group=None, overlap=True):
+    def __init__(self, model, group=None, overlap=True, always_reduce=False):
+        """`always_reduce`: issue the collectives even in a one-rank group (a one-GPU box can then exercise RCCL itself and
+        the stream ordering between the backward kernels and the all-reduce; the sum over one rank is the identity)."""
         self.model, self.group = model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (always_reduce and dist.is_initialized())
         self.split = model.decoder_offset
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self.active
         self._pending = []
         self._fired = 0
         self._decoder_launched = False
@@ -87,7 +90,7 @@ class GradBucketReducer:
         """The decoder slice of the bucket is final: start its all-reduce now (once per step).  Called by
         DecoderFn.backward (which writes its gradients straight into the bucket) or, on the generic
         autograd path, by the post-accumulate-grad hooks."""
-        if self._decoder_launched or self.world == 1 or self.model.flat_grads is None:
+        if self._decoder_launched or not self.active or self.model.flat_grads is None:
             return
         self._decoder_launched = True
         g = self.model.flat_grads[self.split:]
@@ -103,7 +106,7 @@ class GradBucketReducer:
     def finish(self, average=True):
         """Call after loss.backward(): completes the reduction and averages (`average=False`: leave the SUM and hand
         `1 / world` to `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep)."""
-        if self.world == 1:
+        if not self.active:
             return self.model.flat_grads
         g = self.model.flat_grads
         if self._pending:
@@ -114,7 +117,7 @@ class GradBucketReducer:
         for w in self._pending:
             w.wait()
         self._pending = []
-        if average:
+        if average and self.world > 1:
             g.mul_(1.0 / self.world)
         return g
 
@@ -145,3 +148,6 @@ class FlatAdam:
         ops.sumsq(self.model.flat_grads, self.sumsq)
         ops.clip_adam_step(self.model.flat_params, self.model.flat_grads, self.m, self.v, self.sumsq, self.clip, self.lr,
                            self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        # the kernel wrote the weights through raw pointers: no torch version counter moved, so the decode-time snapshots
+        # (x->gates table, K-concatenated LSTM matrices, captured hipGraphs) must be told explicitly
+        self.model.invalidate_decode_caches()

@@ -235,3 +235,26 @@ def test_clip_adam_grad_scale_equals_scaling_first(n):
         outs.append((p, gr, m, v))
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("opt_over", [dict(sample_max=1, beam_size=1), dict(sample_max=1, beam_size=2)])
+def test_decode_after_the_fused_optimizer_step_uses_the_new_weights(golden, opt_over):
+    """train -> eval -> train -> eval: `parallel.FlatAdam.step` writes the weights through raw device pointers (no torch
+    version counter moves), so it has to retire the decode-time snapshots itself (x->gates table, K-concatenated LSTM
+    matrices, captured hipGraphs); a second decode must equal a freshly built model holding the updated weights."""
+    from subgc import parallel
+    g = golden("subgc_greedy")
+    m = build(g, golden("subgc_train").group("weights"), False)
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    opt = dict(g.meta["sample_opt"], **opt_over)
+    first = m(*synthetic.sample_args(b), opt=opt, mode="sample")
+    adam = parallel.FlatAdam(m, lr=5e-2)                                            # a large step so that every caption changes
+    grads = m.flatten_grads()
+    grads.copy_(torch.randn(grads.numel(), generator=torch.Generator().manual_seed(5)).to(DEV))
+    adam.step()
+    again = m(*synthetic.sample_args(b), opt=opt, mode="sample")
+    w2 = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    fresh = build(g, w2, False)(*synthetic.sample_args(b), opt=opt, mode="sample")
+    assert torch.equal(again[0], fresh[0])
+    torch.testing.assert_close(again[1], fresh[1], atol=1e-5, rtol=1e-5)
+    assert not torch.allclose(first[1], again[1])

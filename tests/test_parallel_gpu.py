@@ -100,3 +100,56 @@ def test_two_ranks_one_gpu_bucket_reduction_matches_mean_of_shards():
         assert early, "decoder slice must be in flight before the encoder backward ends"
         np.testing.assert_allclose(flat, want, atol=3e-5 * scale + 1e-8, rtol=1e-4)
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def _nccl_worker(port, q):
+    """world size 1, backend nccl (= RCCL on ROCm): the REAL Sub_GC_Kar model (280 MB flat bucket), real fwd+bwd, the decoder
+    slice all-reduced from DecoderFn.backward's callback while the encoder backward still runs, the encoder slice at the end."""
+    _setup_paths()
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import argparse
+    import torch.distributed as dist
+    from subgc import parallel, synthetic
+    import subgc.models as models
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    kar = dict(OPT, vocab_size=9487, input_encoding_size=1000, rnn_size=1000, fc_feat_size=2048, att_feat_size=2048, att_hid_size=512,
+               embed_dim=300, gcn_dim=1024, sg_obj_cnt=1599, drop_prob_lm=0.5, gpn_drop_prob=0.5)
+    torch.manual_seed(3)
+    m = models.setup(argparse.Namespace(**kar)).to("cuda:0").train()
+    batch = synthetic.make_train_batch(8, seed=11)
+    m.injected_masks = None
+    m._dropout_calls = 0
+    plain, _ = _shard_step(m, models, batch)                        # no reducer: the reference gradients (same dropout stream below)
+    m._dropout_calls = 0
+    red = parallel.GradBucketReducer(m, always_reduce=True)
+    assert red.active and red.overlap
+    flat, early = _shard_step(m, models, batch, red)
+    # a second step through the same reducer, then the fused optimizer sweep on the reduced bucket (stream order: RCCL -> Adam)
+    adam = parallel.FlatAdam(m)
+    before = m.flat_params.clone()
+    _shard_step(m, models, batch, red)
+    adam.step(grad_scale=1.0)
+    torch.cuda.synchronize()
+    moved = float((m.flat_params - before).abs().max())
+    red.close()
+    q.put((flat.numel() * 4, bool(early), float((flat - plain).abs().max()), float(plain.abs().max()), moved, dist.get_backend()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_world_size_one_pushes_the_real_280mb_bucket():
+    """RCCL itself (backend "nccl") on the one-GPU box: loads librccl, creates the communicator, all-reduces the real flat
+    bucket in two slices on RCCL's stream ordered against the backward kernels; one rank => the result equals the plain backward."""
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    nbytes, early, err, scale, moved, backend = q.get(timeout=800)
+    p.join(120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and nbytes > 270e6
+    assert early, "decoder slice must be in flight before the encoder backward ends"
+    assert err <= 1e-4 * scale + 1e-12, (err, scale)        # two runs of the backward differ by fp32 atomic order only
+    assert 0 < moved < 1e-2

@@ -12,11 +12,19 @@ import pytest
 import torch
 
 from oracle import subgc_oracle as O
-from subgc import synthetic
+from subgc import ops, synthetic
 import subgc.models as models
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def gemm_mode(request):
+    """Arithmetic of the 128x128-tile GEMM forms (ops.gemm_mode): the default fp32 matrix pipe, and the exact three-way bf16
+    split on the bf16 pipe -- which claims fp32-grade results and therefore has to meet the SAME tolerances below."""
+    with ops.gemm_mode(request.param):
+        yield request.param
 
 
 def close(a, b, name, atol=1e-4, rtol=1e-4):
@@ -46,7 +54,7 @@ def run_train(m, batch):
 
 
 @pytest.mark.parametrize("name", ["subgc_train", "subgc_gtsubg_train", "fullgc_train"])
-def test_train_matches_reference_golden(golden, name):
+def test_train_matches_reference_golden(golden, name, gemm_mode):
     g = golden(name)
     m = build(g, g.group("weights"), True)
     batch = g.tensors("inputs")
@@ -80,7 +88,7 @@ def test_train_matches_reference_golden(golden, name):
 
 @pytest.mark.parametrize("name,wf", [("subgc_greedy", "subgc_train"), ("subgc_greedy_nms55", "subgc_train"),
                                       ("subgc_sct", "subgc_train"), ("fullgc_greedy", "fullgc_train")])
-def test_greedy_decode_token_identical_to_reference(golden, name, wf):
+def test_greedy_decode_token_identical_to_reference(golden, name, wf, gemm_mode):
     g = golden(name)
     m = build(g, golden(wf).group("weights"), False)
     b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
@@ -180,7 +188,7 @@ def _sharpen(sd, gen):
             v.mul_(4.0)
 
 
-def test_full_size_subgc_kar_train_and_decode_match_oracle():
+def test_full_size_subgc_kar_train_and_decode_match_oracle(gemm_mode):
     """Sub_GC_Kar dimensions (D=2048, L=1024, R=1000, V+1=9488, N=37, K=65), B=2 images."""
     torch.manual_seed(0)
     opt = argparse.Namespace(**KAR)
@@ -212,6 +220,35 @@ def test_full_size_subgc_kar_train_and_decode_match_oracle():
     np.testing.assert_array_equal(ret[0].cpu().numpy(), want[0].numpy())
     close(ret[1], want[1], "seqLogprobs", atol=2e-4)
     close(ret[4], want[4], "att2_weights", atol=1e-5)
+
+
+def test_full_size_b32_train_matches_oracle_in_every_fp32_grade_gemm_mode(gemm_mode):
+    """B=32 images at the Sub_GC_Kar dimensions: 160 sentences x 17 steps = 2720 decoder rows, enough for the 128x128-tile
+    and split-K GEMM forms (the ones `gemm_mode` switches) to carry the logits, x->gates and every weight gradient.  Loss,
+    log-probs and gradients against the CPU oracle at the fp32 tolerances of this file, in both fp32-grade modes."""
+    torch.manual_seed(0)
+    opt = argparse.Namespace(**KAR)
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(32, seed=13)
+    out, loss = run_train(m, batch)
+    orc = O.Oracle(opt, sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss")
+    grads = {k: m.P(k).grad.clone() for k in ("logit.weight", "core.att_lstm.weight_ih", "core.att_lstm.weight_hh", "core.lang_lstm.weight_ih",
+                                               "embed.0.weight", "obj_v_proj.weight", "att_embed.0.weight", "fc_embed.0.weight",
+                                               "gcn_backbone.gcn.1.gcn_collect.collect_units.0.fc_rgt.weight", "gpn_layer.gpn_fc.0.weight")}
+    with torch.no_grad():
+        outputs, _, score = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+    close(outputs, ref["outputs"], "outputs", atol=2e-4, rtol=1e-4)
+    close(score, ref["subgraph_score"], "score", atol=1e-5)
+    for k, gk in grads.items():
+        close(gk, orc.P[k].grad, "grad " + k, atol=2e-5 + 2e-3 * float(orc.P[k].grad.abs().max()), rtol=5e-3)
 
 
 def test_size_independent_properties_at_bench_size():
