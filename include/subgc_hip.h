@@ -365,6 +365,10 @@ int subgc_pad_rows_f32(const float* src, const int64_t* off, int B, int R, int C
                        float* dst, void* stream);
 int subgc_pad_rows_i64(const int64_t* src, const int64_t* off, int B, int R, int C, int limit, int64_t pad,
                        int64_t* dst, void* stream);
+/* pad_segments (:303-308, gpn_nrel_ind): group g owns rows start[g] .. start[g] + count[g] of the packed `src [sum, C]`
+ * (segments in any order, repeats allowed); dst[g, r, :] = its r-th row for r < min(count[g], R), else `pad`.        */
+int subgc_pad_segments_i64(const int64_t* src, const int64_t* start, const int64_t* count, int G, int R, int C,
+                           int64_t pad, int64_t* dst, void* stream);
 /* caption_labels (:356-363): labels[s] = [0, captions[s, :seq_length], 0]; masks[s, j] = j < nonzero(captions[s]) + 2 */
 int subgc_caption_labels(const int64_t* captions, int64_t ld, int S, int seq_length, int64_t* labels,
                          float* masks, void* stream);

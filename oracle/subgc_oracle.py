@@ -579,20 +579,76 @@ def rank_subgraphs(gpn, seqq, subgraph_score, keep_nms_ind, sct_mode=False):
     return seqq, subgraph_score, keep_nms_ind, torch.arange(subgraph_score.size(0)).type_as(keep_nms_ind)
 
 
-# --------------------------------------------------------------------------- batch assembly (dataloaders/dataloader.py:269-367)
-# PARITY UNPINNED for this block: the reference loader imports h5py and reads dataset files, neither of which
-# exists in the build container, so no golden vector could be produced by running it; this is a line-by-line
-# numpy restatement of the cited lines only.
-def assemble_image(object_fmap, object_dist, rel_ind, pred_dist, node_masks, pred_masks, captions, obj_num, rel_num):
-    """One image: node_masks [S, 2, hb, obj_num-1] bool, pred_masks [S, 2, hb, rel_num-1] bool, captions [S, seq_length]."""
+# --------------------------------------------------------------------------- batch assembly (dataloaders/dataloader.py:139-157,225-367)
+# PINNED: tests/golden/loader_*.npz hold what the reference's own `DataLoader.__getitem__` returned for fabricated dataset
+# entries (make_golden.py loader_cases: h5py stubbed so the module imports, object made with object.__new__), for the
+# sampled-sub-graph branch with seeded np.random and for `use_gt_subg`; tests/test_oracle_golden.py replays them here.
+def choose_subgraphs(node_iou_mtx, thres, hb, seq_per_img=5, rng=np.random):
+    """dataloader.py:229-270: the (positive, negative) sub-graph ids of every sentence's mini-batch -> mask_idx [S, hb, 2],
+    indices into `subgraph_mask_list` (the +5 shift of :270 applied).  Consumes `rng` exactly as the reference consumes np.random."""
+    sampled_node_iou = node_iou_mtx[:, 5:]
+    mask_idx = np.full((seq_per_img, hb, 2), -1)
+    pos_mask = sampled_node_iou >= thres                                                          # :234
+    neg_mask = sampled_node_iou < thres
+    neg_mask[:, pos_mask.nonzero()[1]] = 0                                                        # :237
+    weight = pos_mask / (pos_mask.sum(0) + 1e-7)
+    n_weight = (weight.T / (weight.sum(1) + 1e-7)).T
+    for i in range(seq_per_img):
+        pos_idx = pos_mask[i].nonzero()[0]
+        if pos_idx.shape[0] < hb:                                                                 # :243-245
+            to_pad = hb - pos_idx.shape[0]
+            mask_idx[i, :to_pad, 0] = i - 5
+            mask_idx[i, to_pad:, 0] = pos_idx
+        else:                                                                                     # :246-250
+            pos_weight = n_weight[i][pos_idx]
+            rd_ind = rng.randint(pos_weight.shape[0], size=1)
+            pos_weight[rd_ind[0]] = 1.0 - (pos_weight.sum() - pos_weight[rd_ind[0]])
+            mask_idx[i, :, 0] = rng.choice(pos_idx, size=hb, replace=True, p=pos_weight)
+        neg_idx = neg_mask[i].nonzero()[0]                                                        # :252-266
+        if neg_idx.shape[0] < hb:
+            tmp_neg_idx = (sampled_node_iou[i] <= thres).nonzero()[0]
+            if tmp_neg_idx.shape[0] == 0:
+                neg_idx = (sampled_node_iou[i] <= 1.0).nonzero()[0]
+                mask_idx[i, :, 1] = rng.choice(neg_idx, size=hb, replace=True)
+            elif neg_idx.shape[0] == 0:
+                mask_idx[i, :, 1] = rng.choice(tmp_neg_idx, size=hb, replace=True)
+            else:
+                mask_idx[i, :, 1] = rng.choice(neg_idx, size=hb, replace=True)
+        else:
+            mask_idx[i, :, 1] = rng.choice(neg_idx, size=hb, replace=False)
+    return mask_idx + 5                                                                           # :270
+
+
+def pick_captions(label, label_start_ix, label_end_ix, ix, seq_per_img, seq_length, pyrandom=None):
+    """dataloader.py:139-157 get_captions: the first `seq_per_img` captions, or draws with replacement (python `random`)."""
+    import random as _random
+    pyrandom = pyrandom or _random
+    ix1 = label_start_ix[ix] - 1
+    ix2 = label_end_ix[ix] - 1
+    ncap = ix2 - ix1 + 1
+    assert ncap > 0
+    if ncap < seq_per_img:
+        seq = np.zeros([seq_per_img, seq_length], dtype='int')
+        for q in range(seq_per_img):
+            ixl = pyrandom.randint(ix1, ix2)
+            seq[q, :] = label[ixl, :seq_length]
+        return seq
+    return label[ix1: ix1 + seq_per_img, :seq_length]
+
+
+def assemble_image(object_fmap, object_dist, rel_ind, pred_dist, node_masks, pred_masks, captions, obj_num, rel_num, nrel=None):
+    """One image: node_masks [S, 2, hb, obj_num-1] bool, pred_masks [S, 2, hb, rel_num-1] bool, captions [S, seq_length];
+    `nrel[i][side][k]` (optional): the re-indexed relation endpoints [n, 2] of the chosen sub-graphs (:303-308).
+    The use_gt_subg branch (:310-327) is the same call with sentence i's own masks broadcast over (side, k)."""
     S, _, hb, _ = node_masks.shape
     gpn_obj_ind = np.full((S, 2, hb, obj_num), obj_num - 1)                                       # :276
     gpn_att_mask = np.full((S, 2, hb, obj_num), 0).astype('float32')                              # :277
     gpn_pred_ind = np.full((S, 2, hb, rel_num), rel_num - 1)                                      # :278
+    gpn_nrel_ind = np.full((S, 2, hb, rel_num, 2), obj_num - 1)                                   # :279
     gpn_pool_mtx = np.zeros((S, 2, hb, obj_num, obj_num)).astype('float32')                       # :280
     for i in range(S):
         for k in range(hb):
-            for side in range(2):                                                                 # :283-301 (pos then neg)
+            for side in range(2):                                                                 # :283-308 (pos then neg)
                 tmp = node_masks[i, side, k].nonzero()[0]
                 if tmp.shape[0] != 0:
                     gpn_obj_ind[i, side, k, :tmp.shape[0]] = tmp
@@ -601,6 +657,10 @@ def assemble_image(object_fmap, object_dist, rel_ind, pred_dist, node_masks, pre
                 tmp = pred_masks[i, side, k].nonzero()[0]
                 if tmp.shape[0] != 0:
                     gpn_pred_ind[i, side, k, :tmp.shape[0]] = tmp
+                if nrel is not None:
+                    tmp = nrel[i][side][k]
+                    if tmp.shape[0] != 0:
+                        gpn_nrel_ind[i, side, k, :tmp.shape[0]] = tmp
     pad_fmap = np.full((1, obj_num, object_fmap.shape[1]), 0).astype('float32')                   # :336
     pad_dist = np.concatenate((np.ones((1, obj_num, 1)), np.zeros((1, obj_num, object_dist.shape[1] - 1))), axis=2).astype('float32')
     fc_feat = np.full((1, object_fmap.shape[1]), 0).astype('float32')
@@ -619,4 +679,5 @@ def assemble_image(object_fmap, object_dist, rel_ind, pred_dist, node_masks, pre
     for idx in range(S):
         mask[idx, :nonzeros[idx]] = 1
     return dict(fc_feats=fc_feat, att_feats=pad_fmap, obj_dist=pad_dist, rel_ind=pad_rel, pred_dist=pad_pred, labels=label, masks=mask,
-                gpn_obj_ind=gpn_obj_ind, att_masks=gpn_att_mask, gpn_pred_ind=gpn_pred_ind, gpn_pool_mtx=gpn_pool_mtx)
+                gpn_obj_ind=gpn_obj_ind, att_masks=gpn_att_mask, gpn_pred_ind=gpn_pred_ind, gpn_nrel_ind=gpn_nrel_ind,
+                gpn_pool_mtx=gpn_pool_mtx)

@@ -72,6 +72,20 @@ __global__ __launch_bounds__(256) void pad_rows_i64_kernel(const int64_t* __rest
     }
 }
 
+// rows start[g] .. start[g] + count[g] of the packed src -> dst[g, :R, :C], the rest `pad` (segments need not be contiguous or ordered)
+__global__ __launch_bounds__(256) void pad_segments_i64_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ start,
+                                                               const int64_t* __restrict__ count, int R, int C, int64_t pad,
+                                                               int64_t* __restrict__ dst, int G) {
+    const int64_t total = (int64_t)G * R * C;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(q % C);
+        const int r = (int)((q / C) % R);
+        const int g = (int)(q / ((int64_t)R * C));
+        const int64_t n = min(count[g], (int64_t)R);
+        dst[q] = r < n ? src[(start[g] + r) * C + c] : pad;
+    }
+}
+
 __global__ __launch_bounds__(64) void caption_labels_kernel(const int64_t* __restrict__ cap, int64_t ld, int S, int Lq,
                                                             int64_t* __restrict__ labels, float* __restrict__ masks) {
     const int s = blockIdx.x;
@@ -118,6 +132,17 @@ SUBGC_API int subgc_pad_rows_i64(const int64_t* src, const int64_t* off, int B, 
     hipLaunchKernelGGL(pad_rows_i64_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, src,
                        off, R, C, limit, pad, dst, B);
     return subgc::check_launch("subgc_pad_rows_i64");
+}
+
+SUBGC_API int subgc_pad_segments_i64(const int64_t* src, const int64_t* start, const int64_t* count, int G, int R, int C, int64_t pad,
+                                     int64_t* dst, void* stream) {
+    SUBGC_REQUIRE(G >= 0 && R > 0 && C > 0, "pad_segments_i64: bad sizes");
+    if (G == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(start && count && dst, "pad_segments_i64: null pointer");
+    const int64_t total = (int64_t)G * R * C;
+    hipLaunchKernelGGL(pad_segments_i64_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       src, start, count, R, C, pad, dst, G);
+    return subgc::check_launch("subgc_pad_segments_i64");
 }
 
 SUBGC_API int subgc_caption_labels(const int64_t* captions, int64_t ld, int S, int seq_length, int64_t* labels, float* masks, void* stream) {

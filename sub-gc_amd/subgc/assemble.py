@@ -4,14 +4,73 @@ The reference builds every training batch with numpy loops inside `__getitem__` 
 index compaction of the chosen sub-graph masks, a dense [5,2,hb,N,N] diagonal pooling matrix per image,
 dummy-node padding of the scene graph, label/mask rows.  Here the loader only has to hand over the RAW
 per-image arrays (already on the device) and the chosen sub-graph ids; three HBM-bound kernels build the
-model's 14 arguments.  The random choice of sub-graphs (:232-267) is host-side integer work and stays there.
+model's 14 arguments.  The random choice of sub-graphs (:229-270) and of captions (:139-157) is host-side integer work on
+a handful of numbers per image and stays on the host (`choose_subgraphs`, `pick_captions`: same random streams as the
+reference, so a seeded run draws the same mini-batches).  Pinned on what the reference's own `__getitem__` returns
+(tests/golden/loader_*.npz).
 """
 from __future__ import annotations
 
+import random as _pyrandom
+
+import numpy as np
 import torch
 
 from ._lib import call
 from .ops import _ptr, _stream
+
+
+def choose_subgraphs(node_iou_mtx, thres, gpn_batch, rng=np.random):
+    """Ids (into the image's `subgraph_mask_list`) of the positive and negative sub-graphs of every sentence's mini-batch
+    -> int [S, gpn_batch, 2] (dataloader.py:229-270).  Column j + 5 of `node_iou_mtx [S, 5 + M]` is the node IoU of sampled
+    candidate j with each sentence's nouns; the first 5 entries of the list are the sentences' own sub-graphs.  `rng` is
+    consumed call for call like the reference consumes np.random (randint, then choice)."""
+    iou = np.asarray(node_iou_mtx)[:, 5:]
+    S = iou.shape[0]
+    pos = iou >= thres
+    neg = (iou < thres) & ~pos.any(0)[None, :]               # a candidate that is positive for ANY sentence is nobody's negative
+    share = pos / (pos.sum(0) + 1e-7)                         # a candidate shared by several sentences is drawn less often by each
+    share = (share.T / (share.sum(1) + 1e-7)).T
+    out = np.empty((S, gpn_batch, 2), dtype=np.int64)
+    for i in range(S):
+        cand = np.flatnonzero(pos[i])
+        if cand.size < gpn_batch:                             # too few positives: the sentence's own sub-graph (entry i) fills the front
+            out[i, :gpn_batch - cand.size, 0] = i
+            out[i, gpn_batch - cand.size:, 0] = cand + 5
+        else:
+            p = share[i][cand]
+            j = int(rng.randint(p.shape[0], size=1)[0])       # one random entry absorbs the rounding so that p sums to 1
+            p[j] = 1.0 - (p.sum() - p[j])
+            out[i, :, 0] = rng.choice(cand, size=gpn_batch, replace=True, p=p) + 5
+        cand = np.flatnonzero(neg[i])
+        if cand.size >= gpn_batch:
+            out[i, :, 1] = rng.choice(cand, size=gpn_batch, replace=False) + 5
+            continue
+        loose = np.flatnonzero(iou[i] <= thres)               # fall back: at or below the threshold, else anything
+        pool = np.flatnonzero(iou[i] <= 1.0) if loose.size == 0 else (loose if cand.size == 0 else cand)
+        out[i, :, 1] = rng.choice(pool, size=gpn_batch, replace=True) + 5
+    return out
+
+
+def pick_captions(label, label_start_ix, label_end_ix, ix, seq_per_img, seq_length, rng=_pyrandom):
+    """The `seq_per_img` caption rows of image `ix` (dataloader.py:139-157): the first ones, or draws with replacement when
+    the image has fewer (python `random.randint`, as the reference)."""
+    first, last = int(label_start_ix[ix]) - 1, int(label_end_ix[ix]) - 1          # the h5 pointers are 1-based
+    if last < first:
+        raise ValueError(f"image {ix} has no caption")
+    if last - first + 1 >= seq_per_img:
+        return np.asarray(label[first:first + seq_per_img, :seq_length])
+    rows = [rng.randint(first, last) for _ in range(seq_per_img)]
+    return np.asarray(label)[rows, :seq_length]
+
+
+def pad_segments(src, start, count, R, pad):
+    """dst[g, r] = src[start[g] + r] for r < min(count[g], R), else `pad` (int64 rows; subgc_pad_segments_i64)."""
+    G, C = start.numel(), src.size(1)
+    dst = torch.empty(G, R, C, device=start.device, dtype=torch.int64)
+    call("subgc_pad_segments_i64", _ptr(src.contiguous(), torch.int64) if src.numel() else None, _ptr(start.contiguous(), torch.int64),
+         _ptr(count.contiguous(), torch.int64), G, R, C, int(pad), _ptr(dst), _stream())
+    return dst
 
 
 def subgraph_indices(node_mask, N, pad=None, want_att_mask=True, want_pool_mtx=False):
@@ -57,6 +116,8 @@ def assemble_train_batch(raw, obj_num, rel_num, want_pool_mtx=True):
          rel_ind [sum_k, 2] i64, pred_dist [sum_k, P] f32, rel_off [B+1] i64            (ragged relations, :344-354)
          node_mask [B*S, 2, hb, obj_num-1] u8, pred_mask [B*S, 2, hb, rel_num-1] u8     (the chosen pos/neg sub-graphs, :276-301)
          captions [B*S, seq_length] i64                                                 (:356)
+         optional: nrel [sum, 2] i64 + nrel_start, nrel_count [B*S, 2, hb] i64: the re-indexed relation endpoints of the
+         chosen sub-graphs as segments of one packed array (:303-308; the model never reads gpn_nrel_ind, the dict has it)
        -> the dict `get_batch` returns (dataloader.py:190-205), ready for LossWrapper."""
     fmap, dist = raw["object_fmap"], raw["object_dist"]
     B, n_obj, D = fmap.shape
@@ -73,5 +134,9 @@ def assemble_train_batch(raw, obj_num, rel_num, want_pool_mtx=True):
     }
     out["gpn_obj_ind"], out["att_masks"], out["gpn_pool_mtx"] = subgraph_indices(raw["node_mask"], obj_num, want_pool_mtx=want_pool_mtx)
     out["gpn_pred_ind"], _, _ = subgraph_indices(raw["pred_mask"], rel_num, want_att_mask=False)
+    if "nrel" in raw:
+        lead = raw["nrel_start"].shape
+        out["gpn_nrel_ind"] = pad_segments(raw["nrel"], raw["nrel_start"].reshape(-1), raw["nrel_count"].reshape(-1), rel_num,
+                                           obj_num - 1).view(*lead, rel_num, 2)
     out["labels"], out["masks"] = caption_labels(raw["captions"])
     return out

@@ -225,6 +225,188 @@ def beam_cases(w, meta):
         torch.Tensor.cuda = orig
 
 
+def ss_case(w, meta):
+    """Scheduled sampling (AttModel.py:157-167) on the subgc_train weights and inputs, p = 0.25.  The two random streams the
+    reference consumes there are replaced, for the duration of the forward, by injected numbers: `Tensor.uniform_` on the
+    [batch] selector returns sel_u[i]; `torch.multinomial(prob_prev, 1)` returns the inverse CDF of prob_prev at u[i] in index
+    order.  Everything else -- which rows are re-drawn, from which step's distribution, that the draw replaces the INPUT word
+    only and carries no gradient, the early break -- is the reference's own code.  Stored: the injected numbers, the words
+    actually fed at every step, outputs, losses, every parameter gradient."""
+    from misc.utils import LanguageModelCriterion
+    with open(os.path.join(HERE, "meta.json")) as f:
+        base = json.load(f)["subgc_train"]
+    opt = ref_opt(sampling_prob=0.25)
+    model = build(opt, base["seed"], base["gcn_scale"])
+    for k, v in model.state_dict().items():
+        assert np.array_equal(np_(v), w[k]), k                    # same construction as subgc_train: no second weight file
+    model.train()
+    assert model.ss_prob == 0.25
+    with np.load(os.path.join(HERE, "subgc_train_inputs.npz")) as z:
+        batch = {k: torch.from_numpy(z[k]) for k in z.files}
+    S, T = batch["labels"].shape[0], batch["labels"].shape[1] - 1
+    gen = torch.Generator().manual_seed(4242)
+    sel_u, u = torch.rand(T, S, generator=gen), torch.rand(T, S, generator=gen)
+    state = dict(step=0, fed=[], n_uniform=0, n_multi=0)
+    orig_uniform, orig_multi, orig_step = torch.Tensor.uniform_, torch.multinomial, model.get_logprobs_state
+
+    def uniform_(self, *a, **k):
+        assert tuple(self.shape) == (S,) and a == (0, 1)
+        state["n_uniform"] += 1
+        state["step"] += 1                                        # the reference draws the selector once per step i >= 1, in order
+        return self.copy_(sel_u[state["step"]])
+
+    def multinomial(prob, n, *a, **k):
+        assert n == 1 and tuple(prob.shape) == (S, opt.vocab_size + 1)
+        state["n_multi"] += 1
+        cdf = torch.cumsum(prob, 1)
+        draw = (cdf <= (u[state["step"]] * cdf[:, -1]).unsqueeze(1)).sum(1).clamp(max=cdf.size(1) - 1)
+        return draw.view(-1, 1)
+
+    def step(it, *a, **k):
+        state["fed"].append(np_(it))
+        return orig_step(it, *a, **k)
+
+    torch.Tensor.uniform_, torch.multinomial, model.get_logprobs_state = uniform_, multinomial, step
+    try:
+        outputs, gpn_loss, score = model(*synthetic.forward_args({k: v.clone() for k, v in batch.items()}))
+    finally:
+        torch.Tensor.uniform_, torch.multinomial = orig_uniform, orig_multi
+    lang_loss = LanguageModelCriterion()(outputs, batch["labels"][:, 1:], batch["masks"][:, 1:])
+    loss = lang_loss + gpn_loss
+    loss.backward()
+    fed = np.stack(state["fed"], 0)                               # [steps run, S]
+    changed = int((fed != batch["labels"][:, :fed.shape[0]].numpy().T).sum())
+    assert state["n_uniform"] >= fed.shape[0] - 1 and state["n_multi"] > 0 and changed > 10, (state["n_uniform"], state["n_multi"], changed)
+    rec = dict(outputs=np_(outputs), lang_loss=np_(lang_loss), gpn_loss=np_(gpn_loss), loss=np_(loss), subgraph_score=np_(score),
+               sel_u=sel_u.numpy(), u=u.numpy(), fed_tokens=fed)
+    grads = {k: np_(p.grad) for k, p in model.named_parameters() if p.grad is not None}
+    meta["subgc_ss_train"] = dict(kind="train_ss", weights="subgc_train", inputs="subgc_train", sampling_prob=0.25, changed_words=changed,
+                                  opt={k: v for k, v in vars(opt).items() if "path" not in k},
+                                  dead_params=[k for k, p in model.named_parameters() if p.grad is None])
+    save("subgc_ss_train", out=rec, grads=grads)
+
+
+class _LoggedList(list):
+    """`subgraph_mask_list` that remembers which entries the loader read, in order (how the fixture learns the sub-graph
+    ids `__getitem__` drew without touching its source)."""
+
+    def __init__(self, items):
+        super().__init__(items)
+        self.log = []
+
+    def __getitem__(self, i):
+        self.log.append(int(i))
+        return super().__getitem__(i)
+
+
+def loader_cases(meta):
+    """dataloaders/dataloader.py:225-367 `DataLoader.__getitem__` driven on fabricated dataset entries: `h5py` (absent here,
+    only used by `__init__`) is stubbed so the module imports, the object is made with `object.__new__` and given exactly the
+    attributes `__getitem__` / `get_captions` read.  Both branches: sampled sub-graph mini-batches (seeded np.random) and
+    `use_gt_subg`.  Stored per image: the fabricated raw entries, the ids the loader drew, its 13 returned arrays."""
+    import random as pyrandom
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    from dataloaders.dataloader import DataLoader
+    obj_num, rel_num, hb, S, Lq, D, C, Pd = 37, 65, 2, 5, 16, 8, 7, 5
+    rng = np.random.default_rng(99)
+    n_img = 6
+    n_cand = [9, 3, 14, 6, 2, 11]                                 # sampled candidates per image (after the 5 sentence sub-graphs)
+    n_rel = [0, rel_num + 9, 17, rel_num - 1, 40, 5]              # none / more than fit / short / exactly full / ...
+    n_cap = [5, 7, 3, 5, 1, 6]                                    # >= 5: the first five; < 5: random.randint with replacement
+    images, labels_all, start, end = [], [], [], []
+    for b in range(n_img):
+        M = 5 + n_cand[b]
+        iou = rng.random((S, M))
+        if b == 1:
+            iou[:, 5:] = 0.9                                      # every candidate positive for every sentence: no negatives at all
+        if b == 4:
+            iou[:, 5:] = 0.1                                      # no positives: padded with the sentence's own sub-graph (i - 5)
+        if b == 2:
+            iou[0, 5:] = 0.75                                     # exactly at the threshold: positive (>=) AND counted by the <= fallback
+        masks = []
+        for j in range(M):
+            nm = rng.random(obj_num - 1) < 0.25
+            if j == 6:
+                nm[:] = False                                     # an empty sub-graph
+            pm = rng.random(rel_num - 1) < 0.1
+            nrel = rng.integers(0, obj_num - 1, size=(int(pm.sum()), 2))
+            masks.append((j, nm, pm, nrel))
+        sg = dict(object_fmap=rng.standard_normal((obj_num - 1, D)).astype(np.float32), object_dist=rng.random((obj_num - 1, C)).astype(np.float32),
+                  pred_dist=rng.random((n_rel[b], Pd)).astype(np.float32), rel_ind=rng.integers(0, obj_num - 1, size=(n_rel[b], 2)))
+        caps = rng.integers(1, 50, size=(n_cap[b], Lq))
+        for r in range(n_cap[b]):
+            caps[r, rng.integers(0, Lq + 1):] = 0
+        start.append(len(labels_all) + 1)                         # 1-based like the h5 file
+        labels_all.extend(list(caps))
+        end.append(len(labels_all))
+        images.append(dict(iou=iou, masks=masks, sg=sg))
+    dl = object.__new__(DataLoader)
+    dl.info = {"images": [{"id": 1000 + b} for b in range(n_img)]}
+    dl.seq_per_img, dl.half_mini_batch, dl.obj_num, dl.rel_num, dl.seq_length, dl.thres = S, hb, obj_num, rel_num, Lq, 0.75
+    dl.label = np.stack(labels_all).astype(np.int64)
+    dl.label_start_ix, dl.label_end_ix = np.array(start), np.array(end)
+    logged = {}
+
+    class _Masks:
+        def get(self, key):
+            im = images[int(key) - 1000]
+            logged[key] = _LoggedList(im["masks"])
+            return {"node_iou_mtx": im["iou"].copy(), "subgraph_mask_list": logged[key]}
+
+    class _Trip:
+        def get(self, key):
+            return images[int(key) - 1000]["sg"]
+
+    dl.subgraph_mask, dl.trip_loader = _Masks(), _Trip()
+    names = ("fc_feats", "att_feats", "obj_dist", "rel_ind", "pred_dist", "labels", "masks", "ix", "gpn_obj_ind", "gpn_pred_ind",
+             "gpn_nrel_ind", "att_masks", "gpn_pool_mtx")
+    out = {}
+    branches = set()
+    for gt in (0, 1):
+        dl.use_gt_subg = gt
+        np.random.seed(2024 + gt)
+        pyrandom.seed(7 + gt)
+        for b in range(n_img):
+            ret = dl.__getitem__(b)
+            tag = f"{'gt' if gt else 'smp'}{b}"
+            for nme, arr in zip(names, ret):
+                out[f"{tag}_{nme}"] = np.asarray(arr)
+            log = logged[str(1000 + b)].log
+            if gt:
+                assert log == [i for i in range(S) for _ in range(3)]
+            else:
+                ids = np.array(log).reshape(S, hb, 3, 2)             # per (i, k): [obj, pred, nrel] x [pos, neg]
+                assert (ids[:, :, 0] == ids[:, :, 1]).all() and (ids[:, :, 0] == ids[:, :, 2]).all()
+                out[f"{tag}_mask_idx"] = ids[:, :, 0]                # [S, hb, 2] AFTER the +5 shift (:270)
+                iou = images[b]["iou"][:, 5:]
+                pos, neg = iou >= 0.75, iou < 0.75
+                neg[:, pos.nonzero()[1]] = 0
+                for i in range(S):
+                    branches.add("pos_pad" if pos[i].sum() < hb else "pos_draw")
+                    if neg[i].sum() >= hb:
+                        branches.add("neg_plain")
+                    elif (iou[i] <= 0.75).sum() == 0:
+                        branches.add("neg_all")
+                    elif neg[i].sum() == 0:
+                        branches.add("neg_le_thres")
+                    else:
+                        branches.add("neg_few")
+    assert branches == {"pos_pad", "pos_draw", "neg_plain", "neg_all", "neg_le_thres", "neg_few"}, branches
+    raw = {}
+    for b, im in enumerate(images):
+        raw[f"img{b}_node_iou_mtx"] = im["iou"]
+        raw[f"img{b}_node_masks"] = np.stack([m[1] for m in im["masks"]])
+        raw[f"img{b}_pred_masks"] = np.stack([m[2] for m in im["masks"]])
+        raw[f"img{b}_nrel"] = np.concatenate([m[3] for m in im["masks"]]).reshape(-1, 2)
+        raw[f"img{b}_nrel_off"] = np.cumsum([0] + [m[3].shape[0] for m in im["masks"]])
+        for k, v in im["sg"].items():
+            raw[f"img{b}_{k}"] = v
+    raw.update(label=dl.label, label_start_ix=dl.label_start_ix, label_end_ix=dl.label_end_ix)
+    meta["loader"] = dict(kind="loader", obj_num=obj_num, rel_num=rel_num, gpn_batch=hb, seq_per_img=S, seq_length=Lq, thres=0.75,
+                          n_images=n_img, np_seed=[2024, 2025], py_seed=[7, 8], branches=sorted(branches))
+    save("loader", inputs=raw, out=out)
+
+
 def eval_cases(meta):
     """misc/utils.py:59-81 decode_sequence (with and without REMOVE_BAD_ENDINGS) on token rows that end in function words."""
     import misc.utils as U
@@ -253,6 +435,22 @@ def main():
         with open(os.path.join(HERE, "meta.json")) as f:
             meta = json.load(f)
         eval_cases(meta)
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        return
+    if "--only-loader" in sys.argv:
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        loader_cases(meta)
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        return
+    if "--only-ss" in sys.argv:                                 # add the scheduled-sampling case without rewriting the others
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        with np.load(os.path.join(HERE, "subgc_train_weights.npz")) as z:
+            w = {k: z[k] for k in z.files}
+        ss_case(w, meta)
         with open(os.path.join(HERE, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, sort_keys=True, default=str)
         return
@@ -286,6 +484,10 @@ def main():
     # 4. beam search / diverse beam search
     beam_cases(w, meta)
     eval_cases(meta)
+    with open(os.path.join(HERE, "meta.json"), "w") as f:       # ss_case reads subgc_train's entry back
+        json.dump(meta, f, indent=1, sort_keys=True, default=str)
+    ss_case(w, meta)
+    loader_cases(meta)
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True, default=str)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

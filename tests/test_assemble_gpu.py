@@ -1,6 +1,6 @@
-"""On-device batch assembly (dataloaders/dataloader.py:269-367) against the numpy restatement in the oracle
-(parity unpinned: the reference loader needs h5py + dataset files and cannot run in the build container).
-Integer outputs and the 0/1 float masks are compared bit-exactly."""
+"""On-device batch assembly (dataloaders/dataloader.py:225-367) against (1) what the reference's own `DataLoader.__getitem__`
+returned for fabricated dataset entries (tests/golden/loader_*.npz, both branches) and (2) the oracle's restatement on
+random inputs incl. the Flickr sizes.  Everything is compared bit-exactly."""
 import numpy as np
 import pytest
 import torch
@@ -71,3 +71,40 @@ def test_assembled_batch_feeds_the_model(golden):
         np.testing.assert_array_equal(got[k].cpu().numpy(), batch[k].numpy(), err_msg=k)
     out, _ = run_train(m, {**{k: v for k, v in batch.items()}, **{k: v.cpu() for k, v in got.items()}})
     assert float(out["lang_loss"]) == float(ref_out["lang_loss"])
+
+
+@pytest.mark.parametrize("tag", ["smp", "gt"])
+def test_assembled_batch_equals_the_reference_loader_output(golden, tag):
+    """All images of the golden `loader` case as ONE device-assembled batch: the drawn sub-graph ids come from the host
+    sampler replaying the reference's np.random stream (`smp`) or are the sentences' own sub-graphs (`gt` = use_gt_subg)."""
+    import random as pyrandom
+    from loader_golden import NAMES, LoaderCase
+    c = LoaderCase(golden)
+    m = c.meta
+    gt = tag == "gt"
+    np.random.seed(m["np_seed"][int(gt)])
+    pyrandom.seed(m["py_seed"][int(gt)])
+    B = m["n_images"]
+    ims = [c.image(b) for b in range(B)]
+    node_m, pred_m, caps, starts, counts, nrel_rows, base = [], [], [], [], [], [], 0
+    for b, im in enumerate(ims):
+        ids = c.gt_ids() if gt else assemble.choose_subgraphs(im["iou"], m["thres"], c.hb)
+        ids = np.transpose(ids, (0, 2, 1))                                        # [S, side, k]
+        node_m.append(im["node_masks"][ids]); pred_m.append(im["pred_masks"][ids])
+        off = c.raw[f"img{b}_nrel_off"]
+        starts.append(base + off[:-1][ids]); counts.append((off[1:] - off[:-1])[ids])
+        nrel_rows.append(c.raw[f"img{b}_nrel"]); base += c.raw[f"img{b}_nrel"].shape[0]
+        caps.append(assemble.pick_captions(c.raw["label"], c.raw["label_start_ix"], c.raw["label_end_ix"], b, c.S, c.Lq))
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(DEV)
+    n_rel = [im["rel_ind"].shape[0] for im in ims]
+    raw = dict(object_fmap=t(np.stack([im["object_fmap"] for im in ims]), torch.float32), object_dist=t(np.stack([im["object_dist"] for im in ims]), torch.float32),
+               rel_ind=t(np.concatenate([im["rel_ind"] for im in ims]), torch.int64), pred_dist=t(np.concatenate([im["pred_dist"] for im in ims]), torch.float32),
+               rel_off=t(np.concatenate([[0], np.cumsum(n_rel)]), torch.int64), node_mask=t(np.concatenate(node_m), torch.uint8),
+               pred_mask=t(np.concatenate(pred_m), torch.uint8), captions=t(np.concatenate(caps), torch.int64),
+               nrel=t(np.concatenate(nrel_rows), torch.int64), nrel_start=t(np.concatenate(starts), torch.int64), nrel_count=t(np.concatenate(counts), torch.int64))
+    got = assemble.assemble_train_batch(raw, c.obj_num, c.rel_num)
+    for k in NAMES:
+        want = np.concatenate([c.out[f"{tag}{b}_{k}"] for b in range(B)])
+        g = got[k].cpu().numpy()
+        assert g.shape == want.shape, (k, g.shape, want.shape)
+        np.testing.assert_array_equal(g, want.astype(g.dtype), err_msg=k)

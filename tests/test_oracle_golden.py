@@ -131,3 +131,62 @@ def test_nms_tie_rule_and_duplicates():
     np.testing.assert_array_equal(keep, [2, 3])          # tie 0.9/0.9 -> larger index first; dups suppressed
     keep1 = O.subgraph_nms(score, obj, m, 0.75, 1, sort_kind="stable")
     np.testing.assert_array_equal(keep1, [2])
+
+
+def test_scheduled_sampling_path_matches_the_reference(golden):
+    """AttModel.py:157-167 run BY THE REFERENCE with its two random streams replaced by injected numbers
+    (tests/golden/make_golden.py ss_case): the oracle, fed the same numbers, must feed the same words at every step and
+    reproduce outputs, losses and every gradient."""
+    g = golden("subgc_ss_train")
+    ref = g.group("out")
+    w = golden("subgc_train").group("weights")
+    batch = golden("subgc_train").tensors("inputs")
+    orc = O.Oracle(g.opt(gpn_drop_prob=0.0), w, requires_grad=True)
+    orc.training = True
+    assert orc.cfg.ss_prob == 0.25
+    out = O.loss_wrapper(orc, batch, ss=(torch.from_numpy(ref["sel_u"]), torch.from_numpy(ref["u"])))
+    (out["lang_loss"] + out["gpn_loss"]).backward()
+    fed = ref["fed_tokens"]                                       # [steps run, S]: the words the reference actually fed
+    labels = batch["labels"].numpy()
+    assert (fed != labels[:, :fed.shape[0]].T).sum() == g.meta["changed_words"] > 10
+    for i in range(1, fed.shape[0]):
+        want = fed[i]
+        got = orc.ss_tokens[i].numpy() if i in orc.ss_tokens else labels[:, i]
+        np.testing.assert_array_equal(got, want, err_msg=f"words fed at step {i}")
+    close(out["outputs"], ref["outputs"], "outputs")
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss")
+    grads = g.group("grads")
+    dead = set(g.meta["dead_params"])
+    for k, p in orc.P.items():
+        if k in dead:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            close(p.grad, grads[k], "grad " + k, atol=5e-5, rtol=1e-4)
+
+
+def test_loader_restatement_matches_the_reference_getitem(golden):
+    """dataloaders/dataloader.py:139-157,225-367 run by the reference on fabricated dataset entries (golden `loader`): the
+    oracle's sub-graph sampling (same np.random stream), caption picking (same python `random` stream) and tensor building
+    reproduce all 12 model-facing arrays of every image, in the sampled branch and in the `use_gt_subg` branch."""
+    import random as pyrandom
+    from loader_golden import LoaderCase
+    c = LoaderCase(golden)
+    m = c.meta
+    assert set(m["branches"]) == {"pos_pad", "pos_draw", "neg_plain", "neg_all", "neg_le_thres", "neg_few"}
+    for gt, tag in ((0, "smp"), (1, "gt")):
+        np.random.seed(m["np_seed"][gt])
+        pyrandom.seed(m["py_seed"][gt])
+        for b in range(m["n_images"]):
+            im = c.image(b)
+            if gt:
+                ids = c.gt_ids()
+            else:
+                ids = O.choose_subgraphs(im["iou"], m["thres"], c.hb, c.S)
+                np.testing.assert_array_equal(ids, c.out[f"smp{b}_mask_idx"], err_msg=f"image {b}: drawn sub-graph ids")
+            nm, pm, nrel = c.chosen(im, ids)
+            caps = O.pick_captions(c.raw["label"], c.raw["label_start_ix"], c.raw["label_end_ix"], b, c.S, c.Lq)
+            got = O.assemble_image(im["object_fmap"], im["object_dist"], im["rel_ind"], im["pred_dist"], nm, pm, caps, c.obj_num, c.rel_num, nrel)
+            for k, want in c.expect(tag, b).items():
+                assert got[k].shape == want.shape and got[k].dtype == want.dtype, (tag, b, k, got[k].shape, want.shape, got[k].dtype, want.dtype)
+                np.testing.assert_array_equal(got[k], want, err_msg=f"{tag}{b} {k}")

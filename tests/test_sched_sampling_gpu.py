@@ -86,3 +86,31 @@ def test_model_with_scheduled_sampling_matches_oracle(golden):
     m.injected_ss = None
     out2, loss2 = run_train(m, batch)
     assert torch.isfinite(loss2)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_scheduled_sampling_matches_the_reference_golden(golden, packed):
+    """The reference's own run of AttModel.py:157-167 with injected selector / draw numbers (golden `subgc_ss_train`):
+    outputs, loss and every live gradient of the HIP path, through both decoder Functions."""
+    g = golden("subgc_ss_train")
+    ref = g.group("out")
+    w = golden("subgc_train").group("weights")
+    batch = golden("subgc_train").tensors("inputs")
+    m = build(g, w, True)
+    assert m.ss_prob == 0.25
+    m.packed_decoder = packed
+    inj = (torch.from_numpy(ref["sel_u"]).to(DEV), torch.from_numpy(ref["u"]).to(DEV))
+    m.injected_ss = inj
+    out, loss = run_train(m, batch)
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss")
+    grads, dead = g.group("grads"), set(g.meta["dead_params"])
+    for k, p in m.named_parameters():
+        if k in dead:
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            close(p.grad, grads[k], "grad " + k, atol=2e-4, rtol=2e-3)
+    if not packed:
+        m.injected_ss = inj
+        outputs, _, _ = m(*__import__("subgc").synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+        close(outputs, ref["outputs"], "outputs")
