@@ -352,6 +352,26 @@ int subgc_beam_step(const float* tv, const int32_t* ti, int32_t* seq, float* lps
  * sorted[r] = that score (may be NULL).  n <= 8192 (an image has at most 2M candidate sub-graphs).     */
 int subgc_rank_desc_f32(const float* score, int n, int64_t* order, float* sorted, void* stream);
 
+/* ---- bf16-operand GEMM (BASELINE configs 3 / 5: "bf16") ---------------------------------------------------------------
+ * C = epilogue(op(A) . op(B)) with A, B STORED as bf16 (raw uint16 bit patterns), fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16; the result goes to C32 (fp32) and / or C16 (bf16, round-to-nearest-even) -- either may be NULL.
+ * Forms: (transA, transB) = (0,1) x[M,K] W[N,K]^T | (0,0) x[M,K] W[K,N] | (1,0) A stored [K,M], B [K,N].  Bases 16-byte
+ * aligned, lda / ldb multiples of 8; a K-contiguous operand needs K % 8 == 0 (pad with zero columns).
+ * Epilogue as subgc_gemm_f32 (bias[N], add[M,N] fp32, ReLU, dense keep[M,N] mask x keep_scale, ACCUM into C32); m_dev bounds
+ * the rows of the stored A.  `workspace` / `ws_bytes`: caller-owned scratch for the split-K form of THIS call (may be NULL:
+ * no split); stream-ordered, so calls on different streams need different workspaces.                                  */
+int subgc_gemm_bf16(int transA, int transB, int M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B,
+                    int64_t ldb, float* C32, int64_t ldc32, uint16_t* C16, int64_t ldc16, const float* bias,
+                    const float* add, int64_t ldadd, const uint8_t* keep, float keep_scale, int flags,
+                    const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
+int subgc_gemm_bf16_workspace_bytes(int M, int N, int K, size_t* bytes);
+/* y[r, :cols_pad] = bf16(x[r, :cols]) with zero padding columns (cols_pad % 8 == 0, ldy % 8 == 0); rows bounded by *m_dev */
+int subgc_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, int cols_pad,
+                        const int32_t* m_dev, void* stream);
+/* y[c, r] = bf16(x[r, c]) (the W^T snapshots: every data-gradient product becomes an x W^T one) */
+int subgc_transpose_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, void* stream);
+int subgc_copy2d_b16(const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, void* stream);
+
 /* ---- on-device batch assembly (dataloaders/dataloader.py:269-367) ----------------------------------------
  * mask_compact (:276-308): row g of the 0/1 `mask [G, W]` -> ind[g, :] = ascending set positions, padded with `pad`
  * (the dummy node / predicate index) to N columns; att_mask[g, i] = i < count (may be NULL); pool_mtx[g] = the

@@ -6,11 +6,12 @@
 
 Collected as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `--pmc` passes of the
 same bench command (tools/pmc_traffic.sh); rocprofv3 reports both in KiB.  The guide warns that on gfx950 FETCH_SIZE
-can count HALF the bytes of wide streaming reads and asks for a calibration on the kernel's own access pattern:
-tools/pmc_calibrate.sh runs one 128x128 tile over K = 262144 (each operand read exactly once: 268,435,456 B) and
-FETCH_SIZE reports 262,181..262,186 KiB = 268.47 MB for the NT, NN and TN forms alike -- for this kernel's loads
-(global_load_dwordx4 in 128-B row segments) the counter is exact, so NO correction factor is applied.
-WRITE_SIZE is uncalibrated and taken as reported.  A logical launch = one `subgc_gemm_f32` call = its main kernel
+counts HALF the bytes of wide coalesced reads and asks for a calibration on known byte counts in the kernel's own access
+pattern.  Round 2 redid it (tools/pmc_calibrate2.sh -> profiles/r02_pmc_calibration.txt): ONE 64x64 workgroup of this GEMM
+(Grid_Size 256) reading 134,217,728 B counts 67,120,448 B; four workgroups reading 536,870,912 B through four private
+L2s count 268,478,336 B; a 2 GiB float4 streaming read counts 1 GiB -- FETCH_SIZE x 2.0 in every case -- while WRITE_SIZE
+is exact (2 GiB fill: 2,147,483,648 B; the GEMM's 16 / 64 KB of results to the byte).  (Round 1's "factor 1.0" compared the
+four-workgroup launch with the bytes of ONE pass over the operands; each panel is fetched by two XCDs there.)  A logical launch = one `subgc_gemm_f32` call = its main kernel
 plus, in split-K form, the reduce kernel (both are inside the HIP-event bracket that times it in bench.py).
 """
 import argparse
@@ -18,6 +19,7 @@ import collections
 import csv
 import json
 
+FETCH_FACTOR = 2.0          # profiles/r02_pmc_calibration.txt
 FAMILY = ("gemm_f32_kernel", "gemm_f32_splitk_kernel", "splitk_reduce_kernel", "gemm_skinny")
 
 
@@ -46,7 +48,7 @@ def main():
     a = ap.parse_args()
     f, fd = totals(a.fetch_csv, "FETCH_SIZE")
     w, wd = totals(a.write_csv, "WRITE_SIZE")
-    fetch = 1024.0 * sum(f.values())                # KiB -> B; calibrated factor 1.0 (see above)
+    fetch = FETCH_FACTOR * 1024.0 * sum(f.values())  # KiB -> B, x the calibrated factor (see above)
     write = 1024.0 * sum(w.values())
     mains = sum(v for k, v in fd.items() if k != "splitk_reduce_kernel")          # one main kernel per subgc_gemm_f32 call
     if not a.steps_total:
@@ -57,12 +59,13 @@ def main():
         raise SystemExit(f"{mains} GEMM dispatches != {a.steps_total} steps x {a.launches_per_step} launches")
     launches = a.steps_total * a.launches_per_step
     out = {
-        "counters": "FETCH_SIZE (calibrated on this kernel: factor 1.0) + WRITE_SIZE, separate --pmc passes, KiB",
+        "counters": "FETCH_SIZE x 2.0 (gfx950 halving, calibrated: profiles/r02_pmc_calibration.txt) + WRITE_SIZE (exact), separate --pmc passes",
+        "fetch_factor": FETCH_FACTOR,
         "steps_profiled": a.steps_total, "gemm_launches_per_step": a.launches_per_step,
         "kernel_dispatches": fd,
         "fetch_bytes_per_step": fetch / a.steps_total, "write_bytes_per_step": write / a.steps_total,
         "traffic_bytes_per_launch": (fetch + write) / launches,
-        "per_kernel_bytes_per_dispatch": {k: {"fetch": 1024.0 * f[k] / fd[k], "write": 1024.0 * w.get(k, 0.0) / max(wd.get(k, 1), 1)} for k in f},
+        "per_kernel_bytes_per_dispatch": {k: {"fetch": FETCH_FACTOR * 1024.0 * f[k] / fd[k], "write": 1024.0 * w.get(k, 0.0) / max(wd.get(k, 1), 1)} for k in f},
     }
     if a.alg_bytes_per_launch:
         out["algorithmic_bytes_per_launch"] = a.alg_bytes_per_launch
