@@ -13,8 +13,12 @@
  *   - all pointers are BORROWED device pointers owned by the caller (e.g. tensor.data_ptr());
  *     outputs / scratch are caller-allocated; row-major, fp32 unless noted, indices int64 where
  *     the reference uses LongTensor inputs and int32 for internal index structures;
- *   - re-entrant per stream; subgc_last_error() returns a thread-local message for the last
- *     failing call on the calling thread.
+ *   - re-entrant per stream: there is NO process-global scratch or mode -- the entry points that can use a split-K scratch
+ *     take `workspace, ws_bytes` as CALL arguments (subgc_gemm_workspace_bytes / subgc_gemm_bf16_workspace_bytes say how much
+ *     a shape can use; NULL / smaller is legal), so calls on different streams only need different workspaces;
+ *     subgc_last_error() returns a thread-local message for the last failing call on the calling thread;
+ *   - "bf16" tensors are raw uint16 bit patterns (torch.bfloat16 storage); an `*_bf16` int argument says that the named
+ *     destination (or source) pointer, declared void*, holds bf16 instead of fp32.
  */
 #ifndef SUBGC_HIP_H
 #define SUBGC_HIP_H
@@ -77,31 +81,35 @@ int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* 
  */
 #define SUBGC_GEMM_RELU 1
 #define SUBGC_GEMM_ACCUM 2
+/* arithmetic of the 128x128-tile forms, chosen PER CALL in bits 4-5 of `flags` (0 = the process default, which is fp32
+ * unless the environment says SUBGC_GEMM_X3=1|2 at first use):
+ *   F32     v_mfma_f32_32x32x2_f32 on fp32 operands;
+ *   BF16X3  each fp32 operand is split EXACTLY into three bf16 planes and the product is formed from six
+ *           v_mfma_f32_32x32x16_bf16 terms accumulated in fp32 (csrc/gemm_x3.h): fp32-level accuracy at 2.67x the pipe rate;
+ *   BF16R   each fp32 operand is rounded to nearest-even bf16 on its way to LDS, one bf16 MFMA term (storage stays fp32;
+ *           the bf16-STORAGE path of BASELINE configs 3 and 5 is subgc_gemm_bf16 below).                                   */
+#define SUBGC_GEMM_MODE_F32 (1 << 4)
+#define SUBGC_GEMM_MODE_BF16X3 (2 << 4)
+#define SUBGC_GEMM_MODE_BF16R (3 << 4)
+/* workspace / ws_bytes: caller-owned scratch for the split-K forms of THIS call (shapes whose 128x128 tile count cannot
+ * fill the 256 CUs, e.g. the per-step recurrent GEMMs with M = 640, write partial tiles there and reduce them, all ordered
+ * on `stream`).  NULL / 0: those shapes run with 64x64 tiles.  Concurrent calls on different streams need different
+ * workspaces; calls on one stream may share one.                                                                      */
 int subgc_gemm_f32(int transA, int transB, int M, int N, int K,
                    const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                    const float* bias, const float* add, int64_t ldadd,
                    const uint8_t* keep, float keep_scale, int flags,
-                   const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev, void* stream);
-
-/* GEMM arithmetic mode for the 128x128-tile forms (process-wide; also SUBGC_GEMM_X3=0|1 at first use):
- *   0  v_mfma_f32_32x32x2_f32 on fp32 operands;
- *   1  each fp32 operand is split EXACTLY into three bf16 planes and the product is formed from six
- *      v_mfma_f32_32x32x16_bf16 terms accumulated in fp32 (csrc/gemm_x3.h): fp32-level accuracy at
- *      2.67x the matrix-pipe rate;
- *   2  bf16 compute (BASELINE configs 3 and 5): each fp32 operand is rounded to nearest-even bf16 on its way
- *      to LDS, one v_mfma_f32_32x32x16_bf16 term.  Inputs, outputs and accumulation stay fp32 in every mode. */
-int subgc_set_gemm_mode(int mode);
-
-/* Optional scratch for the split-K form of subgc_gemm_f32 (used for shapes whose 128x128 tile count
- * cannot fill the 256 CUs, e.g. the per-step recurrent GEMMs with M = 640): a caller-owned device
- * buffer into which partial tiles are written and from which they are reduced, all stream-ordered on
- * the GEMM's stream.  Without a workspace those shapes run with 64x64 tiles.  One stream at a time
- * may issue GEMMs while a workspace is registered.  ptr = NULL, bytes = 0 unregisters.            */
-int subgc_set_workspace(void* ptr, size_t bytes);
+                   const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev,
+                   void* workspace, size_t ws_bytes, void* stream);
+/* the most scratch subgc_gemm_f32 can use for a shape (0: it never splits) */
+int subgc_gemm_workspace_bytes(int M, int N, int K, size_t* bytes);
 
 /* column sums: out[n] (+)= sum_m X[m, n]  -- bias gradients.  accumulate != 0 adds to out. */
 int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
                      const int32_t* m_dev, void* stream);
+/* the same over bf16 rows: bias gradients from bf16-stored gate / logit gradients */
+int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, float* out, int accumulate,
+                      const int32_t* m_dev, void* stream);
 
 /* ======================================================================================
  * Index kernels (bit-exact)
@@ -212,7 +220,7 @@ int subgc_pack_rows(const int32_t* len, const int64_t* idx, int64_t idx_stride, 
  * steps at once).  tok int64 [n] (tok_stride elements apart); out [n,E].  bwd scatter-adds
  * dEmb[tok] += dxt * [Emb[tok] > 0] * keep * scale with fp32 atomics.                         */
 int subgc_embed_fwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep,
-                    float keep_scale, float* out, int n, int E, int vocab_rows, void* stream);
+                    float keep_scale, void* out, int n, int E, int vocab_rows, int out_bf16, void* stream);
 int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep,
                     float keep_scale, const float* dout, float* dtable, int n, int E, int vocab_rows,
                     void* stream);
@@ -245,26 +253,30 @@ int subgc_token_rows_f32(const float* table, int64_t ldt, const int64_t* tok, in
  *   (0 = all S) limit how many leading rows of h / h2 are written: with sentences sorted by length
  *   the next step only consumes a prefix of them (packed decoder).                              */
 int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int64_t ld1, const float* g2, int64_t ld2,
-                   const float* b0, const float* b1, const float* c_prev, float* c, float* h, int64_t ldh,
-                   float* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd,
-                   float* gates, int S, int R, int rows_h, int rows_h2,
+                   const float* b0, const float* b1, const float* c_prev, float* c, void* h, int64_t ldh,
+                   void* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, void* hdrop, int64_t ldhd,
+                   float* gates, int S, int R, int rows_h, int rows_h2, int h_bf16,
                    void* stream);
 /* subgc_gemm_f32(x . w^T) + subgc_lstm_fwd in one call for the teacher-forced steps (S in the hundreds): when the product
  * takes the split-K form its partial planes stay in the workspace and the cell kernel adds them while it reads the
  * pre-activations (no reduce launch, no [S,4R] round trip); otherwise the product goes to `pre` [S, >= 4R] (scratch) and the
- * two entry points run back to back.  w [4R, K] = [W_ih(cols) | W_hh] K-concatenated; remaining arguments as subgc_lstm_fwd.  */
-int subgc_lstm_fwd_gemm(const float* x, int64_t ldx, const float* w, int64_t ldw, int K, float* pre, int64_t ldpre,
+ * two entry points run back to back.  w [4R, K] = [W_ih(cols) | W_hh] K-concatenated; remaining arguments as subgc_lstm_fwd.
+ * bf16_bits: bit 0 = x and w are bf16 (the product runs as subgc_gemm_bf16), bit 1 = the h destinations are bf16;
+ * gemm_flags: the SUBGC_GEMM_MODE_* bits of the fp32 product; workspace / ws_bytes: as subgc_gemm_f32.                    */
+int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, int K, float* pre, int64_t ldpre,
                         const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1,
-                        const float* c_prev, float* c, float* h, int64_t ldh, float* h2, int64_t ldh2,
-                        const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd, float* gates, int S, int R,
-                        int rows_h, int rows_h2, void* stream);
+                        const float* c_prev, float* c, void* h, int64_t ldh, void* h2, int64_t ldh2,
+                        const uint8_t* keep, float keep_scale, void* hdrop, int64_t ldhd, float* gates, int S, int R,
+                        int rows_h, int rows_h2, int bf16_bits, int gemm_flags, void* workspace, size_t ws_bytes,
+                        void* stream);
 
 /* dh (up to two sources summed: dh_a, dh_b, either may be NULL) and dc (may be NULL) ->
  * dpre [S,4R] and dc_prev.  dh_drop (optional) is a gradient that arrives through the dropout
  * mask (keep/keep_scale).                                                                    */
 int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda,
                    const float* dh_b, int64_t ldb, const float* dh_drop, int64_t ldd, const uint8_t* keep,
-                   float keep_scale, const float* dc, float* dpre, float* dc_prev, int S, int R, void* stream);
+                   float keep_scale, const float* dc, void* dpre, float* dc_prev, int S, int R, int dpre_bf16,
+                   void* stream);
 
 /* one attention step over the ragged node sets (AttModel.py:453-466):
  *   e_i = <w_a, tanh(u[m,:] + ah[s,:])> + b_a ; alpha = softmax over the sentence's valid rows
@@ -273,24 +285,24 @@ int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, cons
  * u [rows,A], v [rows,R] packed; ah [S,A]; alpha_out [S,n_stride] (entries i >= len are 0);
  * ctx written with leading dim ldctx.                                                        */
 int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a,
-                   const int32_t* off, const int32_t* len, float* ctx, int64_t ldctx, float* alpha,
-                   int n_stride, int S, int A, int R, void* stream);
+                   const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha,
+                   int n_stride, int S, int A, int R, int ctx_bf16, void* stream);
 /* backward of one step: dctx [S,R] (ld lddctx) -> dah [S,A]; du, dv ACCUMULATE (+=) over steps;
  * dw_a [S,A] and db_a [S] receive PER-SENTENCE partial gradients of w_a / b_a (plain stores; the
  * caller column-sums them once over all steps: 640 workgroups x 512 same-address atomics per step
  * cost more than the rest of the kernel).                                                    */
 int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off,
                    const int32_t* len, const float* alpha, int n_stride, const float* dctx, int64_t lddctx,
-                   float* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R,
-                   void* stream);
+                   void* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R,
+                   int dah_bf16, void* stream);
 
 /* in-place row log-softmax of logits[rows, V] (AttModel.py:336,340).  active (int32 [rows] or
  * NULL): rows with active == 0 are written as zeros (the reference leaves `outputs` rows of the
  * steps after its early break at zero, AttModel.py:152,171-172).                              */
 int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, const int32_t* active, void* stream);
 /* dlogits = dout - exp(logp) * sum(dout); dlogits may alias dout (in place).                 */
-int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, float* dlogits, int64_t ld, int rows,
-                               int V, const int32_t* active, void* stream);
+int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, void* dlogits, int64_t ld, int rows,
+                               int V, const int32_t* active, int out_bf16, void* stream);
 /* LanguageModelCriterion (misc/utils.py:115-124): num = -sum mask*logp[target], den = sum mask,
  * loss = num/den.  logp [S,T,V]; target, mask are [S,T] views of the [S,T+1] label/mask tensors
  * shifted by one (row strides t_stride / m_stride).  bwd writes dlogp (dense, zero elsewhere). */
@@ -303,8 +315,8 @@ int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* m
  * log-probabilities, as LossWrapper does): dlogits = dloss * mask/den * (softmax - onehot(target));
  * never materialises the dense dlogp.  scratch2 is the {num, den} pair written by masked_nll_fwd.  */
 int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask,
-                             int64_t m_stride, const float* scratch2, const float* dloss, float* dlogits,
-                             int S, int T, int V, const int32_t* active, void* stream);
+                             int64_t m_stride, const float* scratch2, const float* dloss, void* dlogits,
+                             int64_t ld_out, int S, int T, int V, const int32_t* active, int out_bf16, void* stream);
 /* step_active[t] = 1 for t = 0 and for t >= 1 while no earlier step had all labels[:, t] == 0
  * (AttModel.py:171-172), expanded to rows: active[s*T + t].                                  */
 int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream);
@@ -356,7 +368,7 @@ int subgc_rank_desc_f32(const float* score, int n, int64_t* order, float* sorted
  * C = epilogue(op(A) . op(B)) with A, B STORED as bf16 (raw uint16 bit patterns), fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16; the result goes to C32 (fp32) and / or C16 (bf16, round-to-nearest-even) -- either may be NULL.
  * Forms: (transA, transB) = (0,1) x[M,K] W[N,K]^T | (0,0) x[M,K] W[K,N] | (1,0) A stored [K,M], B [K,N].  Bases 16-byte
- * aligned, lda / ldb multiples of 8; a K-contiguous operand needs K % 8 == 0 (pad with zero columns).
+ * aligned, lda / ldb multiples of 8 (M, N, K arbitrary: a row may be over-read up to its ld, which is masked).
  * Epilogue as subgc_gemm_f32 (bias[N], add[M,N] fp32, ReLU, dense keep[M,N] mask x keep_scale, ACCUM into C32); m_dev bounds
  * the rows of the stored A.  `workspace` / `ws_bytes`: caller-owned scratch for the split-K form of THIS call (may be NULL:
  * no split); stream-ordered, so calls on different streams need different workspaces.                                  */
@@ -403,17 +415,18 @@ int subgc_multinomial_rows(const float* logits, int64_t ld, int rows, int V, con
 
 /* Packed (length-sorted) decoder: dst[s, :C] = sum_t src[offsets[t] + s, :C] over the steps t with s < offsets[t+1] - offsets[t]
  * (offsets int32 [T+1] on the device, step sizes non-increasing).  The gradient of the loop-invariant fc->gates term. */
-int subgc_packed_time_sum(const float* src, const int32_t* offsets, int T, int S, int C, float* dst, void* stream);
+int subgc_packed_time_sum(const void* src, const int32_t* offsets, int T, int S, int C, float* dst, int src_bf16,
+                          void* stream);
 
 /* dropout keep-mask generator (counter-based, Philox-4x32-10): keep[i] = uniform(seed, offset+i) >= p */
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 /* small utilities */
 /* dz = dy * scale * [y > 0]   (backward of y = relu(z) * keep * scale: y > 0 <=> z > 0 and kept) */
-int subgc_relu_bwd(const float* dy, const float* y, float scale, float* dz, int64_t n, void* stream);
+int subgc_relu_bwd(const float* dy, const float* y, float scale, void* dz, int64_t n, int out_bf16, void* stream);
 /* dst[m, :] = src[rows[m], :] for m < min(M, *m_dev); negative rows give zero rows               */
-int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, float* dst, int64_t ldd,
-                      int M, int L, const int32_t* m_dev, void* stream);
+int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, void* dst, int64_t ldd,
+                      int M, int L, const int32_t* m_dev, int out_bf16, void* stream);
 /* the same gather for `count` (1..4) tensors in one launch: dst_k[m, :c_k] = src_k[rows[m], :c_k] -- the state fork of beam
  * search (CaptionModel.py:76-90: h and c of both LSTMs follow the surviving beams), four tensors per step            */
 int subgc_gather_rows_multi(int count, const float* s0, int64_t lds0, float* d0, int64_t ldd0, int c0, const float* s1,
@@ -432,11 +445,13 @@ int subgc_scatter_add_rows(const float* src, int64_t lds, const int32_t* rows, f
  * pass 1 accumulates sum(g^2) into *sumsq (caller zeroes it), pass 2 applies
  * g *= max_norm / max(sqrt(sumsq), max_norm) (utils.py:193) and the torch.optim.Adam update.  grad_scale (1 for one GPU,
  * 1/world after a SUM all-reduce: DataParallel's mean of the replica losses, train.py:154-156) multiplies g first -- norm and
- * update see the averaged gradient without a separate pass over the bucket; g is left scaled and clipped.            */
+ * update see the averaged gradient without a separate pass over the bucket; g is left scaled and clipped.
+ * p_bf16 (optional, n elements): the bf16 snapshot of the updated weights, written in the same sweep (what the bf16-storage
+ * GEMMs of BASELINE configs 3 / 5 read).                                                                                */
 int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* stream);
 int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         int step, float grad_scale, void* stream);
+                         int step, float grad_scale, uint16_t* p_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 // global round trip per loop iteration.
 // Reference: AttModel.py:453-466 (forward), its autograd backward.
 #include "common.h"
+#include "bf16_util.h"
 
 namespace {
 
@@ -20,8 +21,8 @@ template <int CA, int CR>
 __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
                                                            const float* __restrict__ b_a, const int32_t* __restrict__ off,
-                                                           const int32_t* __restrict__ len, float* __restrict__ ctx, int64_t ldctx,
-                                                           float* __restrict__ alpha, int n_stride, int A, int R) {
+                                                           const int32_t* __restrict__ len, void* __restrict__ ctx, int64_t ldctx,
+                                                           float* __restrict__ alpha, int n_stride, int A, int R, int ctx_b16) {
     __shared__ float e_s[MAXLEN];
     const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l = min(len[s], MAXLEN), m0 = off[s];
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restri
             const float a0 = e_s[i];
             acc.x += a0 * x0.x; acc.y += a0 * x0.y; acc.z += a0 * x0.z; acc.w += a0 * x0.w;
         }
-        st4(ctx + (int64_t)s * ldctx + r4 * 4, acc);
+        const float o[4] = {acc.x, acc.y, acc.z, acc.w};        // the context row is the lang-LSTM GEMM's operand: bf16 when asked
+        subgc_store_act<4>(ctx, (int64_t)s * ldctx + r4 * 4, o, ctx_b16);
     }
 }
 
@@ -89,9 +91,9 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restri
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
                                                            const int32_t* __restrict__ off, const int32_t* __restrict__ len,
                                                            const float* __restrict__ alpha, int n_stride,
-                                                           const float* __restrict__ dctx, int64_t lddctx, float* __restrict__ dah,
+                                                           const float* __restrict__ dctx, int64_t lddctx, void* __restrict__ dah,
                                                            float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
-                                                           float* __restrict__ db_a, int A, int R) {
+                                                           float* __restrict__ db_a, int A, int R, int dah_b16) {
     __shared__ float al_s[MAXLEN];    // alpha, then de
     __shared__ float da_s[MAXLEN];    // dalpha
     __shared__ float4 part_d[128], part_w[128];
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restri
             const float4 od = part_d[t & 127], ow = part_w[t & 127];
             dsum.x += od.x; dsum.y += od.y; dsum.z += od.z; dsum.w += od.w;
             wsum.x += ow.x; wsum.y += ow.y; wsum.z += ow.z; wsum.w += ow.w;
-            st4(dah + (int64_t)s * A + a4 * 4, dsum);
+            const float o[4] = {dsum.x, dsum.y, dsum.z, dsum.w};
+            subgc_store_act<4>(dah, (int64_t)s * A + a4 * 4, o, dah_b16);
             st4(dw_a + (int64_t)s * A + a4 * 4, wsum);      // per-sentence partial; the caller column-sums once over all steps
         }
     }
@@ -178,13 +181,13 @@ namespace subgc {
 
 // return -100 when the vector form does not apply
 int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
-                 const int32_t* len, float* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, hipStream_t s) {
+                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, hipStream_t s) {
     if (A % 4 || R % 4 || ldctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(ctx)) return -100;
     const int ca = (A / 4 + 63) / 64, cr = (R / 4 + 255) / 256;
     if (ca > 2 || cr > 2) return -100;
 #define SUBGC_ATT_FWD(CA_, CR_)                                                                                                  \
     hipLaunchKernelGGL((attn_fwd_vec_kernel<CA_, CR_>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, \
-                       n_stride, A, R)
+                       n_stride, A, R, ctx_b16)
     if (ca == 1 && cr == 1) SUBGC_ATT_FWD(1, 1);
     else if (ca == 2 && cr == 1) SUBGC_ATT_FWD(2, 1);
     else if (ca == 1 && cr == 2) SUBGC_ATT_FWD(1, 2);
@@ -194,8 +197,8 @@ int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w
 }
 
 int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
-                 const float* alpha, int n_stride, const float* dctx, int64_t lddctx, float* dah, float* du, float* dv, float* dw_a,
-                 float* db_a, int S, int A, int R, hipStream_t s) {
+                 const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
+                 float* db_a, int S, int A, int R, int dah_b16, hipStream_t s) {
     if (A % 4 || R % 4 || lddctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
         !al16(dv) || !al16(dw_a))
         return -100;
@@ -203,7 +206,7 @@ int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w
     if (ca > 2 || cr > 8) return -100;
 #define SUBGC_ATT_BWD(CA_, CR_)                                                                                                     \
     hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, \
-                       dah, du, dv, dw_a, db_a, A, R)
+                       dah, du, dv, dw_a, db_a, A, R, dah_b16)
     if (ca == 1) {
         if (cr <= 1) SUBGC_ATT_BWD(1, 1); else if (cr <= 2) SUBGC_ATT_BWD(1, 2); else if (cr <= 4) SUBGC_ATT_BWD(1, 4); else SUBGC_ATT_BWD(1, 8);
     } else {

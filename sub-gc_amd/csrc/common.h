@@ -36,16 +36,19 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // gemm_skinny.hip: C[M,N] = act(A[M,K] W[N,K]^T + bias) for M <= 16 (weight-streaming bound); returns -100
 // when the shape is not covered (caller falls back to the tiled MFMA kernels).
-int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, hipStream_t s, const float** ws, int* splits);
+int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, int gemm_flags, float* ws, size_t ws_bytes,
+                     hipStream_t s, int* splits);
+int gemm_bf16_nt_partials(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, float* ws, size_t ws_bytes,
+                          hipStream_t s, int* splits);
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N,
                    int K, int relu, hipStream_t stream, const float* add = nullptr, int64_t ldadd = 0);
 
 // attention_vec.hip: float4 forms of the per-step attention kernels; return -100 when they do not apply
 int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
-                 const int32_t* len, float* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, hipStream_t s);
+                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, hipStream_t s);
 int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
-                 const float* alpha, int n_stride, const float* dctx, int64_t lddctx, float* dah, float* du, float* dv, float* dw_a,
-                 float* db_a, int S, int A, int R, hipStream_t s);
+                 const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
+                 float* db_a, int S, int A, int R, int dah_b16, hipStream_t s);
 
 }  // namespace subgc
 

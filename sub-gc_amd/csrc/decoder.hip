@@ -7,6 +7,7 @@
 // (LSTMCell), :445-471 (Attention), :336,340 (log_softmax), :295-316 (token choice),
 // misc/utils.py:115-124 (criterion), :174-200,234-235 (clip-norm, Adam).
 #include "common.h"
+#include "bf16_util.h"
 
 #include <algorithm>
 
@@ -59,14 +60,15 @@ __global__ __launch_bounds__(1024) void pack_rows_kernel(const int32_t* __restri
 // ------------------------------------------------------------------ embedding (+ReLU +dropout)
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
                                                         int64_t tok_stride, const uint8_t* __restrict__ keep, float scale,
-                                                        float* __restrict__ out, int n, int E, int rows) {
+                                                        void* __restrict__ out, int n, int E, int rows, int b16) {
     const int r = blockIdx.x;
     int64_t w = tok[(int64_t)r * tok_stride];
     w = w < 0 ? 0 : (w >= rows ? rows - 1 : w);
     for (int c = threadIdx.x; c < E; c += blockDim.x) {
         float v = fmaxf(table[w * E + c], 0.f);
         if (keep) v = keep[(int64_t)r * E + c] ? v * scale : 0.f;
-        out[(int64_t)r * E + c] = v;
+        const float o[1] = {v};
+        subgc_store_act<1>(out, (int64_t)r * E + c, o, b16);
     }
 }
 // plain row lookup by token: out[r, :] = table[tok[r], :]  (decode-time x->gates table, see subgc_token_rows_f32)
@@ -125,10 +127,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
                                                        int64_t ld1, const float* __restrict__ g2, int64_t ld2,
                                                        const float* __restrict__ b0, const float* __restrict__ b1,
                                                        const float* __restrict__ c_prev, float* __restrict__ c,
-                                                       float* __restrict__ h, int64_t ldh, float* __restrict__ h2, int64_t ldh2,
-                                                       const uint8_t* __restrict__ keep, float scale, float* __restrict__ hdrop,
+                                                       void* __restrict__ h, int64_t ldh, void* __restrict__ h2, int64_t ldh2,
+                                                       const uint8_t* __restrict__ keep, float scale, void* __restrict__ hdrop,
                                                        int64_t ldhd, float* __restrict__ gates, int S, int R, int rows_h, int rows_h2,
-                                                       int parts, int64_t plane) {
+                                                       int parts, int64_t plane, int hb16) {
+    // hb16: the three h destinations are bf16 (they are GEMM operands only: the next step's / the logit product's A rows)
     // parts > 1: g0 is a stack of split-K partial planes g0[p * plane + ...] (subgc_lstm_fwd_gemm): summed here, no reduce pass
     const int RV = R / VW;
     const int64_t qv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,15 +171,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         hn[e] = og[e] * tanhf(cn[e]);
     }
     stv<VW>(c + q, cn);
-    if (s < rows_h) stv<VW>(h + (int64_t)s * ldh + j, hn);
-    if (h2 && s < rows_h2) stv<VW>(h2 + (int64_t)s * ldh2 + j, hn);
+    if (s < rows_h) subgc_store_act<VW>(h, (int64_t)s * ldh + j, hn, hb16);
+    if (h2 && s < rows_h2) subgc_store_act<VW>(h2, (int64_t)s * ldh2 + j, hn, hb16);
     if (hdrop) {
         float hd[VW];
         bool kp[VW];
         if (keep) ldk<VW>(keep + q, kp);
 #pragma unroll
         for (int e = 0; e < VW; ++e) hd[e] = keep ? (kp[e] ? hn[e] * scale : 0.f) : hn[e];
-        stv<VW>(hdrop + (int64_t)s * ldhd + j, hd);
+        subgc_store_act<VW>(hdrop, (int64_t)s * ldhd + j, hd, hb16);
     }
     if (gates) {
         float* gp = gates + (int64_t)s * 4 * R + j;
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ c, const float* __restrict__ dh_a, int64_t lda,
                                                        const float* __restrict__ dh_b, int64_t ldb, const float* __restrict__ dh_d,
                                                        int64_t ldd, const uint8_t* __restrict__ keep, float scale,
-                                                       const float* __restrict__ dc, float* __restrict__ dpre,
-                                                       float* __restrict__ dc_prev, int S, int R) {
+                                                       const float* __restrict__ dc, void* __restrict__ dpre,
+                                                       float* __restrict__ dc_prev, int S, int R, int pb16) {
     const int RV = R / VW;
     const int64_t qv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qv >= (int64_t)S * RV) return;
@@ -229,8 +232,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         d3[e] = dh[e] * tc * og[e] * (1.f - og[e]);
         dcp[e] = dct * fg[e];
     }
-    float* dp = dpre + (int64_t)s * 4 * R + j;
-    stv<VW>(dp, d0); stv<VW>(dp + R, d1); stv<VW>(dp + 2 * R, d2); stv<VW>(dp + 3 * R, d3);
+    const int64_t dp = (int64_t)s * 4 * R + j;                  // gate gradients: GEMM operands only -> may be stored bf16
+    subgc_store_act<VW>(dpre, dp, d0, pb16); subgc_store_act<VW>(dpre, dp + R, d1, pb16);
+    subgc_store_act<VW>(dpre, dp + 2 * R, d2, pb16); subgc_store_act<VW>(dpre, dp + 3 * R, d3, pb16);
     stv<VW>(dc_prev + q, dcp);
 }
 
@@ -360,21 +364,25 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x,
         if (c < V) p[c] = v[j] - lse;
     }
 }
-__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ logp, const float* dout, float* dlogits,
-                                                              int64_t ld, int rows, int V, const int32_t* __restrict__ active) {
+__device__ __forceinline__ void store_one(void* base, int64_t i, float v, int b16) {
+    if (b16) static_cast<uint16_t*>(base)[i] = (uint16_t)subgc_f2bf(v);
+    else static_cast<float*>(base)[i] = v;
+}
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ logp, const float* dout, void* dlogits,
+                                                              int64_t ld, int rows, int V, const int32_t* __restrict__ active, int b16) {
     __shared__ float sm[16];
     const int r = blockIdx.x;
     const float* lp = logp + (int64_t)r * ld;
     const float* d = dout + (int64_t)r * ld;
-    float* o = dlogits + (int64_t)r * ld;
+    const int64_t o = (int64_t)r * ld;
     if (active && !active[r]) {
-        for (int c = threadIdx.x; c < V; c += blockDim.x) o[c] = 0.f;
+        for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, o + c, 0.f, b16);
         return;
     }
     float sum = 0.f;
     for (int c = threadIdx.x; c < V; c += blockDim.x) sum += d[c];
     sum = block_sum(sum, sm);
-    for (int c = threadIdx.x; c < V; c += blockDim.x) o[c] = d[c] - expf(lp[c]) * sum;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, o + c, d[c] - expf(lp[c]) * sum, b16);
 }
 __global__ __launch_bounds__(1024) void nll_fwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
                                                        int64_t t_stride, const float* __restrict__ mask, int64_t m_stride,
@@ -409,20 +417,21 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* __restrict_
 __global__ __launch_bounds__(256) void nll_logsoftmax_bwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
                                                                  int64_t t_stride, const float* __restrict__ mask, int64_t m_stride,
                                                                  const float* __restrict__ scratch2, const float* __restrict__ dloss,
-                                                                 float* __restrict__ dlogits, int T, int V,
-                                                                 const int32_t* __restrict__ active) {
+                                                                 void* __restrict__ dlogits, int64_t ldo, int T, int V,
+                                                                 const int32_t* __restrict__ active, int b16) {
+    // b16: d(logits) is a GEMM operand only (weight gradient and d(hidden)): written bf16, half the bytes of the largest tensor
     const int r = blockIdx.x, s = r / T, t = r % T;
     const float m = mask[(int64_t)s * m_stride + t];
-    float* d = dlogits + (int64_t)r * V;
+    const int64_t d = (int64_t)r * ldo;
     if (m == 0.f || (active && !active[r])) {
-        for (int c = threadIdx.x; c < V; c += blockDim.x) d[c] = 0.f;
+        for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, d + c, 0.f, b16);
         return;
     }
     int64_t w = target[(int64_t)s * t_stride + t];
     w = w < 0 ? 0 : (w >= V ? V - 1 : w);
     const float g = dloss[0] * m / scratch2[1];
     const float* lp = logp + (int64_t)r * V;
-    for (int c = threadIdx.x; c < V; c += blockDim.x) d[c] = g * (expf(lp[c]) - (c == (int)w ? 1.f : 0.f));
+    for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, d + c, g * (expf(lp[c]) - (c == (int)w ? 1.f : 0.f)), b16);
 }
 __global__ __launch_bounds__(256) void step_active_kernel(const int64_t* __restrict__ labels, int64_t l_stride, int S, int T,
                                                           int32_t* __restrict__ active) {
@@ -599,18 +608,18 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     if (r < 0) return;
     for (int c = threadIdx.x; c < L; c += blockDim.x) unsafeAtomicAdd(dX + (int64_t)r * ldx + c, src[(int64_t)m * lds_ + c]);
 }
-__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float scale, float* __restrict__ dz, int64_t n) {
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float scale, void* __restrict__ dz, int64_t n, int b16) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+        store_one(dz, i, y[i] > 0.f ? dy[i] * scale : 0.f, b16);
 }
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ rows,
-                                                          float* __restrict__ dst, int64_t ldd, int M, int L,
-                                                          const int32_t* __restrict__ m_dev) {
+                                                          void* __restrict__ dst, int64_t ldd, int M, int L,
+                                                          const int32_t* __restrict__ m_dev, int b16) {
     if (m_dev) M = min(M, *m_dev);
     const int m = blockIdx.x;
     if (m >= M) return;
     const int r = rows[m];
-    for (int c = threadIdx.x; c < L; c += blockDim.x) dst[(int64_t)m * ldd + c] = r >= 0 ? src[(int64_t)r * lds_ + c] : 0.f;
+    for (int c = threadIdx.x; c < L; c += blockDim.x) store_one(dst, (int64_t)m * ldd + c, r >= 0 ? src[(int64_t)r * lds_ + c] : 0.f, b16);
 }
 // the same row gather for up to four tensors in ONE launch (blockIdx.y picks the tensor): the beam-search state fork
 struct GatherSet { const float* src[4]; float* dst[4]; int64_t lds[4], ldd[4]; int cols[4]; };
@@ -632,7 +641,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, const float* __restrict__ sumsq,
                                                         float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                        float bc2, float gscale) {
+                                                        float bc2, float gscale, uint16_t* __restrict__ p16) {
     // misc/utils.py:193: coef = clip / max(total_norm, clip); gscale (1/world after a SUM all-reduce) is applied first
     const float coef = gscale * (max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]) * gscale, max_norm) : 1.f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -643,7 +652,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
         const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-        p[i] = p[i] - (lr / bc1) * (mi / denom);
+        const float pn = p[i] - (lr / bc1) * (mi / denom);
+        p[i] = pn;
+        if (p16) p16[i] = (uint16_t)subgc_f2bf(pn);              // the bf16 weight snapshot the bf16 GEMMs read, refreshed in the same sweep
     }
 }
 
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(256) void sumsq_vec_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void clip_adam_vec_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                             float4* __restrict__ v, int64_t n4, const float* __restrict__ sumsq,
                                                             float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                            float bc2, float gscale) {
+                                                            float bc2, float gscale, uint16_t* __restrict__ p16) {
     const float coef = gscale * (max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]) * gscale, max_norm) : 1.f);
     const float rs2 = sqrtf(bc2), step = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -679,6 +690,7 @@ __global__ __launch_bounds__(256) void clip_adam_vec_kernel(float4* __restrict__
             pp[e] = pp[e] - step * (mi / denom);
         }
         g[i] = G; m[i] = M; v[i] = V; p[i] = P;
+        if (p16) *reinterpret_cast<uint2*>(p16 + 4 * i) = subgc_pack4(P.x, P.y, P.z, P.w);
     }
 }
 
@@ -696,12 +708,12 @@ SUBGC_API int subgc_pack_rows(const int32_t* len, const int64_t* idx, int64_t id
 }
 
 SUBGC_API int subgc_embed_fwd(const float* table, const int64_t* tok, int64_t tok_stride, const uint8_t* keep, float keep_scale,
-                              float* out, int n, int E, int vocab_rows, void* stream) {
+                              void* out, int n, int E, int vocab_rows, int out_bf16, void* stream) {
     SUBGC_REQUIRE(n >= 0 && E > 0 && vocab_rows > 0, "embed_fwd: bad sizes");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(table && tok && out, "embed_fwd: null pointer");
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, tok, tok_stride, keep, keep_scale, out, n,
-                       E, vocab_rows);
+                       E, vocab_rows, out_bf16);
     return subgc::check_launch("subgc_embed_fwd");
 }
 SUBGC_API int subgc_token_rows_f32(const float* table, int64_t ldt, const int64_t* tok, int64_t tok_stride, float* out, int64_t ldo,
@@ -725,9 +737,9 @@ SUBGC_API int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t to
 }
 
 SUBGC_API int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0,
-                             const float* b1, const float* c_prev, float* c, float* h, int64_t ldh, float* h2, int64_t ldh2,
-                             const uint8_t* keep, float keep_scale, float* hdrop, int64_t ldhd, float* gates, int S, int R,
-                             int rows_h, int rows_h2, void* stream) {
+                             const float* b1, const float* c_prev, float* c, void* h, int64_t ldh, void* h2, int64_t ldh2,
+                             const uint8_t* keep, float keep_scale, void* hdrop, int64_t ldhd, float* gates, int S, int R,
+                             int rows_h, int rows_h2, int h_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 0 && R > 0, "lstm_fwd: bad sizes");
     if (rows_h <= 0 || rows_h > S) rows_h = S;
     if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
@@ -742,45 +754,53 @@ SUBGC_API int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int6
                      (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
     if (vec)
         hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev,
-                           c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, 1, 0);
+                           c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, 1, 0, h_bf16);
     else
         hipLaunchKernelGGL(lstm_fwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, ld0, g1, ld1, g2, ld2, b0, b1, c_prev, c,
-                           h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, 1, 0);
+                           h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, 1, 0, h_bf16);
     return subgc::check_launch("subgc_lstm_fwd");
 }
 // gate GEMM + cell update with the split-K reduce folded into the cell kernel (training steps, S in the hundreds)
-SUBGC_API int subgc_lstm_fwd_gemm(const float* x, int64_t ldx, const float* w, int64_t ldw, int K, float* pre, int64_t ldpre, const float* g1,
+SUBGC_API int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, int K, float* pre, int64_t ldpre, const float* g1,
                                   int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c,
-                                  float* h, int64_t ldh, float* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, float* hdrop,
-                                  int64_t ldhd, float* gates, int S, int R, int rows_h, int rows_h2, void* stream) {
+                                  void* h, int64_t ldh, void* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, void* hdrop,
+                                  int64_t ldhd, float* gates, int S, int R, int rows_h, int rows_h2, int bf16_bits, int gemm_flags,
+                                  void* workspace, size_t ws_bytes, void* stream) {
+    // bf16_bits: bit 0 = x and w are bf16 (subgc_gemm_bf16 arithmetic), bit 1 = the h destinations are bf16
     SUBGC_REQUIRE(S >= 0 && R > 0 && K > 0, "lstm_fwd_gemm: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(x && w && pre && c && h && ldpre >= 4 * R, "lstm_fwd_gemm: null pointer / scratch too narrow");
     hipStream_t s = (hipStream_t)stream;
-    const float* ws = nullptr;
+    float* const ws = static_cast<float*>(workspace);
+    const int xb16 = bf16_bits & 1, h_bf16 = (bf16_bits >> 1) & 1;
     int parts = 0;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = R % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && ldh % 4 == 0 && ldh2 % 4 == 0 && ldhd % 4 == 0 && al(g1) && al(g2) && al(b0) &&
                      al(b1) && al(c_prev) && al(c) && al(h) && al(h2) && al(hdrop) && al(gates) && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
-    int rc = vec ? subgc::gemm_nt_partials(x, ldx, w, ldw, S, 4 * R, K, s, &ws, &parts) : -100;
-    if (rc == -100)                                                               // not the split-K shape: plain product, then the cell kernel
-        return (rc = subgc_gemm_f32(0, 1, S, 4 * R, K, x, ldx, w, ldw, pre, ldpre, nullptr, nullptr, 0, nullptr, 1.f, 0, nullptr, nullptr, nullptr,
-                                    stream)) != SUBGC_OK
-                   ? rc
-                   : subgc_lstm_fwd(pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R,
-                                    rows_h, rows_h2, stream);
+    int rc = !vec ? -100
+             : xb16 ? subgc::gemm_bf16_nt_partials(static_cast<const uint16_t*>(x), ldx, static_cast<const uint16_t*>(w), ldw, S, 4 * R, K, ws, ws_bytes, s, &parts)
+                    : subgc::gemm_nt_partials(static_cast<const float*>(x), ldx, static_cast<const float*>(w), ldw, S, 4 * R, K, gemm_flags, ws, ws_bytes, s, &parts);
+    if (rc == -100) {                                                             // not the split-K shape: plain product, then the cell kernel
+        rc = xb16 ? subgc_gemm_bf16(0, 1, S, 4 * R, K, static_cast<const uint16_t*>(x), ldx, static_cast<const uint16_t*>(w), ldw, pre, ldpre, nullptr, 0,
+                                    nullptr, nullptr, 0, nullptr, 1.f, 0, nullptr, workspace, ws_bytes, stream)
+                  : subgc_gemm_f32(0, 1, S, 4 * R, K, static_cast<const float*>(x), ldx, static_cast<const float*>(w), ldw, pre, ldpre, nullptr, nullptr, 0,
+                                   nullptr, 1.f, gemm_flags & ~15, nullptr, nullptr, nullptr, workspace, ws_bytes, stream);
+        return rc != SUBGC_OK ? rc
+                              : subgc_lstm_fwd(pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates,
+                                               S, R, rows_h, rows_h2, h_bf16, stream);
+    }
     if (rc != SUBGC_OK) return rc;
     if (rows_h <= 0 || rows_h > S) rows_h = S;
     if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
     const int64_t n = (int64_t)S * R;
     subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12);
-    hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ws, (int64_t)4 * R, g1, ld1, g2, ld2, b0, b1,
-                       c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, parts, (int64_t)S * 4 * R);
+    hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, (int64_t)4 * R, g1, ld1, g2, ld2, b0, b1,
+                       c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, parts, (int64_t)S * 4 * R, h_bf16);
     return subgc::check_launch("subgc_lstm_fwd_gemm");
 }
 SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda, const float* dh_b,
                              int64_t ldb, const float* dh_drop, int64_t ldd, const uint8_t* keep, float keep_scale, const float* dc,
-                             float* dpre, float* dc_prev, int S, int R, void* stream) {
+                             void* dpre, float* dc_prev, int S, int R, int dpre_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 0 && R > 0, "lstm_bwd: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(gates && c && dpre && dc_prev, "lstm_bwd: null pointer");
@@ -792,37 +812,39 @@ SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const floa
                      al(dh_drop) && al(dc) && al(dpre) && al(dc_prev) && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
     if (vec)
         hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
-                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R);
+                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16);
     else
         hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
-                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R);
+                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16);
     return subgc::check_launch("subgc_lstm_bwd");
 }
 
 SUBGC_API int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
-                             const int32_t* len, float* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R,
-                             void* stream) {
+                             const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R,
+                             int ctx_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride >= 0 && n_stride <= MAXLEN, "attn_fwd: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(u && v && ah && w_a && b_a && off && len && ctx, "attn_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
-    if (const int rc = subgc::attn_fwd_vec(u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R, s); rc != -100) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R);
+    if (const int rc = subgc::attn_fwd_vec(u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R, ctx_bf16, s); rc != -100) return rc;
+    SUBGC_REQUIRE(!ctx_bf16, "attn_fwd: the bf16 context destination needs the vector form (A, R %% 4 == 0, 16-byte aligned rows)");
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, static_cast<float*>(ctx), ldctx, alpha, n_stride, S, A, R);
     return subgc::check_launch("subgc_attn_fwd");
 }
 SUBGC_API int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
-                             const float* alpha, int n_stride, const float* dctx, int64_t lddctx, float* dah, float* du, float* dv,
-                             float* dw_a, float* db_a, int S, int A, int R, void* stream) {
+                             const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv,
+                             float* dw_a, float* db_a, int S, int A, int R, int dah_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride > 0 && n_stride <= MAXLEN, "attn_bwd: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dv && dw_a, "attn_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
-    if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, s);
+    if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, dah_bf16, s);
         rc != -100)
         return rc;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv,
+    SUBGC_REQUIRE(!dah_bf16, "attn_bwd: the bf16 d(query) destination needs the vector form");
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, static_cast<float*>(dah), du, dv,
                        dw_a, db_a, S, A, R);
     return subgc::check_launch("subgc_attn_bwd");
 }
@@ -841,14 +863,14 @@ SUBGC_API int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, con
     else hipLaunchKernelGGL(log_softmax_kernel<64>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
     return subgc::check_launch("subgc_log_softmax_rows");
 }
-SUBGC_API int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, float* dlogits, int64_t ld, int rows, int V,
-                                         const int32_t* active, void* stream) {
+SUBGC_API int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, void* dlogits, int64_t ld, int rows, int V,
+                                         const int32_t* active, int out_bf16, void* stream) {
     SUBGC_REQUIRE(rows >= 0 && V > 0 && ld >= V, "log_softmax_rows_bwd: bad sizes");
     if (rows == 0) return SUBGC_OK;
     SUBGC_REQUIRE(logp && dout && dlogits, "log_softmax_rows_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * rows * (double)V * 3);
-    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, s, logp, dout, dlogits, ld, rows, V, active);
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, s, logp, dout, dlogits, ld, rows, V, active, out_bf16);
     return subgc::check_launch("subgc_log_softmax_rows_bwd");
 }
 SUBGC_API int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
@@ -871,14 +893,14 @@ SUBGC_API int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, cons
     return subgc::check_launch("subgc_masked_nll_bwd");
 }
 SUBGC_API int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
-                                       const float* scratch2, const float* dloss, float* dlogits, int S, int T, int V,
-                                       const int32_t* active, void* stream) {
-    SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "nll_logsoftmax_bwd: bad sizes");
+                                       const float* scratch2, const float* dloss, void* dlogits, int64_t ld_out, int S, int T, int V,
+                                       const int32_t* active, int out_bf16, void* stream) {
+    SUBGC_REQUIRE(S > 0 && T > 0 && V > 0 && ld_out >= V, "nll_logsoftmax_bwd: bad sizes");
     SUBGC_REQUIRE(logp && target && mask && scratch2 && dloss && dlogits, "nll_logsoftmax_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * S * T * (double)V * 2);
     hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3(S * T), dim3(256), 0, s, logp, target, t_stride, mask, m_stride, scratch2, dloss,
-                       dlogits, T, V, active);
+                       dlogits, ld_out, T, V, active, out_bf16);
     return subgc::check_launch("subgc_nll_logsoftmax_bwd");
 }
 SUBGC_API int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream) {
@@ -938,19 +960,19 @@ SUBGC_API int subgc_scatter_add_rows(const float* src, int64_t lds, const int32_
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dX, ldx, M, L, m_dev);
     return subgc::check_launch("subgc_scatter_add_rows");
 }
-SUBGC_API int subgc_relu_bwd(const float* dy, const float* y, float scale, float* dz, int64_t n, void* stream) {
+SUBGC_API int subgc_relu_bwd(const float* dy, const float* y, float scale, void* dz, int64_t n, int out_bf16, void* stream) {
     SUBGC_REQUIRE(n >= 0, "relu_bwd: bad size");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(dy && y && dz, "relu_bwd: null pointer");
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, out_bf16);
     return subgc::check_launch("subgc_relu_bwd");
 }
-SUBGC_API int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, float* dst, int64_t ldd, int M, int L,
-                                const int32_t* m_dev, void* stream) {
+SUBGC_API int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, void* dst, int64_t ldd, int M, int L,
+                                const int32_t* m_dev, int out_bf16, void* stream) {
     SUBGC_REQUIRE(M >= 0 && L > 0 && lds >= L && ldd >= L, "gather_rows: bad sizes");
     if (M == 0) return SUBGC_OK;
     SUBGC_REQUIRE(src && rows && dst, "gather_rows: null pointer");
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dst, ldd, M, L, m_dev);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dst, ldd, M, L, m_dev, out_bf16);
     return subgc::check_launch("subgc_gather_rows");
 }
 SUBGC_API int subgc_gather_rows_multi(int count, const float* s0, int64_t lds0, float* d0, int64_t ldd0, int c0, const float* s1, int64_t lds1,
@@ -978,20 +1000,21 @@ SUBGC_API int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* str
     return subgc::check_launch("subgc_sumsq_f32");
 }
 SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, uint16_t* p_bf16,
+                                   void* stream) {
     SUBGC_REQUIRE(n >= 0 && step >= 1 && grad_scale > 0.f, "clip_adam_step: bad arguments");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(p && g && m && v && sumsq, "clip_adam_step: null pointer");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (n % 4 == 0 && al(p) && al(g) && al(m) && al(v)) {
+    if (n % 4 == 0 && al(p) && al(g) && al(m) && al(v) && (reinterpret_cast<uintptr_t>(p_bf16) & 7) == 0) {
         hipLaunchKernelGGL(clip_adam_vec_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(p),
                            reinterpret_cast<float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n / 4, sumsq, max_norm, lr,
-                           beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                           beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, p_bf16);
         return subgc::check_launch("subgc_clip_adam_step");
     }
     hipLaunchKernelGGL(clip_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                       beta2, eps, weight_decay, bc1, bc2, grad_scale, p_bf16);
     return subgc::check_launch("subgc_clip_adam_step");
 }
 
@@ -1000,8 +1023,8 @@ SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64
 // (the gradient of the loop-invariant fc->gates term; replaces T accumulate-copies).  M_t = ot[t+1] - ot[t] is
 // non-increasing, so a row's live steps are a prefix of 0..T-1.
 namespace {
-__global__ __launch_bounds__(256) void packed_time_sum_kernel(const float* __restrict__ src, const int32_t* __restrict__ ot, int T, int S,
-                                                              int C4, float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void packed_time_sum_kernel(const void* __restrict__ src, const int32_t* __restrict__ ot, int T, int S,
+                                                              int C4, float* __restrict__ dst, int b16) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (int64_t)S * C4) return;
     const int s = (int)(q / C4), c = (int)(q % C4) * 4;
@@ -1010,20 +1033,22 @@ __global__ __launch_bounds__(256) void packed_time_sum_kernel(const float* __res
     for (int t = 0; t < T; ++t) {
         const int o = ot[t];
         if (s >= ot[t + 1] - o) break;
-        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(o + s) * C + c);
+        const int64_t at = (int64_t)(o + s) * C + c;
+        const float4 v = b16 ? subgc_load4_bf(static_cast<const uint16_t*>(src) + at) : *reinterpret_cast<const float4*>(static_cast<const float*>(src) + at);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     *reinterpret_cast<float4*>(dst + (int64_t)s * C + c) = a;
 }
 }  // namespace
 
-SUBGC_API int subgc_packed_time_sum(const float* src, const int32_t* offsets, int T, int S, int C, float* dst, void* stream) {
+SUBGC_API int subgc_packed_time_sum(const void* src, const int32_t* offsets, int T, int S, int C, float* dst, int src_bf16, void* stream) {
     SUBGC_REQUIRE(T >= 0 && S >= 0 && C > 0 && C % 4 == 0, "packed_time_sum: bad sizes (C % 4 == 0)");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(src && offsets && dst, "packed_time_sum: null pointer");
-    SUBGC_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "packed_time_sum: 16-byte alignment");
+    SUBGC_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & (src_bf16 ? 7 : 15)) == 0,
+                  "packed_time_sum: 16-byte alignment (8 for a bf16 source)");
     const int64_t n = (int64_t)S * (C / 4);
     hipLaunchKernelGGL(packed_time_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, offsets, T, S, C / 4,
-                       dst);
+                       dst, src_bf16);
     return subgc::check_launch("subgc_packed_time_sum");
 }

@@ -64,7 +64,7 @@ struct Stage {
     uint4 r[4];
     const uint16_t* base[4];
     int64_t ld_;
-    unsigned ok;                                               // bit v: r[v] holds data inside K (decided per tile)
+    unsigned ok;                                               // KM: bit j = r[j] holds a k inside K; !KM: how many of the chunk's 8 k lie inside K
     bool colok;                                                // KM: this thread's 8-row group lies inside the operand
 
     __device__ __forceinline__ void init(const uint16_t* src, int64_t ld, int row0, int nrows) {
@@ -90,8 +90,8 @@ struct Stage {
         const int t = threadIdx.x;
         if (!KM) {
             const int k = k0 + (t & 7) * 8;
-            const bool in = INTERIOR || k < K;                 // K % 8 == 0: a chunk is all in or all out
-            ok = in ? 0xfu : 0u;
+            const bool in = INTERIOR || k < K;
+            ok = INTERIOR ? 8u : (unsigned)min(max(K - k, 0), 8);   // a chunk straddling K keeps its leading K - k elements
 #pragma unroll
             for (int v = 0; v < 4; ++v) r[v] = *reinterpret_cast<const uint4*>(base[v] + (in ? k0 : -((t & 7) * 8)));
         } else {
@@ -112,7 +112,14 @@ struct Stage {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = (t >> 3) + 32 * v;
-                const uint4 q = (INTERIOR || ok) ? r[v] : make_uint4(0u, 0u, 0u, 0u);
+                uint4 q = r[v];
+                if (!INTERIOR && ok < 8u) {                    // K tail: zero the elements at and past K (the row's ld covers the over-read)
+                    const unsigned nv = ok;
+                    uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) w[d] = (2u * d + 1u < nv) ? w[d] : ((2u * d < nv) ? (w[d] & 0xffffu) : 0u);
+                    q = make_uint4(w[0], w[1], w[2], w[3]);
+                }
                 *reinterpret_cast<uint4*>(lds + swz(row, t & 7)) = q;
             }
         } else {
@@ -391,10 +398,10 @@ int check(int transA, int transB, int M, int N, int K, const void* A, int64_t ld
     SUBGC_REQUIRE(!(transA && transB), "gemm_bf16: transA && transB not supported");
     SUBGC_REQUIRE(A && B, "gemm_bf16: null operand");
     SUBGC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm_bf16: leading dimension too small");
-    // 16-byte row segments: aligned bases, leading dimensions in multiples of 8 elements; K-contiguous operands need K % 8 == 0
-    // (callers pad K with zero columns); K-major operands may have any K and any row count (their ld covers the over-read)
+    // 16-byte row segments: aligned bases, leading dimensions in multiples of 8 elements (a row's ld then covers the over-read
+    // of a chunk that straddles the logical row end; the kernel masks what lies past K, and what lies past M / N only feeds
+    // accumulator rows / columns that are never stored)
     SUBGC_REQUIRE(aligned16(A) && aligned16(B) && lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16: operands must be 16-byte aligned with ld %% 8 == 0");
-    SUBGC_REQUIRE((transA || K % 8 == 0) && (!transB || K % 8 == 0), "gemm_bf16: a K-contiguous operand needs K %% 8 == 0 (pad with zeros)");
     return SUBGC_OK;
 }
 
@@ -434,7 +441,7 @@ namespace subgc {
 // kernel adds the planes while it reads the pre-activations.  -100 when the dispatch would not split this shape.
 int gemm_bf16_nt_partials(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, float* ws, size_t ws_bytes,
                           hipStream_t s, int* splits) {
-    if (!ws || !aligned16(A) || !aligned16(B) || lda % 8 || ldb % 8 || K % 8 || N % 4) return -100;
+    if (!ws || !aligned16(A) || !aligned16(B) || lda % 8 || ldb % 8 || N % 4) return -100;
     Args a{A, B, ws, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, 0, M, N, K, 0, 1.f};
     ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
     return run<false, false>(a, ws, ws_bytes, s, true, splits);

@@ -22,6 +22,7 @@
 // per MFMA -- A and B use the same assignment, so the sum over k is complete (order differs
 // from a sequential loop, which fp32 tolerates: results are within rounding, not bit-equal).
 #include "common.h"
+#include "bf16_util.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -38,6 +39,8 @@ struct GemmArgs {
     int64_t lda, ldb, ldc, ldadd;
     int M, N, K, flags;
     float keep_scale;
+    float* ws; size_t ws_bytes;      // the caller's split-K scratch for THIS call (host-side use only)
+    int xmode;                       // arithmetic of the 128x128-tile forms: 0 fp32 pipe, 1 bf16x3 split, 2 bf16 operands
 };
 
 constexpr int BK = 32;
@@ -506,13 +509,10 @@ int launch(const GemmArgs& a, hipStream_t s) {
     return subgc::check_launch("subgc_gemm_f32");
 }
 
-// caller-provided scratch for the split-K partial tiles (subgc_set_workspace); one stream at a time
-float* g_ws = nullptr;
-size_t g_ws_bytes = 0;
 int g_splitk = 1;            // 0 disables the split-K form (SUBGC_SPLITK=0)
 int g_smallm = 256;          // M <= this prefers the 64x64 split-K form: one 128x128 workgroup per CU is latency-bound (SUBGC_SMALLM)
 int g_ragged64 = 1;          // ragged launches use 64x64 tiles (SUBGC_RAGGED64=0 to compare)
-int g_x3 = 0;                // subgc_set_gemm_mode: 1 = 3-way split operands on the bf16 matrix pipe, 2 = operands rounded to bf16
+int g_x3 = 0;                // default arithmetic when a call names none (SUBGC_GEMM_X3): 1 = 3-way split operands on the bf16 pipe, 2 = operands rounded to bf16
 
 // pick the number of K parts for 128x128 tiles so that tiles x parts fills the 512 workgroup slots
 // (2 per CU) in whole rounds; returns 1 when splitting does not pay
@@ -538,12 +538,12 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits, bool reduce = tr
     const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
     static bool attr_set = false;
     if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
-    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, g_ws, splits, per);
+    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, a.ws, splits, per);
     if (!reduce) return subgc::check_launch("subgc_gemm_f32(split-K, partials)");   // the consumer sums the planes itself
     const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)g_ws,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)a.ws,
                        splits, a.M, a.N, a.C, a.ldc, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0, vec);
     return subgc::check_launch("subgc_gemm_f32(split-K)");
 }
@@ -554,7 +554,9 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     // when the epilogue is a plain (bias / accumulate) one and a workspace was registered; else small tiles.
     const int64_t big = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
     // bf16x3-split form (gemm_x3.h): vector-addressable operands, no gathered A rows, 128x128 tiles
-    const int xm = (VEC && !a.a_rows) ? g_x3 : 0;
+    const int xm = (VEC && !a.a_rows) ? a.xmode : 0;
+    float* const g_ws = a.ws;
+    const size_t g_ws_bytes = a.ws_bytes;
     // a ragged launch (device-side row count) is sized for the allocation; its live tiles are usually few, and one 128x128
     // workgroup alone on a CU cannot hide its own load latency: small tiles put several workgroups on every CU
     if (a.m_dev && !TA && xm == 0 && g_ragged64) return launch<64, 64, TA, TB, VEC>(a, s);
@@ -595,8 +597,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int64_t lda,
                              const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
                              const float* add, int64_t ldadd, const uint8_t* keep, float keep_scale, int flags,
-                             const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev, void* stream) {
+                             const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev, void* workspace, size_t ws_bytes,
+                             void* stream) {
     SUBGC_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size M=%d N=%d K=%d", M, N, K);
+    SUBGC_REQUIRE((workspace != nullptr || ws_bytes == 0) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                  "gemm: workspace must be 16-byte aligned (NULL with 0 bytes = none)");
     if (M == 0 || N == 0) return SUBGC_OK;
     SUBGC_REQUIRE(A && B && C, "gemm: null operand");
     SUBGC_REQUIRE(!(transA && transB), "gemm: transA && transB not supported");
@@ -611,7 +616,9 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
         if (const char* e = getenv("SUBGC_GEMM_X3")) g_x3 = atoi(e);
         env_read = true;
     }
-    GemmArgs a{A, B, C, bias, add, keep, a_rows, c_rows, m_dev, lda, ldb, ldc, ldadd, M, N, K, flags, keep_scale};
+    const int mode_bits = (flags >> 4) & 3;                  // SUBGC_GEMM_MODE_*: 0 = the process default
+    GemmArgs a{A, B, C, bias, add, keep, a_rows, c_rows, m_dev, lda, ldb, ldc, ldadd, M, N, K, flags & 15, keep_scale,
+               static_cast<float*>(workspace), ws_bytes, mode_bits ? mode_bits - 1 : g_x3};
     hipStream_t s = (hipStream_t)stream;
     // vector path: every staged line is read as aligned float4 and is all-in or all-out of range
     const bool vecA = aligned16(A) && lda % 4 == 0 && (transA ? M % 4 == 0 : K % 4 == 0);
@@ -632,32 +639,29 @@ namespace subgc {
 // x[M,K] . W[N,K]^T left as `splits` partial planes ws[part][M][N] in the registered workspace, WITHOUT the reduce pass: for a
 // consumer that reads the pre-activations exactly once and can add the planes on the way (the LSTM cell kernel).  Same tile
 // and split choice as subgc_gemm_f32 would make for the plain product; -100 when that choice is not the 128x128 split-K form.
-int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, hipStream_t s, const float** ws, int* splits) {
+int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, int gemm_flags, float* g_ws, size_t g_ws_bytes,
+                     hipStream_t s, int* splits) {
     if (!(aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0) || !g_splitk || !g_ws || M <= g_smallm) return -100;
+    const int mode_bits = (gemm_flags >> 4) & 3, xmode = mode_bits ? mode_bits - 1 : g_x3;
     const int64_t big = cdiv(M, 128) * cdiv(N, 128);
     if (big < 16 || big >= 384) return -100;
     const int sp = choose_splits((int)big, (K + BK - 1) / BK);
     if (sp <= 1 || big * sp < 200 || (size_t)sp * M * N * sizeof(float) > g_ws_bytes) return -100;
-    GemmArgs a{A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, M, N, K, 0, 1.f};
+    GemmArgs a{A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, M, N, K, 0, 1.f, g_ws, g_ws_bytes, xmode};
     ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
-    const int rc = g_x3 == 1 ? launch_splitk<128, 128, false, true, true, 3>(a, s, sp, false)
-                 : g_x3 == 2 ? launch_splitk<128, 128, false, true, true, 2>(a, s, sp, false) : launch_splitk<128, 128, false, true, true>(a, s, sp, false);
-    *ws = g_ws; *splits = sp;
+    const int rc = xmode == 1 ? launch_splitk<128, 128, false, true, true, 3>(a, s, sp, false)
+                 : xmode == 2 ? launch_splitk<128, 128, false, true, true, 2>(a, s, sp, false) : launch_splitk<128, 128, false, true, true>(a, s, sp, false);
+    *splits = sp;
     return rc;
 }
 }  // namespace subgc
 
-SUBGC_API int subgc_set_gemm_mode(int mode) {
-    SUBGC_REQUIRE(mode >= 0 && mode <= 2, "set_gemm_mode: 0 = fp32 matrix pipe, 1 = bf16 pipe with 3-way split fp32 operands, 2 = bf16 operands");
-    g_x3 = mode;
-    return SUBGC_OK;
-}
-
-SUBGC_API int subgc_set_workspace(void* ptr, size_t bytes) {
-    SUBGC_REQUIRE(ptr != nullptr || bytes == 0, "set_workspace: null pointer with non-zero size");
-    SUBGC_REQUIRE((reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "set_workspace: pointer must be 16-byte aligned");
-    g_ws = static_cast<float*>(ptr);
-    g_ws_bytes = bytes;
+SUBGC_API int subgc_gemm_workspace_bytes(int M, int N, int K, size_t* bytes) {
+    // the most scratch the dispatch of subgc_gemm_f32 can use for this shape (its split-K forms cut K into at most 8 fp32
+    // partial planes); a smaller or absent workspace is legal, the dispatch then splits less or uses small tiles
+    SUBGC_REQUIRE(M >= 0 && N >= 0 && K >= 0 && bytes, "gemm_workspace_bytes: bad arguments");
+    const int64_t big = subgc::cdiv(M, 128) * subgc::cdiv(N, 128);
+    *bytes = big >= 1024 ? 0 : (size_t)8 * M * N * sizeof(float);
     return SUBGC_OK;
 }
 
@@ -706,11 +710,69 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
         atomicAdd(out + col + 3, a.w + b.w + c.w + d.w);
     }
 }
+// bf16 rows (the bf16-stored gate / logit gradients): a lane owns 4 adjacent columns (8 bytes)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ X, int64_t ldx, int M, int N,
+                                                          float* __restrict__ out, const int32_t* m_dev, int rows_per_block) {
+    __shared__ float4 sm[4][64];
+    if (m_dev) M = min(M, *m_dev);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < N)
+        for (int r = r0 + w; r < r1; r += 4) {
+            const float4 v = subgc_load4_bf(X + (int64_t)r * ldx + col);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    sm[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && col < N) {
+        const float4 a = sm[0][lane], b = sm[1][lane], c = sm[2][lane], d = sm[3][lane];
+        atomicAdd(out + col, a.x + b.x + c.x + d.x);
+        atomicAdd(out + col + 1, a.y + b.y + c.y + d.y);
+        atomicAdd(out + col + 2, a.z + b.z + c.z + d.z);
+        atomicAdd(out + col + 3, a.w + b.w + c.w + d.w);
+    }
+}
+// any N / ld (the 7001-column logit gradients of the Flickr vocabulary): one column per lane
+__global__ __launch_bounds__(256) void colsum_bf16_scalar_kernel(const uint16_t* __restrict__ X, int64_t ldx, int M, int N,
+                                                                 float* __restrict__ out, const int32_t* m_dev, int rows_per_block) {
+    __shared__ float sm[4][64];
+    if (m_dev) M = min(M, *m_dev);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc = 0.f;
+    if (col < N)
+        for (int r = r0 + w; r < r1; r += 4) acc += subgc_bf2f(X[(int64_t)r * ldx + col]);
+    sm[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && col < N) atomicAdd(out + col, sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane]);
+}
 __global__ void zero_kernel(float* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.f;
 }
 }  // namespace
+
+SUBGC_API int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, float* out, int accumulate, const int32_t* m_dev,
+                                void* stream) {
+    SUBGC_REQUIRE(M >= 0 && N >= 0 && ldx >= N, "colsum_bf16: bad sizes");
+    if (N == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(X && out, "colsum_bf16: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) hipLaunchKernelGGL(zero_kernel, dim3((N + 255) / 256), dim3(256), 0, s, out, N);
+    if (M == 0) return subgc::check_launch("subgc_colsum_bf16");
+    const int rows_per_block = 256;
+    if (N % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 7) == 0) {
+        dim3 grid((N / 4 + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block);
+    } else {
+        dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(colsum_bf16_scalar_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block);
+    }
+    return subgc::check_launch("subgc_colsum_bf16");
+}
 
 SUBGC_API int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
                                const int32_t* m_dev, void* stream) {

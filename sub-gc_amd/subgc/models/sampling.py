@@ -201,7 +201,7 @@ class _GraphedLoop:
         self._loop()                                                             # eager warm-up (sets kernel attributes, fills caches)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with ops.graph_capture(self.graph, dev):
             self._loop()
 
     def _loop(self):
@@ -248,7 +248,7 @@ class _GraphedBeam:
         self._loop()                                                             # eager warm-up
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with ops.graph_capture(self.graph, dev):
             self._loop()
 
     def _loop(self):

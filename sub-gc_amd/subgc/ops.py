@@ -19,43 +19,109 @@ def _stream():
 
 
 _WS = {}
+WS_MBYTES = 160
 
 
-def ensure_workspace(device, mbytes=96):
-    """Register a per-device scratch buffer for the split-K GEMM form (see subgc_set_workspace)."""
-    dev = torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if _WS.get("dev") != key:
-        buf = torch.empty(mbytes << 20, dtype=torch.uint8, device=dev)
-        call("subgc_set_workspace", buf.data_ptr(), buf.numel())
-        _WS["dev"], _WS["buf"] = key, buf
-    return _WS["buf"]
+def ensure_workspace(device=None, mbytes=None):
+    """The split-K scratch of the CURRENT stream of `device`: one buffer per (device, stream), handed to every GEMM call as
+    its `workspace, ws_bytes` arguments (the C ABI keeps no global scratch), so concurrent streams never share partial planes.
+    Buffers live for the life of the process: captured hipGraphs bake their addresses in."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise SubgcError("no split-K workspace for the capturing stream: capture through ops.graph_capture(), which brings its own")
+        buf = _WS[key] = torch.empty((mbytes or WS_MBYTES) << 20, dtype=torch.uint8, device=torch.device("cuda", idx))
+    return buf
 
 
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+def _ws(t):
+    buf = ensure_workspace(t.device)
+    return buf.data_ptr(), buf.numel()
+
+
+_CAPTURE_STREAMS = {}
+
+
+class graph_capture:
+    """`with ops.graph_capture(graph, device): ...` = torch.cuda.graph on a dedicated capture stream of that device whose
+    split-K workspace was allocated EAGERLY (outside any graph's private pool), so the addresses a captured GEMM bakes in stay
+    valid for every later capture and replay."""
+
+    def __init__(self, graph, device):
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        st = _CAPTURE_STREAMS.get(idx)
+        if st is None:
+            st = _CAPTURE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+            with torch.cuda.stream(st):
+                ensure_workspace(torch.device("cuda", idx))
+        self.ctx = torch.cuda.graph(graph, stream=st)
+
+    def __enter__(self):
+        return self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+GEMM_MODES = {"f32": 1 << 4, "bf16x3": 2 << 4, "bf16": 3 << 4}       # SUBGC_GEMM_MODE_* bits of the per-call flags
 
 
 class gemm_mode:
-    """`with ops.gemm_mode("bf16"): ...` -- arithmetic of the 128x128-tile GEMM forms (subgc_set_gemm_mode): "f32" (default),
-    "bf16x3" (fp32 operands split exactly into three bf16 planes, six MFMA terms) or "bf16" (operands rounded to bf16:
-    the compute type BASELINE configs 3 and 5 name).  Storage and accumulation are fp32 in every mode."""
+    """`with ops.gemm_mode("bf16x3"): ...` -- arithmetic of the 128x128-tile forms of the fp32-OPERAND GEMM, passed with every
+    call (SUBGC_GEMM_MODE_*): "f32" (default), "bf16x3" (fp32 operands split exactly into three bf16 planes, six MFMA terms:
+    fp32-grade) or "bf16" (fp32 operands rounded to bf16 in the staging path).  Storage stays fp32 in all three; the
+    bf16-STORAGE path of BASELINE configs 3 / 5 is `model.bf16_storage` + bf16 tensors through `gemm` (subgc_gemm_bf16)."""
 
     current = "f32"
 
     def __init__(self, mode):
+        if mode not in GEMM_MODES:
+            raise SubgcError(f"unknown GEMM mode {mode!r}")
         self.mode = mode
 
     def __enter__(self):
         self.prev = gemm_mode.current
-        set_gemm_mode(self.mode)
+        gemm_mode.current = self.mode
 
     def __exit__(self, *exc):
-        set_gemm_mode(self.prev)
+        gemm_mode.current = self.prev
 
 
 def set_gemm_mode(mode):
-    call("subgc_set_gemm_mode", GEMM_MODES[mode])
+    if mode not in GEMM_MODES:
+        raise SubgcError(f"unknown GEMM mode {mode!r}")
     gemm_mode.current = mode
+
+
+BF16 = torch.bfloat16
+
+
+def is_b16(t):
+    return t is not None and t.dtype == BF16
+
+
+def cast_bf16(x, out=None, m_dev=None):
+    """bf16 copy of a 2-D fp32 view (subgc_cast_f32_bf16); the destination's columns are padded with zeros to a multiple of 8
+    (a K-contiguous GEMM operand needs K % 8 == 0).  Returns the [rows, cols_pad] bf16 tensor."""
+    rows, cols = x.shape
+    pad = (cols + 7) // 8 * 8
+    if out is None:
+        out = torch.empty(rows, pad, device=x.device, dtype=BF16)
+    call("subgc_cast_f32_bf16", _ptr(x, torch.float32), ld(x), _ptr(out, BF16), ld(out), rows, cols, out.size(1), _ptr(m_dev, torch.int32), _stream())
+    return out
+
+
+def transpose_bf16(x, out=None):
+    """out[c, r] = bf16(x[r, c]) (subgc_transpose_f32_bf16): the W^T snapshots; rows of `out` padded to a multiple of 8 elements."""
+    rows, cols = x.shape
+    if out is None:
+        out = torch.zeros(cols, (rows + 7) // 8 * 8, device=x.device, dtype=BF16)[:, :rows]
+    call("subgc_transpose_f32_bf16", _ptr(x, torch.float32), ld(x), _ptr(out, BF16), ld(out), rows, cols, _stream())
+    return out
 
 
 def _ptr(t, dtype=None):
@@ -78,8 +144,14 @@ def ld(t):
 
 
 def gemm(a, b, out, *, ta=False, tb=False, bias=None, add=None, keep=None, keep_scale=1.0, relu=False,
-         accum=False, a_rows=None, c_rows=None, m_dev=None):
-    """out = epilogue(op(a) @ op(b));  a, b, out are 2-D row-major views (any leading dim)."""
+         accum=False, a_rows=None, c_rows=None, m_dev=None, out16=None):
+    """out = epilogue(op(a) @ op(b));  a, b, out are 2-D row-major views (any leading dim).
+    fp32 a, b -> subgc_gemm_f32 (arithmetic = the current `gemm_mode`); bf16 a, b -> subgc_gemm_bf16: `out` may then be fp32 or
+    bf16 and `out16` an additional bf16 destination of the same result (for consumers that are GEMMs themselves)."""
+    if is_b16(a) or is_b16(b):
+        return _gemm_b16(a, b, out, ta, tb, bias, add, keep, keep_scale, relu, accum, a_rows, c_rows, m_dev, out16)
+    if out16 is not None:
+        raise SubgcError("out16 needs bf16 operands")
     M = a.size(1) if ta else a.size(0)
     K = a.size(0) if ta else a.size(1)
     N = b.size(0) if tb else b.size(1)
@@ -97,13 +169,45 @@ def gemm(a, b, out, *, ta=False, tb=False, bias=None, add=None, keep=None, keep_
         FLOPS["gemm_calls"] += 1
     call("subgc_gemm_f32", int(ta), int(tb), M, N, K, _ptr(a, torch.float32), ld(a), _ptr(b, torch.float32), ld(b),
          _ptr(out, torch.float32), ld(out), _ptr(bias), _ptr(add), ld(add) if add is not None else 0,
-         _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0),
-         _ptr(a_rows, torch.int32), _ptr(c_rows, torch.int32), _ptr(m_dev, torch.int32), _stream())
+         _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0) | GEMM_MODES[gemm_mode.current],
+         _ptr(a_rows, torch.int32), _ptr(c_rows, torch.int32), _ptr(m_dev, torch.int32), *_ws(a), _stream())
+    return out
+
+
+def _gemm_b16(a, b, out, ta, tb, bias, add, keep, keep_scale, relu, accum, a_rows, c_rows, m_dev, out16):
+    if not (is_b16(a) and is_b16(b)):
+        raise SubgcError(f"bf16 GEMM needs both operands in bf16, got {a.dtype} / {b.dtype}")
+    if a_rows is not None or c_rows is not None:
+        raise SubgcError("the bf16 GEMM has no gathered / scattered row forms")
+    M = a.size(1) if ta else a.size(0)
+    K = a.size(0) if ta else a.size(1)
+    N = b.size(0) if tb else b.size(1)
+    Kb = b.size(1) if tb else b.size(0)
+    if K != Kb or out.size(0) < M or out.size(1) != N:
+        raise SubgcError(f"gemm shape mismatch: op(a)=[{M},{K}] op(b)=[{Kb},{N}] out={tuple(out.shape)}")
+    c32, c16 = (None, out) if is_b16(out) else (out, out16)
+    if c16 is not None and (c16.size(0) < M or c16.size(1) != N or not is_b16(c16)):
+        raise SubgcError("out16 must be a bf16 [M, N] view")
+    if FLOPS["on"]:
+        r = int(m_dev.item()) if m_dev is not None else None
+        me, ke = (M, min(K, r)) if (ta and r is not None) else ((min(M, r) if r is not None else M), K)
+        FLOPS["gemm"] += 2.0 * me * N * ke
+        FLOPS["gemm_bytes"] += 2.0 * (me * ke + ke * N) + me * N * ((4.0 * (2 if (accum or add is not None) else 1) if c32 is not None else 0.0)
+                                                                   + (2.0 if c16 is not None else 0.0))
+        FLOPS["gemm_calls"] += 1
+    call("subgc_gemm_bf16", int(ta), int(tb), M, N, K, _ptr(a, BF16), ld(a), _ptr(b, BF16), ld(b), _ptr(c32, torch.float32),
+         ld(c32) if c32 is not None else 0, _ptr(c16, BF16), ld(c16) if c16 is not None else 0, _ptr(bias, torch.float32), _ptr(add, torch.float32),
+         ld(add) if add is not None else 0, _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0),
+         _ptr(m_dev, torch.int32), *_ws(a), _stream())
     return out
 
 
 def colsum(x, out=None, accumulate=False, m_dev=None):
     out = torch.empty(x.size(1), device=x.device, dtype=torch.float32) if out is None else out
+    if is_b16(x):
+        call("subgc_colsum_bf16", _ptr(x, BF16), ld(x), x.size(0), x.size(1), _ptr(out, torch.float32), int(accumulate),
+             _ptr(m_dev, torch.int32), _stream())
+        return out
     call("subgc_colsum_f32", _ptr(x, torch.float32), ld(x), x.size(0), x.size(1), _ptr(out), int(accumulate),
          _ptr(m_dev, torch.int32), _stream())
     return out
@@ -257,9 +361,10 @@ def pack_rows(lens, idx, img, S, N):
 
 
 def embed_fwd(table, tok, tok_stride, keep, scale, out):
+    """out [n, E] fp32 or bf16 (contiguous rows)."""
     n, E = out.shape
     call("subgc_embed_fwd", _ptr(table), _ptr(tok, torch.int64), tok_stride, _ptr(keep, torch.uint8), float(scale), _ptr(out), n, E,
-         table.size(0), _stream())
+         table.size(0), int(is_b16(out)), _stream())
     return out
 
 
@@ -298,30 +403,45 @@ def embed_bwd(table, tok, tok_stride, keep, scale, dout, dtable):
     return dtable
 
 
+def _same_storage(*ts):
+    """1 when the (non-None) h destinations are bf16, 0 when fp32; mixing is an error."""
+    kinds = {is_b16(t) for t in ts if t is not None}
+    if len(kinds) > 1:
+        raise SubgcError("the h destinations of one LSTM call must all be fp32 or all be bf16")
+    return int(kinds.pop()) if kinds else 0
+
+
 def lstm_fwd(g0, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0):
     L = lambda t: ld(t) if t is not None else 0
     call("subgc_lstm_fwd", _ptr(g0), L(g0), _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c),
          _ptr(h), L(h), _ptr(h2), L(h2), _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h),
-         int(rows_h2), _stream())
+         int(rows_h2), _same_storage(h, h2, hdrop), _stream())
 
 
 def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0):
-    """gemm(x, w^T) + lstm_fwd with the split-K reduce folded into the cell kernel (subgc_lstm_fwd_gemm); `pre` [S, 4R] is scratch."""
+    """gemm(x, w^T) + lstm_fwd with the split-K reduce folded into the cell kernel (subgc_lstm_fwd_gemm); `pre` [S, 4R] is scratch.
+    x, w both fp32 or both bf16; h / h2 / hdrop all fp32 or all bf16."""
     L = lambda t: ld(t) if t is not None else 0
     K = x.size(1)
+    xb = int(is_b16(x))
+    if is_b16(w) != bool(xb):
+        raise SubgcError("lstm_fwd_gemm: x and w must have the same storage type")
     if FLOPS["on"]:                      # same accounting as ops.gemm: the product is the same launch family
+        eb = 2.0 if xb else 4.0
         FLOPS["gemm"] += 2.0 * S * 4 * R * K
-        FLOPS["gemm_bytes"] += 4.0 * (S * K + K * 4 * R + S * 4 * R)
+        FLOPS["gemm_bytes"] += eb * (S * K + K * 4 * R) + 4.0 * S * 4 * R
         FLOPS["gemm_calls"] += 1
-    call("subgc_lstm_fwd_gemm", _ptr(x, torch.float32), ld(x), _ptr(w, torch.float32), ld(w), K, _ptr(pre, torch.float32), ld(pre),
+    call("subgc_lstm_fwd_gemm", _ptr(x), ld(x), _ptr(w), ld(w), K, _ptr(pre, torch.float32), ld(pre),
          _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c), _ptr(h), L(h), _ptr(h2), L(h2),
-         _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h), int(rows_h2), _stream())
+         _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h), int(rows_h2),
+         xb | (_same_storage(h, h2, hdrop) << 1), GEMM_MODES[gemm_mode.current], *_ws(x), _stream())
 
 
 def lstm_bwd(gates, c_prev, c, dh_a, dh_b, dh_drop, keep, scale, dc, dpre, dc_prev, S, R):
+    """dpre [S, 4R] contiguous rows, fp32 or bf16 (the gate gradients only feed GEMMs and bias sums)."""
     L = lambda t: ld(t) if t is not None else 0
     call("subgc_lstm_bwd", _ptr(gates), _ptr(c_prev), _ptr(c), _ptr(dh_a), L(dh_a), _ptr(dh_b), L(dh_b), _ptr(dh_drop), L(dh_drop),
-         _ptr(keep, torch.uint8), float(scale), _ptr(dc), _ptr(dpre), _ptr(dc_prev), S, R, _stream())
+         _ptr(keep, torch.uint8), float(scale), _ptr(dc), _ptr(dpre), _ptr(dc_prev), S, R, int(is_b16(dpre)), _stream())
 
 
 def _attn_account(lens, S, A, R, passes):
@@ -332,13 +452,13 @@ def _attn_account(lens, S, A, R, passes):
 def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R):
     _attn_account(lens, S, A, R, 1)      # read u and v rows once
     call("subgc_attn_fwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32),
-         _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, _stream())
+         _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, int(is_b16(ctx)), _stream())
 
 
 def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R):
     _attn_account(lens, S, A, R, 3)      # read u, v; read-modify-write du, dv
     call("subgc_attn_bwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
-         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R, _stream())
+         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R, int(is_b16(dah)), _stream())
 
 
 def log_softmax_rows_(x, active=None):
@@ -349,7 +469,8 @@ def log_softmax_rows_(x, active=None):
 
 def log_softmax_rows_bwd(logp, dout, dlogits, active=None):
     rows, V = logp.shape
-    call("subgc_log_softmax_rows_bwd", _ptr(logp), _ptr(dout), _ptr(dlogits), ld(logp), rows, V, _ptr(active, torch.int32), _stream())
+    call("subgc_log_softmax_rows_bwd", _ptr(logp), _ptr(dout), _ptr(dlogits), ld(logp), rows, V, _ptr(active, torch.int32),
+         int(is_b16(dlogits)), _stream())
     return dlogits
 
 
@@ -372,7 +493,7 @@ def masked_nll_bwd(target, mask, scratch, dloss, S, T, V):
 
 def nll_logsoftmax_bwd(logp, target, mask, scratch, dloss, dlogits, active, S, T, V):
     call("subgc_nll_logsoftmax_bwd", _ptr(logp), _ptr(target, torch.int64), target.stride(0), _ptr(mask), mask.stride(0), _ptr(scratch),
-         _ptr(dloss), _ptr(dlogits), S, T, V, _ptr(active, torch.int32), _stream())
+         _ptr(dloss), _ptr(dlogits), ld(dlogits), S, T, V, _ptr(active, torch.int32), int(is_b16(dlogits)), _stream())
     return dlogits
 
 
@@ -420,8 +541,8 @@ def multinomial_rows_(logits, u, sel_u, prob, tok):
 
 def packed_time_sum(src, offsets, T, S, dst):
     """dst[s] = sum over live steps t of src[offsets[t] + s] (packed decoder; offsets int32 [T+1] on the device)."""
-    call("subgc_packed_time_sum", _ptr(src, torch.float32), _ptr(offsets, torch.int32), int(T), int(S), src.size(1), _ptr(dst, torch.float32),
-         _stream())
+    call("subgc_packed_time_sum", _ptr(src), _ptr(offsets, torch.int32), int(T), int(S), src.size(1), _ptr(dst, torch.float32),
+         int(is_b16(src)), _stream())
     return dst
 
 
@@ -450,19 +571,27 @@ def zeros(*shape, device):
 
 
 def copy2d(x, y, accumulate=False):
+    if is_b16(x):
+        if accumulate or not is_b16(y):
+            raise SubgcError("copy2d: bf16 rows are copied to bf16 rows only")
+        call("subgc_copy2d_b16", _ptr(x, BF16), ld(x), _ptr(y, BF16), ld(y), x.size(0), x.size(1), _stream())
+        return y
     call("subgc_copy2d_f32", _ptr(x), ld(x), _ptr(y), ld(y), x.size(0), x.size(1), int(accumulate), _stream())
     return y
 
 
-def relu_bwd(dy, y, scale=1.0, out=None):
-    out = torch.empty_like(y) if out is None else out
-    call("subgc_relu_bwd", _ptr(dy), _ptr(y), float(scale), _ptr(out), y.numel(), _stream())
+def relu_bwd(dy, y, scale=1.0, out=None, bf16=False):
+    """dz = dy * scale * [y > 0] (contiguous); `bf16`: dz is written bf16 (it only feeds the two gradient GEMMs)."""
+    if out is None:
+        out = torch.empty(y.shape, device=y.device, dtype=BF16 if bf16 else torch.float32)
+    call("subgc_relu_bwd", _ptr(dy, torch.float32), _ptr(y, torch.float32), float(scale), _ptr(out), y.numel(), int(is_b16(out)), _stream())
     return out
 
 
 def gather_rows(src, rows, dst, m_dev=None):
-    call("subgc_gather_rows", _ptr(src), ld(src), _ptr(rows, torch.int32), _ptr(dst), ld(dst), dst.size(0), dst.size(1),
-         _ptr(m_dev, torch.int32), _stream())
+    """dst fp32 or bf16."""
+    call("subgc_gather_rows", _ptr(src, torch.float32), ld(src), _ptr(rows, torch.int32), _ptr(dst), ld(dst), dst.size(0), dst.size(1),
+         _ptr(m_dev, torch.int32), int(is_b16(dst)), _stream())
     return dst
 
 
@@ -488,6 +617,6 @@ def sumsq(g, out):
     return out
 
 
-def clip_adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+def clip_adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf16=None):
     call("subgc_clip_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(max_norm), float(lr),
-         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), _stream())
+         float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), _ptr(p_bf16, BF16), _stream())

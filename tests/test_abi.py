@@ -22,10 +22,22 @@ def test_header_symbols_all_exported():
 
 def test_host_side_argument_validation_needs_no_gpu():
     L = _lib.lib()
-    rc = L.subgc_gemm_f32(0, 1, -1, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 1.0, 0, None, None, None, None)
+    rc = L.subgc_gemm_f32(0, 1, -1, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 1.0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"negative size" in L.subgc_last_error()
-    rc = L.subgc_gemm_f32(1, 1, 4, 4, 4, 1, 4, 1, 4, 1, 4, None, None, 0, None, 1.0, 0, None, None, None, None)
+    rc = L.subgc_gemm_f32(1, 1, 4, 4, 4, 1, 4, 1, 4, 1, 4, None, None, 0, None, 1.0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"transA && transB" in L.subgc_last_error()
+    rc = L.subgc_gemm_f32(0, 1, 4, 4, 4, 16, 4, 16, 4, 16, 4, None, None, 0, None, 1.0, 0, None, None, None, None, 64, None)
+    assert rc == -1 and b"workspace" in L.subgc_last_error()                   # bytes without a pointer
+    # the bf16-operand GEMM: alignment / padding rules are checked on the host
+    rc = L.subgc_gemm_bf16(0, 1, 4, 4, 12, 24, 16, 16, 16, 16, 4, None, 0, None, None, 0, None, 1.0, 0, None, None, 0, None)
+    assert rc == -1 and b"16-byte aligned" in L.subgc_last_error()
+    rc = L.subgc_gemm_bf16(0, 1, 4, 4, 16, 16, 20, 16, 16, 16, 4, None, 0, None, None, 0, None, 1.0, 0, None, None, 0, None)
+    assert rc == -1 and b"ld %" in L.subgc_last_error()
+    import ctypes
+    need = ctypes.c_size_t(1)
+    assert L.subgc_gemm_workspace_bytes(640, 4000, 3000, ctypes.byref(need)) == 0 and need.value >= 2 * 640 * 4000 * 4
+    assert L.subgc_gemm_bf16_workspace_bytes(1280, 4000, 3000, ctypes.byref(need)) == 0 and need.value >= 1280 * 4000 * 4
+    assert L.subgc_gemm_bf16_workspace_bytes(21760, 9488, 1000, ctypes.byref(need)) == 0 and need.value == 0
     rc = L.subgc_row_argmax_f32(None, 4, 2, 4, 4, None, None, None)
     assert rc == -1
     with pytest.raises(_lib.SubgcError):

@@ -1,0 +1,128 @@
+"""The bf16-operand MFMA GEMM (csrc/gemm_bf16.hip, subgc_gemm_bf16) and the bf16 plumbing kernels against fp64 products of
+the SAME bf16 operands: the kernel accumulates in fp32, so the only error is summation order (tolerance 2e-5 of the
+result scale, like the fp32 GEMM's), plus one bf16 rounding (2^-9 relative) where the destination is bf16."""
+import numpy as np
+import pytest
+import torch
+
+from subgc import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(DEV)
+
+
+def operands(mode, M, N, K, seed, lda_pad=0, ldb_pad=0):
+    a = rnd(*((K, M + lda_pad) if mode == "tn" else (M, K + lda_pad)), seed=seed).to(BF)
+    b = rnd(*((N, K + ldb_pad) if mode == "nt" else (K, N + ldb_pad)), seed=seed + 1).to(BF)
+    a = a[:, :M] if mode == "tn" else a[:, :K]
+    b = b[:, :K] if mode == "nt" else b[:, :N]
+    ad = a.double().t() if mode == "tn" else a.double()
+    bd = b.double().t() if mode == "nt" else b.double()
+    return a, b, ad @ bd
+
+
+SHAPES = [("nt", 1280, 4000, 3000), ("nt", 300, 512, 1000), ("nn", 1280, 3000, 4000), ("nn", 200, 1000, 512), ("tn", 4000, 2000, 2176),
+          ("tn", 9488, 1000, 1357), ("nt", 129, 130, 72), ("nn", 5, 8, 8), ("tn", 24, 48, 3), ("nt", 4736, 1024, 2048), ("tn", 512, 1000, 21760)]
+
+
+@pytest.mark.parametrize("mode,M,N,K", SHAPES)
+def test_gemm_bf16_matches_fp64_product_of_the_same_operands(mode, M, N, K):
+    a, b, ref = operands(mode, M, N, K, seed=M + N + K, lda_pad=8, ldb_pad=16)
+    scale = float(ref.abs().max())
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(a, b, out, ta=mode == "tn", tb=mode == "nt")
+    assert float((out.double() - ref).abs().max()) < 2e-5 * scale
+    o16 = torch.empty(M, N + 4, device=DEV, dtype=BF)[:, :N]
+    ops.gemm(a, b, o16, ta=mode == "tn", tb=mode == "nt")
+    assert float((o16.double() - ref).abs().max()) < 2.0 ** -8 * scale
+    assert torch.equal(o16, out.to(BF))                                  # the bf16 destination is the rounded fp32 result
+
+
+def test_gemm_bf16_epilogues_and_second_destination():
+    M, N, K = 700, 1000, 512
+    a, b, ref = operands("nt", M, N, K, seed=3)
+    bias, add = rnd(N, seed=5), rnd(M, N, seed=6)
+    keep = (torch.rand(M, N, generator=torch.Generator().manual_seed(7)) < 0.5).to(torch.uint8).to(DEV)
+    want = torch.relu(ref + bias.double() + add.double()) * keep.double() * 2.0
+    out, o16 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm(a, b, out, tb=True, bias=bias, add=add, relu=True, keep=keep, keep_scale=2.0, out16=o16)
+    scale = float(want.abs().max())
+    assert float((out.double() - want).abs().max()) < 2e-5 * scale
+    assert torch.equal(o16, out.to(BF))
+    prev = rnd(M, N, seed=8)
+    acc = prev.clone()
+    ops.gemm(a, b, acc, tb=True, bias=bias, accum=True)                  # split-K capable shape: the reduce kernel applies bias + accumulate
+    assert float((acc.double() - (ref + bias.double() + prev.double())).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["nt", "tn"])
+def test_gemm_bf16_device_side_row_count(mode):
+    """m_dev bounds the rows of the stored A: M for [M,K] operands, K for the transposed (weight-gradient) form."""
+    M, N, K = (2000, 512, 1000) if mode == "nt" else (512, 1000, 2000)
+    a, b, _ = operands(mode, M, N, K, seed=11)
+    live = 1237
+    m_dev = torch.tensor([live], device=DEV, dtype=torch.int32)
+    out = torch.full((M, N), 7.0, device=DEV)
+    ops.gemm(a, b, out, ta=mode == "tn", tb=mode == "nt", m_dev=m_dev)
+    if mode == "nt":
+        ref = a[:live].double() @ b.double().t()
+        assert float((out[:live].double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+        assert float((out[live:] - 7.0).abs().max()) == 0.0              # rows past the device-side count are not written
+    else:
+        ref = a[:live].double().t() @ b[:live].double()
+        assert float((out.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_two_streams_issue_split_k_gemms_concurrently():
+    """The split-K scratch is an argument of the call (one buffer per stream on the host side), not a process global: the same
+    products issued from two streams at once equal the serial results, for the fp32 and the bf16 kernels."""
+    M, N, K = 640, 4000, 3000
+    a32, b32 = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    c32, d32 = rnd(M, K, seed=3), rnd(N, K, seed=4)
+    serial = []
+    for x, w in ((a32, b32), (c32, d32), (a32.to(BF), b32.to(BF)), (c32.to(BF), d32.to(BF))):
+        o = torch.empty(M, N, device=DEV)
+        ops.gemm(x, w, o, tb=True)
+        serial.append(o)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        outs = [torch.empty(M, N, device=DEV) for _ in range(4)]
+        with torch.cuda.stream(s1):
+            for _ in range(4):
+                ops.gemm(a32, b32, outs[0], tb=True)
+                ops.gemm(a32.to(BF), b32.to(BF), outs[2], tb=True)
+        with torch.cuda.stream(s2):
+            for _ in range(4):
+                ops.gemm(c32, d32, outs[1], tb=True)
+                ops.gemm(c32.to(BF), d32.to(BF), outs[3], tb=True)
+        torch.cuda.synchronize()
+        for got, want in zip(outs, serial):
+            assert torch.equal(got, want)
+    assert len({k for k in ops._WS if k[0] == torch.cuda.current_device()}) >= 3      # default stream + the two side streams
+
+
+def test_cast_transpose_and_copy_kernels():
+    x = rnd(37, 300, seed=2)
+    y = ops.cast_bf16(x)
+    assert y.shape == (37, 304) and torch.equal(y[:, :300], x.to(BF)) and float(y[:, 300:].abs().max()) == 0.0
+    m_dev = torch.tensor([20], device=DEV, dtype=torch.int32)
+    z = torch.full((37, 304), 3.0, device=DEV, dtype=BF)
+    ops.cast_bf16(x, out=z, m_dev=m_dev)
+    assert torch.equal(z[:20, :300], x[:20].to(BF)) and float((z[20:].float() - 3.0).abs().max()) == 0.0
+    big = rnd(1000, 4000, seed=3)
+    assert torch.equal(ops.cast_bf16(big), big.to(BF))
+    t = ops.transpose_bf16(big[:, :3001])
+    assert t.shape == (3001, 1000) and t.stride(0) % 8 == 0 and torch.equal(t, big[:, :3001].t().to(BF))
+    dst = torch.zeros(1000, 5000, device=DEV, dtype=BF)
+    ops.copy2d(ops.cast_bf16(big), dst[:, 1000:])
+    assert torch.equal(dst[:, 1000:], big.to(BF)) and float(dst[:, :1000].abs().max()) == 0.0
+    g = torch.Generator().manual_seed(4)
+    xb = torch.randn(777, 4000, generator=g).to(DEV).to(BF)
+    cs = ops.colsum(xb)
+    np.testing.assert_allclose(cs.cpu().numpy(), xb.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)

@@ -475,7 +475,7 @@ def test_row_topk_matches_sorted_log_softmax(rows, cols, k):
 
 @pytest.mark.parametrize("mode,M,N,K", [("nt", 1280, 4000, 1000), ("nn", 640, 3000, 4000), ("tn", 4000, 1000, 2176), ("nt", 2560, 512, 2048)])
 def test_gemm_bf16x3_split_mode_is_fp32_grade(mode, M, N, K):
-    """subgc_set_gemm_mode(1): fp32 operands split exactly into 3 bf16 planes, 6 bf16-MFMA terms, fp32 accumulate
+    """SUBGC_GEMM_MODE_BF16X3: fp32 operands split exactly into 3 bf16 planes, 6 bf16-MFMA terms, fp32 accumulate
     (csrc/gemm_x3.h).  Its error against an fp64 product must stay within 2x of the fp32-MFMA kernel's."""
     from subgc import _lib
     ops.ensure_workspace(DEV)
@@ -485,14 +485,11 @@ def test_gemm_bf16x3_split_mode_is_fp32_grade(mode, M, N, K):
     bd = b.double().t() if mode == "nt" else b.double()
     ref = ad @ bd
     errs = []
-    try:
-        for m in (0, 1):
-            _lib.call("subgc_set_gemm_mode", m)
+    for m in ("f32", "bf16x3"):
+        with ops.gemm_mode(m):
             out = torch.empty(M, N, device=DEV)
             ops.gemm(a, b, out, ta=mode == "tn", tb=mode == "nt")
             errs.append(float((out.double() - ref).abs().max()))
-    finally:
-        _lib.call("subgc_set_gemm_mode", 0)
     scale = float(ref.abs().max())
     assert errs[0] < 2e-5 * scale and errs[1] < 2e-5 * scale, errs
     assert errs[1] <= 2.0 * errs[0] + 1e-7 * scale, errs
