@@ -38,7 +38,28 @@ KAR = dict(caption_model="topdown", vocab_size=9487, input_encoding_size=1000, r
            use_gpn=1, embed_dim=300, gcn_dim=1024, noun_fuse=1, pred_emb_type=1, gcn_layers=2, gcn_residual=2, gcn_bn=0,
            obj_name_path=None, rel_name_path=None)
 MFMA_F32_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16); never the 2:1-sparse 5 PF
+HBM_PEAK_GBPS = 8000.0
 MODEL_GFLOP_PER_IMAGE = 22.0            # live-graph fwd 7.32 GFLOP x 3 (fwd+bwd)
+FULLGC = dict(KAR, use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1, compute_dtype="bf16")
+FLICKR = dict(KAR, vocab_size=7000, fc_feat_size=4096, att_feat_size=4096, gcn_dim=2048, compute_dtype="bf16")
+# --config: the headline workload (BASELINE.json configs[1]) and the two bf16 parity configs as their own contract lines
+CONFIGS = {
+    "kar": dict(opt=KAR, batch=128, data={}, dtype="f32", peak=MFMA_F32_PEAK_TFLOPS, gflop_img=MODEL_GFLOP_PER_IMAGE,
+                kernel="gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", metric="images/sec (training fwd+bwd), Sub_GC_Kar",
+                workload="Sub_GC_Kar train fwd+bwd (BASELINE.json configs[1]): 128 images/GPU, 36+1 nodes, 64+1 relations, "
+                         "2048-d region feats, 5 sentences/image, 2 pos + 2 neg sub-graphs/sentence, T=17, V+1=9488, dropout on"),
+    "full_gc_kar": dict(opt=FULLGC, batch=256, data={}, dtype="bf16", peak=MFMA_BF16_PEAK_TFLOPS, gflop_img=3 * 9.01,
+                        kernel="gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, bf16-stored operands)",
+                        metric="images/sec (training fwd+bwd), Full_GC_Kar bf16",
+                        workload="Full_GC_Kar train fwd+bwd (BASELINE.json configs[2]): 256 images/GPU, full-graph 4-layer GCN with BatchNorm, "
+                                 "no sGPN, attention over all 36 nodes, bf16 compute / fp32 masters, T=17, V+1=9488, dropout on"),
+    "flickr": dict(opt=FLICKR, batch=64, data=dict(N=101, K=301, D=4096, n_edges=300, max_nodes=30, vocab=7000), dtype="bf16",
+                   peak=MFMA_BF16_PEAK_TFLOPS, gflop_img=3 * 12.1, kernel="gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, bf16-stored operands)",
+                   metric="images/sec (training fwd+bwd), Sub_GC_Flickr stress bf16",
+                   workload="Flickr stress shape train fwd+bwd (BASELINE.json configs[4]): 64 images/GPU, 100+1 nodes, 300+1 relations, 4096-d "
+                            "feats, gcn_dim 2048, V+1=7001, bf16 compute / fp32 masters, dropout on"),
+}
 
 
 def lw_args(b):
@@ -62,6 +83,27 @@ def effective_cores():
         except Exception:
             pass
     return n
+
+
+def cpu_decode_baseline(M, images=2):
+    """The oracle's greedy decode as the reference runs it (one image per call, test.py:184-185; NMS 0.75 keeping <= 10 of the 2M
+    candidate sub-graphs, 20 tokens each; the python-set NMS of gpn.py:101-150 included): tokens/s on the host cores."""
+    from oracle import subgc_oracle as O
+    cores = effective_cores()
+    torch.set_num_threads(cores)
+    opt = argparse.Namespace(**dict(KAR, test_LSTM=1, gpn_nms_thres=0.75, gpn_max_subg=10))
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in models.setup(opt).state_dict().items()}
+    orc = O.Oracle(opt, sd)
+    batches = [synthetic.make_test_batch(M, seed=500 + i) for i in range(images)]
+    sopt = dict(sample_max=1, beam_size=1)
+    tokens, t0 = 0, time.perf_counter()
+    for b in batches:
+        seq = orc.sample(*synthetic.sample_args(b), opt=sopt)[0]
+        tokens += seq.size(0) * seq.size(1)
+    dt = time.perf_counter() - t0
+    return {"value": round(tokens / dt, 1), "unit": "tokens/s", "cores": cores, "kind": "port", "s_per_image": round(dt / images, 3),
+            "sample": f"oracle greedy decode, {images} images looped one per call, {2 * M} candidate sub-graphs each -> NMS 0.75 -> <= 10 kept x 20 tokens"}
 
 
 def cpu_train_baseline(images, iters):
@@ -109,6 +151,29 @@ def decode_bench(model_sd, dev, images, M):
     dt = time.perf_counter() - t0
     out = {"decode_tokens_per_s": round(tokens / dt, 1), "decode_ms_per_image": round(1e3 * dt / images, 3),
            "decode_config": f"greedy, {2 * M} candidate sub-graphs/image -> NMS 0.75 -> <=10 kept x 20 tokens, {images} images looped"}
+    # decode roofline: the token loop streams the decoder's weights once per step (weight-streaming GEMMs, M <= 16 rows).  The
+    # captured loop of the 10-row case is replayed alone and timed with events on its stream: bytes streamed per step / time per step.
+    loops = [g for k, g in getattr(m, "_graph_cache", {}).items() if hasattr(g, "st") and g.n == 10]
+    if loops:
+        g = loops[0]
+        R, A, V1 = m.rnn_size, m.att_hid_size, m.vocab_size + 1
+        steps = g.T + 1
+        bytes_step = 4.0 * (4 * R * 2 * R + 4 * R * 3 * R + A * R + V1 * R) + 4.0 * g.n * 4 * R      # both LSTM matrices, h2att, logit + the x->gates rows
+        for _ in range(3):
+            g.graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            g.graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us_step = 1e3 * e0.elapsed_time(e1) / 20 / steps
+        gbps = bytes_step / (us_step * 1e-6) / 1e9
+        out["decode_roofline"] = {"bound": "hbm", "kernel": "gemm_skinny_mfma_kernel (weight streaming, M <= 16 rows)", "achieved": round(gbps, 1),
+                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                                  "bytes_per_step": round(bytes_step), "us_per_step": round(us_step, 2), "steps_per_replay": steps,
+                                  "note": "whole replayed token loop of one image (10 sub-graphs; 5 launches per step + the in-graph survivor "
+                                          "gathers) / 21 steps; the 120 MB of weights fit the 256 MiB Infinity Cache, so the HBM roof is generous"}
     # the same images, decoded `group` at a time as one batch (sample_images): same tokens per image, weights streamed once per step
     group = min(256, images)                              # sized for 288 GB: 2560 sub-graph rows per decode step
     m.sample_images(batches[:group], opt=sopt)
@@ -164,7 +229,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU (Sub_GC_Kar bench workload: 128)")
+    ap.add_argument("--config", default="kar", choices=sorted(CONFIGS), help="kar = the headline (BASELINE.json configs[1]); full_gc_kar / "
+                    "flickr = the bf16 parity configs 3 / 5 as their own contract lines")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the config's, 128 for Sub_GC_Kar)")
     ap.add_argument("--cpu-images", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,6 +241,9 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true", help="accepted for older command lines: the optimizer step is on by default")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    a.batch = a.batch or cfg["batch"]
+    headline = a.config == "kar"
 
     # SUBGC_BENCH_REHEARSAL=1: run the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo carrying the tensors) --
     # a functional rehearsal of the launch contract, not a measurement
@@ -187,18 +257,18 @@ def main():
     torch.cuda.set_device(dev)
     _lib.lib()
     torch.manual_seed(1234)                     # identical replicas on every rank
-    opt = argparse.Namespace(**KAR)
+    opt = argparse.Namespace(**cfg["opt"])
     model = models.setup(opt).to(dev).train()
     model.ss_prob = a.ss_prob
     lw = models.LossWrapper(model, None)
-    batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=1000 + rank).items()}
+    batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=1000 + rank, **cfg["data"]).items()}
     red = parallel.GradBucketReducer(model)
     adam = None if a.no_optimizer else parallel.FlatAdam(model)      # a training step ends with the parameter update (misc/utils.py:174-200 + Adam)
 
     def step():
         red.prepare()
         out = lw(*lw_args(batch))
-        loss = out["lang_loss"] + out["gpn_loss"]
+        loss = out["lang_loss"] + out["gpn_loss"] if out["gpn_loss"] is not None else out["lang_loss"]
         loss.backward()
         red.finish(average=adam is None)                 # with the optimizer on, 1/world rides in its sweep
         if adam is not None:
@@ -257,22 +327,21 @@ def main():
         flops_step = ops.FLOPS["gemm"]
         alg_bytes_launch = ops.FLOPS["gemm_bytes"] / max(ops.FLOPS["gemm_calls"], 1)
         n_s = max(len(sampled), 1)
-        traffic, traffic_note = pmc_traffic(a, world, n_launch // n_s)
+        traffic, traffic_note = pmc_traffic(a, world, n_launch // n_s) if headline else (None, "no PMC profile for this configuration")
         achieved = flops_step * n_s / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         ms_per_step = 1e3 * elapsed / a.steps
         imgs = world * a.batch
         res = {
-            "metric": "images/sec (training fwd+bwd), Sub_GC_Kar", "value": round(imgs * a.steps / elapsed, 2), "unit": "images/s",
+            "metric": cfg["metric"], "value": round(imgs * a.steps / elapsed, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Sub_GC_Kar train fwd+bwd (BASELINE.json configs[1]): 128 images/GPU, 36+1 nodes, 64+1 relations, "
-                                   "2048-d region feats, 5 sentences/image, 2 pos + 2 neg sub-graphs/sentence, T=17, V+1=9488, dropout on",
+            "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["workload"],
                        "images_per_gpu": a.batch, "global_images": imgs, "parallelism": f"dp{world}" if world > 1 else "single",
                        "decoder": "packed (length-sorted, loss-only: masked-out steps skipped; identical loss and gradients)",
                        "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")
                                    + (f" + scheduled sampling p={a.ss_prob} (per-step logits and draws)" if a.ss_prob > 0 else "")},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
-                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": cfg["kernel"], "achieved": round(achieved, 2),
+                         "peak": cfg["peak"], "unit": "TFLOP/s", "frac": round(achieved / cfg["peak"], 4),
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": round(alg_bytes_launch), "launches_per_step": n_launch // n_s,
                          "event_sampled_steps": f"{len(sampled)} of the {a.steps} timed steps ({n_launch} launches)",
@@ -281,11 +350,11 @@ def main():
                          # whole step (all kernels + gaps) against the MFMA peak: with the GEMM FLOPs actually executed, and with
                          # the reference's nominal live-graph FLOPs (22.0 GFLOP/image; includes the masked-out decoder
                          # steps that the packed loss-only path never computes)
-                         "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                         "whole_step_frac_nominal": round(MODEL_GFLOP_PER_IMAGE * a.batch / (ms_per_step * 1e-3) / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
+                         "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / cfg["peak"], 4),
+                         "whole_step_frac_nominal": round(cfg["gflop_img"] * a.batch / (ms_per_step * 1e-3) / 1e3 / cfg["peak"], 4)},
             "final_loss": round(final_loss, 4),
         }
-        if world == 1:
+        if world == 1 and headline:
             # the HBM-bound kernel families of the same step (reported individually in GB/s against the 8 TB/s
             # roof): two extra untimed steps with every family bracketed by HIP events on its launch stream; algorithmic
             # bytes are counted by the entry points themselves (attention: sum of the ragged set sizes, counted here)
@@ -321,7 +390,22 @@ def main():
             dt = time.perf_counter() - t0
             adam = saved
             res["fwd_bwd_only"] = {"value": round(imgs * a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3)}
-        if world == 1 and not a.packed_only:
+        if world == 1 and headline:
+            # host side of the step: the same launch sequence on a 4-image batch -- the device work shrinks ~30x, the number of
+            # launches and host reads does not, so the step time there is what the host needs to enqueue one step
+            small = {k: v.to(dev) for k, v in synthetic.make_train_batch(4, seed=999).items()}
+            big, batch = batch, small
+            for _ in range(3):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            fence()
+            res["host_enqueue_ms_per_step"] = round(1e2 * (time.perf_counter() - t0), 3)
+            res["host_enqueue_note"] = "ms per step of the identical launch sequence on a 4-image batch (device time negligible): the host-side floor of a step"
+            batch = big
+        if world == 1 and headline and not a.packed_only:
             # the same step with the loss-only packing switched off (every sentence runs all T steps, `outputs`
             # is materialised exactly like the reference does): reported beside the default for comparison
             model.packed_decoder = False
@@ -354,11 +438,16 @@ def main():
                         "value": round(imgs * a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3),
                         "gemm_algorithmic_tflops": round(flops_step * ns3 / (ms3 * 1e-3) / 1e12, 2),
                         "final_loss": round(float(loss3.item()), 4), "note": notes[mode]}
-        if world == 1 and not a.no_decode:
+        if world == 1 and headline and not a.no_decode:
             res.update(decode_bench(model.state_dict(), dev, images=256, M=50))
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and headline and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_train_baseline(a.cpu_images, a.cpu_iters)
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+            # the reference's own CPU-runnable case (B = 2) and its decode shape at M = 50 and M = 500 pairs
+            res["cpu_baseline_b2"] = cpu_train_baseline(2, 5)
+            if not a.no_decode:
+                res["cpu_baseline_decode"] = {"M50": cpu_decode_baseline(50, 4), "M500": cpu_decode_baseline(500, 2)}
+                res["decode_speedup_vs_cpu_M50"] = round(res["decode_tokens_per_s"] / res["cpu_baseline_decode"]["M50"]["value"], 1)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

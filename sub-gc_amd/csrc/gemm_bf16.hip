@@ -44,11 +44,8 @@ struct Args {
     float keep_scale;
 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int ROWB = BK * 2;                                   // bytes per LDS row
-constexpr int OPER = BM * ROWB;                                // bytes per operand and stage (16 KB)
-constexpr int STAGE = 2 * OPER;
-constexpr size_t LDS_BYTES = 2 * STAGE;                        // 64 KB
+constexpr int BK = 64;
+constexpr int ROWB = BK * 2;                                   // bytes per LDS row of a K-contiguous image
 
 __device__ __forceinline__ uint32_t f2bf(float x) {            // round-to-nearest-even, NaN kept quiet
     uint32_t u = __float_as_uint(x);
@@ -57,169 +54,179 @@ __device__ __forceinline__ uint32_t f2bf(float x) {            // round-to-neare
 }
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + (((chunk ^ (row >> 1)) & 7) << 4); }
 
-// ---- staging -----------------------------------------------------------------------------------------------------------
-// One operand tile (128 rows x 64 k).  KM = false: memory rows are K-contiguous; KM = true: memory is [k][row].
-template <bool KM>
-struct Stage {
-    uint4 r[4];
-    const uint16_t* base[4];
-    int64_t ld_;
-    unsigned ok;                                               // KM: bit j = r[j] holds a k inside K; !KM: how many of the chunk's 8 k lie inside K
-    bool colok;                                                // KM: this thread's 8-row group lies inside the operand
+// ---- LDS-DMA form ------------------------------------------------------------------------------------------------------
+// The register-staged loop above spends more LDS cycles on its ds_write traffic (8 x ds_write_b128 ~ 13 cycles each per wave and
+// K-tile) than on the fragment reads: it is LDS-issue bound at ~0.5 PFLOP/s.  Here the tiles travel HBM -> LDS directly
+// (global_load_lds_dwordx4, 1 KB per wave instruction, no VGPRs, no ds_write), and the LDS image follows the MEMORY layout:
+//   K-contiguous operand: [128 rows][64 k] as above (chunk ^ (row >> 1) & 7); a lane fetches the chunk whose swizzled place
+//       is its linear LDS slot (the DMA writes lane l at base + 16 l), i.e. the swizzle is applied to the SOURCE address;
+//       fragments by ds_read_b128.
+//   K-major operand: [64 k][128 rows] (256-byte k-rows; 16-byte chunk ^ ((k & 3) << 2)); fragments by TWO
+//       ds_read_b64_tr_b16: the 16 lanes of a group address a [4 k][16 rows] block (lane i: k-row i / 4, rows 4 (i % 4) .. +3)
+//       and lane i receives (k .. k+3) of row i -- the hardware transpose; the XOR puts the four k-rows of a block into
+//       four different 64-byte windows of the 256-byte bank row (conflict-free).
+// Two stages; tile f + 1 is in flight while tile f is multiplied; one barrier per K-tile.  A partial last K-tile (K % 64 != 0)
+// cannot be masked by the DMA and goes through registers (zero fill), un-pipelined.
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+#define SUBGC_LDS(p) ((__attribute__((address_space(3))) unsigned char*)(p))
 
-    __device__ __forceinline__ void init(const uint16_t* src, int64_t ld, int row0, int nrows) {
-        const int t = threadIdx.x;
-        ld_ = ld;
-        if (!KM) {
+// Geometry of one workgroup: TBM x TBN output tile, WM x WN waves of 64x64 each.  Two instances:
+//   128x128, 2x2 waves (256 threads), 64 KB of LDS, two workgroups per CU -- shapes with few tiles (with split-K);
+//   256x256, 4x4 waves (1024 threads), 128 KB, one workgroup per CU -- the large products.  The 128x128 form is bound by what a
+//   CU can pull from L2 (~16 B/clk: 32 KB per 2.1 MFLOP K-step); the 256x256 tile needs half the bytes per flop.
+template <int TBM_, int TBN_>
+struct Geo {
+    static constexpr int TBM = TBM_, TBN = TBN_, WM = TBM_ / 64, WN = TBN_ / 64, NW = WM * WN, NT = NW * 64;
+    static constexpr int A_BYTES = TBM_ * ROWB, B_BYTES = TBN_ * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr size_t LDS = 2 * (size_t)STAGE_BYTES;
+};
+
+// K-major image of an operand tile with ROWS rows: [64 k][ROWS], 16-byte chunk c of k-row k at chunk c ^ ((k & 3) << 2)
+template <int ROWS>
+__device__ __forceinline__ int swz_km(int k, int chunk) { return k * (ROWS * 2) + ((chunk ^ ((k & 3) << 2)) << 4); }
+
+template <bool KM, int ROWS, int NW>
+struct Dma {
+    static constexpr int NI = ROWS / 8 / NW;                   // 1 KB wave instructions per wave and tile
+    static_assert(NI >= 1 && NI * NW * 8 == ROWS, "tile rows must split evenly over the waves");
+    const uint16_t* src[NI];                                   // this lane's source per instruction, at k0 = 0
+    int64_t kstride;
+
+    __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int row0, int nrows) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = min(row0 + (t >> 3) + 32 * v, nrows - 1);      // rows past the edge: a valid row, never stored
-                base[v] = src + (int64_t)max(row, 0) * ld + (t & 7) * 8;
+        for (int v = 0; v < NI; ++v) {
+            const int q = wave * NI + v;                       // instruction q fills LDS bytes [1024 q, 1024 q + 1024) of the region
+            if (!KM) {
+                const int r = q * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int row = max(min(row0 + r, nrows - 1), 0);
+                src[v] = base + (int64_t)row * ld + c * 8;
+            } else {
+                const int byte = q * 1024 + lane * 16;
+                const int k = byte / (ROWS * 2), pc = (byte % (ROWS * 2)) >> 4;
+                const int c = pc ^ ((k & 3) << 2);
+                const int col = row0 + c * 8;
+                src[v] = base + (int64_t)k * ld + (col < nrows ? col : 0);
             }
-            colok = true;
-        } else {
-            const int col = row0 + (t >> 4) * 8;
-            colok = col < nrows;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) base[j] = src + (colok ? col : 0);     // + k * ld per tile
         }
+        kstride = KM ? ld : 1;
     }
-    // tile starting at k0; K = logical contraction length
-    template <bool INTERIOR>
-    __device__ __forceinline__ void load(int k0, int K) {
-        const int t = threadIdx.x;
-        if (!KM) {
-            const int k = k0 + (t & 7) * 8;
-            const bool in = INTERIOR || k < K;
-            ok = INTERIOR ? 8u : (unsigned)min(max(K - k, 0), 8);   // a chunk straddling K keeps its leading K - k elements
+    __device__ __forceinline__ void issue(unsigned char* region, int k0) const {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) r[v] = *reinterpret_cast<const uint4*>(base[v] + (in ? k0 : -((t & 7) * 8)));
-        } else {
-            ok = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + (t & 15) * 4 + j;
-                const bool in = INTERIOR || k < K;
-                r[j] = *reinterpret_cast<const uint4*>(base[j] + (int64_t)(in ? k : 0) * ld_);
-                if (in) ok |= 1u << j;
-            }
-        }
+        for (int v = 0; v < NI; ++v)
+            __builtin_amdgcn_global_load_lds(src[v] + (int64_t)k0 * kstride,
+                                             (__attribute__((address_space(3))) void*)SUBGC_LDS(region + (wave * NI + v) * 1024), 16, 0, 0);
     }
-    template <bool INTERIOR>
-    __device__ __forceinline__ void store(unsigned char* lds) const {
-        const int t = threadIdx.x;
-        if (!KM) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = (t >> 3) + 32 * v;
-                uint4 q = r[v];
-                if (!INTERIOR && ok < 8u) {                    // K tail: zero the elements at and past K (the row's ld covers the over-read)
-                    const unsigned nv = ok;
+    // partial tile through registers: k >= K reads as zero
+    __device__ __forceinline__ void tail(unsigned char* region, const uint16_t* base, int64_t ld, int row0, int nrows, int k0, int K) const {
+        constexpr int NT = NW * 64;
+        for (int i = threadIdx.x; i < ROWS * 8; i += NT) {
+            if (!KM) {
+                const int r = i >> 3, c = i & 7, k = k0 + c * 8;
+                const int row = max(min(row0 + r, nrows - 1), 0);
+                const int nv = min(max(K - k, 0), 8);
+                uint4 q = nv > 0 ? *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + k) : make_uint4(0u, 0u, 0u, 0u);
+                if (nv < 8) {
                     uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) w[d] = (2u * d + 1u < nv) ? w[d] : ((2u * d < nv) ? (w[d] & 0xffffu) : 0u);
+                    for (int d = 0; d < 4; ++d) w[d] = (2 * d + 1 < nv) ? w[d] : ((2 * d < nv) ? (w[d] & 0xffffu) : 0u);
                     q = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                *reinterpret_cast<uint4*>(lds + swz(row, t & 7)) = q;
-            }
-        } else {
-            uint32_t w[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool in = INTERIOR || ((ok >> j) & 1u);
-                w[j][0] = in ? r[j].x : 0u; w[j][1] = in ? r[j].y : 0u; w[j][2] = in ? r[j].z : 0u; w[j][3] = in ? r[j].w : 0u;
-            }
-            const int kq = t & 15, rg = t >> 4;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {                      // row rg*8 + e gets k = 4*kq .. +3
-                const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
-                uint2 o;
-                o.x = __builtin_amdgcn_perm(w[1][e >> 1], w[0][e >> 1], sel);
-                o.y = __builtin_amdgcn_perm(w[3][e >> 1], w[2][e >> 1], sel);
-                const int row = rg * 8 + e;
-                *reinterpret_cast<uint2*>(lds + swz(row, kq >> 1) + (kq & 1) * 8) = o;
+                *reinterpret_cast<uint4*>(region + swz(r, c)) = q;
+            } else {
+                const int k = i / (ROWS / 8), c = i % (ROWS / 8), col = row0 + c * 8;
+                const bool in = k0 + k < K;
+                const uint4 q = in ? *reinterpret_cast<const uint4*>(base + (int64_t)(k0 + k) * ld + (col < nrows ? col : 0)) : make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(region + swz_km<ROWS>(k, c)) = q;
             }
         }
     }
 };
 
-__device__ __forceinline__ bf16x8 frag(const unsigned char* lds, int r0, int step, int lane) {
-    const int row = r0 + (lane & 31);
-    return *reinterpret_cast<const bf16x8*>(lds + swz(row, step * 2 + (lane >> 5)));
-}
+// Fragment addressing of one operand image, hoisted out of the K loop: `base` = this lane's LDS byte offset for the 32-row
+// MFMA tile at r0 and step 0; a later step is an XOR (K-contiguous image: chunk index bits 1-2) or a constant add (K-major
+// image: 16 k-rows further; the swizzle only depends on k & 3).
+template <bool KM, int ROWS>
+struct FragAddr {
+    int base;
+    __device__ __forceinline__ void init(int r0, int lane) {
+        if (!KM) {
+            const int row = r0 + (lane & 31);
+            base = swz(row, lane >> 5);
+        } else {
+            const int g = lane >> 4, i = lane & 15;
+            const int k = (g >> 1) * 8 + (i >> 2);
+            const int c = ((r0 + (g & 1) * 16) >> 3) + ((i & 3) >> 1);
+            base = swz_km<ROWS>(k, c) + (i & 1) * 8;
+        }
+    }
+    __device__ __forceinline__ bf16x8 load(const unsigned char* region, int step) const {
+        if (!KM) return *reinterpret_cast<const bf16x8*>(region + (base ^ (step << 5)));
+        const unsigned char* p0 = region + base + step * 16 * (ROWS * 2);
+        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)SUBGC_LDS(p0));
+        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)SUBGC_LDS(p0 + 4 * (ROWS * 2)));
+        union { struct { i16x4 a, b; } h; bf16x8 v; } u;
+        u.h.a = lo; u.h.b = hi;
+        return u.v;
+    }
+};
 
-// acc += A[m0.., kt0*BK .. kt1*BK) x B[.., n0..]
-template <bool A_KM, bool B_KM>
-__device__ __forceinline__ void mainloop(const Args& p, unsigned char* smem, int M, int K, int m0, int n0, int kt0, int kt1,
-                                         f32x16 (&acc)[2][2]) {
+template <typename G, bool A_KM, bool B_KM>
+__device__ __forceinline__ void mainloop_dma(const Args& p, unsigned char* smem, int M, int K, int m0, int n0, int kt0, int kt1,
+                                             f32x16 (&acc)[2][2]) {
+#if defined(__HIP_DEVICE_COMPILE__)       // gfx950 builtins inside: hipcc's host pass gets an empty body
     if (kt1 <= kt0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    Stage<A_KM> sa;
-    Stage<B_KM> sb;
-    sa.init(p.A, p.lda, m0, M);
-    sb.init(p.B, p.ldb, n0, p.N);
-    sa.template load<false>(kt0 * BK, K);
-    sb.template load<false>(kt0 * BK, K);
-    sa.template store<false>(smem);
-    sb.template store<false>(smem + OPER);
-    if (kt0 + 1 < kt1) {
-        sa.template load<false>((kt0 + 1) * BK, K);
-        sb.template load<false>((kt0 + 1) * BK, K);
-    }
-    __syncthreads();
-    bf16x8 fa[2][2], fb[2][2];
+    const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64;
+    Dma<A_KM, G::TBM, G::NW> da;
+    Dma<B_KM, G::TBN, G::NW> db;
+    da.init(p.A, p.lda, m0, M);
+    db.init(p.B, p.ldb, n0, p.N);
+    const int full_end = min(kt1, K / BK);                     // tiles kt0 .. full_end-1 lie entirely inside K
+    FragAddr<A_KM, G::TBM> xa[2];
+    FragAddr<B_KM, G::TBN> xb[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) fa[0][a] = frag(smem, wm + a * 32, 0, lane);
+    for (int a = 0; a < 2; ++a) xa[a].init(wm + a * 32, lane);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) fb[0][b] = frag(smem + OPER, wn + b * 32, 0, lane);
-
-    auto ktile = [&](int kt, auto steady_tag) {
-        constexpr bool STEADY = decltype(steady_tag)::value;   // tiles kt+1 and kt+2 exist and are interior: no masks, no tests
-        const int cur = (kt - kt0) & 1;
-        const unsigned char* lc = smem + cur * STAGE;
-        unsigned char* ln = smem + (cur ^ 1) * STAGE;
-        const bool has_next = STEADY || kt + 1 < kt1;
+    for (int b = 0; b < 2; ++b) xb[b].init(wn + b * 32, lane);
+    auto compute = [&](const unsigned char* st) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int fc = s & 1, fn = fc ^ 1;
-            if (s + 1 < 4) {
+            bf16x8 fa[2], fb[2];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) fa[fn][a] = frag(lc, wm + a * 32, s + 1, lane);
+            for (int a = 0; a < 2; ++a) fa[a] = xa[a].load(st, s);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) fb[fn][b] = frag(lc + OPER, wn + b * 32, s + 1, lane);
-            }
-            if (s == 1 && has_next) {                          // drain the staging registers into the other stage, refill them
-                sa.template store<STEADY>(ln);
-                sb.template store<STEADY>(ln + OPER);
-                if (STEADY) {
-                    sa.template load<true>((kt + 2) * BK, K);
-                    sb.template load<true>((kt + 2) * BK, K);
-                } else if (kt + 2 < kt1) {
-                    sa.template load<false>((kt + 2) * BK, K);
-                    sb.template load<false>((kt + 2) * BK, K);
-                }
-            }
-            if (s == 3) {
-                __syncthreads();
-                if (has_next) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) fa[fn][a] = frag(ln, wm + a * 32, 0, lane);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) fb[fn][b] = frag(ln + OPER, wn + b * 32, 0, lane);
-                }
-            }
+            for (int b = 0; b < 2; ++b) fb[b] = xb[b].load(st + G::A_BYTES, s);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fc][a], fb[fc][b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
     };
-    int kt = kt0;
-    const int steady_end = min(kt1, K / BK) - 2;
-    for (; kt < steady_end; ++kt) ktile(kt, std::true_type{});
-    for (; kt < kt1; ++kt) ktile(kt, std::false_type{});
+    if (kt0 < full_end) {
+        da.issue(smem, kt0 * BK);
+        db.issue(smem + G::A_BYTES, kt0 * BK);
+    }
+    for (int kt = kt0; kt < full_end; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt have landed ...
+        __syncthreads();                                       // ... and so have everybody's; everybody is done reading the other stage
+        if (kt + 1 < full_end) {
+            da.issue(smem + (cur ^ 1) * G::STAGE_BYTES, (kt + 1) * BK);
+            db.issue(smem + (cur ^ 1) * G::STAGE_BYTES + G::A_BYTES, (kt + 1) * BK);
+        }
+        compute(smem + cur * G::STAGE_BYTES);
+    }
+    if (full_end < kt1) {                                      // the partial last tile of K
+        __syncthreads();
+        da.tail(smem, p.A, p.lda, m0, M, full_end * BK, K);
+        db.tail(smem + G::A_BYTES, p.B, p.ldb, n0, p.N, full_end * BK, K);
+        __syncthreads();
+        compute(smem);
+    }
+#endif
 }
 
 // workgroup -> tile mapping (see gemm_f32.hip): XCD b % 8 gets a contiguous chunk of a GROUP_M-ordered tile sequence
@@ -246,21 +253,21 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Args p) {
+template <typename G, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(G::NT, G::NT == 256 ? 2 : 4) void gemm_bf16_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = (p.m_dev && !A_KM) ? min(p.M, *p.m_dev) : p.M;
     const int K = (p.m_dev && A_KM) ? min(p.K, *p.m_dev) : p.K;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, live = tiles_m * tiles_n;
+    const int tiles_m = (M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN, live = tiles_m * tiles_n;
     if ((int)blockIdx.x >= live) return;
     int tm, tn;
     tile_of(xcd_chunked_id(blockIdx.x, live), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * G::TBM, n0 = tn * G::TBN;
     f32x16 acc[2][2];
     zero_acc(acc);
-    mainloop<A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+    mainloop_dma<G, A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, col_l = lane & 31, hrow = 4 * (lane >> 5);
+    const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64, col_l = lane & 31, hrow = 4 * (lane >> 5);
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -287,24 +294,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Args p) {
     }
 }
 
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_splitk_kernel(const Args p, float* __restrict__ ws, int splits, int kt_per_split) {
+template <typename G, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(G::NT, G::NT == 256 ? 2 : 4) void gemm_bf16_splitk_kernel(const Args p, float* __restrict__ ws, int splits, int kt_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const int u = xcd_chunked_id(blockIdx.x, gridDim.x);
     const int tile = u / splits, part = u - tile * splits;
     int tm, tn;
     tile_of(tile, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * G::TBM, n0 = tn * G::TBN;
     const int K = (A_KM && p.m_dev) ? min(p.K, *p.m_dev) : p.K;
     const int kt_all = (K + BK - 1) / BK;
     if (A_KM && p.m_dev) kt_per_split = (kt_all + splits - 1) / splits;
     const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
     f32x16 acc[2][2];
     zero_acc(acc);
-    mainloop<A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
+    mainloop_dma<G, A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, col_l = lane & 31, hrow = 4 * (lane >> 5);
+    const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64, col_l = lane & 31, hrow = 4 * (lane >> 5);
     float* out = ws + (size_t)part * p.M * p.N;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -351,46 +358,85 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __r
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// number of K parts for `tiles` 128x128 tiles over kt K-tiles of 64: fill the 512 workgroup slots in whole rounds
-inline int choose_splits(int64_t tiles, int kt) {
-    int best = 1;
-    double best_cost = 1e30;
-    for (int s = 1; s <= 8; ++s) {
-        const int per = (kt + s - 1) / s;
-        if (s > 1 && per < 6) break;                            // keep >= 384 of K per part
-        const int64_t rounds = (tiles * s + 511) / 512;
-        const double cost = rounds * (per + 2.0) + 0.5 * (s > 1 ? s + 1 : 0);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+using G128 = Geo<128, 128>;
+using G256 = Geo<256, 256>;
+
+// Cost model of a launch: `tiles` workgroups x `splits` K parts over `slots` resident workgroups, each walking kt / splits
+// K-tiles (+ prologue / epilogue); a 256x256 workgroup does 4x the flops of a 128x128 one in ~2x the time (the L2 -> LDS
+// path, not the matrix pipe, sets the pace of both).
+struct Plan { int big; int splits; double cost; };
+inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes) {
+    const int kt = (int)subgc::cdiv(K, BK);
+    Plan best{0, 1, 1e30};
+    for (int big = 0; big < 2; ++big) {
+        const int64_t tiles = big ? subgc::cdiv(M, 256) * subgc::cdiv(N, 256) : subgc::cdiv(M, 128) * subgc::cdiv(N, 128);
+        const int slots = big ? 256 : 512;
+        const double per_tile = big ? 2.0 : 1.0, fixed = big ? 6.0 : 3.0;      // K-tile pace, prologue + epilogue in K-tile units
+        for (int s = 1; s <= 8; ++s) {
+            if (s > 1 && (!may_split || (kt + s - 1) / s < 6 || (size_t)s * M * N * sizeof(float) > ws_bytes)) break;
+            const int per = (kt + s - 1) / s;
+            const int64_t rounds = (tiles * s + slots - 1) / slots;
+            const double cost = rounds * (per * per_tile + fixed) + (s > 1 ? 1.0 + 0.4 * s : 0.0);
+            if (cost < best.cost - 1e-9) best = Plan{big, s, cost};
+        }
     }
     return best;
 }
 
-template <bool A_KM, bool B_KM>
-int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out) {
-    const int64_t tiles = subgc::cdiv(a.M, BM) * subgc::cdiv(a.N, BN);
-    const int kt = (int)subgc::cdiv(a.K, BK);
-    const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
-                       (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias));
-    int splits = 1;
-    if (ws && plain && tiles < 448) {
-        splits = choose_splits(tiles, kt);
-        while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > ws_bytes) --splits;
+template <typename KernelT>
+int raise_lds(KernelT kernel, size_t lds, bool& done) {
+    if (done || lds <= 64 * 1024) return SUBGC_OK;    // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        subgc::set_error("gemm_bf16: cannot raise dynamic LDS limit to %zu", lds);
+        return SUBGC_ELAUNCH;
     }
-    if (partials_only && splits <= 1) return -100;
-    // 64 KB of dynamic LDS: the default limit, no opt-in needed
+    done = true;
+    return SUBGC_OK;
+}
+
+template <typename G, bool A_KM, bool B_KM>
+int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t s) {
+    const int64_t tiles = subgc::cdiv(a.M, G::TBM) * subgc::cdiv(a.N, G::TBN);
+    const int kt = (int)subgc::cdiv(a.K, BK);
+    static bool attr_a = false, attr_b = false;
     if (splits <= 1) {
-        hipLaunchKernelGGL((gemm_bf16_kernel<A_KM, B_KM>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, s, a);
+        if (int rc = raise_lds(gemm_bf16_kernel<G, A_KM, B_KM>, G::LDS, attr_a)) return rc;
+        hipLaunchKernelGGL((gemm_bf16_kernel<G, A_KM, B_KM>), dim3((unsigned)tiles), dim3(G::NT), G::LDS, s, a);
         return subgc::check_launch("subgc_gemm_bf16");
     }
-    const int per = (kt + splits - 1) / splits;
-    hipLaunchKernelGGL((gemm_bf16_splitk_kernel<A_KM, B_KM>), dim3((unsigned)(tiles * splits)), dim3(256), LDS_BYTES, s, a, ws, splits, per);
-    if (splits_out) *splits_out = splits;
+    if (int rc = raise_lds(gemm_bf16_splitk_kernel<G, A_KM, B_KM>, G::LDS, attr_b)) return rc;
+    hipLaunchKernelGGL((gemm_bf16_splitk_kernel<G, A_KM, B_KM>), dim3((unsigned)(tiles * splits)), dim3(G::NT), G::LDS, s, a, ws, splits,
+                       (kt + splits - 1) / splits);
     if (partials_only) return subgc::check_launch("subgc_gemm_bf16(split-K, partials)");
     const int64_t n = (int64_t)a.M * a.N / 4;
     hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws,
                        splits, a.M, a.N, a.C32, a.ldc32, a.C16, a.ldc16, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0,
                        (a.flags & SUBGC_GEMM_RELU) ? 1 : 0);
     return subgc::check_launch("subgc_gemm_bf16(split-K)");
+}
+
+template <bool A_KM, bool B_KM>
+int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out) {
+    const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
+                       (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias));
+    static const int force = [] { const char* e = getenv("SUBGC_BF16_TILE"); return e ? atoi(e) : 0; }();     // 128 / 256: tile A/B timing
+    Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes);
+    if (partials_only) {                                        // the LSTM cell kernel adds row-major planes: 128x128 split form only
+        pl = Plan{0, 1, 0.0};
+        const int64_t tiles = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
+        const int kt = (int)subgc::cdiv(a.K, BK);
+        double best = 1e30;
+        for (int sp = 2; sp <= 8 && (kt + sp - 1) / sp >= 6 && (size_t)sp * a.M * a.N * sizeof(float) <= ws_bytes; ++sp) {
+            const double c = (double)((tiles * sp + 511) / 512) * ((kt + sp - 1) / sp + 3.0) + 0.4 * sp;
+            if (c < best) { best = c; pl.splits = sp; }
+        }
+        if (pl.splits <= 1 || tiles >= 448) return -100;
+    } else if (force == 128 || force == 256) {
+        pl.big = force == 256;
+        if (pl.big) pl.splits = 1;
+    }
+    if (splits_out) *splits_out = pl.splits;
+    return pl.big ? launch<G256, A_KM, B_KM>(a, ws, pl.splits, partials_only, s) : launch<G128, A_KM, B_KM>(a, ws, pl.splits, partials_only, s);
 }
 
 int check(int transA, int transB, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb) {
@@ -411,9 +457,8 @@ SUBGC_API int subgc_gemm_bf16_workspace_bytes(int M, int N, int K, size_t* bytes
     // scratch the split-K form of this shape wants (its fp32 partial planes); 0 when the shape never splits.  A smaller
     // (or no) workspace is legal: the dispatch then splits less (or not at all).
     SUBGC_REQUIRE(M >= 0 && N >= 0 && K >= 0 && bytes, "gemm_bf16_workspace_bytes: bad arguments");
-    const int64_t tiles = subgc::cdiv(M, BM) * subgc::cdiv(N, BN);
-    const int sp = tiles < 448 ? choose_splits(tiles, (int)subgc::cdiv(K, BK)) : 1;
-    *bytes = sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+    const Plan pl = plan_for(M, N, K, true, (size_t)8 * M * N * sizeof(float));
+    *bytes = pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
     return SUBGC_OK;
 }
 

@@ -24,48 +24,107 @@ def _direct(p, dev):
 
 # ------------------------------------------------------------------------------- linear
 class LinearFn(Function):
-    """y = [dropout]([relu](x W^T + b [+ add])) on 2-D row-major x (any leading dim)."""
+    """y = [dropout]([relu](x W^T + b [+ add])) on 2-D row-major x (any leading dim).
+
+    With `W16` (the bf16 twin of W, compute_dtype = bf16) the three products -- forward, data gradient, weight gradient -- run
+    on bf16-stored operands (subgc_gemm_bf16): x may arrive as bf16 or is cast once (`x16` supplies an existing copy), the
+    output is fp32, or bf16 when only GEMMs consume it (`out_b16`), or both (`want16`: second, non-differentiable output);
+    d(out) is taken as fp32 or bf16, d(x) is produced in x's storage type; parameter gradients stay fp32."""
 
     @staticmethod
-    def forward(ctx, x, W, b, add, keep, scale, relu):
-        y = torch.empty(x.size(0), W.size(0), device=x.device, dtype=torch.float32)
-        ops.gemm(x, W, y, tb=True, bias=b, add=add, keep=keep, keep_scale=scale, relu=relu)
+    def forward(ctx, x, W, b, add, keep, scale, relu, W16=None, x16=None, out_b16=False, want16=False):
+        M, N = x.size(0), W.size(0)
+        dev = x.device
         ctx.relu, ctx.scale, ctx.has_add = relu, scale, add is not None
-        ctx.save_for_backward(x, W, y if (relu or keep is not None) else None)
         ctx.has_b = b is not None
         ctx.param_objs = (W, b)           # the leaf objects themselves: their .grad (a flat-bucket view) is written directly
+        ctx.b16 = W16 is not None
+        ctx.x_b16 = ops.is_b16(x)
+        if W16 is None:
+            if ops.is_b16(x) or out_b16 or want16:
+                raise ops.SubgcError("LinearFn: bf16 activations need the bf16 twin of the weight")
+            y = torch.empty(M, N, device=dev, dtype=torch.float32)
+            ops.gemm(x, W, y, tb=True, bias=b, add=add, keep=keep, keep_scale=scale, relu=relu)
+            ctx.save_for_backward(x, W, y if (relu or keep is not None) else None)
+            return y
+        if out_b16 and (relu or keep is not None):
+            raise ops.SubgcError("LinearFn: a bf16-only output cannot carry the ReLU / dropout mask its backward needs")
+        xa = x if ops.is_b16(x) else (x16 if x16 is not None else ops.as_b16(x))
+        y = ops.empty_b16(M, N, dev) if out_b16 else torch.empty(M, N, device=dev, dtype=torch.float32)
+        y16 = ops.empty_b16(M, N, dev) if want16 else None
+        ops.gemm(xa, W16, y, tb=True, bias=b, add=add, keep=keep, keep_scale=scale, relu=relu, out16=y16)
+        ctx.save_for_backward(xa, W16, y if (relu or keep is not None) else None)
+        if want16:
+            ctx.mark_non_differentiable(y16)
+            return y, y16
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, W, y = ctx.saved_tensors
-        dy = dy.contiguous()
-        dz = ops.relu_bwd(dy, y, ctx.scale) if y is not None else dy
+        dev = dy.device
         dx = dW = db = dadd = None
+        gW, gb = (_direct(p, dev) for p in ctx.param_objs)
+        if not ctx.b16:
+            dy = dy.contiguous()
+            dz = ops.relu_bwd(dy, y, ctx.scale) if y is not None else dy
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(x.size(0), W.size(1), device=dev, dtype=torch.float32)
+                ops.gemm(dz, W, dx)
+            if ctx.needs_input_grad[1]:
+                if gW is not None:            # accumulate in the GEMM epilogue: no temporary, no separate `+=` pass by autograd
+                    ops.gemm(dz, x, gW, ta=True, accum=True)
+                else:
+                    dW = torch.empty_like(W)
+                    ops.gemm(dz, x, dW, ta=True)
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                if gb is not None:
+                    ops.colsum(dz, out=gb, accumulate=True)
+                else:
+                    db = ops.colsum(dz)
+            if ctx.has_add and ctx.needs_input_grad[3]:
+                dadd = dz
+            return dx, dW, db, dadd, None, None, None, None, None, None, None
+        # bf16-stored operands: dz only feeds the two gradient GEMMs and the bias sum -> bf16 (fp32 too when `add` needs it)
+        dz32 = None
+        if y is not None:
+            dy = dy.contiguous()
+            if (ctx.has_add and ctx.needs_input_grad[3]) or y.size(1) % 8:
+                dz32 = ops.relu_bwd(dy, y, ctx.scale)
+                dz = ops.as_b16(dz32)
+                dz32 = dz32 if ctx.has_add else None
+            else:
+                dz = ops.relu_bwd(dy, y, ctx.scale, bf16=True)          # contiguous [M, N], N % 8 == 0: a legal GEMM operand as it is
+        else:
+            dz = dy if ops.is_b16(dy) else ops.as_b16(dy.contiguous())
+            if ctx.has_add and ctx.needs_input_grad[3]:
+                dz32 = dy if not ops.is_b16(dy) else dy.float()
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(x.size(0), W.size(1), device=dy.device, dtype=torch.float32)
+            dx = ops.empty_b16(x.size(0), W.size(1), dev) if ctx.x_b16 else torch.empty(x.size(0), W.size(1), device=dev, dtype=torch.float32)
             ops.gemm(dz, W, dx)
-        gW, gb = (_direct(p, dy.device) for p in ctx.param_objs)
+        Wm = ctx.param_objs[0]
         if ctx.needs_input_grad[1]:
-            if gW is not None:            # accumulate in the GEMM epilogue: no temporary, no separate `+=` pass by autograd
+            if gW is not None:
                 ops.gemm(dz, x, gW, ta=True, accum=True)
             else:
-                dW = torch.empty_like(W)
+                dW = torch.empty(Wm.shape, device=dev, dtype=torch.float32)
                 ops.gemm(dz, x, dW, ta=True)
         if ctx.has_b and ctx.needs_input_grad[2]:
             if gb is not None:
                 ops.colsum(dz, out=gb, accumulate=True)
             else:
                 db = ops.colsum(dz)
-        if ctx.has_add and ctx.needs_input_grad[3]:
-            dadd = dz
-        return dx, dW, db, dadd, None, None, None
+        if dz32 is not None:
+            dadd = dz32
+        return dx, dW, db, dadd, None, None, None, None, None, None, None
 
 
-def linear(x, W, b=None, add=None, keep=None, scale=1.0, relu=False):
+def linear(x, W, b=None, add=None, keep=None, scale=1.0, relu=False, W16=None, x16=None, out_b16=False, want16=False):
     shp = x.shape
     x2 = x.reshape(-1, shp[-1]) if x.dim() != 2 else x
     add2 = add.reshape(-1, add.shape[-1]) if add is not None and add.dim() != 2 else add
+    if W16 is not None:                  # bf16-stored operands: 2-D callers only (the result may be a padded view)
+        return LinearFn.apply(x2, W, b, add2, keep, scale, relu, W16, x16, out_b16, want16)
     y = LinearFn.apply(x2, W, b, add2, keep, scale, relu)
     return y.view(*shp[:-1], W.size(0)) if x.dim() != 2 else y
 
@@ -231,10 +290,23 @@ PARAM_ORDER = (
 )
 
 
-class Prepared:
-    """Loop-invariant decoder state (AttModel._prepare_feature + pack): shared by train and decode."""
+def bf16_twins(P, W16):
+    """Per-parameter GEMM-operand form for the decoder Functions: the bf16 twin where one exists (2-D weights with 16-byte
+    rows), the fp32 parameter otherwise (biases, alpha_net).  `W16` = list aligned with P (None entries allowed) or None."""
+    if W16 is None:
+        return list(P), False
+    missing = [n for n, w, p in zip(PARAM_ORDER, W16, P) if p.dim() == 2 and p.size(0) > 1 and w is None]
+    if missing:
+        raise ops.SubgcError(f"compute_dtype=bf16: no 16-byte-row bf16 twin for {missing}")
+    return [w if w is not None else p for w, p in zip(W16, P)], True
 
-    def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale):
+
+class Prepared:
+    """Loop-invariant decoder state (AttModel._prepare_feature + pack): shared by train and decode.
+    `W` = bf16_twins(P, ...)[0] switches the five products to bf16-stored operands: the fp32 results the pointwise kernels
+    read (f1, f, v, u) are kept, and every tensor a GEMM reads gets a bf16 twin written by its producer (`*16`)."""
+
+    def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale, W=None):
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b) = P[:8]
         dev = fc_in.device
         S = fc_in.size(0)
@@ -243,6 +315,22 @@ class Prepared:
         self.lens = lens
         MR = S * N
         L = X_nodes.size(1)
+        new = lambda r, c: torch.empty(r, c, device=dev, dtype=torch.float32)
+        if W is not None and ops.is_b16(W[0]):
+            w0, w2, wa, wc = W[0], W[2], W[4], W[6]
+            self.fc16 = ops.as_b16(fc_in)
+            self.Xg = None                                     # the gathered node rows only feed GEMMs: bf16 only
+            self.Xg16 = ops.empty_b16(MR, L, dev)
+            ops.gather_rows(X_nodes, self.src_row, self.Xg16, m_dev=self.total)
+            self.f1, self.f116 = new(S, fc0_w.size(0)), ops.empty_b16(S, fc0_w.size(0), dev)
+            ops.gemm(self.fc16, w0, self.f1, tb=True, bias=fc0_b, relu=True, out16=self.f116)
+            self.f, self.f16 = new(S, fc2_w.size(0)), ops.empty_b16(S, fc2_w.size(0), dev)
+            ops.gemm(self.f116, w2, self.f, tb=True, bias=fc2_b, relu=True, keep=keep_fc, keep_scale=scale, out16=self.f16)
+            self.v, self.v16 = ops.zeros(MR, att_w.size(0), device=dev), ops.empty_b16(MR, att_w.size(0), dev, zero=True)
+            ops.gemm(self.Xg16, wa, self.v, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total, out16=self.v16)
+            self.u = new(MR, c2a_w.size(0))
+            ops.gemm(self.v16, wc, self.u, tb=True, bias=c2a_b, m_dev=self.total)
+            return
         self.Xg = torch.empty(MR, L, device=dev, dtype=torch.float32)
         ops.gather_rows(X_nodes, self.src_row, self.Xg, m_dev=self.total)
         self.f1 = torch.empty(S, fc0_w.size(0), device=dev, dtype=torch.float32)
@@ -256,9 +344,9 @@ class Prepared:
 
 
 def _cat_weights(w_ih_part, w_hh):
-    """[W_ih(:, cols) | W_hh] as one K-contiguous operand so a recurrent step is ONE GEMM."""
+    """[W_ih(:, cols) | W_hh] as one K-contiguous operand so a recurrent step is ONE GEMM (fp32 or bf16 like its parts)."""
     R4, a = w_ih_part.shape
-    out = torch.empty(R4, a + w_hh.size(1), device=w_hh.device, dtype=torch.float32)
+    out = torch.empty(R4, a + w_hh.size(1), device=w_hh.device, dtype=w_hh.dtype)
     ops.copy2d(w_ih_part, out[:, :a])
     ops.copy2d(w_hh, out[:, a:])
     return out
@@ -278,29 +366,33 @@ class DecoderFn(Function):
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         k_fc, k_att, k_xt, k_out = (masks.get(k) for k in ("fc", "att", "xt", "out"))
         fc_in = fc_in.contiguous(); X_nodes = X_nodes.contiguous()
-        pr = Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale)
+        # W[i]: GEMM-operand form of parameter i -- its bf16 twin under compute_dtype = bf16 (meta["W16"]), else the parameter
+        W, bf = bf16_twins(P, meta.get("W16"))
+        act = lambda *shape, zero=False: ops.act_buffer(shape, dev, bf, zero)        # buffers that only GEMMs read
+        pr = Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W if bf else None)
+        f_op = pr.f16 if bf else pr.f
 
         # scheduled sampling (AttModel.py:157-167): meta["ss"] = (prob, sel_u [T,S], u [T,S]); the input word of step
         # t >= 1 then depends on step t-1's distribution, so embeddings / x->gates / logits are produced step by step.
         # The sampled words are constants of the graph (the reference detaches them): the backward is unchanged.
         ss = meta.get("ss")
         tokens = labels if ss is None else labels[:, :T].clone()
-        xt = torch.empty(T, S, E, device=dev, dtype=torch.float32)
+        xt = act(T, S, E)
         Gx = torch.empty(T * S, 4 * R, device=dev, dtype=torch.float32)
         if ss is None:
             for t in range(T):
                 ops.embed_fwd(emb, labels[:, t], labels.stride(0), None if k_xt is None else k_xt[t], scale, xt[t])
-            ops.gemm(xt.view(T * S, E), w1i[:, 2 * R:], Gx, tb=True)
+            ops.gemm(xt.view(T * S, E), W[9][:, 2 * R:], Gx, tb=True)
         Gf = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
-        ops.gemm(pr.f, w1i[:, R:2 * R], Gf, tb=True)
-        Wc1 = _cat_weights(w1i[:, :R], w1h)           # [4R, 2R]  x [h2_prev | h1_prev]
-        Wc2 = _cat_weights(w2i, w2h)                  # [4R, 3R]  x [ctx | h1 | h2_prev]
+        ops.gemm(f_op, W[9][:, R:2 * R], Gf, tb=True)
+        Wc1 = _cat_weights(W[9][:, :R], W[10])        # [4R, 2R]  x [h2_prev | h1_prev]
+        Wc2 = _cat_weights(W[13], W[14])              # [4R, 3R]  x [ctx | h1 | h2_prev]
 
-        H1 = ops.zeros(T + 1, S, 2 * R, device=dev)
-        H2 = ops.zeros(T + 1, S, 3 * R, device=dev)
+        H1 = act(T + 1, S, 2 * R, zero=True)
+        H2 = act(T + 1, S, 3 * R, zero=True)
         C1 = ops.zeros(T + 1, S, R, device=dev)
         C2 = ops.zeros(T + 1, S, R, device=dev)
-        Hout = torch.empty(S, T, R, device=dev, dtype=torch.float32)
+        Hout = act(S, T, R)
         G1 = torch.empty(T, S, 4 * R, device=dev, dtype=torch.float32)
         G2 = torch.empty(T, S, 4 * R, device=dev, dtype=torch.float32)
         AH = torch.empty(T, S, A, device=dev, dtype=torch.float32)
@@ -312,20 +404,20 @@ class DecoderFn(Function):
         for t in range(T):
             if ss is not None:
                 if t >= 1:
-                    ops.gemm(Hout[:, t - 1, :], lg_w, logits3[:, t - 1, :], tb=True, bias=lg_b)     # raw logits of the previous step
+                    ops.gemm(Hout[:, t - 1, :], W[21], logits3[:, t - 1, :], tb=True, bias=lg_b)    # raw logits of the previous step
                     ops.multinomial_rows_(logits3[:, t - 1, :], ss[2][t], ss[1][t], ss[0], tokens[:, t])
                 ops.embed_fwd(emb, tokens[:, t], tokens.stride(0), None if k_xt is None else k_xt[t], scale, xt[t])
-                ops.gemm(xt[t], w1i[:, 2 * R:], Gx3[t], tb=True)
+                ops.gemm(xt[t], W[9][:, 2 * R:], Gx3[t], tb=True)
             ops.lstm_fwd_gemm(H1[t], Wc1, pre, Gx3[t], Gf, b1i, b1h, C1[t], C1[t + 1], H2[t][:, R:2 * R], H1[t + 1][:, R:], None, 1.0, None,
                               G1[t], S, R)
-            ops.gemm(H2[t][:, R:2 * R], h2a_w, AH[t], tb=True, bias=h2a_b)
+            ops.gemm(H2[t][:, R:2 * R], W[17], AH[t], tb=True, bias=h2a_b)
             ops.attn_fwd(pr.u, pr.v, AH[t], an_w, an_b, pr.off, lens, H2[t][:, :R], AL[t], S, A, R)
             ops.lstm_fwd_gemm(H2[t], Wc2, pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
                               None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
         if ss is None:
-            ops.gemm(Hout.view(S * T, R), lg_w, logits, tb=True, bias=lg_b)
+            ops.gemm(Hout.view(S * T, R), W[21], logits, tb=True, bias=lg_b)
         else:
-            ops.gemm(Hout[:, T - 1, :], lg_w, logits3[:, T - 1, :], tb=True, bias=lg_b)
+            ops.gemm(Hout[:, T - 1, :], W[21], logits3[:, T - 1, :], tb=True, bias=lg_b)
         active = ops.step_active(labels, T)
         ops.log_softmax_rows_(logits, active)
 
@@ -339,7 +431,7 @@ class DecoderFn(Function):
         ctx.pr = pr
         ctx.crit = crit
         ctx.nll_scratch = nll_scratch
-        ctx.params = P
+        ctx.params, ctx.W, ctx.bf = P, W, bf
         ctx.set_materialize_grads(False)
         ctx.tokens_used = tokens
         ctx.save_for_backward(labels, fc_in, X_nodes, lens, logits, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
@@ -351,12 +443,14 @@ class DecoderFn(Function):
         k_xt, k_out = ctx.masks
         pr = ctx.pr
         (labels, fc_in, X_nodes, lens, logp, active, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
-        P = ctx.params
+        P, W, bf = ctx.params, ctx.W, ctx.bf
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
          h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
         dev = logp.device
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         zer = lambda *s: ops.zeros(*s, device=dev)
+        act = lambda *shape: ops.act_buffer(shape, dev, bf)                 # gradients that only GEMMs (and bias sums) read
+        opnd = (lambda t, m_dev=None: ops.as_b16(t, m_dev)) if bf else (lambda t, m_dev=None: t)    # fp32 tensor -> GEMM operand
 
         # Gradient destinations: when a parameter already owns a .grad buffer (the flat bucket of
         # AttModel.flatten_grads) the kernels accumulate straight into it and autograd gets None --
@@ -385,24 +479,29 @@ class DecoderFn(Function):
             for j in (i, also):
                 ops.copy2d(tmp, out_for(j).view(1, -1), accumulate=acc[j])
 
-        dlogits = new(S * T, V1)
-        if ctx.crit is not None and dloss is not None:
+        if ctx.crit is not None and dloss is not None and dout is None:
+            # d(logits) only feeds the logit layer's two gradient GEMMs and its bias sum: written bf16 under compute_dtype = bf16
+            dlogits = ops.empty_b16(S * T, V1, dev) if bf else new(S * T, V1)
             ops.nll_logsoftmax_bwd(logp, ctx.crit[0], ctx.crit[1], ctx.nll_scratch, dloss.contiguous(), dlogits, active, S, T, V1)
-            if dout is not None:                         # the log-probabilities were ALSO used elsewhere
+        elif dout is not None:
+            dlogits = new(S * T, V1)
+            if ctx.crit is not None and dloss is not None:   # the log-probabilities were ALSO used elsewhere
+                ops.nll_logsoftmax_bwd(logp, ctx.crit[0], ctx.crit[1], ctx.nll_scratch, dloss.contiguous(), dlogits, active, S, T, V1)
                 extra = new(S * T, V1)
                 ops.log_softmax_rows_bwd(logp, dout.contiguous().view(S * T, V1), extra, active)
                 dlogits.add_(extra)
-        elif dout is not None:
-            ops.log_softmax_rows_bwd(logp, dout.contiguous().view(S * T, V1), dlogits, active)
+            else:
+                ops.log_softmax_rows_bwd(logp, dout.contiguous().view(S * T, V1), dlogits, active)
+            dlogits = opnd(dlogits)
         else:
             return (None,) * (7 + len(P))
         Hout2 = Hout.view(S * T, R)
         wgrad(21, dlogits, Hout2)
         bgrad(22, dlogits)
-        dHout = new(S, T, R); ops.gemm(dlogits, lg_w, dHout.view(S * T, R))
+        dHout = new(S, T, R); ops.gemm(dlogits, W[21], dHout.view(S * T, R))
         del dlogits
 
-        dP1, dP2, dAH = new(T, S, 4 * R), new(T, S, 4 * R), new(T, S, A)
+        dP1, dP2, dAH = act(T, S, 4 * R), act(T, S, 4 * R), act(T, S, A)
         du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
         dWa, dBa = new(T, S, A), new(T, S)                     # per-(step, sentence) partials of alpha_net's gradient
         dH1 = [zer(S, 2 * R), new(S, 2 * R)]          # [next, cur] ping-pong
@@ -415,7 +514,7 @@ class DecoderFn(Function):
                          scale, nC2, dP2[t], cC2, S, R)
             ops.gemm(dP2[t], Wc2, cH2)                                     # -> [dctx | dh1 | dh2_prev]
             ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, dv, dWa[t], dBa[t], S, A, R)
-            ops.gemm(dAH[t], h2a_w, cH2[:, R:2 * R], accum=True)          # h1 also feeds the attention query
+            ops.gemm(dAH[t], W[17], cH2[:, R:2 * R], accum=True)           # h1 also feeds the attention query
             ops.lstm_bwd(G1[t], C1[t], C1[t + 1], cH2[:, R:2 * R], nH1[:, R:], None, None, 1.0, nC1, dP1[t], cC1, S, R)
             ops.gemm(dP1[t], Wc1, cH1)                                     # -> [dh2_prev | dh1_prev]
             dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
@@ -426,13 +525,13 @@ class DecoderFn(Function):
         wgrad(14, P2, H2a[:, 2 * R:])
         bgrad(15, P2, also=16)
         wgrad(9, P1, H1a[:, :R], cols=(0, R))
-        dGf = ops.colsum(dP1.view(T, S * 4 * R)).view(S, 4 * R)
-        wgrad(9, dGf, pr.f, cols=(R, 2 * R))
+        dGf = opnd(ops.colsum(dP1.view(T, S * 4 * R)).view(S, 4 * R))
+        wgrad(9, dGf, pr.f16 if bf else pr.f, cols=(R, 2 * R))
         wgrad(9, P1, xt.view(T * S, E), cols=(2 * R, 2 * R + E))
         wgrad(10, P1, H1a[:, R:])
         bgrad(11, P1, also=12)
-        df = new(S, R); ops.gemm(dGf, w1i[:, R:2 * R], df)
-        dxt = new(T * S, E); ops.gemm(P1, w1i[:, 2 * R:], dxt)
+        df = new(S, R); ops.gemm(dGf, W[9][:, R:2 * R], df)
+        dxt = new(T * S, E); ops.gemm(P1, W[9][:, 2 * R:], dxt)
         d_emb = out_for(8, zero=True)
         dxt3 = dxt.view(T, S, E)
         toks = ctx.tokens_used                       # the words actually fed (ground truth, or scheduled-sampling draws)
@@ -444,33 +543,67 @@ class DecoderFn(Function):
         ops.colsum(dWa.view(T * S, A), out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa.view(T * S, 1), out=out_for(20).view(-1), accumulate=acc[20])
 
-        tot = pr.total
-        ops.gemm(du, c2a_w, dv, accum=True, m_dev=tot)                     # u = v W_c^T + b_c
-        ops.gemm(du, pr.v, out_for(6), ta=True, accum=acc[6], m_dev=tot)
-        bgrad(7, du, m_dev=tot)
-        dzv = ops.relu_bwd(dv, pr.v, scale)
-        ops.gemm(dzv, pr.Xg, out_for(4), ta=True, accum=acc[4], m_dev=tot)
-        bgrad(5, dzv, m_dev=tot)
-        dX = None
-        if ctx.needs_input_grad[3]:
-            dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
-            dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
-            ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
-
-        dz2 = ops.relu_bwd(df, pr.f, scale)
-        wgrad(2, dz2, pr.f1)
-        bgrad(3, dz2)
-        df1 = new(S, pr.f1.size(1)); ops.gemm(dz2, fc2_w, df1)
-        dz1 = ops.relu_bwd(df1, pr.f1, 1.0)
-        wgrad(0, dz1, fc_in)
-        bgrad(1, dz1)
-        dfc_in = None
-        if ctx.needs_input_grad[2]:
-            dfc_in = new(S, fc_in.size(1)); ops.gemm(dz1, fc0_w, dfc_in)
+        dX, dfc_in = prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, acc, wgrad, bgrad,
+                                       ctx.needs_input_grad[3], ctx.needs_input_grad[2])
         ctx.pr = None
         if on_decoder_grads_ready is not None:           # data-parallel reducer: the decoder bucket is complete
             on_decoder_grads_ready()
         return (None, None, dfc_in, dX, None, None, None) + tuple(ret)
+
+
+def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, acc, wgrad, bgrad, need_dX, need_dfc):
+    """Backward of `Prepared` (ctx2att, att_embed, fc_embed): du [rows, A], dv [rows, R] over the packed attention rows (fp32, the
+    attention kernel accumulated them), df [S, R].  Shared by both decoder Functions; `fc_in` in the order `pr` was built in."""
+    dev = du.device
+    new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    tot = pr.total
+    att_w, fc0_w, fc2_w = P[4], P[0], P[2]
+    if bf:
+        du16 = ops.as_b16(du)                                              # dead rows are zero: cast them all, bound the products
+        ops.gemm(du16, W[6], dv, accum=True, m_dev=tot)                    # u = v W_c^T + b_c
+        ops.gemm(du16, pr.v16, out_for(6), ta=True, accum=acc[6], m_dev=tot)
+        bgrad(7, du, m_dev=tot)
+        dzv = ops.relu_bwd(dv, pr.v, scale, bf16=True)
+        ops.gemm(dzv, pr.Xg16, out_for(4), ta=True, accum=acc[4], m_dev=tot)
+        bgrad(5, dzv, m_dev=tot)
+        dX = None
+        if need_dX:
+            dXg = new(pr.Xg16.size(0), pr.Xg16.size(1)); ops.gemm(dzv, W[4], dXg, m_dev=tot)
+            dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
+            ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
+        dz2 = ops.relu_bwd(df, pr.f, scale, bf16=True)
+        wgrad(2, dz2, pr.f116)
+        bgrad(3, dz2)
+        df1 = new(pr.S, pr.f1.size(1)); ops.gemm(dz2, W[2], df1)
+        dz1 = ops.relu_bwd(df1, pr.f1, 1.0, bf16=True)
+        wgrad(0, dz1, pr.fc16)
+        bgrad(1, dz1)
+        dfc_in = None
+        if need_dfc:
+            dfc_in = new(pr.S, fc_in.size(1)); ops.gemm(dz1, W[0], dfc_in)
+        return dX, dfc_in
+    ops.gemm(du, P[6], dv, accum=True, m_dev=tot)                          # u = v W_c^T + b_c
+    ops.gemm(du, pr.v, out_for(6), ta=True, accum=acc[6], m_dev=tot)
+    bgrad(7, du, m_dev=tot)
+    dzv = ops.relu_bwd(dv, pr.v, scale)
+    ops.gemm(dzv, pr.Xg, out_for(4), ta=True, accum=acc[4], m_dev=tot)
+    bgrad(5, dzv, m_dev=tot)
+    dX = None
+    if need_dX:
+        dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
+        dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
+        ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
+    dz2 = ops.relu_bwd(df, pr.f, scale)
+    wgrad(2, dz2, pr.f1)
+    bgrad(3, dz2)
+    df1 = new(pr.S, pr.f1.size(1)); ops.gemm(dz2, fc2_w, df1)
+    dz1 = ops.relu_bwd(df1, pr.f1, 1.0)
+    wgrad(0, dz1, fc_in)
+    bgrad(1, dz1)
+    dfc_in = None
+    if need_dfc:
+        dfc_in = new(pr.S, fc_in.size(1)); ops.gemm(dz1, fc0_w, dfc_in)
+    return dX, dfc_in
 
 
 # ------------------------------------------------------------------------------- decode (no grad)

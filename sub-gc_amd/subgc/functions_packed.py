@@ -69,7 +69,9 @@ class PackedDecoderLossFn(Function):
         img_p = img.index_select(0, perm).contiguous()
         fc_p = fc_in.index_select(0, perm).contiguous()
         X_nodes = X_nodes.contiguous()
-        pr = F_.Prepared(fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale)
+        W, bf = F_.bf16_twins(P, meta.get("W16"))               # GEMM-operand form of every parameter (bf16 twins under compute_dtype = bf16)
+        act = lambda r, c, zero=False: ops.act_buffer((r, c), dev, bf, zero)
+        pr = F_.Prepared(fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale, W if bf else None)
 
         # scheduled sampling (AttModel.py:157-167; see functions.DecoderFn): input words, x->gates and logits go step by step
         ss = meta.get("ss")
@@ -77,7 +79,7 @@ class PackedDecoderLossFn(Function):
         if ss is not None:
             tokens_p = labels_p[:, :T].clone()
             sel_p, u_p = ss[1].index_select(1, perm).contiguous(), ss[2].index_select(1, perm).contiguous()
-        xt = new(max(rows, 1), E)
+        xt = act(max(rows, 1), E)
         Gx = new(max(rows, 1), 4 * R)
         tok_flat = k_flat = None
         if ss is None and rows > 0:
@@ -85,22 +87,22 @@ class PackedDecoderLossFn(Function):
             tok_flat = torch.cat([labels_p[:M[t], t] for t in range(T_live)]).contiguous()
             k_flat = None if k_xt is None else torch.cat([k_xt[t][:M[t]] for t in range(T_live)]).contiguous()
             ops.embed_fwd(emb, tok_flat, 1, k_flat, scale, xt[:rows])
-            ops.gemm(xt[:rows], w1i[:, 2 * R:], Gx[:rows], tb=True)
+            ops.gemm(xt[:rows], W[9][:, 2 * R:], Gx[:rows], tb=True)
         Gf = new(S, 4 * R)
-        ops.gemm(pr.f, w1i[:, R:2 * R], Gf, tb=True)
-        Wc1 = F_._cat_weights(w1i[:, :R], w1h)
-        Wc2 = F_._cat_weights(w2i, w2h)
+        ops.gemm(pr.f16 if bf else pr.f, W[9][:, R:2 * R], Gf, tb=True)
+        Wc1 = F_._cat_weights(W[9][:, :R], W[10])
+        Wc2 = F_._cat_weights(W[13], W[14])
 
-        H1 = new(rows + S, 2 * R)                              # packed [h2_{t-1} | h1_{t-1}], + S rows of slack after the last step
-        H2 = new(rows + S, 3 * R)                              # packed [ctx_t | h1_t | h2_{t-1}]
+        H1 = act(rows + S, 2 * R)                              # packed [h2_{t-1} | h1_{t-1}], + S rows of slack after the last step
+        H2 = act(rows + S, 3 * R)                              # packed [ctx_t | h1_t | h2_{t-1}]
         C1, C2 = new(T + 1, S, R), new(T + 1, S, R)
         # only the state entering step 0 is zero; every other row is written by the step before it is read (checked by the
         # SUBGC_POISON_EMPTY run of the GPU suite), so ~250 MB of fills per forward shrink to ~20 MB
         m0 = M[0] if T_live > 0 else 0
         for buf in (H1[:m0], H2[:m0], C1[0], C2[0]):
             if buf.numel():
-                ops.fill_(buf, 0.0)
-        Hout, G1, G2 = new(max(rows, 1), R), new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R)
+                ops.fill_(buf.view(torch.float32) if ops.is_b16(buf) else buf, 0.0)      # bf16 zero = all-zero bits (even element counts)
+        Hout, G1, G2 = act(max(rows, 1), R), new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R)
         AH, AL = new(max(rows, 1), A), new(max(rows, 1), N)
         pre = new(S, 4 * R)
         logits = new(max(rows, 1), V1)
@@ -111,22 +113,22 @@ class PackedDecoderLossFn(Function):
             if ss is not None:
                 if t >= 1:                                      # raw logits of every row live at step t-1; draws for the rows still live now
                     op, mp = ot[t - 1], M[t - 1]
-                    ops.gemm(Hout[op:op + mp], lg_w, logits[op:op + mp], tb=True, bias=lg_b)
+                    ops.gemm(Hout[op:op + mp], W[21], logits[op:op + mp], tb=True, bias=lg_b)
                     ops.multinomial_rows_(logits[op:op + m], u_p[t][:m], sel_p[t][:m], ss[0], tokens_p[:m, t])
                 ops.embed_fwd(emb, tokens_p[:, t], tokens_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[o:o + m])
-                ops.gemm(xt[o:o + m], w1i[:, 2 * R:], Gx[o:o + m], tb=True)
+                ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True)
             ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
                               H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
-            ops.gemm(H2[o:o + m, R:2 * R], h2a_w, AH[o:o + m], tb=True, bias=h2a_b)
+            ops.gemm(H2[o:o + m, R:2 * R], W[17], AH[o:o + m], tb=True, bias=h2a_b)
             ops.attn_fwd(pr.u, pr.v, AH[o:o + m], an_w, an_b, pr.off, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R)
             ops.lstm_fwd_gemm(H2[o:o + m], Wc2, pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R],
                               H2[o1:o1 + mn_, 2 * R:], None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R,
                               rows_h=mn_, rows_h2=mn_)
         if ss is None:
-            ops.gemm(Hout[:rows], lg_w, logits[:rows], tb=True, bias=lg_b)
+            ops.gemm(Hout[:rows], W[21], logits[:rows], tb=True, bias=lg_b)
         elif T_live > 0:
             op = ot[T_live - 1]
-            ops.gemm(Hout[op:rows], lg_w, logits[op:rows], tb=True, bias=lg_b)
+            ops.gemm(Hout[op:rows], W[21], logits[op:rows], tb=True, bias=lg_b)
         ops.log_softmax_rows_(logits[:rows])
         # criterion over the packed rows: row ot[t] + s  <->  (sentence perm[s], step t)
         target_s, mask_s = target.index_select(0, perm), mask_t.index_select(0, perm)      # sorted once; the per-step prefixes are views
@@ -139,6 +141,7 @@ class PackedDecoderLossFn(Function):
         ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
         ctx.masks = (k_xt, k_out)
         ctx.flat_tokens = (tok_flat, k_flat)
+        ctx.W, ctx.bf = W, bf
         ctx.pr, ctx.params, ctx.aux = pr, P, (perm, tokens_p, lens_p, tgt_p, msk_p, nll)      # tokens_p: the words actually fed
         ctx.save_for_backward(fc_in, X_nodes, logits, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
         return loss
@@ -148,7 +151,7 @@ class PackedDecoderLossFn(Function):
         N, scale, S, T, T_live, R, E, A, V1, M, ot, rows = ctx.meta
         k_xt, k_out = ctx.masks
         tok_flat, k_flat = ctx.flat_tokens
-        pr, P = ctx.pr, ctx.params
+        pr, P, W, bf = ctx.pr, ctx.params, ctx.W, ctx.bf
         perm, labels_p, lens_p, tgt_p, msk_p, nll = ctx.aux
         (fc_in, X_nodes, logp, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
@@ -156,6 +159,8 @@ class PackedDecoderLossFn(Function):
         dev = logp.device
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         zer = lambda *s: ops.zeros(*s, device=dev)
+        act = lambda r, c: ops.act_buffer((r, c), dev, bf)      # gradients that only GEMMs (and bias sums) read
+        opnd = (lambda t: ops.as_b16(t)) if bf else (lambda t: t)
         dst, acc, ret = [], [], []
         for prm in P:                                           # accumulate straight into the flat gradient bucket when it exists
             g = prm.grad if F_.DIRECT_GRADS else None
@@ -180,14 +185,14 @@ class PackedDecoderLossFn(Function):
             for j in (i, also):
                 ops.copy2d(tmp, out_for(j).view(1, -1), accumulate=acc[j])
 
-        dlogits = new(max(rows, 1), V1)
+        dlogits = ops.empty_b16(max(rows, 1), V1, dev) if bf else new(max(rows, 1), V1)      # bf16: half the bytes of the largest tensor
         ops.nll_logsoftmax_bwd(logp[:rows], tgt_p, msk_p, nll, dloss.contiguous(), dlogits[:rows], None, rows, 1, V1)
         wgrad(21, dlogits[:rows], Hout[:rows])
         bgrad(22, dlogits[:rows])
-        dHout = new(max(rows, 1), R); ops.gemm(dlogits[:rows], lg_w, dHout[:rows])
+        dHout = new(max(rows, 1), R); ops.gemm(dlogits[:rows], W[21], dHout[:rows])
         del dlogits
 
-        dP1, dP2, dAH = new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R), new(max(rows, 1), A)
+        dP1, dP2, dAH = act(max(rows, 1), 4 * R), act(max(rows, 1), 4 * R), act(max(rows, 1), A)
         du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
         dWa, dBa = new(max(rows, 1), A), new(max(rows, 1))     # per-(step, sentence) partials of alpha_net's gradient
         # rows that are dead at step t+1 but live at step t enter the recurrence with zero state-gradient:
@@ -206,7 +211,7 @@ class PackedDecoderLossFn(Function):
             ops.gemm(dP2[o:o + m], Wc2, cH2[:m])
             ops.attn_bwd(pr.u, pr.v, AH[o:o + m], an_w, pr.off, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, dv, dWa[o:o + m],
                          dBa[o:o + m], m, A, R)
-            ops.gemm(dAH[o:o + m], h2a_w, cH2[:m, R:2 * R], accum=True)
+            ops.gemm(dAH[o:o + m], W[17], cH2[:m, R:2 * R], accum=True)
             ops.lstm_bwd(G1[o:o + m], C1[t][:m], C1[t + 1][:m], cH2[:m, R:2 * R], nH1[:m, R:], None, None, 1.0, nC1[:m], dP1[o:o + m],
                          cC1[:m], m, R)
             ops.gemm(dP1[o:o + m], Wc1, cH1[:m])
@@ -219,12 +224,13 @@ class PackedDecoderLossFn(Function):
         wgrad(9, P1, H1a[:, :R], cols=(0, R))
         dGf = new(S, 4 * R)                                     # d(fc->gates) = sum over each sentence's live steps of dP1: one launch
         ops.packed_time_sum(dP1, torch.tensor(ot[:T_live + 1], device=dev, dtype=torch.int32), T_live, S, dGf)
-        wgrad(9, dGf, pr.f, cols=(R, 2 * R))
+        dGf = opnd(dGf)
+        wgrad(9, dGf, pr.f16 if bf else pr.f, cols=(R, 2 * R))
         wgrad(9, P1, xt[:rows], cols=(2 * R, 2 * R + E))
         wgrad(10, P1, H1a[:, R:])
         bgrad(11, P1, also=12)
-        df = new(S, R); ops.gemm(dGf, w1i[:, R:2 * R], df)
-        dxt = new(max(rows, 1), E); ops.gemm(P1, w1i[:, 2 * R:], dxt[:rows])
+        df = new(S, R); ops.gemm(dGf, W[9][:, R:2 * R], df)
+        dxt = new(max(rows, 1), E); ops.gemm(P1, W[9][:, 2 * R:], dxt[:rows])
         d_emb = out_for(8, zero=True)
         for t in range(T_live):
             if tok_flat is not None:
@@ -237,30 +243,10 @@ class PackedDecoderLossFn(Function):
         ops.colsum(dWa[:rows], out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa[:rows].view(-1, 1), out=out_for(20).view(-1), accumulate=acc[20])
 
-        tot = pr.total
-        ops.gemm(du, c2a_w, dv, accum=True, m_dev=tot)
-        ops.gemm(du, pr.v, out_for(6), ta=True, accum=acc[6], m_dev=tot)
-        bgrad(7, du, m_dev=tot)
-        dzv = ops.relu_bwd(dv, pr.v, scale)
-        ops.gemm(dzv, pr.Xg, out_for(4), ta=True, accum=acc[4], m_dev=tot)
-        bgrad(5, dzv, m_dev=tot)
-        dX = None
-        if ctx.needs_input_grad[3]:
-            dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
-            dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
-            ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
-        dz2 = ops.relu_bwd(df, pr.f, scale)
-        wgrad(2, dz2, pr.f1)
-        bgrad(3, dz2)
-        df1 = new(S, pr.f1.size(1)); ops.gemm(dz2, fc2_w, df1)
-        dz1 = ops.relu_bwd(df1, pr.f1, 1.0)
         fc_p = fc_in.index_select(0, perm)
-        wgrad(0, dz1, fc_p)
-        bgrad(1, dz1)
-        dfc_in = None
-        if ctx.needs_input_grad[2]:
-            dfc_p = new(S, fc_in.size(1)); ops.gemm(dz1, fc0_w, dfc_p)
-            dfc_in = torch.empty_like(dfc_p).index_copy_(0, perm, dfc_p)
+        dX, dfc_p = F_.prepared_backward(pr, P, W, bf, fc_p, X_nodes, du, dv, df, scale, out_for, acc, wgrad, bgrad,
+                                         ctx.needs_input_grad[3], ctx.needs_input_grad[2])
+        dfc_in = None if dfc_p is None else torch.empty_like(dfc_p).index_copy_(0, perm, dfc_p)
         ctx.pr = None
         if F_.on_decoder_grads_ready is not None:
             F_.on_decoder_grads_ready()

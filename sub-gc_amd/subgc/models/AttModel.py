@@ -107,6 +107,12 @@ class AttModel(CaptionModel):
         if self.gpn and self.att_feat_size != 2 * self.GCN_dim:
             raise ValueError("att_feat_size must equal 2*gcn_dim: fc_embed consumes the [max|mean] read-out "
                              "(reference AttModel.py:109 with gpn.py:35-36,79)")
+        # compute_dtype "bf16" (BASELINE configs 3 / 5): every dense contraction runs on bf16-STORED operands (weights: a bf16
+        # snapshot of the fp32 masters; activations that only feed GEMMs: written bf16 by their producers), fp32 accumulation,
+        # fp32 master weights / gradients / optimizer state.  Not a reference option (the reference is fp32 only).
+        self.bf16_storage = str(g("compute_dtype", "fp32")).lower() in ("bf16", "bfloat16")
+        if self.bf16_storage and (self.rnn_size % 8 or self.input_encoding_size % 8 or self.att_hid_size % 8 or self.GCN_dim % 8):
+            raise ValueError("compute_dtype=bf16 needs rnn_size, input_encoding_size, att_hid_size and gcn_dim to be multiples of 8")
         self.dropout_seed = g("seed", 2019)
         self._dropout_calls = 0
         self.injected_masks = None       # tests inject {'fc','att','xt','out','gpn_hid'} keep-masks here
@@ -166,11 +172,12 @@ class AttModel(CaptionModel):
 
     def _build_parameters(self):
         specs = self._specs()
-        # 16-byte (4-float) aligned slots so every parameter can feed the vector GEMM path
+        # 32-byte (8-float) aligned slots: every parameter can feed the vector GEMM path, and its twin at the same element
+        # offset of the bf16 snapshot (`flat_params_b16`) starts on a 16-byte boundary
         offs, total = [], 0
         for _, shape, _ in specs:
             offs.append(total)
-            total += (int(np.prod(shape)) + 3) // 4 * 4
+            total += (int(np.prod(shape)) + 7) // 8 * 8
         self.flat_params = torch.zeros(total, dtype=torch.float32)
         self.flat_grads = None
         self._slots = {}
@@ -229,6 +236,35 @@ class AttModel(CaptionModel):
     def P(self, name):
         return self._pmap[name]
 
+    # ------------------------------------------------------------------ bf16 weight snapshot (compute_dtype = bf16)
+    def _all_versions(self):
+        fp = self.flat_params
+        return (fp.data_ptr(), fp._version, self.__dict__.get("_cache_epoch", 0)) + tuple(p._version for p in self._pmap.values())
+
+    def weights_b16(self, fresh_from_optimizer=False):
+        """The bf16 snapshot of the flat parameter buffer (same element offsets), re-cast whenever the fp32 masters may have
+        changed (same version keys as the decode caches).  `fresh_from_optimizer`: the fused Adam sweep has just written it."""
+        fp = self.flat_params
+        buf = self.__dict__.get("_flat16")
+        if buf is None or buf.device != fp.device or buf.numel() != fp.numel():
+            buf = torch.empty(fp.numel(), device=fp.device, dtype=torch.bfloat16)
+            self.__dict__["_flat16"], self.__dict__["_flat16_key"] = buf, None
+        key = self._all_versions()
+        if fresh_from_optimizer:
+            self.__dict__["_flat16_key"] = key
+        elif self.__dict__.get("_flat16_key") != key:
+            ops.cast_bf16(fp.view(1, -1), out=buf.view(1, -1))
+            self.__dict__["_flat16_key"] = key
+        return buf
+
+    def W16(self, name, flat16):
+        """bf16 twin of a 2-D parameter inside `flat16` (None when its rows are not multiples of 8 elements: those few
+        contractions -- the 300-d class-embedding projections -- stay on the fp32-operand GEMM)."""
+        o, n, shape = self._slots[name]
+        if len(shape) != 2 or shape[1] % 8:
+            return None
+        return flat16[o:o + n].view(shape)
+
     def init_hidden(self, bsz):
         w = self.P("logit.weight")
         return (w.new_zeros(self.num_layers, bsz, self.rnn_size), w.new_zeros(self.num_layers, bsz, self.rnn_size))
@@ -281,11 +317,18 @@ class AttModel(CaptionModel):
                 needP[s] |= live_edges[l]
         return needX, needP, live_nodes, live_edges
 
-    def _unit(self, l, u, src):
+    def _unit(self, l, u, src, src16=None, w16=None):
+        """`src16` / `w16` (compute_dtype = bf16): the bf16 copy of the source rows (shared by the two units that read them) and the
+        parameter-name -> bf16 twin lookup; the 512-wide hidden rows then exist in bf16 only."""
         pre = f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}."
         shp = src.shape
-        h = F_.linear(src.reshape(-1, shp[-1]), self.P(pre + "fc_lft.weight"), self.P(pre + "fc_lft.bias"))
-        y = F_.linear(h, self.P(pre + "fc_rgt.weight"), self.P(pre + "fc_rgt.bias"))
+        if w16 is not None:
+            h = F_.linear(src.reshape(-1, shp[-1]), self.P(pre + "fc_lft.weight"), self.P(pre + "fc_lft.bias"), W16=w16(pre + "fc_lft.weight"),
+                          x16=src16, out_b16=True)
+            y = F_.linear(h, self.P(pre + "fc_rgt.weight"), self.P(pre + "fc_rgt.bias"), W16=w16(pre + "fc_rgt.weight"))
+        else:
+            h = F_.linear(src.reshape(-1, shp[-1]), self.P(pre + "fc_lft.weight"), self.P(pre + "fc_lft.bias"))
+            y = F_.linear(h, self.P(pre + "fc_rgt.weight"), self.P(pre + "fc_rgt.bias"))
         if self.GCN_use_bn:
             y = F_.BatchNormFn.apply(y, self.P(pre + "bn.weight"), self.P(pre + "bn.bias"), self._bmap[pre + "bn.running_mean"],
                                      self._bmap[pre + "bn.running_var"], self.training)
@@ -300,6 +343,11 @@ class AttModel(CaptionModel):
         ops.ensure_workspace(att_feats.device)          # scratch for the split-K form of the M=5B recurrent GEMMs
         needX, needP, live_nodes, live_edges = self._gcn_liveness()
         att2 = att_feats.reshape(B * N, D)
+        w16 = None
+        if self.bf16_storage:
+            flat16 = self.weights_b16()
+            w16 = lambda name: self.W16(name, flat16)
+        lin16 = lambda name: {} if w16 is None or w16(name) is None else {"W16": w16(name)}      # fp32-operand GEMM where no twin exists
         # the reference's `.view(-1, sg_obj_cnt)` (AttModel.py:374,381) fails loudly on a width mismatch; here the class ids index
         # the embedding tables on the device, so a wider distribution than the table would read / scatter out of bounds
         if self.noun_fuse and obj_dist.size(-1) != self.sg_obj_cnt:
@@ -309,16 +357,16 @@ class AttModel(CaptionModel):
         if self.noun_fuse:
             cls = ops.row_argmax(obj_dist.reshape(B * N, -1), skip=1).to(torch.int32)
             emb = F_.GatherRowsFn.apply(self.P("sg_obj_embed.weight"), cls)
-            e = F_.linear(emb, self.P("obj_emb_proj.weight"), self.P("obj_emb_proj.bias"))
-            x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), add=e, relu=True)
+            e = F_.linear(emb, self.P("obj_emb_proj.weight"), self.P("obj_emb_proj.bias"), **lin16("obj_emb_proj.weight"))
+            x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), add=e, relu=True, **lin16("obj_v_proj.weight"))
         else:
-            x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"))
+            x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), **lin16("obj_v_proj.weight"))
         x = x.view(B, N, L)
         p = None
         if needP[0] or self.GCN_layers == 0:
             pc = ops.row_argmax(pred_dist.reshape(B * K, -1), skip=1 if self.pred_emb_type == 1 else 0).to(torch.int32)
             pe = F_.GatherRowsFn.apply(self.P("sg_pred_embed.weight"), pc)
-            p = F_.linear(pe, self.P("pred_emb_prj.weight"), self.P("pred_emb_prj.bias")).view(B, K, L)
+            p = F_.linear(pe, self.P("pred_emb_prj.weight"), self.P("pred_emb_prj.bias"), **lin16("pred_emb_prj.weight")).view(B, K, L)
         if self.GCN_layers == 0:
             return x
         rel_ind = rel_ind.contiguous()
@@ -327,10 +375,12 @@ class AttModel(CaptionModel):
         for l in range(self.GCN_layers):
             res = (l + 1) % self.GCN_residual == 0
             new_x = new_p = None
+            p16 = ops.as_b16(p.reshape(B * K, L)) if (w16 is not None and live_nodes[l]) else None      # one bf16 copy per source and layer
+            x16 = ops.as_b16(x.reshape(B * N, L)) if (w16 is not None and live_edges[l]) else None
             if live_nodes[l]:
-                new_x = F_.GcnNodesFn.apply(self._unit(l, 0, p), self._unit(l, 1, p), skip_x if res else None, rel_ind, ptr, edges, N)
+                new_x = F_.GcnNodesFn.apply(self._unit(l, 0, p, p16, w16), self._unit(l, 1, p, p16, w16), skip_x if res else None, rel_ind, ptr, edges, N)
             if live_edges[l]:
-                new_p = F_.GcnEdgesFn.apply(self._unit(l, 2, x), self._unit(l, 3, x), skip_p if res else None, rel_ind, ptr, edges, K)
+                new_p = F_.GcnEdgesFn.apply(self._unit(l, 2, x, x16, w16), self._unit(l, 3, x, x16, w16), skip_p if res else None, rel_ind, ptr, edges, K)
             x, p = new_x, new_p
             if res:
                 skip_x, skip_p = x, p
@@ -340,9 +390,18 @@ class AttModel(CaptionModel):
     def _pool(self, X2, idx, w, denom, img, N):
         return F_.SubgraphPoolFn.apply(X2, idx, w, w.stride(0), 1, denom, img, N)
 
+    def _lin(self, x, name, **kw):
+        """nn.Linear `name` on 2-D rows; under compute_dtype = bf16 on bf16-stored operands when the weight has a twin."""
+        if self.bf16_storage:
+            w = self.W16(name + ".weight", self.weights_b16())
+            if w is not None:
+                return F_.linear(x, self.P(name + ".weight"), self.P(name + ".bias"), W16=w, **kw)
+        kw.pop("out_b16", None)
+        return F_.linear(x, self.P(name + ".weight"), self.P(name + ".bias"), **kw)
+
     def _read_out_proj(self, r, prefix):
-        h = F_.linear(r, self.P(prefix + "read_out_proj.0.weight"), self.P(prefix + "read_out_proj.0.bias"))
-        return F_.linear(h, self.P(prefix + "read_out_proj.1.weight"), self.P(prefix + "read_out_proj.1.bias"))
+        h = self._lin(r, prefix + "read_out_proj.0", out_b16=True)              # the 512-wide hidden rows only feed the next product
+        return self._lin(h, prefix + "read_out_proj.1")
 
     def _gpn_train(self, X, gpn_obj_ind, gpn_pool_mtx, att_masks, masks):
         """gpn.py:41-81: score all (pos, neg) sub-graphs, pick the best positive one per sentence."""
@@ -359,7 +418,7 @@ class AttModel(CaptionModel):
         img = img_s.repeat_interleave(hb).repeat(2)
         read_out = self._pool(X.reshape(B * N, L), idx.contiguous(), w, denom.contiguous(), img.contiguous(), N)
         if self.use_sGPN_score:
-            hid = F_.linear(read_out, self.P("gpn_layer.gpn_fc.0.weight"), self.P("gpn_layer.gpn_fc.0.bias"), relu=True)
+            hid = self._lin(read_out, "gpn_layer.gpn_fc.0", relu=True)
             p = self.gpn_drop_prob if self.training else 0.0
             keep = masks.get("gpn_hid") if p > 0 else None
             score, gpn_loss = F_.GpnScoreFn.apply(hid, self.P("gpn_layer.gpn_fc.3.weight"), self.P("gpn_layer.gpn_fc.3.bias"), keep,
@@ -450,6 +509,9 @@ class AttModel(CaptionModel):
             sel_idx = ar.expand(b5, N).contiguous()
         lens = mask_sel.sum(1).to(torch.int32)
         meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit}
+        if self.bf16_storage:
+            flat16 = self.weights_b16()
+            meta["W16"] = [self.W16(n, flat16) for n in F_.PARAM_ORDER]
         ss_on = self.training and self.ss_prob > 0.0
         if ss_on:                                                                         # scheduled sampling, AttModel.py:157-167
             if self.injected_ss is not None:

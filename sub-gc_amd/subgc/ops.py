@@ -104,6 +104,31 @@ def is_b16(t):
     return t is not None and t.dtype == BF16
 
 
+def empty_b16(rows, cols, device, zero=False):
+    """[rows, cols] bf16 view whose leading dimension is padded to a multiple of 8 elements (16-byte row segments for the GEMM)."""
+    pad = (cols + 7) // 8 * 8
+    if zero:                                                  # bf16 zero is the all-zero bit pattern: fill the fp32 view
+        buf = fill_(torch.empty(max(rows * pad // 2, 1), device=device, dtype=torch.float32), 0.0).view(BF16)[: rows * pad].view(rows, pad)
+    else:
+        buf = torch.empty(rows, pad, device=device, dtype=BF16)
+    return buf[:, :cols] if pad != cols else buf
+
+
+def act_buffer(shape, device, bf16, zero=False):
+    """A buffer that only GEMMs consume: bf16 (last dim must be a multiple of 8 so that every [.., cols] slice keeps 16-byte
+    rows) or fp32."""
+    if not bf16:
+        return zeros(*shape, device=device) if zero else torch.empty(*shape, device=device, dtype=torch.float32)
+    n = 1
+    for d in shape:
+        n *= d
+    if shape[-1] % 8:
+        raise SubgcError(f"bf16 activation buffers need a last dimension that is a multiple of 8, got {tuple(shape)}")
+    if zero:
+        return fill_(torch.empty(max(n // 2, 1), device=device, dtype=torch.float32), 0.0).view(BF16)[:n].view(*shape)
+    return torch.empty(*shape, device=device, dtype=BF16)
+
+
 def cast_bf16(x, out=None, m_dev=None):
     """bf16 copy of a 2-D fp32 view (subgc_cast_f32_bf16); the destination's columns are padded with zeros to a multiple of 8
     (a K-contiguous GEMM operand needs K % 8 == 0).  Returns the [rows, cols_pad] bf16 tensor."""
@@ -113,6 +138,14 @@ def cast_bf16(x, out=None, m_dev=None):
         out = torch.empty(rows, pad, device=x.device, dtype=BF16)
     call("subgc_cast_f32_bf16", _ptr(x, torch.float32), ld(x), _ptr(out, BF16), ld(out), rows, cols, out.size(1), _ptr(m_dev, torch.int32), _stream())
     return out
+
+
+def as_b16(x, m_dev=None):
+    """The GEMM-operand form of a 2-D activation: itself when already bf16, else a bf16 copy ([rows, cols] view, padded ld)."""
+    if is_b16(x):
+        return x
+    y = cast_bf16(x, m_dev=m_dev)
+    return y[:, : x.size(1)] if y.size(1) != x.size(1) else y
 
 
 def transpose_bf16(x, out=None):

@@ -146,8 +146,12 @@ class FlatAdam:
         self.t += 1
         ops.fill_(self.sumsq, 0.0)
         ops.sumsq(self.model.flat_grads, self.sumsq)
-        ops.clip_adam_step(self.model.flat_params, self.model.flat_grads, self.m, self.v, self.sumsq, self.clip, self.lr,
-                           self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        m = self.model
+        snap = m.weights_b16() if getattr(m, "bf16_storage", False) else None     # compute_dtype = bf16: refreshed in the same sweep
+        ops.clip_adam_step(m.flat_params, m.flat_grads, self.m, self.v, self.sumsq, self.clip, self.lr,
+                           self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale, p_bf16=snap)
         # the kernel wrote the weights through raw pointers: no torch version counter moved, so the decode-time snapshots
         # (x->gates table, K-concatenated LSTM matrices, captured hipGraphs) must be told explicitly
-        self.model.invalidate_decode_caches()
+        m.invalidate_decode_caches()
+        if snap is not None:
+            m.weights_b16(fresh_from_optimizer=True)                               # ... while the bf16 weight snapshot is already current

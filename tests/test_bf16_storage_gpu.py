@@ -1,0 +1,151 @@
+"""compute_dtype = bf16 (BASELINE configs 3 and 5): weights snapshotted to bf16, GEMM-only activations stored bf16 by their
+producers, every contraction on subgc_gemm_bf16, fp32 masters / gradients / pointwise math.  Compared with the fp32 CPU
+oracle at SURVEY 8(c)'s bf16 tolerance: loss and log-probs atol 5e-2, greedy tokens equal wherever the oracle's top-1 / top-2
+margin exceeds 2 x atol; gradients by direction (cosine) and norm, since every product carries 2^-9 relative rounding."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import subgc_oracle as O
+from subgc import ops, parallel, synthetic
+import subgc.models as models
+from test_parity_gpu import DEV, KAR, _sharpen, build, close, run_train
+from test_shapes_gpu import FLICKR, FLICKR_DATA, FULLGC
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def cosine(a, b):
+    a, b = a.detach().double().flatten().cpu(), b.detach().double().flatten().cpu()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def margin_tokens_equal(outputs, ref_outputs, min_rows):
+    got = outputs.argmax(-1).cpu()
+    top2 = ref_outputs.topk(2, -1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 0.1
+    live = ref_outputs.abs().sum(-1) > 0
+    assert int((sure & live).sum()) >= min_rows
+    assert bool((got[sure & live] == ref_outputs.argmax(-1)[sure & live]).all())
+
+
+def grads_roughly_equal(m, orc, keys, cos_min=0.995):
+    for k in keys:
+        g, r = m.P(k).grad, orc.P[k].grad
+        assert g.dtype == torch.float32
+        c = cosine(g, r)
+        assert c > cos_min, (k, c)
+        assert abs(float(g.norm()) / float(r.norm()) - 1.0) < 0.05, k
+
+
+@pytest.mark.parametrize("name", ["subgc_train", "fullgc_train"])
+@pytest.mark.parametrize("packed", [True, False])
+def test_golden_train_cases_in_bf16_storage(golden, name, packed):
+    g = golden(name)
+    m = build(g, g.group("weights"), True, compute_dtype="bf16")
+    assert m.bf16_storage
+    m.packed_decoder = packed
+    batch, ref = g.tensors("inputs"), g.group("out")
+    out, loss = run_train(m, batch)
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss", atol=5e-2, rtol=0)
+    grads, dead = g.group("grads"), set(g.meta["dead_params"])
+    worst = 1.0
+    for k, p in m.named_parameters():
+        if k in dead:
+            assert float(p.grad.abs().max()) == 0.0, k
+        elif float(np.abs(grads[k]).max()) > 1e-6:
+            c = cosine(p.grad, torch.from_numpy(grads[k]))
+            worst = min(worst, c)
+            if k in ("logit.weight", "core.lang_lstm.weight_ih", "core.att_lstm.weight_hh", "embed.0.weight"):
+                assert c > 0.995, (k, c)
+    # the golden weights are sharpened (GCN x50, LSTM x3, logit x8) to make the fp32 parity tests bite; with one 2^-9 rounding
+    # per product that also amplifies the bf16 noise of the small encoder gradients
+    assert worst > 0.95, worst
+    with torch.no_grad():
+        outputs, gpn_loss, score = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+    close(outputs, ref["outputs"], "outputs", atol=5e-2, rtol=2e-2)
+    assert float((outputs.cpu() - torch.from_numpy(ref["outputs"])).abs().max()) > 1e-5      # bf16 arithmetic really ran
+    assert m.weights_b16().dtype == BF and torch.equal(m.W16("logit.weight", m.weights_b16()), m.P("logit.weight").detach().to(BF))
+
+
+@pytest.mark.timeout(900)
+def test_flickr_stress_shape_in_bf16_storage_matches_fp32_oracle():
+    """BASELINE config 5 at its stated precision: N = 101 nodes, K = 301 relations, D = 4096, L = 2048, V + 1 = 7001 (rows that are
+    NOT multiples of 8 elements: padded leading dimensions and the K-tail mask of the GEMM), return_att decode."""
+    torch.manual_seed(5)
+    opt = argparse.Namespace(**dict(FLICKR, compute_dtype="bf16"))
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(8, vocab=7000, seed=6, **FLICKR_DATA)
+    out, loss = run_train(m, batch)
+    orc = O.Oracle(argparse.Namespace(**FLICKR), sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss", atol=5e-2, rtol=0)
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss", atol=5e-2, rtol=0)
+    grads_roughly_equal(m, orc, ("logit.weight", "core.att_lstm.weight_ih", "core.lang_lstm.weight_hh", "embed.0.weight", "obj_v_proj.weight",
+                                 "obj_emb_proj.weight", "gcn_backbone.gcn.0.gcn_collect.collect_units.3.fc_rgt.weight",
+                                 "gcn_backbone.gcn.1.gcn_collect.collect_units.0.fc_lft.weight", "gpn_layer.gpn_fc.0.weight",
+                                 "att_embed.0.weight", "ctx2att.weight", "fc_embed.0.weight", "core.attention.h2att.weight"))
+    with torch.no_grad():
+        outputs, _, score = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
+    assert tuple(outputs.shape) == (40, 17, 7001)
+    close(outputs, ref["outputs"].detach(), "outputs", atol=5e-2, rtol=2e-2)
+    close(score, ref["subgraph_score"].detach(), "score", atol=2e-2)
+    margin_tokens_equal(outputs, ref["outputs"].detach(), 100)
+    # the attention-grounding output path (return_att) of the fp32-stored decode kernels with the same weights
+    tb = synthetic.make_test_batch(9, seed=7, **FLICKR_DATA)
+    sopt = dict(sample_max=1, beam_size=1, return_att=1)
+    topt = argparse.Namespace(**dict(FLICKR, test_LSTM=1, sct=1, compute_dtype="bf16"))
+    mt = models.setup(topt); mt.load_state_dict(sd); mt = mt.to(DEV).eval()
+    ret = mt(*synthetic.sample_args({k: v.to(DEV) for k, v in tb.items()}), opt=sopt, mode="sample")
+    assert ret[0].shape[0] == 18 and ret[4].shape[0] == 18 and torch.isfinite(ret[1]).all()
+
+
+@pytest.mark.timeout(900)
+def test_full_gc_kar_batch_256_properties_in_bf16_storage():
+    """BASELINE config 3 at its stated size and precision (Full_GC_Kar, 256 images = 1280 sentences, bf16): size-independent
+    properties -- log-probs normalise, padded steps are zero, the loss is finite and equals the packed path's, dead parameters get
+    no gradient, BatchNorm statistics move, and one fused optimizer step leaves the bf16 snapshot equal to the rounded masters."""
+    torch.manual_seed(1)
+    opt = argparse.Namespace(**dict(FULLGC, drop_prob_lm=0.5, compute_dtype="bf16"))
+    m = models.setup(opt).to(DEV).train()
+    batch = synthetic.make_train_batch(256, seed=0)
+    adam = parallel.FlatAdam(m)
+    out, loss = run_train(m, batch)                                                  # packed decoder
+    assert torch.isfinite(loss) and out["gpn_loss"] is None
+    for k in ("gcn_backbone.gcn.3.gcn_collect.collect_units.2.fc_lft.weight",):      # Full-GC: only the last layer's units 2, 3 are dead
+        assert float(m.P(k).grad.abs().max()) == 0.0
+    assert float(m.P("logit.weight").grad.abs().max()) > 0 and float(m.P("gcn_backbone.gcn.0.gcn_collect.collect_units.0.fc_lft.weight").grad.abs().max()) > 0
+    assert float(m.state_dict()["gcn_backbone.gcn.0.gcn_collect.collect_units.0.bn.running_mean"].abs().max()) > 0
+    adam.step()
+    torch.cuda.synchronize()
+    snap = m.weights_b16()
+    assert torch.equal(snap, m.flat_params.to(BF))                                   # written by the Adam sweep itself, no re-cast needed
+    m.eval()
+    with torch.no_grad():
+        b = {k: v.to(DEV) for k, v in batch.items()}
+        outputs, _, _ = m(*synthetic.forward_args(b))
+    assert tuple(outputs.shape) == (1280, 17, 9488)
+    lse = torch.logsumexp(outputs, -1)
+    live = outputs.abs().sum(-1) > 0
+    assert float(lse[live].abs().max()) < 1e-3 and int(live.sum()) > 1280 * 5
+    assert (~live).sum() == 0 or float(outputs[~live].abs().max()) == 0.0
+
+
+def test_bf16_snapshot_follows_the_masters(golden):
+    g = golden("subgc_train")
+    m = build(g, g.group("weights"), True, compute_dtype="bf16")
+    s0 = m.weights_b16().clone()
+    assert m.weights_b16().data_ptr() == m.weights_b16().data_ptr()                  # cached while the masters stand
+    with torch.no_grad():
+        m.P("logit.weight").mul_(0.5)
+    assert torch.equal(m.W16("logit.weight", m.weights_b16()), m.P("logit.weight").detach().to(BF))
+    assert not torch.equal(m.weights_b16(), s0)
+    assert m.W16("obj_emb_proj.weight", m.weights_b16()) is None                     # 20-column rows: no 16-byte twin, fp32-operand GEMM
