@@ -214,14 +214,15 @@ def decode_bench(model_sd, dev, images, M):
 def pmc_traffic(a, world, launches_per_step):
     """HBM bytes per GEMM launch from the committed PMC passes of THIS command (tools/pmc_traffic.sh -> profiles/): hardware
     counters cannot be read from inside the timed run, so the figure is only reported when the profiled workload matches."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if world != 1 or a.batch != 128 or not os.path.exists(path):
         return None, "no PMC profile for this configuration"
     with open(path) as f:
         p = json.load(f)
     if p.get("gemm_launches_per_step") != launches_per_step:
-        return None, f"profiles/r01_pmc_traffic.json was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
-    return round(p["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (calibrated on this kernel, factor 1.0) + WRITE_SIZE, separate passes"
+        return None, f"profiles/r02_pmc_traffic.json was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
+    return round(p["traffic_bytes_per_launch"]), ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2.0 (gfx950 halves wide reads; calibrated in "
+                                                  "profiles/r02_pmc_calibration.txt) + WRITE_SIZE (exact), separate passes")
 
 
 def main():

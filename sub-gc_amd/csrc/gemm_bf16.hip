@@ -44,7 +44,7 @@ struct Args {
     float keep_scale;
 };
 
-constexpr int BK = 64;
+constexpr int BK = 32;                                         // K per LDS stage
 constexpr int ROWB = BK * 2;                                   // bytes per LDS row of a K-contiguous image
 
 __device__ __forceinline__ uint32_t f2bf(float x) {            // round-to-nearest-even, NaN kept quiet
@@ -52,43 +52,58 @@ __device__ __forceinline__ uint32_t f2bf(float x) {            // round-to-neare
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + (((chunk ^ (row >> 1)) & 7) << 4); }
+__host__ __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__host__ __device__ __forceinline__ bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+__host__ __device__ __forceinline__ bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + (((chunk ^ (row >> 2)) & 3) << 4); }
 
-// ---- LDS-DMA form ------------------------------------------------------------------------------------------------------
-// The register-staged loop above spends more LDS cycles on its ds_write traffic (8 x ds_write_b128 ~ 13 cycles each per wave and
-// K-tile) than on the fragment reads: it is LDS-issue bound at ~0.5 PFLOP/s.  Here the tiles travel HBM -> LDS directly
-// (global_load_lds_dwordx4, 1 KB per wave instruction, no VGPRs, no ds_write), and the LDS image follows the MEMORY layout:
-//   K-contiguous operand: [128 rows][64 k] as above (chunk ^ (row >> 1) & 7); a lane fetches the chunk whose swizzled place
-//       is its linear LDS slot (the DMA writes lane l at base + 16 l), i.e. the swizzle is applied to the SOURCE address;
-//       fragments by ds_read_b128.
-//   K-major operand: [64 k][128 rows] (256-byte k-rows; 16-byte chunk ^ ((k & 3) << 2)); fragments by TWO
-//       ds_read_b64_tr_b16: the 16 lanes of a group address a [4 k][16 rows] block (lane i: k-row i / 4, rows 4 (i % 4) .. +3)
-//       and lane i receives (k .. k+3) of row i -- the hardware transpose; the XOR puts the four k-rows of a block into
-//       four different 64-byte windows of the 256-byte bank row (conflict-free).
-// Two stages; tile f + 1 is in flight while tile f is multiplied; one barrier per K-tile.  A partial last K-tile (K % 64 != 0)
-// cannot be masked by the DMA and goes through registers (zero fill), un-pipelined.
+// ---- staging: LDS-DMA ring ------------------------------------------------------------------------------------------------
+// Tiles travel HBM / L2 -> LDS directly (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPRs, no ds_write) and the
+// LDS image follows the MEMORY layout of each operand:
+//   K-contiguous operand: [rows][32 k] = 64-byte rows of four 16-byte chunks, chunk ^ ((row >> 2) & 3): the 16 rows a
+//       ds_read_b128 lane group reads land on the 16 different 16-byte slots of the 256-byte bank row.  The DMA writes lane l
+//       at base + 16 l, so the swizzle is applied to the SOURCE address: a lane fetches the chunk whose swizzled place is
+//       its linear slot.  Fragment = one ds_read_b128.
+//   K-major operand: [32 k][rows] (k-rows of 2 x rows bytes; chunk ^ ((k & 3) << 2)); fragment = TWO ds_read_b64_tr_b16:
+//       the 16 lanes of a group address a [4 k][16 rows] block (lane i: k-row i / 4, rows 4 (i % 4) .. +3) and lane i receives
+//       k .. k+3 of row i -- the hardware transpose; the XOR puts the four k-rows of a block into four different 64-byte
+//       windows of the bank row (conflict-free, SQ_LDS_BANK_CONFLICT = 0 in both forms).
+// Pipeline.  A 2-stage loop (tile f+1 requested while tile f is multiplied) measured 0.45-0.65 PFLOP/s with the waves parked
+// 58 % of the time (rocprofv3: SQ_WAIT_ANY): 14 % of the L2 requests of a K-tile miss (every operand slice is fetched once
+// per XCD and reused by the 8 workgroups of its row / column, TCC hit rate 86 % = the ideal of that mapping) and a K-tile is
+// complete only when its slowest line has arrived, so EVERY iteration paid one Infinity-Cache / HBM round trip (~1.6 us).
+// Hence a RING of four 32-deep stages: three tiles (96 KB per CU) are in flight while one is multiplied; a wave waits with
+// a COUNTED s_waitcnt vmcnt for its own pieces of the oldest tile only, and a raw s_barrier (no vmcnt(0) drain) hands the
+// stage over.  A partial last K-tile (K % 32 != 0) cannot be masked by the DMA and goes through registers, un-pipelined.
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 #define SUBGC_LDS(p) ((__attribute__((address_space(3))) unsigned char*)(p))
 
-// Geometry of one workgroup: TBM x TBN output tile, WM x WN waves of 64x64 each.  Two instances:
-//   128x128, 2x2 waves (256 threads), 64 KB of LDS, two workgroups per CU -- shapes with few tiles (with split-K);
-//   256x256, 4x4 waves (1024 threads), 128 KB, one workgroup per CU -- the large products.  The 128x128 form is bound by what a
-//   CU can pull from L2 (~16 B/clk: 32 KB per 2.1 MFLOP K-step); the 256x256 tile needs half the bytes per flop.
-template <int TBM_, int TBN_>
+constexpr int NSTAGE = 4;
+
+// Geometry of one workgroup: TBM x TBN output tile, WM x WN waves, each owning MA x NB MFMA tiles of 32x32.  Two instances:
+//   128x128, 2x2 waves of 64x64 (256 threads), 4 x 16 KB of LDS, two workgroups per CU -- shapes with few tiles (with split-K):
+//       0.67 us per 32-deep K-tile and workgroup = 0.80 PFLOP/s in the K loop;
+//   256x256, 4x4 waves of 64x64 (1024 threads), 4 x 32 KB, one workgroup per CU -- the large products: half the operand bytes
+//       per flop, 0.85 us per K-tile = 1.26 PFLOP/s in the K loop.  (Measured alternative: 2x4 waves of 128x64 -- twice the MFMAs
+//       per barrier and per fragment read, but 8 waves per CU instead of 16 to cover ds_read / barrier latency: 2x SLOWER.)
+// For K = 1000 products with fp32 results the K loop is only half of a tile's time: the 256 KB of a 256x256 fp32 tile leave
+// at ~11 GB/s per CU = 2.8 TB/s for the chip -- the HBM write rate, not the store pattern (scalar, 16-byte-quad and row forms
+// measured within 10 %) -- which is why the GEMM-only results are kept bf16 wherever their consumer allows.
+template <int TBM_, int TBN_, int MA_, int NB_>
 struct Geo {
-    static constexpr int TBM = TBM_, TBN = TBN_, WM = TBM_ / 64, WN = TBN_ / 64, NW = WM * WN, NT = NW * 64;
+    static constexpr int TBM = TBM_, TBN = TBN_, MA = MA_, NB = NB_, WM = TBM_ / (32 * MA_), WN = TBN_ / (32 * NB_), NW = WM * WN, NT = NW * 64;
     static constexpr int A_BYTES = TBM_ * ROWB, B_BYTES = TBN_ * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr size_t LDS = 2 * (size_t)STAGE_BYTES;
+    static constexpr size_t LDS = NSTAGE * (size_t)STAGE_BYTES;
 };
 
-// K-major image of an operand tile with ROWS rows: [64 k][ROWS], 16-byte chunk c of k-row k at chunk c ^ ((k & 3) << 2)
+// K-major image of an operand tile with ROWS rows: [32 k][ROWS], 16-byte chunk c of k-row k at chunk c ^ ((k & 3) << 2)
 template <int ROWS>
 __device__ __forceinline__ int swz_km(int k, int chunk) { return k * (ROWS * 2) + ((chunk ^ ((k & 3) << 2)) << 4); }
 
 template <bool KM, int ROWS, int NW>
 struct Dma {
-    static constexpr int NI = ROWS / 8 / NW;                   // 1 KB wave instructions per wave and tile
-    static_assert(NI >= 1 && NI * NW * 8 == ROWS, "tile rows must split evenly over the waves");
+    static constexpr int NI = ROWS * ROWB / 1024 / NW;         // 1 KB wave instructions per wave and tile
+    static_assert(NI >= 1 && NI * NW * 1024 == ROWS * ROWB, "tile bytes must split evenly over the waves");
     const uint16_t* src[NI];                                   // this lane's source per instruction, at k0 = 0
     int64_t kstride;
 
@@ -96,14 +111,13 @@ struct Dma {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int v = 0; v < NI; ++v) {
-            const int q = wave * NI + v;                       // instruction q fills LDS bytes [1024 q, 1024 q + 1024) of the region
+            const int byte = (wave * NI + v) * 1024 + lane * 16;   // this lane's linear place in the operand's region
             if (!KM) {
-                const int r = q * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int r = byte / ROWB, pc = (byte % ROWB) >> 4;
+                const int c = pc ^ ((r >> 2) & 3);
                 const int row = max(min(row0 + r, nrows - 1), 0);
                 src[v] = base + (int64_t)row * ld + c * 8;
             } else {
-                const int byte = q * 1024 + lane * 16;
                 const int k = byte / (ROWS * 2), pc = (byte % (ROWS * 2)) >> 4;
                 const int c = pc ^ ((k & 3) << 2);
                 const int col = row0 + c * 8;
@@ -122,9 +136,9 @@ struct Dma {
     // partial tile through registers: k >= K reads as zero
     __device__ __forceinline__ void tail(unsigned char* region, const uint16_t* base, int64_t ld, int row0, int nrows, int k0, int K) const {
         constexpr int NT = NW * 64;
-        for (int i = threadIdx.x; i < ROWS * 8; i += NT) {
+        for (int i = threadIdx.x; i < ROWS * (ROWB / 16); i += NT) {
             if (!KM) {
-                const int r = i >> 3, c = i & 7, k = k0 + c * 8;
+                const int r = i / (ROWB / 16), c = i % (ROWB / 16), k = k0 + c * 8;
                 const int row = max(min(row0 + r, nrows - 1), 0);
                 const int nv = min(max(K - k, 0), 8);
                 uint4 q = nv > 0 ? *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + k) : make_uint4(0u, 0u, 0u, 0u);
@@ -146,8 +160,8 @@ struct Dma {
 };
 
 // Fragment addressing of one operand image, hoisted out of the K loop: `base` = this lane's LDS byte offset for the 32-row
-// MFMA tile at r0 and step 0; a later step is an XOR (K-contiguous image: chunk index bits 1-2) or a constant add (K-major
-// image: 16 k-rows further; the swizzle only depends on k & 3).
+// MFMA tile at r0 and step 0; the second 16-deep step is an XOR (K-contiguous image: chunk index bit 1) or a constant add
+// (K-major image: 16 k-rows further; the swizzle only depends on k & 3).
 template <bool KM, int ROWS>
 struct FragAddr {
     int base;
@@ -162,62 +176,116 @@ struct FragAddr {
             base = swz_km<ROWS>(k, c) + (i & 1) * 8;
         }
     }
+    // K-contiguous image: one ds_read_b128 (the compiler's own load: it schedules and counts it)
     __device__ __forceinline__ bf16x8 load(const unsigned char* region, int step) const {
-        if (!KM) return *reinterpret_cast<const bf16x8*>(region + (base ^ (step << 5)));
-        const unsigned char* p0 = region + base + step * 16 * (ROWS * 2);
-        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)SUBGC_LDS(p0));
-        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)SUBGC_LDS(p0 + 4 * (ROWS * 2)));
-        union { struct { i16x4 a, b; } h; bf16x8 v; } u;
-        u.h.a = lo; u.h.b = hi;
-        return u.v;
+        return *reinterpret_cast<const bf16x8*>(region + (base ^ (step << 5)));
+    }
+    // K-major image: two transpose reads, issued from inline asm.  (The __builtin_amdgcn_ds_read_tr16_b64 form makes hipcc's
+    // wait-count pass put `s_waitcnt vmcnt(0)` in front of the first such read of every K-tile -- it cannot tell the read from
+    // the LDS-DMA writes in flight to the OTHER ring stages -- which drains the ring.)  The caller waits with tr_wait().
+    template <int STEP>
+    __device__ __forceinline__ void load_tr(const unsigned char* region, unsigned long long& lo, unsigned long long& hi) const {
+        const uint32_t addr = (uint32_t)(uintptr_t)SUBGC_LDS(region) + (uint32_t)base;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(STEP * 16 * (ROWS * 2)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(STEP * 16 * (ROWS * 2) + 4 * (ROWS * 2)));
     }
 };
 
+// lgkmcnt(0) for transpose reads issued from asm: the values are threaded through so that no consumer is scheduled above it
+__device__ __forceinline__ void tr_wait(unsigned long long (&r)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
+__device__ __forceinline__ void tr_wait(unsigned long long (&r)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+}
+__device__ __forceinline__ bf16x8 tr_join(unsigned long long lo, unsigned long long hi) {
+    union { struct { unsigned long long a, b; } h; bf16x8 v; } u;
+    u.h.a = lo; u.h.b = hi;
+    return u.v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 2 || N == 4 || N == 8, "counts used by the ring");      // P = 4 DMA instructions per wave and tile in both geometries
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
 template <typename G, bool A_KM, bool B_KM>
 __device__ __forceinline__ void mainloop_dma(const Args& p, unsigned char* smem, int M, int K, int m0, int n0, int kt0, int kt1,
-                                             f32x16 (&acc)[2][2]) {
+                                             f32x16 (&acc)[G::MA][G::NB]) {
 #if defined(__HIP_DEVICE_COMPILE__)       // gfx950 builtins inside: hipcc's host pass gets an empty body
     if (kt1 <= kt0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64;
-    Dma<A_KM, G::TBM, G::NW> da;
-    Dma<B_KM, G::TBN, G::NW> db;
+    constexpr int MA = G::MA, NB = G::NB;
+    const int wm = (wave / G::WN) * (32 * MA), wn = (wave % G::WN) * (32 * NB);
+    using DA = Dma<A_KM, G::TBM, G::NW>;
+    using DB = Dma<B_KM, G::TBN, G::NW>;
+    constexpr int P = DA::NI + DB::NI;                         // DMA instructions per wave and tile
+    DA da;
+    DB db;
     da.init(p.A, p.lda, m0, M);
     db.init(p.B, p.ldb, n0, p.N);
     const int full_end = min(kt1, K / BK);                     // tiles kt0 .. full_end-1 lie entirely inside K
-    FragAddr<A_KM, G::TBM> xa[2];
-    FragAddr<B_KM, G::TBN> xb[2];
+    const int F = max(full_end - kt0, 0);
+    FragAddr<A_KM, G::TBM> xa[MA];
+    FragAddr<B_KM, G::TBN> xb[NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) xa[a].init(wm + a * 32, lane);
+    for (int a = 0; a < MA; ++a) xa[a].init(wm + a * 32, lane);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) xb[b].init(wn + b * 32, lane);
-    auto compute = [&](const unsigned char* st) {
+    for (int b = 0; b < NB; ++b) xb[b].init(wn + b * 32, lane);
+    auto step = [&](const unsigned char* st, auto s_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        bf16x8 fa[MA], fb[NB];
+        unsigned long long ra[2 * MA], rb[2 * NB];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) fa[a] = xa[a].load(st, s);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = xb[b].load(st + G::A_BYTES, s);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < MA; ++a) {
+            if (A_KM) xa[a].template load_tr<S>(st, ra[2 * a], ra[2 * a + 1]);
+            else fa[a] = xa[a].load(st, S);
         }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (B_KM) xb[b].template load_tr<S>(st + G::A_BYTES, rb[2 * b], rb[2 * b + 1]);
+            else fb[b] = xb[b].load(st + G::A_BYTES, S);
+        }
+        if (A_KM) {
+            tr_wait(ra);
+#pragma unroll
+            for (int a = 0; a < MA; ++a) fa[a] = tr_join(ra[2 * a], ra[2 * a + 1]);
+        }
+        if (B_KM) {
+            tr_wait(rb);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fb[b] = tr_join(rb[2 * b], rb[2 * b + 1]);
+        }
+#pragma unroll
+        for (int a = 0; a < MA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);   // C^T tile: see the epilogue
     };
-    if (kt0 < full_end) {
-        da.issue(smem, kt0 * BK);
-        db.issue(smem + G::A_BYTES, kt0 * BK);
-    }
-    for (int kt = kt0; kt < full_end; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile kt have landed ...
-        __syncthreads();                                       // ... and so have everybody's; everybody is done reading the other stage
-        if (kt + 1 < full_end) {
-            da.issue(smem + (cur ^ 1) * G::STAGE_BYTES, (kt + 1) * BK);
-            db.issue(smem + (cur ^ 1) * G::STAGE_BYTES + G::A_BYTES, (kt + 1) * BK);
-        }
-        compute(smem + cur * G::STAGE_BYTES);
+    auto compute = [&](const unsigned char* st) {
+        static_assert(BK == 32, "two 16-deep steps per stage");
+        step(st, std::integral_constant<int, 0>{});
+        step(st, std::integral_constant<int, 1>{});
+    };
+    auto issue = [&](int f) {                                  // full tile f (0-based in this unit) -> stage f % NSTAGE
+        unsigned char* st = smem + (f % NSTAGE) * G::STAGE_BYTES;
+        da.issue(st, (kt0 + f) * BK);
+        db.issue(st + G::A_BYTES, (kt0 + f) * BK);
+    };
+    for (int f = 0; f < min(F, NSTAGE - 1); ++f) issue(f);
+    for (int f = 0; f < F; ++f) {
+        // this wave's pieces of tile f have landed once at most min(F - f - 1, NSTAGE - 2) younger tiles are outstanding
+        const int younger = F - f - 1;
+        if (younger >= 2) wait_vmcnt<2 * P>();
+        else if (younger == 1) wait_vmcnt<P>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                          // everybody's pieces have; everybody is done reading stage (f - 1) % NSTAGE
+        asm volatile("" ::: "memory");                         // no LDS read of this tile may be scheduled above the barrier
+        if (f + NSTAGE - 1 < F) issue(f + NSTAGE - 1);
+        compute(smem + (f % NSTAGE) * G::STAGE_BYTES);
     }
     if (full_end < kt1) {                                      // the partial last tile of K
         __syncthreads();
@@ -243,18 +311,43 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
     tn = in_g / gsize;
 }
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+template <int MA, int NB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MA][NB]) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 }
 
-// C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+// Epilogue.  The MFMAs are issued with the operands SWAPPED (B fragment first), so an accumulator tile holds C^T: lane l owns
+// output ROW m = (l & 31) and register r the column n = (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the 32x32 tile -- four CONSECUTIVE
+// columns per register quad, i.e. one 16-byte (fp32) or 8-byte (bf16) store per quad instead of four scalar stores that a
+// column-per-lane layout needs (64 dword stores per lane and tile made the store issue as long as the whole K loop at K = 1000).
+struct Quad { float v[4]; };
+template <typename G, typename F>
+__device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, F&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave / G::WN) * (32 * G::MA), wn = (wave % G::WN) * (32 * G::NB);
+#pragma unroll
+    for (int a = 0; a < G::MA; ++a) {
+        const int m = m0 + wm + a * 32 + (lane & 31);
+        if (m >= M) continue;
+#pragma unroll
+        for (int b = 0; b < G::NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn + b * 32 + 8 * q + 4 * (lane >> 5);
+                if (n >= N) continue;
+                Quad x{{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]}};
+                f(m, n, x);
+            }
+    }
+}
+
 template <typename G, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(G::NT, G::NT == 256 ? 2 : 4) void gemm_bf16_kernel(const Args p) {
+__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = (p.m_dev && !A_KM) ? min(p.M, *p.m_dev) : p.M;
     const int K = (p.m_dev && A_KM) ? min(p.K, *p.m_dev) : p.K;
@@ -263,39 +356,60 @@ __global__ __launch_bounds__(G::NT, G::NT == 256 ? 2 : 4) void gemm_bf16_kernel(
     int tm, tn;
     tile_of(xcd_chunked_id(blockIdx.x, live), tiles_m, tiles_n, tm, tn);
     const int m0 = tm * G::TBM, n0 = tn * G::TBN;
-    f32x16 acc[2][2];
+    f32x16 acc[G::MA][G::NB];
     zero_acc(acc);
     mainloop_dma<G, A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64, col_l = lane & 31, hrow = 4 * (lane >> 5);
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
+    // vector form: every quad is whole (N % 4 == 0) and every row start 16 / 8 bytes aligned
+    const bool vec = p.N % 4 == 0 && (!p.C32 || (p.ldc32 % 4 == 0 && aligned16(p.C32))) && (!p.C16 || (p.ldc16 % 4 == 0 && aligned8(p.C16))) &&
+                     (!p.bias || aligned16(p.bias)) && (!p.add || (p.ldadd % 4 == 0 && aligned16(p.add))) && (!p.keep || aligned4(p.keep));
+    for_each_quad<G>(acc, m0, n0, M, p.N, [&](int m, int n, Quad& x) {
+        const int64_t row = m;
+        if (vec) {
+            if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); x.v[0] += t.x; x.v[1] += t.y; x.v[2] += t.z; x.v[3] += t.w; }
+            if (p.add) { const float4 t = *reinterpret_cast<const float4*>(p.add + row * p.ldadd + n); x.v[0] += t.x; x.v[1] += t.y; x.v[2] += t.z; x.v[3] += t.w; }
+            if (relu) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int col = n0 + wn + b * 32 + col_l;
-        if (col >= p.N) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-                if (m >= M) continue;
-                float v = acc[a][b][r] + bias;
-                if (p.add) v += p.add[m * p.ldadd + col];
-                if (relu) v = fmaxf(v, 0.f);
-                if (p.keep) v *= p.keep[m * (int64_t)p.N + col] ? p.keep_scale : 0.f;      // dense [M, N] mask
-                if (p.C32) {
-                    float* d = p.C32 + m * p.ldc32 + col;
-                    if (accum) v += *d;
-                    *d = v;
-                }
-                if (p.C16) p.C16[m * p.ldc16 + col] = (uint16_t)f2bf(v);
+                for (int e = 0; e < 4; ++e) x.v[e] = fmaxf(x.v[e], 0.f);
             }
-    }
+            if (p.keep) {                                       // dense [M, N] mask
+                const uint32_t k4 = *reinterpret_cast<const uint32_t*>(p.keep + row * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x.v[e] = ((k4 >> (8 * e)) & 0xffu) ? x.v[e] * p.keep_scale : 0.f;
+            }
+            if (p.C32) {
+                float4* d = reinterpret_cast<float4*>(p.C32 + row * p.ldc32 + n);
+                if (accum) { const float4 o = *d; x.v[0] += o.x; x.v[1] += o.y; x.v[2] += o.z; x.v[3] += o.w; }
+                *d = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+            }
+            if (p.C16) {
+                uint2 o;
+                o.x = f2bf(x.v[0]) | (f2bf(x.v[1]) << 16);
+                o.y = f2bf(x.v[2]) | (f2bf(x.v[3]) << 16);
+                *reinterpret_cast<uint2*>(p.C16 + row * p.ldc16 + n) = o;
+            }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = n + e;
+            if (col >= p.N) break;
+            float v = x.v[e] + (p.bias ? p.bias[col] : 0.f);
+            if (p.add) v += p.add[row * p.ldadd + col];
+            if (relu) v = fmaxf(v, 0.f);
+            if (p.keep) v *= p.keep[row * p.N + col] ? p.keep_scale : 0.f;
+            if (p.C32) {
+                float* d = p.C32 + row * p.ldc32 + col;
+                if (accum) v += *d;
+                *d = v;
+            }
+            if (p.C16) p.C16[row * p.ldc16 + col] = (uint16_t)f2bf(v);
+        }
+    });
 }
 
 template <typename G, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(G::NT, G::NT == 256 ? 2 : 4) void gemm_bf16_splitk_kernel(const Args p, float* __restrict__ ws, int splits, int kt_per_split) {
+__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_splitk_kernel(const Args p, float* __restrict__ ws, int splits, int kt_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const int u = xcd_chunked_id(blockIdx.x, gridDim.x);
@@ -307,24 +421,13 @@ __global__ __launch_bounds__(G::NT, G::NT == 256 ? 2 : 4) void gemm_bf16_splitk_
     const int kt_all = (K + BK - 1) / BK;
     if (A_KM && p.m_dev) kt_per_split = (kt_all + splits - 1) / splits;
     const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
-    f32x16 acc[2][2];
+    f32x16 acc[G::MA][G::NB];
     zero_acc(acc);
     mainloop_dma<G, A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave / G::WN) * 64, wn = (wave % G::WN) * 64, col_l = lane & 31, hrow = 4 * (lane >> 5);
-    float* out = ws + (size_t)part * p.M * p.N;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int col = n0 + wn + b * 32 + col_l;
-        if (col >= p.N) continue;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-                if (m < p.M) out[(size_t)m * p.N + col] = acc[a][b][r];
-            }
-    }
+    float* out = ws + (size_t)part * p.M * p.N;                 // raw partial plane [M][N]; N % 4 == 0 on this path
+    for_each_quad<G>(acc, m0, n0, p.M, p.N, [&](int m, int n, Quad& x) {
+        *reinterpret_cast<float4*>(out + (size_t)m * p.N + n) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    });
 }
 
 // C = epilogue(bias + sum_parts ws[part]); fp32 and / or bf16 destination
@@ -356,27 +459,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __r
     }
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+using G128 = Geo<128, 128, 2, 2>;
+using G256 = Geo<256, 256, 2, 2>;
 
-using G128 = Geo<128, 128>;
-using G256 = Geo<256, 256>;
-
-// Cost model of a launch: `tiles` workgroups x `splits` K parts over `slots` resident workgroups, each walking kt / splits
-// K-tiles (+ prologue / epilogue); a 256x256 workgroup does 4x the flops of a 128x128 one in ~2x the time (the L2 -> LDS
-// path, not the matrix pipe, sets the pace of both).
+// Cost model of a launch, in microseconds, from measured constants (tools/gemm_bf16_bench.py with SUBGC_BF16_TILE=128 / 256):
+// a workgroup spends c us per 32-deep K-tile and e us in its prologue + epilogue (e is dominated by the result bytes: halve it
+// for a bf16-only destination); `slots` workgroups run at a time; a split costs the partial planes' round trip at ~3 TB/s + a launch.
 struct Plan { int big; int splits; double cost; };
-inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes) {
+inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool out32 = true) {
     const int kt = (int)subgc::cdiv(K, BK);
     Plan best{0, 1, 1e30};
     for (int big = 0; big < 2; ++big) {
         const int64_t tiles = big ? subgc::cdiv(M, 256) * subgc::cdiv(N, 256) : subgc::cdiv(M, 128) * subgc::cdiv(N, 128);
         const int slots = big ? 256 : 512;
-        const double per_tile = big ? 2.0 : 1.0, fixed = big ? 6.0 : 3.0;      // K-tile pace, prologue + epilogue in K-tile units
+        const double c = big ? 0.85 : 0.67, e = (big ? 24.0 : 12.0) * (out32 ? 1.0 : 0.55);
         for (int s = 1; s <= 8; ++s) {
-            if (s > 1 && (!may_split || (kt + s - 1) / s < 6 || (size_t)s * M * N * sizeof(float) > ws_bytes)) break;
+            if (s > 1 && (!may_split || (kt + s - 1) / s < 12 || (size_t)s * M * N * sizeof(float) > ws_bytes)) break;
             const int per = (kt + s - 1) / s;
             const int64_t rounds = (tiles * s + slots - 1) / slots;
-            const double cost = rounds * (per * per_tile + fixed) + (s > 1 ? 1.0 + 0.4 * s : 0.0);
+            const double tail = s > 1 ? 3.0 + (double)(s + 1) * M * N * 4.0 / 3.0e6 : 0.0;       // us: planes written + read back
+            const double cost = rounds * (per * c + (s > 1 ? e * 0.7 : e)) + tail;
             if (cost < best.cost - 1e-9) best = Plan{big, s, cost};
         }
     }
@@ -420,14 +522,14 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
     const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
                        (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias));
     static const int force = [] { const char* e = getenv("SUBGC_BF16_TILE"); return e ? atoi(e) : 0; }();     // 128 / 256: tile A/B timing
-    Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes);
+    Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes, a.C32 != nullptr);
     if (partials_only) {                                        // the LSTM cell kernel adds row-major planes: 128x128 split form only
         pl = Plan{0, 1, 0.0};
         const int64_t tiles = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
         const int kt = (int)subgc::cdiv(a.K, BK);
         double best = 1e30;
-        for (int sp = 2; sp <= 8 && (kt + sp - 1) / sp >= 6 && (size_t)sp * a.M * a.N * sizeof(float) <= ws_bytes; ++sp) {
-            const double c = (double)((tiles * sp + 511) / 512) * ((kt + sp - 1) / sp + 3.0) + 0.4 * sp;
+        for (int sp = 2; sp <= 8 && (kt + sp - 1) / sp >= 12 && (size_t)sp * a.M * a.N * sizeof(float) <= ws_bytes; ++sp) {
+            const double c = (double)((tiles * sp + 511) / 512) * ((kt + sp - 1) / sp + 8.0) + 0.8 * sp;
             if (c < best) { best = c; pl.splits = sp; }
         }
         if (pl.splits <= 1 || tiles >= 448) return -100;

@@ -293,7 +293,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, 
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][a][s], fb[fc][b][s], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[fc][b][s], fa[fc][a][s], acc[a][b], 0, 0, 0);   // operands swapped: C^T tile (epilogue)
         }
     };
     int kt = kt0;
@@ -307,46 +307,76 @@ __device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, 
     __syncthreads();      // a following unit (stream-K) re-uses the LDS stages
 }
 
-// epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// ATOMIC = this unit holds only part of the K range (stream-K): fp32 atomic add, bias from the first part.
-template <int BM, int BN, int MT, int NT, bool ATOMIC>
-__device__ __forceinline__ void epilogue(const GemmArgs& p, int M, int m0, int n0, bool first_part, f32x16 (&acc)[MT][NT]) {
+// Epilogue.  Every main loop issues its MFMAs with the operands SWAPPED (B fragment first), so an accumulator tile holds C^T:
+// lane l owns output ROW (l & 31) and register r the column (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the 32x32 tile -- four
+// CONSECUTIVE columns per register quad = one 16-byte store (with the column-per-lane layout a lane issued 64 scalar stores per
+// 128x128 tile and the store issue of a K = 1000 product rivalled its K loop).  f(m, n, quad) is called per whole / partial quad.
+struct Quad { float v[4]; };
+template <int BM, int BN, int MT, int NT, typename F>
+__device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[MT][NT], int m0, int n0, int M, int N, F&& f) {
     constexpr int WM = BM / 2, WN = BN / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-    const int col_l = lane & 31, hrow = 4 * (lane >> 5);
-    const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int col = n0 + wn + b * 32 + col_l;
-        if (col >= p.N) continue;
-        const float bias = (p.bias && first_part) ? p.bias[col] : 0.f;
+    for (int a = 0; a < MT; ++a) {
+        const int m = m0 + wm + a * 32 + (lane & 31);
+        if (m >= M) continue;
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-                if (m >= M) continue;
-                int64_t row = m;
-                if (!ATOMIC && p.c_rows) {
-                    const int g = p.c_rows[m];
-                    if (g < 0) continue;
-                    row = g;
-                }
-                float v = acc[a][b][r] + bias;
-                float* dst = p.C + row * p.ldc + col;
-                if (ATOMIC) {
-                    unsafeAtomicAdd(dst, v);
-                } else {
-                    if (p.add) v += p.add[row * p.ldadd + col];
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (p.keep) v *= p.keep[row * p.ldc + col] ? p.keep_scale : 0.f;
-                    if (accum) v += *dst;
-                    *dst = v;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn + b * 32 + 8 * q + 4 * (lane >> 5);
+                if (n >= N) continue;
+                Quad x{{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]}};
+                f(m, n, x);
             }
-        }
     }
+}
+
+__device__ __forceinline__ bool dev_aligned(const void* p, unsigned mask) { return (reinterpret_cast<uintptr_t>(p) & mask) == 0; }
+
+template <int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, int M, int m0, int n0, f32x16 (&acc)[MT][NT]) {
+    const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
+    const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && dev_aligned(p.C, 15) && (!p.bias || dev_aligned(p.bias, 15)) &&
+                     (!p.add || (p.ldadd % 4 == 0 && dev_aligned(p.add, 15))) && (!p.keep || dev_aligned(p.keep, 3));
+    for_each_quad<BM, BN, MT, NT>(acc, m0, n0, M, p.N, [&](int m, int n, Quad& x) {
+        int64_t row = m;
+        if (p.c_rows) {
+            const int g = p.c_rows[m];
+            if (g < 0) return;
+            row = g;
+        }
+        if (vec) {
+            if (p.bias) { const float4 t = ld4(p.bias + n); x.v[0] += t.x; x.v[1] += t.y; x.v[2] += t.z; x.v[3] += t.w; }
+            if (p.add) { const float4 t = ld4(p.add + row * p.ldadd + n); x.v[0] += t.x; x.v[1] += t.y; x.v[2] += t.z; x.v[3] += t.w; }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x.v[e] = fmaxf(x.v[e], 0.f);
+            }
+            if (p.keep) {
+                const uint32_t k4 = *reinterpret_cast<const uint32_t*>(p.keep + row * p.ldc + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x.v[e] = ((k4 >> (8 * e)) & 0xffu) ? x.v[e] * p.keep_scale : 0.f;
+            }
+            float4* d = reinterpret_cast<float4*>(p.C + row * p.ldc + n);
+            if (accum) { const float4 o = *d; x.v[0] += o.x; x.v[1] += o.y; x.v[2] += o.z; x.v[3] += o.w; }
+            *d = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = n + e;
+            if (col >= p.N) break;
+            float v = x.v[e] + (p.bias ? p.bias[col] : 0.f);
+            float* dst = p.C + row * p.ldc + col;
+            if (p.add) v += p.add[row * p.ldadd + col];
+            if (relu) v = fmaxf(v, 0.f);
+            if (p.keep) v *= p.keep[row * p.ldc + col] ? p.keep_scale : 0.f;
+            if (accum) v += *dst;
+            *dst = v;
+        }
+    });
 }
 
 // ---- workgroup -> tile mapping for L2 locality ------------------------------------------------------
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kern
         mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
         if (threadIdx.x >= 256) return;                          // staging waves hold no accumulators
     } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
-    epilogue<BM, BN, MT, NT, false>(p, M, m0, n0, true, acc);
+    epilogue<BM, BN, MT, NT>(p, M, m0, n0, acc);
 }
 
 // split-K form for shapes whose tile count cannot fill 256 CUs (the per-step recurrent GEMMs, M = 640:
@@ -437,23 +467,16 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_spli
         mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
         if (threadIdx.x >= 256) return;
     } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
-    // raw partial tile -> ws[part][m][n]
-    constexpr int WM = BM / 2, WN = BN / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN, col_l = lane & 31, hrow = 4 * (lane >> 5);
+    // raw partial tile -> ws[part][m][n] (accumulators hold C^T quads, see epilogue)
     float* out = ws + (size_t)part * p.M * p.N;
+    const bool vec = p.N % 4 == 0;                               // ws planes are 16-byte aligned
+    for_each_quad<BM, BN, MT, NT>(acc, m0, n0, p.M, p.N, [&](int m, int n, Quad& x) {
+        float* d = out + (size_t)m * p.N + n;
+        if (vec) { *reinterpret_cast<float4*>(d) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]); return; }
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int col = n0 + wn + b * 32 + col_l;
-        if (col >= p.N) continue;
-#pragma unroll
-        for (int a = 0; a < MT; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-                if (m < p.M) out[(size_t)m * p.N + col] = acc[a][b][r];
-            }
-    }
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) d[e] = x.v[e];
+    });
 }
 
 // C = [C +] bias + sum_parts ws[part]   (float4 along N when N % 4 == 0 and C is 16-byte aligned)

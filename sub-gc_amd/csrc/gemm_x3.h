@@ -296,7 +296,7 @@ __device__ __forceinline__ void mainloop_x3_ws(const GemmArgs& p, float* smem_f,
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
                         for (int b = 0; b < NT; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][a][TI[t]], fb[f][b][TJ[t]], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[f][b][TJ[t]], fa[f][a][TI[t]], acc[a][b], 0, 0, 0);   // swapped: C^T tile
             __syncthreads();
         }
     }

@@ -204,7 +204,7 @@ __device__ __forceinline__ void mainloop_x16_ws(const GemmArgs& p, float* smem_f
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][TI[t]], fb[b][TJ[t]], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][TJ[t]], fa[a][TI[t]], acc[a][b], 0, 0, 0);   // swapped: C^T tile
             __syncthreads();
         }
     }

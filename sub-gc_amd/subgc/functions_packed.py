@@ -10,7 +10,7 @@ LossWrapper - does what cuDNN-style packed sequences do:
     are computed (M_t is non-increasing), every per-step buffer is stored packed time-major
     (offset ot[t], M_t rows), so the batched-over-time GEMMs (x_t -> gates, logits, every weight
     gradient) run over sum_t M_t rows instead of T*S;
-  * the live counts come from the label masks with ONE small device->host read per step of training;
+  * the live counts come from the label masks with ONE small device->host read (T integers) per step of training;
   * loss and gradients are identical to the unpacked path (tests/test_parity_gpu.py compares both with
     the reference's golden gradients); only the [S,T,V+1] `outputs` tensor is not produced.
 
@@ -34,11 +34,11 @@ def live_plan(labels, mask_t):
     live = ((mask_t > 0) * steps).amax(1)                                  # last live step index + 1
     any_tok = (labels[:, :T] != 0).any(0)
     any_tok[0] = True
-    t_break = int(torch.cumprod(any_tok.to(torch.int32), 0).sum().item())   # host read #1 (tiny)
-    live = live.clamp(max=t_break)
+    t_break = torch.cumprod(any_tok.to(torch.int64), 0).sum()              # stays on the device: folded into the one read below
+    live = torch.minimum(live, t_break)
     order = torch.sort(live, descending=True, stable=True)
     counts = (order.values.view(1, S) > torch.arange(T, device=mask_t.device).view(T, 1)).sum(1)
-    return order.indices, [int(c) for c in counts.tolist()], mask_t.sum()
+    return order.indices, [int(c) for c in counts.tolist()], mask_t.sum()      # the ONE host read of a step: T small integers
 
 
 class PackedDecoderLossFn(Function):

@@ -40,7 +40,9 @@ def test_gemm_bf16_matches_fp64_product_of_the_same_operands(mode, M, N, K):
     o16 = torch.empty(M, N + 4, device=DEV, dtype=BF)[:, :N]
     ops.gemm(a, b, o16, ta=mode == "tn", tb=mode == "nt")
     assert float((o16.double() - ref).abs().max()) < 2.0 ** -8 * scale
-    assert torch.equal(o16, out.to(BF))                                  # the bf16 destination is the rounded fp32 result
+    # the bf16 destination is the rounded fp32 result (the two calls may split K differently: last-bit fp32 differences can
+    # move a rounding boundary, never more than one bf16 ulp)
+    assert float(((o16.float() - out).abs() - 2.0 ** -8 * out.abs()).max()) <= 1e-6 * scale
 
 
 def test_gemm_bf16_epilogues_and_second_destination():

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shape", default="")
+    ap.add_argument("--out16", action="store_true", help="bf16 destination (what torch.mm on bf16 tensors writes) instead of fp32")
     a = ap.parse_args()
     sh = shapes(a.config)
     if a.shape:
@@ -69,8 +70,8 @@ def main():
         g = torch.Generator().manual_seed(0)
         x = torch.randn(M, K, generator=g).to(dev).to(BF)
         w = torch.randn(K, N, generator=g).to(dev).to(BF)
-        out = torch.empty(M, N, device=dev)
         out16 = torch.empty(M, N, device=dev, dtype=BF)
+        out = torch.empty(M, N, device=dev, dtype=BF) if a.out16 else torch.empty(M, N, device=dev)
         if mode == "nt":
             wt = w.t().contiguous()
             mine = lambda: ops.gemm(x, wt, out, tb=True)
