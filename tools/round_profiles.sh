@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 ROUND=${ROUND:-r02}
-python $R/bench.py > $O/${ROUND}_bench_n1.log 2>&1; tail -1 $O/${ROUND}_bench_n1.log > $O/${ROUND}_bench_n1.json
+python $R/bench.py > $O/${ROUND}_bench_n1.log 2>&1; tail -1 $O/${ROUND}_bench_n1.log > $R/profiles/${ROUND}_bench_n1.json
 for C in full_gc_kar flickr; do
   python $R/bench.py --config $C --steps 10 --warmup 3 > $O/${ROUND}_bench_$C.log 2>&1; tail -1 $O/${ROUND}_bench_$C.log > $O/${ROUND}_bench_$C.json
 done
@@ -23,9 +23,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$C
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode --packed-only > $O/pmc_$C.log 2>&1
 done
-LPS=$(python -c "import json;print(json.load(open('$O/${ROUND}_bench_n1.json'))['roofline']['launches_per_step'])")
-ALG=$(python -c "import json;print(json.load(open('$O/${ROUND}_bench_n1.json'))['roofline']['algorithmic_bytes_per_launch'])")
+LPS=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1.json'))['roofline']['launches_per_step'])")
+ALG=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1.json'))['roofline']['algorithmic_bytes_per_launch'])")
 python $R/tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) \
    --launches-per-step $LPS --alg-bytes-per-launch $ALG > $O/${ROUND}_pmc_traffic.json 2> $O/${ROUND}_pmc_traffic.err
-cut -c1-700 $O/${ROUND}_bench_n1.json; cut -c1-400 $O/${ROUND}_bench_full_gc_kar.json; cut -c1-400 $O/${ROUND}_bench_flickr.json
+cut -c1-700 $R/profiles/${ROUND}_bench_n1.json; cut -c1-400 $O/${ROUND}_bench_full_gc_kar.json; cut -c1-400 $O/${ROUND}_bench_flickr.json
 head -14 $O/${ROUND}_train_kernel_stats.txt | cut -c1-150; head -12 $O/${ROUND}_full_gc_kar_kernel_stats.txt | cut -c1-150; cat $O/${ROUND}_pmc_traffic.json | head -20
