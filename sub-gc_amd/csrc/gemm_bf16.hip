@@ -87,8 +87,8 @@ constexpr int NSTAGE = 4;
 //       per flop, 0.85 us per K-tile = 1.26 PFLOP/s in the K loop.  (Measured alternative: 2x4 waves of 128x64 -- twice the MFMAs
 //       per barrier and per fragment read, but 8 waves per CU instead of 16 to cover ds_read / barrier latency: 2x SLOWER.)
 // For K = 1000 products with fp32 results the K loop is only half of a tile's time: the 256 KB of a 256x256 fp32 tile leave
-// at ~11 GB/s per CU = 2.8 TB/s for the chip -- the HBM write rate, not the store pattern (scalar, 16-byte-quad and row forms
-// measured within 10 %) -- which is why the GEMM-only results are kept bf16 wherever their consumer allows.
+// at ~11 GB/s per CU = 2.8 TB/s for the chip -- about the HBM write rate (scalar vs 16-byte-quad stores moved it by 5 %) --
+// which is why the GEMM-only results are kept bf16 wherever their consumer allows.
 template <int TBM_, int TBN_, int MA_, int NB_>
 struct Geo {
     static constexpr int TBM = TBM_, TBN = TBN_, MA = MA_, NB = NB_, WM = TBM_ / (32 * MA_), WN = TBN_ / (32 * NB_), NW = WM * WN, NT = NW * 64;
