@@ -133,7 +133,40 @@ struct Dma {
             __builtin_amdgcn_global_load_lds(src[v] + (int64_t)k0 * kstride,
                                              (__attribute__((address_space(3))) void*)SUBGC_LDS(region + (wave * NI + v) * 1024), 16, 0, 0);
     }
-    // partial tile through registers: k >= K reads as zero
+    // Partial last K-tile THROUGH THE RING (K % 8 == 0: whole 16-byte chunks are in or out).  The DMA cannot mask, so a lane
+    // whose chunk / k-row lies at or past K fetches a valid place of the same row instead (chunk 0 / k-row 0 of the tile:
+    // k0 < K) and the out-of-range part of the LDS image is zeroed after the tile has landed (zero_past_k): the tile then costs
+    // one extra barrier instead of an exposed, un-pipelined global round trip (K = 1000 vs 992 on the logit product measured
+    // +36 us with 256x256 tiles and +119 us with 128x128 through the register path below).
+    __device__ __forceinline__ void issue_tail(unsigned char* region, int k0, int K) const {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int v = 0; v < NI; ++v) {
+            const int byte = (wave * NI + v) * 1024 + lane * 16;
+            const uint16_t* src_v = src[v] + (int64_t)k0 * kstride;
+            if (!KM) {
+                const int r = byte / ROWB, c = ((byte % ROWB) >> 4) ^ ((r >> 2) & 3);
+                if (k0 + c * 8 >= K) src_v -= c * 8;
+            } else {
+                const int k = byte / (ROWS * 2);
+                if (k0 + k >= K) src_v -= (int64_t)k * kstride;
+            }
+            __builtin_amdgcn_global_load_lds(src_v, (__attribute__((address_space(3))) void*)SUBGC_LDS(region + (wave * NI + v) * 1024), 16, 0, 0);
+        }
+    }
+    // zero what lies at k >= rem (rem = K - k0, a multiple of 8 in 8..24) of a landed tile image
+    __device__ __forceinline__ void zero_past_k(unsigned char* region, int rem) const {
+        constexpr int NT = NW * 64;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        if (!KM) {
+            const int c0 = rem >> 3, nz = ROWB / 16 - c0;
+            for (int i = threadIdx.x; i < ROWS * nz; i += NT) *reinterpret_cast<uint4*>(region + swz(i / nz, c0 + i % nz)) = z;
+        } else {
+            uint4* q = reinterpret_cast<uint4*>(region + rem * (ROWS * 2));        // k-rows are contiguous; the swizzle stays inside a k-row
+            for (int i = threadIdx.x; i < (BK - rem) * (ROWS * 2) / 16; i += NT) q[i] = z;
+        }
+    }
+    // partial tile through registers (any K): k >= K reads as zero
     __device__ __forceinline__ void tail(unsigned char* region, const uint16_t* base, int64_t ld, int row0, int nrows, int k0, int K) const {
         constexpr int NT = NW * 64;
         for (int i = threadIdx.x; i < ROWS * (ROWB / 16); i += NT) {
@@ -275,19 +308,34 @@ __device__ __forceinline__ void mainloop_dma(const Args& p, unsigned char* smem,
         da.issue(st, (kt0 + f) * BK);
         db.issue(st + G::A_BYTES, (kt0 + f) * BK);
     };
-    for (int f = 0; f < min(F, NSTAGE - 1); ++f) issue(f);
-    for (int f = 0; f < F; ++f) {
-        // this wave's pieces of tile f have landed once at most min(F - f - 1, NSTAGE - 2) younger tiles are outstanding
-        const int younger = F - f - 1;
+    // the partial last tile of K rides the ring as tile F when its boundary falls between 16-byte chunks
+    const bool has_tail = full_end < kt1, ring_tail = has_tail && K % 8 == 0;
+    const int FT = F + (ring_tail ? 1 : 0);
+    auto request = [&](int f) {
+        if (f < F) { issue(f); return; }
+        unsigned char* st = smem + (f % NSTAGE) * G::STAGE_BYTES;
+        da.issue_tail(st, full_end * BK, K);
+        db.issue_tail(st + G::A_BYTES, full_end * BK, K);
+    };
+    for (int f = 0; f < min(FT, NSTAGE - 1); ++f) request(f);
+    for (int f = 0; f < FT; ++f) {
+        // this wave's pieces of tile f have landed once at most min(FT - f - 1, NSTAGE - 2) younger tiles are outstanding
+        const int younger = FT - f - 1;
         if (younger >= 2) wait_vmcnt<2 * P>();
         else if (younger == 1) wait_vmcnt<P>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                          // everybody's pieces have; everybody is done reading stage (f - 1) % NSTAGE
         asm volatile("" ::: "memory");                         // no LDS read of this tile may be scheduled above the barrier
-        if (f + NSTAGE - 1 < F) issue(f + NSTAGE - 1);
-        compute(smem + (f % NSTAGE) * G::STAGE_BYTES);
+        if (f + NSTAGE - 1 < FT) request(f + NSTAGE - 1);
+        unsigned char* st = smem + (f % NSTAGE) * G::STAGE_BYTES;
+        if (f == F) {                                          // the ring's tail tile: blank k >= K, then everybody may read it
+            da.zero_past_k(st, K - full_end * BK);
+            db.zero_past_k(st + G::A_BYTES, K - full_end * BK);
+            __syncthreads();
+        }
+        compute(st);
     }
-    if (full_end < kt1) {                                      // the partial last tile of K
+    if (has_tail && !ring_tail) {                              // K % 8 != 0: element masks, through registers
         __syncthreads();
         da.tail(smem, p.A, p.lda, m0, M, full_end * BK, K);
         db.tail(smem + G::A_BYTES, p.B, p.ldb, n0, p.N, full_end * BK, K);

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shape", default="")
+    ap.add_argument("--pad", type=int, default=0, help="row pitch of every operand rounded up to this many elements (64 = 128-byte aligned rows)")
     ap.add_argument("--out16", action="store_true", help="bf16 destination (what torch.mm on bf16 tensors writes) instead of fp32")
     a = ap.parse_args()
     sh = shapes(a.config)
@@ -70,17 +71,26 @@ def main():
         g = torch.Generator().manual_seed(0)
         x = torch.randn(M, K, generator=g).to(dev).to(BF)
         w = torch.randn(K, N, generator=g).to(dev).to(BF)
+
+        def padded(t):                                    # same values, rows `--pad`-aligned (a view with ld > columns)
+            if not a.pad:
+                return t
+            ld = (t.size(1) + a.pad - 1) // a.pad * a.pad
+            buf = torch.zeros(t.size(0), ld, device=dev, dtype=t.dtype)
+            buf[:, :t.size(1)] = t
+            return buf[:, :t.size(1)]
+        x, w = padded(x), padded(w)
         out16 = torch.empty(M, N, device=dev, dtype=BF)
         out = torch.empty(M, N, device=dev, dtype=BF) if a.out16 else torch.empty(M, N, device=dev)
         if mode == "nt":
-            wt = w.t().contiguous()
+            wt = padded(w.t().contiguous())
             mine = lambda: ops.gemm(x, wt, out, tb=True)
             lib = lambda: torch.mm(x, wt.t(), out=out16)
         elif mode == "nn":
             mine = lambda: ops.gemm(x, w, out)
             lib = lambda: torch.mm(x, w, out=out16)
         else:
-            xt = x.t().contiguous()
+            xt = padded(x.t().contiguous())
             mine = lambda: ops.gemm(xt, w, out, ta=True)
             lib = lambda: torch.mm(xt.t(), w, out=out16)
         tm, tl = timeit(mine, a.iters), timeit(lib, a.iters)
