@@ -132,7 +132,11 @@ class GradBucketReducer:
 
 class FlatAdam:
     """Global-norm clip + Adam over the flat bucket in one fused sweep
-    (reference misc/utils.py:174-200 `clip_gradient_norm(optimizer, 10.)` + `torch.optim.Adam`)."""
+    (reference misc/utils.py:174-200 `clip_gradient_norm(optimizer, 10.)` + `torch.optim.Adam`).
+
+    One difference from `torch.optim.Adam`, visible only with `weight_decay > 0` (the reference trains with 0, opts.py): torch
+    skips a parameter whose `.grad` is None, the flat sweep has no such notion -- a parameter the step never touched (e.g. the
+    unused `ctx2att` of a Sub-GC model) has a zero gradient slot and still receives its decay term."""
 
     def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=10.0):
         self.model, self.lr, self.betas, self.eps, self.wd, self.clip = model, lr, betas, eps, weight_decay, clip_norm
