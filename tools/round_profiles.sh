@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 ROUND=${ROUND:-r02}
 python $R/bench.py > $O/${ROUND}_bench_n1.log 2>&1; tail -1 $O/${ROUND}_bench_n1.log > $R/profiles/${ROUND}_bench_n1.json
+cp $R/profiles/${ROUND}_bench_n1.json $O/${ROUND}_bench_n1.json          # profiles/ on the box is not merged back, gpurun_out/ is
 for C in full_gc_kar flickr; do
   python $R/bench.py --config $C --steps 10 --warmup 3 > $O/${ROUND}_bench_$C.log 2>&1; tail -1 $O/${ROUND}_bench_$C.log > $O/${ROUND}_bench_$C.json
 done
