@@ -290,11 +290,21 @@ int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float*
 /* backward of one step: dctx [S,R] (ld lddctx) -> dah [S,A]; du, dv ACCUMULATE (+=) over steps;
  * dw_a [S,A] and db_a [S] receive PER-SENTENCE partial gradients of w_a / b_a (plain stores; the
  * caller column-sums them once over all steps: 640 workgroups x 512 same-address atomics per step
- * cost more than the rest of the kernel).                                                    */
+ * cost more than the rest of the kernel).
+ * Deferred d(v): with dv == NULL the step leaves d(v) alone and (dctx_keep != NULL) stores a copy of its d(ctx) rows to
+ * dctx_keep [S, >= R] (ld ldkeep); after the time loop ONE call of subgc_attn_dv_accum forms d(v) from the kept rows and the
+ * attention weights of all steps -- every d(v) row is then written once instead of read and written at every step.           */
 int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off,
                    const int32_t* len, const float* alpha, int n_stride, const float* dctx, int64_t lddctx,
                    void* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R,
-                   int dah_bf16, void* stream);
+                   int dah_bf16, float* dctx_keep, int64_t ldkeep, void* stream);
+/* dv[off[s] + i, :] = sum over steps t < T with s < step_off[t+1] - step_off[t] of
+ *                     alpha[step_off[t] + s, i] * dctx[step_off[t] + s, :]              (overwrites dv)
+ * alpha [rows, n_stride] and dctx [rows, >= R] (ld lddctx) hold the live sentences of step t as rows step_off[t] ..
+ * step_off[t+1]-1 in sentence order (the packed decoder's layout; step_off[t] = t*S for the unpacked one); step_off: int32
+ * [T+1] on the device.  off / len [S]: each sentence's node rows in dv [sum len, R].                                         */
+int subgc_attn_dv_accum(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off,
+                        int T, const int32_t* off, const int32_t* len, float* dv, int S, int R, void* stream);
 
 /* in-place row log-softmax of logits[rows, V] (AttModel.py:336,340).  active (int32 [rows] or
  * NULL): rows with active == 0 are written as zeros (the reference leaves `outputs` rows of the

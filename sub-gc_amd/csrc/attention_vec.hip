@@ -9,6 +9,8 @@
 #include "common.h"
 #include "bf16_util.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int MAXLEN = 512;
@@ -93,7 +95,10 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restri
                                                            const float* __restrict__ alpha, int n_stride,
                                                            const float* __restrict__ dctx, int64_t lddctx, void* __restrict__ dah,
                                                            float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
-                                                           float* __restrict__ db_a, int A, int R, int dah_b16) {
+                                                           float* __restrict__ db_a, int A, int R, int dah_b16,
+                                                           float* __restrict__ dctx_keep, int64_t ldkeep) {
+    // dv == NULL: d(v) is deferred -- the caller keeps every step's d(ctx) rows (dctx_keep, written here by wave 0) and alpha
+    // and calls subgc_attn_dv_accum once after the time loop instead of read-modify-writing all of d(v) at every step
     __shared__ float al_s[MAXLEN];    // alpha, then de
     __shared__ float da_s[MAXLEN];    // dalpha
     __shared__ float4 part_d[128], part_w[128];
@@ -105,25 +110,32 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restri
     float4 g[CR64];
 #pragma unroll
     for (int c = 0; c < CR64; ++c) g[c] = (lane + c * 64 < R4) ? ld4(dctx + (int64_t)s * lddctx + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dctx_keep && wave == 0) {
+#pragma unroll
+        for (int c = 0; c < CR64; ++c)
+            if (lane + c * 64 < R4) st4(dctx_keep + (int64_t)s * ldkeep + (lane + c * 64) * 4, g[c]);
+    }
     __syncthreads();
     for (int i = wave; i < l; i += 4) {
         const float a_i = al_s[i];
         const float* vr = v + (int64_t)(m0 + i) * R;
-        float* dvr = dv + (int64_t)(m0 + i) * R;
-        float4 x[CR64], y[CR64];
+        float4 x[CR64];
 #pragma unroll
-        for (int c = 0; c < CR64; ++c) {
-            const bool ok = lane + c * 64 < R4;
-            x[c] = ok ? ld4(vr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            y[c] = ok ? ld4(dvr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int c = 0; c < CR64; ++c) x[c] = (lane + c * 64 < R4) ? ld4(vr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float acc = 0.f;
+        if (dv) {
+            float* dvr = dv + (int64_t)(m0 + i) * R;
+            float4 y[CR64];
 #pragma unroll
-        for (int c = 0; c < CR64; ++c) {
-            acc += g[c].x * x[c].x + g[c].y * x[c].y + g[c].z * x[c].z + g[c].w * x[c].w;
-            y[c].x += a_i * g[c].x; y[c].y += a_i * g[c].y; y[c].z += a_i * g[c].z; y[c].w += a_i * g[c].w;
-            if (lane + c * 64 < R4) st4(dvr + (lane + c * 64) * 4, y[c]);
+            for (int c = 0; c < CR64; ++c) y[c] = (lane + c * 64 < R4) ? ld4(dvr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < CR64; ++c) {
+                y[c].x += a_i * g[c].x; y[c].y += a_i * g[c].y; y[c].z += a_i * g[c].z; y[c].w += a_i * g[c].w;
+                if (lane + c * 64 < R4) st4(dvr + (lane + c * 64) * 4, y[c]);
+            }
         }
+#pragma unroll
+        for (int c = 0; c < CR64; ++c) acc += g[c].x * x[c].x + g[c].y * x[c].y + g[c].z * x[c].z + g[c].w * x[c].w;
         acc = wave_sum(acc);
         if (lane == 0) da_s[i] = acc;
     }
@@ -173,6 +185,61 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restri
     }
 }
 
+// d(v) of ALL time steps in one pass: dv[m0 + i, :] = sum over the steps t at which sentence s is live of alpha_t[s, i] *
+// dctx_t[s, :].  One workgroup per sentence; the sentence's d(ctx) rows and attention weights of up to `tg` steps are staged
+// in LDS once (17 steps x 4 KB on Sub-GC) and every node row is then written exactly once -- instead of reading and writing all
+// of d(v) at every step (Full-GC, 36 nodes per sentence: 380 of the 830 MB a step's attention backward moved).
+// Step t holds its live sentences as rows step_off[t] .. step_off[t+1]-1 of alpha / dctx (sentence s live iff s < the count):
+// the packed decoder's layout; the unpacked one is step_off[t] = t * S.
+template <int CR64>
+__global__ __launch_bounds__(256) void attn_dv_accum_kernel(const float* __restrict__ alpha, int n_stride, const float* __restrict__ dctx,
+                                                            int64_t lddctx, const int32_t* __restrict__ step_off, int T,
+                                                            const int32_t* __restrict__ off, const int32_t* __restrict__ len,
+                                                            float* __restrict__ dv, int R, int tg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dv_lds[];
+    const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l = min(len[s], MAXLEN), m0 = off[s], R4 = R >> 2;
+    float4* g_s = reinterpret_cast<float4*>(dv_lds);                      // [tg][R4]
+    float* a_s = reinterpret_cast<float*>(g_s + (size_t)tg * R4);         // [tg][n_stride]
+    bool first = true;
+    for (int t0 = 0; t0 < T; t0 += tg) {
+        __syncthreads();                                                   // the previous group has been consumed
+        int nl = 0;                                                        // live steps of this group (uniform over the workgroup)
+        for (int tt = t0; tt < min(T, t0 + tg); ++tt) {
+            const int o = step_off[tt], m = step_off[tt + 1] - o;
+            if (s >= m) continue;
+            const int64_t flat = (int64_t)o + s;
+            for (int c = t; c < R4; c += 256) g_s[(size_t)nl * R4 + c] = ld4(dctx + flat * lddctx + c * 4);
+            for (int i = t; i < l; i += 256) a_s[nl * n_stride + i] = alpha[flat * n_stride + i];
+            ++nl;
+        }
+        __syncthreads();
+        if (nl == 0 && !first) continue;
+        for (int i = wave; i < l; i += 4) {
+            float4 acc[CR64];
+#pragma unroll
+            for (int c = 0; c < CR64; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < nl; ++k) {
+                const float a = a_s[k * n_stride + i];
+#pragma unroll
+                for (int c = 0; c < CR64; ++c) {
+                    if (lane + c * 64 >= R4) continue;
+                    const float4 g = g_s[(size_t)k * R4 + lane + c * 64];
+                    acc[c].x += a * g.x; acc[c].y += a * g.y; acc[c].z += a * g.z; acc[c].w += a * g.w;
+                }
+            }
+            float* dvr = dv + (int64_t)(m0 + i) * R;
+#pragma unroll
+            for (int c = 0; c < CR64; ++c) {
+                if (lane + c * 64 >= R4) continue;
+                if (!first) { const float4 o = ld4(dvr + (lane + c * 64) * 4); acc[c].x += o.x; acc[c].y += o.y; acc[c].z += o.z; acc[c].w += o.w; }
+                st4(dvr + (lane + c * 64) * 4, acc[c]);
+            }
+        }
+        first = false;
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -198,15 +265,15 @@ int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w
 
 int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                  const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
-                 float* db_a, int S, int A, int R, int dah_b16, hipStream_t s) {
-    if (A % 4 || R % 4 || lddctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
-        !al16(dv) || !al16(dw_a))
+                 float* db_a, int S, int A, int R, int dah_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s) {
+    if (A % 4 || R % 4 || lddctx % 4 || ldkeep % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
+        !al16(dv) || !al16(dw_a) || !al16(dctx_keep))
         return -100;
     const int ca = (A / 4 + 127) / 128, cr = (R / 4 + 63) / 64;
     if (ca > 2 || cr > 8) return -100;
 #define SUBGC_ATT_BWD(CA_, CR_)                                                                                                     \
     hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, \
-                       dah, du, dv, dw_a, db_a, A, R, dah_b16)
+                       dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep)
     if (ca == 1) {
         if (cr <= 1) SUBGC_ATT_BWD(1, 1); else if (cr <= 2) SUBGC_ATT_BWD(1, 2); else if (cr <= 4) SUBGC_ATT_BWD(1, 4); else SUBGC_ATT_BWD(1, 8);
     } else {
@@ -214,6 +281,30 @@ int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w
     }
 #undef SUBGC_ATT_BWD
     return check_launch("subgc_attn_bwd(vec)");
+}
+
+// -100 when the float4 form does not apply (the caller then has to accumulate d(v) inside subgc_attn_bwd)
+int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T, const int32_t* off,
+                      const int32_t* len, float* dv, int S, int R, hipStream_t s) {
+    if (R % 4 || lddctx % 4 || !al16(dctx) || !al16(dv)) return -100;
+    const int cr = (R / 4 + 63) / 64;
+    if (cr > 8) return -100;
+    const size_t per_step = (size_t)R * 4 + (size_t)n_stride * 4;
+    const int tg = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, (size_t)(72 * 1024) / per_step));   // <= 72 KB: two workgroups per CU
+    const size_t lds = (size_t)tg * per_step;
+    if (lds > 150 * 1024) return -100;
+#define SUBGC_ATT_DV(CR_)                                                                                                                 \
+    do {                                                                                                                                  \
+        if (lds > 64 * 1024 &&                                                                                                            \
+            hipFuncSetAttribute((const void*)attn_dv_accum_kernel<CR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            set_error("attn_dv_accum: cannot raise the dynamic LDS limit to %zu", lds);                                                  \
+            return SUBGC_ELAUNCH;                                                                                                         \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((attn_dv_accum_kernel<CR_>), dim3(S), dim3(256), lds, s, alpha, n_stride, dctx, lddctx, step_off, T, off, len, dv, R, tg); \
+    } while (0)
+    if (cr <= 1) SUBGC_ATT_DV(1); else if (cr <= 2) SUBGC_ATT_DV(2); else if (cr <= 4) SUBGC_ATT_DV(4); else SUBGC_ATT_DV(8);
+#undef SUBGC_ATT_DV
+    return check_launch("subgc_attn_dv_accum");
 }
 
 }  // namespace subgc

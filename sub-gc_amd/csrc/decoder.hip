@@ -834,19 +834,34 @@ SUBGC_API int subgc_attn_fwd(const float* u, const float* v, const float* ah, co
 }
 SUBGC_API int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                              const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv,
-                             float* dw_a, float* db_a, int S, int A, int R, int dah_bf16, void* stream) {
+                             float* dw_a, float* db_a, int S, int A, int R, int dah_bf16, float* dctx_keep, int64_t ldkeep, void* stream) {
     SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride > 0 && n_stride <= MAXLEN, "attn_bwd: bad sizes");
     if (S == 0) return SUBGC_OK;
-    SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dv && dw_a, "attn_bwd: null pointer");
+    SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dw_a, "attn_bwd: null pointer");
+    SUBGC_REQUIRE(!dctx_keep || ldkeep >= R, "attn_bwd: dctx_keep rows too short");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
-    if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, dah_bf16, s);
+    if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, dah_bf16,
+                                           dctx_keep, ldkeep, s);
         rc != -100)
         return rc;
     SUBGC_REQUIRE(!dah_bf16, "attn_bwd: the bf16 d(query) destination needs the vector form");
+    SUBGC_REQUIRE(dv && !dctx_keep, "attn_bwd: deferring d(v) (dv == NULL / dctx_keep) needs the vector form (A, R %% 4 == 0, aligned rows)");
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, static_cast<float*>(dah), du, dv,
                        dw_a, db_a, S, A, R);
     return subgc::check_launch("subgc_attn_bwd");
+}
+
+SUBGC_API int subgc_attn_dv_accum(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,
+                                  const int32_t* off, const int32_t* len, float* dv, int S, int R, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && R > 0 && T >= 1 && n_stride > 0 && n_stride <= MAXLEN && lddctx >= R, "attn_dv_accum: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(alpha && dctx && step_off && off && len && dv, "attn_dv_accum: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    const int rc = subgc::attn_dv_accum_vec(alpha, n_stride, dctx, lddctx, step_off, T, off, len, dv, S, R, s);
+    SUBGC_REQUIRE(rc != -100, "attn_dv_accum: needs R %% 4 == 0, R <= 2048 and 16-byte aligned rows");
+    return rc;
 }
 
 SUBGC_API int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, const int32_t* active, void* stream) {

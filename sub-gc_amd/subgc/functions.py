@@ -502,7 +502,12 @@ class DecoderFn(Function):
         del dlogits
 
         dP1, dP2, dAH = act(T, S, 4 * R), act(T, S, 4 * R), act(T, S, A)
-        du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
+        # d(v) = sum_t alpha_t^T d(ctx_t) is formed ONCE after the loop from the kept d(ctx) rows (subgc_attn_dv_accum) instead of
+        # being read and written at every step: on Full-GC (36 nodes per sentence) that was 380 of a step's 830 MB
+        defer_dv = R % 4 == 0 and A % 4 == 0 and T > 0
+        du = zer(pr.u.size(0), A)
+        dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
+        dCtx = new(T, S, R) if defer_dv else None
         dWa, dBa = new(T, S, A), new(T, S)                     # per-(step, sentence) partials of alpha_net's gradient
         dH1 = [zer(S, 2 * R), new(S, 2 * R)]          # [next, cur] ping-pong
         dH2 = [zer(S, 3 * R), new(S, 3 * R)]
@@ -513,12 +518,17 @@ class DecoderFn(Function):
             ops.lstm_bwd(G2[t], C2[t], C2[t + 1], nH1[:, :R], nH2[:, 2 * R:], dHout[:, t, :], None if k_out is None else k_out[t],
                          scale, nC2, dP2[t], cC2, S, R)
             ops.gemm(dP2[t], Wc2, cH2)                                     # -> [dctx | dh1 | dh2_prev]
-            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, dv, dWa[t], dBa[t], S, A, R)
+            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, None if defer_dv else dv, dWa[t], dBa[t], S, A, R,
+                         dctx_keep=dCtx[t] if defer_dv else None)
             ops.gemm(dAH[t], W[17], cH2[:, R:2 * R], accum=True)           # h1 also feeds the attention query
             ops.lstm_bwd(G1[t], C1[t], C1[t + 1], cH2[:, R:2 * R], nH1[:, R:], None, None, 1.0, nC1, dP1[t], cC1, S, R)
             ops.gemm(dP1[t], Wc1, cH1)                                     # -> [dh2_prev | dh1_prev]
             dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
 
+        if defer_dv:
+            ops.attn_dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), torch.arange(T + 1, device=dev, dtype=torch.int32) * S, T, pr.off, lens,
+                              dv, S, R)
+            del dCtx
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
         H1a, H2a = H1[:T].view(T * S, 2 * R), H2[:T].view(T * S, 3 * R)
         wgrad(13, P2, H2a[:, :2 * R])

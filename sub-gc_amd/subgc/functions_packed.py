@@ -193,7 +193,11 @@ class PackedDecoderLossFn(Function):
         del dlogits
 
         dP1, dP2, dAH = act(max(rows, 1), 4 * R), act(max(rows, 1), 4 * R), act(max(rows, 1), A)
-        du, dv = zer(pr.u.size(0), A), zer(pr.v.size(0), R)
+        # d(v) is formed once after the loop from the kept d(ctx) rows (see DecoderFn.backward)
+        defer_dv = R % 4 == 0 and A % 4 == 0 and T_live > 0
+        du = zer(pr.u.size(0), A)
+        dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
+        dCtx = new(max(rows, 1), R) if defer_dv else None
         dWa, dBa = new(max(rows, 1), A), new(max(rows, 1))     # per-(step, sentence) partials of alpha_net's gradient
         # rows that are dead at step t+1 but live at step t enter the recurrence with zero state-gradient:
         # both ping-pong buffers start zeroed and a row >= M[t+1] is never written before step t reads it
@@ -209,8 +213,8 @@ class PackedDecoderLossFn(Function):
             ops.lstm_bwd(G2[o:o + m], C2[t][:m], C2[t + 1][:m], nH1[:m, :R], nH2[:m, 2 * R:], dHout[o:o + m],
                          None if k_out is None else k_out[t], scale, nC2[:m], dP2[o:o + m], cC2[:m], m, R)
             ops.gemm(dP2[o:o + m], Wc2, cH2[:m])
-            ops.attn_bwd(pr.u, pr.v, AH[o:o + m], an_w, pr.off, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, dv, dWa[o:o + m],
-                         dBa[o:o + m], m, A, R)
+            ops.attn_bwd(pr.u, pr.v, AH[o:o + m], an_w, pr.off, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, None if defer_dv else dv,
+                         dWa[o:o + m], dBa[o:o + m], m, A, R, dctx_keep=dCtx[o:o + m] if defer_dv else None)
             ops.gemm(dAH[o:o + m], W[17], cH2[:m, R:2 * R], accum=True)
             ops.lstm_bwd(G1[o:o + m], C1[t][:m], C1[t + 1][:m], cH2[:m, R:2 * R], nH1[:m, R:], None, None, 1.0, nC1[:m], dP1[o:o + m],
                          cC1[:m], m, R)
@@ -222,8 +226,12 @@ class PackedDecoderLossFn(Function):
         wgrad(14, P2, H2a[:, 2 * R:])
         bgrad(15, P2, also=16)
         wgrad(9, P1, H1a[:, :R], cols=(0, R))
+        step_off = torch.tensor(ot[:T_live + 1], device=dev, dtype=torch.int32)
+        if defer_dv:
+            ops.attn_dv_accum(AL, dCtx, step_off, T_live, pr.off, lens_p, dv, S, R)
+            del dCtx
         dGf = new(S, 4 * R)                                     # d(fc->gates) = sum over each sentence's live steps of dP1: one launch
-        ops.packed_time_sum(dP1, torch.tensor(ot[:T_live + 1], device=dev, dtype=torch.int32), T_live, S, dGf)
+        ops.packed_time_sum(dP1, step_off, T_live, S, dGf)
         dGf = opnd(dGf)
         wgrad(9, dGf, pr.f16 if bf else pr.f, cols=(R, 2 * R))
         wgrad(9, P1, xt[:rows], cols=(2 * R, 2 * R + E))

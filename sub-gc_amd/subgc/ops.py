@@ -488,10 +488,19 @@ def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R):
          _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, int(is_b16(ctx)), _stream())
 
 
-def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R):
-    _attn_account(lens, S, A, R, 3)      # read u, v; read-modify-write du, dv
+def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R, dctx_keep=None):
+    """dv None: d(v) is deferred to one `attn_dv_accum` after the time loop; `dctx_keep` [S, R] then receives this step's d(ctx) rows."""
+    _attn_account(lens, S, A, R, 3 if dv is not None else 2)      # read u, v; read-modify-write du (and dv)
     call("subgc_attn_bwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
-         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R, int(is_b16(dah)), _stream())
+         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R, int(is_b16(dah)),
+         _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
+
+
+def attn_dv_accum(alpha, dctx, step_off, T, off, lens, dv, S, R):
+    """d(v) of all time steps in one pass (subgc_attn_dv_accum): alpha [rows, n], dctx [rows, R] hold step t's live sentences as
+    rows step_off[t] .. step_off[t+1]-1; dv [sum lens, R] is overwritten."""
+    call("subgc_attn_dv_accum", _ptr(alpha, torch.float32), alpha.size(1), _ptr(dctx, torch.float32), ld(dctx), _ptr(step_off, torch.int32), int(T),
+         _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(dv, torch.float32), S, R, _stream())
 
 
 def log_softmax_rows_(x, active=None):

@@ -529,3 +529,42 @@ def test_batched_nms_equals_per_image_nms():
         c = int(n1.item()) if n else 0
         assert int(n_keep[b]) == c
         np.testing.assert_array_equal(keep[g0:g0 + c].cpu().numpy(), k1[:c].cpu().numpy())
+
+
+@pytest.mark.parametrize("S,R,T,N", [(9, 48, 5, 7), (40, 1000, 17, 37), (6, 2048, 20, 12)])
+def test_deferred_dv_equals_the_per_step_accumulation(S, R, T, N):
+    """subgc_attn_bwd with dv = NULL + ONE subgc_attn_dv_accum after the loop (packed layout: step t holds its live sentences
+    as a prefix) vs the per-step read-modify-write of d(v), and vs the plain sum  dv_j = sum_t alpha_t[s, j] * dctx_t[s]."""
+    g = torch.Generator().manual_seed(S + R)
+    A = 32
+    lens = torch.randint(1, N + 1, (S,), generator=g).to(torch.int32)
+    off = (torch.cumsum(lens, 0) - lens).to(torch.int32)
+    rows = int(lens.sum())
+    live = sorted(torch.randint(1, S + 1, (T,), generator=g).tolist(), reverse=True)       # live sentences per step: non-increasing
+    live[0] = S
+    step_off = torch.tensor([0] + list(np.cumsum(live)), dtype=torch.int32)
+    tot = int(step_off[-1])
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    u, v, ah, w_a = rnd(rows, A), rnd(rows, R), rnd(tot, A), rnd(1, A)
+    alpha = torch.rand(tot, N, generator=g).to(DEV)
+    dctx = rnd(tot, R)
+    lens_d, off_d, so_d = lens.to(DEV), off.to(DEV), step_off.to(DEV)
+    new = lambda *s: torch.empty(*s, device=DEV)
+    du1, dv1, du2 = torch.zeros(rows, A, device=DEV), torch.zeros(rows, R, device=DEV), torch.zeros(rows, A, device=DEV)
+    keep, dv2 = new(tot, R), torch.full((rows, R), 7.0, device=DEV)                          # dv2 is overwritten, never read
+    dah1, dah2, dwa1, dwa2, dba1, dba2 = new(tot, A), new(tot, A), new(tot, A), new(tot, A), new(tot), new(tot)
+    for t in range(T - 1, -1, -1):
+        o, m = int(step_off[t]), live[t]
+        sl = slice(o, o + m)
+        ops.attn_bwd(u, v, ah[sl], w_a, off_d, lens_d, alpha[sl], dctx[sl], dah1[sl], du1, dv1, dwa1[sl], dba1[sl], m, A, R)
+        ops.attn_bwd(u, v, ah[sl], w_a, off_d, lens_d, alpha[sl], dctx[sl], dah2[sl], du2, None, dwa2[sl], dba2[sl], m, A, R, dctx_keep=keep[sl])
+    ops.attn_dv_accum(alpha, keep, so_d, T, off_d, lens_d, dv2, S, R)
+    assert torch.equal(keep, dctx) and torch.equal(du1, du2) and torch.equal(dah1, dah2) and torch.equal(dwa1, dwa2) and torch.equal(dba1, dba2)
+    want = torch.zeros(rows, R, dtype=torch.float64)
+    al, dc = alpha.double().cpu(), dctx.double().cpu()
+    for t in range(T):
+        for s in range(live[t]):
+            f = int(step_off[t]) + s
+            want[int(off[s]):int(off[s]) + int(lens[s])] += al[f, :int(lens[s]), None] * dc[f][None, :]
+    torch.testing.assert_close(dv2.double().cpu(), want, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(dv1, dv2, atol=2e-5, rtol=1e-5)
