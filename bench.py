@@ -355,6 +355,10 @@ def main():
                          "whole_step_frac_nominal": round(cfg["gflop_img"] * a.batch / (ms_per_step * 1e-3) / 1e3 / cfg["peak"], 4)},
             "final_loss": round(final_loss, 4),
         }
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_gemm_f32.json")
+        if headline and os.path.exists(pmc_path):                 # committed PMC passes over single shapes of the same kernel
+            with open(pmc_path) as f:
+                res["roofline"]["pmc"] = json.load(f)
         if world == 1 and headline:
             # the HBM-bound kernel families of the same step (reported individually in GB/s against the 8 TB/s
             # roof): two extra untimed steps with every family bracketed by HIP events on its launch stream; algorithmic
