@@ -151,12 +151,16 @@ int subgc_gcn_edges_bwd(const float* dP, const float* F2, const float* F3, const
 
 /* BatchNorm1d over the rows of X[M,C] (graph_conv_unit.py:31-32; Full-GC only).
  * training != 0: batch statistics (biased variance for the normalisation, unbiased for the
- * running_var update, momentum 0.1, eps 1e-5), saves mean / rstd [C] for the backward.   */
+ * running_var update, momentum 0.1, eps 1e-5), saves mean / rstd [C] for the backward.
+ * workspace / ws_bytes (optional scratch of THIS call, 16-byte aligned; ~1024 x C floats, twice that for the backward): the
+ * column reductions then leave per-slab partial sums there and add them in a fixed order (no atomics, reproducible
+ * statistics); with a smaller or no workspace they fall back to float atomics.                                            */
 int subgc_bn_fwd(const float* X, float* Y, int M, int C, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float* save_mean, float* save_rstd,
-                 int training, float momentum, float eps, void* stream);
+                 int training, float momentum, float eps, void* workspace, size_t ws_bytes, void* stream);
 int subgc_bn_bwd(const float* dY, const float* X, const float* gamma, const float* save_mean,
-                 const float* save_rstd, float* dX, float* dgamma, float* dbeta, int M, int C, void* stream);
+                 const float* save_rstd, float* dX, float* dgamma, float* dbeta, int M, int C,
+                 void* workspace, size_t ws_bytes, void* stream);
 
 /* ======================================================================================
  * sGPN (replaces gpn.py:152-185 gather + diagonal bmm + max/mean pooling, never materialising

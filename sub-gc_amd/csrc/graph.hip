@@ -250,15 +250,30 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
 }
 // float4 form (C % 4 == 0, 16-byte aligned rows): a wave covers 256 columns of a row per load instruction (1 KB) instead of 64
 // (the scalar form moved 68 MB in 39.5 us = 1.7 TB/s on the [16640, 1024] relation features of Full-GC); grid (C/256, slabs)
+// part != NULL: the slab's column sums go to part[blockIdx.y][C] with plain stores and bn_finalize_kernel adds the slabs in a
+// fixed order -- no zero-fill launches, no atomics (256 same-address float atomics per column from 8 XCDs were most of the
+// 32 us the pass still took), and bit-reproducible statistics
 __global__ __launch_bounds__(256) void bn_colsum_vec_kernel(const float* __restrict__ X, int M, int C, const float* __restrict__ center,
-                                                            float* __restrict__ sum, int square, int rows_per_block) {
+                                                            float* __restrict__ sum, int square, int rows_per_block, float* __restrict__ part) {
     __shared__ float4 sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < C) {
         const float4 mu = center ? *reinterpret_cast<const float4*>(center + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = r0 + w; r < r1; r += 4) {
+        int r = r0 + w;
+        for (; r + 12 < r1; r += 16) {                                  // four rows in flight per wave
+            float4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const float4*>(X + (int64_t)(r + 4 * q) * C + col);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d0 = x[q].x - mu.x, d1 = x[q].y - mu.y, d2 = x[q].z - mu.z, d3 = x[q].w - mu.w;
+                if (square) { acc.x += d0 * d0; acc.y += d1 * d1; acc.z += d2 * d2; acc.w += d3 * d3; }
+                else { acc.x += d0; acc.y += d1; acc.z += d2; acc.w += d3; }
+            }
+        }
+        for (; r < r1; r += 4) {
             const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)r * C + col);
             const float d0 = x.x - mu.x, d1 = x.y - mu.y, d2 = x.z - mu.z, d3 = x.w - mu.w;
             if (square) { acc.x += d0 * d0; acc.y += d1 * d1; acc.z += d2 * d2; acc.w += d3 * d3; }
@@ -269,13 +284,16 @@ __global__ __launch_bounds__(256) void bn_colsum_vec_kernel(const float* __restr
     __syncthreads();
     if (w == 0 && col < C) {
         const float4 a = sm[0][lane], b = sm[1][lane], c = sm[2][lane], d = sm[3][lane];
-        atomicAdd(sum + col, a.x + b.x + c.x + d.x); atomicAdd(sum + col + 1, a.y + b.y + c.y + d.y);
-        atomicAdd(sum + col + 2, a.z + b.z + c.z + d.z); atomicAdd(sum + col + 3, a.w + b.w + c.w + d.w);
+        const float4 t = make_float4(a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w);
+        if (part) *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + col) = t;
+        else { atomicAdd(sum + col, t.x); atomicAdd(sum + col + 1, t.y); atomicAdd(sum + col + 2, t.z); atomicAdd(sum + col + 3, t.w); }
     }
 }
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __restrict__ dY, const float* __restrict__ X, int M, int C,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int rows_per_block) {
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int rows_per_block,
+                                                                float* __restrict__ part) {
+    // part != NULL: slab sums to part[blockIdx.y][2][C] (dgamma row, dbeta row); bn_sum_slabs_kernel adds them
     __shared__ float4 sg[4][64], sb[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -295,18 +313,64 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __r
     if (w == 0 && col < C) {
         const float4 g0 = sg[0][lane], g1 = sg[1][lane], g2 = sg[2][lane], g3 = sg[3][lane];
         const float4 b0 = sb[0][lane], b1 = sb[1][lane], b2 = sb[2][lane], b3 = sb[3][lane];
-        atomicAdd(dgamma + col, g0.x + g1.x + g2.x + g3.x); atomicAdd(dgamma + col + 1, g0.y + g1.y + g2.y + g3.y);
-        atomicAdd(dgamma + col + 2, g0.z + g1.z + g2.z + g3.z); atomicAdd(dgamma + col + 3, g0.w + g1.w + g2.w + g3.w);
-        atomicAdd(dbeta + col, b0.x + b1.x + b2.x + b3.x); atomicAdd(dbeta + col + 1, b0.y + b1.y + b2.y + b3.y);
-        atomicAdd(dbeta + col + 2, b0.z + b1.z + b2.z + b3.z); atomicAdd(dbeta + col + 3, b0.w + b1.w + b2.w + b3.w);
+        const float4 tg = make_float4(g0.x + g1.x + g2.x + g3.x, g0.y + g1.y + g2.y + g3.y, g0.z + g1.z + g2.z + g3.z, g0.w + g1.w + g2.w + g3.w);
+        const float4 tb = make_float4(b0.x + b1.x + b2.x + b3.x, b0.y + b1.y + b2.y + b3.y, b0.z + b1.z + b2.z + b3.z, b0.w + b1.w + b2.w + b3.w);
+        if (part) {
+            *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2 + 0) * C + col) = tg;
+            *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2 + 1) * C + col) = tb;
+        } else {
+            atomicAdd(dgamma + col, tg.x); atomicAdd(dgamma + col + 1, tg.y); atomicAdd(dgamma + col + 2, tg.z); atomicAdd(dgamma + col + 3, tg.w);
+            atomicAdd(dbeta + col, tb.x); atomicAdd(dbeta + col + 1, tb.y); atomicAdd(dbeta + col + 2, tb.z); atomicAdd(dbeta + col + 3, tb.w);
+        }
     }
 }
+// column c of vector j: sum over slabs of part[slab][j][c] in a fixed order.  256 threads = 64 columns x 4 waves, wave w adds
+// slabs w, w+4, ... eight loads at a time, LDS combines the four; every thread of the column's lane gets the total.
+__device__ __forceinline__ float bn_slab_sum(const float* __restrict__ part, int slabs, int nvec, int j, int C, int c, float (*sm)[64]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C) {
+        int k = w;
+        for (; k + 28 < slabs; k += 32) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = part[((int64_t)(k + 4 * q) * nvec + j) * C + c];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += x[q];
+        }
+        for (; k < slabs; k += 4) s += part[((int64_t)k * nvec + j) * C + c];
+    }
+    __syncthreads();
+    sm[w][lane] = s;
+    __syncthreads();
+    return sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+}
+// grid C/64 x 256 threads: out0 / out1 [C] = the two summed vectors of the backward (dgamma, dbeta)
+__global__ __launch_bounds__(256) void bn_sum_slabs_kernel(const float* __restrict__ part, int slabs, int C, float* __restrict__ out0,
+                                                           float* __restrict__ out1) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float a = bn_slab_sum(part, slabs, 2, 0, C, c, sm), b = bn_slab_sum(part, slabs, 2, 1, C, c, sm);
+    if (threadIdx.x < 64 && c < C) { out0[c] = a; out1[c] = b; }
+}
 // finalise: mean = s/M (pass 0)  |  var -> rstd, running stats (pass 1)
-__global__ void bn_finalize_kernel(float* __restrict__ mean_or_var, int M, int C, int pass, float* __restrict__ save_mean,
-                                   float* __restrict__ save_rstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ mean_or_var, int M, int C, int pass, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum, float eps,
+                                                          const float* __restrict__ part, int slabs) {
+    // part == NULL: grid C/256, thread per column, the sums are in mean_or_var (atomic path)
+    // part != NULL: grid C/64, 64 columns x 4 waves: the column sums arrive as per-slab partials (bn_slab_sum)
+    __shared__ float sm[4][64];
+    int c;
+    if (part) {
+        c = blockIdx.x * 64 + (threadIdx.x & 63);
+        const float tot = bn_slab_sum(part, slabs, 1, 0, C, c, sm);
+        if (threadIdx.x >= 64 || c >= C) return;
+        mean_or_var[c] = tot;
+    } else {
+        c = blockIdx.x * blockDim.x + threadIdx.x;
+        if (c >= C) return;
+    }
     if (pass == 0) {
         const float m = mean_or_var[c] / (float)M;
         save_mean[c] = m;
@@ -374,10 +438,10 @@ inline bool bn_vec_ok(int C, const void* a, const void* b, const void* c) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return C % 4 == 0 && al(a) && al(b) && al(c);
 }
-// rows per workgroup of the float4 column reductions: ~1000 workgroups (4 per CU) however tall the matrix is
+// rows per workgroup of the float4 column reductions: ~512 workgroups (2 per CU) however tall the matrix is
 inline int bn_rows_per_block(int M, int C) {
     const int col_groups = (C + 255) / 256;
-    const int slabs = std::max(1, 1024 / col_groups);
+    const int slabs = std::max(1, 512 / col_groups);
     return std::max(16, (M + slabs - 1) / slabs);
 }
 
@@ -463,7 +527,7 @@ SUBGC_API int subgc_gcn_edges_bwd(const float* dP, const float* F2, const float*
 
 SUBGC_API int subgc_bn_fwd(const float* X, float* Y, int M, int C, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float* save_mean, float* save_rstd, int training, float momentum, float eps,
-                           void* stream) {
+                           void* workspace, size_t ws_bytes, void* stream) {
     SUBGC_REQUIRE(M > 0 && C > 0, "bn_fwd: bad sizes");
     SUBGC_REQUIRE(X && Y && gamma && beta, "bn_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -475,27 +539,32 @@ SUBGC_API int subgc_bn_fwd(const float* X, float* Y, int M, int C, const float* 
                            running_var, eps, gamma, beta);
         return subgc::check_launch("subgc_bn_fwd");
     }
+    SUBGC_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "bn_fwd: workspace must be 16-byte aligned");
     SUBGC_REQUIRE(save_mean && save_rstd, "bn_fwd(train): save buffers required");
     const bool vec = bn_vec_ok(C, X, save_mean, save_rstd);
     const int rpb = vec ? bn_rows_per_block(M, C) : 512;
     dim3 g(vec ? (C + 255) / 256 : (C + 63) / 64, (M + rpb - 1) / rpb);
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_mean, (int64_t)C);
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_rstd, (int64_t)C);
-    if (vec) hipLaunchKernelGGL(bn_colsum_vec_kernel, g, dim3(256), 0, s, X, M, C, (const float*)nullptr, save_mean, 0, rpb);
+    float* part = vec && workspace && ws_bytes >= (size_t)g.y * C * sizeof(float) ? static_cast<float*>(workspace) : nullptr;
+    if (!part) {
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_mean, (int64_t)C);
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_rstd, (int64_t)C);
+    }
+    if (vec) hipLaunchKernelGGL(bn_colsum_vec_kernel, g, dim3(256), 0, s, X, M, C, (const float*)nullptr, save_mean, 0, rpb, part);
     else hipLaunchKernelGGL(bn_colsum_kernel, g, dim3(256), 0, s, X, M, C, (const float*)nullptr, save_mean, 0, rpb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_mean, M, C, 0, save_mean, save_rstd,
-                       running_mean, running_var, momentum, eps);
-    if (vec) hipLaunchKernelGGL(bn_colsum_vec_kernel, g, dim3(256), 0, s, X, M, C, (const float*)save_mean, save_rstd, 1, rpb);
+    const dim3 fg(part ? (C + 63) / 64 : (C + 255) / 256);
+    hipLaunchKernelGGL(bn_finalize_kernel, fg, dim3(256), 0, s, save_mean, M, C, 0, save_mean, save_rstd,
+                       running_mean, running_var, momentum, eps, (const float*)part, (int)g.y);
+    if (vec) hipLaunchKernelGGL(bn_colsum_vec_kernel, g, dim3(256), 0, s, X, M, C, (const float*)save_mean, save_rstd, 1, rpb, part);
     else hipLaunchKernelGGL(bn_colsum_kernel, g, dim3(256), 0, s, X, M, C, (const float*)save_mean, save_rstd, 1, rpb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, save_rstd, M, C, 1, save_mean, save_rstd,
-                       running_mean, running_var, momentum, eps);
+    hipLaunchKernelGGL(bn_finalize_kernel, fg, dim3(256), 0, s, save_rstd, M, C, 1, save_mean, save_rstd,
+                       running_mean, running_var, momentum, eps, (const float*)part, (int)g.y);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks), dim3(256), 0, s, X, Y, total, C, (const float*)save_mean,
                        (const float*)save_rstd, (const float*)nullptr, eps, gamma, beta);
     return subgc::check_launch("subgc_bn_fwd");
 }
 
 SUBGC_API int subgc_bn_bwd(const float* dY, const float* X, const float* gamma, const float* save_mean, const float* save_rstd,
-                           float* dX, float* dgamma, float* dbeta, int M, int C, void* stream) {
+                           float* dX, float* dgamma, float* dbeta, int M, int C, void* workspace, size_t ws_bytes, void* stream) {
     SUBGC_REQUIRE(M > 0 && C > 0, "bn_bwd: bad sizes");
     SUBGC_REQUIRE(dY && X && gamma && save_mean && save_rstd && dX && dgamma && dbeta, "bn_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -503,10 +572,14 @@ SUBGC_API int subgc_bn_bwd(const float* dY, const float* X, const float* gamma, 
     const bool vec = bn_vec_ok(C, X, dY, save_mean) && bn_vec_ok(C, save_rstd, dgamma, dbeta);
     const int rpb = vec ? bn_rows_per_block(M, C) : 512;
     dim3 g(vec ? (C + 255) / 256 : (C + 63) / 64, (M + rpb - 1) / rpb);
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dgamma, (int64_t)C);
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dbeta, (int64_t)C);
-    if (vec) hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, g, dim3(256), 0, s, dY, X, M, C, save_mean, save_rstd, dgamma, dbeta, rpb);
+    float* part = vec && workspace && ws_bytes >= (size_t)g.y * 2 * C * sizeof(float) ? static_cast<float*>(workspace) : nullptr;
+    if (!part) {
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dgamma, (int64_t)C);
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dbeta, (int64_t)C);
+    }
+    if (vec) hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, g, dim3(256), 0, s, dY, X, M, C, save_mean, save_rstd, dgamma, dbeta, rpb, part);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, dim3(256), 0, s, dY, X, M, C, save_mean, save_rstd, dgamma, dbeta, rpb);
+    if (part) hipLaunchKernelGGL(bn_sum_slabs_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)part, (int)g.y, C, dgamma, dbeta);
     const int ew_blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks), dim3(256), 0, s, dY, X, dX, total, M, C, save_mean, save_rstd, gamma,
                        (const float*)dgamma, (const float*)dbeta);

@@ -296,7 +296,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training, momentum=0.1, ep
     sm = torch.empty(C, device=x.device, dtype=torch.float32) if training else None
     sr = torch.empty(C, device=x.device, dtype=torch.float32) if training else None
     call("subgc_bn_fwd", _ptr(x), _ptr(y), M, C, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-         _ptr(sm), _ptr(sr), int(training), float(momentum), float(eps), _stream())
+         _ptr(sm), _ptr(sr), int(training), float(momentum), float(eps), *_ws(x), _stream())
     return y, sm, sr
 
 
@@ -305,7 +305,7 @@ def bn_bwd(dy, x, gamma, sm, sr):
     dx = torch.empty_like(x)
     dg = torch.empty(C, device=x.device, dtype=torch.float32)
     db = torch.empty_like(dg)
-    call("subgc_bn_bwd", _ptr(dy), _ptr(x), _ptr(gamma), _ptr(sm), _ptr(sr), _ptr(dx), _ptr(dg), _ptr(db), M, C, _stream())
+    call("subgc_bn_bwd", _ptr(dy), _ptr(x), _ptr(gamma), _ptr(sm), _ptr(sr), _ptr(dx), _ptr(dg), _ptr(db), M, C, *_ws(x), _stream())
     return dx, dg, db
 
 
