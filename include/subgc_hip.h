@@ -288,9 +288,11 @@ int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, cons
  *   ctx[s,:] = sum_i alpha_i v[m,:],  m = off[s]+i.
  * u [rows,A], v [rows,R] packed; ah [S,A]; alpha_out [S,n_stride] (entries i >= len are 0);
  * ctx written with leading dim ldctx.                                                        */
-int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a,
+int subgc_attn_fwd(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a,
                    const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha,
-                   int n_stride, int S, int A, int R, int ctx_bf16, void* stream);
+                   int n_stride, int S, int A, int R, int bf16_bits, void* stream);
+/* bf16_bits of subgc_attn_fwd / subgc_attn_bwd: bit 0 = the ctx (fwd) / dah (bwd) destination is bf16; bit 1 = u and v are
+ * bf16 [rows, A] / [rows, R] (compute_dtype = bf16: the node features survive only as the tensors the GEMMs wrote).            */
 /* backward of one step: dctx [S,R] (ld lddctx) -> dah [S,A]; du, dv ACCUMULATE (+=) over steps;
  * dw_a [S,A] and db_a [S] receive PER-SENTENCE partial gradients of w_a / b_a (plain stores; the
  * caller column-sums them once over all steps: 640 workgroups x 512 same-address atomics per step
@@ -298,10 +300,10 @@ int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float*
  * Deferred d(v): with dv == NULL the step leaves d(v) alone and (dctx_keep != NULL) stores a copy of its d(ctx) rows to
  * dctx_keep [S, >= R] (ld ldkeep); after the time loop ONE call of subgc_attn_dv_accum forms d(v) from the kept rows and the
  * attention weights of all steps -- every d(v) row is then written once instead of read and written at every step.           */
-int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off,
+int subgc_attn_bwd(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off,
                    const int32_t* len, const float* alpha, int n_stride, const float* dctx, int64_t lddctx,
                    void* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R,
-                   int dah_bf16, float* dctx_keep, int64_t ldkeep, void* stream);
+                   int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream);
 /* dv[off[s] + i, :] = sum over steps t < T with s < step_off[t+1] - step_off[t] of
  *                     alpha[step_off[t] + s, i] * dctx[step_off[t] + s, :]              (overwrites dv)
  * alpha [rows, n_stride] and dctx [rows, >= R] (ld lddctx) hold the live sentences of step t as rows step_off[t] ..
@@ -436,8 +438,9 @@ int subgc_packed_time_sum(const void* src, const int32_t* offsets, int T, int S,
 int subgc_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 /* small utilities */
-/* dz = dy * scale * [y > 0]   (backward of y = relu(z) * keep * scale: y > 0 <=> z > 0 and kept) */
-int subgc_relu_bwd(const float* dy, const float* y, float scale, void* dz, int64_t n, int out_bf16, void* stream);
+/* dz = dy * scale * [y > 0]   (backward of y = relu(z) * keep * scale: y > 0 <=> z > 0 and kept)
+ * bf16_bits: bit 0 = dz is bf16, bit 1 = y is bf16                                                */
+int subgc_relu_bwd(const float* dy, const void* y, float scale, void* dz, int64_t n, int bf16_bits, void* stream);
 /* dst[m, :] = src[rows[m], :] for m < min(M, *m_dev); negative rows give zero rows               */
 int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, void* dst, int64_t ldd,
                       int M, int L, const int32_t* m_dev, int out_bf16, void* stream);

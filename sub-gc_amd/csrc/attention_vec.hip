@@ -17,10 +17,16 @@ constexpr int MAXLEN = 512;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// four consecutive elements at index i of a node-feature array that is fp32 or (UV16: compute_dtype = bf16, where u and v are
+// kept only as the bf16 tensors the GEMMs wrote) bf16
+template <bool UV16>
+__device__ __forceinline__ float4 ldx(const void* base, int64_t i) {
+    return UV16 ? subgc_load4_bf(static_cast<const uint16_t*>(base) + i) : ld4(static_cast<const float*>(base) + i);
+}
 
 // CA = ceil(A/4 / 64): float4 chunks of a score row per lane;  CR = ceil(R/4 / 256): float4 chunks of a value row per thread
-template <int CA, int CR>
-__global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restrict__ u, const float* __restrict__ v,
+template <int CA, int CR, bool UV16>
+__global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restrict__ u, const void* __restrict__ v,
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
                                                            const float* __restrict__ b_a, const int32_t* __restrict__ off,
                                                            const int32_t* __restrict__ len, void* __restrict__ ctx, int64_t ldctx,
@@ -39,10 +45,10 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restri
         w[c] = ok ? ld4(w_a + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int i = wave; i < l; i += 4) {
-        const float* ur = u + (int64_t)(m0 + i) * A;
+        const int64_t ur = (int64_t)(m0 + i) * A;
         float4 x[CA];
 #pragma unroll
-        for (int c = 0; c < CA; ++c) x[c] = (lane + c * 64 < A4) ? ld4(ur + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < CA; ++c) x[c] = (lane + c * 64 < A4) ? ldx<UV16>(u, ur + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < CA; ++c)
@@ -67,11 +73,11 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restri
         const int r4 = t + c * 256;
         if (r4 >= R4) continue;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* vp = v + (int64_t)m0 * R + r4 * 4;
+        const int64_t vp = (int64_t)m0 * R + r4 * 4;
         int i = 0;
         for (; i + 4 <= l; i += 4) {
-            const float4 x0 = ld4(vp + (int64_t)(i + 0) * R), x1 = ld4(vp + (int64_t)(i + 1) * R);
-            const float4 x2 = ld4(vp + (int64_t)(i + 2) * R), x3 = ld4(vp + (int64_t)(i + 3) * R);
+            const float4 x0 = ldx<UV16>(v, vp + (int64_t)(i + 0) * R), x1 = ldx<UV16>(v, vp + (int64_t)(i + 1) * R);
+            const float4 x2 = ldx<UV16>(v, vp + (int64_t)(i + 2) * R), x3 = ldx<UV16>(v, vp + (int64_t)(i + 3) * R);
             const float a0 = e_s[i], a1 = e_s[i + 1], a2 = e_s[i + 2], a3 = e_s[i + 3];
             acc.x += a0 * x0.x; acc.y += a0 * x0.y; acc.z += a0 * x0.z; acc.w += a0 * x0.w;
             acc.x += a1 * x1.x; acc.y += a1 * x1.y; acc.z += a1 * x1.z; acc.w += a1 * x1.w;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restri
             acc.x += a3 * x3.x; acc.y += a3 * x3.y; acc.z += a3 * x3.z; acc.w += a3 * x3.w;
         }
         for (; i < l; ++i) {
-            const float4 x0 = ld4(vp + (int64_t)i * R);
+            const float4 x0 = ldx<UV16>(v, vp + (int64_t)i * R);
             const float a0 = e_s[i];
             acc.x += a0 * x0.x; acc.y += a0 * x0.y; acc.z += a0 * x0.z; acc.w += a0 * x0.w;
         }
@@ -88,8 +94,8 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const float* __restri
     }
 }
 
-template <int CA, int CR64>
-__global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restrict__ u, const float* __restrict__ v,
+template <int CA, int CR64, bool UV16>
+__global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restrict__ u, const void* __restrict__ v,
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
                                                            const int32_t* __restrict__ off, const int32_t* __restrict__ len,
                                                            const float* __restrict__ alpha, int n_stride,
@@ -118,10 +124,10 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restri
     __syncthreads();
     for (int i = wave; i < l; i += 4) {
         const float a_i = al_s[i];
-        const float* vr = v + (int64_t)(m0 + i) * R;
+        const int64_t vr = (int64_t)(m0 + i) * R;
         float4 x[CR64];
 #pragma unroll
-        for (int c = 0; c < CR64; ++c) x[c] = (lane + c * 64 < R4) ? ld4(vr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < CR64; ++c) x[c] = (lane + c * 64 < R4) ? ldx<UV16>(v, vr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float acc = 0.f;
         if (dv) {
             float* dvr = dv + (int64_t)(m0 + i) * R;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const float* __restri
             const float4 wa = ld4(w_a + a4 * 4), ha = ld4(ah + (int64_t)s * A + a4 * 4);
             for (int i = grp; i < l; i += 2) {
                 const int64_t o = (int64_t)(m0 + i) * A + a4 * 4;
-                const float4 x = ld4(u + o);
+                const float4 x = ldx<UV16>(u, o);
                 float4 d = ld4(du + o);
                 const float de = al_s[i];
                 const float t0 = tanhf(x.x + ha.x), t1 = tanhf(x.y + ha.y), t2 = tanhf(x.z + ha.z), t3 = tanhf(x.w + ha.w);
@@ -247,14 +253,18 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 namespace subgc {
 
 // return -100 when the vector form does not apply
-int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
-                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, hipStream_t s) {
+int attn_fwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
+                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, int uv_b16, hipStream_t s) {
     if (A % 4 || R % 4 || ldctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(ctx)) return -100;
     const int ca = (A / 4 + 63) / 64, cr = (R / 4 + 255) / 256;
     if (ca > 2 || cr > 2) return -100;
-#define SUBGC_ATT_FWD(CA_, CR_)                                                                                                  \
-    hipLaunchKernelGGL((attn_fwd_vec_kernel<CA_, CR_>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, \
-                       n_stride, A, R, ctx_b16)
+#define SUBGC_ATT_FWD(CA_, CR_)                                                                                                          \
+    do {                                                                                                                                   \
+        if (uv_b16) hipLaunchKernelGGL((attn_fwd_vec_kernel<CA_, CR_, true>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, \
+                                       alpha, n_stride, A, R, ctx_b16);                                                                   \
+        else hipLaunchKernelGGL((attn_fwd_vec_kernel<CA_, CR_, false>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, \
+                                alpha, n_stride, A, R, ctx_b16);                                                                          \
+    } while (0)
     if (ca == 1 && cr == 1) SUBGC_ATT_FWD(1, 1);
     else if (ca == 2 && cr == 1) SUBGC_ATT_FWD(2, 1);
     else if (ca == 1 && cr == 2) SUBGC_ATT_FWD(1, 2);
@@ -263,17 +273,21 @@ int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w
     return check_launch("subgc_attn_fwd(vec)");
 }
 
-int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                  const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
-                 float* db_a, int S, int A, int R, int dah_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s) {
+                 float* db_a, int S, int A, int R, int dah_b16, int uv_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s) {
     if (A % 4 || R % 4 || lddctx % 4 || ldkeep % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
         !al16(dv) || !al16(dw_a) || !al16(dctx_keep))
         return -100;
     const int ca = (A / 4 + 127) / 128, cr = (R / 4 + 63) / 64;
     if (ca > 2 || cr > 8) return -100;
-#define SUBGC_ATT_BWD(CA_, CR_)                                                                                                     \
-    hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, \
-                       dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep)
+#define SUBGC_ATT_BWD(CA_, CR_)                                                                                                          \
+    do {                                                                                                                                   \
+        if (uv_b16) hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, true>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
+                                       dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep);                          \
+        else hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, false>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
+                                dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep);                                 \
+    } while (0)
     if (ca == 1) {
         if (cr <= 1) SUBGC_ATT_BWD(1, 1); else if (cr <= 2) SUBGC_ATT_BWD(1, 2); else if (cr <= 4) SUBGC_ATT_BWD(1, 4); else SUBGC_ATT_BWD(1, 8);
     } else {

@@ -44,11 +44,12 @@ int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, flo
                    int K, int relu, hipStream_t stream, const float* add = nullptr, int64_t ldadd = 0);
 
 // attention_vec.hip: float4 forms of the per-step attention kernels; return -100 when they do not apply
-int attn_fwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
-                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, hipStream_t s);
-int attn_bwd_vec(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+int attn_fwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
+                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, int uv_b16,
+                 hipStream_t s);
+int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                  const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
-                 float* db_a, int S, int A, int R, int dah_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s);
+                 float* db_a, int S, int A, int R, int dah_b16, int uv_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s);
 int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T, const int32_t* off,
                       const int32_t* len, float* dv, int S, int R, hipStream_t s);
 

@@ -608,9 +608,14 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     if (r < 0) return;
     for (int c = threadIdx.x; c < L; c += blockDim.x) unsafeAtomicAdd(dX + (int64_t)r * ldx + c, src[(int64_t)m * lds_ + c]);
 }
-__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float scale, void* __restrict__ dz, int64_t n, int b16) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        store_one(dz, i, y[i] > 0.f ? dy[i] * scale : 0.f, b16);
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const void* __restrict__ y, float scale, void* __restrict__ dz, int64_t n, int b16,
+                                int y16) {
+    // y16: the activation survives only as the bf16 tensor the GEMM wrote (same exponent range: y > 0 is unchanged by the rounding)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool pos = y16 ? (static_cast<const uint16_t*>(y)[i] & 0x7fffu) != 0 && !(static_cast<const uint16_t*>(y)[i] & 0x8000u)
+                             : static_cast<const float*>(y)[i] > 0.f;
+        store_one(dz, i, pos ? dy[i] * scale : 0.f, b16);
+    }
 }
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ rows,
                                                           void* __restrict__ dst, int64_t ldd, int M, int L,
@@ -819,22 +824,26 @@ SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const floa
     return subgc::check_launch("subgc_lstm_bwd");
 }
 
-SUBGC_API int subgc_attn_fwd(const float* u, const float* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
+SUBGC_API int subgc_attn_fwd(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
                              const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R,
-                             int ctx_bf16, void* stream) {
+                             int bf16_bits, void* stream) {
+    const int ctx_bf16 = bf16_bits & 1, uv_bf16 = (bf16_bits >> 1) & 1;      // bit 0: ctx destination, bit 1: u and v are bf16
     SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride >= 0 && n_stride <= MAXLEN, "attn_fwd: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(u && v && ah && w_a && b_a && off && len && ctx, "attn_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
-    if (const int rc = subgc::attn_fwd_vec(u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R, ctx_bf16, s); rc != -100) return rc;
-    SUBGC_REQUIRE(!ctx_bf16, "attn_fwd: the bf16 context destination needs the vector form (A, R %% 4 == 0, 16-byte aligned rows)");
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, static_cast<float*>(ctx), ldctx, alpha, n_stride, S, A, R);
+    if (const int rc = subgc::attn_fwd_vec(u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R, ctx_bf16, uv_bf16, s); rc != -100)
+        return rc;
+    SUBGC_REQUIRE(!bf16_bits, "attn_fwd: bf16 node features / context need the vector form (A, R %% 4 == 0, 16-byte aligned rows)");
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(S), dim3(256), 0, s, static_cast<const float*>(u), static_cast<const float*>(v), ah, w_a, b_a, off, len,
+                       static_cast<float*>(ctx), ldctx, alpha, n_stride, S, A, R);
     return subgc::check_launch("subgc_attn_fwd");
 }
-SUBGC_API int subgc_attn_bwd(const float* u, const float* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+SUBGC_API int subgc_attn_bwd(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                              const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv,
-                             float* dw_a, float* db_a, int S, int A, int R, int dah_bf16, float* dctx_keep, int64_t ldkeep, void* stream) {
+                             float* dw_a, float* db_a, int S, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream) {
+    const int dah_bf16 = bf16_bits & 1, uv_bf16 = (bf16_bits >> 1) & 1;      // bit 0: dah destination, bit 1: u and v are bf16
     SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride > 0 && n_stride <= MAXLEN, "attn_bwd: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dw_a, "attn_bwd: null pointer");
@@ -842,12 +851,13 @@ SUBGC_API int subgc_attn_bwd(const float* u, const float* v, const float* ah, co
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
     if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, dah_bf16,
-                                           dctx_keep, ldkeep, s);
+                                           uv_bf16, dctx_keep, ldkeep, s);
         rc != -100)
         return rc;
-    SUBGC_REQUIRE(!dah_bf16, "attn_bwd: the bf16 d(query) destination needs the vector form");
+    SUBGC_REQUIRE(!bf16_bits, "attn_bwd: bf16 node features / d(query) destination need the vector form");
     SUBGC_REQUIRE(dv && !dctx_keep, "attn_bwd: deferring d(v) (dv == NULL / dctx_keep) needs the vector form (A, R %% 4 == 0, aligned rows)");
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, static_cast<float*>(dah), du, dv,
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, static_cast<const float*>(u), static_cast<const float*>(v), ah, w_a, off, len, alpha,
+                       n_stride, dctx, lddctx, static_cast<float*>(dah), du, dv,
                        dw_a, db_a, S, A, R);
     return subgc::check_launch("subgc_attn_bwd");
 }
@@ -975,11 +985,11 @@ SUBGC_API int subgc_scatter_add_rows(const float* src, int64_t lds, const int32_
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dX, ldx, M, L, m_dev);
     return subgc::check_launch("subgc_scatter_add_rows");
 }
-SUBGC_API int subgc_relu_bwd(const float* dy, const float* y, float scale, void* dz, int64_t n, int out_bf16, void* stream) {
+SUBGC_API int subgc_relu_bwd(const float* dy, const void* y, float scale, void* dz, int64_t n, int bf16_bits, void* stream) {
     SUBGC_REQUIRE(n >= 0, "relu_bwd: bad size");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(dy && y && dz, "relu_bwd: null pointer");
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, out_bf16);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, bf16_bits & 1, (bf16_bits >> 1) & 1);
     return subgc::check_launch("subgc_relu_bwd");
 }
 SUBGC_API int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, void* dst, int64_t ldd, int M, int L,

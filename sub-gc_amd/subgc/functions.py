@@ -304,7 +304,8 @@ def bf16_twins(P, W16):
 class Prepared:
     """Loop-invariant decoder state (AttModel._prepare_feature + pack): shared by train and decode.
     `W` = bf16_twins(P, ...)[0] switches the five products to bf16-stored operands: the fp32 results the pointwise kernels
-    read (f1, f, v, u) are kept, and every tensor a GEMM reads gets a bf16 twin written by its producer (`*16`)."""
+    read (f1, f) are kept, every tensor a GEMM reads gets a bf16 twin written by its producer (`*16`), and the node features
+    u, v are bf16 only (the attention kernels read them as such)."""
 
     def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale, W=None):
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b) = P[:8]
@@ -326,9 +327,13 @@ class Prepared:
             ops.gemm(self.fc16, w0, self.f1, tb=True, bias=fc0_b, relu=True, out16=self.f116)
             self.f, self.f16 = new(S, fc2_w.size(0)), ops.empty_b16(S, fc2_w.size(0), dev)
             ops.gemm(self.f116, w2, self.f, tb=True, bias=fc2_b, relu=True, keep=keep_fc, keep_scale=scale, out16=self.f16)
-            self.v, self.v16 = ops.zeros(MR, att_w.size(0), device=dev), ops.empty_b16(MR, att_w.size(0), dev, zero=True)
-            ops.gemm(self.Xg16, wa, self.v, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total, out16=self.v16)
-            self.u = new(MR, c2a_w.size(0))
+            # the node features v = relu(att_embed(X)) and u = ctx2att(v) exist ONLY as the bf16 tensors their GEMMs write: the
+            # attention kernels read them as such (half the bytes of the two largest per-step reads), the ReLU backward takes its
+            # sign test from the bf16 v (same exponent range as fp32), and no fp32 copy is ever stored
+            self.v16 = ops.empty_b16(MR, att_w.size(0), dev, zero=True)
+            ops.gemm(self.Xg16, wa, self.v16, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
+            self.v = self.v16
+            self.u = ops.empty_b16(MR, c2a_w.size(0), dev)
             ops.gemm(self.v16, wc, self.u, tb=True, bias=c2a_b, m_dev=self.total)
             return
         self.Xg = torch.empty(MR, L, device=dev, dtype=torch.float32)

@@ -482,18 +482,28 @@ def _attn_account(lens, S, A, R, passes):
         FLOPS["attn_bytes"] = FLOPS.get("attn_bytes", 0.0) + 4.0 * float(lens[:S].sum().item()) * (A + R) * passes
 
 
+def _uv_b16(u, v, A, R):
+    """1 when the node features u [rows, A] / v [rows, R] are the bf16 tensors of compute_dtype = bf16 (both, contiguous rows)."""
+    b = is_b16(u)
+    if b != is_b16(v):
+        raise SubgcError("attention: u and v must have the same storage type")
+    if b and (ld(u) != A or ld(v) != R):
+        raise SubgcError("attention: bf16 node features must have contiguous rows")
+    return int(b)
+
+
 def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R):
     _attn_account(lens, S, A, R, 1)      # read u and v rows once
     call("subgc_attn_fwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32),
-         _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, int(is_b16(ctx)), _stream())
+         _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), _stream())
 
 
 def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R, dctx_keep=None):
     """dv None: d(v) is deferred to one `attn_dv_accum` after the time loop; `dctx_keep` [S, R] then receives this step's d(ctx) rows."""
     _attn_account(lens, S, A, R, 3 if dv is not None else 2)      # read u, v; read-modify-write du (and dv)
     call("subgc_attn_bwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
-         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R, int(is_b16(dah)),
-         _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
+         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R,
+         int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
 
 
 def attn_dv_accum(alpha, dctx, step_off, T, off, lens, dv, S, R):
@@ -626,7 +636,9 @@ def relu_bwd(dy, y, scale=1.0, out=None, bf16=False):
     """dz = dy * scale * [y > 0] (contiguous); `bf16`: dz is written bf16 (it only feeds the two gradient GEMMs)."""
     if out is None:
         out = torch.empty(y.shape, device=y.device, dtype=BF16 if bf16 else torch.float32)
-    call("subgc_relu_bwd", _ptr(dy, torch.float32), _ptr(y, torch.float32), float(scale), _ptr(out), y.numel(), int(is_b16(out)), _stream())
+    if not (y.is_contiguous() and dy.is_contiguous() and out.is_contiguous()):
+        raise SubgcError("relu_bwd works on contiguous tensors")
+    call("subgc_relu_bwd", _ptr(dy, torch.float32), _ptr(y), float(scale), _ptr(out), y.numel(), int(is_b16(out)) | (int(is_b16(y)) << 1), _stream())
     return out
 
 
