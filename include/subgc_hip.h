@@ -104,12 +104,15 @@ int subgc_gemm_f32(int transA, int transB, int M, int N, int K,
 /* the most scratch subgc_gemm_f32 can use for a shape (0: it never splits) */
 int subgc_gemm_workspace_bytes(int M, int N, int K, size_t* bytes);
 
-/* column sums: out[n] (+)= sum_m X[m, n]  -- bias gradients.  accumulate != 0 adds to out. */
+/* column sums: out[n] (+)= sum_m X[m, n]  -- bias gradients.  accumulate != 0 adds to out.
+ * workspace / ws_bytes (optional scratch of THIS call, 16-byte aligned, up to 1024 x N floats): tall matrices are then cut into
+ * ~1024 short slabs whose partial sums are added in a fixed order by a second launch (no float atomics, reproducible); without
+ * it 256-row slabs are merged with atomics.                                                                              */
 int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
-                     const int32_t* m_dev, void* stream);
+                     const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
 /* the same over bf16 rows: bias gradients from bf16-stored gate / logit gradients */
 int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, float* out, int accumulate,
-                      const int32_t* m_dev, void* stream);
+                      const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
 
 /* ======================================================================================
  * Index kernels (bit-exact)

@@ -710,8 +710,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     }
 }
 // float4 form (N % 4 == 0, 16-byte aligned rows): a lane owns 4 adjacent columns, a wave reads 1 KB of a row per instruction
+// part != NULL: the slab's sums go to part[blockIdx.y][N] (plain stores) and colsum_finish_kernel adds the slabs in a fixed order:
+// many short slabs fill the chip without hundreds of same-address float atomics per column (see bn_colsum_vec_kernel, graph.hip)
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ X, int64_t ldx, int M, int N,
-                                                         float* __restrict__ out, const int32_t* m_dev, int rows_per_block) {
+                                                         float* __restrict__ out, const int32_t* m_dev, int rows_per_block, float* __restrict__ part) {
     __shared__ float4 sm[4][64];
     if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -727,15 +729,37 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
     __syncthreads();
     if (w == 0 && col < N) {
         const float4 a = sm[0][lane], b = sm[1][lane], c = sm[2][lane], d = sm[3][lane];
-        atomicAdd(out + col, a.x + b.x + c.x + d.x);
-        atomicAdd(out + col + 1, a.y + b.y + c.y + d.y);
-        atomicAdd(out + col + 2, a.z + b.z + c.z + d.z);
-        atomicAdd(out + col + 3, a.w + b.w + c.w + d.w);
+        const float4 t = make_float4(a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w);
+        if (part) *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + col) = t;
+        else { atomicAdd(out + col, t.x); atomicAdd(out + col + 1, t.y); atomicAdd(out + col + 2, t.z); atomicAdd(out + col + 3, t.w); }
+    }
+}
+// out[c] (+)= sum over slabs of part[slab][c], fixed order; 256 threads = 64 columns x 4 waves (wave w: slabs w, w+4, ...)
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int slabs, int N, float* __restrict__ out, int accumulate) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < N) {
+        int k = w;
+        for (; k + 28 < slabs; k += 32) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = part[(int64_t)(k + 4 * q) * N + c];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += x[q];
+        }
+        for (; k < slabs; k += 4) s += part[(int64_t)k * N + c];
+    }
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        const float t = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+        out[c] = accumulate ? out[c] + t : t;
     }
 }
 // bf16 rows (the bf16-stored gate / logit gradients): a lane owns 4 adjacent columns (8 bytes)
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ X, int64_t ldx, int M, int N,
-                                                          float* __restrict__ out, const int32_t* m_dev, int rows_per_block) {
+                                                          float* __restrict__ out, const int32_t* m_dev, int rows_per_block, float* __restrict__ part) {
     __shared__ float4 sm[4][64];
     if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -751,10 +775,9 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
     __syncthreads();
     if (w == 0 && col < N) {
         const float4 a = sm[0][lane], b = sm[1][lane], c = sm[2][lane], d = sm[3][lane];
-        atomicAdd(out + col, a.x + b.x + c.x + d.x);
-        atomicAdd(out + col + 1, a.y + b.y + c.y + d.y);
-        atomicAdd(out + col + 2, a.z + b.z + c.z + d.z);
-        atomicAdd(out + col + 3, a.w + b.w + c.w + d.w);
+        const float4 t = make_float4(a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w);
+        if (part) *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + col) = t;
+        else { atomicAdd(out + col, t.x); atomicAdd(out + col + 1, t.y); atomicAdd(out + col + 2, t.z); atomicAdd(out + col + 3, t.w); }
     }
 }
 // any N / ld (the 7001-column logit gradients of the Flickr vocabulary): one column per lane
@@ -778,18 +801,39 @@ __global__ void zero_kernel(float* p, int n) {
 }
 }  // namespace
 
+namespace {
+// slabs of the float4 column sums: with a workspace ~1024 workgroups of short slabs + one finishing pass; without, slabs of 256
+// rows merged by atomics
+struct ColsumPlan { int rows_per_block; int slabs; float* part; };
+inline ColsumPlan colsum_plan(int M, int N, void* workspace, size_t ws_bytes) {
+    const int col_groups = (N / 4 + 63) / 64;
+    int rpb = std::max(16, (int)(((int64_t)M * col_groups + 1023) / 1024));
+    int slabs = (M + rpb - 1) / rpb;
+    if (workspace && N % 4 == 0 && slabs > 8 && (size_t)slabs * N * sizeof(float) <= ws_bytes && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0)
+        return ColsumPlan{rpb, slabs, static_cast<float*>(workspace)};
+    return ColsumPlan{256, (M + 255) / 256, nullptr};
+}
+}  // namespace
+
 SUBGC_API int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, float* out, int accumulate, const int32_t* m_dev,
-                                void* stream) {
+                                void* workspace, size_t ws_bytes, void* stream) {
     SUBGC_REQUIRE(M >= 0 && N >= 0 && ldx >= N, "colsum_bf16: bad sizes");
     if (N == 0) return SUBGC_OK;
     SUBGC_REQUIRE(X && out, "colsum_bf16: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    const bool vec = N % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 7) == 0;
+    const ColsumPlan pl = vec && M > 0 ? colsum_plan(M, N, workspace, ws_bytes) : ColsumPlan{256, (M + 255) / 256, nullptr};
+    if (pl.part) {
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N / 4 + 63) / 64, pl.slabs), dim3(256), 0, s, X, ldx, M, N, out, m_dev, pl.rows_per_block, pl.part);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)pl.part, pl.slabs, N, out, accumulate);
+        return subgc::check_launch("subgc_colsum_bf16");
+    }
     if (!accumulate) hipLaunchKernelGGL(zero_kernel, dim3((N + 255) / 256), dim3(256), 0, s, out, N);
     if (M == 0) return subgc::check_launch("subgc_colsum_bf16");
     const int rows_per_block = 256;
-    if (N % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 7) == 0) {
+    if (vec) {
         dim3 grid((N / 4 + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
-        hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block);
+        hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block, (float*)nullptr);
     } else {
         dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
         hipLaunchKernelGGL(colsum_bf16_scalar_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block);
@@ -798,17 +842,24 @@ SUBGC_API int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, fl
 }
 
 SUBGC_API int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
-                               const int32_t* m_dev, void* stream) {
+                               const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream) {
     SUBGC_REQUIRE(M >= 0 && N >= 0 && ldx >= N, "colsum: bad sizes");
     if (N == 0) return SUBGC_OK;
     SUBGC_REQUIRE(X && out, "colsum: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    const bool vec = N % 4 == 0 && ldx % 4 == 0 && aligned16(X);
+    const ColsumPlan pl = vec && M > 0 ? colsum_plan(M, N, workspace, ws_bytes) : ColsumPlan{256, (M + 255) / 256, nullptr};
+    if (pl.part) {
+        hipLaunchKernelGGL(colsum_vec_kernel, dim3((N / 4 + 63) / 64, pl.slabs), dim3(256), 0, s, X, ldx, M, N, out, m_dev, pl.rows_per_block, pl.part);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)pl.part, pl.slabs, N, out, accumulate);
+        return subgc::check_launch("subgc_colsum_f32");
+    }
     if (!accumulate) hipLaunchKernelGGL(zero_kernel, dim3((N + 255) / 256), dim3(256), 0, s, out, N);
     if (M == 0) return subgc::check_launch("subgc_colsum_f32");
     const int rows_per_block = 256;
-    if (N % 4 == 0 && ldx % 4 == 0 && aligned16(X)) {
+    if (vec) {
         dim3 grid((N / 4 + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
-        hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block);
+        hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block, (float*)nullptr);
         return subgc::check_launch("subgc_colsum_f32");
     }
     dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);

@@ -239,10 +239,10 @@ def colsum(x, out=None, accumulate=False, m_dev=None):
     out = torch.empty(x.size(1), device=x.device, dtype=torch.float32) if out is None else out
     if is_b16(x):
         call("subgc_colsum_bf16", _ptr(x, BF16), ld(x), x.size(0), x.size(1), _ptr(out, torch.float32), int(accumulate),
-             _ptr(m_dev, torch.int32), _stream())
+             _ptr(m_dev, torch.int32), *_ws(x), _stream())
         return out
     call("subgc_colsum_f32", _ptr(x, torch.float32), ld(x), x.size(0), x.size(1), _ptr(out), int(accumulate),
-         _ptr(m_dev, torch.int32), _stream())
+         _ptr(m_dev, torch.int32), *_ws(x), _stream())
     return out
 
 
