@@ -568,3 +568,24 @@ def test_deferred_dv_equals_the_per_step_accumulation(S, R, T, N):
             want[int(off[s]):int(off[s]) + int(lens[s])] += al[f, :int(lens[s]), None] * dc[f][None, :]
     torch.testing.assert_close(dv2.double().cpu(), want, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(dv1, dv2, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,bf", [(9000, 4000, False), (16640, 1024, True), (21760, 9488, False), (300, 512, False), (5000, 37, False)])
+def test_column_sums_slab_partials_and_atomic_fallback(M, N, bf):
+    """subgc_colsum_*: tall matrices take the slab-partials form (workspace + finishing launch, fixed summation order), short
+    or unaligned ones the atomic form; accumulate, a device-side row count, and bit-reproducibility of the partials form."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g).to(DEV)
+    if bf:
+        x = x.to(torch.bfloat16)
+    ref = x.double().sum(0)
+    a = ops.colsum(x)
+    torch.testing.assert_close(a.double(), ref, atol=2e-3 * (M ** 0.5) / 30, rtol=1e-5)
+    if N % 4 == 0 and M > 4096:                                                       # the partials form: same bits every time
+        assert torch.equal(a, ops.colsum(x))
+    base = torch.full((N,), 3.0, device=DEV)
+    ops.colsum(x, out=base, accumulate=True)
+    torch.testing.assert_close(base.double(), ref + 3.0, atol=2e-3 * (M ** 0.5) / 30, rtol=1e-5)
+    rows = M // 3
+    m_dev = torch.tensor([rows], dtype=torch.int32, device=DEV)
+    torch.testing.assert_close(ops.colsum(x, m_dev=m_dev).double(), x[:rows].double().sum(0), atol=2e-3 * (M ** 0.5) / 30, rtol=1e-5)
