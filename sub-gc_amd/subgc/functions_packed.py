@@ -41,6 +41,33 @@ def live_plan(labels, mask_t):
     return order.indices, [int(c) for c in counts.tolist()], mask_t.sum()      # the ONE host read of a step: T small integers
 
 
+class PlanAhead:
+    """`live_plan` issued at the START of the model's forward: the T live-row counts travel to pinned host memory behind an event
+    while the host is still enqueueing the encoder, so the decoder only waits for that event.  Reading them where they are needed
+    (`live_plan`'s `.tolist()`) is a stream synchronisation after the encoder -- the host, which runs a few milliseconds ahead of
+    the GPU during the encoder, then starts the ~150 decoder launches from zero and the GPU idles behind it."""
+
+    def __init__(self, labels, mask_t):
+        S, T = mask_t.shape
+        dev = mask_t.device
+        steps = torch.arange(1, T + 1, device=dev).view(1, T)
+        live = ((mask_t > 0) * steps).amax(1)
+        any_tok = (labels[:, :T] != 0).any(0)
+        any_tok[0] = True
+        live = torch.minimum(live, torch.cumprod(any_tok.to(torch.int64), 0).sum())
+        order = torch.sort(live, descending=True, stable=True)
+        counts = (order.values.view(1, S) > torch.arange(T, device=dev).view(T, 1)).sum(1)
+        self.perm, self.den = order.indices, mask_t.sum()
+        self.host = torch.empty(T, dtype=counts.dtype).pin_memory()
+        self.host.copy_(counts, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def wait(self):
+        self.event.synchronize()
+        return self.perm, [int(c) for c in self.host.tolist()], self.den
+
+
 class PackedDecoderLossFn(Function):
     """(labels, fc_in, X_nodes, lens, idx, img, params...) -> masked NLL (scalar)."""
 
@@ -57,7 +84,7 @@ class PackedDecoderLossFn(Function):
         k_fc, k_att, k_xt, k_out = (masks.get(k) for k in ("fc", "att", "xt", "out"))
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
 
-        perm, M, den = live_plan(labels, mask_t)
+        perm, M, den = meta["plan"].wait() if meta.get("plan") is not None else live_plan(labels, mask_t)
         T_live = sum(1 for m in M if m > 0)
         ot = [0]
         for m in M:

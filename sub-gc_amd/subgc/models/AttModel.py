@@ -490,6 +490,11 @@ class AttModel(CaptionModel):
         b5, T = seq.size(0), seq.size(1) - 1
         p = self.drop_prob_lm if self.training else 0.0
         hb = gpn_obj_ind.size(2) if gpn_obj_ind is not None else 1
+        packed = fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None
+        plan = None
+        if packed:                                                                        # the packed decoder's row plan, read behind an event
+            from ..functions_packed import PlanAhead
+            plan = PlanAhead(seq.contiguous(), fused_crit[1])
         masks = self._masks({"fc": ((b5, R), p), "att": ((b5 * N, R), p), "xt": ((T, b5, E), p), "out": ((T, b5, R), p),
                              "gpn_hid": ((2 * b5 * hb, self.att_hid_size), self.gpn_drop_prob if (self.gpn and self.use_sGPN_score) else 0.0)}, dev)
         X = self._encode(att_feats, obj_dist, pred_dist, rel_ind)
@@ -508,7 +513,7 @@ class AttModel(CaptionModel):
             mask_sel[:, :36].fill_(1.0)                                                   # in place on the caller's tensor
             sel_idx = ar.expand(b5, N).contiguous()
         lens = mask_sel.sum(1).to(torch.int32)
-        meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit}
+        meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit, "plan": plan}
         if self.bf16_storage:
             flat16 = self.weights_b16()
             meta["W16"] = [self.W16(n, flat16) for n in F_.PARAM_ORDER]
@@ -522,7 +527,7 @@ class AttModel(CaptionModel):
                 both = ops.uniform((2, T, b5), seed ^ 0x5C4ED51ED5A3B11F, 0, dev)
                 sel_u, u = both[0], both[1]
             meta["ss"] = (float(self.ss_prob), sel_u.contiguous(), u.contiguous())
-        if fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None:
+        if packed:
             # loss-only call (LossWrapper): length-sorted packed decoder, dead (masked-out) steps are never computed
             from ..functions_packed import PackedDecoderLossFn
             self.fused_lang_loss = PackedDecoderLossFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx,
