@@ -76,12 +76,17 @@ def lib():
     return _lib
 
 
+_FN = {}          # bound entry points (one attribute lookup on the CDLL per name instead of one per call)
+
+
 def call(name, *args):
     """Invoke an int-returning entry point and raise on a non-zero code."""
-    L = lib()
-    rc = getattr(L, name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
+    rc = fn(*args)
     if rc != 0:
-        raise SubgcError(f"{name} failed with code {rc}: {L.subgc_last_error().decode()}")
+        raise SubgcError(f"{name} failed with code {rc}: {lib().subgc_last_error().decode()}")
 
 
 FAM = {"gemm": 1, "attn": 2, "lstm": 3, "gcn": 4, "pool": 5, "softmax": 6}
