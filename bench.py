@@ -221,14 +221,18 @@ def decode_bench(model_sd, dev, images, M):
 def pmc_traffic(a, world, launches_per_step):
     """HBM bytes per GEMM launch from the committed PMC passes of THIS command (tools/pmc_traffic.sh -> profiles/): hardware
     counters cannot be read from inside the timed run, so the figure is only reported when the profiled workload matches."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if world != 1 or a.batch != 128 or not os.path.exists(path):
+    name = "r02_pmc_traffic.json" if a.config == "kar" else f"r02_pmc_traffic_{a.config}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if world != 1 or a.batch != CONFIGS[a.config]["batch"] or not os.path.exists(path):
         return None, "no PMC profile for this configuration"
-    with open(path) as f:
-        p = json.load(f)
+    try:
+        with open(path) as f:
+            p = json.load(f)
+    except ValueError:
+        return None, f"profiles/{name} is not a PMC summary"
     if p.get("gemm_launches_per_step") != launches_per_step:
-        return None, f"profiles/r02_pmc_traffic.json was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
-    return round(p["traffic_bytes_per_launch"]), ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2.0 (gfx950 halves wide reads; calibrated in "
+        return None, f"profiles/{name} was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
+    return round(p["traffic_bytes_per_launch"]), (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE x 2.0 (gfx950 halves wide reads; calibrated in "
                                                   "profiles/r02_pmc_calibration.txt) + WRITE_SIZE (exact), separate passes")
 
 
@@ -335,7 +339,7 @@ def main():
         flops_step = ops.FLOPS["gemm"]
         alg_bytes_launch = ops.FLOPS["gemm_bytes"] / max(ops.FLOPS["gemm_calls"], 1)
         n_s = max(len(sampled), 1)
-        traffic, traffic_note = pmc_traffic(a, world, n_launch // n_s) if headline else (None, "no PMC profile for this configuration")
+        traffic, traffic_note = pmc_traffic(a, world, n_launch // n_s)
         achieved = flops_step * n_s / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         ms_per_step = 1e3 * elapsed / a.steps
         imgs = world * a.batch

@@ -20,7 +20,9 @@ import csv
 import json
 
 FETCH_FACTOR = 2.0          # profiles/r02_pmc_calibration.txt
-FAMILY = ("gemm_f32_kernel", "gemm_f32_splitk_kernel", "splitk_reduce_kernel", "gemm_skinny")
+FAMILY = ("gemm_f32_kernel", "gemm_f32_splitk_kernel", "splitk_reduce_kernel", "gemm_skinny",
+          "gemm_bf16_kernel", "gemm_bf16_splitk_kernel", "splitk_reduce_b16_kernel")          # bf16 configs: both GEMM families run
+REDUCE = ("splitk_reduce_kernel", "splitk_reduce_b16_kernel")
 
 
 def totals(path, counter):
@@ -50,7 +52,7 @@ def main():
     w, wd = totals(a.write_csv, "WRITE_SIZE")
     fetch = FETCH_FACTOR * 1024.0 * sum(f.values())  # KiB -> B, x the calibrated factor (see above)
     write = 1024.0 * sum(w.values())
-    mains = sum(v for k, v in fd.items() if k != "splitk_reduce_kernel")          # one main kernel per subgc_gemm_f32 call
+    mains = sum(v for k, v in fd.items() if k not in REDUCE)                      # one main kernel per subgc_gemm_f32 / _bf16 call
     if not a.steps_total:
         if mains % a.launches_per_step:
             raise SystemExit(f"{mains} GEMM dispatches are not a multiple of {a.launches_per_step} launches per step")

@@ -28,5 +28,16 @@ LPS=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1
 ALG=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1.json'))['roofline']['algorithmic_bytes_per_launch'])")
 python $R/tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) \
    --launches-per-step $LPS --alg-bytes-per-launch $ALG > $O/${ROUND}_pmc_traffic.json 2> $O/${ROUND}_pmc_traffic.err
+# the same two PMC passes for the bf16 configs
+for C in full_gc_kar flickr; do
+  for P in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $O/pmc_${C}_$P
+    rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/pmc_${C}_$P -- python $R/bench.py --config $C --steps 3 --warmup 2 --no-cpu-baseline --no-decode --packed-only > $O/pmc_${C}_$P.log 2>&1
+  done
+  LPS=$(python -c "import json;print(json.load(open('$O/${ROUND}_bench_$C.json'))['roofline']['launches_per_step'])")
+  ALG=$(python -c "import json;print(json.load(open('$O/${ROUND}_bench_$C.json'))['roofline']['algorithmic_bytes_per_launch'])")
+  python $R/tools/pmc_traffic.py $(find $O/pmc_${C}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_${C}_WRITE_SIZE -name "*counter_collection.csv" | head -1) \
+     --launches-per-step $LPS --alg-bytes-per-launch $ALG > $O/${ROUND}_pmc_traffic_$C.json 2> $O/${ROUND}_pmc_traffic_$C.err
+done
 cut -c1-700 $R/profiles/${ROUND}_bench_n1.json; cut -c1-400 $O/${ROUND}_bench_full_gc_kar.json; cut -c1-400 $O/${ROUND}_bench_flickr.json
 head -14 $O/${ROUND}_train_kernel_stats.txt | cut -c1-150; head -12 $O/${ROUND}_full_gc_kar_kernel_stats.txt | cut -c1-150; cat $O/${ROUND}_pmc_traffic.json | head -20
