@@ -58,10 +58,21 @@ def rank_subgraphs(model, seqq, subgraph_score, keep_nms_ind, sct_mode=False):
 
 
 @torch.no_grad()
-def caption_images(model, images, infos, ix_to_word, eval_kwargs=None, group=256):
+def caption_images(model, images, infos, ix_to_word, eval_kwargs=None, group=256, shard=None):
     """The testing branch of eval_split for a list of loader items: returns the `predictions` list
-    (eval_utils.py:132-141): {'image_id', 'caption': [...], 'subgraph_score', 'sorted_subgraph_ind'} per image."""
+    (eval_utils.py:132-141): {'image_id', 'caption': [...], 'subgraph_score', 'sorted_subgraph_ind'} per image.
+    `shard` (default: on when torch.distributed runs with more than one rank): images round-robin across the ranks, every rank
+    captions its share, the predictions are gathered once at the end and every rank returns the full list."""
+    import torch.distributed as dist
+    from . import parallel
     eval_kwargs = dict(eval_kwargs or {})
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if shard is None:
+        shard = world > 1
+    if shard and world > 1:
+        mine, idx = parallel.shard_images(images, dist.get_rank(), world)
+        local = caption_images(model, mine, [infos[i] for i in idx], ix_to_word, eval_kwargs, group, shard=False)
+        return parallel.gather_by_index(local, idx, len(images))
     sct_mode = eval_kwargs.get("sct", 0) == 1
     rbe = eval_kwargs.get("remove_bad_endings", 0)
     was_training = model.training

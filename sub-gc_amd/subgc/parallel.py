@@ -14,6 +14,11 @@ every rank runs fwd+bwd on its own shard and the gradients - which already live 
 Averaging over ranks reproduces DataParallel's mean of per-replica losses (train.py:154-156);
 BatchNorm statistics stay per rank, as they do under DataParallel.  Parameters that receive no
 gradient (dead GCN units) contribute zeros identically on every rank.
+
+Decode (reference test.py:184-185 -> eval_utils.py:98-104, one image per call on one GPU) shards the image
+list round-robin (`shard_images`), every rank decodes its share with no collective on the way, and one
+`all_gather_object` at the end collects token ids / log-probs / scores / kept indices (`sample_images_sharded`,
+`eval_glue.caption_images`).
 """
 from __future__ import annotations
 
@@ -55,6 +60,50 @@ def shard_batch(batch, rank, world, sentences_per_image=5):
         per = v.size(0) // world
         out[k] = v[rank * per:(rank + 1) * per]
     return out
+
+
+def shard_images(items, rank, world):
+    """Decode-side sharding: image i of a list goes to rank i % world (round robin keeps the ranks level when the
+    list is sorted by candidate count).  -> (this rank's items, their indices into `items`)."""
+    idx = list(range(rank, len(items), world))
+    return [items[i] for i in idx], idx
+
+
+def gather_by_index(local, idx, total, group=None):
+    """The ONE exchange of a sharded decode: every rank hands in its results (any picklable objects: tensors travel as host
+    tensors) with their positions in the un-sharded list and gets the complete list back, in the original order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        out = [None] * total
+        for i, r in zip(idx, local):
+            out[i] = r
+        return out
+    host = lambda o: o.cpu() if torch.is_tensor(o) else (type(o)(host(x) for x in o) if isinstance(o, (tuple, list)) else
+                                                        ({k: host(v) for k, v in o.items()} if isinstance(o, dict) else o))
+    parts = [None] * world
+    dist.all_gather_object(parts, (list(idx), [host(r) for r in local]), group=group)
+    out = [None] * total
+    for ids, res in parts:
+        for i, r in zip(ids, res):
+            out[i] = r
+    if any(r is None for r in out):
+        raise RuntimeError("sharded decode: some images were decoded by no rank")
+    return out
+
+
+@torch.no_grad()
+def sample_images_sharded(model, images, opt=None, group_size=256, group=None):
+    """Decode a list of loader items on all ranks (reference: one image per call on one GPU, misc/eval_utils.py:98-104, driven
+    by test.py:184-185): images round-robin across the ranks, each rank decodes its share through `model.sample_images`
+    (`group_size` images per decode batch), no collective on the way, token ids / log-probs / scores / kept indices gathered
+    once at the end.  Every rank returns the full per-image list of `_sample` tuples (host tensors when world > 1)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine, idx = shard_images(images, rank, world)
+    local = []
+    for i in range(0, len(mine), group_size):
+        local.extend(model.sample_images(mine[i:i + group_size], opt=dict(opt or {})))
+    return gather_by_index(local, idx, len(images), group)
 
 
 class GradBucketReducer:

@@ -1,0 +1,190 @@
+"""Sharded decode (second half: "images round-robin across ranks, gather ids at the end"; reference shape
+test.py:184-185 -> misc/eval_utils.py:98-104, one image per call on one device).
+
+CPU: two `gloo` ranks shard a list of 5 images (uneven shares), decode their share with the CPU oracle standing in for the
+device model, gather once, and every rank must hold exactly what one process decoding the whole list produces.
+GPU: two ranks sharing the one MI355X of the test box run the REAL model through `parallel.sample_images_sharded` and
+`eval_glue.caption_images`; tokens, log-probs, scores and kept indices equal the single-process call image by image."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(sample_max=1, beam_size=1)
+SHAPES = [(24, 14), (5, None), (30, 10), (8, None), (16, 12)]              # (candidate pairs, node pool) per image
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _collect(q, procs, timeout):
+    """One result per process; fails at once when a worker died instead of waiting out the queue timeout."""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < len(procs):
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                raise AssertionError(f"worker exit codes {[p.exitcode for p in procs]}")
+            if time.time() - t0 > timeout:
+                raise AssertionError("workers timed out")
+    return sorted(out, key=lambda t: t[0])
+
+
+def _paths():
+    for p in (os.path.join(ROOT, "sub-gc_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _images(D):
+    from subgc import synthetic
+    return [synthetic.make_test_batch(M, D=D, seed=700 + i, fc_size=D, node_pool=pool) for i, (M, pool) in enumerate(SHAPES)]
+
+
+class _OracleModel:
+    """`sample_images` with the oracle doing the arithmetic, one image per call like the reference's loop."""
+
+    def __init__(self, opt, weights):
+        from oracle import subgc_oracle as O
+        self.orc = O.Oracle(opt, weights)
+
+    def sample_images(self, images, opt=None):
+        from subgc import synthetic
+        return [self.orc.sample(*synthetic.sample_args(b), opt=dict(opt or {}), nms_sort_kind="stable")[:4] for b in images]
+
+
+def _np(results):
+    return [tuple(np.asarray(t.cpu() if torch.is_tensor(t) else t) for t in r) for r in results]
+
+
+def _cpu_worker(rank, world, port, q):
+    _paths()
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from conftest import Golden
+    from subgc import parallel
+    parallel.init_distributed("gloo")
+    g = Golden("subgc_greedy")
+    model = _OracleModel(g.opt(caption_model="topdown", gpn_drop_prob=0.0), Golden("subgc_beam").group("weights"))
+    images = _images(g.meta["opt"]["att_feat_size"])
+    mine, idx = parallel.shard_images(images, rank, world)
+    assert idx == list(range(rank, len(images), world))
+    full = parallel.sample_images_sharded(model, images, KW, group_size=2)
+    q.put((rank, len(mine), _np(full)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_sharded_decode_equals_one_process():
+    _paths()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(q, procs, 240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [3, 2]                                   # 5 images round robin over 2 ranks
+    from conftest import Golden
+    g = Golden("subgc_greedy")
+    want = _np(_OracleModel(g.opt(caption_model="topdown", gpn_drop_prob=0.0), Golden("subgc_beam").group("weights")).sample_images(
+        _images(g.meta["opt"]["att_feat_size"]), KW))
+    for _, _, got in res:
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+
+
+def test_gather_by_index_single_process_restores_order():
+    _paths()
+    from subgc import parallel
+    items = list("abcdefg")
+    for world in (1, 2, 3, 8):
+        out = [None] * len(items)
+        for r in range(world):
+            mine, idx = parallel.shard_images(items, r, world)
+            for i, v in zip(idx, mine):
+                assert out[i] is None
+                out[i] = v
+        assert out == items
+    assert parallel.gather_by_index(["x", "y"], [1, 0], 2) == ["y", "x"]
+
+
+# ----------------------------------------------------------------------------------------------- GPU: the real model, two ranks, one device
+def _gpu_model():
+    from conftest import Golden
+    import subgc.models as models
+    g = Golden("subgc_greedy")
+    w = Golden("subgc_beam").group("weights")
+    w["logit.bias"][0] += 2.0
+    opt = g.opt(caption_model="topdown", gpn_drop_prob=0.0)
+    m = models.setup(opt)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return m.to("cuda:0").eval(), g.meta["opt"]["att_feat_size"]
+
+
+VOCAB = {str(i): f"w{i}" for i in range(1, 60)}
+
+
+def _gpu_worker(rank, world, port, q):
+    _paths()
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from subgc import eval_glue, parallel
+    torch.cuda.set_device(0)
+    parallel.init_distributed("gloo")
+    m, D = _gpu_model()
+    images = [{k: v.to("cuda:0") for k, v in b.items()} for b in _images(D)]
+    full = parallel.sample_images_sharded(m, images, KW, group_size=2)
+    preds = eval_glue.caption_images(m, images, [{"id": 50 + i} for i in range(len(images))], VOCAB, KW, group=2)
+    q.put((rank, _np(full), [(p["image_id"], p["caption"], p["sorted_subgraph_ind"].tolist()) for p in preds]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_sharded_decode_is_token_identical_to_one_process():
+    _paths()
+    from subgc import eval_glue, synthetic
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(q, procs, 500)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    m, D = _gpu_model()
+    images = [{k: v.to("cuda:0") for k, v in b.items()} for b in _images(D)]
+    want = _np(m.sample_images(images, opt=KW))
+    one = [m(*synthetic.sample_args(b), opt=KW, mode="sample") for b in images]      # the reference-shaped call
+    preds = eval_glue.caption_images(m, images, [{"id": 50 + i} for i in range(len(images))], VOCAB, KW, shard=False)
+    want_p = [(p["image_id"], p["caption"], p["sorted_subgraph_ind"].tolist()) for p in preds]
+    for _, got, got_p in res:
+        assert got_p == want_p
+        for a, b, c in zip(got, want, _np(one)):
+            np.testing.assert_array_equal(a[0], b[0])                       # tokens
+            np.testing.assert_array_equal(a[0], c[0])
+            np.testing.assert_array_equal(a[3], b[3])                       # kept sub-graph indices
+            np.testing.assert_allclose(a[1], b[1], atol=1e-5)               # log-probs (batch composition changes GEMM tiling)
+            np.testing.assert_allclose(a[2], b[2], atol=1e-6)
