@@ -218,22 +218,185 @@ def decode_bench(model_sd, dev, images, M):
     return out
 
 
-def pmc_traffic(a, world, launches_per_step):
+def pmc_traffic(config, batch, world, launches_per_step):
     """HBM bytes per GEMM launch from the committed PMC passes of THIS command (tools/pmc_traffic.sh -> profiles/): hardware
     counters cannot be read from inside the timed run, so the figure is only reported when the profiled workload matches."""
-    name = "r02_pmc_traffic.json" if a.config == "kar" else f"r02_pmc_traffic_{a.config}.json"
-    path = os.path.join(ROOT, "profiles", name)
-    if world != 1 or a.batch != CONFIGS[a.config]["batch"] or not os.path.exists(path):
+    if world != 1 or batch != CONFIGS[config]["batch"]:
         return None, "no PMC profile for this configuration"
-    try:
-        with open(path) as f:
-            p = json.load(f)
-    except ValueError:
-        return None, f"profiles/{name} is not a PMC summary"
-    if p.get("gemm_launches_per_step") != launches_per_step:
-        return None, f"profiles/{name} was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
-    return round(p["traffic_bytes_per_launch"]), (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE x 2.0 (gfx950 halves wide reads; calibrated in "
-                                                  "profiles/r02_pmc_calibration.txt) + WRITE_SIZE (exact), separate passes")
+    note = "no PMC profile for this configuration"
+    for rnd in ("r03", "r02"):                                      # newest committed pass whose launch count matches this build
+        name = f"{rnd}_pmc_traffic.json" if config == "kar" else f"{rnd}_pmc_traffic_{config}.json"
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                p = json.load(f)
+        except ValueError:
+            note = f"profiles/{name} is not a PMC summary"
+            continue
+        if p.get("gemm_launches_per_step") != launches_per_step:
+            note = f"profiles/{name} was taken with {p.get('gemm_launches_per_step')} launches/step, this run has {launches_per_step}"
+            continue
+        return round(p["traffic_bytes_per_launch"]), (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE x 2.0 (gfx950 halves wide reads; calibrated in "
+                                                      "profiles/r02_pmc_calibration.txt) + WRITE_SIZE (exact), separate passes")
+    return None, note
+
+
+def roofline_block(cfg, batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm_ms, ms_per_step, traffic, traffic_note, steps):
+    achieved = flops_step * n_s / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": cfg["kernel"], "achieved": round(achieved, 2),
+            "peak": cfg["peak"], "unit": "TFLOP/s", "frac": round(achieved / cfg["peak"], 4),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
+            "algorithmic_bytes_per_launch": round(alg_bytes_launch), "launches_per_step": n_launch // n_s,
+            "event_sampled_steps": f"{n_s} of the {steps} timed steps ({n_launch} launches)",
+            "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
+            "gemm_ms_per_step": round(gemm_ms / n_s, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
+            # whole step (all kernels + gaps) against the MFMA peak: with the GEMM FLOPs actually executed, and with
+            # the reference's nominal live-graph FLOPs (22.0 GFLOP/image, SURVEY 8d; includes the masked-out decoder
+            # steps that the packed loss-only path never computes)
+            "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / cfg["peak"], 4),
+            "whole_step_frac_nominal": round(cfg["gflop_img"] * batch / (ms_per_step * 1e-3) / 1e3 / cfg["peak"], 4)}
+
+
+def train_config_leg(name, dev, steps=8, warmup=3):
+    """One of the OTHER BASELINE.json train configs as its own contract block (value / ms_per_step / dtype / config.workload /
+    roofline), measured exactly like the headline: resident synthetic batch, LossWrapper fwd + bwd + fused clip+Adam, GEMM
+    launches of two of the timed steps bracketed by HIP events, one untimed accounting step for the exact FLOPs."""
+    cfg = CONFIGS[name]
+    B = cfg["batch"]
+    torch.manual_seed(1234)
+    model = models.setup(argparse.Namespace(**cfg["opt"])).to(dev).train()
+    lw = models.LossWrapper(model, None)
+    batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(B, seed=1000, **cfg["data"]).items()}
+    adam = parallel.FlatAdam(model)
+
+    def step():
+        model.flatten_grads()
+        out = lw(*lw_args(batch))
+        loss = out["lang_loss"] + out["gpn_loss"] if out["gpn_loss"] is not None else out["lang_loss"]
+        loss.backward()
+        adam.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    smp = sorted({0, steps // 2})
+    t0 = time.perf_counter()
+    for i in range(steps):
+        _lib.prof_enable("gemm", i in smp)
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable("gemm", False)
+    n_launch, gemm_ms, _ = _lib.prof_collect("gemm")
+    ops.FLOPS.update(on=True, gemm=0.0, gemm_bytes=0.0, gemm_calls=0)
+    step()
+    torch.cuda.synchronize()
+    ops.FLOPS["on"] = False
+    flops_step, calls = ops.FLOPS["gemm"], max(ops.FLOPS["gemm_calls"], 1)
+    ms = 1e3 * dt / steps
+    traffic, note = pmc_traffic(name, B, 1, n_launch // len(smp))
+    res = {"metric": cfg["metric"], "value": round(B * steps / dt, 2), "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(ms, 3), "dtype": cfg["dtype"], "data": "synthetic",
+           "config": {"workload": cfg["workload"], "images_per_gpu": B, "decoder": "packed", "includes": "fwd + bwd + fused clip+Adam"},
+           "roofline": roofline_block(cfg, B, flops_step, ops.FLOPS["gemm_bytes"] / calls, n_launch, len(smp), gemm_ms, ms, traffic, note, steps),
+           "final_loss": round(float(loss.item()), 4)}
+    del model, lw, batch, adam, step
+    torch.cuda.empty_cache()
+    return res
+
+
+MRNN = dict(test_LSTM=1, gpn_nms_thres=0.55, gpn_max_subg=1000, use_topk_sampling=1, topk_temp=0.6, the_k=3)      # test.sh:24-30
+DECODE_MFLOP_PER_TOKEN = 76.0           # SURVEY.md section 8(d): decoder forward FLOPs per sentence-token
+
+
+def mrnn_decode_leg(dev, images=6, M=500, seed0=900, model_sd=None):
+    """BASELINE.json configs[3]'s decode half on one GPU, as test.sh runs Sub_GC_S_MRNN: 2M = 1000 candidate sub-graphs per image,
+    NMS 0.55, keep <= 1000, top-k sampling (k = 3, T = 0.6), one image per call.  -> (block, tokens, seconds)."""
+    opt = argparse.Namespace(**dict(KAR, **MRNN))
+    torch.manual_seed(0)
+    m = models.setup(opt)
+    if model_sd is not None:
+        m.load_state_dict(model_sd)
+    m = m.to(dev).eval()
+    batches = [{k: v.to(dev) for k, v in synthetic.make_test_batch(M, seed=seed0 + i).items()} for i in range(images)]
+    sopt = dict(sample_max=1, beam_size=1)
+    for b in batches[:2]:
+        m(*synthetic.sample_args(b), opt=sopt, mode="sample")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows = tokens = 0
+    for b in batches:
+        seq = m(*synthetic.sample_args(b), opt=sopt, mode="sample")[0]
+        rows += seq.size(0); tokens += seq.numel()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tf = tokens * DECODE_MFLOP_PER_TOKEN * 1e6 / dt / 1e12
+    res = {"metric": "decode tokens/sec, Sub_GC_MRNN top-k sampling", "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": 1,
+           "ms_per_step": round(1e3 * dt / images, 3), "step": "one image (one model call)", "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Sub_GC_MRNN decode (BASELINE.json configs[3], test.sh:20-30): {2 * M} candidate sub-graphs/image -> NMS 0.55 -> "
+                                  f"keep <= 1000 -> top-k sampling k=3 T=0.6, 20 tokens, one image per call, {images} images",
+                      "kept_subgraphs_per_image": round(rows / images, 1)},
+           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (decode batch = the image's kept sub-graphs, ~900 rows per token step)",
+                        "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "note": f"whole call (encode + score + node-set NMS + token loop) / {DECODE_MFLOP_PER_TOKEN} MFLOP per sentence-token (SURVEY 8d)"}}
+    del m, batches
+    torch.cuda.empty_cache()
+    return res, tokens, dt
+
+
+def decode_bench_sharded(model_sd, dev, rank, world, per_rank=64, M=50):
+    """N > 1: the decode half of the metric.  Weak scaling: `per_rank` images per GPU, image i of the global list on rank
+    i % world (parallel.shard_images), no collective on the way, ONE gather of the token ids / log-probs / scores / kept indices
+    at the end (inside the timed region).  tokens summed over ranks / max-over-ranks time."""
+    opt = argparse.Namespace(**dict(KAR, test_LSTM=1, gpn_nms_thres=0.75, gpn_max_subg=10))
+    m = models.setup(opt)
+    m.load_state_dict(model_sd)
+    m = m.to(dev).eval()
+    total = per_rank * world
+    idx = list(range(rank, total, world))
+    mine = [{k: v.to(dev) for k, v in synthetic.make_test_batch(M, seed=500 + i).items()} for i in idx]
+    sopt = dict(sample_max=1, beam_size=1)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def agg(tokens, dt):
+        t = torch.tensor([float(tokens), 0.0], device=dev, dtype=torch.float64)
+        d = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        return float(t[0].item()), float(d.item())
+
+    for b in mine[:2]:
+        m(*synthetic.sample_args(b), opt=sopt, mode="sample")
+    m.sample_images(mine, opt=sopt)
+    fence()
+    t0 = time.perf_counter()                                           # the reference's shape: one image per call, per rank
+    local = [m(*synthetic.sample_args(b), opt=sopt, mode="sample") for b in mine]
+    full = parallel.gather_by_index(local, idx, total)
+    fence()
+    tok1, dt1 = agg(sum(r[0].numel() for r in local), time.perf_counter() - t0)
+    assert len(full) == total
+    t0 = time.perf_counter()                                           # each rank's share as one decode batch
+    local = m.sample_images(mine, opt=sopt)
+    full = parallel.gather_by_index(local, idx, total)
+    fence()
+    tok2, dt2 = agg(sum(r[0].numel() for r in local), time.perf_counter() - t0)
+    del m, mine
+    torch.cuda.empty_cache()
+    _, tok3, dt3 = mrnn_decode_leg(dev, images=3, M=500, seed0=900 + 16 * rank, model_sd=None)
+    fence()
+    tok3, dt3 = agg(tok3, dt3)
+    return {"decode_tokens_per_s": round(tok1 / dt1, 1), "decode_ms_per_image": round(1e3 * dt1 / per_rank, 3),
+            "decode_config": f"greedy, {2 * M} candidate sub-graphs/image -> NMS 0.75 -> <=10 kept x 20 tokens, one image per call, {per_rank} images per "
+                             f"rank round-robin over {world} ranks, one all_gather_object of the results at the end (timed)",
+            "decode_batched_tokens_per_s": round(tok2 / dt2, 1), "decode_batched_config": f"sample_images: each rank's {per_rank} images as one decode batch, gathered at the end",
+            "decode_mrnn_topk_tokens_per_s": round(tok3 / dt3, 1),
+            "decode_mrnn_topk_config": "test.sh Sub_GC_S_MRNN: 1000 candidates/image, NMS 0.55, keep <= 1000, top-k 3 @ 0.6, one image per call, 3 images per rank"}
 
 
 def main():
@@ -248,6 +411,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--decode-images", type=int, default=64, help="N > 1: images per rank of the sharded decode leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configs' legs (clean profiles of the headline)")
     ap.add_argument("--packed-only", action="store_true", help="skip the extra unpacked-decoder leg (clean profiles)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd + bwd (+ all-reduce) only; by default the fused clip+Adam update is inside the timed step")
     ap.add_argument("--with-optimizer", action="store_true", help="accepted for older command lines: the optimizer step is on by default")
@@ -339,8 +504,7 @@ def main():
         flops_step = ops.FLOPS["gemm"]
         alg_bytes_launch = ops.FLOPS["gemm_bytes"] / max(ops.FLOPS["gemm_calls"], 1)
         n_s = max(len(sampled), 1)
-        traffic, traffic_note = pmc_traffic(a, world, n_launch // n_s)
-        achieved = flops_step * n_s / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(a.config, a.batch, world, n_launch // n_s)
         ms_per_step = 1e3 * elapsed / a.steps
         imgs = world * a.batch
         res = {
@@ -352,18 +516,7 @@ def main():
                        "decoder": "packed (length-sorted, loss-only: masked-out steps skipped; identical loss and gradients)",
                        "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")
                                    + (f" + scheduled sampling p={a.ss_prob} (per-step logits and draws)" if a.ss_prob > 0 else "")},
-            "roofline": {"bound": "mfma", "kernel": cfg["kernel"], "achieved": round(achieved, 2),
-                         "peak": cfg["peak"], "unit": "TFLOP/s", "frac": round(achieved / cfg["peak"], 4),
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
-                         "algorithmic_bytes_per_launch": round(alg_bytes_launch), "launches_per_step": n_launch // n_s,
-                         "event_sampled_steps": f"{len(sampled)} of the {a.steps} timed steps ({n_launch} launches)",
-                         "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
-                         "gemm_ms_per_step": round(gemm_ms / n_s, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
-                         # whole step (all kernels + gaps) against the MFMA peak: with the GEMM FLOPs actually executed, and with
-                         # the reference's nominal live-graph FLOPs (22.0 GFLOP/image; includes the masked-out decoder
-                         # steps that the packed loss-only path never computes)
-                         "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / cfg["peak"], 4),
-                         "whole_step_frac_nominal": round(cfg["gflop_img"] * a.batch / (ms_per_step * 1e-3) / 1e3 / cfg["peak"], 4)},
+            "roofline": roofline_block(cfg, a.batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm_ms, ms_per_step, traffic, traffic_note, a.steps),
             "final_loss": round(final_loss, 4),
         }
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_gemm_f32.json")
@@ -464,6 +617,21 @@ def main():
             if not a.no_decode:
                 res["cpu_baseline_decode"] = {"M50": cpu_decode_baseline(50, 4), "M500": cpu_decode_baseline(500, 2)}
                 res["decode_speedup_vs_cpu_M50"] = round(res["decode_tokens_per_s"] / res["cpu_baseline_decode"]["M50"]["value"], 1)
+        if world == 1 and headline and not a.no_other_configs:
+            # every other BASELINE.json config that fits one GPU, on the same clock as the headline: configs[2] and [4] as train
+            # steps in bf16 (their own value / dtype / workload / roofline), configs[3]'s decode half as test.sh runs it
+            oc = {}
+            for name in ("full_gc_kar", "flickr"):
+                oc[name + "_bf16"] = train_config_leg(name, dev, steps=8, warmup=3)
+            if not a.no_decode:
+                oc["mrnn_decode_topk"] = mrnn_decode_leg(dev, images=6, M=500)[0]
+            res["other_configs"] = oc
+    sd = None
+    if world > 1 and headline and not a.no_decode:                        # every rank decodes its share; rank 0 prints
+        sd = decode_bench_sharded(model.state_dict(), dev, rank, world, per_rank=a.decode_images)
+    if rank == 0:
+        if sd is not None:
+            res.update(sd)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -21,7 +21,7 @@ def test_two_rank_bench_prints_one_contract_line():
         port = s.getsockname()[1]
     env = dict(os.environ, SUBGC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--decode-images", "6"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -31,4 +31,7 @@ def test_two_rank_bench_prints_one_contract_line():
               "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_images"] == 32 and d["value"] > 0
+    # the decode half of the metric at N > 1: images sharded round-robin, results gathered once, tokens summed over ranks
+    for k in ("decode_tokens_per_s", "decode_batched_tokens_per_s", "decode_mrnn_topk_tokens_per_s"):
+        assert d[k] > 0, k
     assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
