@@ -270,12 +270,13 @@ def train_config_leg(name, dev, steps=8, warmup=3):
     lw = models.LossWrapper(model, None)
     batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(B, seed=1000, **cfg["data"]).items()}
     adam = parallel.FlatAdam(model)
+    one = ops.fill_(torch.empty((), device=dev, dtype=torch.float32), 1.0)
 
     def step():
         model.flatten_grads()
         out = lw(*lw_args(batch))
-        loss = out["lang_loss"] + out["gpn_loss"] if out["gpn_loss"] is not None else out["lang_loss"]
-        loss.backward()
+        loss = models.total_loss(out)
+        loss.backward(one)
         adam.step()
         return loss
 
@@ -441,12 +442,13 @@ def main():
     batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=1000 + rank, **cfg["data"]).items()}
     red = parallel.GradBucketReducer(model)
     adam = None if a.no_optimizer else parallel.FlatAdam(model)      # a training step ends with the parameter update (misc/utils.py:174-200 + Adam)
+    one = ops.fill_(torch.empty((), device=dev, dtype=torch.float32), 1.0)
 
     def step():
         red.prepare()
         out = lw(*lw_args(batch))
-        loss = out["lang_loss"] + out["gpn_loss"] if out["gpn_loss"] is not None else out["lang_loss"]
-        loss.backward()
+        loss = models.total_loss(out)
+        loss.backward(one)                                # d(loss) = 1, a resident scalar (no fill launch per step)
         red.finish(average=adam is None)                 # with the optimizer on, 1/world rides in its sweep
         if adam is not None:
             adam.step(grad_scale=1.0 / world)

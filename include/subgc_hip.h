@@ -122,6 +122,8 @@ int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, float* out, 
  * AttModel.py:306 (greedy token; also returns the max value when val != NULL).          */
 int subgc_row_argmax_f32(const float* X, int64_t ldx, int rows, int cols, int skip,
                          int64_t* idx, float* val, void* stream);
+/* the same arg-max with an int32 index output (the class ids that index the embedding tables, AttModel.py:374-385) */
+int subgc_row_argmax_i32(const float* X, int64_t ldx, int rows, int cols, int skip, int32_t* idx, void* stream);
 
 /* CSR of the scene graph by subject and by object (replaces gcn_backbone.py:55-67 make_map).
  * rel_ind int64 [B,K,2]; for role r in {0,1}: ptr[r][b, 0..N] (int32, [2,B,N+1]) and
@@ -325,8 +327,11 @@ int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, void* dlogi
 /* LanguageModelCriterion (misc/utils.py:115-124): num = -sum mask*logp[target], den = sum mask,
  * loss = num/den.  logp [S,T,V]; target, mask are [S,T] views of the [S,T+1] label/mask tensors
  * shifted by one (row strides t_stride / m_stride).  bwd writes dlogp (dense, zero elsewhere). */
+/* den_override (device float*, may be NULL): use *den_override as the denominator instead of the mask sum of the rows given
+ * (the packed decoder hands in only the live rows; the reference divides by the sum of ALL mask entries). */
 int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask,
-                         int64_t m_stride, float* loss, float* scratch2, int S, int T, int V, void* stream);
+                         int64_t m_stride, float* loss, float* scratch2, int S, int T, int V, const float* den_override,
+                         void* stream);
 int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
                          const float* scratch2, const float* dloss, float* dlogp, int S, int T, int V,
                          void* stream);
@@ -339,6 +344,42 @@ int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, int64_t t
 /* step_active[t] = 1 for t = 0 and for t >= 1 while no earlier step had all labels[:, t] == 0
  * (AttModel.py:171-172), expanded to rows: active[s*T + t].                                  */
 int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream);
+
+/* ======================================================================================
+ * Index plumbing of a training step on the device (csrc/plan.hip): one launch each instead of a dozen ATen ops.
+ *
+ * subgc_live_plan -- row plan of the packed (loss-only) decoder.  labels int64 [S, >= T] (row stride ld_labels), mask fp32
+ *   [S, T] = the criterion mask masks[:, 1:] (row stride ld_mask).  live[s] = 1 + last t with mask[s,t] > 0, clipped to the
+ *   reference's early break (AttModel.py:171-172: the loop stops at the first t >= 1 with labels[:, t] all zero).  perm32 /
+ *   perm64 [S] (perm64 may be NULL): sentences by live steps, descending, stable.  counts[t] (t < T) = sentences with
+ *   live > t; offs[t] (t <= T) = prefix of counts; den[0] = sum of ALL mask entries (misc/utils.py:123); inv32 (may be NULL):
+ *   inverse permutation (inv32[perm32[j]] = j).  S <= 16384, T <= 63.
+ * subgc_packed_rows -- with that plan (device arrays), packed row r = offs[t] + j <-> (sentence perm[j], step t):
+ *   tok_flat[r] = labels[perm[j], t], tgt_p[r] = target[perm[j], t], msk_p[r] = mask[perm[j], t]; and the per-sentence inputs
+ *   in sorted order: labels_p [S, label_cols], lens_p [S], idx_p [S, N] (from idx, row stride ld_idx), img_p [S].
+ * subgc_gpn_prep -- gpn.py:43-52: the loader's [b5, 2, hb, ...] sub-graph tensors as the pos half then the neg half,
+ *   g = c*(b5*hb) + s*hb + h: idx [G, N] node lists, w [G, N] = diagonal of gpn_pool_mtx, denom [G] = mask sums, img [G] =
+ *   s / sentences_per_image.
+ * subgc_gpn_select -- gpn.py:63-78: per sentence the FIRST max of its hb positive scores (score [2*b5*hb]), that sub-graph's
+ *   node list sel_idx [b5, N], its node count lens [b5], its read-out row ro_sel [b5, read_out_cols] (ro_sel may be NULL) and
+ *   the chosen slot sel [b5] (may be NULL); img_s [b5] (may be NULL) = owning image s / sentences_per_image.
+ * subgc_add_n_f32 -- out = a + b (+ c) (+ d), n elements (out may alias a): the sum of the gradient contributions of a tensor with several consumers. */
+int subgc_live_plan(const int64_t* labels, int64_t ld_labels, const float* mask, int64_t ld_mask, int S, int T, int32_t* perm32,
+                    int64_t* perm64, int32_t* inv32, int32_t* counts, int32_t* offs, float* den, void* stream);
+int subgc_packed_rows(const int64_t* labels, int64_t ld_labels, const int64_t* target, int64_t ld_target, const float* mask,
+                      int64_t ld_mask, const int32_t* perm, const int32_t* offs, int S, int T, int64_t* labels_p, int label_cols,
+                      int64_t* tok_flat, int64_t* tgt_p, float* msk_p, const int32_t* lens, const int64_t* idx, int64_t ld_idx,
+                      const int32_t* img, int N, int32_t* lens_p, int64_t* idx_p, int32_t* img_p, void* stream);
+int subgc_gpn_prep(const int64_t* gpn_obj_ind, const float* gpn_pool_mtx, const float* att_masks, int b5, int hb, int N,
+                   int sentences_per_image, int64_t* idx, float* w, float* denom, int32_t* img, void* stream);
+int subgc_gpn_select(const float* score, const int64_t* gpn_obj_ind, const float* att_masks, const float* read_out, int b5, int hb,
+                     int N, int read_out_cols, int64_t* sel_idx, int32_t* lens, float* ro_sel, int32_t* sel,
+                     int sentences_per_image, int32_t* img_s, void* stream);
+int subgc_add_n_f32(float* out, const float* a, const float* b, const float* c, const float* d, int64_t n, void* stream);
+/* x[r, c] = value over a [rows, cols] window (row stride ld): AttModel.py:148-149 `att_masks[:, :36] = 1` on the caller's tensor */
+int subgc_fill2d_f32(float* x, int64_t ld, int rows, int cols, float value, void* stream);
+/* lens[r] = (int32) sum of row r of a 0/1 mask: node counts of the attention sets (AttModel.py:348-354 clip_att's mask sums) */
+int subgc_row_count_f32(const float* x, int64_t ld, int rows, int cols, int32_t* lens, void* stream);
 
 /* greedy / top-k token choice of one decode step (AttModel.py:295-316).
  * greedy (k == 0): it = first argmax, lp = max.  top-k: lp' = log_softmax(logp/temp), keep the

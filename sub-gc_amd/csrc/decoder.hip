@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 }
 __global__ __launch_bounds__(1024) void nll_fwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
                                                        int64_t t_stride, const float* __restrict__ mask, int64_t m_stride,
-                                                       float* __restrict__ loss, float* __restrict__ scratch2, int S, int T, int V) {
+                                                       float* __restrict__ loss, float* __restrict__ scratch2, int S, int T, int V,
+                                                       const float* __restrict__ den_override) {
     __shared__ float sm[16];
     float num = 0.f, den = 0.f;
     for (int q = threadIdx.x; q < S * T; q += blockDim.x) {
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(1024) void nll_fwd_kernel(const float* __restrict__
     }
     num = block_sum(num, sm);
     den = block_sum(den, sm);
+    if (den_override) den = den_override[0];           // the criterion's denominator over rows this call does not see (packed decoder)
     if (threadIdx.x == 0) { scratch2[0] = num; scratch2[1] = den; loss[0] = num / den; }
 }
 __global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* __restrict__ target, int64_t t_stride,
@@ -899,11 +901,11 @@ SUBGC_API int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, v
     return subgc::check_launch("subgc_log_softmax_rows_bwd");
 }
 SUBGC_API int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
-                                   float* loss, float* scratch2, int S, int T, int V, void* stream) {
+                                   float* loss, float* scratch2, int S, int T, int V, const float* den_override, void* stream) {
     SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "masked_nll_fwd: bad sizes");
     SUBGC_REQUIRE(logp && target && mask && loss && scratch2, "masked_nll_fwd: null pointer");
     hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, target, t_stride, mask, m_stride, loss,
-                       scratch2, S, T, V);
+                       scratch2, S, T, V, den_override);
     return subgc::check_launch("subgc_masked_nll_fwd");
 }
 SUBGC_API int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride, const float* scratch2,

@@ -14,7 +14,7 @@ namespace {
 // ------------------------------------------------------------------ row arg-max (first max)
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ X, int64_t ldx, int rows,
                                                          int cols, int skip, int64_t* __restrict__ idx,
-                                                         float* __restrict__ val) {
+                                                         float* __restrict__ val, int32_t* __restrict__ idx32) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* x = X + (int64_t)row * ldx;
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
         if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
     }
     if (lane == 0) {
-        idx[row] = bi;
+        if (idx) idx[row] = bi;
+        if (idx32) idx32[row] = bi;
         if (val) val[row] = best;
     }
 }
@@ -587,8 +588,16 @@ SUBGC_API int subgc_row_argmax_f32(const float* X, int64_t ldx, int rows, int co
     SUBGC_REQUIRE(rows >= 0 && cols > skip && skip >= 0 && ldx >= cols, "row_argmax: bad sizes rows=%d cols=%d skip=%d", rows, cols, skip);
     if (rows == 0) return SUBGC_OK;
     SUBGC_REQUIRE(X && idx, "row_argmax: null pointer");
-    hipLaunchKernelGGL(row_argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, cols, skip, idx, val);
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, cols, skip, idx, val, (int32_t*)nullptr);
     return subgc::check_launch("subgc_row_argmax_f32");
+}
+SUBGC_API int subgc_row_argmax_i32(const float* X, int64_t ldx, int rows, int cols, int skip, int32_t* idx, void* stream) {
+    SUBGC_REQUIRE(rows >= 0 && cols > skip && skip >= 0 && ldx >= cols, "row_argmax: bad sizes rows=%d cols=%d skip=%d", rows, cols, skip);
+    if (rows == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(X && idx, "row_argmax: null pointer");
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, cols, skip, (int64_t*)nullptr,
+                       (float*)nullptr, idx);
+    return subgc::check_launch("subgc_row_argmax_i32");
 }
 
 SUBGC_API int subgc_csr_build(const int64_t* rel_ind, int B, int K, int N, int32_t* ptr, int32_t* edges, void* stream) {

@@ -129,6 +129,38 @@ def linear(x, W, b=None, add=None, keep=None, scale=1.0, relu=False, W16=None, x
     return y.view(*shp[:-1], W.size(0)) if x.dim() != 2 else y
 
 
+class ForkFn(Function):
+    """x -> n aliases of x for n consumers; the backward adds their gradient contributions in ONE launch (subgc_add_n_f32) instead of
+    autograd's chain of pairwise ATen adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        return (gs[0] if len(gs) == 1 else ops.add_n(gs)), None
+
+
+class SumScalarsFn(Function):
+    """a + b for two scalar losses (train.py:154-156 `loss = lang_loss + gpn_loss`) through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add_n([a.reshape(1), b.reshape(1)]).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def fork(x, n):
+    return ForkFn.apply(x, n) if (n > 1 and x is not None and x.requires_grad) else (x,) * n
+
+
 class GatherRowsFn(Function):
     """nn.Embedding lookup with int32 row ids (AttModel.py:376,383,385 class embeddings)."""
 
@@ -138,11 +170,16 @@ class GatherRowsFn(Function):
         ops.gather_rows(table, rows, out)
         ctx.save_for_backward(rows)
         ctx.shape = table.shape
+        ctx.param = table
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (rows,) = ctx.saved_tensors
+        g = _direct(ctx.param, dout.device)
+        if g is not None:                     # scatter straight into the flat gradient bucket (it was zeroed for this step)
+            ops.scatter_add_rows(dout.contiguous(), rows, g)
+            return None, None
         dt = ops.zeros(*ctx.shape, device=dout.device)
         ops.scatter_add_rows(dout.contiguous(), rows, dt)
         return dt, None
@@ -248,13 +285,22 @@ class GpnScoreFn(Function):
         score, loss = ops.gpn_score_fwd(hid, keep, scale, w2, b2)
         ctx.save_for_backward(hid, w2, score, keep)
         ctx.scale = scale
+        ctx.param_objs = (w2, b2)
         ctx.mark_non_differentiable(score)
+        ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) score output
         return score, loss
 
     @staticmethod
     def backward(ctx, dscore, dloss):
+        if dloss is None:
+            return None, None, None, None, None
         hid, w2, score, keep = ctx.saved_tensors
         dhid, dw2, db2 = ops.gpn_score_bwd(hid, keep, ctx.scale, w2, score, dloss.contiguous())
+        gw, gb = (_direct(p, hid.device) for p in ctx.param_objs)
+        if gw is not None and gb is not None:           # accumulate into the flat bucket with one C-ABI launch each instead of autograd's `+=`
+            ops.copy2d(dw2.view(1, -1), gw.view(1, -1), accumulate=True)
+            ops.copy2d(db2.view(1, -1), gb.view(1, -1), accumulate=True)
+            return dhid, None, None, None, None
         return dhid, dw2, db2, None, None
 
 

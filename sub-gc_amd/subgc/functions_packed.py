@@ -25,47 +25,38 @@ from . import functions as F_
 from . import ops
 
 
-def live_plan(labels, mask_t):
-    """-> (perm int64 [S] device, M list[int] per step, den tensor): sentences sorted by live steps.
-    A step t of sentence s is live iff mask_t[s, t'] > 0 for some t' >= t and the reference's early break
-    (AttModel.py:171-172: stop at the first t >= 1 where labels[:, t] is all zero) has not happened."""
-    S, T = mask_t.shape
-    steps = torch.arange(1, T + 1, device=mask_t.device).view(1, T)
-    live = ((mask_t > 0) * steps).amax(1)                                  # last live step index + 1
-    any_tok = (labels[:, :T] != 0).any(0)
-    any_tok[0] = True
-    t_break = torch.cumprod(any_tok.to(torch.int64), 0).sum()              # stays on the device: folded into the one read below
-    live = torch.minimum(live, t_break)
-    order = torch.sort(live, descending=True, stable=True)
-    counts = (order.values.view(1, S) > torch.arange(T, device=mask_t.device).view(T, 1)).sum(1)
-    return order.indices, [int(c) for c in counts.tolist()], mask_t.sum()      # the ONE host read of a step: T small integers
-
-
-class PlanAhead:
-    """`live_plan` issued at the START of the model's forward: the T live-row counts travel to pinned host memory behind an event
-    while the host is still enqueueing the encoder, so the decoder only waits for that event.  Reading them where they are needed
-    (`live_plan`'s `.tolist()`) is a stream synchronisation after the encoder -- the host, which runs a few milliseconds ahead of
-    the GPU during the encoder, then starts the ~150 decoder launches from zero and the GPU idles behind it."""
+class Plan:
+    """The packed decoder's row plan, built by ONE launch (subgc_live_plan): sentences ordered by live steps (a step t of sentence s
+    is live iff mask_t[s, t'] > 0 for some t' >= t and the reference's early break, AttModel.py:171-172, has not happened), the
+    live-row counts per step and their prefix, the criterion's denominator.  The T counts are the one thing the HOST needs (launch
+    dimensions); they travel to pinned memory behind an event."""
 
     def __init__(self, labels, mask_t):
         S, T = mask_t.shape
-        dev = mask_t.device
-        steps = torch.arange(1, T + 1, device=dev).view(1, T)
-        live = ((mask_t > 0) * steps).amax(1)
-        any_tok = (labels[:, :T] != 0).any(0)
-        any_tok[0] = True
-        live = torch.minimum(live, torch.cumprod(any_tok.to(torch.int64), 0).sum())
-        order = torch.sort(live, descending=True, stable=True)
-        counts = (order.values.view(1, S) > torch.arange(T, device=dev).view(T, 1)).sum(1)
-        self.perm, self.den = order.indices, mask_t.sum()
-        self.host = torch.empty(T, dtype=counts.dtype).pin_memory()
-        self.host.copy_(counts, non_blocking=True)
+        self.T = T
+        self.perm32, self.perm, self.inv32, self.plan, self.den = ops.live_plan(labels, mask_t)
+        self.offs = self.plan[T:]                                              # int32 [T+1] on the device
+        self.host = torch.empty(T, dtype=torch.int32).pin_memory()
+        self.host.copy_(self.plan[:T], non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 
     def wait(self):
+        """-> list of live rows per step (blocks until the counts have arrived)."""
         self.event.synchronize()
-        return self.perm, [int(c) for c in self.host.tolist()], self.den
+        return [int(c) for c in self.host.tolist()]
+
+
+# `Plan` issued at the START of the model's forward: the counts travel while the host is still enqueueing the encoder, so the decoder
+# only waits for that event.  Reading them where they are needed is a stream synchronisation after the encoder -- the host, which runs
+# a few milliseconds ahead of the GPU during the encoder, then starts the ~150 decoder launches from zero and the GPU idles behind it.
+PlanAhead = Plan
+
+
+def live_plan(labels, mask_t):
+    """-> (perm int64 [S] on the device, live rows per step as a python list, denominator tensor): the synchronous form of `Plan`."""
+    pl = Plan(labels, mask_t)
+    return pl.perm, pl.wait(), pl.den
 
 
 class PackedDecoderLossFn(Function):
@@ -84,17 +75,18 @@ class PackedDecoderLossFn(Function):
         k_fc, k_att, k_xt, k_out = (masks.get(k) for k in ("fc", "att", "xt", "out"))
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
 
-        perm, M, den = meta["plan"].wait() if meta.get("plan") is not None else live_plan(labels, mask_t)
+        plan = meta.get("plan") or Plan(labels, mask_t)
+        M = plan.wait()
+        perm = plan.perm
         T_live = sum(1 for m in M if m > 0)
         ot = [0]
         for m in M:
             ot.append(ot[-1] + m)
         rows = ot[-1]
-        labels_p = labels.index_select(0, perm).contiguous()
-        lens_p = lens.index_select(0, perm).contiguous()
-        idx_p = idx.index_select(0, perm).contiguous()
-        img_p = img.index_select(0, perm).contiguous()
-        fc_p = fc_in.index_select(0, perm).contiguous()
+        # sorted per-sentence inputs and the packed per-step prefixes of tokens / targets / mask: one launch (subgc_packed_rows)
+        labels_p, tok_all, tgt_all, msk_all, lens_p, idx_p, img_p = ops.packed_rows(labels, target, mask_t, plan.perm32, plan.offs, lens,
+                                                                                    idx if idx.stride(1) == 1 else idx.contiguous(), img)
+        fc_p = ops.gather_rows(fc_in.contiguous(), plan.perm32, torch.empty(S, fc_in.size(1), device=dev, dtype=torch.float32))
         X_nodes = X_nodes.contiguous()
         W, bf = F_.bf16_twins(P, meta.get("W16"))               # GEMM-operand form of every parameter (bf16 twins under compute_dtype = bf16)
         act = lambda r, c, zero=False: ops.act_buffer((r, c), dev, bf, zero)
@@ -110,9 +102,10 @@ class PackedDecoderLossFn(Function):
         Gx = new(max(rows, 1), 4 * R)
         tok_flat = k_flat = None
         if ss is None and rows > 0:
-            # all T steps' input words in packed order -> ONE embedding launch (and one in the backward) instead of one per step
-            tok_flat = torch.cat([labels_p[:M[t], t] for t in range(T_live)]).contiguous()
-            k_flat = None if k_xt is None else torch.cat([k_xt[t][:M[t]] for t in range(T_live)]).contiguous()
+            # all T steps' input words in packed order -> ONE embedding launch (and one in the backward) instead of one per step;
+            # the dropout keep-mask is random, so its first `rows` rows serve the packed rows as they are
+            tok_flat = tok_all[:rows]
+            k_flat = None if k_xt is None else k_xt.view(-1, E)[:rows]
             ops.embed_fwd(emb, tok_flat, 1, k_flat, scale, xt[:rows])
             ops.gemm(xt[:rows], W[9][:, 2 * R:], Gx[:rows], tb=True)
         Gf = new(S, 4 * R)
@@ -157,20 +150,17 @@ class PackedDecoderLossFn(Function):
             op = ot[T_live - 1]
             ops.gemm(Hout[op:rows], W[21], logits[op:rows], tb=True, bias=lg_b)
         ops.log_softmax_rows_(logits[:rows])
-        # criterion over the packed rows: row ot[t] + s  <->  (sentence perm[s], step t)
-        target_s, mask_s = target.index_select(0, perm), mask_t.index_select(0, perm)      # sorted once; the per-step prefixes are views
-        tgt_p = torch.cat([target_s[:M[t], t] for t in range(T_live)]).contiguous().view(-1, 1)
-        msk_p = torch.cat([mask_s[:M[t], t] for t in range(T_live)]).contiguous().view(-1, 1)
-        _, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p)
-        nll[1:2].copy_(den.view(1))                            # denominator = ALL mask entries (dead ones are zero anyway)
-        loss = nll[0] / nll[1]
+        # criterion over the packed rows: row ot[t] + s  <->  (sentence perm[s], step t); the denominator is the sum of ALL mask
+        # entries (dead ones included: the early break can cut live mask entries off), which the plan kernel computed
+        tgt_p, msk_p = tgt_all[:max(rows, 1)], msk_all[:max(rows, 1)]
+        loss, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p, den=plan.den)
 
         ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
         ctx.masks = (k_xt, k_out)
         ctx.flat_tokens = (tok_flat, k_flat)
         ctx.W, ctx.bf = W, bf
-        ctx.pr, ctx.params, ctx.aux = pr, P, (perm, tokens_p, lens_p, tgt_p, msk_p, nll)      # tokens_p: the words actually fed
-        ctx.save_for_backward(fc_in, X_nodes, logits, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
+        ctx.pr, ctx.params, ctx.aux = pr, P, (plan, tokens_p, lens_p, tgt_p, msk_p, nll)      # tokens_p: the words actually fed
+        ctx.save_for_backward(fc_p, X_nodes, logits, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
         return loss
 
     @staticmethod
@@ -179,8 +169,8 @@ class PackedDecoderLossFn(Function):
         k_xt, k_out = ctx.masks
         tok_flat, k_flat = ctx.flat_tokens
         pr, P, W, bf = ctx.pr, ctx.params, ctx.W, ctx.bf
-        perm, labels_p, lens_p, tgt_p, msk_p, nll = ctx.aux
-        (fc_in, X_nodes, logp, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
+        plan, labels_p, lens_p, tgt_p, msk_p, nll = ctx.aux
+        (fc_p, X_nodes, logp, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
          h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
         dev = logp.device
@@ -253,7 +243,7 @@ class PackedDecoderLossFn(Function):
         wgrad(14, P2, H2a[:, 2 * R:])
         bgrad(15, P2, also=16)
         wgrad(9, P1, H1a[:, :R], cols=(0, R))
-        step_off = torch.tensor(ot[:T_live + 1], device=dev, dtype=torch.int32)
+        step_off = plan.offs                                    # int32 [T+1] on the device; steps past T_live repeat `rows`
         if defer_dv:
             ops.attn_dv_accum(AL, dCtx, step_off, T_live, pr.off, lens_p, dv, S, R)
             del dCtx
@@ -278,10 +268,9 @@ class PackedDecoderLossFn(Function):
         ops.colsum(dWa[:rows], out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa[:rows].view(-1, 1), out=out_for(20).view(-1), accumulate=acc[20])
 
-        fc_p = fc_in.index_select(0, perm)
         dX, dfc_p = F_.prepared_backward(pr, P, W, bf, fc_p, X_nodes, du, dv, df, scale, out_for, acc, wgrad, bgrad,
                                          ctx.needs_input_grad[3], ctx.needs_input_grad[2])
-        dfc_in = None if dfc_p is None else torch.empty_like(dfc_p).index_copy_(0, perm, dfc_p)
+        dfc_in = None if dfc_p is None else ops.gather_rows(dfc_p, plan.inv32, torch.empty_like(dfc_p))      # back to the caller's order
         ctx.pr = None
         if F_.on_decoder_grads_ready is not None:
             F_.on_decoder_grads_ready()

@@ -226,6 +226,8 @@ class AttModel(CaptionModel):
         """Point every .grad into one flat fp32 buffer (zeroed); dead parameters contribute zeros."""
         if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
             self.flat_grads = torch.zeros_like(self.flat_params)
+        elif self.flat_grads.is_cuda:
+            ops.fill_(self.flat_grads, 0.0)
         else:
             self.flat_grads.zero_()
         for name, p in self._pmap.items():
@@ -317,6 +319,11 @@ class AttModel(CaptionModel):
                 needP[s] |= live_edges[l]
         return needX, needP, live_nodes, live_edges
 
+    def _skip_used(self, s0, live):
+        """Does the residual block that starts at layer s0 add its input to a LIVE output (nodes: live = live_nodes, edges: live_edges)?"""
+        last = s0 + self.GCN_residual - 1
+        return last < self.GCN_layers and live[last]
+
     def _unit(self, l, u, src, src16=None, w16=None):
         """`src16` / `w16` (compute_dtype = bf16): the bf16 copy of the source rows (shared by the two units that read them) and the
         parameter-name -> bf16 twin lookup; the 512-wide hidden rows then exist in bf16 only."""
@@ -355,7 +362,7 @@ class AttModel(CaptionModel):
         if pred_dist is not None and pred_dist.size(-1) != self.sg_pred_cnt:
             raise ValueError(f"pred_dist has {pred_dist.size(-1)} classes, sg_pred_embed has {self.sg_pred_cnt} rows")
         if self.noun_fuse:
-            cls = ops.row_argmax(obj_dist.reshape(B * N, -1), skip=1).to(torch.int32)
+            cls = ops.row_argmax(obj_dist.reshape(B * N, -1), skip=1, i32=True)
             emb = F_.GatherRowsFn.apply(self.P("sg_obj_embed.weight"), cls)
             e = F_.linear(emb, self.P("obj_emb_proj.weight"), self.P("obj_emb_proj.bias"), **lin16("obj_emb_proj.weight"))
             x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), add=e, relu=True, **lin16("obj_v_proj.weight"))
@@ -364,7 +371,7 @@ class AttModel(CaptionModel):
         x = x.view(B, N, L)
         p = None
         if needP[0] or self.GCN_layers == 0:
-            pc = ops.row_argmax(pred_dist.reshape(B * K, -1), skip=1 if self.pred_emb_type == 1 else 0).to(torch.int32)
+            pc = ops.row_argmax(pred_dist.reshape(B * K, -1), skip=1 if self.pred_emb_type == 1 else 0, i32=True)
             pe = F_.GatherRowsFn.apply(self.P("sg_pred_embed.weight"), pc)
             p = F_.linear(pe, self.P("pred_emb_prj.weight"), self.P("pred_emb_prj.bias"), **lin16("pred_emb_prj.weight")).view(B, K, L)
         if self.GCN_layers == 0:
@@ -375,15 +382,20 @@ class AttModel(CaptionModel):
         for l in range(self.GCN_layers):
             res = (l + 1) % self.GCN_residual == 0
             new_x = new_p = None
+            # a tensor that feeds several consumers is forked explicitly: the backward then adds the contributions in one launch
+            s0 = (l // self.GCN_residual) * self.GCN_residual                                  # layer whose input the residual of this block adds
+            xs = F_.fork(x, (2 if live_edges[l] else 0) + (1 if (l == s0 and self._skip_used(s0, live_nodes)) else 0)) if x is not None else ()
+            ps = F_.fork(p, (2 if live_nodes[l] else 0) + (1 if (l == s0 and self._skip_used(s0, live_edges)) else 0)) if p is not None else ()
+            if l == s0:
+                skip_x = xs[-1] if (x is not None and self._skip_used(s0, live_nodes)) else None
+                skip_p = ps[-1] if (p is not None and self._skip_used(s0, live_edges)) else None
             p16 = ops.as_b16(p.reshape(B * K, L)) if (w16 is not None and live_nodes[l]) else None      # one bf16 copy per source and layer
             x16 = ops.as_b16(x.reshape(B * N, L)) if (w16 is not None and live_edges[l]) else None
             if live_nodes[l]:
-                new_x = F_.GcnNodesFn.apply(self._unit(l, 0, p, p16, w16), self._unit(l, 1, p, p16, w16), skip_x if res else None, rel_ind, ptr, edges, N)
+                new_x = F_.GcnNodesFn.apply(self._unit(l, 0, ps[0], p16, w16), self._unit(l, 1, ps[1], p16, w16), skip_x if res else None, rel_ind, ptr, edges, N)
             if live_edges[l]:
-                new_p = F_.GcnEdgesFn.apply(self._unit(l, 2, x, x16, w16), self._unit(l, 3, x, x16, w16), skip_p if res else None, rel_ind, ptr, edges, K)
+                new_p = F_.GcnEdgesFn.apply(self._unit(l, 2, xs[0], x16, w16), self._unit(l, 3, xs[1], x16, w16), skip_p if res else None, rel_ind, ptr, edges, K)
             x, p = new_x, new_p
-            if res:
-                skip_x, skip_p = x, p
         return x
 
     # ------------------------------------------------------------------ sGPN
@@ -403,20 +415,17 @@ class AttModel(CaptionModel):
         h = self._lin(r, prefix + "read_out_proj.0", out_b16=True)              # the 512-wide hidden rows only feed the next product
         return self._lin(h, prefix + "read_out_proj.1")
 
-    def _gpn_train(self, X, gpn_obj_ind, gpn_pool_mtx, att_masks, masks):
-        """gpn.py:41-81: score all (pos, neg) sub-graphs, pick the best positive one per sentence."""
-        B, N, L = X.shape
-        b5, _, hb, _ = gpn_obj_ind.shape
+    def _gpn_train(self, X2, B, gpn_obj_ind, gpn_pool_mtx, att_masks, masks):
+        """gpn.py:41-81: score all (pos, neg) sub-graphs, pick the best positive one per sentence.  X2: node states [B*N, L].
+        -> (gpn_loss, score [G,1], sel_idx int64 [b5,N], lens int32 [b5], fc [b5, 2L], img_s int32 [b5])."""
+        L = X2.size(1)
+        b5, _, hb, N = gpn_obj_ind.shape
         spi = b5 // B
-        dev = X.device
+        dev = X2.device
         G = 2 * b5 * hb
-        idx = gpn_obj_ind.permute(1, 0, 2, 3).reshape(G, N)
-        w = gpn_pool_mtx.diagonal(dim1=-2, dim2=-1).permute(1, 0, 2, 3).reshape(G, N).contiguous()
-        denom = att_masks.permute(1, 0, 2, 3).reshape(G, N).sum(1)
-        sent = torch.arange(b5, device=dev, dtype=torch.int32)
-        img_s = torch.div(sent, spi, rounding_mode="floor").to(torch.int32)
-        img = img_s.repeat_interleave(hb).repeat(2)
-        read_out = self._pool(X.reshape(B * N, L), idx.contiguous(), w, denom.contiguous(), img.contiguous(), N)
+        # the loader's [b5, 2, hb, ...] tensors as flat pos-half / neg-half arrays: one launch (subgc_gpn_prep)
+        idx, w, denom, img = ops.gpn_prep(gpn_obj_ind, gpn_pool_mtx, att_masks, spi)
+        read_out = self._pool(X2, idx, w, denom, img, N)
         if self.use_sGPN_score:
             hid = self._lin(read_out, "gpn_layer.gpn_fc.0", relu=True)
             p = self.gpn_drop_prob if self.training else 0.0
@@ -424,14 +433,26 @@ class AttModel(CaptionModel):
             score, gpn_loss = F_.GpnScoreFn.apply(hid, self.P("gpn_layer.gpn_fc.3.weight"), self.P("gpn_layer.gpn_fc.3.bias"), keep,
                                                   1.0 / (1.0 - p) if keep is not None else 1.0)
         else:
-            score, gpn_loss = torch.ones(G, 1, device=dev), None
-        sel = ops.row_argmax(score.view(2, b5, hb)[0].contiguous())                       # gpn.py:66 (first max)
-        ar = torch.arange(b5, device=dev)
-        sel_idx = gpn_obj_ind[:, 0][ar, sel].contiguous()                                 # [b5, N]
-        mask_sel = att_masks[:, 0][ar, sel]
-        ro_sel = read_out.detach().view(2, b5, hb, 2 * L)[0][ar, sel].contiguous()        # gpn.py:78 (.detach())
+            score, gpn_loss = ops.fill_(torch.empty(G, 1, device=dev, dtype=torch.float32), 1.0), None
+        # gpn.py:63-78: first max over the hb positive scores, that sub-graph's node list / node count / read-out row (.detach())
+        sel_idx, lens, ro_sel, img_s = ops.gpn_select(score, gpn_obj_ind, att_masks, read_out.detach(), spi)
         fc = self._read_out_proj(ro_sel, "gpn_layer.")
-        return gpn_loss, score, sel_idx, mask_sel, fc, img_s
+        return gpn_loss, score, sel_idx, lens, fc, img_s
+
+    def _consts(self, dev, B, b5, N):
+        """Shape-only index tensors of the Full-GC branch (AttModel.py:140-149), built once per (device, batch shape)."""
+        key = (str(dev), B, b5, N)
+        hit = self.__dict__.setdefault("_const_cache", {}).get(key)
+        if hit is None:
+            spi = b5 // B
+            img_s = torch.div(torch.arange(b5, device=dev, dtype=torch.int32), spi, rounding_mode="floor").to(torch.int32).contiguous()
+            ar = torch.arange(N, device=dev).view(1, N)
+            hit = dict(img_s=img_s, ar_B=ar.expand(B, N).contiguous(), ar_b5=ar.expand(b5, N).contiguous(), ones=torch.ones(B, N, device=dev),
+                       full=torch.full((B,), float(N), device=dev), img_B=torch.arange(B, device=dev, dtype=torch.int32))
+            if len(self.__dict__["_const_cache"]) > 16:
+                self.__dict__["_const_cache"].clear()
+            self.__dict__["_const_cache"][key] = hit
+        return hit
 
     # ------------------------------------------------------------------ train forward
     def _decoder_params(self):
@@ -499,20 +520,20 @@ class AttModel(CaptionModel):
                              "gpn_hid": ((2 * b5 * hb, self.att_hid_size), self.gpn_drop_prob if (self.gpn and self.use_sGPN_score) else 0.0)}, dev)
         X = self._encode(att_feats, obj_dist, pred_dist, rel_ind)
         if self.gpn:
-            gpn_loss, score, sel_idx, mask_sel, fc, img_s = self._gpn_train(X, gpn_obj_ind, gpn_pool_mtx, att_masks, masks)
+            Xa, Xb = F_.fork(X.reshape(B * N, L), 2)                                       # node states feed the sGPN pooling and the decoder
+            gpn_loss, score, sel_idx, lens, fc, img_s = self._gpn_train(Xa, B, gpn_obj_ind, gpn_pool_mtx, att_masks, masks)
         else:                                                                             # AttModel.py:140-149
             gpn_loss = score = None
-            spi = b5 // B
-            img_s = torch.div(torch.arange(b5, device=dev, dtype=torch.int32), spi, rounding_mode="floor").to(torch.int32)
-            ar = torch.arange(N, device=dev).view(1, N)
-            mean = self._pool(X.detach().reshape(B * N, L), ar.expand(B, N).contiguous(), torch.ones(B, N, device=dev),
-                              torch.full((B,), float(N), device=dev), torch.arange(B, device=dev, dtype=torch.int32), N)[:, L:]
-            mean5 = mean.index_select(0, img_s.long())
+            Xb = X.reshape(B * N, L)
+            c = self._consts(dev, B, b5, N)
+            img_s = c["img_s"]
+            mean = self._pool(Xb.detach(), c["ar_B"], c["ones"], c["full"], c["img_B"], N)[:, L:]
+            mean5 = ops.gather_rows(mean, img_s, torch.empty(b5, L, device=dev, dtype=torch.float32))
             fc = self._read_out_proj(mean5, "")
             mask_sel = att_masks[:, 0, 0]
-            mask_sel[:, :36].fill_(1.0)                                                   # in place on the caller's tensor
-            sel_idx = ar.expand(b5, N).contiguous()
-        lens = mask_sel.sum(1).to(torch.int32)
+            ops.fill2d_(mask_sel[:, :36], 1.0)                                            # in place on the caller's tensor
+            sel_idx = c["ar_b5"]
+            lens = ops.row_count(mask_sel)
         meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit, "plan": plan}
         if self.bf16_storage:
             flat16 = self.weights_b16()
@@ -530,11 +551,9 @@ class AttModel(CaptionModel):
         if packed:
             # loss-only call (LossWrapper): length-sorted packed decoder, dead (masked-out) steps are never computed
             from ..functions_packed import PackedDecoderLossFn
-            self.fused_lang_loss = PackedDecoderLossFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx,
-                                                             img_s.contiguous(), *self._decoder_params())
+            self.fused_lang_loss = PackedDecoderLossFn.apply(meta, seq.contiguous(), fc, Xb, lens, sel_idx, img_s, *self._decoder_params())
             return None, gpn_loss, score
-        outputs, lang_loss = F_.DecoderFn.apply(meta, seq.contiguous(), fc, X.reshape(B * N, L), lens, sel_idx, img_s.contiguous(),
-                                                *self._decoder_params())
+        outputs, lang_loss = F_.DecoderFn.apply(meta, seq.contiguous(), fc, Xb, lens, sel_idx, img_s, *self._decoder_params())
         self.fused_lang_loss = lang_loss if fused_crit is not None else None
         return outputs, gpn_loss, score
 

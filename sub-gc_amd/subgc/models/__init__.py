@@ -22,3 +22,11 @@ def setup(opt):
         assert os.path.isfile(os.path.join(start, "infos_" + opt.id + ".pkl")), "infos.pkl file does not exist in path %s" % start
         model.load_state_dict(torch.load(os.path.join(start, "model.pth"), map_location="cpu"))
     return model
+
+
+def total_loss(out):
+    """`lang_loss + gpn_loss` of a LossWrapper result (train.py:154-156), summed by a C-ABI launch (gpn_loss may be None: Full-GC)."""
+    from .. import functions as F_
+    if out.get("gpn_loss") is None:
+        return out["lang_loss"]
+    return F_.SumScalarsFn.apply(out["lang_loss"], out["gpn_loss"])

@@ -267,8 +267,12 @@ def colsum(x, out=None, accumulate=False, m_dev=None):
     return out
 
 
-def row_argmax(x, skip=0, want_val=False):
+def row_argmax(x, skip=0, want_val=False, i32=False):
     rows, cols = x.shape
+    if i32:                              # class ids that index an embedding table: int32 rows for gather_rows / scatter_add_rows
+        idx = torch.empty(rows, device=x.device, dtype=torch.int32)
+        call("subgc_row_argmax_i32", _ptr(x, torch.float32), ld(x), rows, cols, skip, _ptr(idx), _stream())
+        return idx
     idx = torch.empty(rows, device=x.device, dtype=torch.int64)
     val = torch.empty(rows, device=x.device, dtype=torch.float32) if want_val else None
     call("subgc_row_argmax_f32", _ptr(x, torch.float32), ld(x), rows, cols, skip, _ptr(idx), _ptr(val), _stream())
@@ -547,14 +551,107 @@ def log_softmax_rows_bwd(logp, dout, dlogits, active=None):
     return dlogits
 
 
-def masked_nll_fwd(logp, target, mask):
-    """logp [S,T,V] contiguous; target/mask are [S,T] views (unit inner stride) of the label tensors."""
+def masked_nll_fwd(logp, target, mask, den=None):
+    """logp [S,T,V] contiguous; target/mask are [S,T] views (unit inner stride) of the label tensors.  `den` (device scalar):
+    the denominator to use instead of the mask sum of the rows given."""
     S, T, V = logp.shape
     loss = torch.empty((), device=logp.device, dtype=torch.float32)
     scratch = torch.empty(2, device=logp.device, dtype=torch.float32)
     call("subgc_masked_nll_fwd", _ptr(logp), _ptr(target, torch.int64), target.stride(0), _ptr(mask, torch.float32), mask.stride(0),
-         _ptr(loss), _ptr(scratch), S, T, V, _stream())
+         _ptr(loss), _ptr(scratch), S, T, V, _ptr(den, torch.float32), _stream())
     return loss, scratch
+
+
+def live_plan(labels, mask_t):
+    """Row plan of the packed decoder (subgc_live_plan) -> (perm32, perm64, inv32, plan int32 [2T+1] = counts[T] | offs[T+1], den)."""
+    S, T = mask_t.shape
+    dev = mask_t.device
+    perm32 = torch.empty(S, device=dev, dtype=torch.int32)
+    inv32 = torch.empty(S, device=dev, dtype=torch.int32)
+    perm64 = torch.empty(S, device=dev, dtype=torch.int64)
+    plan = torch.empty(2 * T + 1, device=dev, dtype=torch.int32)
+    den = torch.empty(1, device=dev, dtype=torch.float32)
+    if mask_t.stride(1) != 1 or labels.stride(1) != 1:
+        raise SubgcError("live_plan: labels / mask need unit inner stride")
+    call("subgc_live_plan", _ptr(labels, torch.int64), labels.stride(0), _ptr(mask_t, torch.float32), mask_t.stride(0), S, T, _ptr(perm32),
+         _ptr(perm64), _ptr(inv32), _ptr(plan), plan.data_ptr() + 4 * T, _ptr(den), _stream())
+    return perm32, perm64, inv32, plan, den
+
+
+def packed_rows(labels, target, mask_t, perm32, offs, lens, idx, img):
+    """-> (labels_p [S, cols], tok_flat [T*S], tgt_p [T*S, 1], msk_p [T*S, 1], lens_p, idx_p, img_p) in the plan's packed order."""
+    S, T = mask_t.shape
+    N = idx.size(1)
+    dev = labels.device
+    cols = labels.size(1)
+    labels_p = torch.empty(S, cols, device=dev, dtype=torch.int64)
+    tok = torch.empty(T * S, device=dev, dtype=torch.int64)
+    tgt = torch.empty(T * S, 1, device=dev, dtype=torch.int64)
+    msk = torch.empty(T * S, 1, device=dev, dtype=torch.float32)
+    lens_p = torch.empty(S, device=dev, dtype=torch.int32)
+    idx_p = torch.empty(S, N, device=dev, dtype=torch.int64)
+    img_p = torch.empty(S, device=dev, dtype=torch.int32)
+    if idx.stride(1) != 1 or target.stride(1) != 1 or mask_t.stride(1) != 1 or labels.stride(1) != 1:
+        raise SubgcError("packed_rows: unit inner strides needed")
+    call("subgc_packed_rows", _ptr(labels, torch.int64), labels.stride(0), _ptr(target, torch.int64), target.stride(0), _ptr(mask_t, torch.float32),
+         mask_t.stride(0), _ptr(perm32, torch.int32), _ptr(offs, torch.int32), S, T, _ptr(labels_p), cols, _ptr(tok), _ptr(tgt), _ptr(msk),
+         _ptr(lens, torch.int32), _ptr(idx, torch.int64), idx.stride(0), _ptr(img, torch.int32), N, _ptr(lens_p), _ptr(idx_p), _ptr(img_p), _stream())
+    return labels_p, tok, tgt, msk, lens_p, idx_p, img_p
+
+
+def gpn_prep(gpn_obj_ind, gpn_pool_mtx, att_masks, spi):
+    """gpn.py:43-52 views as flat [G = 2*b5*hb] arrays (pos half, then neg half): idx int64 [G,N], w [G,N], denom [G], img int32 [G]."""
+    b5, _, hb, N = gpn_obj_ind.shape
+    dev = gpn_obj_ind.device
+    G = 2 * b5 * hb
+    gpn_obj_ind, gpn_pool_mtx, att_masks = gpn_obj_ind.contiguous(), gpn_pool_mtx.contiguous(), att_masks.contiguous()
+    idx = torch.empty(G, N, device=dev, dtype=torch.int64)
+    w = torch.empty(G, N, device=dev, dtype=torch.float32)
+    denom = torch.empty(G, device=dev, dtype=torch.float32)
+    img = torch.empty(G, device=dev, dtype=torch.int32)
+    call("subgc_gpn_prep", _ptr(gpn_obj_ind, torch.int64), _ptr(gpn_pool_mtx, torch.float32), _ptr(att_masks, torch.float32), b5, hb, N, int(spi),
+         _ptr(idx), _ptr(w), _ptr(denom), _ptr(img), _stream())
+    return idx, w, denom, img
+
+
+def gpn_select(score, gpn_obj_ind, att_masks, read_out, spi):
+    """gpn.py:63-78 -> (sel_idx int64 [b5,N], lens int32 [b5], ro_sel [b5, W], img_s int32 [b5]): the best positive sub-graph of every
+    sentence and the sentence's image."""
+    b5, _, hb, N = gpn_obj_ind.shape
+    dev = score.device
+    W = read_out.size(1)
+    sel_idx = torch.empty(b5, N, device=dev, dtype=torch.int64)
+    lens = torch.empty(b5, device=dev, dtype=torch.int32)
+    ro_sel = torch.empty(b5, W, device=dev, dtype=torch.float32)
+    img_s = torch.empty(b5, device=dev, dtype=torch.int32)
+    call("subgc_gpn_select", _ptr(score, torch.float32), _ptr(gpn_obj_ind.contiguous(), torch.int64), _ptr(att_masks.contiguous(), torch.float32),
+         _ptr(read_out, torch.float32), b5, hb, N, W, _ptr(sel_idx), _ptr(lens), _ptr(ro_sel), None, int(spi), _ptr(img_s), _stream())
+    return sel_idx, lens, ro_sel, img_s
+
+
+def add_n(ts):
+    """Fresh tensor = sum of 2..4 same-shaped contiguous fp32 tensors (one launch)."""
+    ts = [t.contiguous() for t in ts]
+    out = torch.empty_like(ts[0])
+    while len(ts) > 4:
+        call("subgc_add_n_f32", _ptr(out), _ptr(ts[0], torch.float32), _ptr(ts[1], torch.float32), _ptr(ts[2], torch.float32), _ptr(ts[3], torch.float32),
+             out.numel(), _stream())
+        ts = [out] + ts[4:]
+    ts = ts + [None] * (4 - len(ts))
+    call("subgc_add_n_f32", _ptr(out), _ptr(ts[0], torch.float32), _ptr(ts[1], torch.float32), _ptr(ts[2], torch.float32), _ptr(ts[3], torch.float32),
+         out.numel(), _stream())
+    return out
+
+
+def fill2d_(x, value):
+    call("subgc_fill2d_f32", _ptr(x, torch.float32), ld(x), x.size(0), x.size(1), float(value), _stream())
+    return x
+
+
+def row_count(x):
+    lens = torch.empty(x.size(0), device=x.device, dtype=torch.int32)
+    call("subgc_row_count_f32", _ptr(x, torch.float32), ld(x), x.size(0), x.size(1), _ptr(lens), _stream())
+    return lens
 
 
 def masked_nll_bwd(target, mask, scratch, dloss, S, T, V):
