@@ -167,6 +167,33 @@ int subgc_bn_bwd(const float* dY, const float* X, const float* gamma, const floa
                  const float* save_rstd, float* dX, float* dgamma, float* dbeta, int M, int C,
                  void* workspace, size_t ws_bytes, void* stream);
 
+/* The same BatchNorm FUSED into the aggregation kernels that consume it (csrc/gcn_bn.hip; graph_conv_unit.py:31-36): the normalised
+ * tensor is never written.
+ *   subgc_bn_stats: one pass over the raw unit output X [M, C] (fp32, or bf16 when x_bf16 != 0; C % 4 == 0) -> aff [3, C] =
+ *     {mean, gamma * rstd, beta} for the consumer and rstd [C] for the backward; running statistics updated as nn.BatchNorm1d
+ *     does (momentum, unbiased variance).  training == 0: aff from the running statistics (X is not read, rstd may be NULL).
+ *     workspace: subgc_bn_stats_workspace_bytes(M, C) bytes, 16-byte aligned (per-slab shifted sums, merged in double).
+ *   subgc_gcn_{nodes,edges}_fwd_bn: subgc_gcn_{nodes,edges}_fwd with the sources read as (F - mean) * scale + beta through
+ *     aff0/aff1 ([3, L] each; NULL = the source is used as it is), sources fp32 or bf16 (f_bf16), and an optional bf16 copy of
+ *     the result (Xout16 / Pout16: the next layer's GEMM operand).  subgc_gcn_edges_bwd_bn: the ReLU sign test on the same
+ *     normalised values.  L % 4 == 0.
+ *   subgc_bn_bwd_fused: dY = d(normalised) [M, C] fp32 -> dX in X's storage type (dx_bf16) and dgamma / dbeta [C] (accumulate != 0:
+ *     added to what is there); mean = aff[0:C].  workspace: 2/3 of the forward's.                                              */
+int subgc_bn_stats_workspace_bytes(int M, int C, size_t* bytes);
+int subgc_bn_stats(const void* X, int x_bf16, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float* aff, float* rstd, int training, float momentum, float eps, void* workspace,
+                   size_t ws_bytes, void* stream);
+int subgc_bn_bwd_fused(const float* dY, const void* X, int x_bf16, int M, int C, const float* gamma, const float* mean,
+                       const float* rstd, void* dX, int dx_bf16, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                       size_t ws_bytes, void* stream);
+int subgc_gcn_nodes_fwd_bn(const void* F0, const void* F1, int f_bf16, const float* aff0, const float* aff1, const int32_t* ptr,
+                           const int32_t* edges, const float* skip, float* Xout, uint16_t* Xout16, uint8_t* act, int B, int N, int K,
+                           int L, void* stream);
+int subgc_gcn_edges_fwd_bn(const void* F2, const void* F3, int f_bf16, const float* aff2, const float* aff3, const int64_t* rel_ind,
+                           const float* skip, float* Pout, uint16_t* Pout16, int B, int N, int K, int L, void* stream);
+int subgc_gcn_edges_bwd_bn(const float* dP, const void* F2, const void* F3, int f_bf16, const float* aff2, const float* aff3,
+                           const int32_t* ptr, const int32_t* edges, float* dF2, float* dF3, int B, int N, int K, int L, void* stream);
+
 /* ======================================================================================
  * sGPN (replaces gpn.py:152-185 gather + diagonal bmm + max/mean pooling, never materialising
  * the gathered [G,N,L] tensor).  For sub-graph g (image img[g]) with node list idx[g,0..N) and

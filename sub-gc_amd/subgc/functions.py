@@ -230,6 +230,83 @@ class GcnEdgesFn(Function):
         return dF2, dF3, (dP if ctx.has_skip else None), None, None, None, None
 
 
+def _bn_back(dFh, y, gamma, beta, aff, rstd):
+    """BatchNorm backward of one fused source: d(normalised) -> d(raw unit output) in its storage type; the affine gradients go
+    straight into the flat bucket when it exists (returns (dy, dgamma, dbeta) with None for what was written in place)."""
+    M, C = y.numel() // y.size(-1), y.size(-1)
+    gg, gb = _direct(gamma, dFh.device), _direct(beta, dFh.device)
+    if gg is not None and gb is not None:
+        return ops.bn_bwd_fused(dFh.view(M, C), y.view(M, C), gamma, aff, rstd, gg, gb, True).view(y.shape), None, None
+    dg, db = torch.empty(C, device=dFh.device, dtype=torch.float32), torch.empty(C, device=dFh.device, dtype=torch.float32)
+    return ops.bn_bwd_fused(dFh.view(M, C), y.view(M, C), gamma, aff, rstd, dg, db, False).view(y.shape), dg, db
+
+
+class GcnNodesBnFn(Function):
+    """nodes <- relations (GcnNodesFn) with the BatchNorm1d of the two collection units (graph_conv_unit.py:31-32) fused in: y0, y1
+    are the RAW unit outputs (fp32, or bf16 under compute_dtype = bf16); the batch statistics are one pass, the aggregation kernel
+    normalises on load, the backward returns d(y) in y's storage type.  `want16`: also a bf16 copy of the result (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, y0, y1, skip, rel_ind, ptr, edges, N, g0, b0, g1, b1, stats, training, want16):
+        B, K, L = y0.shape
+        y0, y1 = y0.contiguous(), y1.contiguous()
+        aff0, rstd0 = ops.bn_stats(y0.view(B * K, L), g0, b0, stats[0], stats[1], training)
+        aff1, rstd1 = ops.bn_stats(y1.view(B * K, L), g1, b1, stats[2], stats[3], training)
+        out, out16, act = ops.gcn_nodes_fwd_bn(y0, y1, aff0, aff1, ptr, edges, skip.contiguous() if skip is not None else None, B, N, K, L, want16)
+        ctx.save_for_backward(y0, y1, aff0, rstd0, aff1, rstd1, act, rel_ind, ptr)
+        ctx.params = (g0, b0, g1, b1)
+        ctx.dims, ctx.has_skip, ctx.training = (B, N, K, L), skip is not None, training
+        if want16:
+            ctx.mark_non_differentiable(out16)
+            return out, out16
+        return out
+
+    @staticmethod
+    def backward(ctx, dX, *_unused):
+        y0, y1, aff0, rstd0, aff1, rstd1, act, rel_ind, ptr = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("GcnNodesBnFn: backward in eval mode is not part of the Sub-GC path")
+        B, N, K, L = ctx.dims
+        g0, b0, g1, b1 = ctx.params
+        dX = dX.contiguous()
+        dF0, dF1 = ops.gcn_nodes_bwd(dX, act, rel_ind, ptr, B, N, K, L)
+        dy0, dg0, db0 = _bn_back(dF0, y0, g0, b0, aff0, rstd0)
+        dy1, dg1, db1 = _bn_back(dF1, y1, g1, b1, aff1, rstd1)
+        return dy0, dy1, (dX if ctx.has_skip else None), None, None, None, None, dg0, db0, dg1, db1, None, None, None
+
+
+class GcnEdgesBnFn(Function):
+    """relations <- nodes (GcnEdgesFn) with the two units' BatchNorm fused in (see GcnNodesBnFn)."""
+
+    @staticmethod
+    def forward(ctx, y2, y3, skip, rel_ind, ptr, edges, K, g2, b2, g3, b3, stats, training, want16):
+        B, N, L = y2.shape
+        y2, y3 = y2.contiguous(), y3.contiguous()
+        aff2, rstd2 = ops.bn_stats(y2.view(B * N, L), g2, b2, stats[0], stats[1], training)
+        aff3, rstd3 = ops.bn_stats(y3.view(B * N, L), g3, b3, stats[2], stats[3], training)
+        out, out16 = ops.gcn_edges_fwd_bn(y2, y3, aff2, aff3, rel_ind, skip.contiguous() if skip is not None else None, B, N, K, L, want16)
+        ctx.save_for_backward(y2, y3, aff2, rstd2, aff3, rstd3, ptr, edges)
+        ctx.params = (g2, b2, g3, b3)
+        ctx.dims, ctx.has_skip, ctx.training = (B, N, K, L), skip is not None, training
+        if want16:
+            ctx.mark_non_differentiable(out16)
+            return out, out16
+        return out
+
+    @staticmethod
+    def backward(ctx, dP, *_unused):
+        y2, y3, aff2, rstd2, aff3, rstd3, ptr, edges = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("GcnEdgesBnFn: backward in eval mode is not part of the Sub-GC path")
+        B, N, K, L = ctx.dims
+        g2, b2, g3, b3 = ctx.params
+        dP = dP.contiguous()
+        dF2, dF3 = ops.gcn_edges_bwd_bn(dP, y2, y3, aff2, aff3, ptr, edges, B, N, K, L)
+        dy2, dg2, db2 = _bn_back(dF2, y2, g2, b2, aff2, rstd2)
+        dy3, dg3, db3 = _bn_back(dF3, y3, g3, b3, aff3, rstd3)
+        return dy2, dy3, (dP if ctx.has_skip else None), None, None, None, None, dg2, db2, dg3, db3, None, None, None
+
+
 class BatchNormFn(Function):
     """nn.BatchNorm1d over rows (graph_conv_unit.py:31-32); running stats updated in place."""
 

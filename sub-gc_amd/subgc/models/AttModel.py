@@ -117,6 +117,7 @@ class AttModel(CaptionModel):
         self._dropout_calls = 0
         self.injected_masks = None       # tests inject {'fc','att','xt','out','gpn_hid'} keep-masks here
         self.injected_ss = None          # tests inject (selector uniforms [T,S], draw uniforms [T,S]) for scheduled sampling
+        self.__dict__["_nbt_pending"] = {}
         self._build_parameters()
 
     # ------------------------------------------------------------------ parameters
@@ -324,24 +325,47 @@ class AttModel(CaptionModel):
         last = s0 + self.GCN_residual - 1
         return last < self.GCN_layers and live[last]
 
-    def _unit(self, l, u, src, src16=None, w16=None):
+    def _unit(self, l, u, src, src16=None, w16=None, fuse_bn=False):
         """`src16` / `w16` (compute_dtype = bf16): the bf16 copy of the source rows (shared by the two units that read them) and the
-        parameter-name -> bf16 twin lookup; the 512-wide hidden rows then exist in bf16 only."""
+        parameter-name -> bf16 twin lookup; the 512-wide hidden rows then exist in bf16 only.  `fuse_bn`: return the RAW unit output
+        (bf16 under compute_dtype = bf16) -- the BatchNorm is applied by the aggregation kernel that consumes it (`_bn_args`)."""
         pre = f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}."
         shp = src.shape
         if w16 is not None:
             h = F_.linear(src.reshape(-1, shp[-1]), self.P(pre + "fc_lft.weight"), self.P(pre + "fc_lft.bias"), W16=w16(pre + "fc_lft.weight"),
                           x16=src16, out_b16=True)
-            y = F_.linear(h, self.P(pre + "fc_rgt.weight"), self.P(pre + "fc_rgt.bias"), W16=w16(pre + "fc_rgt.weight"))
+            y = F_.linear(h, self.P(pre + "fc_rgt.weight"), self.P(pre + "fc_rgt.bias"), W16=w16(pre + "fc_rgt.weight"), out_b16=fuse_bn)
         else:
             h = F_.linear(src.reshape(-1, shp[-1]), self.P(pre + "fc_lft.weight"), self.P(pre + "fc_lft.bias"))
             y = F_.linear(h, self.P(pre + "fc_rgt.weight"), self.P(pre + "fc_rgt.bias"))
-        if self.GCN_use_bn:
+        if self.GCN_use_bn and not fuse_bn:
             y = F_.BatchNormFn.apply(y, self.P(pre + "bn.weight"), self.P(pre + "bn.bias"), self._bmap[pre + "bn.running_mean"],
                                      self._bmap[pre + "bn.running_var"], self.training)
-            if self.training:
-                self._bmap[pre + "bn.num_batches_tracked"] += 1
+        if self.GCN_use_bn and self.training:
+            self._nbt_pending[pre] = self._nbt_pending.get(pre, 0) + 1                # num_batches_tracked, folded into the buffer lazily
         return y.view(shp[0], shp[1], -1)
+
+    def _bn_args(self, l, ua, ub):
+        """(gamma_a, beta_a, gamma_b, beta_b, (running_mean_a, running_var_a, running_mean_b, running_var_b), training) of two units."""
+        pa, pb = (f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}.bn." for u in (ua, ub))
+        return (self.P(pa + "weight"), self.P(pa + "bias"), self.P(pb + "weight"), self.P(pb + "bias"),
+                (self._bmap[pa + "running_mean"], self._bmap[pa + "running_var"], self._bmap[pb + "running_mean"], self._bmap[pb + "running_var"]),
+                self.training)
+
+    def _flush_bn_counters(self):
+        """nn.BatchNorm1d's num_batches_tracked (a buffer of the state_dict; nothing on the path reads it): counted on the host per
+        forward and added to the device buffers only when somebody looks (state_dict / load_state_dict)."""
+        pend, self.__dict__["_nbt_pending"] = self.__dict__.get("_nbt_pending", {}), {}
+        for pre, n in pend.items():
+            self._bmap[pre + "bn.num_batches_tracked"] += n
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_bn_counters()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__["_nbt_pending"] = {}
+        return super().load_state_dict(*args, **kwargs)
 
     def _encode(self, att_feats, obj_dist, pred_dist, rel_ind):
         """feat_fusion + GCN (AttModel.py:370-387, gcn_backbone.py:29-53) -> X_out [B, N, L]."""
@@ -379,6 +403,7 @@ class AttModel(CaptionModel):
         rel_ind = rel_ind.contiguous()
         ptr, edges = ops.csr_build(rel_ind, N)
         skip_x, skip_p = x, p
+        x16n = p16n = None
         for l in range(self.GCN_layers):
             res = (l + 1) % self.GCN_residual == 0
             new_x = new_p = None
@@ -389,12 +414,34 @@ class AttModel(CaptionModel):
             if l == s0:
                 skip_x = xs[-1] if (x is not None and self._skip_used(s0, live_nodes)) else None
                 skip_p = ps[-1] if (p is not None and self._skip_used(s0, live_edges)) else None
-            p16 = ops.as_b16(p.reshape(B * K, L)) if (w16 is not None and live_nodes[l]) else None      # one bf16 copy per source and layer
-            x16 = ops.as_b16(x.reshape(B * N, L)) if (w16 is not None and live_edges[l]) else None
+            # one bf16 copy per source and layer (compute_dtype = bf16): written by the aggregation kernel that produced the source
+            # when that was a fused-BatchNorm one (`x16n` / `p16n` of the previous layer), else a cast pass
+            if w16 is not None and live_nodes[l]:
+                p16 = p16n if p16n is not None else ops.as_b16(p.reshape(B * K, L))
+            else:
+                p16 = None
+            if w16 is not None and live_edges[l]:
+                x16 = x16n if x16n is not None else ops.as_b16(x.reshape(B * N, L))
+            else:
+                x16 = None
+            x16n = p16n = None
+            fuse = self.GCN_use_bn and L % 4 == 0
+            nxt_x = w16 is not None and l + 1 < self.GCN_layers and live_edges[l + 1]          # the next layer reads new_x as a GEMM operand
+            nxt_p = w16 is not None and l + 1 < self.GCN_layers and live_nodes[l + 1]
             if live_nodes[l]:
-                new_x = F_.GcnNodesFn.apply(self._unit(l, 0, ps[0], p16, w16), self._unit(l, 1, ps[1], p16, w16), skip_x if res else None, rel_ind, ptr, edges, N)
+                y0, y1 = self._unit(l, 0, ps[0], p16, w16, fuse), self._unit(l, 1, ps[1], p16, w16, fuse)
+                if fuse:
+                    r = F_.GcnNodesBnFn.apply(y0, y1, skip_x if res else None, rel_ind, ptr, edges, N, *self._bn_args(l, 0, 1), nxt_x)
+                    new_x, x16n = (r[0], r[1].view(B * N, L)) if nxt_x else (r, None)
+                else:
+                    new_x = F_.GcnNodesFn.apply(y0, y1, skip_x if res else None, rel_ind, ptr, edges, N)
             if live_edges[l]:
-                new_p = F_.GcnEdgesFn.apply(self._unit(l, 2, xs[0], x16, w16), self._unit(l, 3, xs[1], x16, w16), skip_p if res else None, rel_ind, ptr, edges, K)
+                y2, y3 = self._unit(l, 2, xs[0], x16, w16, fuse), self._unit(l, 3, xs[1], x16, w16, fuse)
+                if fuse:
+                    r = F_.GcnEdgesBnFn.apply(y2, y3, skip_p if res else None, rel_ind, ptr, edges, K, *self._bn_args(l, 2, 3), nxt_p)
+                    new_p, p16n = (r[0], r[1].view(B * K, L)) if nxt_p else (r, None)
+                else:
+                    new_p = F_.GcnEdgesFn.apply(y2, y3, skip_p if res else None, rel_ind, ptr, edges, K)
             x, p = new_x, new_p
         return x
 

@@ -334,6 +334,53 @@ def bn_bwd(dy, x, gamma, sm, sr):
     return dx, dg, db
 
 
+def bn_stats(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    """Batch statistics of the raw unit output x [M, C] (fp32 or bf16) -> (aff [3, C] = mean | gamma * rstd | beta, rstd [C]); the
+    consumer kernels normalise on load (subgc_bn_stats).  Eval mode: aff from the running statistics."""
+    M, C = x.shape
+    aff = torch.empty(3, C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    if x.stride(0) != C or x.stride(1) != 1:
+        raise SubgcError("bn_stats: contiguous rows needed")
+    call("subgc_bn_stats", _ptr(x), int(is_b16(x)), M, C, _ptr(gamma, torch.float32), _ptr(beta, torch.float32), _ptr(running_mean, torch.float32),
+         _ptr(running_var, torch.float32), _ptr(aff), _ptr(rstd), int(training), float(momentum), float(eps), *_ws(x), _stream())
+    return aff, rstd
+
+
+def bn_bwd_fused(dy, x, gamma, aff, rstd, dgamma, dbeta, accumulate):
+    """-> d(x) in x's storage type; dgamma / dbeta [C] written (or added to)."""
+    M, C = x.shape
+    dx = torch.empty_like(x)
+    call("subgc_bn_bwd_fused", _ptr(dy, torch.float32), _ptr(x), int(is_b16(x)), M, C, _ptr(gamma, torch.float32), _ptr(aff, torch.float32),
+         _ptr(rstd, torch.float32), _ptr(dx), int(is_b16(dx)), _ptr(dgamma, torch.float32), _ptr(dbeta, torch.float32), int(accumulate), *_ws(x), _stream())
+    return dx
+
+
+def gcn_nodes_fwd_bn(F0, F1, aff0, aff1, ptr, edges, skip, B, N, K, L, want16=False):
+    out = torch.empty(B, N, L, device=F0.device, dtype=torch.float32)
+    out16 = torch.empty(B, N, L, device=F0.device, dtype=BF16) if want16 else None
+    act = torch.empty(B, N, L, device=F0.device, dtype=torch.uint8)
+    call("subgc_gcn_nodes_fwd_bn", _ptr(F0), _ptr(F1), int(is_b16(F0)), _ptr(aff0, torch.float32), _ptr(aff1, torch.float32), _ptr(ptr), _ptr(edges),
+         _ptr(skip, torch.float32), _ptr(out), _ptr(out16), _ptr(act), B, N, K, L, _stream())
+    return out, out16, act
+
+
+def gcn_edges_fwd_bn(F2, F3, aff2, aff3, rel_ind, skip, B, N, K, L, want16=False):
+    out = torch.empty(B, K, L, device=F2.device, dtype=torch.float32)
+    out16 = torch.empty(B, K, L, device=F2.device, dtype=BF16) if want16 else None
+    call("subgc_gcn_edges_fwd_bn", _ptr(F2), _ptr(F3), int(is_b16(F2)), _ptr(aff2, torch.float32), _ptr(aff3, torch.float32), _ptr(rel_ind, torch.int64),
+         _ptr(skip, torch.float32), _ptr(out), _ptr(out16), B, N, K, L, _stream())
+    return out, out16
+
+
+def gcn_edges_bwd_bn(dP, F2, F3, aff2, aff3, ptr, edges, B, N, K, L):
+    dF2 = torch.empty(B, N, L, device=dP.device, dtype=torch.float32)
+    dF3 = torch.empty_like(dF2)
+    call("subgc_gcn_edges_bwd_bn", _ptr(dP, torch.float32), _ptr(F2), _ptr(F3), int(is_b16(F2)), _ptr(aff2, torch.float32), _ptr(aff3, torch.float32),
+         _ptr(ptr), _ptr(edges), _ptr(dF2), _ptr(dF3), B, N, K, L, _stream())
+    return dF2, dF3
+
+
 def _pool_account(denom, G, L, fwd):
     if FLOPS["on"]:                      # untimed accounting step: the valid node rows of every sub-graph (SURVEY 8d), not the padded N
         rows = float(denom[:G].sum().item())
