@@ -402,6 +402,10 @@ int subgc_gpn_prep(const int64_t* gpn_obj_ind, const float* gpn_pool_mtx, const 
 int subgc_gpn_select(const float* score, const int64_t* gpn_obj_ind, const float* att_masks, const float* read_out, int b5, int hb,
                      int N, int read_out_cols, int64_t* sel_idx, int32_t* lens, float* ro_sel, int32_t* sel,
                      int sentences_per_image, int32_t* img_s, void* stream);
+/* part[slab][c][:] = sum of the rows of X [M, L] (row stride ldx) whose class id cls[r] is c, per slab of ceil(M / slabs) rows
+ * (part: slabs * C * L floats, C <= 64): the gradient of a class-indexed table (AttModel.py:383-386: the relation embedding
+ * Emb_pred[argmax] followed by pred_emb_prj has only sg_pred_cnt = 21 distinct rows).  A column sum over the slabs finishes it. */
+int subgc_class_partials(const float* X, int64_t ldx, const int32_t* cls, int M, int L, int C, int slabs, float* part, void* stream);
 int subgc_add_n_f32(float* out, const float* a, const float* b, const float* c, const float* d, int64_t n, void* stream);
 /* x[r, c] = value over a [rows, cols] window (row stride ld): AttModel.py:148-149 `att_masks[:, :36] = 1` on the caller's tensor */
 int subgc_fill2d_f32(float* x, int64_t ld, int rows, int cols, float value, void* stream);

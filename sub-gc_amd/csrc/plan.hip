@@ -207,7 +207,47 @@ __global__ __launch_bounds__(256) void row_count_kernel(const float* __restrict_
     if (lane == 0) lens[r] = (int32_t)c;
 }
 
+// part[slab][c][col] = sum over the slab's rows r with cls[r] == c of X[r, col]   (C <= 64 classes: thread = column, the per-class
+// accumulators of a column live in LDS and are touched by that thread only)
+__global__ __launch_bounds__(256) void class_partials_kernel(const float* __restrict__ X, int64_t ldx, const int32_t* __restrict__ cls, int M, int L,
+                                                             int C, int rpb, float* __restrict__ part) {
+    extern __shared__ float acc[];                     // [C][256]
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    for (int c = 0; c < C; ++c) acc[c * 256 + threadIdx.x] = 0.f;
+    const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    if (col < L) {
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            const int c0 = cls[r], c1 = cls[r + 1], c2 = cls[r + 2], c3 = cls[r + 3];
+            const float x0 = X[(int64_t)r * ldx + col], x1 = X[(int64_t)(r + 1) * ldx + col], x2 = X[(int64_t)(r + 2) * ldx + col],
+                        x3 = X[(int64_t)(r + 3) * ldx + col];
+            if ((unsigned)c0 < (unsigned)C) acc[c0 * 256 + threadIdx.x] += x0;
+            if ((unsigned)c1 < (unsigned)C) acc[c1 * 256 + threadIdx.x] += x1;
+            if ((unsigned)c2 < (unsigned)C) acc[c2 * 256 + threadIdx.x] += x2;
+            if ((unsigned)c3 < (unsigned)C) acc[c3 * 256 + threadIdx.x] += x3;
+        }
+        for (; r < r1; ++r) {
+            const int c0 = cls[r];
+            if ((unsigned)c0 < (unsigned)C) acc[c0 * 256 + threadIdx.x] += X[(int64_t)r * ldx + col];
+        }
+        for (int c = 0; c < C; ++c) part[((int64_t)blockIdx.y * C + c) * L + col] = acc[c * 256 + threadIdx.x];
+    }
+}
+
 }  // namespace
+
+SUBGC_API int subgc_class_partials(const float* X, int64_t ldx, const int32_t* cls, int M, int L, int C, int slabs, float* part, void* stream) {
+    SUBGC_REQUIRE(M > 0 && L > 0 && C > 0 && C <= 64 && slabs > 0 && ldx >= L, "class_partials: bad sizes (at most 64 classes)");
+    SUBGC_REQUIRE(X && cls && part, "class_partials: null pointer");
+    const int rpb = (M + slabs - 1) / slabs;
+    const size_t lds = (size_t)C * 256 * sizeof(float);
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)class_partials_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        subgc::set_error("class_partials: cannot raise the dynamic LDS limit to %zu", lds);
+        return SUBGC_ELAUNCH;
+    }
+    hipLaunchKernelGGL(class_partials_kernel, dim3((L + 255) / 256, slabs), dim3(256), lds, (hipStream_t)stream, X, ldx, cls, M, L, C, rpb, part);
+    return subgc::check_launch("subgc_class_partials");
+}
 
 SUBGC_API int subgc_live_plan(const int64_t* labels, int64_t ld_labels, const float* mask, int64_t ld_mask, int S, int T, int32_t* perm32,
                               int64_t* perm64, int32_t* inv32, int32_t* counts, int32_t* offs, float* den, void* stream) {

@@ -185,6 +185,49 @@ class GatherRowsFn(Function):
         return dt, None
 
 
+class ClassTableFn(Function):
+    """Linear(Embedding[cls]) for class ids (AttModel.py:374-377, 383-386: `obj_emb_proj(sg_obj_embed(argmax))`,
+    `pred_emb_prj(sg_pred_embed(argmax))`): the projection is applied to the TABLE once -- table = Emb W^T + b, [classes, L] --
+    and the rows are looked up (1599 / 21 classes against thousands of rows); the backward sums d(out) per class and runs the
+    two small products on the table.  Same arithmetic up to summation order."""
+
+    @staticmethod
+    def forward(ctx, emb, W, b, cls):
+        C, L = emb.size(0), W.size(0)
+        table = torch.empty(C, L, device=emb.device, dtype=torch.float32)
+        ops.gemm(emb, W, table, tb=True, bias=b)
+        out = torch.empty(cls.numel(), L, device=emb.device, dtype=torch.float32)
+        ops.gather_rows(table, cls, out)
+        ctx.save_for_backward(emb, W, cls)
+        ctx.param_objs = (emb, W, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        emb, W, cls = ctx.saved_tensors
+        dev = dout.device
+        C = emb.size(0)
+        dtab = ops.class_sum(dout.contiguous(), cls, C)                      # [C, L]
+        ge, gW, gb = (_direct(p, dev) for p in ctx.param_objs)
+        demb = dW = db = None
+        if ctx.needs_input_grad[0]:
+            if ge is not None:
+                ops.gemm(dtab, W, ge, accum=True)
+            else:
+                demb = torch.empty_like(emb); ops.gemm(dtab, W, demb)
+        if ctx.needs_input_grad[1]:
+            if gW is not None:
+                ops.gemm(dtab, emb, gW, ta=True, accum=True)
+            else:
+                dW = torch.empty_like(W); ops.gemm(dtab, emb, dW, ta=True)
+        if ctx.needs_input_grad[2]:
+            if gb is not None:
+                ops.colsum(dtab, out=gb, accumulate=True)
+            else:
+                db = ops.colsum(dtab)
+        return demb, dW, db, None
+
+
 # ------------------------------------------------------------------------------- GCN
 class GcnNodesFn(Function):
     """nodes <- relations (graph_conv_unit.py:34-36 for units 0,1 + graph_conv.py:26 + residual)."""

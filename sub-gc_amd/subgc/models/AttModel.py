@@ -387,8 +387,7 @@ class AttModel(CaptionModel):
             raise ValueError(f"pred_dist has {pred_dist.size(-1)} classes, sg_pred_embed has {self.sg_pred_cnt} rows")
         if self.noun_fuse:
             cls = ops.row_argmax(obj_dist.reshape(B * N, -1), skip=1, i32=True)
-            emb = F_.GatherRowsFn.apply(self.P("sg_obj_embed.weight"), cls)
-            e = F_.linear(emb, self.P("obj_emb_proj.weight"), self.P("obj_emb_proj.bias"), **lin16("obj_emb_proj.weight"))
+            e = F_.ClassTableFn.apply(self.P("sg_obj_embed.weight"), self.P("obj_emb_proj.weight"), self.P("obj_emb_proj.bias"), cls)
             x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), add=e, relu=True, **lin16("obj_v_proj.weight"))
         else:
             x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), **lin16("obj_v_proj.weight"))
@@ -396,8 +395,7 @@ class AttModel(CaptionModel):
         p = None
         if needP[0] or self.GCN_layers == 0:
             pc = ops.row_argmax(pred_dist.reshape(B * K, -1), skip=1 if self.pred_emb_type == 1 else 0, i32=True)
-            pe = F_.GatherRowsFn.apply(self.P("sg_pred_embed.weight"), pc)
-            p = F_.linear(pe, self.P("pred_emb_prj.weight"), self.P("pred_emb_prj.bias"), **lin16("pred_emb_prj.weight")).view(B, K, L)
+            p = F_.ClassTableFn.apply(self.P("sg_pred_embed.weight"), self.P("pred_emb_prj.weight"), self.P("pred_emb_prj.bias"), pc).view(B, K, L)
         if self.GCN_layers == 0:
             return x
         rel_ind = rel_ind.contiguous()

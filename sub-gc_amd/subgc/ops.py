@@ -676,6 +676,18 @@ def gpn_select(score, gpn_obj_ind, att_masks, read_out, spi):
     return sel_idx, lens, ro_sel, img_s
 
 
+def class_sum(x, cls, C):
+    """-> [C, L]: sum of the rows of x [M, L] per class id (int32 cls [M]).  <= 64 classes: per-slab LDS accumulation + a column
+    sum over the slabs (no atomics, fixed order); more classes: scatter-add with fp32 atomics (a few rows per class)."""
+    M, L = x.shape
+    if C <= 64:
+        slabs = max(1, min(128, M // 64))
+        part = torch.empty(slabs, C * L, device=x.device, dtype=torch.float32)
+        call("subgc_class_partials", _ptr(x, torch.float32), ld(x), _ptr(cls, torch.int32), M, L, C, slabs, _ptr(part), _stream())
+        return colsum(part).view(C, L)
+    return scatter_add_rows(x, cls, zeros(C, L, device=x.device))
+
+
 def add_n(ts):
     """Fresh tensor = sum of 2..4 same-shaped contiguous fp32 tensors (one launch)."""
     ts = [t.contiguous() for t in ts]
