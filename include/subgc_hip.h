@@ -412,6 +412,25 @@ int subgc_fill2d_f32(float* x, int64_t ld, int rows, int cols, float value, void
 /* lens[r] = (int32) sum of row r of a 0/1 mask: node counts of the attention sets (AttModel.py:348-354 clip_att's mask sums) */
 int subgc_row_count_f32(const float* x, int64_t ld, int rows, int cols, int32_t* lens, void* stream);
 
+/* ======================================================================================
+ * Attention over SHARED sets (csrc/attention_group.hip): the Full-GC model attends, for each of an image's g sentences, over the same
+ * node rows (AttModel.py:140-149; the reference replicates them g = 5 times, gcn_backbone.py:50-51).  u [B*Nn, A], v [B*Nn, R] exist
+ * once per image (fp32 or bf16: bf16_bits bit 1), one workgroup per image serves all its live sentences.
+ *   rows int32 [B*g]: position of sentence j of image b in the step's row arrays (ah / ctx / alpha / dctx ... are indexed by it);
+ *   the sentence takes part iff 0 <= rows[b*g+j] < m.  lens int32 [by row]: valid nodes (<= Nn <= 128).  g <= 8.
+ *   fwd: ctx[row] (fp32 / bf16: bit 0), alpha[row, 0..n_stride).  bwd: dah[row] (fp32 / bf16: bit 0), du [B*Nn, A] += (zero it
+ *   before the first step), dw_a[row, A] / db_a[row] per-sentence partials, dctx_keep[row] (may be NULL) = this step's d(ctx) rows.
+ *   dv_accum: dv [B*Nn, R] = sum over steps t and live sentences of alpha_t[row, i] * dctx_t[row, :]; step t's rows start at
+ *   step_off[t] with step_off[t+1] - step_off[t] of them live (every row of dv is written).                                      */
+int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
+                         const int32_t* lens, int m, int B, int g, int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A,
+                         int R, int bf16_bits, void* stream);
+int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,
+                         int B, int g, int Nn, const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du,
+                         float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream);
+int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,
+                              const int32_t* rows, int B, int g, int Nn, float* dv, int R, void* stream);
+
 /* greedy / top-k token choice of one decode step (AttModel.py:295-316).
  * greedy (k == 0): it = first argmax, lp = max.  top-k: lp' = log_softmax(logp/temp), keep the
  * k largest (ties -> smaller index), renormalise, draw by inverse CDF with uniform u[s];

@@ -1,0 +1,401 @@
+// Attention kernels for SHARED attention sets: the Full-GC model (AttModel.py:140-149) attends, for every one of an image's
+// sentences, over the SAME node rows (all 36 nodes); the reference replicates the node features five times
+// (gcn_backbone.py:50-51) and so reads, projects and differentiates five identical copies.  Here the sets exist once per image
+// (v = relu(att_embed(X)) [B*Nn, R], u = ctx2att(v) [B*Nn, A]); ONE workgroup per image serves all of the image's live sentences:
+// every node row of u / v (and d(u)) is loaded once and used for up to G sentences from registers, so the step's attention traffic
+// drops ~G-fold and d(u) needs neither atomics nor a per-sentence copy.
+//   rows[b*g + j]  position of the image's j-th sentence in the step's row arrays (the packed decoder's sorted rank, or the sentence
+//                  index itself); a sentence takes part in a step iff 0 <= rows[...] < m (m = live rows of the step)
+//   lens[row]      its number of valid nodes (<= Nn, the node rows per image)
+// Same arithmetic per sentence as attention_vec.hip (softmax over the valid rows == the reference's softmax -> mask -> renormalise).
+#include "common.h"
+#include "bf16_util.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int GL = 128;     // node rows per image the grouped kernels handle (Full-GC: 37)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <bool UV16>
+__device__ __forceinline__ float4 ldx(const void* base, int64_t i) {
+    return UV16 ? subgc_load4_bf(static_cast<const uint16_t*>(base) + i) : ld4(static_cast<const float*>(base) + i);
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, float a, float4 x) { acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w; }
+
+template <int CA, int CR, bool UV16, int G>
+__global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restrict__ u, const void* __restrict__ v, const float* __restrict__ ah,
+                                                             const float* __restrict__ w_a, const float* __restrict__ b_a,
+                                                             const int32_t* __restrict__ rows, const int32_t* __restrict__ lens, int m, int g,
+                                                             int Nn, void* __restrict__ ctx, int64_t ldctx, float* __restrict__ alpha,
+                                                             int n_stride, int A, int R, int ctx_b16) {
+    __shared__ float e_s[G][GL];
+    __shared__ int row_s[G], len_s[G];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < G) {
+        const int r = t < g ? rows[b * g + t] : -1;
+        const bool live = r >= 0 && r < m;
+        row_s[t] = live ? r : -1;
+        len_s[t] = live ? min(min(lens[r], Nn), GL) : 0;
+    }
+    for (int i = t; i < G * GL; i += 256) (&e_s[0][0])[i] = 0.f;
+    __syncthreads();
+    int lmax = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) lmax = max(lmax, len_s[j]);
+    if (lmax == 0) return;
+    const int64_t m0 = (int64_t)b * Nn;
+    const int A4 = A >> 2, R4 = R >> 2;
+    // scores: wave per node; the node's u chunk is loaded once and scored against every sentence's query
+    {
+        float4 q[G][CA], w[CA];
+#pragma unroll
+        for (int c = 0; c < CA; ++c) {
+            const int a4 = lane + c * 64;
+            const bool ok = a4 < A4;
+            w[c] = ok ? ld4(w_a + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < G; ++j) q[j][c] = (ok && row_s[j] >= 0) ? ld4(ah + (int64_t)row_s[j] * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float ba = b_a[0];
+        for (int i = wave; i < lmax; i += 4) {
+            float4 x[CA];
+#pragma unroll
+            for (int c = 0; c < CA; ++c) x[c] = (lane + c * 64 < A4) ? ldx<UV16>(u, (m0 + i) * A + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (i >= len_s[j]) continue;                       // wave-uniform
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < CA; ++c)
+                    acc += w[c].x * tanhf(x[c].x + q[j][c].x) + w[c].y * tanhf(x[c].y + q[j][c].y) + w[c].z * tanhf(x[c].z + q[j][c].z) +
+                           w[c].w * tanhf(x[c].w + q[j][c].w);
+                acc = wave_sum(acc);
+                if (lane == 0) e_s[j][i] = acc + ba;
+            }
+        }
+    }
+    __syncthreads();
+    // softmax over the valid rows: wave w takes sentences w, w+4, ...; a lane holds rows lane and lane + 64
+    for (int j = wave; j < G; j += 4) {
+        const int l = len_s[j];
+        if (l == 0) continue;
+        const float e0 = lane < l ? e_s[j][lane] : -INFINITY, e1 = lane + 64 < l ? e_s[j][lane + 64] : -INFINITY;
+        const float mx = wave_max(fmaxf(e0, e1));
+        const float p0 = lane < l ? expf(e0 - mx) : 0.f, p1 = lane + 64 < l ? expf(e1 - mx) : 0.f;
+        const float den = wave_sum(p0 + p1);
+        e_s[j][lane] = p0 / den;
+        e_s[j][lane + 64] = p1 / den;
+        if (alpha) {
+            float* ar = alpha + (int64_t)row_s[j] * n_stride;
+            if (lane < n_stride) ar[lane] = p0 / den;
+            if (lane + 64 < n_stride) ar[lane + 64] = p1 / den;
+            for (int i = lane + 128; i < n_stride; i += 64) ar[i] = 0.f;
+        }
+    }
+    __syncthreads();
+    // contexts: thread = float4 column chunk; a node's v chunk is loaded once for all sentences
+#pragma unroll
+    for (int c = 0; c < CR; ++c) {
+        const int r4 = t + c * 256;
+        if (r4 >= R4) continue;
+        float4 acc[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t vp = m0 * R + r4 * 4;
+        int i = 0;
+        for (; i + 2 <= lmax; i += 2) {
+            const float4 x0 = ldx<UV16>(v, vp + (int64_t)i * R), x1 = ldx<UV16>(v, vp + (int64_t)(i + 1) * R);
+#pragma unroll
+            for (int j = 0; j < G; ++j) { fma4(acc[j], e_s[j][i], x0); fma4(acc[j], e_s[j][i + 1], x1); }
+        }
+        for (; i < lmax; ++i) {
+            const float4 x0 = ldx<UV16>(v, vp + (int64_t)i * R);
+#pragma unroll
+            for (int j = 0; j < G; ++j) fma4(acc[j], e_s[j][i], x0);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (row_s[j] < 0) continue;
+            const float o[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
+            subgc_store_act<4>(ctx, (int64_t)row_s[j] * ldctx + r4 * 4, o, ctx_b16);
+        }
+    }
+}
+
+template <int CA, int CR64, bool UV16, int G>
+__global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restrict__ u, const void* __restrict__ v, const float* __restrict__ ah,
+                                                             const float* __restrict__ w_a, const int32_t* __restrict__ rows,
+                                                             const int32_t* __restrict__ lens, int m, int g, int Nn,
+                                                             const float* __restrict__ alpha, int n_stride, const float* __restrict__ dctx,
+                                                             int64_t lddctx, void* __restrict__ dah, float* __restrict__ du,
+                                                             float* __restrict__ dw_a, float* __restrict__ db_a, int A, int R, int dah_b16,
+                                                             float* __restrict__ dctx_keep, int64_t ldkeep) {
+    __shared__ float al_s[G][GL];     // alpha, then de
+    __shared__ float da_s[G][GL];
+    __shared__ float4 part_d[G][128], part_w[G][128];
+    __shared__ int row_s[G], len_s[G];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < G) {
+        const int r = t < g ? rows[b * g + t] : -1;
+        const bool live = r >= 0 && r < m;
+        row_s[t] = live ? r : -1;
+        len_s[t] = live ? min(min(lens[r], Nn), GL) : 0;
+    }
+    __syncthreads();
+    int lmax = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) lmax = max(lmax, len_s[j]);
+    if (lmax == 0) return;
+    for (int i = t; i < G * GL; i += 256) {
+        const int j = i / GL, k = i - j * GL;
+        al_s[j][k] = (k < len_s[j]) ? alpha[(int64_t)row_s[j] * n_stride + k] : 0.f;
+        da_s[j][k] = 0.f;
+    }
+    __syncthreads();
+    const int64_t m0 = (int64_t)b * Nn;
+    const int A4 = A >> 2, R4 = R >> 2;
+    {
+        // dalpha_i = <dctx_j, v_i>: wave per node, the node's v chunks loaded once; each lane keeps its dctx chunks of every sentence
+        float4 gd[G][CR64];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int c = 0; c < CR64; ++c)
+                gd[j][c] = (row_s[j] >= 0 && lane + c * 64 < R4) ? ld4(dctx + (int64_t)row_s[j] * lddctx + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dctx_keep && wave == 0) {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int c = 0; c < CR64; ++c)
+                    if (row_s[j] >= 0 && lane + c * 64 < R4) st4(dctx_keep + (int64_t)row_s[j] * ldkeep + (lane + c * 64) * 4, gd[j][c]);
+        }
+        for (int i = wave; i < lmax; i += 4) {
+            float4 x[CR64];
+#pragma unroll
+            for (int c = 0; c < CR64; ++c) x[c] = (lane + c * 64 < R4) ? ldx<UV16>(v, (m0 + i) * R + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (i >= len_s[j]) continue;
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < CR64; ++c) acc += dot4(gd[j][c], x[c]);
+                acc = wave_sum(acc);
+                if (lane == 0) da_s[j][i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    // de_i = alpha_i (dalpha_i - sum_k alpha_k dalpha_k): wave w takes sentences w, w+4, ...
+    for (int j = wave; j < G; j += 4) {
+        if (len_s[j] == 0) continue;
+        const float a0 = al_s[j][lane], a1 = al_s[j][lane + 64], d0 = da_s[j][lane], d1 = da_s[j][lane + 64];
+        const float dot = wave_sum(a0 * d0 + a1 * d1);
+        const float e0 = a0 * (d0 - dot), e1 = a1 * (d1 - dot);
+        al_s[j][lane] = e0; al_s[j][lane + 64] = e1;
+        const float desum = wave_sum(e0 + e1);
+        if (lane == 0 && db_a) db_a[row_s[j]] = desum;
+    }
+    __syncthreads();
+    // through tanh: 2 node streams x 128 float4 chunks of the hidden dimension; u and d(u) rows are touched once for all sentences
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+        const int a4 = (t & 127) + c * 128, grp = t >> 7;
+        float4 dsum[G], wsum[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) { dsum[j] = make_float4(0.f, 0.f, 0.f, 0.f); wsum[j] = dsum[j]; }
+        if (a4 < A4) {
+            const float4 wa = ld4(w_a + a4 * 4);
+            float4 ha[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) ha[j] = row_s[j] >= 0 ? ld4(ah + (int64_t)row_s[j] * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = grp; i < lmax; i += 2) {
+                const int64_t o = (m0 + i) * A + a4 * 4;
+                const float4 x = ldx<UV16>(u, o);
+                float4 d = ld4(du + o);
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    if (i >= len_s[j]) continue;
+                    const float de = al_s[j][i];
+                    const float t0 = tanhf(x.x + ha[j].x), t1 = tanhf(x.y + ha[j].y), t2 = tanhf(x.z + ha[j].z), t3 = tanhf(x.w + ha[j].w);
+                    const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
+                    const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
+                    d.x += p0; d.y += p1; d.z += p2; d.w += p3;
+                    dsum[j].x += p0; dsum[j].y += p1; dsum[j].z += p2; dsum[j].w += p3;
+                    wsum[j].x += de * t0; wsum[j].y += de * t1; wsum[j].z += de * t2; wsum[j].w += de * t3;
+                }
+                st4(du + o, d);
+            }
+        }
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) { part_d[j][t & 127] = dsum[j]; part_w[j][t & 127] = wsum[j]; }
+        }
+        __syncthreads();
+        if (grp == 0 && a4 < A4) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (row_s[j] < 0) continue;
+                const float4 od = part_d[j][t & 127], ow = part_w[j][t & 127];
+                const float o[4] = {dsum[j].x + od.x, dsum[j].y + od.y, dsum[j].z + od.z, dsum[j].w + od.w};
+                subgc_store_act<4>(dah, (int64_t)row_s[j] * A + a4 * 4, o, dah_b16);
+                st4(dw_a + (int64_t)row_s[j] * A + a4 * 4, make_float4(wsum[j].x + ow.x, wsum[j].y + ow.y, wsum[j].z + ow.z, wsum[j].w + ow.w));
+            }
+        }
+    }
+}
+
+// d(v) of ALL time steps and ALL of the image's sentences in one pass: dv[b*Nn + i, :] = sum over (step t, sentence j live at t) of
+// alpha_t[row_j, i] * dctx_t[row_j, :].  The (t, j) pairs are staged in LDS `tg` at a time; every one of the image's Nn node rows
+// is written (zeros where nothing attends), so dv needs no zero fill.  step_off: the packed decoder's layout (step t's rows start at
+// step_off[t], step_off[t+1] - step_off[t] of them live); the unpacked one is step_off[t] = t * S.
+template <int CR64>
+__global__ __launch_bounds__(256) void attn_dv_accum_group_kernel(const float* __restrict__ alpha, int n_stride, const float* __restrict__ dctx,
+                                                                  int64_t lddctx, const int32_t* __restrict__ step_off, int T,
+                                                                  const int32_t* __restrict__ rows, int g, int Nn, float* __restrict__ dv, int R,
+                                                                  int tg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dv_lds[];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int R4 = R >> 2, l = min(Nn, n_stride);
+    float4* g_s = reinterpret_cast<float4*>(dv_lds);                      // [tg][R4]
+    float* a_s = reinterpret_cast<float*>(g_s + (size_t)tg * R4);         // [tg][n_stride]
+    bool first = true;
+    const int pairs = T * g;
+    for (int p0 = 0; p0 < pairs || first; p0 += tg) {
+        __syncthreads();
+        int nl = 0;                                                        // live pairs of this group (uniform over the workgroup)
+        for (int p = p0; p < min(pairs, p0 + tg); ++p) {
+            const int tt = p / g, j = p - tt * g;
+            const int r = rows[b * g + j], o = step_off[tt], cnt = step_off[tt + 1] - o;
+            if (r < 0 || r >= cnt) continue;
+            const int64_t flat = (int64_t)o + r;
+            for (int c = t; c < R4; c += 256) g_s[(size_t)nl * R4 + c] = ld4(dctx + flat * lddctx + c * 4);
+            for (int i = t; i < l; i += 256) a_s[nl * n_stride + i] = alpha[flat * n_stride + i];
+            ++nl;
+        }
+        __syncthreads();
+        if (nl == 0 && !first) continue;
+        for (int i = wave; i < Nn; i += 4) {
+            float4 acc[CR64];
+#pragma unroll
+            for (int c = 0; c < CR64; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < l)
+                for (int k = 0; k < nl; ++k) {
+                    const float a = a_s[k * n_stride + i];
+#pragma unroll
+                    for (int c = 0; c < CR64; ++c) {
+                        if (lane + c * 64 >= R4) continue;
+                        fma4(acc[c], a, g_s[(size_t)k * R4 + lane + c * 64]);
+                    }
+                }
+            float* dvr = dv + ((int64_t)b * Nn + i) * R;
+#pragma unroll
+            for (int c = 0; c < CR64; ++c) {
+                if (lane + c * 64 >= R4) continue;
+                if (!first) { const float4 o = ld4(dvr + (lane + c * 64) * 4); acc[c].x += o.x; acc[c].y += o.y; acc[c].z += o.z; acc[c].w += o.w; }
+                st4(dvr + (lane + c * 64) * 4, acc[c]);
+            }
+        }
+        first = false;
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+#define SUBGC_G_DISPATCH(CALL)            \
+    do {                                  \
+        if (g <= 5) { CALL(5); } else { CALL(8); } \
+    } while (0)
+
+SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
+                                   const int32_t* lens, int m, int B, int g, int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A,
+                                   int R, int bf16_bits, void* stream) {
+    const int ctx_b16 = bf16_bits & 1, uv16 = (bf16_bits >> 1) & 1;
+    SUBGC_REQUIRE(B >= 0 && g >= 1 && g <= 8 && Nn >= 1 && Nn <= GL && m >= 0 && A > 0 && R > 0 && n_stride >= 0, "attn_fwd_group: bad sizes (g <= 8, Nn <= %d)", GL);
+    if (B == 0 || m == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(u && v && ah && w_a && b_a && rows && lens && ctx, "attn_fwd_group: null pointer");
+    SUBGC_REQUIRE(A % 4 == 0 && R % 4 == 0 && ldctx % 4 == 0 && al16(u) && al16(v) && al16(ah) && al16(w_a) && al16(ctx), "attn_fwd_group: A, R %% 4 == 0 and 16-byte aligned rows");
+    const int ca = (A / 4 + 63) / 64, cr = (R / 4 + 255) / 256;
+    SUBGC_REQUIRE(ca <= 2 && cr <= 2, "attn_fwd_group: att_hid_size <= 512 and rnn_size <= 2048");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+#define SUBGC_FWD_G(G_)                                                                                                                              \
+    do {                                                                                                                                               \
+        if (uv16) { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
+        else { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
+    } while (0)
+    SUBGC_G_DISPATCH(SUBGC_FWD_G);
+#undef SUBGC_FWD_G
+    return subgc::check_launch("subgc_attn_fwd_group");
+}
+
+SUBGC_API int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,
+                                   int B, int g, int Nn, const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du,
+                                   float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream) {
+    const int dah_b16 = bf16_bits & 1, uv16 = (bf16_bits >> 1) & 1;
+    SUBGC_REQUIRE(B >= 0 && g >= 1 && g <= 8 && Nn >= 1 && Nn <= GL && m >= 0 && A > 0 && R > 0 && n_stride > 0, "attn_bwd_group: bad sizes (g <= 8, Nn <= %d)", GL);
+    if (B == 0 || m == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(u && v && ah && w_a && rows && lens && alpha && dctx && dah && du && dw_a, "attn_bwd_group: null pointer");
+    SUBGC_REQUIRE(A % 4 == 0 && R % 4 == 0 && lddctx % 4 == 0 && ldkeep % 4 == 0 && al16(u) && al16(v) && al16(ah) && al16(w_a) && al16(dctx) && al16(dah) &&
+                      al16(du) && al16(dw_a) && al16(dctx_keep), "attn_bwd_group: A, R %% 4 == 0 and 16-byte aligned rows");
+    SUBGC_REQUIRE(!dctx_keep || ldkeep >= R, "attn_bwd_group: dctx_keep rows too short");
+    const int ca = (A / 4 + 127) / 128, cr = (R / 4 + 63) / 64;
+    SUBGC_REQUIRE(ca <= 2 && cr <= 4, "attn_bwd_group: att_hid_size <= 1024 and rnn_size <= 1024");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+#define SUBGC_BWD_ARGS u, v, ah, w_a, rows, lens, m, g, Nn, alpha, n_stride, dctx, lddctx, dah, du, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep
+#define SUBGC_BWD_G(G_)                                                                                                                               \
+    do {                                                                                                                                                \
+        if (uv16) { if (ca == 1 && cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 2, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);     \
+            else if (ca == 1) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 4, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                  \
+            else if (cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<2, 2, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                  \
+            else hipLaunchKernelGGL((attn_bwd_group_kernel<2, 4, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS); }                             \
+        else { if (ca == 1 && cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 2, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);         \
+            else if (ca == 1) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 4, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                 \
+            else if (cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<2, 2, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                 \
+            else hipLaunchKernelGGL((attn_bwd_group_kernel<2, 4, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS); }                            \
+    } while (0)
+    SUBGC_G_DISPATCH(SUBGC_BWD_G);
+#undef SUBGC_BWD_G
+#undef SUBGC_BWD_ARGS
+    return subgc::check_launch("subgc_attn_bwd_group");
+}
+
+SUBGC_API int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,
+                                        const int32_t* rows, int B, int g, int Nn, float* dv, int R, void* stream) {
+    SUBGC_REQUIRE(B >= 0 && g >= 1 && g <= 8 && Nn >= 1 && R > 0 && T >= 1 && n_stride > 0 && lddctx >= R, "attn_dv_accum_group: bad sizes");
+    if (B == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(alpha && dctx && step_off && rows && dv, "attn_dv_accum_group: null pointer");
+    SUBGC_REQUIRE(R % 4 == 0 && lddctx % 4 == 0 && al16(dctx) && al16(dv), "attn_dv_accum_group: R %% 4 == 0 and 16-byte aligned rows");
+    const int cr = (R / 4 + 63) / 64;
+    SUBGC_REQUIRE(cr <= 8, "attn_dv_accum_group: rnn_size <= 2048");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    const size_t per = (size_t)R * 4 + (size_t)n_stride * 4;
+    const int tg = (int)std::max<size_t>(1, std::min<size_t>((size_t)T * g, (size_t)(144 * 1024) / per));
+    const size_t lds = (size_t)tg * per;
+#define SUBGC_DVG(CR_)                                                                                                                       \
+    do {                                                                                                                                     \
+        if (lds > 64 * 1024 &&                                                                                                               \
+            hipFuncSetAttribute((const void*)attn_dv_accum_group_kernel<CR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            subgc::set_error("attn_dv_accum_group: cannot raise the dynamic LDS limit to %zu", lds);                                         \
+            return SUBGC_ELAUNCH;                                                                                                            \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((attn_dv_accum_group_kernel<CR_>), dim3(B), dim3(256), lds, s, alpha, n_stride, dctx, lddctx, step_off, T, rows, g, Nn, dv, R, tg); \
+    } while (0)
+    if (cr <= 1) SUBGC_DVG(1); else if (cr <= 2) SUBGC_DVG(2); else if (cr <= 4) SUBGC_DVG(4); else SUBGC_DVG(8);
+#undef SUBGC_DVG
+    return subgc::check_launch("subgc_attn_dv_accum_group");
+}

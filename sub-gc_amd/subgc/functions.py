@@ -514,6 +514,91 @@ class Prepared:
         ops.gemm(self.v, c2a_w, self.u, tb=True, bias=c2a_b, m_dev=self.total)
 
 
+    # the per-step attention calls, so that the decoder Functions do not care whether the sets are per sentence or shared per image
+    shared = False
+
+    def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R):
+        ops.attn_fwd(self.u, self.v, ah, w_a, b_a, self.off, lens, ctx, alpha, m, A, R)
+
+    def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep):
+        ops.attn_bwd(self.u, self.v, ah, w_a, self.off, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep=dctx_keep)
+
+    def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
+        ops.attn_dv_accum(alpha, dctx, step_off, T, self.off, lens, dv, S, R)
+
+
+class PreparedShared(Prepared):
+    """`Prepared` for attention sets that are SHARED by the g sentences of an image (Full-GC, AttModel.py:140-149: every sentence
+    attends over all of its image's nodes; the reference replicates the node features g = 5 times, gcn_backbone.py:50-51).
+    v = relu(att_embed(X)) and u = ctx2att(v) are computed ONCE per image over all B*N node rows -- no gather, no ragged packing,
+    a fifth of the rows in the four products -- and the grouped attention kernels serve an image's sentences from one workgroup.
+    `rows` int32 [B*g]: position of every sentence in the per-step row arrays (identity, or the packed decoder's sorted rank).
+    With dropout on, the g sentences of an image share ONE keep-mask on v (the reference draws one per replicated copy): each
+    sentence's marginal distribution is unchanged, the masks are tied within the image."""
+
+    shared = True
+
+    def __init__(self, fc_in, X_nodes, lens, rows, B, g, N, P, keep_fc, keep_att, scale, W=None):
+        (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b) = P[:8]
+        dev = fc_in.device
+        S = fc_in.size(0)
+        self.S, self.N, self.B, self.g = S, N, B, g
+        self.lens, self.rows = lens, rows
+        self.total = self.off = self.src_row = None
+        MR = B * N
+        keep_att = None if keep_att is None else keep_att[:MR]
+        new = lambda r, c: torch.empty(r, c, device=dev, dtype=torch.float32)
+        if W is not None and ops.is_b16(W[0]):
+            w0, w2, wa, wc = W[0], W[2], W[4], W[6]
+            self.fc16 = ops.as_b16(fc_in)
+            self.Xg = None
+            self.Xg16 = ops.as_b16(X_nodes)
+            self.f1, self.f116 = new(S, fc0_w.size(0)), ops.empty_b16(S, fc0_w.size(0), dev)
+            ops.gemm(self.fc16, w0, self.f1, tb=True, bias=fc0_b, relu=True, out16=self.f116)
+            self.f, self.f16 = new(S, fc2_w.size(0)), ops.empty_b16(S, fc2_w.size(0), dev)
+            ops.gemm(self.f116, w2, self.f, tb=True, bias=fc2_b, relu=True, keep=keep_fc, keep_scale=scale, out16=self.f16)
+            self.v16 = ops.empty_b16(MR, att_w.size(0), dev)
+            ops.gemm(self.Xg16, wa, self.v16, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale)
+            self.v = self.v16
+            self.u = ops.empty_b16(MR, c2a_w.size(0), dev)
+            ops.gemm(self.v16, wc, self.u, tb=True, bias=c2a_b)
+            return
+        self.Xg = X_nodes
+        self.f1 = new(S, fc0_w.size(0))
+        ops.gemm(fc_in, fc0_w, self.f1, tb=True, bias=fc0_b, relu=True)
+        self.f = new(S, fc2_w.size(0))
+        ops.gemm(self.f1, fc2_w, self.f, tb=True, bias=fc2_b, relu=True, keep=keep_fc, keep_scale=scale)
+        self.v = new(MR, att_w.size(0))
+        ops.gemm(self.Xg, att_w, self.v, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale)
+        self.u = new(MR, c2a_w.size(0))
+        ops.gemm(self.v, c2a_w, self.u, tb=True, bias=c2a_b)
+
+    def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R):
+        ops.attn_fwd_group(self.u, self.v, ah, w_a, b_a, self.rows, lens, m, self.B, self.g, self.N, ctx, alpha, A, R)
+
+    def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep):
+        if dv is not None:
+            raise ops.SubgcError("shared attention sets: d(v) is always deferred to dv_accum")
+        ops.attn_bwd_group(self.u, self.v, ah, w_a, self.rows, lens, m, self.B, self.g, self.N, alpha, dctx, dah, du, dwa, dba, A, R, dctx_keep)
+
+    def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
+        ops.attn_dv_accum_group(alpha, dctx, step_off, T, self.rows, self.B, self.g, self.N, dv, R)
+
+
+def shared_sets_ok(g, N, A, R):
+    """Can the grouped attention kernels serve this shape? (csrc/attention_group.hip limits)"""
+    return 1 <= g <= 8 and N <= 128 and A % 4 == 0 and R % 4 == 0 and A <= 512 and R <= 1024
+
+
+def make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W, rows=None):
+    sh = meta.get("shared")
+    if sh is None:
+        return Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W)
+    if rows is None:
+        rows = sh["rows"]
+    return PreparedShared(fc_in, X_nodes, lens, rows, sh["B"], sh["g"], N, P, k_fc, k_att, scale, W)
+
+
 def _cat_weights(w_ih_part, w_hh):
     """[W_ih(:, cols) | W_hh] as one K-contiguous operand so a recurrent step is ONE GEMM (fp32 or bf16 like its parts)."""
     R4, a = w_ih_part.shape
@@ -540,7 +625,7 @@ class DecoderFn(Function):
         # W[i]: GEMM-operand form of parameter i -- its bf16 twin under compute_dtype = bf16 (meta["W16"]), else the parameter
         W, bf = bf16_twins(P, meta.get("W16"))
         act = lambda *shape, zero=False: ops.act_buffer(shape, dev, bf, zero)        # buffers that only GEMMs read
-        pr = Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W if bf else None)
+        pr = make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W if bf else None)
         f_op = pr.f16 if bf else pr.f
 
         # scheduled sampling (AttModel.py:157-167): meta["ss"] = (prob, sel_u [T,S], u [T,S]); the input word of step
@@ -582,7 +667,7 @@ class DecoderFn(Function):
             ops.lstm_fwd_gemm(H1[t], Wc1, pre, Gx3[t], Gf, b1i, b1h, C1[t], C1[t + 1], H2[t][:, R:2 * R], H1[t + 1][:, R:], None, 1.0, None,
                               G1[t], S, R)
             ops.gemm(H2[t][:, R:2 * R], W[17], AH[t], tb=True, bias=h2a_b)
-            ops.attn_fwd(pr.u, pr.v, AH[t], an_w, an_b, pr.off, lens, H2[t][:, :R], AL[t], S, A, R)
+            pr.attn_fwd(AH[t], an_w, an_b, lens, H2[t][:, :R], AL[t], S, A, R)
             ops.lstm_fwd_gemm(H2[t], Wc2, pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
                               None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
         if ss is None:
@@ -675,7 +760,7 @@ class DecoderFn(Function):
         dP1, dP2, dAH = act(T, S, 4 * R), act(T, S, 4 * R), act(T, S, A)
         # d(v) = sum_t alpha_t^T d(ctx_t) is formed ONCE after the loop from the kept d(ctx) rows (subgc_attn_dv_accum) instead of
         # being read and written at every step: on Full-GC (36 nodes per sentence) that was 380 of a step's 830 MB
-        defer_dv = R % 4 == 0 and A % 4 == 0 and T > 0
+        defer_dv = pr.shared or (R % 4 == 0 and A % 4 == 0 and A <= 1024 and R <= 2048 and T > 0)      # the float4 forms' limits
         du = zer(pr.u.size(0), A)
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(T, S, R) if defer_dv else None
@@ -689,16 +774,15 @@ class DecoderFn(Function):
             ops.lstm_bwd(G2[t], C2[t], C2[t + 1], nH1[:, :R], nH2[:, 2 * R:], dHout[:, t, :], None if k_out is None else k_out[t],
                          scale, nC2, dP2[t], cC2, S, R)
             ops.gemm(dP2[t], Wc2, cH2)                                     # -> [dctx | dh1 | dh2_prev]
-            ops.attn_bwd(pr.u, pr.v, AH[t], an_w, pr.off, lens, AL[t], cH2[:, :R], dAH[t], du, None if defer_dv else dv, dWa[t], dBa[t], S, A, R,
-                         dctx_keep=dCtx[t] if defer_dv else None)
+            pr.attn_bwd(AH[t], an_w, lens, AL[t], cH2[:, :R], dAH[t], du, None if defer_dv else dv, dWa[t], dBa[t], S, A, R,
+                        dCtx[t] if defer_dv else None)
             ops.gemm(dAH[t], W[17], cH2[:, R:2 * R], accum=True)           # h1 also feeds the attention query
             ops.lstm_bwd(G1[t], C1[t], C1[t + 1], cH2[:, R:2 * R], nH1[:, R:], None, None, 1.0, nC1, dP1[t], cC1, S, R)
             ops.gemm(dP1[t], Wc1, cH1)                                     # -> [dh2_prev | dh1_prev]
             dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
 
         if defer_dv:
-            ops.attn_dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), torch.arange(T + 1, device=dev, dtype=torch.int32) * S, T, pr.off, lens,
-                              dv, S, R)
+            pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), torch.arange(T + 1, device=dev, dtype=torch.int32) * S, T, lens, dv, S, R)
             del dCtx
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
         H1a, H2a = H1[:T].view(T * S, 2 * R), H2[:T].view(T * S, 3 * R)
@@ -750,8 +834,11 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
         dX = None
         if need_dX:
             dXg = new(pr.Xg16.size(0), pr.Xg16.size(1)); ops.gemm(dzv, W[4], dXg, m_dev=tot)
-            dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
-            ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
+            if pr.shared:
+                dX = dXg                                                       # the sets ARE the node rows: nothing to scatter
+            else:
+                dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
+                ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
         dz2 = ops.relu_bwd(df, pr.f, scale, bf16=True)
         wgrad(2, dz2, pr.f116)
         bgrad(3, dz2)
@@ -772,8 +859,11 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
     dX = None
     if need_dX:
         dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
-        dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
-        ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
+        if pr.shared:
+            dX = dXg
+        else:
+            dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
+            ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
     dz2 = ops.relu_bwd(df, pr.f, scale)
     wgrad(2, dz2, pr.f1)
     bgrad(3, dz2)

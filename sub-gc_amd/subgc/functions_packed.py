@@ -90,7 +90,8 @@ class PackedDecoderLossFn(Function):
         X_nodes = X_nodes.contiguous()
         W, bf = F_.bf16_twins(P, meta.get("W16"))               # GEMM-operand form of every parameter (bf16 twins under compute_dtype = bf16)
         act = lambda r, c, zero=False: ops.act_buffer((r, c), dev, bf, zero)
-        pr = F_.Prepared(fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale, W if bf else None)
+        # shared attention sets (Full-GC): sentence s = b*g + j of image b sits at sorted position inv32[s] of every step's rows
+        pr = F_.make_prepared(meta, fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale, W if bf else None, rows=plan.inv32)
 
         # scheduled sampling (AttModel.py:157-167; see functions.DecoderFn): input words, x->gates and logits go step by step
         ss = meta.get("ss")
@@ -140,7 +141,7 @@ class PackedDecoderLossFn(Function):
             ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
                               H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
             ops.gemm(H2[o:o + m, R:2 * R], W[17], AH[o:o + m], tb=True, bias=h2a_b)
-            ops.attn_fwd(pr.u, pr.v, AH[o:o + m], an_w, an_b, pr.off, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R)
+            pr.attn_fwd(AH[o:o + m], an_w, an_b, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R)
             ops.lstm_fwd_gemm(H2[o:o + m], Wc2, pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R],
                               H2[o1:o1 + mn_, 2 * R:], None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R,
                               rows_h=mn_, rows_h2=mn_)
@@ -211,7 +212,7 @@ class PackedDecoderLossFn(Function):
 
         dP1, dP2, dAH = act(max(rows, 1), 4 * R), act(max(rows, 1), 4 * R), act(max(rows, 1), A)
         # d(v) is formed once after the loop from the kept d(ctx) rows (see DecoderFn.backward)
-        defer_dv = R % 4 == 0 and A % 4 == 0 and T_live > 0
+        defer_dv = pr.shared or (R % 4 == 0 and A % 4 == 0 and A <= 1024 and R <= 2048 and T_live > 0)      # the float4 forms' limits
         du = zer(pr.u.size(0), A)
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(max(rows, 1), R) if defer_dv else None
@@ -230,8 +231,8 @@ class PackedDecoderLossFn(Function):
             ops.lstm_bwd(G2[o:o + m], C2[t][:m], C2[t + 1][:m], nH1[:m, :R], nH2[:m, 2 * R:], dHout[o:o + m],
                          None if k_out is None else k_out[t], scale, nC2[:m], dP2[o:o + m], cC2[:m], m, R)
             ops.gemm(dP2[o:o + m], Wc2, cH2[:m])
-            ops.attn_bwd(pr.u, pr.v, AH[o:o + m], an_w, pr.off, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, None if defer_dv else dv,
-                         dWa[o:o + m], dBa[o:o + m], m, A, R, dctx_keep=dCtx[o:o + m] if defer_dv else None)
+            pr.attn_bwd(AH[o:o + m], an_w, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, None if defer_dv else dv,
+                        dWa[o:o + m], dBa[o:o + m], m, A, R, dCtx[o:o + m] if defer_dv else None)
             ops.gemm(dAH[o:o + m], W[17], cH2[:m, R:2 * R], accum=True)
             ops.lstm_bwd(G1[o:o + m], C1[t][:m], C1[t + 1][:m], cH2[:m, R:2 * R], nH1[:m, R:], None, None, 1.0, nC1[:m], dP1[o:o + m],
                          cC1[:m], m, R)
@@ -245,7 +246,7 @@ class PackedDecoderLossFn(Function):
         wgrad(9, P1, H1a[:, :R], cols=(0, R))
         step_off = plan.offs                                    # int32 [T+1] on the device; steps past T_live repeat `rows`
         if defer_dv:
-            ops.attn_dv_accum(AL, dCtx, step_off, T_live, pr.off, lens_p, dv, S, R)
+            pr.dv_accum(AL, dCtx, step_off, max(T_live, 1), lens_p, dv, S, R)
             del dCtx
         dGf = new(S, 4 * R)                                     # d(fc->gates) = sum over each sentence's live steps of dP1: one launch
         ops.packed_time_sum(dP1, step_off, T_live, S, dGf)

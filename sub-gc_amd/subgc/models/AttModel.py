@@ -113,6 +113,11 @@ class AttModel(CaptionModel):
         self.bf16_storage = str(g("compute_dtype", "fp32")).lower() in ("bf16", "bfloat16")
         if self.bf16_storage and (self.rnn_size % 8 or self.input_encoding_size % 8 or self.att_hid_size % 8 or self.GCN_dim % 8):
             raise ValueError("compute_dtype=bf16 needs rnn_size, input_encoding_size, att_hid_size and gcn_dim to be multiples of 8")
+        # Full-GC only: compute the attention sets (att_embed / ctx2att over the node rows) ONCE per image and let the image's
+        # sentences share them (functions.PreparedShared) instead of the reference's x5 replication.  With dropout on this ties the
+        # att_embed keep-mask across the 5 sentences of an image (each sentence's marginal is unchanged); 0 = the reference's
+        # independent masks on replicated rows.  Not a reference option.
+        self.share_attention_sets = g("share_attention_sets", 1) != 0
         self.dropout_seed = g("seed", 2019)
         self._dropout_calls = 0
         self.injected_masks = None       # tests inject {'fc','att','xt','out','gpn_hid'} keep-masks here
@@ -493,6 +498,7 @@ class AttModel(CaptionModel):
             img_s = torch.div(torch.arange(b5, device=dev, dtype=torch.int32), spi, rounding_mode="floor").to(torch.int32).contiguous()
             ar = torch.arange(N, device=dev).view(1, N)
             hit = dict(img_s=img_s, ar_B=ar.expand(B, N).contiguous(), ar_b5=ar.expand(b5, N).contiguous(), ones=torch.ones(B, N, device=dev),
+                       rows=torch.arange(b5, device=dev, dtype=torch.int32),
                        full=torch.full((B,), float(N), device=dev), img_B=torch.arange(B, device=dev, dtype=torch.int32))
             if len(self.__dict__["_const_cache"]) > 16:
                 self.__dict__["_const_cache"].clear()
@@ -580,6 +586,9 @@ class AttModel(CaptionModel):
             sel_idx = c["ar_b5"]
             lens = ops.row_count(mask_sel)
         meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit, "plan": plan}
+        if (not self.gpn and self.share_attention_sets and self.injected_masks is None and b5 % B == 0
+                and F_.shared_sets_ok(b5 // B, N, self.att_hid_size, R)):
+            meta["shared"] = {"B": B, "g": b5 // B, "rows": c["rows"]}                    # every sentence attends over its image's N node rows
         if self.bf16_storage:
             flat16 = self.weights_b16()
             meta["W16"] = [self.W16(n, flat16) for n in F_.PARAM_ORDER]

@@ -585,6 +585,30 @@ def attn_dv_accum(alpha, dctx, step_off, T, off, lens, dv, S, R):
          _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(dv, torch.float32), S, R, _stream())
 
 
+def attn_fwd_group(u, v, ah, w_a, b_a, rows, lens, m, B, g, Nn, ctx, alpha, A, R):
+    """Attention step over per-image shared sets (subgc_attn_fwd_group): ah / ctx / alpha hold the step's rows."""
+    _attn_account_group(B, Nn, A, R, 1)
+    call("subgc_attn_fwd_group", _ptr(u), _ptr(v), _ptr(ah, torch.float32), _ptr(w_a), _ptr(b_a), _ptr(rows, torch.int32), _ptr(lens, torch.int32), int(m),
+         B, g, Nn, _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, A, R, int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), _stream())
+
+
+def attn_bwd_group(u, v, ah, w_a, rows, lens, m, B, g, Nn, alpha, dctx, dah, du, dw_a, db_a, A, R, dctx_keep):
+    _attn_account_group(B, Nn, A, R, 2)
+    call("subgc_attn_bwd_group", _ptr(u), _ptr(v), _ptr(ah, torch.float32), _ptr(w_a), _ptr(rows, torch.int32), _ptr(lens, torch.int32), int(m), B, g, Nn,
+         _ptr(alpha, torch.float32), alpha.size(1), _ptr(dctx, torch.float32), ld(dctx), _ptr(dah), _ptr(du, torch.float32), _ptr(dw_a), _ptr(db_a), A, R,
+         int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
+
+
+def attn_dv_accum_group(alpha, dctx, step_off, T, rows, B, g, Nn, dv, R):
+    call("subgc_attn_dv_accum_group", _ptr(alpha, torch.float32), alpha.size(1), _ptr(dctx, torch.float32), ld(dctx), _ptr(step_off, torch.int32), int(T),
+         _ptr(rows, torch.int32), B, g, Nn, _ptr(dv, torch.float32), R, _stream())
+
+
+def _attn_account_group(B, Nn, A, R, passes):
+    if FLOPS["on"]:                      # shared sets: every node row of u / v (and d(u)) moves once per image and step
+        FLOPS["attn_bytes"] = FLOPS.get("attn_bytes", 0.0) + 4.0 * B * Nn * (A + R) * passes
+
+
 def log_softmax_rows_(x, active=None):
     rows, V = x.shape
     call("subgc_log_softmax_rows", _ptr(x), ld(x), rows, V, _ptr(active, torch.int32), _stream())
