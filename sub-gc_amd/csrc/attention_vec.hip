@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restric
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < CA; ++c)
-            acc += w[c].x * tanhf(x[c].x + q[c].x) + w[c].y * tanhf(x[c].y + q[c].y) + w[c].z * tanhf(x[c].z + q[c].z) +
-                   w[c].w * tanhf(x[c].w + q[c].w);
+            acc += w[c].x * subgc_tanh(x[c].x + q[c].x) + w[c].y * subgc_tanh(x[c].y + q[c].y) + w[c].z * subgc_tanh(x[c].z + q[c].z) +
+                   w[c].w * subgc_tanh(x[c].w + q[c].w);
         acc = wave_sum(acc);
         if (lane == 0) e_s[i] = acc + b_a[0];
     }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
                 const float4 x = ldx<UV16>(u, o);
                 float4 d = ld4(du + o);
                 const float de = al_s[i];
-                const float t0 = tanhf(x.x + ha.x), t1 = tanhf(x.y + ha.y), t2 = tanhf(x.z + ha.z), t3 = tanhf(x.w + ha.w);
+                const float t0 = subgc_tanh(x.x + ha.x), t1 = subgc_tanh(x.y + ha.y), t2 = subgc_tanh(x.z + ha.z), t3 = subgc_tanh(x.w + ha.w);
                 const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
                 const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
                 d.x += p0; d.y += p1; d.z += p2; d.w += p3;

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int i = wave; i < l; i += 4) {                 // one wave per node: dot over A with a wave reduction
         const float* ur = u + (int64_t)(m0 + i) * A;
         float acc = 0.f;
-        for (int a = lane; a < A; a += 64) acc += w_a[a] * tanhf(ur[a] + ahs[a]);
+        for (int a = lane; a < A; a += 64) acc += w_a[a] * subgc_tanh(ur[a] + ahs[a]);
         acc = wave_sum(acc);
         if (lane == 0) e_s[i] = acc + b_a[0];
     }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         float dsum = 0.f, wsum = 0.f;
         for (int i = 0; i < l; ++i) {
             const int64_t o = (int64_t)(m0 + i) * A + a;
-            const float t = tanhf(u[o] + ha);
+            const float t = subgc_tanh(u[o] + ha);
             const float de = al_s[i];
             const float dpre = de * wa * (1.f - t * t);
             du[o] += dpre;
