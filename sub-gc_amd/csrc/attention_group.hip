@@ -250,19 +250,21 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
 }
 
 // d(v) of ALL time steps and ALL of the image's sentences in one pass: dv[b*Nn + i, :] = sum over (step t, sentence j live at t) of
-// alpha_t[row_j, i] * dctx_t[row_j, :].  The (t, j) pairs are staged in LDS `tg` at a time; every one of the image's Nn node rows
-// is written (zeros where nothing attends), so dv needs no zero fill.  step_off: the packed decoder's layout (step t's rows start at
-// step_off[t], step_off[t+1] - step_off[t] of them live); the unpacked one is step_off[t] = t * S.
-template <int CR64>
+// alpha_t[row_j, i] * dctx_t[row_j, :].  grid (B, column slices of 64 float4): a workgroup stages its 1 KB column slice of the d(ctx)
+// rows and the attention weights of up to `tg` live (t, j) pairs in LDS (all T*g = 85 pairs of Full-GC in one go), then wave = node,
+// lane = float4 column.  Every one of the image's Nn node rows is written (zeros where nothing attends), so dv needs no zero fill.
+// step_off: the packed decoder's layout (step t's rows start at step_off[t], step_off[t+1] - step_off[t] of them live); the
+// unpacked one is step_off[t] = t * S.
 __global__ __launch_bounds__(256) void attn_dv_accum_group_kernel(const float* __restrict__ alpha, int n_stride, const float* __restrict__ dctx,
                                                                   int64_t lddctx, const int32_t* __restrict__ step_off, int T,
                                                                   const int32_t* __restrict__ rows, int g, int Nn, float* __restrict__ dv, int R,
                                                                   int tg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dv_lds[];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int R4 = R >> 2, l = min(Nn, n_stride);
-    float4* g_s = reinterpret_cast<float4*>(dv_lds);                      // [tg][R4]
-    float* a_s = reinterpret_cast<float*>(g_s + (size_t)tg * R4);         // [tg][n_stride]
+    const int R4 = R >> 2, l = min(Nn, n_stride), c4 = blockIdx.y * 64 + lane;
+    const bool col_ok = c4 < R4;
+    float4* g_s = reinterpret_cast<float4*>(dv_lds);                      // [tg][64]
+    float* a_s = reinterpret_cast<float*>(g_s + (size_t)tg * 64);         // [tg][n_stride]
     bool first = true;
     const int pairs = T * g;
     for (int p0 = 0; p0 < pairs || first; p0 += tg) {
@@ -273,31 +275,22 @@ __global__ __launch_bounds__(256) void attn_dv_accum_group_kernel(const float* _
             const int r = rows[b * g + j], o = step_off[tt], cnt = step_off[tt + 1] - o;
             if (r < 0 || r >= cnt) continue;
             const int64_t flat = (int64_t)o + r;
-            for (int c = t; c < R4; c += 256) g_s[(size_t)nl * R4 + c] = ld4(dctx + flat * lddctx + c * 4);
-            for (int i = t; i < l; i += 256) a_s[nl * n_stride + i] = alpha[flat * n_stride + i];
+            if (wave == (nl & 3)) {                                        // the four waves take turns: one 1 KB row slice per wave and pair
+                g_s[(size_t)nl * 64 + lane] = col_ok ? ld4(dctx + flat * lddctx + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = lane; i < l; i += 64) a_s[nl * n_stride + i] = alpha[flat * n_stride + i];
+            }
             ++nl;
         }
         __syncthreads();
         if (nl == 0 && !first) continue;
         for (int i = wave; i < Nn; i += 4) {
-            float4 acc[CR64];
-#pragma unroll
-            for (int c = 0; c < CR64; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < l)
-                for (int k = 0; k < nl; ++k) {
-                    const float a = a_s[k * n_stride + i];
-#pragma unroll
-                    for (int c = 0; c < CR64; ++c) {
-                        if (lane + c * 64 >= R4) continue;
-                        fma4(acc[c], a, g_s[(size_t)k * R4 + lane + c * 64]);
-                    }
-                }
-            float* dvr = dv + ((int64_t)b * Nn + i) * R;
-#pragma unroll
-            for (int c = 0; c < CR64; ++c) {
-                if (lane + c * 64 >= R4) continue;
-                if (!first) { const float4 o = ld4(dvr + (lane + c * 64) * 4); acc[c].x += o.x; acc[c].y += o.y; acc[c].z += o.z; acc[c].w += o.w; }
-                st4(dvr + (lane + c * 64) * 4, acc[c]);
+                for (int k = 0; k < nl; ++k) fma4(acc, a_s[k * n_stride + i], g_s[(size_t)k * 64 + lane]);
+            if (col_ok) {
+                float* dvr = dv + ((int64_t)b * Nn + i) * R + c4 * 4;
+                if (!first) { const float4 o = ld4(dvr); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+                st4(dvr, acc);
             }
         }
         first = false;
@@ -379,23 +372,17 @@ SUBGC_API int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const 
     if (B == 0) return SUBGC_OK;
     SUBGC_REQUIRE(alpha && dctx && step_off && rows && dv, "attn_dv_accum_group: null pointer");
     SUBGC_REQUIRE(R % 4 == 0 && lddctx % 4 == 0 && al16(dctx) && al16(dv), "attn_dv_accum_group: R %% 4 == 0 and 16-byte aligned rows");
-    const int cr = (R / 4 + 63) / 64;
-    SUBGC_REQUIRE(cr <= 8, "attn_dv_accum_group: rnn_size <= 2048");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
-    const size_t per = (size_t)R * 4 + (size_t)n_stride * 4;
+    const size_t per = (size_t)64 * 16 + (size_t)n_stride * 4;
     const int tg = (int)std::max<size_t>(1, std::min<size_t>((size_t)T * g, (size_t)(144 * 1024) / per));
     const size_t lds = (size_t)tg * per;
-#define SUBGC_DVG(CR_)                                                                                                                       \
-    do {                                                                                                                                     \
-        if (lds > 64 * 1024 &&                                                                                                               \
-            hipFuncSetAttribute((const void*)attn_dv_accum_group_kernel<CR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-            subgc::set_error("attn_dv_accum_group: cannot raise the dynamic LDS limit to %zu", lds);                                         \
-            return SUBGC_ELAUNCH;                                                                                                            \
-        }                                                                                                                                    \
-        hipLaunchKernelGGL((attn_dv_accum_group_kernel<CR_>), dim3(B), dim3(256), lds, s, alpha, n_stride, dctx, lddctx, step_off, T, rows, g, Nn, dv, R, tg); \
-    } while (0)
-    if (cr <= 1) SUBGC_DVG(1); else if (cr <= 2) SUBGC_DVG(2); else if (cr <= 4) SUBGC_DVG(4); else SUBGC_DVG(8);
-#undef SUBGC_DVG
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)attn_dv_accum_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        subgc::set_error("attn_dv_accum_group: cannot raise the dynamic LDS limit to %zu", lds);
+        return SUBGC_ELAUNCH;
+    }
+    hipLaunchKernelGGL(attn_dv_accum_group_kernel, dim3(B, (R / 4 + 63) / 64), dim3(256), lds, s, alpha, n_stride, dctx, lddctx, step_off, T, rows, g, Nn,
+                       dv, R, tg);
     return subgc::check_launch("subgc_attn_dv_accum_group");
 }

@@ -80,39 +80,49 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ 
         *reinterpret_cast<float4*>(o + 2 * C) = p;
     }
 }
-struct Moments { double n, mean, m2; };
-__device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, double m2b) {
-    if (nb <= 0.0) return;
-    const double tot = a.n + nb, d = mb - a.mean;
-    a.mean += d * nb / tot;
-    a.m2 += m2b + d * d * a.n * nb / tot;
-    a.n = tot;
-}
-// grid C/64 x 256 threads: wave w merges slabs w, w+4, ...; wave 0 merges the four and writes the column's results
+// grid C/64 x 256 threads: wave w takes slabs w, w+4, ...  Two sweeps over the (L2-resident) partials, no division in the loops:
+// the batch mean from the slab means, then M2 = sum_k [M2_k + n_k (mean_k - mean)^2] (Chan's formula for many groups), in double
 __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ part, int slabs, int rpb, int M, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ aff, float* __restrict__ rstd_out, float momentum, float eps) {
-    __shared__ double sn[4][64], smean[4][64], sm2[4][64];
+    __shared__ double sacc[4][64];
+    __shared__ double smean[64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
-    Moments a{0.0, 0.0, 0.0};
+    const int n_last = M - (slabs - 1) * rpb;
+    const double inv_full = 1.0 / (double)rpb, inv_last = 1.0 / (double)n_last;
+    double acc = 0.0;
+    if (c < C)
+        for (int k = w; k < slabs; k += 4) {                               // sum_k n_k mean_k = sum_k (n_k p_k + s_k)
+            const float* o = part + (int64_t)k * 3 * C + c;
+            acc += (double)(k == slabs - 1 ? n_last : rpb) * (double)o[2 * C] + (double)o[0];
+        }
+    sacc[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) smean[lane] = (sacc[0][lane] + sacc[1][lane] + sacc[2][lane] + sacc[3][lane]) / (double)M;
+    __syncthreads();
+    const double mean = smean[lane];
+    acc = 0.0;
     if (c < C)
         for (int k = w; k < slabs; k += 4) {
-            const double n = (double)min(rpb, M - k * rpb);
             const float* o = part + (int64_t)k * 3 * C + c;
+            const bool last = k == slabs - 1;
+            const double n = last ? (double)n_last : (double)rpb, inv = last ? inv_last : inv_full;
             const double s = o[0], q = o[C], p = o[2 * C];
-            chan_merge(a, n, p + s / n, q - s * s / n);
+            const double d = p + s * inv - mean;
+            acc += (q - s * s * inv) + n * d * d;
         }
-    sn[w][lane] = a.n; smean[w][lane] = a.mean; sm2[w][lane] = a.m2;
+    __syncthreads();
+    sacc[w][lane] = acc;
     __syncthreads();
     if (w != 0 || c >= C) return;
-    for (int k = 1; k < 4; ++k) chan_merge(a, sn[k][lane], smean[k][lane], sm2[k][lane]);
-    const float mean = (float)a.mean, var_b = (float)(a.m2 / (double)M);
+    const double m2 = sacc[0][lane] + sacc[1][lane] + sacc[2][lane] + sacc[3][lane];
+    const float meanf = (float)mean, var_b = (float)(m2 / (double)M);
     const float rs = 1.f / sqrtf(var_b + eps);
-    aff[c] = mean; aff[C + c] = gamma[c] * rs; aff[2 * C + c] = beta[c];
+    aff[c] = meanf; aff[C + c] = gamma[c] * rs; aff[2 * C + c] = beta[c];
     rstd_out[c] = rs;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1 ? (float)(a.m2 / (double)(M - 1)) : var_b);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1 ? (float)(m2 / (double)(M - 1)) : var_b);
 }
 __global__ __launch_bounds__(256) void bn_eval_aff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ running_mean, const float* __restrict__ running_var,
