@@ -13,7 +13,8 @@
  *   - all pointers are BORROWED device pointers owned by the caller (e.g. tensor.data_ptr());
  *     outputs / scratch are caller-allocated; row-major, fp32 unless noted, indices int64 where
  *     the reference uses LongTensor inputs and int32 for internal index structures;
- *   - re-entrant per stream: there is NO process-global scratch or mode -- the entry points that can use a split-K scratch
+ *   - re-entrant per stream: there is NO process-global scratch, mode or tuning state (no environment variable is read; the ONE
+ *     exception is the opt-in profiling hook subgc_prof_enable / subgc_prof_collect below, a process-wide event log for bench.py) -- the entry points that can use a split-K scratch
  *     take `workspace, ws_bytes` as CALL arguments (subgc_gemm_workspace_bytes / subgc_gemm_bf16_workspace_bytes say how much
  *     a shape can use; NULL / smaller is legal), so calls on different streams only need different workspaces;
  *     subgc_last_error() returns a thread-local message for the last failing call on the calling thread;
@@ -88,6 +89,12 @@ int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* 
  *           v_mfma_f32_32x32x16_bf16 terms accumulated in fp32 (csrc/gemm_x3.h): fp32-level accuracy at 2.67x the pipe rate;
  *   BF16R   each fp32 operand is rounded to nearest-even bf16 on its way to LDS, one bf16 MFMA term (storage stays fp32;
  *           the bf16-STORAGE path of BASELINE configs 3 and 5 is subgc_gemm_bf16 below).                                   */
+/* measurement-script switches, per call like everything else (the library reads no environment variable and keeps no tunable
+ * state): keep subgc_gemm_f32 off its split-K forms / off the weight-streaming form for M <= 80; force subgc_gemm_bf16's tile */
+#define SUBGC_GEMM_NO_SPLITK (1 << 6)
+#define SUBGC_GEMM_NO_SKINNY (1 << 7)
+#define SUBGC_GEMM_TILE128 (1 << 6)
+#define SUBGC_GEMM_TILE256 (1 << 7)
 #define SUBGC_GEMM_MODE_F32 (1 << 4)
 #define SUBGC_GEMM_MODE_BF16X3 (2 << 4)
 #define SUBGC_GEMM_MODE_BF16R (3 << 4)

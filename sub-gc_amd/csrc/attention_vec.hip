@@ -1,5 +1,5 @@
 // Vectorised (float4) forms of the per-step attention kernels, used when A % 4 == 0, R % 4 == 0 and all
-// row starts are 16-byte aligned (every Sub-GC preset); decoder.hip keeps the scalar forms as fallback.
+// row starts are 16-byte aligned (every Sub-GC preset; other widths are rejected at model construction).
 //
 // One workgroup (256 threads = 4 waves) per sentence.  The sets are tiny (<= 11 nodes on Sub_GC_Kar), so
 // the kernels are latency-bound: everything is arranged so that each thread issues ALL of its loads for a

@@ -239,97 +239,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ attention step
-// one workgroup (256 threads = 4 waves) per sentence.  LDS: e/alpha [len].
+// the per-step attention kernels live in attention_vec.hip (one workgroup per sentence) and attention_group.hip (shared sets)
 constexpr int MAXLEN = 512;
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                       const float* __restrict__ ah, const float* __restrict__ w_a,
-                                                       const float* __restrict__ b_a, const int32_t* __restrict__ off,
-                                                       const int32_t* __restrict__ len, float* __restrict__ ctx, int64_t ldctx,
-                                                       float* __restrict__ alpha, int n_stride, int S, int A, int R) {
-    __shared__ float e_s[MAXLEN];
-    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l = min(len[s], MAXLEN), m0 = off[s];
-    const float* ahs = ah + (int64_t)s * A;
-    for (int i = wave; i < l; i += 4) {                 // one wave per node: dot over A with a wave reduction
-        const float* ur = u + (int64_t)(m0 + i) * A;
-        float acc = 0.f;
-        for (int a = lane; a < A; a += 64) acc += w_a[a] * subgc_tanh(ur[a] + ahs[a]);
-        acc = wave_sum(acc);
-        if (lane == 0) e_s[i] = acc + b_a[0];
-    }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int i = 0; i < l; ++i) mx = fmaxf(mx, e_s[i]);
-    float den = 0.f;
-    for (int i = 0; i < l; ++i) den += expf(e_s[i] - mx);
-    __syncthreads();
-    for (int i = threadIdx.x; i < l; i += blockDim.x) e_s[i] = expf(e_s[i] - mx) / den;
-    __syncthreads();
-    if (alpha)
-        for (int i = threadIdx.x; i < n_stride; i += blockDim.x) alpha[(int64_t)s * n_stride + i] = i < l ? e_s[i] : 0.f;
-    for (int c = threadIdx.x; c < R; c += blockDim.x) {
-        float acc = 0.f;
-        for (int i = 0; i < l; ++i) acc += e_s[i] * v[(int64_t)(m0 + i) * R + c];
-        ctx[(int64_t)s * ldctx + c] = acc;
-    }
-}
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                       const float* __restrict__ ah, const float* __restrict__ w_a,
-                                                       const int32_t* __restrict__ off, const int32_t* __restrict__ len,
-                                                       const float* __restrict__ alpha, int n_stride,
-                                                       const float* __restrict__ dctx, int64_t lddctx, float* __restrict__ dah,
-                                                       float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
-                                                       float* __restrict__ db_a, int S, int A, int R) {
-    __shared__ float al_s[MAXLEN];    // alpha, then de
-    __shared__ float da_s[MAXLEN];    // dalpha
-    __shared__ float red[16];
-    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l = min(len[s], MAXLEN), m0 = off[s];
-    const float* dc = dctx + (int64_t)s * lddctx;
-    for (int i = threadIdx.x; i < l; i += blockDim.x) al_s[i] = alpha[(int64_t)s * n_stride + i];
-    __syncthreads();
-    // dalpha_i = <dctx, v_i> ; dv_i += alpha_i dctx
-    for (int i = wave; i < l; i += 4) {
-        const float a_i = al_s[i];
-        const float* vr = v + (int64_t)(m0 + i) * R;
-        float* dvr = dv + (int64_t)(m0 + i) * R;
-        float acc = 0.f;
-        for (int c = lane; c < R; c += 64) {
-            const float g = dc[c];
-            acc += g * vr[c];
-            dvr[c] += a_i * g;
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) da_s[i] = acc;
-    }
-    __syncthreads();
-    float dot = 0.f;
-    for (int i = 0; i < l; ++i) dot += al_s[i] * da_s[i];
-    __syncthreads();
-    float desum = 0.f;
-    for (int i = threadIdx.x; i < l; i += blockDim.x) al_s[i] = al_s[i] * (da_s[i] - dot);   // de_i
-    __syncthreads();
-    for (int i = 0; i < l; ++i) desum += al_s[i];
-    if (threadIdx.x == 0 && db_a) db_a[s] = desum;
-    // through tanh: thread per hidden unit a
-    const float* ahs = ah + (int64_t)s * A;
-    for (int a = threadIdx.x; a < A; a += blockDim.x) {
-        const float wa = w_a[a], ha = ahs[a];
-        float dsum = 0.f, wsum = 0.f;
-        for (int i = 0; i < l; ++i) {
-            const int64_t o = (int64_t)(m0 + i) * A + a;
-            const float t = subgc_tanh(u[o] + ha);
-            const float de = al_s[i];
-            const float dpre = de * wa * (1.f - t * t);
-            du[o] += dpre;
-            dsum += dpre;
-            wsum += de * t;
-        }
-        dah[(int64_t)s * A + a] = dsum;
-        dw_a[(int64_t)s * A + a] = wsum;
-    }
-    (void)red;
-}
 
 // ------------------------------------------------------------------ log-softmax rows / NLL
 // the row is held in registers between its single read and its single write (PER x 256 >= V)
@@ -837,10 +748,8 @@ SUBGC_API int subgc_attn_fwd(const void* u, const void* v, const float* ah, cons
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
     if (const int rc = subgc::attn_fwd_vec(u, v, ah, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R, ctx_bf16, uv_bf16, s); rc != -100)
         return rc;
-    SUBGC_REQUIRE(!bf16_bits, "attn_fwd: bf16 node features / context need the vector form (A, R %% 4 == 0, 16-byte aligned rows)");
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(S), dim3(256), 0, s, static_cast<const float*>(u), static_cast<const float*>(v), ah, w_a, b_a, off, len,
-                       static_cast<float*>(ctx), ldctx, alpha, n_stride, S, A, R);
-    return subgc::check_launch("subgc_attn_fwd");
+    subgc::set_error("attn_fwd: needs att_hid_size, rnn_size %% 4 == 0 (<= 512 / <= 2048) and 16-byte aligned rows (A=%d R=%d)", A, R);
+    return SUBGC_EINVAL;
 }
 SUBGC_API int subgc_attn_bwd(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                              const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv,
@@ -856,12 +765,8 @@ SUBGC_API int subgc_attn_bwd(const void* u, const void* v, const float* ah, cons
                                            uv_bf16, dctx_keep, ldkeep, s);
         rc != -100)
         return rc;
-    SUBGC_REQUIRE(!bf16_bits, "attn_bwd: bf16 node features / d(query) destination need the vector form");
-    SUBGC_REQUIRE(dv && !dctx_keep, "attn_bwd: deferring d(v) (dv == NULL / dctx_keep) needs the vector form (A, R %% 4 == 0, aligned rows)");
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S), dim3(256), 0, s, static_cast<const float*>(u), static_cast<const float*>(v), ah, w_a, off, len, alpha,
-                       n_stride, dctx, lddctx, static_cast<float*>(dah), du, dv,
-                       dw_a, db_a, S, A, R);
-    return subgc::check_launch("subgc_attn_bwd");
+    subgc::set_error("attn_bwd: needs att_hid_size, rnn_size %% 4 == 0 (<= 1024 / <= 2048) and 16-byte aligned rows (A=%d R=%d)", A, R);
+    return SUBGC_EINVAL;
 }
 
 SUBGC_API int subgc_attn_dv_accum(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,

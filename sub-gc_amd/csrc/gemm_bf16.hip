@@ -8,23 +8,15 @@
 // 386,411-413,421-423,336-340,453; graph_conv_unit.py:29-30; gpn.py:54,79 and their backward), same epilogues (bias,
 // residual add, ReLU, dropout keep-mask, accumulate), results to fp32 and/or bf16.
 //
-// Workgroup: 256 threads = 4 waves in a 2x2 grid over a 128x128 tile, K in steps of 64; a wave owns 64x64 = 2x2 MFMA tiles
-// (64 accumulator registers).  LDS image of BOTH operands, whatever their memory layout: K-contiguous rows of 64 bf16
-// (128 B) whose eight 16-byte chunks are XOR-swizzled with (row >> 1) & 7 -- a ds_read_b128 fragment read (32 consecutive
-// rows, one chunk) then touches 16 distinct 16-byte slots per 16-lane group: conflict-free without padding, 16 KB per
-// operand and stage, 64 KB for two stages, two workgroups per CU.
-//   K-contiguous operand (A [M,K] / B = nn.Linear weight [N,K]): a thread moves four 16-byte chunks (8 k of one row) per
-//       K-tile, global_load_dwordx4 -> ds_write_b128; 8 lanes cover one 128-byte row.
-//   K-major operand (A^T stored [K,M] / B stored [K,N]; every weight-gradient and data-gradient product): a thread loads
-//       4 k x 8 rows as four 16-byte row segments, transposes the 4x8 block in registers (16 v_perm_b32) and writes eight
-//       ds_write_b64 (row r, 4 consecutive k); 16 lanes write the 16 eight-byte slots of one LDS row: conflict-free.
-// Fragment of v_mfma_f32_32x32x16_bf16: lane l holds row (l & 31), k = 8 * (l >> 5) .. +7 of a 16-deep step = ONE
-// ds_read_b128 (chunk 2 * step + (l >> 5)).
-//
-// Pipeline (as gemm_f32.hip's): global loads run two K-tiles ahead in one register set, which is drained into the other
-// LDS stage in the middle of a tile and refilled at once; fragments are double-buffered; one barrier per K-tile.
-// Split-K (tile count below the 512 workgroup slots): raw fp32 partial tiles to the CALLER's workspace (argument of
-// the call, not a global), summed by a reduce kernel that applies the epilogue.
+// Workgroup geometries (struct Geo below): 128x128 (4 waves of 64x64, two workgroups per CU, also the split-K form) and 256x256
+// (16 waves of 64x64, one per CU); K advances in 32-deep LDS stages.  Operand tiles travel HBM / L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) into a RING of four stages -- no VGPR staging, no ds_write; the LDS image follows each operand's
+// MEMORY layout, XOR-swizzled on the DMA's source address: K-contiguous operands are read back with ds_read_b128, K-major ones
+// with ds_read_b64_tr_b16 (hardware transpose); counted s_waitcnt vmcnt + raw s_barrier hand a stage over.  Details next to
+// Dma / FragAddr / mainloop_dma.  The accumulators hold C^T so that the epilogue stores 16-byte (fp32) / 8-byte (bf16) quads.
+// Split-K (tile count below the 512 workgroup slots): raw fp32 partial tiles to the CALLER's workspace (argument of the call,
+// not a global), summed by a reduce kernel that applies the epilogue -- or left as planes for a consumer that adds them itself
+// (subgc_lstm_fwd_gemm).
 #include "common.h"
 
 #include <algorithm>
@@ -237,13 +229,12 @@ __device__ __forceinline__ bf16x8 tr_join(unsigned long long lo, unsigned long l
     return u.v;
 }
 
+// s_waitcnt vmcnt(N) with a compile-time N (the ring waits for 0, P or 2 P outstanding DMA instructions, P = per wave and tile:
+// 4 in the 128x128 geometry, 2 in the 256x256 one)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 2 || N == 4 || N == 8, "counts used by the ring");      // P = 4 DMA instructions per wave and tile in both geometries
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <typename G, bool A_KM, bool B_KM>
@@ -534,13 +525,17 @@ inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool 
 }
 
 template <typename KernelT>
-int raise_lds(KernelT kernel, size_t lds, bool& done) {
-    if (done || lds <= 64 * 1024) return SUBGC_OK;    // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+int raise_lds(KernelT kernel, size_t lds, uint64_t& done) {
+    if (lds <= 64 * 1024) return SUBGC_OK;            // > 64 KiB of dynamic LDS needs the opt-in once per kernel AND DEVICE (bit = device index)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done & bit) return SUBGC_OK;
     if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         subgc::set_error("gemm_bf16: cannot raise dynamic LDS limit to %zu", lds);
         return SUBGC_ELAUNCH;
     }
-    done = true;
+    done |= bit;
     return SUBGC_OK;
 }
 
@@ -548,7 +543,7 @@ template <typename G, bool A_KM, bool B_KM>
 int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t s) {
     const int64_t tiles = subgc::cdiv(a.M, G::TBM) * subgc::cdiv(a.N, G::TBN);
     const int kt = (int)subgc::cdiv(a.K, BK);
-    static bool attr_a = false, attr_b = false;
+    static uint64_t attr_a = 0, attr_b = 0;
     if (splits <= 1) {
         if (int rc = raise_lds(gemm_bf16_kernel<G, A_KM, B_KM>, G::LDS, attr_a)) return rc;
         hipLaunchKernelGGL((gemm_bf16_kernel<G, A_KM, B_KM>), dim3((unsigned)tiles), dim3(G::NT), G::LDS, s, a);
@@ -569,7 +564,7 @@ template <bool A_KM, bool B_KM>
 int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out) {
     const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
                        (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias));
-    static const int force = [] { const char* e = getenv("SUBGC_BF16_TILE"); return e ? atoi(e) : 0; }();     // 128 / 256: tile A/B timing
+    const int force = (a.flags & SUBGC_GEMM_TILE128) ? 128 : (a.flags & SUBGC_GEMM_TILE256) ? 256 : 0;      // measurement scripts: tile A/B timing
     Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes, a.C32 != nullptr);
     if (partials_only) {                                        // the LSTM cell kernel adds row-major planes: 128x128 split form only
         pl = Plan{0, 1, 0.0};

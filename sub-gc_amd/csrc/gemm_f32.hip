@@ -41,6 +41,7 @@ struct GemmArgs {
     float keep_scale;
     float* ws; size_t ws_bytes;      // the caller's split-K scratch for THIS call (host-side use only)
     int xmode;                       // arithmetic of the 128x128-tile forms: 0 fp32 pipe, 1 bf16x3 split, 2 bf16 operands
+    int no_splitk;                   // SUBGC_GEMM_NO_SPLITK of this call (measurement scripts)
 };
 
 constexpr int BK = 32;
@@ -510,13 +511,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 template <typename KernelT>
-int raise_lds(KernelT kernel, size_t lds, bool& done) {
-    if (done || lds <= 64 * 1024) return SUBGC_OK;    // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+int raise_lds(KernelT kernel, size_t lds, uint64_t& done) {
+    if (lds <= 64 * 1024) return SUBGC_OK;            // > 64 KiB of dynamic LDS needs the opt-in once per kernel AND DEVICE (bit = device index)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done & bit) return SUBGC_OK;
     if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         subgc::set_error("gemm: cannot raise dynamic LDS limit to %zu", lds);
         return SUBGC_ELAUNCH;
     }
-    done = true;
+    done |= bit;
     return SUBGC_OK;
 }
 
@@ -526,16 +531,17 @@ int launch(const GemmArgs& a, hipStream_t s) {
     using SB = Stage<BN, !TB>;
     const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
-    static bool attr_set = false;
+    static uint64_t attr_set = 0;
     if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>), grid, dim3(XM ? 512 : 256), lds, s, a);
     return subgc::check_launch("subgc_gemm_f32");
 }
 
-int g_splitk = 1;            // 0 disables the split-K form (SUBGC_SPLITK=0)
-int g_smallm = 256;          // M <= this prefers the 64x64 split-K form: one 128x128 workgroup per CU is latency-bound (SUBGC_SMALLM)
-int g_ragged64 = 1;          // ragged launches use 64x64 tiles (SUBGC_RAGGED64=0 to compare)
-int g_x3 = 0;                // default arithmetic when a call names none (SUBGC_GEMM_X3): 1 = 3-way split operands on the bf16 pipe, 2 = operands rounded to bf16
+// Dispatch constants (measured).  The library reads NO environment variable and keeps no tunable state: what a
+// measurement script wants to switch off is a bit of the call's `flags` (SUBGC_GEMM_NO_SPLITK / SUBGC_GEMM_NO_SKINNY).
+constexpr int g_smallm = 256;          // M <= this prefers the 64x64 split-K form: one 128x128 workgroup per CU is latency-bound
+constexpr int g_ragged64 = 1;          // ragged launches use 64x64 tiles
+constexpr int g_x3 = 0;                // arithmetic when a call names none: the fp32 matrix pipe
 
 // pick the number of K parts for 128x128 tiles so that tiles x parts fills the 512 workgroup slots
 // (2 per CU) in whole rounds; returns 1 when splitting does not pay
@@ -559,7 +565,7 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits, bool reduce = tr
     const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     const int tiles = (int)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM));
     const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
-    static bool attr_set = false;
+    static uint64_t attr_set = 0;
     if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
     hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, a.ws, splits, per);
     if (!reduce) return subgc::check_launch("subgc_gemm_f32(split-K, partials)");   // the consumer sums the planes itself
@@ -580,6 +586,7 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     const int xm = (VEC && !a.a_rows) ? a.xmode : 0;
     float* const g_ws = a.ws;
     const size_t g_ws_bytes = a.ws_bytes;
+    const int g_splitk = a.no_splitk ? 0 : 1;
     // a ragged launch (device-side row count) is sized for the allocation; its live tiles are usually few, and one 128x128
     // workgroup alone on a CU cannot hide its own load latency: small tiles put several workgroups on every CU
     if (a.m_dev && !TA && xm == 0 && g_ragged64) return launch<64, 64, TA, TB, VEC>(a, s);
@@ -631,24 +638,16 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     SUBGC_REQUIRE(!(transA && a_rows), "gemm: a_rows needs transA == 0");
     SUBGC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "gemm: leading dimension too small");
     SUBGC_REQUIRE(!add || ldadd >= N, "gemm: ldadd too small");
-    static bool env_read = false;
-    if (!env_read) {
-        if (const char* e = getenv("SUBGC_SPLITK")) g_splitk = atoi(e);
-        if (const char* e = getenv("SUBGC_RAGGED64")) g_ragged64 = atoi(e);
-        if (const char* e = getenv("SUBGC_SMALLM")) g_smallm = atoi(e);
-        if (const char* e = getenv("SUBGC_GEMM_X3")) g_x3 = atoi(e);
-        env_read = true;
-    }
     const int mode_bits = (flags >> 4) & 3;                  // SUBGC_GEMM_MODE_*: 0 = the process default
     GemmArgs a{A, B, C, bias, add, keep, a_rows, c_rows, m_dev, lda, ldb, ldc, ldadd, M, N, K, flags & 15, keep_scale,
-               static_cast<float*>(workspace), ws_bytes, mode_bits ? mode_bits - 1 : g_x3};
+               static_cast<float*>(workspace), ws_bytes, mode_bits ? mode_bits - 1 : g_x3, (flags & SUBGC_GEMM_NO_SPLITK) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     // vector path: every staged line is read as aligned float4 and is all-in or all-out of range
     const bool vecA = aligned16(A) && lda % 4 == 0 && (transA ? M % 4 == 0 : K % 4 == 0);
     const bool vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0);
     const bool vec = vecA && vecB;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
-    if (!transA && transB && M <= 80 && vec && N >= 64 && !keep && !(flags & SUBGC_GEMM_ACCUM) && !a_rows && !c_rows && !m_dev &&
+    if (!transA && transB && M <= 80 && vec && N >= 64 && !keep && !(flags & SUBGC_GEMM_NO_SKINNY) && !(flags & SUBGC_GEMM_ACCUM) && !a_rows && !c_rows && !m_dev &&
         (!add || add != C)) {
         const int rc = subgc::gemm_skinny_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, (flags & SUBGC_GEMM_RELU) ? 1 : 0, s, add, ldadd);
         if (rc != -100) return rc;      // -100: shape not covered by the weight-streaming form
@@ -664,13 +663,13 @@ namespace subgc {
 // and split choice as subgc_gemm_f32 would make for the plain product; -100 when that choice is not the 128x128 split-K form.
 int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, int gemm_flags, float* g_ws, size_t g_ws_bytes,
                      hipStream_t s, int* splits) {
-    if (!(aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0) || !g_splitk || !g_ws || M <= g_smallm) return -100;
+    if (!(aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0) || (gemm_flags & SUBGC_GEMM_NO_SPLITK) || !g_ws || M <= g_smallm) return -100;
     const int mode_bits = (gemm_flags >> 4) & 3, xmode = mode_bits ? mode_bits - 1 : g_x3;
     const int64_t big = cdiv(M, 128) * cdiv(N, 128);
     if (big < 16 || big >= 384) return -100;
     const int sp = choose_splits((int)big, (K + BK - 1) / BK);
     if (sp <= 1 || big * sp < 200 || (size_t)sp * M * N * sizeof(float) > g_ws_bytes) return -100;
-    GemmArgs a{A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, M, N, K, 0, 1.f, g_ws, g_ws_bytes, xmode};
+    GemmArgs a{A, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, M, N, K, 0, 1.f, g_ws, g_ws_bytes, xmode, 0};
     ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
     const int rc = xmode == 1 ? launch_splitk<128, 128, false, true, true, 3>(a, s, sp, false)
                  : xmode == 2 ? launch_splitk<128, 128, false, true, true, 2>(a, s, sp, false) : launch_splitk<128, 128, false, true, true>(a, s, sp, false);

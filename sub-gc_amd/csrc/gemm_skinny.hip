@@ -172,8 +172,6 @@ namespace subgc {
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                    int relu, hipStream_t s, const float* add, int64_t ldadd) {
     if (M < 1 || M > 80) return -100;
-    static const int form = [] { const char* e = getenv("SUBGC_SKINNY"); return e ? atoi(e) : 1; }();   // 0: off (the tiled kernels take the shape)
-    if (form != 1) return -100;
     if (M > 16) {                                                 // 2..5 activation tiles, shallower ring
         const int wgs = (N + 15) / 16, mt = (M + 15) / 16;
 #define SUBGC_SKINNY_MT(MT_, D_)                                                                                                            \

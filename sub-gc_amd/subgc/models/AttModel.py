@@ -104,6 +104,8 @@ class AttModel(CaptionModel):
         self.sg_pred_cnt = _count_names(g("rel_name_path"), g("sg_pred_cnt", 21))
         if self.use_bn:
             raise NotImplementedError("use_bn != 0 (BatchNorm inside att_embed) is not on the Sub-GC presets' path")
+        if self.att_hid_size % 4 or self.rnn_size % 4 or self.att_hid_size > 512 or self.rnn_size > 2048:
+            raise ValueError("the attention kernels need att_hid_size % 4 == 0 (<= 512) and rnn_size % 4 == 0 (<= 2048)")
         if self.gpn and self.att_feat_size != 2 * self.GCN_dim:
             raise ValueError("att_feat_size must equal 2*gcn_dim: fc_embed consumes the [max|mean] read-out "
                              "(reference AttModel.py:109 with gpn.py:35-36,79)")

@@ -69,7 +69,9 @@ _CAPTURE_STREAMS = {}
 class graph_capture:
     """`with ops.graph_capture(graph, device): ...` = torch.cuda.graph on a dedicated capture stream of that device whose
     split-K workspace was allocated EAGERLY (outside any graph's private pool), so the addresses a captured GEMM bakes in stay
-    valid for every later capture and replay."""
+    valid for every later capture and replay.  All graphs captured through this class on one device share that one workspace:
+    they must not be REPLAYED concurrently on different streams (the decode paths replay them one after the other on the current
+    stream); a caller that wants concurrent replays captures on its own stream with its own `ensure_workspace`."""
 
     def __init__(self, graph, device):
         dev = torch.device(device)
@@ -116,6 +118,25 @@ def set_gemm_mode(mode):
     if mode not in GEMM_MODES:
         raise SubgcError(f"unknown GEMM mode {mode!r}")
     gemm_mode.current = mode
+
+
+class gemm_tune:
+    """Measurement-script switches of the GEMM dispatch, handed over per call in `flags` (the library keeps no tunable state):
+    `with ops.gemm_tune(no_splitk=True, no_skinny=True): ...` for subgc_gemm_f32, `tile=128|256` for subgc_gemm_bf16."""
+
+    f32_bits = 0
+    b16_bits = 0
+
+    def __init__(self, no_splitk=False, no_skinny=False, tile=0):
+        self.f32 = (64 if no_splitk else 0) | (128 if no_skinny else 0)      # SUBGC_GEMM_NO_SPLITK | SUBGC_GEMM_NO_SKINNY
+        self.b16 = {0: 0, 128: 64, 256: 128}[tile]                            # SUBGC_GEMM_TILE128 / SUBGC_GEMM_TILE256
+
+    def __enter__(self):
+        self.prev = (gemm_tune.f32_bits, gemm_tune.b16_bits)
+        gemm_tune.f32_bits, gemm_tune.b16_bits = self.f32, self.b16
+
+    def __exit__(self, *exc):
+        gemm_tune.f32_bits, gemm_tune.b16_bits = self.prev
 
 
 BF16 = torch.bfloat16
@@ -223,7 +244,7 @@ def gemm(a, b, out, *, ta=False, tb=False, bias=None, add=None, keep=None, keep_
         FLOPS["gemm_calls"] += 1
     call("subgc_gemm_f32", int(ta), int(tb), M, N, K, _ptr(a, torch.float32), ld(a), _ptr(b, torch.float32), ld(b),
          _ptr(out, torch.float32), ld(out), _ptr(bias), _ptr(add), ld(add) if add is not None else 0,
-         _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0) | GEMM_MODES[gemm_mode.current],
+         _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0) | GEMM_MODES[gemm_mode.current] | gemm_tune.f32_bits,
          _ptr(a_rows, torch.int32), _ptr(c_rows, torch.int32), _ptr(m_dev, torch.int32), *_ws(a), _stream())
     return out
 
@@ -251,7 +272,7 @@ def _gemm_b16(a, b, out, ta, tb, bias, add, keep, keep_scale, relu, accum, a_row
         FLOPS["gemm_calls"] += 1
     call("subgc_gemm_bf16", int(ta), int(tb), M, N, K, _ptr(a, BF16), ld(a), _ptr(b, BF16), ld(b), _ptr(c32, torch.float32),
          ld(c32) if c32 is not None else 0, _ptr(c16, BF16), ld(c16) if c16 is not None else 0, _ptr(bias, torch.float32), _ptr(add, torch.float32),
-         ld(add) if add is not None else 0, _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0),
+         ld(add) if add is not None else 0, _ptr(keep, torch.uint8), float(keep_scale), (RELU if relu else 0) | (ACCUM if accum else 0) | gemm_tune.b16_bits,
          _ptr(m_dev, torch.int32), *_ws(a), _stream())
     return out
 

@@ -46,7 +46,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shape", default="", help="extra shape mode,M,N,K (e.g. nt,4096,4096,8192); replaces the built-in list")
+    ap.add_argument("--mode", default="f32", choices=("f32", "bf16x3", "bf16"), help="arithmetic of the 128x128-tile forms (ops.gemm_mode)")
     a = ap.parse_args()
+    ops.set_gemm_mode(a.mode)
     global SHAPES
     if a.shape:
         SHAPES = [("custom",) + tuple(int(x) if i else x for i, x in enumerate(sh.split(","))) + (1,) for sh in a.shape.split(";")]

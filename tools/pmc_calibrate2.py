@@ -6,7 +6,7 @@ Run under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --ke
 report (tools/pmc_calibrate2_report.py) divides the counter by the bytes below.  Every buffer is larger than the 256 MiB
 Infinity Cache or touched exactly once, so nothing can be served on-die.
 
-  gemm 1 WG   : subgc_gemm_f32 NT, M = N = 64, K = 262144, SUBGC_SPLITK=0 -> ONE 64x64 workgroup (Grid_Size 256);
+  gemm 1 WG   : subgc_gemm_f32 NT, M = N = 64, K = 262144, ops.gemm_tune(no_splitk, no_skinny) -> ONE 64x64 workgroup (Grid_Size 256);
                 each operand row is read exactly once: 2 x 64 x K x 4 B = 134,217,728 B
   gemm 4 WG   : M = N = 128 -> four 64x64 workgroups on four XCDs; every operand panel is read by TWO workgroups whose L2s
                 are private: 4 x 134,217,728 = 536,870,912 B cross the fabric (268,435,456 B if the Infinity Cache dedups)
@@ -19,8 +19,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sub-gc_amd"))
-os.environ["SUBGC_SPLITK"] = "0"
-os.environ["SUBGC_SKINNY"] = "0"      # M = 64 must go to the tiled kernel, not the weight-streaming form
 import torch  # noqa: E402
 
 from subgc import ops  # noqa: E402
@@ -34,7 +32,8 @@ for M in (64, 128):
     out = torch.empty(M, M, device=dev)
     big = torch.empty(1 << 28, device=dev).normal_()          # 1 GiB of other data through L2 / MALL between the launches
     torch.cuda.synchronize()
-    ops.gemm(a, b, out, tb=True)
+    with ops.gemm_tune(no_splitk=True, no_skinny=True):        # M = 64 must go to ONE tiled workgroup, not the split-K / weight-streaming forms
+        ops.gemm(a, b, out, tb=True)
     torch.cuda.synchronize()
     del big
 n = 1 << 29                                                    # 2 GiB of fp32

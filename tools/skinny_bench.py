@@ -31,4 +31,4 @@ for i, (name, n, k) in enumerate(shapes):
     us = 1e3 * t[len(t) // 2]
     tot += us
     print(f"{name:16s} N={n:5d} K={k:5d}  {us:7.2f} us  {4e-6 * n * k / us:6.2f} TB/s")
-print(f"per step {tot:.1f} us (M={M}, form SUBGC_SKINNY={os.getenv('SUBGC_SKINNY', '1')})")
+print(f"per step {tot:.1f} us (M={M})")
