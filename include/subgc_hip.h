@@ -420,6 +420,31 @@ int subgc_fill2d_f32(float* x, int64_t ld, int rows, int cols, float value, void
 int subgc_row_count_f32(const float* x, int64_t ld, int rows, int cols, int32_t* lens, void* stream);
 
 /* ======================================================================================
+ * Greedy pick folded into the decode step's launches (csrc/gemm_skinny.hip; AttModel.py:295-319 with sample_max, <= 16 rows).
+ * `best` buffers: uint64 [16 rows][8 slots][16] (16 KB; slot (m, x) at element (m*8 + x)*16, its own 128-byte line), all zero
+ * before the logits launch that fills them.
+ *   subgc_logits_pick  -- logits = x W^T + bias WITHOUT writing them (logits may be NULL): slot (m, workgroup & 7) <- atomicMax of
+ *       (ordered logit bits << 32 | ~column): the row's arg-max with ties to the smaller column (torch.max's first max);
+ *       lse_part[(wg*16 + m)*2 + {0,1}] = (max, sum exp(. - max)) over the 16 vocabulary rows of workgroup wg (ceil(V/16) of them).
+ *   subgc_lstm_step_pick -- subgc_lstm_step_skinny whose input word of row m is that arg-max (finished rows feed 0; the word selects
+ *       row add1[word] of the per-token x->gates table); workgroup 0 files the pick of step t_prev exactly once: seq[m, t_prev],
+ *       unf_out[m] (= unf_in[m] && word > 0; word > 0 at t_prev = 0), count_out += live rows; nothing is written when *prev_count
+ *       == 0 (the reference has left its loop); `best_reset` (the other buffer) is cleared for this step's logits launch (NULL: none).
+ *   subgc_pick_file    -- that bookkeeping alone (after the last pick).
+ *   subgc_pick_lse_finish -- seqlp[m, t] = -log sum_wg sum_wg exp(max_wg - max) for every step the loop reached, from
+ *       lse_part [T][ceil(V/16)][16][2]: one pass after the loop instead of a vocabulary reduction per step.                      */
+int subgc_logits_pick(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
+                      int64_t ldl, uint64_t* best, float* lse_part, void* stream);
+int subgc_lstm_step_pick(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
+                         int64_t ld1, int tok_rows, const float* add2, int64_t ld2, const float* b0, const float* b1,
+                         const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2,
+                         const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int T, int t_prev,
+                         int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, void* stream);
+int subgc_pick_file(const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int S, int T, int t_prev,
+                    int32_t* count_out, const int32_t* prev_count, void* stream);
+int subgc_pick_lse_finish(const float* lse_part, int V, int S, int T, const int32_t* counts, float* seqlp, void* stream);
+
+/* ======================================================================================
  * Attention over SHARED sets (csrc/attention_group.hip): the Full-GC model attends, for each of an image's g sentences, over the same
  * node rows (AttModel.py:140-149; the reference replicates them g = 5 times, gcn_backbone.py:50-51).  u [B*Nn, A], v [B*Nn, R] exist
  * once per image (fp32 or bf16: bf16_bits bit 1), one workgroup per image serves all its live sentences.

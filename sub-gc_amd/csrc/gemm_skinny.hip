@@ -37,6 +37,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // decode step needs no separate pointwise kernel and the [S, 4R] pre-activations never reach memory.  The additive gate
 // terms (a per-token table row or a plain [S,4R] array, a second [S,4R] array, two bias vectors) and c_prev are fetched
 // by wave mt (< MT) BEFORE the K loop, so their latency hides behind the weight stream.
+// Greedy pick folded into the step's launches (AttModel.py:295-316 with sample_max).  The logits launch leaves, per decode row, the
+// packed arg-max (ordered logit bits << 32 | ~column: ties -> smaller column = torch.max's first max) by 64-bit atomicMax -- into ONE
+// OF EIGHT slots per row (slot = workgroup & 7, i.e. its XCD; every slot on its own 128-byte line): 593 workgroups hammering one
+// address per row measured +5 us on the 10 us launch (device-scope atomics queue memory-side), 74 per slot do not; reducing plain
+// per-workgroup partials in the consumer instead costs it 24 MB of extra reads (+6 us).  It also leaves per-workgroup (max, sum exp)
+// partials for the log-prob, which nothing needs before the loop ends.  The NEXT step's attention-LSTM launch merges the eight slots
+// into the input word (finished rows feed 0) and its workgroup 0 does the reference's bookkeeping exactly once: seq[:, t], the
+// unfinished flags, the live count that drives the early break (AttModel.py:318-319).  No pick launch, no [n, V+1] logits in memory.
+constexpr int PICK_SLOTS = 8, PICK_LINE = 16;                               // uint64 per 128-byte line; slot (m, x) at (m * 8 + x) * 16
+struct PickIn {
+    const unsigned long long* best;     // [16 rows][8 slots][16] of the previous step's logits launch; NULL = token ids come from LstmEpi::tok
+    const int32_t* unf_in; int32_t* unf_out;
+    int64_t* seq; int T; int t_prev;    // seq[m * T + t_prev] <- word
+    int32_t* count_out;                 // live rows after step t_prev (pre-zeroed, accumulated)
+    const int32_t* prev_count;          // live rows after step t_prev - 1 (NULL at t_prev = 0): 0 = the loop has ended, write nothing
+    unsigned long long* best_reset;     // the other buffer, cleared for this step's logits launch (NULL: none follows)
+};
 struct LstmEpi {
     const float* add1; int64_t ld1; const int64_t* tok; int tok_rows;       // add1 row = tok ? clamp(tok[m]) : m
     const float* add2; int64_t ld2;
@@ -44,18 +61,34 @@ struct LstmEpi {
     const float* c_prev; float* c;
     float* h0; int64_t ldh0; float* h1; int64_t ldh1; float* h2; int64_t ldh2;
     int R;
+    PickIn pk;
 };
+struct PickOut { unsigned long long* best; float* lse_part; };              // logits launch: slots as above, [workgroups][16][2] partials
+
+__device__ __forceinline__ uint32_t ordered_bits(float f) {                 // monotone float -> uint32
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ int picked_word(const PickIn& pk, int m, bool& unf) {
+    unsigned long long b = 0ull;
+#pragma unroll
+    for (int x = 0; x < PICK_SLOTS; ++x) { const unsigned long long v = pk.best[(m * PICK_SLOTS + x) * PICK_LINE]; b = v > b ? v : b; }
+    const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(b & 0xFFFFFFFFull);
+    unf = idx > 0u && (pk.t_prev == 0 || pk.unf_in[m] != 0);
+    return unf ? (int)idx : 0;
+}
 
 // MT > 1: the same stream against MT 16-row activation tiles (M <= 16*MT: the one-image encoder GEMMs, 37 node / 65 relation
 // rows) -- one W load, MT activation loads and 4*MT MFMAs per step; `add` [M,N] is an optional residual term of the epilogue.
-template <int WAVES, int D, bool LSTM, int MT>
+template <int WAVES, int D, bool LSTM, int MT, bool PICK = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                                       int64_t ldb, float* __restrict__ C, int64_t ldc,
                                                                       const float* __restrict__ bias, int M, int N, int K, int relu,
-                                                                      LstmEpi ep, const float* __restrict__ add, int64_t ldadd) {
+                                                                      LstmEpi ep, const float* __restrict__ add, int64_t ldadd, PickOut po = PickOut{}) {
     static_assert(!LSTM || MT <= 2, "the fused cell update handles up to two 16-row activation tiles (wave mt owns tile mt)");
+    static_assert(!PICK || (!LSTM && MT == 1), "the arg-max epilogue belongs to the plain one-tile form (the logits launch)");
     __shared__ float part[WAVES][MT * 256];
-    __shared__ float tile[LSTM ? 256 * MT : 1];
+    __shared__ float tile[(LSTM || PICK) ? 256 * MT : 1];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: uniform loop control
     const int r16 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -73,9 +106,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
     float gadd[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;                        // LSTM: wave mt < MT, lane (u = lane/16, m = 16*mt + lane%16)
     const int eu = lane >> 4, em = wave * 16 + (lane & 15), ej = blockIdx.x * 4 + eu;
     const bool elive = LSTM && wave < MT && em < M && ej < ep.R;
+    if (LSTM && ep.pk.best && blockIdx.x == 0 && t < 128) {                   // the previous step's pick, filed once (workgroup 0)
+        if (ep.pk.best_reset) ep.pk.best_reset[t * PICK_LINE] = 0ull;
+        if (t < M) {
+            bool unf;
+            const int w = picked_word(ep.pk, t, unf);
+            const bool alive = !(ep.pk.prev_count && *ep.pk.prev_count == 0);
+            if (alive) {
+                ep.pk.seq[(int64_t)t * ep.pk.T + ep.pk.t_prev] = w;
+                if (unf) atomicAdd(ep.pk.count_out, 1);
+            }
+            ep.pk.unf_out[t] = alive && unf;
+        }
+    }
     if (elive) {
         int64_t row1 = em;
-        if (ep.tok) { const int64_t w = ep.tok[em]; row1 = w < 0 ? 0 : (w >= ep.tok_rows ? ep.tok_rows - 1 : w); }
+        if (ep.pk.best) { bool unf; const int w = picked_word(ep.pk, em, unf); row1 = w >= ep.tok_rows ? ep.tok_rows - 1 : w; }
+        else if (ep.tok) { const int64_t w = ep.tok[em]; row1 = w < 0 ? 0 : (w >= ep.tok_rows ? ep.tok_rows - 1 : w); }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = g * ep.R + ej;
@@ -143,11 +190,48 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
         for (int w = 0; w < WAVES; ++w) sum += part[w][e];
         const int n = n0 + 4 * (l >> 4) + v, m = mt * 16 + (l & 15);
         if (LSTM) tile[(4 * (l >> 4) + v) * (16 * MT) + m] = sum;             // row 4*g + u of this workgroup, column m
-        else if (m < M && n < N) {
+        else if (PICK) {
+            // (e == t < 256 here: waves 0..3, all lanes.)  Online (max, arg, sum exp) merge: two shuffles fold the four lanes that
+            // hold a decode row inside this wave, the four waves' results meet in LDS -- a short chain instead of a 16-step scan
+            const float o = n < N ? sum + (bias ? bias[n] : 0.f) : -INFINITY;
+            if (C && m < M && n < N) C[(int64_t)m * ldc + n] = o;
+            float mx = o, se = n < N ? 1.f : 0.f;
+            int arg = n;
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float om = __shfl_xor(mx, off, 64), os = __shfl_xor(se, off, 64);
+                const int oa = __shfl_xor(arg, off, 64);
+                const float big = fmaxf(mx, om);
+                se = big == -INFINITY ? 0.f : se * __expf(mx - big) + os * __expf(om - big);
+                if (om > mx || (om == mx && oa < arg)) arg = oa;
+                mx = big;
+            }
+            if (l < 16) { tile[(v * 16 + l) * 4] = mx; tile[(v * 16 + l) * 4 + 1] = se; tile[(v * 16 + l) * 4 + 2] = __int_as_float(arg); }
+        } else if (m < M && n < N) {
             float o = sum + (bias ? bias[n] : 0.f);
             if (add) o += add[(int64_t)m * ldadd + n];
             if (relu) o = fmaxf(o, 0.f);
             C[(int64_t)m * ldc + n] = o;
+        }
+    }
+    if (PICK) {
+        __syncthreads();
+        if (t < M) {                                                          // thread = decode row: merge the four waves' results
+            float mx = tile[t * 4], se = tile[t * 4 + 1];
+            int arg = __float_as_int(tile[t * 4 + 2]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float om = tile[(w * 16 + t) * 4], os = tile[(w * 16 + t) * 4 + 1];
+                const int oa = __float_as_int(tile[(w * 16 + t) * 4 + 2]);
+                const float big = fmaxf(mx, om);
+                se = big == -INFINITY ? 0.f : se * __expf(mx - big) + os * __expf(om - big);
+                if (om > mx || (om == mx && oa < arg)) arg = oa;
+                mx = big;
+            }
+            atomicMax(po.best + (t * PICK_SLOTS + (blockIdx.x & (PICK_SLOTS - 1))) * PICK_LINE,
+                      ((unsigned long long)ordered_bits(mx) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)arg));
+            float* lp = po.lse_part + ((int64_t)blockIdx.x * 16 + t) * 2;
+            lp[0] = mx; lp[1] = se;
         }
     }
     if (LSTM) {
@@ -211,11 +295,101 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w
     SUBGC_REQUIRE(!tok || (add1 && tok_rows > 0), "lstm_step_skinny: tok needs a table in add1");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
-    LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R};
+    LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, PickIn{}};
     const int N = 4 * R, wgs = N / 16;
     if (S > 16)                                                                // two activation tiles (beam search: <= 10 sub-graphs x 2-3 beams)
         hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 2>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
     else
         hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
     return subgc::check_launch("subgc_lstm_step_skinny");
+}
+
+// ---- C ABI: the greedy pick folded into the decode step's launches (see PickIn above) ------------------------------------------
+// `best` buffers: 16 rows x 8 slots x 16 uint64 (16 KB), zero before the logits launch that fills them.
+// subgc_lstm_step_pick: subgc_lstm_step_skinny whose input word of row m is the arg-max `best_prev` that the previous step's
+//   subgc_logits_pick left (finished rows feed word 0; the table row add1[word] is the x->gates term); workgroup 0 files that pick:
+//   seq[m, t_prev], unf_out[m], counts[t_prev], and clears `best_reset` (the other buffer) for this step's logits launch.  S <= 16.
+SUBGC_API int subgc_lstm_step_pick(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
+                                   int64_t ld1, int tok_rows, const float* add2, int64_t ld2, const float* b0, const float* b1,
+                                   const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2,
+                                   const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int T, int t_prev,
+                                   int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, void* stream) {
+    SUBGC_REQUIRE(S >= 1 && S <= 16 && R > 0 && R % 4 == 0 && K > 0 && K % 4 == 0, "lstm_step_pick: need 1 <= S <= 16, R % 4 == 0, K % 4 == 0");
+    SUBGC_REQUIRE(x && w_perm && c && (h0 || h1 || h2) && add1 && tok_rows > 0, "lstm_step_pick: null pointer");
+    SUBGC_REQUIRE(best_prev && unf_out && seq && count_out && t_prev >= 0 && t_prev < T && (t_prev == 0 || unf_in), "lstm_step_pick: pick arguments");
+    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % 16) == 0,
+                  "lstm_step_pick: x / w_perm rows must be 16-byte aligned float4 rows");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
+    PickIn pk{reinterpret_cast<const unsigned long long*>(best_prev), unf_in, unf_out, seq, T, t_prev, count_out, prev_count,
+              reinterpret_cast<unsigned long long*>(best_reset)};
+    LstmEpi ep{add1, ld1, nullptr, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, pk};
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1>), dim3(4 * R / 16), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, 4 * R, K, 0, ep,
+                       nullptr, 0, PickOut{});
+    return subgc::check_launch("subgc_lstm_step_pick");
+}
+
+// subgc_logits_pick: logits = x W^T + bias for S <= 16 rows WITHOUT writing them (logits may be NULL): `best` slots <- packed arg-max
+//   (64-bit atomicMax; zero before the launch), lse_part[(wg * 16 + m) * 2 + {0, 1}] = (max, sum exp(. - max)) over the 16 vocabulary
+//   rows of workgroup wg = 0 .. ceil(V/16)-1.
+SUBGC_API int subgc_logits_pick(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
+                                int64_t ldl, uint64_t* best, float* lse_part, void* stream) {
+    SUBGC_REQUIRE(S >= 1 && S <= 16 && V > 0 && K > 0 && K % 4 == 0, "logits_pick: need 1 <= S <= 16 and K % 4 == 0");
+    SUBGC_REQUIRE(x && W && best && lse_part && (!logits || ldl >= V), "logits_pick: null pointer");
+    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0,
+                  "logits_pick: x / W rows must be 16-byte aligned float4 rows");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * (double)V * K);
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, true>), dim3((V + 15) / 16), dim3(512), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
+                       LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
+    return subgc::check_launch("subgc_logits_pick");
+}
+
+namespace {
+__global__ __launch_bounds__(64) void pick_file_kernel(PickIn pk, int M) {
+    const int t = threadIdx.x;
+    if (t >= M) return;
+    bool unf;
+    const int w = picked_word(pk, t, unf);
+    const bool alive = !(pk.prev_count && *pk.prev_count == 0);
+    if (alive) {
+        pk.seq[(int64_t)t * pk.T + pk.t_prev] = w;
+        if (unf) atomicAdd(pk.count_out, 1);
+    }
+    pk.unf_out[t] = alive && unf;
+}
+// seqlp[m, t] = log_softmax(logits_t[m])[argmax] = -log sum_wg sum_wg * exp(max_wg - max) for every step the loop reached
+__global__ __launch_bounds__(256) void pick_lse_finish_kernel(const float* __restrict__ lse_part, int wgs, int S, int T, const int32_t* __restrict__ counts,
+                                                              float* __restrict__ seqlp) {
+    __shared__ float sm[16];
+    const int t = blockIdx.x, m = blockIdx.y;
+    if (t > 0 && counts[t - 1] == 0) return;                       // the reference has left its loop (AttModel.py:318-319)
+    const float* p = lse_part + (int64_t)t * wgs * 32 + m * 2;
+    float mx = -INFINITY;
+    for (int w = threadIdx.x; w < wgs; w += 256) mx = fmaxf(mx, p[(int64_t)w * 32]);
+    mx = block_max(mx, sm);
+    float sum = 0.f;
+    for (int w = threadIdx.x; w < wgs; w += 256) sum += p[(int64_t)w * 32 + 1] * expf(p[(int64_t)w * 32] - mx);
+    sum = block_sum(sum, sm);
+    if (threadIdx.x == 0) seqlp[(int64_t)m * T + t] = -logf(sum);
+}
+}  // namespace
+
+// subgc_pick_file: the bookkeeping of subgc_lstm_step_pick alone (the LAST pick of a loop has no following LSTM launch)
+SUBGC_API int subgc_pick_file(const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int S, int T, int t_prev,
+                              int32_t* count_out, const int32_t* prev_count, void* stream) {
+    SUBGC_REQUIRE(S >= 1 && S <= 16 && t_prev >= 0 && t_prev < T, "pick_file: bad sizes");
+    SUBGC_REQUIRE(best_prev && unf_out && seq && count_out && (t_prev == 0 || unf_in), "pick_file: null pointer");
+    PickIn pk{reinterpret_cast<const unsigned long long*>(best_prev), unf_in, unf_out, seq, T, t_prev, count_out, prev_count, nullptr};
+    hipLaunchKernelGGL(pick_file_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pk, S);
+    return subgc::check_launch("subgc_pick_file");
+}
+
+// subgc_pick_lse_finish: after the token loop, the log-probabilities of the T picks from the per-step partials
+//   lse_part [T][ceil(V/16)][16][2] (one pass instead of a log-softmax reduction inside every step).
+SUBGC_API int subgc_pick_lse_finish(const float* lse_part, int V, int S, int T, const int32_t* counts, float* seqlp, void* stream) {
+    SUBGC_REQUIRE(V > 0 && S >= 1 && S <= 16 && T >= 1, "pick_lse_finish: bad sizes");
+    SUBGC_REQUIRE(lse_part && counts && seqlp, "pick_lse_finish: null pointer");
+    hipLaunchKernelGGL(pick_lse_finish_kernel, dim3(T, S), dim3(256), 0, (hipStream_t)stream, lse_part, (V + 15) / 16, S, T, counts, seqlp);
+    return subgc::check_launch("subgc_pick_lse_finish");
 }

@@ -971,6 +971,48 @@ class DecodeState:
             ops.log_softmax_rows_(self.logits)
         return self.logits
 
+    def greedy_loop(self, T, seq, seqlp, counts, AL, it0):
+        """The whole greedy token loop (AttModel.py:282-319 with sample_max) for <= 16 rows on the fused state, with the PICK folded
+        into the step's launches: the logits launch leaves the packed arg-max and log-sum-exp partials (subgc_logits_pick), the next
+        step's attention-LSTM launch reads its input word from there and files seq / unfinished / the live count
+        (subgc_lstm_step_pick), the log-probabilities are formed once after the loop (subgc_pick_lse_finish).  Five launches per
+        token (att-LSTM, h2att, attention, lang-LSTM, logits) instead of six, no [n, V+1] logits in memory; the last core step, whose
+        logits the reference never reads, runs only as far as its attention weights are wanted (`AL`).
+        seq [S,T] / counts [T] zeroed by the caller, `it0` = S zeros (the <bos> input of step 0)."""
+        if not (self.fused and self.xt_table is not None and self.S <= 16):
+            raise ops.SubgcError("greedy_loop needs the fused decode state with the x->gates table and <= 16 rows")
+        S, R, A, V1 = self.S, self.R, self.A, self.V1
+        pr, dev = self.pr, self.H1.device
+        if getattr(self, "_pick", None) is None or self._pick[2].size(0) != T:
+            self._pick = (torch.zeros(2, ops.PICK_BEST_ELEMS, device=dev, dtype=torch.int64), torch.zeros(2, S, device=dev, dtype=torch.int32),
+                          torch.empty(T, (V1 + 15) // 16, 16, 2, device=dev, dtype=torch.float32))
+        best, unf, lse = self._pick
+        best.zero_()
+        for t in range(T + 1):
+            last = t == T
+            hs = [self.H2[:, R:2 * R], self.H1n[:, R:]]
+            if t == 0:
+                ops.lstm_step_skinny(self.H1, self.Wc1, self.C1[0], self.C1[1], hs, self.b1i, self.b1h, self.xt_table, it0, self.Gf)
+            else:
+                pick = (best[(t - 1) & 1], unf[(t - 2) & 1] if t >= 2 else None, unf[(t - 1) & 1], seq, t - 1, counts[t - 1:t],
+                        counts[t - 2:t - 1] if t >= 2 else None)
+                if last and AL is None:
+                    ops.pick_file(*pick)
+                    break
+                ops.lstm_step_pick(self.H1, self.Wc1, self.C1[0], self.C1[1], hs, self.b1i, self.b1h, self.xt_table, self.Gf, *pick,
+                                   None if last else best[t & 1])
+            self.C1.reverse()
+            ops.gemm(self.H2[:, R:2 * R], self.h2a_w, self.ah, tb=True, bias=self.h2a_b)
+            ops.attn_fwd(pr.u, pr.v, self.ah, self.an_w, self.an_b, pr.off, pr.lens, self.H2[:, :R], None if AL is None else AL[t], S, A, R)
+            if last:
+                break
+            ops.lstm_step_skinny(self.H2, self.Wc2, self.C2[0], self.C2[1], [self.H1n[:, :R], self.H2n[:, 2 * R:], self.hout], self.b2i, self.b2h)
+            self.C2.reverse()
+            self.H1, self.H1n = self.H1n, self.H1
+            self.H2, self.H2n = self.H2n, self.H2
+            ops.logits_pick(self.hout, self.lg_w, self.lg_b, best[t & 1], lse[t])
+        ops.pick_lse_finish(lse, V1, counts, seqlp)
+
     def step(self, it, alpha_out, normalize=True):
         if self.fused:
             return self._step_fused(it, alpha_out, normalize)

@@ -213,6 +213,10 @@ class _GraphedLoop:
         self.st.reset()
         for b in (self.seq, self.seqlp, self.it, self.unfinished, self.counts) + ((self.AL,) if self.AL is not None else ()):
             b.zero_()
+        if self.k == 0 and self.st.fused and self.st.xt_table is not None and getattr(self.m, "decode_fused_pick", True):
+            # greedy: the pick rides in the logits / attention-LSTM launches (functions.DecodeState.greedy_loop)
+            self.st.greedy_loop(T, self.seq, self.seqlp, self.counts, self.AL, self.it)
+            return
         for t in range(T + 1):
             logp = self.st.step(self.it, self.AL[t] if self.return_att else None, normalize=False)
             if t == T:

@@ -522,6 +522,41 @@ def lstm_step_skinny(x, w_perm, c_prev, c, hs, b0=None, b1=None, add1=None, tok=
          _ptr(c_prev, torch.float32), _ptr(c, torch.float32), *hp, _stream())
 
 
+PICK_BEST_ELEMS = 16 * 8 * 16       # uint64 slots of one `best` buffer of the fused greedy pick (subgc_hip.h)
+
+
+def logits_pick(x, W, bias, best, lse_part, logits=None):
+    """Logits launch of a greedy decode step with the arg-max / log-sum-exp partials in its epilogue (subgc_logits_pick)."""
+    S, K = x.shape
+    V = W.size(0)
+    call("subgc_logits_pick", _ptr(x, torch.float32), ld(x), _ptr(W, torch.float32), ld(W), _ptr(bias, torch.float32), S, V, K, _ptr(logits),
+         ld(logits) if logits is not None else 0, _ptr(best, torch.int64), _ptr(lse_part, torch.float32), _stream())
+
+
+def lstm_step_pick(x, w_perm, c_prev, c, hs, b0, b1, table, add2, best_prev, unf_in, unf_out, seq, t_prev, count_out, prev_count, best_reset):
+    """lstm_step_skinny fed by the previous step's fused arg-max (subgc_lstm_step_pick)."""
+    S, K = x.shape
+    R = c.size(1)
+    hs = list(hs) + [None] * (3 - len(hs))
+    hp = []
+    for h_ in hs:
+        hp += [_ptr(h_, torch.float32), ld(h_) if h_ is not None else 0]
+    call("subgc_lstm_step_pick", _ptr(x, torch.float32), ld(x), _ptr(w_perm, torch.float32), ld(w_perm), K, S, R, _ptr(table, torch.float32), ld(table),
+         table.size(0), _ptr(add2, torch.float32), ld(add2) if add2 is not None else 0, _ptr(b0, torch.float32), _ptr(b1, torch.float32),
+         _ptr(c_prev, torch.float32), _ptr(c, torch.float32), *hp, _ptr(best_prev, torch.int64), _ptr(unf_in, torch.int32), _ptr(unf_out, torch.int32),
+         _ptr(seq, torch.int64), seq.size(1), int(t_prev), _ptr(count_out, torch.int32), _ptr(prev_count, torch.int32), _ptr(best_reset, torch.int64), _stream())
+
+
+def pick_file(best_prev, unf_in, unf_out, seq, t_prev, count_out, prev_count):
+    call("subgc_pick_file", _ptr(best_prev, torch.int64), _ptr(unf_in, torch.int32), _ptr(unf_out, torch.int32), _ptr(seq, torch.int64), seq.size(0),
+         seq.size(1), int(t_prev), _ptr(count_out, torch.int32), _ptr(prev_count, torch.int32), _stream())
+
+
+def pick_lse_finish(lse_part, V, counts, seqlp):
+    S, T = seqlp.shape
+    call("subgc_pick_lse_finish", _ptr(lse_part, torch.float32), int(V), S, T, _ptr(counts, torch.int32), _ptr(seqlp, torch.float32), _stream())
+
+
 def embed_bwd(table, tok, tok_stride, keep, scale, dout, dtable):
     n, E = dout.shape
     call("subgc_embed_bwd", _ptr(table), _ptr(tok, torch.int64), tok_stride, _ptr(keep, torch.uint8), float(scale), _ptr(dout),

@@ -258,3 +258,32 @@ def test_decode_after_the_fused_optimizer_step_uses_the_new_weights(golden, opt_
     assert torch.equal(again[0], fresh[0])
     torch.testing.assert_close(again[1], fresh[1], atol=1e-5, rtol=1e-5)
     assert not torch.allclose(first[1], again[1])
+
+
+@pytest.mark.parametrize("return_att", [0, 1])
+def test_greedy_pick_folded_into_the_step_launches_equals_the_separate_pick(golden, return_att):
+    """One-image greedy decode with the pick in the logits / attention-LSTM launches (DecodeState.greedy_loop: packed 64-bit arg-max,
+    lazy log-sum-exp) against the same replayed loop with the separate subgc_decode_pick launch: tokens, kept sub-graphs and attention
+    weights identical, log-probs to fp32 rounding; includes rows that finish early and images whose loop breaks before T."""
+    g = golden("subgc_greedy")
+    w = golden("subgc_beam").group("weights")
+    w["logit.bias"][0] += 1.5                                      # <eos> wins early for some rows: finished-row masking and the early break
+    opt = g.meta["opt"]
+    N, K = g.tensors("inputs")["att_feats"].size(1), g.tensors("inputs")["rel_ind"].size(1)
+    ma, mb = build(g, w, False, gpn_nms_thres=0.55, gpn_max_subg=6), build(g, w, False, gpn_nms_thres=0.55, gpn_max_subg=6)
+    mb.decode_fused_pick = False
+    sopt = dict(sample_max=1, beam_size=1, return_att=return_att)
+    lens = set()
+    for seed in range(30, 42):
+        b = {k: v.to(DEV) for k, v in synthetic.make_test_batch(4 + seed % 5, seed=seed, D=opt["att_feat_size"], N=N, K=K).items()}
+        x = ma(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")
+        y = mb(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")
+        assert len(x) == len(y)
+        assert torch.equal(x[0], y[0]) and torch.equal(x[3], y[3])
+        torch.testing.assert_close(x[1], y[1], atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(x[2], y[2], atol=1e-6, rtol=1e-6)
+        if return_att:
+            assert x[4].shape == y[4].shape
+            torch.testing.assert_close(x[4], y[4], atol=1e-6, rtol=1e-5)
+        lens.update((x[0] > 0).sum(1).tolist())
+    assert len(lens) >= 3 and min(lens) < ma.seq_length              # rows of different lengths were decoded
