@@ -275,10 +275,10 @@ int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t tok_stride, 
  * + add1[tok ? tok[s] : s] + add2[s]  (add1/add2 [*,4R] in the UNpermuted gate order, optional; tok int64 [S] selects
  * rows of a [tok_rows,4R] table);  c = f*c_prev + i*g;  h = o*tanh(c) is stored to every non-null h0/h1/h2 (row
  * stride ldh*).  x must not alias any h destination (the caller ping-pongs its state buffers).  R % 4 == 0.          */
-int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R,
+int subgc_lstm_step_skinny(const float* x, int64_t ldx, const void* w_perm, int64_t ldw, int K, int S, int R,
                            const float* add1, int64_t ld1, const int64_t* tok, int tok_rows, const float* add2,
                            int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c, float* h0,
-                           int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2, void* stream);
+                           int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2, int w_bf16, void* stream);
 
 /* out[r,:] = table[tok[r],:] -- plain token-row lookup, float4 when the rows allow it.  Decode only: with frozen weights
  * the x->gates product of the attention LSTM, relu(Emb) . W_ih[:, 2R:]^T (AttModel.py:332 feeding :409-411), depends on the
@@ -433,13 +433,18 @@ int subgc_row_count_f32(const float* x, int64_t ld, int rows, int cols, int32_t*
  *   subgc_pick_file    -- that bookkeeping alone (after the last pick).
  *   subgc_pick_lse_finish -- seqlp[m, t] = -log sum_wg sum_wg exp(max_wg - max) for every step the loop reached, from
  *       lse_part [T][ceil(V/16)][16][2]: one pass after the loop instead of a vocabulary reduction per step.                      */
-int subgc_logits_pick(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
-                      int64_t ldl, uint64_t* best, float* lse_part, void* stream);
-int subgc_lstm_step_pick(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
+int subgc_logits_pick(const float* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
+                      int64_t ldl, uint64_t* best, float* lse_part, int w_bf16, void* stream);
+int subgc_lstm_step_pick(const float* x, int64_t ldx, const void* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
                          int64_t ld1, int tok_rows, const float* add2, int64_t ld2, const float* b0, const float* b1,
                          const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2,
                          const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int T, int t_prev,
-                         int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, void* stream);
+                         int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, int w_bf16, void* stream);
+/* C[M,N] = act(A[M,K] W[N,K]^T + bias), M <= 16, with bf16-STORED W (raw uint16) and fp32 activations / results: the weight-streaming
+ * products of a decode step under compute_dtype = bf16 (w_bf16 != 0 in the three entry points above selects the same for them:
+ * half the bytes of the 120 MB a token step streams; accumulation and everything downstream stay fp32). */
+int subgc_gemm_skinny_wb16(const float* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc, const float* bias, int M,
+                           int N, int K, int relu, void* stream);
 int subgc_pick_file(const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int S, int T, int t_prev,
                     int32_t* count_out, const int32_t* prev_count, void* stream);
 int subgc_pick_lse_finish(const float* lse_part, int V, int S, int T, const int32_t* counts, float* seqlp, void* stream);

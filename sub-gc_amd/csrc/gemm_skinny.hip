@@ -6,6 +6,7 @@
 // >= 84 % of their rows; this kernel streams the weights once through 16-row v_mfma_f32_16x16x4_f32 tiles
 // (see the kernel comment below for the data layout).
 #include "common.h"
+#include "bf16_util.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -80,8 +81,10 @@ __device__ __forceinline__ int picked_word(const PickIn& pk, int m, bool& unf) {
 
 // MT > 1: the same stream against MT 16-row activation tiles (M <= 16*MT: the one-image encoder GEMMs, 37 node / 65 relation
 // rows) -- one W load, MT activation loads and 4*MT MFMAs per step; `add` [M,N] is an optional residual term of the epilogue.
-template <int WAVES, int D, bool LSTM, int MT, bool PICK = false>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+// WB16: the weight matrix is bf16-stored (compute_dtype = bf16: the decode step then streams 60 instead of 120 MB); a lane's four k of
+// a W row are one 8-byte load, widened to fp32 in registers -- activations, accumulation and everything downstream stay fp32.
+template <int WAVES, int D, bool LSTM, int MT, bool PICK = false, bool WB16 = false>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* __restrict__ A, int64_t lda, const void* __restrict__ W,
                                                                       int64_t ldb, float* __restrict__ C, int64_t ldc,
                                                                       const float* __restrict__ bias, int M, int N, int K, int relu,
                                                                       LstmEpi ep, const float* __restrict__ add, int64_t ldadd, PickOut po = PickOut{}) {
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: uniform loop control
     const int r16 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const float* wrow = W + (int64_t)min(n0 + r16, N - 1) * ldb;            // rows past N: clamped, their results are not stored
+    const float* wrow = static_cast<const float*>(W) + (WB16 ? 0 : (int64_t)min(n0 + r16, N - 1) * ldb);   // rows past N: clamped, their results are not stored
+    const uint16_t* wrow16 = static_cast<const uint16_t*>(W) + (WB16 ? (int64_t)min(n0 + r16, N - 1) * ldb : 0);
     const float* arow[MT];                                                 // columns m >= M of a tile: garbage, never stored
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (int64_t)min(mt * 16 + r16, M - 1) * lda;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
     auto issue = [&](int slot, int i) {                                       // i-th step of this wave -> ring slot (static index)
         const int k = k_of(i);
         const int kc = (i < mine && k < K) ? k : 0;                           // clamped address, never a predicated load
-        wq[slot] = ld4(wrow + kc);
+        wq[slot] = WB16 ? subgc_load4_bf(wrow16 + kc) : ld4(wrow + kc);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) aq[slot][mt] = ld4(arow[mt] + kc);
     };
@@ -282,25 +286,39 @@ int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, flo
 
 }  // namespace subgc
 
+// C[M,N] = act(A[M,K] W[N,K]^T + bias) with bf16-STORED W and fp32 activations / results, M <= 16 (the h2att product of a bf16 decode step)
+SUBGC_API int subgc_gemm_skinny_wb16(const float* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc, const float* bias, int M,
+                                     int N, int K, int relu, void* stream) {
+    SUBGC_REQUIRE(M >= 1 && M <= 16 && N > 0 && K > 0 && K % 4 == 0, "gemm_skinny_wb16: need 1 <= M <= 16 and K % 4 == 0");
+    SUBGC_REQUIRE(A && W && C && lda >= K && lda % 4 == 0 && ldw >= K && ldw % 4 == 0 && ldc >= N && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 8) == 0,
+                  "gemm_skinny_wb16: 16-byte aligned fp32 rows, 8-byte aligned bf16 rows");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, false, true>), dim3((N + 15) / 16), dim3(512), 0, s, A, lda, W, ldw, C, ldc, bias, M, N, K, relu,
+                       LstmEpi{}, nullptr, 0, PickOut{});
+    return subgc::check_launch("subgc_gemm_skinny_wb16");
+}
+
 // ---- C ABI: one LSTM cell step of a decode batch of <= 16 rows, gate GEMM and cell update in one launch ---------------------
-SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
+SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const void* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
                                      int64_t ld1, const int64_t* tok, int tok_rows, const float* add2, int64_t ld2, const float* b0,
                                      const float* b1, const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1,
-                                     float* h2, int64_t ldh2, void* stream) {
+                                     float* h2, int64_t ldh2, int w_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 0 && S <= 32 && R > 0 && R % 4 == 0 && K > 0 && K % 4 == 0, "lstm_step_skinny: need S <= 32, R % 4 == 0, K % 4 == 0");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(x && w_perm && c && (h0 || h1 || h2), "lstm_step_skinny: null pointer");
-    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % 16) == 0,
-                  "lstm_step_skinny: x / w_perm rows must be 16-byte aligned float4 rows");
+    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % (w_bf16 ? 8 : 16)) == 0,
+                  "lstm_step_skinny: x / w_perm rows must be 16-byte aligned float4 rows (8-byte aligned bf16 rows)");
     SUBGC_REQUIRE(!tok || (add1 && tok_rows > 0), "lstm_step_skinny: tok needs a table in add1");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
     LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, PickIn{}};
     const int N = 4 * R, wgs = N / 16;
-    if (S > 16)                                                                // two activation tiles (beam search: <= 10 sub-graphs x 2-3 beams)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 2>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
-    else
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0);
+#define SUBGC_LSTM_GO(MT_, W16_) \
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, MT_, false, W16_>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0, PickOut{})
+    if (S > 16) { if (w_bf16) SUBGC_LSTM_GO(2, true); else SUBGC_LSTM_GO(2, false); }      // two activation tiles (beam search: <= 10 sub-graphs x 2-3 beams)
+    else { if (w_bf16) SUBGC_LSTM_GO(1, true); else SUBGC_LSTM_GO(1, false); }
+#undef SUBGC_LSTM_GO
     return subgc::check_launch("subgc_lstm_step_skinny");
 }
 
@@ -309,39 +327,47 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const float* w
 // subgc_lstm_step_pick: subgc_lstm_step_skinny whose input word of row m is the arg-max `best_prev` that the previous step's
 //   subgc_logits_pick left (finished rows feed word 0; the table row add1[word] is the x->gates term); workgroup 0 files that pick:
 //   seq[m, t_prev], unf_out[m], counts[t_prev], and clears `best_reset` (the other buffer) for this step's logits launch.  S <= 16.
-SUBGC_API int subgc_lstm_step_pick(const float* x, int64_t ldx, const float* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
+SUBGC_API int subgc_lstm_step_pick(const float* x, int64_t ldx, const void* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
                                    int64_t ld1, int tok_rows, const float* add2, int64_t ld2, const float* b0, const float* b1,
                                    const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2,
                                    const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int T, int t_prev,
-                                   int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, void* stream) {
+                                   int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, int w_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 1 && S <= 16 && R > 0 && R % 4 == 0 && K > 0 && K % 4 == 0, "lstm_step_pick: need 1 <= S <= 16, R % 4 == 0, K % 4 == 0");
     SUBGC_REQUIRE(x && w_perm && c && (h0 || h1 || h2) && add1 && tok_rows > 0, "lstm_step_pick: null pointer");
     SUBGC_REQUIRE(best_prev && unf_out && seq && count_out && t_prev >= 0 && t_prev < T && (t_prev == 0 || unf_in), "lstm_step_pick: pick arguments");
-    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % 16) == 0,
-                  "lstm_step_pick: x / w_perm rows must be 16-byte aligned float4 rows");
+    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % (w_bf16 ? 8 : 16)) == 0,
+                  "lstm_step_pick: x / w_perm rows must be 16-byte aligned float4 rows (8-byte aligned bf16 rows)");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
     PickIn pk{reinterpret_cast<const unsigned long long*>(best_prev), unf_in, unf_out, seq, T, t_prev, count_out, prev_count,
               reinterpret_cast<unsigned long long*>(best_reset)};
     LstmEpi ep{add1, ld1, nullptr, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, pk};
-    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1>), dim3(4 * R / 16), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, 4 * R, K, 0, ep,
-                       nullptr, 0, PickOut{});
+    if (w_bf16)
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1, false, true>), dim3(4 * R / 16), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, 4 * R, K,
+                           0, ep, nullptr, 0, PickOut{});
+    else
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1>), dim3(4 * R / 16), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, 4 * R, K, 0, ep,
+                           nullptr, 0, PickOut{});
     return subgc::check_launch("subgc_lstm_step_pick");
 }
 
 // subgc_logits_pick: logits = x W^T + bias for S <= 16 rows WITHOUT writing them (logits may be NULL): `best` slots <- packed arg-max
 //   (64-bit atomicMax; zero before the launch), lse_part[(wg * 16 + m) * 2 + {0, 1}] = (max, sum exp(. - max)) over the 16 vocabulary
 //   rows of workgroup wg = 0 .. ceil(V/16)-1.
-SUBGC_API int subgc_logits_pick(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
-                                int64_t ldl, uint64_t* best, float* lse_part, void* stream) {
+SUBGC_API int subgc_logits_pick(const float* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
+                                int64_t ldl, uint64_t* best, float* lse_part, int w_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 1 && S <= 16 && V > 0 && K > 0 && K % 4 == 0, "logits_pick: need 1 <= S <= 16 and K % 4 == 0");
     SUBGC_REQUIRE(x && W && best && lse_part && (!logits || ldl >= V), "logits_pick: null pointer");
-    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0,
-                  "logits_pick: x / W rows must be 16-byte aligned float4 rows");
+    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)W % (w_bf16 ? 8 : 16)) == 0,
+                  "logits_pick: x / W rows must be 16-byte aligned float4 rows (8-byte aligned bf16 rows)");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * (double)V * K);
-    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, true>), dim3((V + 15) / 16), dim3(512), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
-                       LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
+    if (w_bf16)
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, true, true>), dim3((V + 15) / 16), dim3(512), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
+                           LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
+    else
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, true>), dim3((V + 15) / 16), dim3(512), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
+                           LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
     return subgc::check_launch("subgc_logits_pick");
 }
 

@@ -881,7 +881,7 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
 class DecodeState:
     """Step-wise decoder for sampling (AttModel._sample loop body): same kernels, batch n."""
 
-    def __init__(self, pr: Prepared, P, N, want_att, xt_table=None, fuse_lstm=False, snapshots=None):
+    def __init__(self, pr: Prepared, P, N, want_att, xt_table=None, fuse_lstm=False, snapshots=None, W16=None):
         """`xt_table` [V+1, 4R] (optional, frozen weights only): relu(Emb) . W_ih[:, 2R:]^T, one row per token -- the x->gates
         product of the attention LSTM looked up instead of recomputed every step (AttModel.xt_gates_table).
         `fuse_lstm` (<= 32 rows, R % 4 == 0): each LSTM cell is ONE launch, gate GEMM + cell update (subgc_lstm_step_skinny) on
@@ -892,6 +892,10 @@ class DecodeState:
         (and, fused, row-permuted) LSTM matrices are built once per set of weights, not once per state / captured graph."""
         self.xt_table = xt_table
         self.fused = bool(fuse_lstm) and pr.S <= 32 and P[10].size(1) % 4 == 0
+        # `W16` (compute_dtype = bf16; list aligned with P, see bf16_twins): the fused (<= 32 row) step streams bf16-STORED weights --
+        # both LSTM matrices, h2att (<= 16 rows) and the logit layer -- against fp32 activations with fp32 accumulation: half the
+        # bytes of the weight stream that bounds the one-image decode; cell state, attention and the pick stay fp32
+        self.w16 = W16 if (self.fused and W16 is not None and all(W16[i] is not None for i in (9, 10, 13, 14, 17, 21))) else None
         (_, _, _, _, _, _, _, _, self.emb, w1i, w1h, self.b1i, self.b1h, w2i, w2h, self.b2i, self.b2h,
          self.h2a_w, self.h2a_b, self.an_w, self.an_b, self.lg_w, self.lg_b) = P
         self.pr, self.N = pr, N
@@ -899,12 +903,16 @@ class DecodeState:
         S = pr.S
         R, E = w1h.size(1), self.emb.size(1)
         self.S, self.R, self.E, self.A, self.V1 = S, R, E, self.h2a_w.size(0), self.lg_w.size(0)
-        key = "perm" if self.fused else "cat"
+        key = ("perm16" if self.w16 is not None else "perm") if self.fused else "cat"
         if snapshots is not None and key in snapshots:
             self.Wc1, self.Wc2 = snapshots[key]
         else:
-            self.Wc1 = _cat_weights(w1i[:, :R], w1h)
-            self.Wc2 = _cat_weights(w2i, w2h)
+            if self.w16 is not None:
+                self.Wc1 = _cat_weights(self.w16[9][:, :R], self.w16[10])
+                self.Wc2 = _cat_weights(self.w16[13], self.w16[14])
+            else:
+                self.Wc1 = _cat_weights(w1i[:, :R], w1h)
+                self.Wc2 = _cat_weights(w2i, w2h)
             if self.fused:
                 perm = ops.lstm_gate_perm(R, dev)
                 self.Wc1, self.Wc2 = self.Wc1[perm].contiguous(), self.Wc2[perm].contiguous()    # only the permuted snapshots are kept
@@ -925,6 +933,21 @@ class DecodeState:
         self.hout, self.logits = new(S, R), new(S, self.V1)
         self.want_att = want_att
         self._alt = None
+        self.lg_op = self.w16[21] if (self.w16 is not None and S <= 16) else self.lg_w        # the logit matrix as the skinny launches stream it
+
+    def _h2att(self):
+        """ah = h2att(h1): the weight-streaming form on the bf16 twin when there is one (<= 16 rows), else the fp32 product."""
+        R = self.R
+        if self.w16 is not None and self.S <= 16:
+            ops.gemm_skinny_wb16(self.H2[:, R:2 * R], self.w16[17], self.ah, bias=self.h2a_b)
+        else:
+            ops.gemm(self.H2[:, R:2 * R], self.h2a_w, self.ah, tb=True, bias=self.h2a_b)
+
+    def _logits(self):
+        if self.w16 is not None and self.S <= 16:
+            ops.gemm_skinny_wb16(self.hout, self.w16[21], self.logits, bias=self.lg_b)
+        else:
+            ops.gemm(self.hout, self.lg_w, self.logits, tb=True, bias=self.lg_b)
 
     def reset(self):
         """Start a new decode on the SAME buffers (hipGraph replay: `pr`'s tensors were overwritten in place)."""
@@ -960,13 +983,13 @@ class DecodeState:
         ops.lstm_step_skinny(self.H1, self.Wc1, self.C1[0], self.C1[1], [self.H2[:, R:2 * R], self.H1n[:, R:]], self.b1i, self.b1h,
                              add1, tok, self.Gf)
         self.C1.reverse()
-        ops.gemm(self.H2[:, R:2 * R], self.h2a_w, self.ah, tb=True, bias=self.h2a_b)
+        self._h2att()
         ops.attn_fwd(pr.u, pr.v, self.ah, self.an_w, self.an_b, pr.off, pr.lens, self.H2[:, :R], alpha_out, S, A, R)
         ops.lstm_step_skinny(self.H2, self.Wc2, self.C2[0], self.C2[1], [self.H1n[:, :R], self.H2n[:, 2 * R:], self.hout], self.b2i, self.b2h)
         self.C2.reverse()
         self.H1, self.H1n = self.H1n, self.H1
         self.H2, self.H2n = self.H2n, self.H2
-        ops.gemm(self.hout, self.lg_w, self.logits, tb=True, bias=self.lg_b)
+        self._logits()
         if normalize:
             ops.log_softmax_rows_(self.logits)
         return self.logits
@@ -1002,7 +1025,7 @@ class DecodeState:
                 ops.lstm_step_pick(self.H1, self.Wc1, self.C1[0], self.C1[1], hs, self.b1i, self.b1h, self.xt_table, self.Gf, *pick,
                                    None if last else best[t & 1])
             self.C1.reverse()
-            ops.gemm(self.H2[:, R:2 * R], self.h2a_w, self.ah, tb=True, bias=self.h2a_b)
+            self._h2att()
             ops.attn_fwd(pr.u, pr.v, self.ah, self.an_w, self.an_b, pr.off, pr.lens, self.H2[:, :R], None if AL is None else AL[t], S, A, R)
             if last:
                 break
@@ -1010,7 +1033,7 @@ class DecodeState:
             self.C2.reverse()
             self.H1, self.H1n = self.H1n, self.H1
             self.H2, self.H2n = self.H2n, self.H2
-            ops.logits_pick(self.hout, self.lg_w, self.lg_b, best[t & 1], lse[t])
+            ops.logits_pick(self.hout, self.lg_op, self.lg_b, best[t & 1], lse[t])
         ops.pick_lse_finish(lse, V1, counts, seqlp)
 
     def step(self, it, alpha_out, normalize=True):

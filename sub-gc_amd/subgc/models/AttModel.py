@@ -530,6 +530,14 @@ class AttModel(CaptionModel):
             self.__dict__["_decode_snapshots"] = hit
         return hit[1]
 
+    def decode_w16(self):
+        """bf16 twins of the decoder parameters (aligned with functions.PARAM_ORDER) for the weight-streaming decode step under
+        compute_dtype = bf16, else None: the <= 32-row step then streams half the bytes (functions.DecodeState)."""
+        if not self.bf16_storage:
+            return None
+        flat16 = self.weights_b16()
+        return [self.W16(n, flat16) for n in F_.PARAM_ORDER]
+
     def invalidate_decode_caches(self):
         self.__dict__["_cache_epoch"] = self.__dict__.get("_cache_epoch", 0) + 1
 

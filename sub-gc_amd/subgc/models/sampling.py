@@ -192,7 +192,7 @@ class _GraphedLoop:
         cap = n * N
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
-        self.st = F_.DecodeState(self.pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots())
+        self.st = F_.DecodeState(self.pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots(), W16=m.decode_w16())
         self.seq, self.seqlp = z(n, T, dt=torch.long), z(n, T)
         self.it, self.unfinished, self.counts = z(n, dt=torch.long), z(n, dt=torch.int32), z(T, dt=torch.int32)
         self.AL = z(T + 1, n, N) if return_att else None
@@ -389,7 +389,7 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     if graphed is not None:
         seq, seqlp, counts, AL = graphed.run(pr, uniforms)
     else:
-        st = F_.DecodeState(pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots())
+        st = F_.DecodeState(pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots(), W16=m.decode_w16())
         seq = torch.zeros(n, T, device=dev, dtype=torch.long)
         seqlp = torch.zeros(n, T, device=dev)
         it = torch.zeros(n, device=dev, dtype=torch.long)

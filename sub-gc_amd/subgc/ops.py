@@ -516,10 +516,10 @@ def lstm_step_skinny(x, w_perm, c_prev, c, hs, b0=None, b1=None, add1=None, tok=
     hp = []
     for h_ in hs:
         hp += [_ptr(h_, torch.float32), ld(h_) if h_ is not None else 0]
-    call("subgc_lstm_step_skinny", _ptr(x, torch.float32), ld(x), _ptr(w_perm, torch.float32), ld(w_perm), K, S, R,
+    call("subgc_lstm_step_skinny", _ptr(x, torch.float32), ld(x), _ptr(w_perm), ld(w_perm), K, S, R,
          _ptr(add1, torch.float32), ld(add1) if add1 is not None else 0, _ptr(tok, torch.int64), add1.size(0) if tok is not None else 0,
          _ptr(add2, torch.float32), ld(add2) if add2 is not None else 0, _ptr(b0, torch.float32), _ptr(b1, torch.float32),
-         _ptr(c_prev, torch.float32), _ptr(c, torch.float32), *hp, _stream())
+         _ptr(c_prev, torch.float32), _ptr(c, torch.float32), *hp, int(is_b16(w_perm)), _stream())
 
 
 PICK_BEST_ELEMS = 16 * 8 * 16       # uint64 slots of one `best` buffer of the fused greedy pick (subgc_hip.h)
@@ -529,8 +529,8 @@ def logits_pick(x, W, bias, best, lse_part, logits=None):
     """Logits launch of a greedy decode step with the arg-max / log-sum-exp partials in its epilogue (subgc_logits_pick)."""
     S, K = x.shape
     V = W.size(0)
-    call("subgc_logits_pick", _ptr(x, torch.float32), ld(x), _ptr(W, torch.float32), ld(W), _ptr(bias, torch.float32), S, V, K, _ptr(logits),
-         ld(logits) if logits is not None else 0, _ptr(best, torch.int64), _ptr(lse_part, torch.float32), _stream())
+    call("subgc_logits_pick", _ptr(x, torch.float32), ld(x), _ptr(W), ld(W), _ptr(bias, torch.float32), S, V, K, _ptr(logits),
+         ld(logits) if logits is not None else 0, _ptr(best, torch.int64), _ptr(lse_part, torch.float32), int(is_b16(W)), _stream())
 
 
 def lstm_step_pick(x, w_perm, c_prev, c, hs, b0, b1, table, add2, best_prev, unf_in, unf_out, seq, t_prev, count_out, prev_count, best_reset):
@@ -541,10 +541,19 @@ def lstm_step_pick(x, w_perm, c_prev, c, hs, b0, b1, table, add2, best_prev, unf
     hp = []
     for h_ in hs:
         hp += [_ptr(h_, torch.float32), ld(h_) if h_ is not None else 0]
-    call("subgc_lstm_step_pick", _ptr(x, torch.float32), ld(x), _ptr(w_perm, torch.float32), ld(w_perm), K, S, R, _ptr(table, torch.float32), ld(table),
+    call("subgc_lstm_step_pick", _ptr(x, torch.float32), ld(x), _ptr(w_perm), ld(w_perm), K, S, R, _ptr(table, torch.float32), ld(table),
          table.size(0), _ptr(add2, torch.float32), ld(add2) if add2 is not None else 0, _ptr(b0, torch.float32), _ptr(b1, torch.float32),
          _ptr(c_prev, torch.float32), _ptr(c, torch.float32), *hp, _ptr(best_prev, torch.int64), _ptr(unf_in, torch.int32), _ptr(unf_out, torch.int32),
-         _ptr(seq, torch.int64), seq.size(1), int(t_prev), _ptr(count_out, torch.int32), _ptr(prev_count, torch.int32), _ptr(best_reset, torch.int64), _stream())
+         _ptr(seq, torch.int64), seq.size(1), int(t_prev), _ptr(count_out, torch.int32), _ptr(prev_count, torch.int32), _ptr(best_reset, torch.int64),
+         int(is_b16(w_perm)), _stream())
+
+
+def gemm_skinny_wb16(x, w16, out, bias=None, relu=False):
+    """out = act(x w16^T + bias): fp32 rows (<= 16) against a bf16-STORED weight matrix (subgc_gemm_skinny_wb16)."""
+    M, K = x.shape
+    call("subgc_gemm_skinny_wb16", _ptr(x, torch.float32), ld(x), _ptr(w16, BF16), ld(w16), _ptr(out, torch.float32), ld(out), _ptr(bias, torch.float32),
+         M, w16.size(0), K, int(relu), _stream())
+    return out
 
 
 def pick_file(best_prev, unf_in, unf_out, seq, t_prev, count_out, prev_count):

@@ -99,13 +99,41 @@ def test_flickr_stress_shape_in_bf16_storage_matches_fp32_oracle():
     close(outputs, ref["outputs"].detach(), "outputs", atol=5e-2, rtol=2e-2)
     close(score, ref["subgraph_score"].detach(), "score", atol=2e-2)
     margin_tokens_equal(outputs, ref["outputs"].detach(), 100)
-    # the attention-grounding output path (return_att) of the fp32-stored decode kernels with the same weights
-    tb = synthetic.make_test_batch(9, seed=7, **FLICKR_DATA)
+    # the attention-grounding output path (return_att; misc/grd_utils.py:44-47 takes the arg-max of these weights) decoded IN bf16: the
+    # <= 16-row step streams the bf16 weight snapshot (functions.DecodeState: both LSTM matrices, h2att, logit) with fp32 accumulation.
+    # Compared with the fp32 oracle along the SAME token path (oracle teacher-forced with the tokens the bf16 decode produced): log-probs
+    # atol 5e-2, attention weights atol 2e-2, attention arg-max equal wherever the oracle's top-1 / top-2 margin exceeds 2 x atol; where the
+    # free-running oracle picks another word, its margin over the bf16 word must be below 2 x atol.
+    tb = synthetic.make_test_batch(5, seed=7, **FLICKR_DATA)
     sopt = dict(sample_max=1, beam_size=1, return_att=1)
     topt = argparse.Namespace(**dict(FLICKR, test_LSTM=1, sct=1, compute_dtype="bf16"))
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["core.attention.alpha_net.weight"] *= 10.0                  # peaky attention: the arg-max the grounding code reads has margins to test
     mt = models.setup(topt); mt.load_state_dict(sd); mt = mt.to(DEV).eval()
     ret = mt(*synthetic.sample_args({k: v.to(DEV) for k, v in tb.items()}), opt=sopt, mode="sample")
-    assert ret[0].shape[0] == 18 and ret[4].shape[0] == 18 and torch.isfinite(ret[1]).all()
+    loops = [g for g in mt._graph_cache.values() if hasattr(g, "st")]
+    assert loops and loops[0].st.w16 is not None and loops[0].st.Wc1.dtype == BF           # the bf16 weight stream really ran
+    orc_t = O.Oracle(argparse.Namespace(**dict(FLICKR, test_LSTM=1, sct=1)), sd)
+    free = orc_t.sample(*synthetic.sample_args(tb), opt=sopt)
+    forced = orc_t.sample(*synthetic.sample_args(tb), opt=sopt, forced=ret[0].cpu())
+    seq_b = ret[0].cpu()
+    assert seq_b.shape == (10, mt.seq_length) and int((seq_b > 0).sum()) > 40
+    close(ret[1], forced[1], "seqLogprobs", atol=5e-2, rtol=0)
+    assert tuple(ret[4].shape) == tuple(forced[4].shape)
+    close(ret[4], forced[4], "att2_weights", atol=2e-2, rtol=0)
+    top2 = forced[4].topk(2, -1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 4e-2
+    assert int(sure.sum()) > 20 and bool((ret[4].cpu().argmax(-1)[sure] == forced[4].argmax(-1)[sure]).all())
+    same = 0
+    for r in range(seq_b.size(0)):
+        diff = (free[0][r] != seq_b[r]).nonzero()
+        if diff.numel() == 0:
+            same += 1
+            continue
+        t0 = int(diff[0])                                          # same history up to t0: both log-probs come from the same oracle state
+        assert float(free[1][r, t0] - forced[1][r, t0]) < 0.1, (r, t0)
+    assert same >= 5
+    close(ret[2], free[2], "score", atol=2e-2)
 
 
 @pytest.mark.timeout(900)
@@ -137,6 +165,21 @@ def test_full_gc_kar_batch_256_properties_in_bf16_storage():
     live = outputs.abs().sum(-1) > 0
     assert float(lse[live].abs().max()) < 1e-3 and int(live.sum()) > 1280 * 5
     assert (~live).sum() == 0 or float(outputs[~live].abs().max()) == 0.0
+    # ... and against the fp32 oracle: in eval mode no row depends on another image (BatchNorm uses its running statistics), so the
+    # oracle runs on the first 13 images alone (65 sentences) and must agree with the first 65 rows of the 256-image bf16 forward
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    sub = {k: v[:13 * (v.size(0) // 256)].clone() for k, v in batch.items()}
+    orc = O.Oracle(argparse.Namespace(**dict(FULLGC, drop_prob_lm=0.5)), sd)
+    orc.training = False
+    with torch.no_grad():
+        ref = O.loss_wrapper(orc, sub)
+    got = outputs[:65].cpu()
+    reached = ref["outputs"].abs().sum(-1) > 0                    # the oracle's early break is that of ITS 65 sentences
+    close(got[reached], ref["outputs"][reached], "outputs[:65]", atol=5e-2, rtol=2e-2)
+    margin_tokens_equal(got, ref["outputs"], 200)
+    lab, msk = sub["labels"][:, 1:], sub["masks"][:, 1:]
+    my_loss = -(got.gather(2, lab[:, :17].unsqueeze(2)).squeeze(2) * msk[:, :17] * reached).sum() / msk[:, :17].sum()
+    close(my_loss, ref["lang_loss"], "lang_loss of the first 65 sentences", atol=5e-2, rtol=0)
 
 
 def test_bf16_snapshot_follows_the_masters(golden):
