@@ -374,6 +374,14 @@ class AttModel(CaptionModel):
         self.__dict__["_nbt_pending"] = {}
         return super().load_state_dict(*args, **kwargs)
 
+    def _class_proj(self, table, lin, cls):
+        """Linear(Embedding[cls]) (AttModel.py:374-377,383-386).  More rows than classes (a training batch): project the TABLE once and
+        look the rows up (functions.ClassTableFn); fewer (one image at decode time: 37 rows against 1599 classes): look up, then project."""
+        emb = self.P(table)
+        if cls.numel() >= emb.size(0):
+            return F_.ClassTableFn.apply(emb, self.P(lin + ".weight"), self.P(lin + ".bias"), cls)
+        return F_.linear(F_.GatherRowsFn.apply(emb, cls), self.P(lin + ".weight"), self.P(lin + ".bias"))
+
     def _encode(self, att_feats, obj_dist, pred_dist, rel_ind):
         """feat_fusion + GCN (AttModel.py:370-387, gcn_backbone.py:29-53) -> X_out [B, N, L]."""
         B, N, D = att_feats.shape
@@ -394,7 +402,7 @@ class AttModel(CaptionModel):
             raise ValueError(f"pred_dist has {pred_dist.size(-1)} classes, sg_pred_embed has {self.sg_pred_cnt} rows")
         if self.noun_fuse:
             cls = ops.row_argmax(obj_dist.reshape(B * N, -1), skip=1, i32=True)
-            e = F_.ClassTableFn.apply(self.P("sg_obj_embed.weight"), self.P("obj_emb_proj.weight"), self.P("obj_emb_proj.bias"), cls)
+            e = self._class_proj("sg_obj_embed.weight", "obj_emb_proj", cls)
             x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), add=e, relu=True, **lin16("obj_v_proj.weight"))
         else:
             x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), **lin16("obj_v_proj.weight"))
@@ -402,7 +410,7 @@ class AttModel(CaptionModel):
         p = None
         if needP[0] or self.GCN_layers == 0:
             pc = ops.row_argmax(pred_dist.reshape(B * K, -1), skip=1 if self.pred_emb_type == 1 else 0, i32=True)
-            p = F_.ClassTableFn.apply(self.P("sg_pred_embed.weight"), self.P("pred_emb_prj.weight"), self.P("pred_emb_prj.bias"), pc).view(B, K, L)
+            p = self._class_proj("sg_pred_embed.weight", "pred_emb_prj", pc).view(B, K, L)
         if self.GCN_layers == 0:
             return x
         rel_ind = rel_ind.contiguous()
