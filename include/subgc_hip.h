@@ -320,6 +320,25 @@ int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, cons
                    const float* dh_b, int64_t ldb, const float* dh_drop, int64_t ldd, const uint8_t* keep,
                    float keep_scale, const float* dc, void* dpre, float* dc_prev, int S, int R, int dpre_bf16,
                    void* stream);
+/* Split-K partial planes consumed in place (the backward's recurrent data-gradient products, M <= a few hundred rows, are split-K;
+ * their consumers read d(h) / d(ctx) exactly once, so they add the planes themselves and the reduce launches disappear):
+ *   subgc_gemm_f32_planes / subgc_gemm_bf16_planes: op(A) op(B) as *n_planes fp32 planes planes[q][M][N] (stride M*N) whose sum is the
+ *     product -- the dispatch's split-K form without its reduce pass; *n_planes = 1 when it does not split (plane 0 = the product).
+ *   subgc_lstm_bwd_planes: subgc_lstm_bwd with up to three d(h) sources, source i = sum_{q < n_i} p_i[q*stride_i + s*ld_i + j] for rows
+ *     s < rows_i (a column window of a plane stack: ld_i = the planes' N, p_i offset by the window's first column).
+ *   subgc_attn_bwd_planes: subgc_attn_bwd with d(ctx) = sum of dctx_planes planes dctx + q * plane_stride.                      */
+int subgc_gemm_f32_planes(int transA, int transB, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* planes, size_t planes_bytes, int* n_planes, int flags, void* stream);
+int subgc_gemm_bf16_planes(int transA, int transB, int M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                           float* planes, size_t planes_bytes, int* n_planes, void* stream);
+int subgc_lstm_bwd_planes(const float* gates, const float* c_prev, const float* c, const float* p0, int64_t ld0, int n0, int64_t stride0,
+                          int rows0, const float* p1, int64_t ld1, int n1, int64_t stride1, int rows1, const float* p2, int64_t ld2, int n2,
+                          int64_t stride2, int rows2, const float* dh_drop, int64_t ldd, const uint8_t* keep, float keep_scale,
+                          const float* dc, void* dpre, float* dc_prev, int S, int R, int dpre_bf16, void* stream);
+int subgc_attn_bwd_planes(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                          const float* alpha, int n_stride, const float* dctx, int64_t lddctx, int dctx_planes, int64_t plane_stride,
+                          void* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R, int bf16_bits,
+                          float* dctx_keep, int64_t ldkeep, void* stream);
 
 /* one attention step over the ragged node sets (AttModel.py:453-466):
  *   e_i = <w_a, tanh(u[m,:] + ah[s,:])> + b_a ; alpha = softmax over the sentence's valid rows
@@ -456,7 +475,8 @@ int subgc_pick_lse_finish(const float* lse_part, int V, int S, int T, const int3
  *   rows int32 [B*g]: position of sentence j of image b in the step's row arrays (ah / ctx / alpha / dctx ... are indexed by it);
  *   the sentence takes part iff 0 <= rows[b*g+j] < m.  lens int32 [by row]: valid nodes (<= Nn <= 128).  g <= 8.
  *   fwd: ctx[row] (fp32 / bf16: bit 0), alpha[row, 0..n_stride).  bwd: dah[row] (fp32 / bf16: bit 0), du [B*Nn, A] += (zero it
- *   before the first step), dw_a[row, A] / db_a[row] per-sentence partials, dctx_keep[row] (may be NULL) = this step's d(ctx) rows.
+ *   before the first step), dw_a[row, A] / db_a[row] per-sentence partials, dctx_keep[row] (may be NULL) = this step's d(ctx) rows;
+ *   d(ctx) = sum of dctx_planes planes dctx + q * plane_stride (1, 0: a plain array).
  *   dv_accum: dv [B*Nn, R] = sum over steps t and live sentences of alpha_t[row, i] * dctx_t[row, :]; step t's rows start at
  *   step_off[t] with step_off[t+1] - step_off[t] of them live (every row of dv is written).                                      */
 int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
@@ -464,7 +484,8 @@ int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const fl
                          int R, int bf16_bits, void* stream);
 int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,
                          int B, int g, int Nn, const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du,
-                         float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream);
+                         float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, int dctx_planes,
+                         int64_t plane_stride, void* stream);
 int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,
                               const int32_t* rows, int B, int g, int Nn, float* dv, int R, void* stream);
 

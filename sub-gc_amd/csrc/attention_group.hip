@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
                                                              const float* __restrict__ alpha, int n_stride, const float* __restrict__ dctx,
                                                              int64_t lddctx, void* __restrict__ dah, float* __restrict__ du,
                                                              float* __restrict__ dw_a, float* __restrict__ db_a, int A, int R, int dah_b16,
-                                                             float* __restrict__ dctx_keep, int64_t ldkeep) {
+                                                             float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride) {
     __shared__ float al_s[G][GL];     // alpha, then de
     __shared__ float da_s[G][GL];
     __shared__ float4 part_d[G][128], part_w[G][128];
@@ -164,8 +164,14 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
 #pragma unroll
         for (int j = 0; j < G; ++j)
 #pragma unroll
-            for (int c = 0; c < CR64; ++c)
-                gd[j][c] = (row_s[j] >= 0 && lane + c * 64 < R4) ? ld4(dctx + (int64_t)row_s[j] * lddctx + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < CR64; ++c) {
+                gd[j][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row_s[j] >= 0 && lane + c * 64 < R4)
+                    for (int q = 0; q < n_planes; ++q) {             // split-K partial planes of the data-gradient GEMM, summed on load
+                        const float4 x = ld4(dctx + q * plane_stride + (int64_t)row_s[j] * lddctx + (lane + c * 64) * 4);
+                        gd[j][c].x += x.x; gd[j][c].y += x.y; gd[j][c].z += x.z; gd[j][c].w += x.w;
+                    }
+            }
         if (dctx_keep && wave == 0) {
 #pragma unroll
             for (int j = 0; j < G; ++j)
@@ -336,9 +342,11 @@ SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah
 
 SUBGC_API int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,
                                    int B, int g, int Nn, const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du,
-                                   float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream) {
+                                   float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, int dctx_planes,
+                                   int64_t plane_stride, void* stream) {
     const int dah_b16 = bf16_bits & 1, uv16 = (bf16_bits >> 1) & 1;
-    SUBGC_REQUIRE(B >= 0 && g >= 1 && g <= 8 && Nn >= 1 && Nn <= GL && m >= 0 && A > 0 && R > 0 && n_stride > 0, "attn_bwd_group: bad sizes (g <= 8, Nn <= %d)", GL);
+    const int n_planes = dctx_planes;
+    SUBGC_REQUIRE(B >= 0 && g >= 1 && g <= 8 && Nn >= 1 && Nn <= GL && m >= 0 && A > 0 && R > 0 && n_stride > 0 && dctx_planes >= 1 && plane_stride % 4 == 0, "attn_bwd_group: bad sizes (g <= 8, Nn <= %d)", GL);
     if (B == 0 || m == 0) return SUBGC_OK;
     SUBGC_REQUIRE(u && v && ah && w_a && rows && lens && alpha && dctx && dah && du && dw_a, "attn_bwd_group: null pointer");
     SUBGC_REQUIRE(A % 4 == 0 && R % 4 == 0 && lddctx % 4 == 0 && ldkeep % 4 == 0 && al16(u) && al16(v) && al16(ah) && al16(w_a) && al16(dctx) && al16(dah) &&
@@ -348,7 +356,7 @@ SUBGC_API int subgc_attn_bwd_group(const void* u, const void* v, const float* ah
     SUBGC_REQUIRE(ca <= 2 && cr <= 4, "attn_bwd_group: att_hid_size <= 1024 and rnn_size <= 1024");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
-#define SUBGC_BWD_ARGS u, v, ah, w_a, rows, lens, m, g, Nn, alpha, n_stride, dctx, lddctx, dah, du, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep
+#define SUBGC_BWD_ARGS u, v, ah, w_a, rows, lens, m, g, Nn, alpha, n_stride, dctx, lddctx, dah, du, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride
 #define SUBGC_BWD_G(G_)                                                                                                                               \
     do {                                                                                                                                                \
         if (uv16) { if (ca == 1 && cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 2, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);     \

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
                                                            const float* __restrict__ dctx, int64_t lddctx, void* __restrict__ dah,
                                                            float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
                                                            float* __restrict__ db_a, int A, int R, int dah_b16,
-                                                           float* __restrict__ dctx_keep, int64_t ldkeep) {
+                                                           float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride) {
+    // n_planes > 1: d(ctx) arrives as the split-K partial planes of the data-gradient GEMM (dctx + q * plane_stride), summed on load
     // dv == NULL: d(v) is deferred -- the caller keeps every step's d(ctx) rows (dctx_keep, written here by wave 0) and alpha
     // and calls subgc_attn_dv_accum once after the time loop instead of read-modify-writing all of d(v) at every step
     __shared__ float al_s[MAXLEN];    // alpha, then de
@@ -115,7 +116,14 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
     // dalpha_i = <dctx, v_i>,  dv_i += alpha_i dctx : wave per node; this lane's dctx chunks are loaded once
     float4 g[CR64];
 #pragma unroll
-    for (int c = 0; c < CR64; ++c) g[c] = (lane + c * 64 < R4) ? ld4(dctx + (int64_t)s * lddctx + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < CR64; ++c) {
+        g[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane + c * 64 < R4)
+            for (int q = 0; q < n_planes; ++q) {
+                const float4 x = ld4(dctx + q * plane_stride + (int64_t)s * lddctx + (lane + c * 64) * 4);
+                g[c].x += x.x; g[c].y += x.y; g[c].z += x.z; g[c].w += x.w;
+            }
+    }
     if (dctx_keep && wave == 0) {
 #pragma unroll
         for (int c = 0; c < CR64; ++c)
@@ -275,8 +283,9 @@ int attn_fwd_vec(const void* u, const void* v, const float* ah, const float* w_a
 
 int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                  const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
-                 float* db_a, int S, int A, int R, int dah_b16, int uv_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s) {
-    if (A % 4 || R % 4 || lddctx % 4 || ldkeep % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
+                 float* db_a, int S, int A, int R, int dah_b16, int uv_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s, int n_planes,
+                 int64_t plane_stride) {
+    if (A % 4 || R % 4 || lddctx % 4 || ldkeep % 4 || plane_stride % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
         !al16(dv) || !al16(dw_a) || !al16(dctx_keep))
         return -100;
     const int ca = (A / 4 + 127) / 128, cr = (R / 4 + 63) / 64;
@@ -284,9 +293,9 @@ int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a
 #define SUBGC_ATT_BWD(CA_, CR_)                                                                                                          \
     do {                                                                                                                                   \
         if (uv_b16) hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, true>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
-                                       dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep);                          \
+                                       dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride); \
         else hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, false>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
-                                dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep);                                 \
+                                dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride);        \
     } while (0)
     if (ca == 1) {
         if (cr <= 1) SUBGC_ATT_BWD(1, 1); else if (cr <= 2) SUBGC_ATT_BWD(1, 2); else if (cr <= 4) SUBGC_ATT_BWD(1, 4); else SUBGC_ATT_BWD(1, 8);

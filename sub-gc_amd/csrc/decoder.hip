@@ -186,11 +186,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         stv<VW>(gp, ig); stv<VW>(gp + R, fg); stv<VW>(gp + 2 * R, gg); stv<VW>(gp + 3 * R, og);
     }
 }
+// one additive source of d(h): sum over its `n` split-K partial planes p[q * stride + s * ld + j] for rows s < rows (rows past it: 0).
+// n = 1 is a plain [S, R] view; n > 1 lets this kernel consume the partial planes of the data-gradient GEMM directly (no reduce pass)
+struct PlaneSrc { const float* p; int64_t ld; int n; int64_t stride; int rows; };
+template <int VW>
+__device__ __forceinline__ void add_src(const PlaneSrc& a, int s, int j, float (&dh)[VW]) {
+    if (!a.p || s >= a.rows) return;
+    float t[VW];
+    for (int q = 0; q < a.n; ++q) {
+        ldv<VW>(a.p + q * a.stride + (int64_t)s * a.ld + j, t);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) dh[e] += t[e];
+    }
+}
 template <int VW>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
-                                                       const float* __restrict__ c, const float* __restrict__ dh_a, int64_t lda,
-                                                       const float* __restrict__ dh_b, int64_t ldb, const float* __restrict__ dh_d,
-                                                       int64_t ldd, const uint8_t* __restrict__ keep, float scale,
+                                                       const float* __restrict__ c, PlaneSrc sa, PlaneSrc sb, PlaneSrc sc,
+                                                       const float* __restrict__ dh_d, int64_t ldd, const uint8_t* __restrict__ keep, float scale,
                                                        const float* __restrict__ dc, void* __restrict__ dpre,
                                                        float* __restrict__ dc_prev, int S, int R, int pb16) {
     const int RV = R / VW;
@@ -203,12 +215,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     ldv<VW>(gp, ig); ldv<VW>(gp + R, fg); ldv<VW>(gp + 2 * R, gg); ldv<VW>(gp + 3 * R, og);
 #pragma unroll
     for (int e = 0; e < VW; ++e) dh[e] = 0.f;
-    if (dh_a) { ldv<VW>(dh_a + (int64_t)s * lda + j, t);
-#pragma unroll
-        for (int e = 0; e < VW; ++e) dh[e] += t[e]; }
-    if (dh_b) { ldv<VW>(dh_b + (int64_t)s * ldb + j, t);
-#pragma unroll
-        for (int e = 0; e < VW; ++e) dh[e] += t[e]; }
+    add_src<VW>(sa, s, j, dh);
+    add_src<VW>(sb, s, j, dh);
+    add_src<VW>(sc, s, j, dh);
     if (dh_d) {
         bool kp[VW];
         ldv<VW>(dh_d + (int64_t)s * ldd + j, t);
@@ -716,25 +725,48 @@ SUBGC_API int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int
                        c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, parts, (int64_t)S * 4 * R, h_bf16);
     return subgc::check_launch("subgc_lstm_fwd_gemm");
 }
+namespace {
+int lstm_bwd_launch(const float* gates, const float* c_prev, const float* c, PlaneSrc sa, PlaneSrc sb, PlaneSrc sc, const float* dh_drop, int64_t ldd,
+                    const uint8_t* keep, float keep_scale, const float* dc, void* dpre, float* dc_prev, int S, int R, int dpre_bf16, hipStream_t s,
+                    const char* what) {
+    const int64_t n = (int64_t)S * R;
+    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 14);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    auto src_ok = [&](const PlaneSrc& a) { return !a.p || (al(a.p) && a.ld % 4 == 0 && a.stride % 4 == 0); };
+    const bool vec = R % 4 == 0 && ldd % 4 == 0 && al(gates) && al(c_prev) && al(c) && src_ok(sa) && src_ok(sb) && src_ok(sc) &&
+                     al(dh_drop) && al(dc) && al(dpre) && al(dc_prev) && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
+    if (vec)
+        hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, sa, sb, sc,
+                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16);
+    else
+        hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, sa, sb, sc,
+                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16);
+    return subgc::check_launch(what);
+}
+}  // namespace
+
 SUBGC_API int subgc_lstm_bwd(const float* gates, const float* c_prev, const float* c, const float* dh_a, int64_t lda, const float* dh_b,
                              int64_t ldb, const float* dh_drop, int64_t ldd, const uint8_t* keep, float keep_scale, const float* dc,
                              void* dpre, float* dc_prev, int S, int R, int dpre_bf16, void* stream) {
     SUBGC_REQUIRE(S >= 0 && R > 0, "lstm_bwd: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(gates && c && dpre && dc_prev, "lstm_bwd: null pointer");
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t n = (int64_t)S * R;
-    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 14);
-    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool vec = R % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldd % 4 == 0 && al(gates) && al(c_prev) && al(c) && al(dh_a) && al(dh_b) &&
-                     al(dh_drop) && al(dc) && al(dpre) && al(dc_prev) && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
-    if (vec)
-        hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
-                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16);
-    else
-        hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gates, c_prev, c, dh_a, lda, dh_b, ldb,
-                           dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16);
-    return subgc::check_launch("subgc_lstm_bwd");
+    return lstm_bwd_launch(gates, c_prev, c, PlaneSrc{dh_a, lda, 1, 0, S}, PlaneSrc{dh_b, ldb, 1, 0, S}, PlaneSrc{nullptr, 0, 0, 0, 0}, dh_drop, ldd, keep,
+                           keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16, (hipStream_t)stream, "subgc_lstm_bwd");
+}
+
+// subgc_lstm_bwd with up to three d(h) sources that are stacks of split-K partial planes (subgc_gemm_*_planes): source i contributes
+// sum_{q < n_i} p_i[q * stride_i + s * ld_i + j] to rows s < rows_i (a NULL p_i or n_i = 0: nothing).
+SUBGC_API int subgc_lstm_bwd_planes(const float* gates, const float* c_prev, const float* c, const float* p0, int64_t ld0, int n0, int64_t stride0,
+                                    int rows0, const float* p1, int64_t ld1, int n1, int64_t stride1, int rows1, const float* p2, int64_t ld2, int n2,
+                                    int64_t stride2, int rows2, const float* dh_drop, int64_t ldd, const uint8_t* keep, float keep_scale,
+                                    const float* dc, void* dpre, float* dc_prev, int S, int R, int dpre_bf16, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && R > 0 && n0 >= 0 && n1 >= 0 && n2 >= 0, "lstm_bwd_planes: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(gates && c && dpre && dc_prev, "lstm_bwd_planes: null pointer");
+    return lstm_bwd_launch(gates, c_prev, c, PlaneSrc{n0 ? p0 : nullptr, ld0, n0, stride0, rows0}, PlaneSrc{n1 ? p1 : nullptr, ld1, n1, stride1, rows1},
+                           PlaneSrc{n2 ? p2 : nullptr, ld2, n2, stride2, rows2}, dh_drop, ldd, keep, keep_scale, dc, dpre, dc_prev, S, R, dpre_bf16,
+                           (hipStream_t)stream, "subgc_lstm_bwd_planes");
 }
 
 SUBGC_API int subgc_attn_fwd(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
@@ -751,22 +783,37 @@ SUBGC_API int subgc_attn_fwd(const void* u, const void* v, const float* ah, cons
     subgc::set_error("attn_fwd: needs att_hid_size, rnn_size %% 4 == 0 (<= 512 / <= 2048) and 16-byte aligned rows (A=%d R=%d)", A, R);
     return SUBGC_EINVAL;
 }
-SUBGC_API int subgc_attn_bwd(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
-                             const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv,
-                             float* dw_a, float* db_a, int S, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream) {
+namespace {
+int attn_bwd_any(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len, const float* alpha,
+                 int n_stride, const float* dctx, int64_t lddctx, int n_planes, int64_t plane_stride, void* dah, float* du, float* dv, float* dw_a,
+                 float* db_a, int S, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream) {
     const int dah_bf16 = bf16_bits & 1, uv_bf16 = (bf16_bits >> 1) & 1;      // bit 0: dah destination, bit 1: u and v are bf16
-    SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride > 0 && n_stride <= MAXLEN, "attn_bwd: bad sizes");
+    SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride > 0 && n_stride <= MAXLEN && n_planes >= 1, "attn_bwd: bad sizes");
     if (S == 0) return SUBGC_OK;
     SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dw_a, "attn_bwd: null pointer");
     SUBGC_REQUIRE(!dctx_keep || ldkeep >= R, "attn_bwd: dctx_keep rows too short");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
     if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, dah_bf16,
-                                           uv_bf16, dctx_keep, ldkeep, s);
+                                           uv_bf16, dctx_keep, ldkeep, s, n_planes, plane_stride);
         rc != -100)
         return rc;
     subgc::set_error("attn_bwd: needs att_hid_size, rnn_size %% 4 == 0 (<= 1024 / <= 2048) and 16-byte aligned rows (A=%d R=%d)", A, R);
     return SUBGC_EINVAL;
+}
+}  // namespace
+SUBGC_API int subgc_attn_bwd(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                             const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv,
+                             float* dw_a, float* db_a, int S, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream) {
+    return attn_bwd_any(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, 1, 0, dah, du, dv, dw_a, db_a, S, A, R, bf16_bits, dctx_keep, ldkeep, stream);
+}
+// subgc_attn_bwd whose d(ctx) is the sum of `dctx_planes` split-K partial planes dctx + q * plane_stride (subgc_gemm_*_planes)
+SUBGC_API int subgc_attn_bwd_planes(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                                    const float* alpha, int n_stride, const float* dctx, int64_t lddctx, int dctx_planes, int64_t plane_stride,
+                                    void* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R, int bf16_bits,
+                                    float* dctx_keep, int64_t ldkeep, void* stream) {
+    return attn_bwd_any(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dctx_planes, plane_stride, dah, du, dv, dw_a, db_a, S, A, R, bf16_bits,
+                        dctx_keep, ldkeep, stream);
 }
 
 SUBGC_API int subgc_attn_dv_accum(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,

@@ -626,6 +626,26 @@ SUBGC_API int subgc_gemm_bf16(int transA, int transB, int M, int N, int K, const
     return run<true, true>(a, ws, ws_bytes, s, false, nullptr);
 }
 
+// bf16 operands -> `*n_planes` fp32 partial planes planes[q][M][N] whose SUM is the product (see subgc_gemm_f32_planes)
+SUBGC_API int subgc_gemm_bf16_planes(int transA, int transB, int M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                                     float* planes, size_t planes_bytes, int* n_planes, void* stream) {
+    SUBGC_REQUIRE(M > 0 && N > 0 && K > 0 && n_planes, "gemm_bf16_planes: bad sizes");
+    if (int rc = check(transA, transB, M, N, K, A, lda, B, ldb)) return rc;
+    SUBGC_REQUIRE(planes && aligned16(planes) && planes_bytes >= (size_t)M * N * sizeof(float) && N % 4 == 0, "gemm_bf16_planes: plane buffer / N %% 4");
+    Args a{A, B, planes, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, 0, M, N, K, 0, 1.f};
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
+    int sp = 1, rc;
+    if (!transA && transB) rc = run<false, false>(a, planes, planes_bytes, s, true, &sp);
+    else if (!transA && !transB) rc = run<false, true>(a, planes, planes_bytes, s, true, &sp);
+    else rc = run<true, true>(a, planes, planes_bytes, s, true, &sp);
+    if (rc != -100) { *n_planes = sp; return rc; }
+    *n_planes = 1;                                                  // the dispatch would not split this shape: the plain kernel writes plane 0
+    if (!transA && transB) return run<false, false>(a, nullptr, 0, s, false, nullptr);
+    if (!transA && !transB) return run<false, true>(a, nullptr, 0, s, false, nullptr);
+    return run<true, true>(a, nullptr, 0, s, false, nullptr);
+}
+
 namespace subgc {
 // x[M,K] . W[N,K]^T (bf16 operands) left as `splits` fp32 partial planes ws[part][M][N] WITHOUT the reduce pass: the LSTM cell
 // kernel adds the planes while it reads the pre-activations.  -100 when the dispatch would not split this shape.

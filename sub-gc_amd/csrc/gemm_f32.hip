@@ -42,6 +42,8 @@ struct GemmArgs {
     float* ws; size_t ws_bytes;      // the caller's split-K scratch for THIS call (host-side use only)
     int xmode;                       // arithmetic of the 128x128-tile forms: 0 fp32 pipe, 1 bf16x3 split, 2 bf16 operands
     int no_splitk;                   // SUBGC_GEMM_NO_SPLITK of this call (measurement scripts)
+    int planes_only = 0;             // subgc_gemm_f32_planes: split-K forms leave their partial planes in `ws` (no reduce pass)
+    int* splits_out = nullptr;       // ... and report how many (1 = the plain kernel wrote C)
 };
 
 constexpr int BK = 32;
@@ -531,6 +533,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     using SB = Stage<BN, !TB>;
     const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
+    if (a.splits_out) *a.splits_out = 1;
     static uint64_t attr_set = 0;
     if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>), grid, dim3(XM ? 512 : 256), lds, s, a);
@@ -568,7 +571,8 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits, bool reduce = tr
     static uint64_t attr_set = 0;
     if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
     hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, a.ws, splits, per);
-    if (!reduce) return subgc::check_launch("subgc_gemm_f32(split-K, partials)");   // the consumer sums the planes itself
+    if (a.splits_out) *a.splits_out = splits;
+    if (!reduce || a.planes_only) return subgc::check_launch("subgc_gemm_f32(split-K, partials)");   // the consumer sums the planes itself
     const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);
@@ -652,6 +656,30 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
         const int rc = subgc::gemm_skinny_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, (flags & SUBGC_GEMM_RELU) ? 1 : 0, s, add, ldadd);
         if (rc != -100) return rc;      // -100: shape not covered by the weight-streaming form
     }
+    if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);
+    if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
+    return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
+}
+
+// op(A) op(B) as `*n_planes` fp32 partial planes planes[q][M][N] (plane stride M * N) whose SUM is the product: the split-K forms of the
+// dispatch without their reduce pass, for a consumer that adds the planes while it reads them (subgc_lstm_bwd_planes,
+// subgc_attn_bwd_planes); *n_planes = 1 when the dispatch does not split (the plain kernel then wrote plane 0).
+SUBGC_API int subgc_gemm_f32_planes(int transA, int transB, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                    float* planes, size_t planes_bytes, int* n_planes, int flags, void* stream) {
+    SUBGC_REQUIRE(M > 0 && N > 0 && K > 0 && n_planes, "gemm_f32_planes: bad sizes");
+    SUBGC_REQUIRE(A && B && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && planes_bytes >= (size_t)M * N * sizeof(float),
+                  "gemm_f32_planes: null / misaligned / too small plane buffer");
+    SUBGC_REQUIRE(!(transA && transB), "gemm_f32_planes: transA && transB not supported");
+    SUBGC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm_f32_planes: leading dimension too small");
+    const int mode_bits = (flags >> 4) & 3;
+    GemmArgs a{A, B, planes, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, N, 0, M, N, K, 0, 1.f,
+               planes, planes_bytes, mode_bits ? mode_bits - 1 : g_x3, (flags & SUBGC_GEMM_NO_SPLITK) ? 1 : 0, 1, n_planes};
+    *n_planes = 1;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vecA = aligned16(A) && lda % 4 == 0 && (transA ? M % 4 == 0 : K % 4 == 0);
+    const bool vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0);
+    const bool vec = vecA && vecB;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
     if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);
     if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
     return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);

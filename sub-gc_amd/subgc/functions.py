@@ -765,21 +765,27 @@ class DecoderFn(Function):
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(T, S, R) if defer_dv else None
         dWa, dBa = new(T, S, A), new(T, S)                     # per-(step, sentence) partials of alpha_net's gradient
-        dH1 = [zer(S, 2 * R), new(S, 2 * R)]          # [next, cur] ping-pong
-        dH2 = [zer(S, 3 * R), new(S, 3 * R)]
-        dC1 = [zer(S, R), new(S, R)]
+        # The three recurrent data-gradient products of a step are split-K on <= a few hundred rows; their results are read exactly
+        # once (d(ctx) by the attention backward, d(h) by the two cell backwards), so they stay as partial PLANES that the consumers
+        # add on load (subgc_gemm_*_planes, subgc_lstm_bwd_planes, subgc_attn_bwd_planes): no reduce launches, no summed copies.
+        PA, PB, PC = new(8 * S * 3 * R), new(8 * S * R), new(8 * S * 2 * R)
+        sA = sC = None                                # (planes, N, n, stride, rows) of the previous step's dP2.Wc2 / dP1.Wc1
+        win = lambda st, col0: None if st is None else (st[0], st[1], col0, st[2], st[3], st[4])
+        dC1 = [zer(S, R), new(S, R)]                  # [next, cur] ping-pong
         dC2 = [zer(S, R), new(S, R)]
         for t in range(T - 1, -1, -1):
-            nH1, cH1 = dH1; nH2, cH2 = dH2; nC1, cC1 = dC1; nC2, cC2 = dC2
-            ops.lstm_bwd(G2[t], C2[t], C2[t + 1], nH1[:, :R], nH2[:, 2 * R:], dHout[:, t, :], None if k_out is None else k_out[t],
-                         scale, nC2, dP2[t], cC2, S, R)
-            ops.gemm(dP2[t], Wc2, cH2)                                     # -> [dctx | dh1 | dh2_prev]
-            pr.attn_bwd(AH[t], an_w, lens, AL[t], cH2[:, :R], dAH[t], du, None if defer_dv else dv, dWa[t], dBa[t], S, A, R,
+            nC1, cC1 = dC1; nC2, cC2 = dC2
+            ops.lstm_bwd_planes(G2[t], C2[t], C2[t + 1], [win(sC, 0), win(sA, 2 * R)], dHout[:, t, :], None if k_out is None else k_out[t],
+                                scale, nC2, dP2[t], cC2, S, R)
+            n, st = ops.gemm_planes(dP2[t], Wc2, PA)                       # -> [dctx | dh1 | dh2_prev]
+            sA = (PA, 3 * R, n, st, S)
+            pr.attn_bwd(AH[t], an_w, lens, AL[t], win(sA, 0), dAH[t], du, None if defer_dv else dv, dWa[t], dBa[t], S, A, R,
                         dCtx[t] if defer_dv else None)
-            ops.gemm(dAH[t], W[17], cH2[:, R:2 * R], accum=True)           # h1 also feeds the attention query
-            ops.lstm_bwd(G1[t], C1[t], C1[t + 1], cH2[:, R:2 * R], nH1[:, R:], None, None, 1.0, nC1, dP1[t], cC1, S, R)
-            ops.gemm(dP1[t], Wc1, cH1)                                     # -> [dh2_prev | dh1_prev]
-            dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
+            n, st = ops.gemm_planes(dAH[t], W[17], PB)                     # h1 also feeds the attention query
+            ops.lstm_bwd_planes(G1[t], C1[t], C1[t + 1], [win(sA, R), (PB, R, 0, n, st, S), win(sC, R)], None, None, 1.0, nC1, dP1[t], cC1, S, R)
+            n, st = ops.gemm_planes(dP1[t], Wc1, PC)                       # -> [dh2_prev | dh1_prev]
+            sC = (PC, 2 * R, n, st, S)
+            dC1.reverse(); dC2.reverse()
 
         if defer_dv:
             pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), torch.arange(T + 1, device=dev, dtype=torch.int32) * S, T, lens, dv, S, R)

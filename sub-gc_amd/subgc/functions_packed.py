@@ -217,27 +217,30 @@ class PackedDecoderLossFn(Function):
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(max(rows, 1), R) if defer_dv else None
         dWa, dBa = new(max(rows, 1), A), new(max(rows, 1))     # per-(step, sentence) partials of alpha_net's gradient
-        # rows that are dead at step t+1 but live at step t enter the recurrence with zero state-gradient:
-        # both ping-pong buffers start zeroed and a row >= M[t+1] is never written before step t reads it
-        arena = zer(2 * S * 7 * R)                             # the eight ping-pong buffers below: one fill instead of eight
-        cut, pos = [], 0
-        for width in (2 * R, 2 * R, 3 * R, 3 * R, R, R, R, R):
-            cut.append(arena[pos:pos + S * width].view(S, width))
-            pos += S * width
-        dH1, dH2, dC1, dC2 = cut[0:2], cut[2:4], cut[4:6], cut[6:8]
+        # The recurrent data-gradient products stay as split-K partial PLANES that their consumers add on load (see DecoderFn.backward).
+        # Rows that are dead at step t+1 but live at step t enter the recurrence with zero state-gradient: a plane source only
+        # contributes to the rows its own step had (`rows` of the window), and the cell-state ping-pong starts zeroed with a row
+        # >= M[t+1] never written before step t reads it.
+        PA, PB, PC = new(8 * S * 3 * R), new(8 * S * R), new(8 * S * 2 * R)
+        sA = sC = None
+        win = lambda st, col0: None if st is None else (st[0], st[1], col0, st[2], st[3], st[4])
+        arena = zer(4 * S * R)
+        dC1, dC2 = [arena[:S * R].view(S, R), arena[S * R:2 * S * R].view(S, R)], [arena[2 * S * R:3 * S * R].view(S, R), arena[3 * S * R:].view(S, R)]
         for t in range(T_live - 1, -1, -1):
             m, o = M[t], ot[t]
-            nH1, cH1 = dH1; nH2, cH2 = dH2; nC1, cC1 = dC1; nC2, cC2 = dC2
-            ops.lstm_bwd(G2[o:o + m], C2[t][:m], C2[t + 1][:m], nH1[:m, :R], nH2[:m, 2 * R:], dHout[o:o + m],
-                         None if k_out is None else k_out[t], scale, nC2[:m], dP2[o:o + m], cC2[:m], m, R)
-            ops.gemm(dP2[o:o + m], Wc2, cH2[:m])
-            pr.attn_bwd(AH[o:o + m], an_w, lens_p, AL[o:o + m], cH2[:m, :R], dAH[o:o + m], du, None if defer_dv else dv,
+            nC1, cC1 = dC1; nC2, cC2 = dC2
+            ops.lstm_bwd_planes(G2[o:o + m], C2[t][:m], C2[t + 1][:m], [win(sC, 0), win(sA, 2 * R)], dHout[o:o + m],
+                                None if k_out is None else k_out[t], scale, nC2[:m], dP2[o:o + m], cC2[:m], m, R)
+            n, st = ops.gemm_planes(dP2[o:o + m], Wc2, PA)
+            sA = (PA, 3 * R, n, st, m)
+            pr.attn_bwd(AH[o:o + m], an_w, lens_p, AL[o:o + m], win(sA, 0), dAH[o:o + m], du, None if defer_dv else dv,
                         dWa[o:o + m], dBa[o:o + m], m, A, R, dCtx[o:o + m] if defer_dv else None)
-            ops.gemm(dAH[o:o + m], W[17], cH2[:m, R:2 * R], accum=True)
-            ops.lstm_bwd(G1[o:o + m], C1[t][:m], C1[t + 1][:m], cH2[:m, R:2 * R], nH1[:m, R:], None, None, 1.0, nC1[:m], dP1[o:o + m],
-                         cC1[:m], m, R)
-            ops.gemm(dP1[o:o + m], Wc1, cH1[:m])
-            dH1.reverse(); dH2.reverse(); dC1.reverse(); dC2.reverse()
+            n, st = ops.gemm_planes(dAH[o:o + m], W[17], PB)
+            ops.lstm_bwd_planes(G1[o:o + m], C1[t][:m], C1[t + 1][:m], [win(sA, R), (PB, R, 0, n, st, m), win(sC, R)], None, None, 1.0, nC1[:m],
+                                dP1[o:o + m], cC1[:m], m, R)
+            n, st = ops.gemm_planes(dP1[o:o + m], Wc1, PC)
+            sC = (PC, 2 * R, n, st, m)
+            dC1.reverse(); dC2.reverse()
 
         P1, P2, H1a, H2a = dP1[:rows], dP2[:rows], H1[:rows], H2[:rows]
         wgrad(13, P2, H2a[:, :2 * R])

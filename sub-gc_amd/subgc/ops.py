@@ -607,6 +607,49 @@ def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdro
          xb | (_same_storage(h, h2, hdrop) << 1), GEMM_MODES[gemm_mode.current], *_ws(x), _stream())
 
 
+def gemm_planes(a, b, planes, *, ta=False, tb=False):
+    """op(a) @ op(b) left as n fp32 partial planes planes[q][M][N] whose sum is the product (subgc_gemm_*_planes: the split-K forms
+    without their reduce pass; n = 1 when the dispatch does not split).  `planes`: a flat fp32 buffer of >= 8*M*N elements.
+    -> (n, M * N)"""
+    import ctypes
+    M = a.size(1) if ta else a.size(0)
+    K = a.size(0) if ta else a.size(1)
+    N = b.size(0) if tb else b.size(1)
+    if K != (b.size(1) if tb else b.size(0)):
+        raise SubgcError("gemm_planes: shape mismatch")
+    n = ctypes.c_int(0)
+    if FLOPS["on"]:
+        eb = 2.0 if is_b16(a) else 4.0
+        FLOPS["gemm"] += 2.0 * M * N * K
+        FLOPS["gemm_bytes"] += eb * (M * K + K * N) + 4.0 * M * N
+        FLOPS["gemm_calls"] += 1
+    if is_b16(a) or is_b16(b):
+        if not (is_b16(a) and is_b16(b)):
+            raise SubgcError("gemm_planes: both operands bf16 or both fp32")
+        call("subgc_gemm_bf16_planes", int(ta), int(tb), M, N, K, _ptr(a, BF16), ld(a), _ptr(b, BF16), ld(b), _ptr(planes, torch.float32), planes.numel() * 4,
+             ctypes.byref(n), _stream())
+    else:
+        call("subgc_gemm_f32_planes", int(ta), int(tb), M, N, K, _ptr(a, torch.float32), ld(a), _ptr(b, torch.float32), ld(b), _ptr(planes, torch.float32),
+             planes.numel() * 4, ctypes.byref(n), GEMM_MODES[gemm_mode.current] | gemm_tune.f32_bits, _stream())
+    return n.value, M * N
+
+
+def lstm_bwd_planes(gates, c_prev, c, srcs, dh_drop, keep, scale, dc, dpre, dc_prev, S, R):
+    """lstm_bwd whose d(h) sources are column windows of split-K plane stacks: srcs = up to three (planes, N, col0, n, stride, rows)
+    -- `planes` the flat buffer gemm_planes filled ([n][rows][N]), the window starts at column col0; n = 0 entries are skipped."""
+    args = []
+    srcs = [x for x in srcs if x is not None and x[3] > 0]
+    for k in range(3):
+        if k < len(srcs):
+            buf, N, col0, n, stride, rows = srcs[k]
+            args += [buf.data_ptr() + 4 * col0, N, n, stride, rows]
+        else:
+            args += [None, 0, 0, 0, 0]
+    L = lambda t: ld(t) if t is not None else 0
+    call("subgc_lstm_bwd_planes", _ptr(gates), _ptr(c_prev), _ptr(c), *args, _ptr(dh_drop), L(dh_drop), _ptr(keep, torch.uint8), float(scale), _ptr(dc),
+         _ptr(dpre), _ptr(dc_prev), S, R, int(is_b16(dpre)), _stream())
+
+
 def lstm_bwd(gates, c_prev, c, dh_a, dh_b, dh_drop, keep, scale, dc, dpre, dc_prev, S, R):
     """dpre [S, 4R] contiguous rows, fp32 or bf16 (the gate gradients only feed GEMMs and bias sums)."""
     L = lambda t: ld(t) if t is not None else 0
@@ -635,11 +678,21 @@ def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R):
          _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), _stream())
 
 
+def _dctx_args(dctx):
+    """d(ctx) as (pointer, ld, planes, plane stride): a 2-D view, or a window (planes, N, col0, n, stride, rows) of a plane stack."""
+    if isinstance(dctx, tuple):
+        buf, N, col0, n, stride, _rows = dctx
+        return buf.data_ptr() + 4 * col0, N, n, stride
+    return _ptr(dctx, torch.float32), ld(dctx), 1, 0
+
+
 def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R, dctx_keep=None):
-    """dv None: d(v) is deferred to one `attn_dv_accum` after the time loop; `dctx_keep` [S, R] then receives this step's d(ctx) rows."""
+    """dv None: d(v) is deferred to one `attn_dv_accum` after the time loop; `dctx_keep` [S, R] then receives this step's d(ctx) rows.
+    `dctx`: a 2-D view or a plane-stack window (see _dctx_args): the split-K planes of the data-gradient GEMM are summed on load."""
     _attn_account(lens, S, A, R, 3 if dv is not None else 2)      # read u, v; read-modify-write du (and dv)
-    call("subgc_attn_bwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
-         alpha.size(1), _ptr(dctx), ld(dctx), _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R,
+    dp, dl, dn, ds = _dctx_args(dctx)
+    call("subgc_attn_bwd_planes", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
+         alpha.size(1), dp, dl, dn, ds, _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R,
          int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
 
 
@@ -659,9 +712,10 @@ def attn_fwd_group(u, v, ah, w_a, b_a, rows, lens, m, B, g, Nn, ctx, alpha, A, R
 
 def attn_bwd_group(u, v, ah, w_a, rows, lens, m, B, g, Nn, alpha, dctx, dah, du, dw_a, db_a, A, R, dctx_keep):
     _attn_account_group(B, Nn, A, R, 2)
+    dp, dl, dn, ds = _dctx_args(dctx)
     call("subgc_attn_bwd_group", _ptr(u), _ptr(v), _ptr(ah, torch.float32), _ptr(w_a), _ptr(rows, torch.int32), _ptr(lens, torch.int32), int(m), B, g, Nn,
-         _ptr(alpha, torch.float32), alpha.size(1), _ptr(dctx, torch.float32), ld(dctx), _ptr(dah), _ptr(du, torch.float32), _ptr(dw_a), _ptr(db_a), A, R,
-         int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
+         _ptr(alpha, torch.float32), alpha.size(1), dp, dl, _ptr(dah), _ptr(du, torch.float32), _ptr(dw_a), _ptr(db_a), A, R,
+         int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, dn, ds, _stream())
 
 
 def attn_dv_accum_group(alpha, dctx, step_off, T, rows, B, g, Nn, dv, R):
