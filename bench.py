@@ -169,18 +169,27 @@ def decode_bench(model_sd, dev, images, M):
         torch.cuda.synchronize()
         us_step = 1e3 * e0.elapsed_time(e1) / 20 / steps
         gbps = bytes_step / (us_step * 1e-6) / 1e9
-        traffic, pmc_path = None, os.path.join(ROOT, "profiles", "r02_pmc_decode.json")
-        if os.path.exists(pmc_path):                      # committed PMC passes over the same loop: 2 LSTM + 2 plain weight-streaming launches per step
+        traffic, pmc_name = None, None
+        for rnd in ("r03", "r02"):                       # committed PMC passes over the same loop (tools/pmc_decode.sh)
+            pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_decode.json")
+            if not os.path.exists(pmc_path):
+                continue
             with open(pmc_path) as f:
                 kk = json.load(f)["kernels"]
-            traffic = 2 * (kk["lstm"]["hbm_fetch_bytes_per_launch"] + kk["lstm"]["hbm_write_bytes_per_launch"]) + \
-                2 * (kk["plain_1tile"]["hbm_fetch_bytes_per_launch"] + kk["plain_1tile"]["hbm_write_bytes_per_launch"])
+            per = lambda k_: kk[k_]["hbm_fetch_bytes_per_launch"] + kk[k_]["hbm_write_bytes_per_launch"]
+            if "logits_pick" in kk:                      # r03 loop: 2 LSTM launches, h2att (plain) and the logits launch with the pick epilogue
+                traffic, pmc_name = 2 * per("lstm") + per("plain_1tile") + per("logits_pick"), f"{rnd}_pmc_decode.json"
+                break
+            if not getattr(m, "decode_fused_pick", True):
+                traffic, pmc_name = 2 * per("lstm") + 2 * per("plain_1tile"), f"{rnd}_pmc_decode.json"
+                break
         out["decode_roofline"] = {"bound": "hbm", "kernel": "gemm_skinny_mfma_kernel (weight streaming, M <= 16 rows)", "achieved": round(gbps, 1),
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                                  "traffic_unit": "bytes fetched + written past L2 per token step (profiles/r02_pmc_decode.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_decode.sh)",
+                                  "traffic_unit": f"bytes fetched + written past L2 per token step (profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_decode.sh)",
                                   "bytes_per_step": round(bytes_step), "us_per_step": round(us_step, 2), "steps_per_replay": steps,
-                                  "note": "whole replayed token loop of one image (10 sub-graphs; 5 launches per step + the in-graph survivor "
-                                          "gathers) / 21 steps; the 120 MB of weights fit the 256 MiB Infinity Cache, so the HBM roof is generous"}
+                                  "note": "whole replayed token loop of one image (10 sub-graphs; 5 launches per step -- att-LSTM (files the previous pick), h2att, "
+                                          "attention, lang-LSTM, logits with the arg-max epilogue -- + the in-graph survivor gathers) / 21 steps; "
+                                          "the 120 MB of weights fit the 256 MiB Infinity Cache, so the HBM roof is generous"}
     # the same images, decoded `group` at a time as one batch (sample_images): same tokens per image, weights streamed once per step
     group = min(256, images)                              # sized for 288 GB: 2560 sub-graph rows per decode step
     m.sample_images(batches[:group], opt=sopt)

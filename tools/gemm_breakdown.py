@@ -68,6 +68,25 @@ def main():
         if getattr(mod, "gemm", None) is real:
             mod.gemm = timed
     ops.gemm = timed
+    real_planes, real_lstm = ops.gemm_planes, ops.lstm_fwd_gemm
+
+    def timed_planes(a_, b_, planes, *, ta=False, tb=False):
+        M, K, N = a_.size(0), a_.size(1), b_.size(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real_planes(a_, b_, planes, ta=ta, tb=tb)
+        e1.record()
+        rec.append(("nn", M, N, K, "P%d" % r[0], e0, e1))
+        return r
+
+    def timed_lstm(x, w, *rest, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_lstm(x, w, *rest, **kw)
+        e1.record()
+        rec.append(("nt", x.size(0), w.size(0), x.size(1), "L", e0, e1))      # includes the cell kernel
+
+    ops.gemm_planes, ops.lstm_fwd_gemm = timed_planes, timed_lstm
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
     step()

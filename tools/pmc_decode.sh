@@ -1,7 +1,8 @@
-# FETCH_SIZE / WRITE_SIZE of the one-image decode loop's weight-streaming kernels -> gpurun_out/r02_pmc_decode.json
+# FETCH_SIZE / WRITE_SIZE of the one-image decode loop's weight-streaming kernels -> gpurun_out/${ROUND}_pmc_decode.json (ROUND=r03 by default)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
+ROUND=${ROUND:-r03}
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmcd_$C
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmcd_$C -- python $R/tools/decode_bench.py 16 50 > $O/pmcd_$C.log 2>&1
@@ -15,13 +16,16 @@ def load(c):
         k = r["Kernel_Name"]
         if "gemm_skinny_mfma_kernel" not in k:
             continue
-        key = "lstm" if "true, 1>" in k or "true, 2>" in k else ("plain_1tile" if "false, 1>" in k else "other")
+        import re
+        a = [x.strip() for x in re.search(r"gemm_skinny_mfma_kernel<([^>]*)>", k).group(1).split(",")]     # WAVES, D, LSTM, MT, PICK, WB16
+        lstm, mt, pick = a[2] == "true", a[3], len(a) > 4 and a[4] == "true"
+        key = "lstm" if lstm else ("logits_pick" if pick else ("plain_1tile" if mt == "1" else "other"))
         d[key][0] += 1; d[key][1] += float(r["Counter_Value"])
     return d
 f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/decode_bench.py 16 50 (tools/pmc_decode.sh); FETCH x 2.0 (gfx950), KB -> bytes",
        "kernels": {k: {"launches": f[k][0], "hbm_fetch_bytes_per_launch": round(f[k][1] * 2.0 * 1024 / max(f[k][0], 1)),
                        "hbm_write_bytes_per_launch": round(w[k][1] * 1024 / max(w[k][0], 1))} for k in f}}
-json.dump(out, open("$O/r02_pmc_decode.json", "w"), indent=1)
+json.dump(out, open("$O/${ROUND}_pmc_decode.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -1,10 +1,10 @@
-# End-of-round evidence (ROUND=r02 by default): the default bench line, the bf16 config lines, rocprofv3 kernel stats of the
+# End-of-round evidence (ROUND=r03 by default): the default bench line, the bf16 config lines, rocprofv3 kernel stats of the
 # train legs and of the one-image decode, and the two PMC passes behind roofline.traffic.  Everything lands in gpurun_out/ as
 # ${ROUND}_*; copy the summaries to profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 python $R/bench.py > $O/${ROUND}_bench_n1.log 2>&1; tail -1 $O/${ROUND}_bench_n1.log > $R/profiles/${ROUND}_bench_n1.json
 cp $R/profiles/${ROUND}_bench_n1.json $O/${ROUND}_bench_n1.json          # profiles/ on the box is not merged back, gpurun_out/ is
 for C in full_gc_kar flickr; do
@@ -16,13 +16,13 @@ prof() {  # name, command...
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- "$@" > $O/prof_$name.log 2>&1
   timeout 120 python $R/tools/rocprof_summary.py $O/prof_$name $O/${ROUND}_${name}_kernel_stats.txt > /dev/null
 }
-prof train python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-decode --packed-only
+prof train python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-decode --packed-only --no-other-configs
 prof full_gc_kar python $R/bench.py --config full_gc_kar --steps 8 --warmup 2
 prof flickr python $R/bench.py --config flickr --steps 8 --warmup 2
 prof decode python $R/tools/decode_bench.py
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode --packed-only > $O/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode --packed-only --no-other-configs > $O/pmc_$C.log 2>&1
 done
 LPS=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1.json'))['roofline']['launches_per_step'])")
 ALG=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1.json'))['roofline']['algorithmic_bytes_per_launch'])")
