@@ -476,7 +476,9 @@ int subgc_pick_lse_finish(const float* lse_part, int V, int S, int T, const int3
  *   the sentence takes part iff 0 <= rows[b*g+j] < m.  lens int32 [by row]: valid nodes (<= Nn <= 128).  g <= 8.
  *   fwd: ctx[row] (fp32 / bf16: bit 0), alpha[row, 0..n_stride).  bwd: dah[row] (fp32 / bf16: bit 0), du [B*Nn, A] += (zero it
  *   before the first step), dw_a[row, A] / db_a[row] per-sentence partials, dctx_keep[row] (may be NULL) = this step's d(ctx) rows;
- *   d(ctx) = sum of dctx_planes planes dctx + q * plane_stride (1, 0: a plain array).
+ *   d(ctx) = sum of dctx_planes planes dctx + q * plane_stride (1, 0: a plain array).  An image is served by
+ *   subgc_attn_group_du_planes(g) workgroups (1 or 2: a second wave per SIMD hides the tanh chains' latency); each accumulates into
+ *   its own d(u) plane du + p * du_plane_stride -- the caller zeroes du_planes planes and adds them after the last step.
  *   dv_accum: dv [B*Nn, R] = sum over steps t and live sentences of alpha_t[row, i] * dctx_t[row, :]; step t's rows start at
  *   step_off[t] with step_off[t+1] - step_off[t] of them live (every row of dv is written).                                      */
 int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
@@ -485,7 +487,8 @@ int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const fl
 int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,
                          int B, int g, int Nn, const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du,
                          float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, int dctx_planes,
-                         int64_t plane_stride, void* stream);
+                         int64_t plane_stride, int du_planes, int64_t du_plane_stride, void* stream);
+int subgc_attn_group_du_planes(int g);
 int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,
                               const int32_t* rows, int B, int g, int Nn, float* dv, int R, void* stream);
 

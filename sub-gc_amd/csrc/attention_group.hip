@@ -23,6 +23,19 @@ template <bool UV16>
 __device__ __forceinline__ float4 ldx(const void* base, int64_t i) {
     return UV16 ? subgc_load4_bf(static_cast<const uint16_t*>(base) + i) : ld4(static_cast<const float*>(base) + i);
 }
+// sum over the 64 lanes of N values at once: the six exchange steps are shared, so N independent ds_bpermute chains overlap instead
+// of running back to back (a lone wave_sum is six DEPENDENT cross-lane exchanges, ~1 us; the kernels below need 45 per wave)
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float t[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], o, 64);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += t[k];
+    }
+}
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ void fma4(float4& acc, float a, float4 x) { acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w; }
 
@@ -35,8 +48,9 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
     __shared__ float e_s[G][GL];
     __shared__ int row_s[G], len_s[G];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int j0 = blockIdx.y * G;                                     // this workgroup's share of the image's sentences (see the entry point)
     if (t < G) {
-        const int r = t < g ? rows[b * g + t] : -1;
+        const int r = j0 + t < g ? rows[b * g + j0 + t] : -1;
         const bool live = r >= 0 && r < m;
         row_s[t] = live ? r : -1;
         len_s[t] = live ? min(min(lens[r], Nn), GL) : 0;
@@ -44,37 +58,56 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
     for (int i = t; i < G * GL; i += 256) (&e_s[0][0])[i] = 0.f;
     __syncthreads();
     int lmax = 0;
+    int len_r[G], row_r[G];                                            // registers: the unrolled sentence loops index them statically
 #pragma unroll
-    for (int j = 0; j < G; ++j) lmax = max(lmax, len_s[j]);
+    for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); }
     if (lmax == 0) return;
     const int64_t m0 = (int64_t)b * Nn;
     const int A4 = A >> 2, R4 = R >> 2;
     // scores: wave per node; the node's u chunk is loaded once and scored against every sentence's query
     {
-        float4 q[G][CA], w[CA];
+        float4 q_[G][CA], w[CA];
 #pragma unroll
         for (int c = 0; c < CA; ++c) {
             const int a4 = lane + c * 64;
             const bool ok = a4 < A4;
             w[c] = ok ? ld4(w_a + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < G; ++j) q[j][c] = (ok && row_s[j] >= 0) ? ld4(ah + (int64_t)row_s[j] * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < G; ++j) q_[j][c] = (ok && row_s[j] >= 0) ? ld4(ah + (int64_t)row_s[j] * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const float ba = b_a[0];
-        for (int i = wave; i < lmax; i += 4) {
-            float4 x[CA];
+        // One wave per SIMD and every node row a compulsory HBM / Infinity-Cache miss (~2 us): nothing hides a load but other loads,
+        // so a wave requests the rows of NCH of its nodes at once and scores them when they have landed (9 exposed round trips of
+        // a 36-node image become 3; measured 58 -> 40 us came from the tanh alone, the rest is this latency).
+        constexpr int NCH = 3;
+        for (int i0 = wave; i0 < lmax; i0 += 4 * NCH) {
+            float4 x[NCH][CA];
 #pragma unroll
-            for (int c = 0; c < CA; ++c) x[c] = (lane + c * 64 < A4) ? ldx<UV16>(u, (m0 + i) * A + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                if (i >= len_s[j]) continue;                       // wave-uniform
-                float acc = 0.f;
+            for (int q = 0; q < NCH; ++q)
 #pragma unroll
                 for (int c = 0; c < CA; ++c)
-                    acc += w[c].x * subgc_tanh(x[c].x + q[j][c].x) + w[c].y * subgc_tanh(x[c].y + q[j][c].y) + w[c].z * subgc_tanh(x[c].z + q[j][c].z) +
-                           w[c].w * subgc_tanh(x[c].w + q[j][c].w);
-                acc = wave_sum(acc);
-                if (lane == 0) e_s[j][i] = acc + ba;
+                    x[q][c] = (i0 + 4 * q < lmax && lane + c * 64 < A4) ? ldx<UV16>(u, (m0 + i0 + 4 * q) * A + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float sc[NCH * G];
+#pragma unroll
+            for (int q = 0; q < NCH; ++q)
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    float acc = 0.f;
+                    if (i0 + 4 * q < len_r[j]) {                       // wave-uniform
+#pragma unroll
+                        for (int c = 0; c < CA; ++c)
+                            acc += w[c].x * subgc_tanh(x[q][c].x + q_[j][c].x) + w[c].y * subgc_tanh(x[q][c].y + q_[j][c].y) + w[c].z * subgc_tanh(x[q][c].z + q_[j][c].z) +
+                                   w[c].w * subgc_tanh(x[q][c].w + q_[j][c].w);
+                    }
+                    sc[q * G + j] = acc;
+                }
+            wave_sum_n<NCH * G>(sc);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q)
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        if (i0 + 4 * q < len_r[j]) e_s[j][i0 + 4 * q] = sc[q * G + j] + ba;
             }
         }
     }
@@ -107,6 +140,15 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
         for (int j = 0; j < G; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int64_t vp = m0 * R + r4 * 4;
         int i = 0;
+        for (; i + 12 <= lmax; i += 12) {                          // twelve node rows in flight per thread: 3 round trips for 36 nodes
+            float4 x[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) x[q] = ldx<UV16>(v, vp + (int64_t)(i + q) * R);
+#pragma unroll
+            for (int q = 0; q < 12; ++q)
+#pragma unroll
+                for (int j = 0; j < G; ++j) fma4(acc[j], e_s[j][i + q], x[q]);
+        }
         for (; i + 2 <= lmax; i += 2) {
             const float4 x0 = ldx<UV16>(v, vp + (int64_t)i * R), x1 = ldx<UV16>(v, vp + (int64_t)(i + 1) * R);
 #pragma unroll
@@ -133,22 +175,26 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
                                                              const float* __restrict__ alpha, int n_stride, const float* __restrict__ dctx,
                                                              int64_t lddctx, void* __restrict__ dah, float* __restrict__ du,
                                                              float* __restrict__ dw_a, float* __restrict__ db_a, int A, int R, int dah_b16,
-                                                             float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride) {
+                                                             float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride,
+                                                             int64_t du_split_stride) {
     __shared__ float al_s[G][GL];     // alpha, then de
     __shared__ float da_s[G][GL];
     __shared__ float4 part_d[G][128], part_w[G][128];
     __shared__ int row_s[G], len_s[G];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int j0 = blockIdx.y * G;                                     // this workgroup's share of the image's sentences; it accumulates
+    du += (int64_t)blockIdx.y * du_split_stride;                      // into ITS plane of d(u) (the caller adds the planes)
     if (t < G) {
-        const int r = t < g ? rows[b * g + t] : -1;
+        const int r = j0 + t < g ? rows[b * g + j0 + t] : -1;
         const bool live = r >= 0 && r < m;
         row_s[t] = live ? r : -1;
         len_s[t] = live ? min(min(lens[r], Nn), GL) : 0;
     }
     __syncthreads();
     int lmax = 0;
+    int len_r[G], row_r[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) lmax = max(lmax, len_s[j]);
+    for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); }
     if (lmax == 0) return;
     for (int i = t; i < G * GL; i += 256) {
         const int j = i / GL, k = i - j * GL;
@@ -159,38 +205,54 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
     const int64_t m0 = (int64_t)b * Nn;
     const int A4 = A >> 2, R4 = R >> 2;
     {
-        // dalpha_i = <dctx_j, v_i>: wave per node, the node's v chunks loaded once; each lane keeps its dctx chunks of every sentence
+        // d(ctx) of the image's sentences: the split-K planes are added on load by ALL threads at once (one round trip) and the sums
+        // staged in LDS (G x R floats); a sentence's kept copy (dctx_keep) is written from there
+        extern __shared__ __attribute__((aligned(16))) float dctx_s[];      // [G][R4] float4
+        float4* gs = reinterpret_cast<float4*>(dctx_s);
+        for (int idx = t; idx < G * R4; idx += 256) {
+            const int j = idx / R4, c = idx - j * R4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_r[j] >= 0)
+                for (int q = 0; q < n_planes; ++q) {
+                    const float4 x = ld4(dctx + q * plane_stride + (int64_t)row_s[j] * lddctx + c * 4);
+                    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+                }
+            gs[idx] = a;
+            if (dctx_keep && row_s[j] >= 0) st4(dctx_keep + (int64_t)row_s[j] * ldkeep + c * 4, a);
+        }
+        __syncthreads();
+        // dalpha_i = <dctx_j, v_i>: wave per node; the rows of NCH of the wave's nodes are requested at once, and the NCH x G dot
+        // products are reduced over the lanes TOGETHER
         float4 gd[G][CR64];
 #pragma unroll
         for (int j = 0; j < G; ++j)
 #pragma unroll
-            for (int c = 0; c < CR64; ++c) {
-                gd[j][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_s[j] >= 0 && lane + c * 64 < R4)
-                    for (int q = 0; q < n_planes; ++q) {             // split-K partial planes of the data-gradient GEMM, summed on load
-                        const float4 x = ld4(dctx + q * plane_stride + (int64_t)row_s[j] * lddctx + (lane + c * 64) * 4);
-                        gd[j][c].x += x.x; gd[j][c].y += x.y; gd[j][c].z += x.z; gd[j][c].w += x.w;
-                    }
-            }
-        if (dctx_keep && wave == 0) {
+            for (int c = 0; c < CR64; ++c) gd[j][c] = (lane + c * 64 < R4) ? gs[j * R4 + lane + c * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int NCH = 3;
+        for (int i0 = wave; i0 < lmax; i0 += 4 * NCH) {
+            float4 x[NCH][CR64];
 #pragma unroll
-            for (int j = 0; j < G; ++j)
+            for (int q = 0; q < NCH; ++q)
 #pragma unroll
                 for (int c = 0; c < CR64; ++c)
-                    if (row_s[j] >= 0 && lane + c * 64 < R4) st4(dctx_keep + (int64_t)row_s[j] * ldkeep + (lane + c * 64) * 4, gd[j][c]);
-        }
-        for (int i = wave; i < lmax; i += 4) {
-            float4 x[CR64];
+                    x[q][c] = (i0 + 4 * q < lmax && lane + c * 64 < R4) ? ldx<UV16>(v, (m0 + i0 + 4 * q) * R + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float sc[NCH * G];
 #pragma unroll
-            for (int c = 0; c < CR64; ++c) x[c] = (lane + c * 64 < R4) ? ldx<UV16>(v, (m0 + i) * R + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < NCH; ++q)
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                if (i >= len_s[j]) continue;
-                float acc = 0.f;
+                for (int j = 0; j < G; ++j) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int c = 0; c < CR64; ++c) acc += dot4(gd[j][c], x[c]);
-                acc = wave_sum(acc);
-                if (lane == 0) da_s[j][i] = acc;
+                    for (int c = 0; c < CR64; ++c) acc += dot4(gd[j][c], x[q][c]);
+                    sc[q * G + j] = acc;
+                }
+            wave_sum_n<NCH * G>(sc);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q)
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        if (i0 + 4 * q < len_r[j]) da_s[j][i0 + 4 * q] = sc[q * G + j];
             }
         }
     }
@@ -218,22 +280,33 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
             float4 ha[G];
 #pragma unroll
             for (int j = 0; j < G; ++j) ha[j] = row_s[j] >= 0 ? ld4(ah + (int64_t)row_s[j] * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = grp; i < lmax; i += 2) {
-                const int64_t o = (m0 + i) * A + a4 * 4;
-                const float4 x = ldx<UV16>(u, o);
-                float4 d = ld4(du + o);
+            constexpr int TCH = 6;                                    // u and d(u) rows of six nodes of this stream in flight at once
+            for (int i0 = grp; i0 < lmax; i0 += 2 * TCH) {
+                float4 x[TCH], d[TCH];
 #pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    if (i >= len_s[j]) continue;
-                    const float de = al_s[j][i];
-                    const float t0 = subgc_tanh(x.x + ha[j].x), t1 = subgc_tanh(x.y + ha[j].y), t2 = subgc_tanh(x.z + ha[j].z), t3 = subgc_tanh(x.w + ha[j].w);
-                    const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
-                    const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
-                    d.x += p0; d.y += p1; d.z += p2; d.w += p3;
-                    dsum[j].x += p0; dsum[j].y += p1; dsum[j].z += p2; dsum[j].w += p3;
-                    wsum[j].x += de * t0; wsum[j].y += de * t1; wsum[j].z += de * t2; wsum[j].w += de * t3;
+                for (int q = 0; q < TCH; ++q) {
+                    const int i = i0 + 2 * q;
+                    const int64_t o = (m0 + min(i, lmax - 1)) * A + a4 * 4;
+                    x[q] = ldx<UV16>(u, o);
+                    d[q] = ld4(du + o);
                 }
-                st4(du + o, d);
+#pragma unroll
+                for (int q = 0; q < TCH; ++q) {
+                    const int i = i0 + 2 * q;
+                    if (i >= lmax) break;
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        if (i >= len_r[j]) continue;
+                        const float de = al_s[j][i];
+                        const float t0 = subgc_tanh(x[q].x + ha[j].x), t1 = subgc_tanh(x[q].y + ha[j].y), t2 = subgc_tanh(x[q].z + ha[j].z), t3 = subgc_tanh(x[q].w + ha[j].w);
+                        const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
+                        const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
+                        d[q].x += p0; d[q].y += p1; d[q].z += p2; d[q].w += p3;
+                        dsum[j].x += p0; dsum[j].y += p1; dsum[j].z += p2; dsum[j].w += p3;
+                        wsum[j].x += de * t0; wsum[j].y += de * t1; wsum[j].z += de * t2; wsum[j].w += de * t3;
+                    }
+                    st4(du + (m0 + i) * A + a4 * 4, d[q]);
+                }
             }
         }
         __syncthreads();
@@ -266,33 +339,56 @@ __global__ __launch_bounds__(256) void attn_dv_accum_group_kernel(const float* _
                                                                   const int32_t* __restrict__ rows, int g, int Nn, float* __restrict__ dv, int R,
                                                                   int tg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dv_lds[];
+    __shared__ int so_s[66], rr_s[8], flat_s[1024], nl_s;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int R4 = R >> 2, l = min(Nn, n_stride), c4 = blockIdx.y * 64 + lane;
     const bool col_ok = c4 < R4;
     float4* g_s = reinterpret_cast<float4*>(dv_lds);                      // [tg][64]
     float* a_s = reinterpret_cast<float*>(g_s + (size_t)tg * 64);         // [tg][n_stride]
+    // the step table and the image's row positions once (a dependent global read per (step, sentence) pair serialised the staging:
+    // 85 round trips, 220 us)
+    for (int i = t; i <= T; i += 256) so_s[i] = step_off[i];
+    if (t < g) rr_s[t] = rows[b * g + t];
     bool first = true;
     const int pairs = T * g;
     for (int p0 = 0; p0 < pairs || first; p0 += tg) {
         __syncthreads();
-        int nl = 0;                                                        // live pairs of this group (uniform over the workgroup)
-        for (int p = p0; p < min(pairs, p0 + tg); ++p) {
-            const int tt = p / g, j = p - tt * g;
-            const int r = rows[b * g + j], o = step_off[tt], cnt = step_off[tt + 1] - o;
-            if (r < 0 || r >= cnt) continue;
-            const int64_t flat = (int64_t)o + r;
-            if (wave == (nl & 3)) {                                        // the four waves take turns: one 1 KB row slice per wave and pair
-                g_s[(size_t)nl * 64 + lane] = col_ok ? ld4(dctx + flat * lddctx + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int i = lane; i < l; i += 64) a_s[nl * n_stride + i] = alpha[flat * n_stride + i];
+        if (t == 0) {                                                      // flat row of every live pair of this group
+            int nl = 0;
+            for (int p = p0; p < min(pairs, p0 + tg); ++p) {
+                const int tt = p / g, j = p - tt * g;
+                const int r = rr_s[j], o = so_s[tt], cnt = so_s[tt + 1] - o;
+                if (r >= 0 && r < cnt) flat_s[nl++] = o + r;
             }
-            ++nl;
+            nl_s = nl;
+        }
+        __syncthreads();
+        const int nl = nl_s;
+        // stage: all loads of the group in flight at once -- thread = (pair, float4 column) for d(ctx), (pair, node) for alpha
+        for (int idx = t; idx < nl * 64; idx += 256) {
+            const int k = idx >> 6, c = blockIdx.y * 64 + (idx & 63);
+            g_s[idx] = c < R4 ? ld4(dctx + (int64_t)flat_s[k] * lddctx + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int idx = t; idx < nl * l; idx += 256) {
+            const int k = idx / l, i = idx - k * l;
+            a_s[k * n_stride + i] = alpha[(int64_t)flat_s[k] * n_stride + i];
         }
         __syncthreads();
         if (nl == 0 && !first) continue;
         for (int i = wave; i < Nn; i += 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < l)
-                for (int k = 0; k < nl; ++k) fma4(acc, a_s[k * n_stride + i], g_s[(size_t)k * 64 + lane]);
+            if (i < l) {
+                int k = 0;
+                for (; k + 8 <= nl; k += 8) {                          // eight LDS read pairs in flight (the serial form was LDS-latency bound)
+                    float a[8];
+                    float4 x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { a[q] = a_s[(k + q) * n_stride + i]; x[q] = g_s[(size_t)(k + q) * 64 + lane]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) fma4(acc, a[q], x[q]);
+                }
+                for (; k < nl; ++k) fma4(acc, a_s[k * n_stride + i], g_s[(size_t)k * 64 + lane]);
+            }
             if (col_ok) {
                 float* dvr = dv + ((int64_t)b * Nn + i) * R + c4 * 4;
                 if (!first) { const float4 o = ld4(dvr); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
@@ -307,9 +403,15 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-#define SUBGC_G_DISPATCH(CALL)            \
-    do {                                  \
-        if (g <= 5) { CALL(5); } else { CALL(8); } \
+// An image's sentences are served by `splits` workgroups of ceil(g / splits) sentences each (blockIdx.y): with one workgroup per image
+// the chip holds ONE wave per SIMD and every dependent instruction (the tanh chains) exposes its latency; two per image re-read
+// the image's u / v rows from L2 but give every SIMD a second wave (fwd 40 -> 2x-wave figure in DESIGN 3.4).  The backward's two
+// workgroups accumulate into separate d(u) planes.
+inline int group_splits(int g) { return g >= 4 ? 2 : 1; }
+#define SUBGC_G_DISPATCH(CALL)                                   \
+    do {                                                         \
+        const int per = (g + splits - 1) / splits;               \
+        if (per <= 3) { CALL(3); } else if (per <= 5) { CALL(5); } else { CALL(8); } \
     } while (0)
 
 SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
@@ -324,16 +426,17 @@ SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah
     SUBGC_REQUIRE(ca <= 2 && cr <= 2, "attn_fwd_group: att_hid_size <= 512 and rnn_size <= 2048");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    const int splits = group_splits(g);
 #define SUBGC_FWD_G(G_)                                                                                                                              \
     do {                                                                                                                                               \
-        if (uv16) { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, true, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
-        else { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, false, G_>), dim3(B), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
+        if (uv16) { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
+        else { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
+            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
     } while (0)
     SUBGC_G_DISPATCH(SUBGC_FWD_G);
 #undef SUBGC_FWD_G
@@ -343,7 +446,7 @@ SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah
 SUBGC_API int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,
                                    int B, int g, int Nn, const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du,
                                    float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, int dctx_planes,
-                                   int64_t plane_stride, void* stream) {
+                                   int64_t plane_stride, int du_planes, int64_t du_plane_stride, void* stream) {
     const int dah_b16 = bf16_bits & 1, uv16 = (bf16_bits >> 1) & 1;
     const int n_planes = dctx_planes;
     SUBGC_REQUIRE(B >= 0 && g >= 1 && g <= 8 && Nn >= 1 && Nn <= GL && m >= 0 && A > 0 && R > 0 && n_stride > 0 && dctx_planes >= 1 && plane_stride % 4 == 0, "attn_bwd_group: bad sizes (g <= 8, Nn <= %d)", GL);
@@ -356,17 +459,21 @@ SUBGC_API int subgc_attn_bwd_group(const void* u, const void* v, const float* ah
     SUBGC_REQUIRE(ca <= 2 && cr <= 4, "attn_bwd_group: att_hid_size <= 1024 and rnn_size <= 1024");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
-#define SUBGC_BWD_ARGS u, v, ah, w_a, rows, lens, m, g, Nn, alpha, n_stride, dctx, lddctx, dah, du, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride
+    const size_t bwd_lds = (size_t)8 * R * sizeof(float);                 // d(ctx) rows of up to 8 sentences
+    SUBGC_REQUIRE(bwd_lds <= 32 * 1024, "attn_bwd_group: rnn_size <= 1024");
+    const int splits = group_splits(g);
+    SUBGC_REQUIRE(du_planes >= splits && (splits == 1 || du_plane_stride >= (int64_t)B * Nn * A), "attn_bwd_group: d(u) needs %d planes of B * Nn * A floats", splits);
+#define SUBGC_BWD_ARGS u, v, ah, w_a, rows, lens, m, g, Nn, alpha, n_stride, dctx, lddctx, dah, du, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, du_plane_stride
 #define SUBGC_BWD_G(G_)                                                                                                                               \
     do {                                                                                                                                                \
-        if (uv16) { if (ca == 1 && cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 2, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);     \
-            else if (ca == 1) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 4, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                  \
-            else if (cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<2, 2, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                  \
-            else hipLaunchKernelGGL((attn_bwd_group_kernel<2, 4, true, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS); }                             \
-        else { if (ca == 1 && cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 2, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);         \
-            else if (ca == 1) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 4, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                 \
-            else if (cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<2, 2, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS);                 \
-            else hipLaunchKernelGGL((attn_bwd_group_kernel<2, 4, false, G_>), dim3(B), dim3(256), 0, s, SUBGC_BWD_ARGS); }                            \
+        if (uv16) { if (ca == 1 && cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 2, true, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS);     \
+            else if (ca == 1) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 4, true, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS);                  \
+            else if (cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<2, 2, true, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS);                  \
+            else hipLaunchKernelGGL((attn_bwd_group_kernel<2, 4, true, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS); }                             \
+        else { if (ca == 1 && cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 2, false, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS);         \
+            else if (ca == 1) hipLaunchKernelGGL((attn_bwd_group_kernel<1, 4, false, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS);                 \
+            else if (cr <= 2) hipLaunchKernelGGL((attn_bwd_group_kernel<2, 2, false, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS);                 \
+            else hipLaunchKernelGGL((attn_bwd_group_kernel<2, 4, false, G_>), dim3(B, splits), dim3(256), bwd_lds, s, SUBGC_BWD_ARGS); }                            \
     } while (0)
     SUBGC_G_DISPATCH(SUBGC_BWD_G);
 #undef SUBGC_BWD_G
@@ -383,7 +490,8 @@ SUBGC_API int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const 
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
     const size_t per = (size_t)64 * 16 + (size_t)n_stride * 4;
-    const int tg = (int)std::max<size_t>(1, std::min<size_t>((size_t)T * g, (size_t)(144 * 1024) / per));
+    SUBGC_REQUIRE(T <= 64, "attn_dv_accum_group: at most 64 steps");
+    const int tg = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)T * g, 1024), (size_t)(140 * 1024) / per));
     const size_t lds = (size_t)tg * per;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)attn_dv_accum_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -394,3 +502,6 @@ SUBGC_API int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const 
                        dv, R, tg);
     return subgc::check_launch("subgc_attn_dv_accum_group");
 }
+
+// how many d(u) planes subgc_attn_bwd_group accumulates into for groups of g sentences (the caller zeroes and finally adds them)
+SUBGC_API int subgc_attn_group_du_planes(int g) { return group_splits(g); }

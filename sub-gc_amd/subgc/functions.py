@@ -526,6 +526,13 @@ class Prepared:
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum(alpha, dctx, step_off, T, self.off, lens, dv, S, R)
 
+    def new_du(self, A):
+        """Zeroed accumulator of d(u) for the backward's time loop."""
+        return ops.zeros(self.u.size(0), A, device=self.u.device)
+
+    def finish_du(self, du):
+        return du
+
 
 class PreparedShared(Prepared):
     """`Prepared` for attention sets that are SHARED by the g sentences of an image (Full-GC, AttModel.py:140-149: every sentence
@@ -583,6 +590,13 @@ class PreparedShared(Prepared):
 
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum_group(alpha, dctx, step_off, T, self.rows, self.B, self.g, self.N, dv, R)
+
+    def new_du(self, A):
+        """One zeroed d(u) plane per workgroup that serves an image (subgc_attn_group_du_planes)."""
+        return ops.zeros(ops.attn_group_du_planes(self.g), self.u.size(0), A, device=self.u.device)
+
+    def finish_du(self, du):
+        return du[0] if du.size(0) == 1 else ops.add_n([du[k] for k in range(du.size(0))])
 
 
 def shared_sets_ok(g, N, A, R):
@@ -761,7 +775,7 @@ class DecoderFn(Function):
         # d(v) = sum_t alpha_t^T d(ctx_t) is formed ONCE after the loop from the kept d(ctx) rows (subgc_attn_dv_accum) instead of
         # being read and written at every step: on Full-GC (36 nodes per sentence) that was 380 of a step's 830 MB
         defer_dv = pr.shared or (R % 4 == 0 and A % 4 == 0 and A <= 1024 and R <= 2048 and T > 0)      # the float4 forms' limits
-        du = zer(pr.u.size(0), A)
+        du = pr.new_du(A)
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(T, S, R) if defer_dv else None
         dWa, dBa = new(T, S, A), new(T, S)                     # per-(step, sentence) partials of alpha_net's gradient
@@ -814,7 +828,7 @@ class DecoderFn(Function):
         ops.colsum(dWa.view(T * S, A), out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa.view(T * S, 1), out=out_for(20).view(-1), accumulate=acc[20])
 
-        dX, dfc_in = prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, acc, wgrad, bgrad,
+        dX, dfc_in = prepared_backward(pr, P, W, bf, fc_in, X_nodes, pr.finish_du(du), dv, df, scale, out_for, acc, wgrad, bgrad,
                                        ctx.needs_input_grad[3], ctx.needs_input_grad[2])
         ctx.pr = None
         if on_decoder_grads_ready is not None:           # data-parallel reducer: the decoder bucket is complete

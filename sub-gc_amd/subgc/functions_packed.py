@@ -213,7 +213,7 @@ class PackedDecoderLossFn(Function):
         dP1, dP2, dAH = act(max(rows, 1), 4 * R), act(max(rows, 1), 4 * R), act(max(rows, 1), A)
         # d(v) is formed once after the loop from the kept d(ctx) rows (see DecoderFn.backward)
         defer_dv = pr.shared or (R % 4 == 0 and A % 4 == 0 and A <= 1024 and R <= 2048 and T_live > 0)      # the float4 forms' limits
-        du = zer(pr.u.size(0), A)
+        du = pr.new_du(A)
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(max(rows, 1), R) if defer_dv else None
         dWa, dBa = new(max(rows, 1), A), new(max(rows, 1))     # per-(step, sentence) partials of alpha_net's gradient
@@ -272,7 +272,7 @@ class PackedDecoderLossFn(Function):
         ops.colsum(dWa[:rows], out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa[:rows].view(-1, 1), out=out_for(20).view(-1), accumulate=acc[20])
 
-        dX, dfc_p = F_.prepared_backward(pr, P, W, bf, fc_p, X_nodes, du, dv, df, scale, out_for, acc, wgrad, bgrad,
+        dX, dfc_p = F_.prepared_backward(pr, P, W, bf, fc_p, X_nodes, pr.finish_du(du), dv, df, scale, out_for, acc, wgrad, bgrad,
                                          ctx.needs_input_grad[3], ctx.needs_input_grad[2])
         dfc_in = None if dfc_p is None else ops.gather_rows(dfc_p, plan.inv32, torch.empty_like(dfc_p))      # back to the caller's order
         ctx.pr = None

@@ -715,7 +715,13 @@ def attn_bwd_group(u, v, ah, w_a, rows, lens, m, B, g, Nn, alpha, dctx, dah, du,
     dp, dl, dn, ds = _dctx_args(dctx)
     call("subgc_attn_bwd_group", _ptr(u), _ptr(v), _ptr(ah, torch.float32), _ptr(w_a), _ptr(rows, torch.int32), _ptr(lens, torch.int32), int(m), B, g, Nn,
          _ptr(alpha, torch.float32), alpha.size(1), dp, dl, _ptr(dah), _ptr(du, torch.float32), _ptr(dw_a), _ptr(db_a), A, R,
-         int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, dn, ds, _stream())
+         int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, dn, ds,
+         du.size(0) if du.dim() == 3 else 1, du.stride(0) if du.dim() == 3 else 0, _stream())
+
+
+def attn_group_du_planes(g):
+    from ._lib import lib
+    return int(lib().subgc_attn_group_du_planes(int(g)))
 
 
 def attn_dv_accum_group(alpha, dctx, step_off, T, rows, B, g, Nn, dv, R):
