@@ -23,19 +23,6 @@ template <bool UV16>
 __device__ __forceinline__ float4 ldx(const void* base, int64_t i) {
     return UV16 ? subgc_load4_bf(static_cast<const uint16_t*>(base) + i) : ld4(static_cast<const float*>(base) + i);
 }
-// sum over the 64 lanes of N values at once: the six exchange steps are shared, so N independent ds_bpermute chains overlap instead
-// of running back to back (a lone wave_sum is six DEPENDENT cross-lane exchanges, ~1 us; the kernels below need 45 per wave)
-template <int N>
-__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float t[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], o, 64);
-#pragma unroll
-        for (int k = 0; k < N; ++k) v[k] += t[k];
-    }
-}
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ void fma4(float4& acc, float a, float4 x) { acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w; }
 
@@ -407,11 +394,11 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // the chip holds ONE wave per SIMD and every dependent instruction (the tanh chains) exposes its latency; two per image re-read
 // the image's u / v rows from L2 but give every SIMD a second wave (fwd 40 -> 2x-wave figure in DESIGN 3.4).  The backward's two
 // workgroups accumulate into separate d(u) planes.
-inline int group_splits(int g) { return g >= 4 ? 2 : 1; }
+inline int group_splits(int g) { return g >= 4 ? 2 : 1; }       // three per image measured the same as two (44.6 / 23.7 vs 45.2 / 25.3 us)
 #define SUBGC_G_DISPATCH(CALL)                                   \
     do {                                                         \
         const int per = (g + splits - 1) / splits;               \
-        if (per <= 3) { CALL(3); } else if (per <= 5) { CALL(5); } else { CALL(8); } \
+        if (per <= 2) { CALL(2); } else if (per <= 3) { CALL(3); } else if (per <= 5) { CALL(5); } else { CALL(8); } \
     } while (0)
 
 SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,

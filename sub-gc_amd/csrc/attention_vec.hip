@@ -44,18 +44,35 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restric
         q[c] = ok ? ld4(ah + (int64_t)s * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         w[c] = ok ? ld4(w_a + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = wave; i < l; i += 4) {
-        const int64_t ur = (int64_t)(m0 + i) * A;
-        float4 x[CA];
+    // four of this wave's nodes at a time: their rows are requested together and their scores reduced over the lanes TOGETHER (four
+    // overlapping exchange chains instead of four dependent ones)
+    constexpr int NCH = 4;
+    const float ba = b_a[0];
+    for (int i0 = wave; i0 < l; i0 += 4 * NCH) {
+        float4 x[NCH][CA];
 #pragma unroll
-        for (int c = 0; c < CA; ++c) x[c] = (lane + c * 64 < A4) ? ldx<UV16>(u, ur + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float acc = 0.f;
+        for (int k = 0; k < NCH; ++k)
 #pragma unroll
-        for (int c = 0; c < CA; ++c)
-            acc += w[c].x * subgc_tanh(x[c].x + q[c].x) + w[c].y * subgc_tanh(x[c].y + q[c].y) + w[c].z * subgc_tanh(x[c].z + q[c].z) +
-                   w[c].w * subgc_tanh(x[c].w + q[c].w);
-        acc = wave_sum(acc);
-        if (lane == 0) e_s[i] = acc + b_a[0];
+            for (int c = 0; c < CA; ++c)
+                x[k][c] = (i0 + 4 * k < l && lane + c * 64 < A4) ? ldx<UV16>(u, (int64_t)(m0 + i0 + 4 * k) * A + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            float acc = 0.f;
+            if (i0 + 4 * k < l) {
+#pragma unroll
+                for (int c = 0; c < CA; ++c)
+                    acc += w[c].x * subgc_tanh(x[k][c].x + q[c].x) + w[c].y * subgc_tanh(x[k][c].y + q[c].y) + w[c].z * subgc_tanh(x[k][c].z + q[c].z) +
+                           w[c].w * subgc_tanh(x[k][c].w + q[c].w);
+            }
+            sc[k] = acc;
+        }
+        wave_sum_n<NCH>(sc);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (i0 + 4 * k < l) e_s[i0 + 4 * k] = sc[k] + ba;
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -130,28 +147,44 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
             if (lane + c * 64 < R4) st4(dctx_keep + (int64_t)s * ldkeep + (lane + c * 64) * 4, g[c]);
     }
     __syncthreads();
-    for (int i = wave; i < l; i += 4) {
-        const float a_i = al_s[i];
-        const int64_t vr = (int64_t)(m0 + i) * R;
-        float4 x[CR64];
+    // NCH of this wave's nodes at a time: rows requested together, the NCH dot products reduced over the lanes together
+    constexpr int NCH = CR64 <= 2 ? 4 : (CR64 <= 4 ? 3 : 1);
+    for (int i0 = wave; i0 < l; i0 += 4 * NCH) {
+        float4 x[NCH][CR64];
 #pragma unroll
-        for (int c = 0; c < CR64; ++c) x[c] = (lane + c * 64 < R4) ? ldx<UV16>(v, vr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float acc = 0.f;
-        if (dv) {
-            float* dvr = dv + (int64_t)(m0 + i) * R;
-            float4 y[CR64];
+        for (int k = 0; k < NCH; ++k)
 #pragma unroll
-            for (int c = 0; c < CR64; ++c) y[c] = (lane + c * 64 < R4) ? ld4(dvr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < CR64; ++c)
+                x[k][c] = (i0 + 4 * k < l && lane + c * 64 < R4) ? ldx<UV16>(v, (int64_t)(m0 + i0 + 4 * k) * R + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc[NCH];
 #pragma unroll
-            for (int c = 0; c < CR64; ++c) {
-                y[c].x += a_i * g[c].x; y[c].y += a_i * g[c].y; y[c].z += a_i * g[c].z; y[c].w += a_i * g[c].w;
-                if (lane + c * 64 < R4) st4(dvr + (lane + c * 64) * 4, y[c]);
+        for (int k = 0; k < NCH; ++k) {
+            const int i = i0 + 4 * k;
+            float acc = 0.f;
+            if (i < l) {
+                if (dv) {
+                    const float a_i = al_s[i];
+                    float* dvr = dv + (int64_t)(m0 + i) * R;
+                    float4 y[CR64];
+#pragma unroll
+                    for (int c = 0; c < CR64; ++c) y[c] = (lane + c * 64 < R4) ? ld4(dvr + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < CR64; ++c) {
+                        y[c].x += a_i * g[c].x; y[c].y += a_i * g[c].y; y[c].z += a_i * g[c].z; y[c].w += a_i * g[c].w;
+                        if (lane + c * 64 < R4) st4(dvr + (lane + c * 64) * 4, y[c]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CR64; ++c) acc += g[c].x * x[k][c].x + g[c].y * x[k][c].y + g[c].z * x[k][c].z + g[c].w * x[k][c].w;
             }
+            sc[k] = acc;
         }
+        wave_sum_n<NCH>(sc);
+        if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < CR64; ++c) acc += g[c].x * x[c].x + g[c].y * x[c].y + g[c].z * x[c].z + g[c].w * x[c].w;
-        acc = wave_sum(acc);
-        if (lane == 0) da_s[i] = acc;
+            for (int k = 0; k < NCH; ++k)
+                if (i0 + 4 * k < l) da_s[i0 + 4 * k] = sc[k];
+        }
     }
     __syncthreads();
     float dot = 0.f;
@@ -233,7 +266,22 @@ __global__ __launch_bounds__(256) void attn_dv_accum_kernel(const float* __restr
             float4 acc[CR64];
 #pragma unroll
             for (int c = 0; c < CR64; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < nl; ++k) {
+            int k = 0;
+            for (; k + 4 <= nl; k += 4) {                              // four steps' LDS reads in flight (the serial form waited for each)
+                float a[4];
+                float4 g[4][CR64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = a_s[(k + q) * n_stride + i];
+#pragma unroll
+                    for (int c = 0; c < CR64; ++c) g[q][c] = (lane + c * 64 < R4) ? g_s[(size_t)(k + q) * R4 + lane + c * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < CR64; ++c) { acc[c].x += a[q] * g[q][c].x; acc[c].y += a[q] * g[q][c].y; acc[c].z += a[q] * g[q][c].z; acc[c].w += a[q] * g[q][c].w; }
+            }
+            for (; k < nl; ++k) {
                 const float a = a_s[k * n_stride + i];
 #pragma unroll
                 for (int c = 0; c < CR64; ++c) {

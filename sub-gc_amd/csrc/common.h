@@ -70,6 +70,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// sum over the 64 lanes of N values at once: the six exchange steps are shared, so the N ds_bpermute chains overlap instead of running
+// back to back (a lone wave_sum is six DEPENDENT cross-lane exchanges, ~1 us when nothing else is ready to issue)
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float t[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], o, 64);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += t[k];
+    }
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
