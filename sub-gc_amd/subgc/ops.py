@@ -404,7 +404,7 @@ def gcn_edges_bwd_bn(dP, F2, F3, aff2, aff3, ptr, edges, B, N, K, L):
 
 def _pool_account(denom, G, L, fwd):
     if FLOPS["on"]:                      # untimed accounting step: the valid node rows of every sub-graph, not the padded N
-        rows = float(denom[:G].sum().item())
+        rows = float(denom[:G].cpu().sum())                  # host-side sum: the accounting step launches nothing of its own
         # fwd: read the member rows, write [max | mean] (+ arg-max);  bwd: read d[max | mean] + arg-max, read-modify-write the member rows
         FLOPS["pool_bytes"] = FLOPS.get("pool_bytes", 0.0) + 4.0 * ((rows * L + 3.0 * G * L) if fwd else (3.0 * G * L + 2.0 * rows * L))
 
@@ -659,7 +659,7 @@ def lstm_bwd(gates, c_prev, c, dh_a, dh_b, dh_drop, keep, scale, dc, dpre, dc_pr
 
 def _attn_account(lens, S, A, R, passes):
     if FLOPS["on"]:                      # untimed accounting step: algorithmic bytes of the ragged attention sets
-        FLOPS["attn_bytes"] = FLOPS.get("attn_bytes", 0.0) + 4.0 * float(lens[:S].sum().item()) * (A + R) * passes
+        FLOPS["attn_bytes"] = FLOPS.get("attn_bytes", 0.0) + 4.0 * float(lens[:S].cpu().sum()) * (A + R) * passes
 
 
 def _uv_b16(u, v, A, R):
