@@ -83,6 +83,9 @@ __device__ __forceinline__ int picked_word(const PickIn& pk, int m, bool& unf) {
 // rows) -- one W load, MT activation loads and 4*MT MFMAs per step; `add` [M,N] is an optional residual term of the epilogue.
 // WB16: the weight matrix is bf16-stored (compute_dtype = bf16: the decode step then streams 60 instead of 120 MB); a lane's four k of
 // a W row are one 8-byte load, widened to fp32 in registers -- activations, accumulation and everything downstream stay fp32.
+constexpr int PICK_WAVES = 8, PLAIN_WAVES = 8;      // 16 measured: no gain (593 logits workgroups are 2-3 per CU already)
+constexpr int LSTM_WAVES = 16;                                                // waves per workgroup of the fused LSTM-step launches
+
 template <int WAVES, int D, bool LSTM, int MT, bool PICK = false, bool WB16 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* __restrict__ A, int64_t lda, const void* __restrict__ W,
                                                                       int64_t ldb, float* __restrict__ C, int64_t ldc,
@@ -280,7 +283,7 @@ int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, flo
     // half of all load instructions at depth 8 when a wave owns 8 steps), and with ~50 VGPRs eight waves per SIMD hide the
     // latency that the ring was meant to hide.  The refill is also guarded by the (wave-uniform) step count, so no load is
     // issued past the wave's share: logits 11.9 -> 10.0 us (38 MB: 3.8 TB/s); guarded depth 4: 10.8, depth 8: 11.5.
-    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1>), dim3(wgs), dim3(512), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{}, add, ldadd);
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<PLAIN_WAVES, 2, false, 1>), dim3(wgs), dim3(PLAIN_WAVES * 64), 0, s, A, lda, W, ldb, C, ldc, bias, M, N, K, relu, LstmEpi{}, add, ldadd);
     return subgc::check_launch("subgc_gemm_f32(skinny)");
 }
 
@@ -294,7 +297,7 @@ SUBGC_API int subgc_gemm_skinny_wb16(const float* A, int64_t lda, const uint16_t
                   "gemm_skinny_wb16: 16-byte aligned fp32 rows, 8-byte aligned bf16 rows");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
-    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, false, true>), dim3((N + 15) / 16), dim3(512), 0, s, A, lda, W, ldw, C, ldc, bias, M, N, K, relu,
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<PLAIN_WAVES, 2, false, 1, false, true>), dim3((N + 15) / 16), dim3(PLAIN_WAVES * 64), 0, s, A, lda, W, ldw, C, ldc, bias, M, N, K, relu,
                        LstmEpi{}, nullptr, 0, PickOut{});
     return subgc::check_launch("subgc_gemm_skinny_wb16");
 }
@@ -314,8 +317,10 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const void* w_
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
     LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, PickIn{}};
     const int N = 4 * R, wgs = N / 16;
+    // 4R/16 workgroups (250 at R = 1000) are at most one per CU: 16 waves each instead of 8 (tools/ubench/lstm_step_bench.py, att + lang
+    // pair, 10 rows: 21.2 -> 19.9 us with fp32 weights, 22.2 -> 17.4 us with bf16 ones; deeper rings instead: 20.6 / 21.0; 4 waves: 30)
 #define SUBGC_LSTM_GO(MT_, W16_) \
-    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, MT_, false, W16_>), dim3(wgs), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0, PickOut{})
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<LSTM_WAVES, 2, true, MT_, false, W16_>), dim3(wgs), dim3(LSTM_WAVES * 64), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, N, K, 0, ep, nullptr, 0, PickOut{})
     if (S > 16) { if (w_bf16) SUBGC_LSTM_GO(2, true); else SUBGC_LSTM_GO(2, false); }      // two activation tiles (beam search: <= 10 sub-graphs x 2-3 beams)
     else { if (w_bf16) SUBGC_LSTM_GO(1, true); else SUBGC_LSTM_GO(1, false); }
 #undef SUBGC_LSTM_GO
@@ -343,11 +348,11 @@ SUBGC_API int subgc_lstm_step_pick(const float* x, int64_t ldx, const void* w_pe
               reinterpret_cast<unsigned long long*>(best_reset)};
     LstmEpi ep{add1, ld1, nullptr, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, pk};
     if (w_bf16)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1, false, true>), dim3(4 * R / 16), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, 4 * R, K,
-                           0, ep, nullptr, 0, PickOut{});
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<LSTM_WAVES, 2, true, 1, false, true>), dim3(4 * R / 16), dim3(LSTM_WAVES * 64), 0, s, x, ldx, w_perm, ldw, nullptr, 0,
+                           nullptr, S, 4 * R, K, 0, ep, nullptr, 0, PickOut{});
     else
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, true, 1>), dim3(4 * R / 16), dim3(512), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S, 4 * R, K, 0, ep,
-                           nullptr, 0, PickOut{});
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<LSTM_WAVES, 2, true, 1>), dim3(4 * R / 16), dim3(LSTM_WAVES * 64), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S,
+                           4 * R, K, 0, ep, nullptr, 0, PickOut{});
     return subgc::check_launch("subgc_lstm_step_pick");
 }
 
@@ -363,10 +368,10 @@ SUBGC_API int subgc_logits_pick(const float* x, int64_t ldx, const void* W, int6
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * (double)V * K);
     if (w_bf16)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, true, true>), dim3((V + 15) / 16), dim3(512), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<PICK_WAVES, 2, false, 1, true, true>), dim3((V + 15) / 16), dim3(PICK_WAVES * 64), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
                            LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
     else
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<8, 2, false, 1, true>), dim3((V + 15) / 16), dim3(512), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
+        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<PICK_WAVES, 2, false, 1, true>), dim3((V + 15) / 16), dim3(PICK_WAVES * 64), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
                            LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
     return subgc::check_launch("subgc_logits_pick");
 }

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""One-image decode (the reference's call shape): wall time per phase, synchronising between phases."""
+"""Where one reference-shaped greedy decode call (one image) spends its time: encoder launches, candidate scoring + NMS, the copies into the
+graph's static buffers, the host read of the survivor count, the graph replay.  Two passes: host time per phase (asynchronous launches,
+the GPU may lag) and, with a synchronize after every phase, the time each phase takes on the device when nothing overlaps.
+    python tools/decode_phases.py [images] [M]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "sub-gc_amd"), ROOT]
@@ -17,29 +20,38 @@ opt = argparse.Namespace(**dict(bench.KAR, test_LSTM=1, gpn_nms_thres=0.75, gpn_
 m = models.setup(opt).to(dev).eval()
 batches = [{k: v.to(dev) for k, v in synthetic.make_test_batch(M, seed=500 + i).items()} for i in range(images)]
 sopt = dict(sample_max=1, beam_size=1)
-for b in batches[:3]:
-    m(*synthetic.sample_args(b), opt=sopt, mode="sample")
-torch.cuda.synchronize()
-acc = [0.0] * 4
-with torch.no_grad():
-    for im in batches:
-        t = [time.perf_counter()]
-        att = im["att_feats"][:1]
-        N = att.size(1)
-        X2 = m._encode(att, im["obj_dist"][:1], im["pred_dist"][:1], im["rel_ind"][:1]).reshape(N, m.GCN_dim).contiguous()
-        torch.cuda.synchronize(); t.append(time.perf_counter())
-        sel = sampling.select_subgraphs(m, X2, N, [(0, im["gpn_obj_ind"], im["att_masks"], im["gpn_pool_mtx"])])
-        torch.cuda.synchronize(); t.append(time.perf_counter())
-        out = sampling.decode(m, X2, N, sel, sopt)
-        torch.cuda.synchronize(); t.append(time.perf_counter())
-        g = m._graph_cache[next(iter(m._graph_cache))] if getattr(m, "_graph_cache", None) else None
-        if g is not None:
-            g.graph.replay()
-        torch.cuda.synchronize(); t.append(time.perf_counter())
-        acc = [a + 1e3 * (y - x) for a, x, y in zip(acc, t, t[1:])]
-print("ms per image (encode, select, decode incl. prepare, bare graph replay):", [round(a / images, 3) for a in acc])
-t0 = time.perf_counter()
 for b in batches:
     m(*synthetic.sample_args(b), opt=sopt, mode="sample")
 torch.cuda.synchronize()
-print("end-to-end ms per image:", round(1e3 * (time.perf_counter() - t0) / images, 3))
+
+acc, SYNC = {}, [False]
+
+
+def wrap(owner, name, label):
+    real = getattr(owner, name)
+
+    def f(*a, **k):
+        t0 = time.perf_counter()
+        r = real(*a, **k)
+        if SYNC[0]:
+            torch.cuda.synchronize()
+        acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
+        return r
+    setattr(owner, name, f)
+
+
+wrap(m, "_encode", "encode")
+wrap(sampling, "score_candidates", "score+nms")
+wrap(sampling._FrontBuffers, "load", "front copies")
+wrap(sampling._GraphedLoop, "run", "replay+clones")
+for sync in (False, True):
+    SYNC[0] = sync
+    acc.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches:
+        m(*synthetic.sample_args(b), opt=sopt, mode="sample")
+    torch.cuda.synchronize()
+    tot = 1e3 * (time.perf_counter() - t0) / images
+    parts = ", ".join(f"{k} {1e3 * v / images:.3f}" for k, v in acc.items())
+    print(f"sync_after_each_phase={sync}: {tot:.3f} ms/image; ms per phase: {parts}; rest (host read, result clones, python) {tot - 1e3 * sum(acc.values()) / images:.3f}", flush=True)
