@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-situ per-call GEMM timing of ONE Sub_GC_Kar train step (packed decoder by default): every `ops.gemm`
+"""In-situ per-call GEMM timing of ONE train step of a BASELINE config (--config, default Sub_GC_Kar) (packed decoder by default): every `ops.gemm`
 call is bracketed by events on the stream it runs on; calls are grouped by (layout, M-bucket, N, K, epilogue).
 
     python tools/gemm_breakdown.py [--unpacked] [--batch 128] [--top 40]
@@ -26,19 +26,25 @@ def main():
     ap.add_argument("--unpacked", action="store_true")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--config", default="kar", choices=["kar", "full_gc_kar", "flickr"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(1234)
-    model = models.setup(argparse.Namespace(**bench.KAR)).to(dev).train()
+    if a.config == "kar":
+        model = models.setup(argparse.Namespace(**bench.KAR)).to(dev).train()
+        b = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=0).items()}
+    else:
+        cfg = bench.CONFIGS[a.config]
+        model = models.setup(argparse.Namespace(**cfg["opt"])).to(dev).train()
+        b = {k: v.to(dev) for k, v in synthetic.make_train_batch(cfg["batch"], seed=1000, **cfg["data"]).items()}
     model.packed_decoder = not a.unpacked
     lw = models.LossWrapper(model, None)
-    b = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=0).items()}
 
     def step():
         model.flatten_grads()
         out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
                  None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
-        (out["lang_loss"] + out["gpn_loss"]).backward()
+        models.total_loss(out).backward()
 
     for _ in range(3):
         step()
@@ -94,7 +100,7 @@ def main():
     torch.cuda.synchronize()
     agg = collections.OrderedDict()
     for mode, M, N, K, epi, e0, e1 in rec:
-        mb = M if M > 640 else (640 if M > 512 else 512 if M > 384 else 384 if M > 256 else 256 if M > 128 else 128)
+        mb = M if M > 1536 else (-(-M // 256) * 256 if M > 640 else 640 if M > 512 else 512 if M > 384 else 384 if M > 256 else 256 if M > 128 else 128)
         key = (mode, mb if mode != "tn" else M, N, K if mode != "tn" else (K // 1000) * 1000, epi)
         d = agg.setdefault(key, [0, 0.0, 0.0])
         d[0] += 1
