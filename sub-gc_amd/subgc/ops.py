@@ -6,6 +6,8 @@ here (see functions.py) and no fallback: CPU tensors raise.
 """
 from __future__ import annotations
 
+import gc
+
 import torch
 
 from ._lib import SubgcError, call
@@ -84,10 +86,26 @@ class graph_capture:
         self.ctx = torch.cuda.graph(graph, stream=st)
 
     def __enter__(self):
-        return self.ctx.__enter__()
+        # The cyclic garbage collector must not run INSIDE a capture: a dead cycle that owns an older CUDAGraph (a dropped model's
+        # graph cache) frees its private pool when collected, hipFree is illegal while a stream of the process captures
+        # (capture_error_mode "global") and the error surfaces in a destructor, i.e. as abort().  torch.cuda.graph stopped
+        # collecting on entry (torch.compiler.config.force_cudagraph_gc), so: collect now, keep the collector off until the end.
+        self._gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self._gc_was_on:
+                gc.enable()
+            raise
 
     def __exit__(self, *exc):
-        return self.ctx.__exit__(*exc)
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self._gc_was_on:
+                gc.enable()
 
 
 GEMM_MODES = {"f32": 1 << 4, "bf16x3": 2 << 4, "bf16": 3 << 4}       # SUBGC_GEMM_MODE_* bits of the per-call flags

@@ -287,3 +287,37 @@ def test_greedy_pick_folded_into_the_step_launches_equals_the_separate_pick(gold
             torch.testing.assert_close(x[4], y[4], atol=1e-6, rtol=1e-5)
         lens.update((x[0] > 0).sum(1).tolist())
     assert len(lens) >= 3 and min(lens) < ma.seq_length              # rows of different lengths were decoded
+
+
+def test_no_garbage_collection_inside_a_graph_capture(golden):
+    """A dead reference cycle that owns an older hipGraph must not be collected while another capture is in progress (freeing the graph's
+    pool during a capture aborts the process): ops.graph_capture collects before it starts and keeps the collector off until it ends."""
+    import gc
+    from subgc.models import sampling
+    g = golden("subgc_greedy")
+    b = {k: v.to(DEV) for k, v in g.tensors("inputs").items()}
+    sopt = g.meta["sample_opt"]
+    w = golden("subgc_train").group("weights")
+    old = build(g, w, False)
+    old(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")     # captures a graph
+    old.self_cycle = old                                                                             # dead cycle once dropped
+    del old
+    seen = []
+    real = sampling._GraphedLoop._loop
+
+    def spy(self):
+        if torch.cuda.is_current_stream_capturing():
+            seen.append(gc.isenabled())
+        return real(self)
+
+    sampling._GraphedLoop._loop = spy
+    thr = gc.get_threshold()
+    gc.set_threshold(1)                                                                              # collect at every opportunity
+    try:
+        m = build(g, w, False)
+        out = m(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")
+    finally:
+        gc.set_threshold(*thr)
+        sampling._GraphedLoop._loop = real
+    assert seen == [False] and gc.isenabled()
+    assert torch.equal(out[0].cpu(), torch.from_numpy(g.group("out")["seq"]))
