@@ -68,3 +68,17 @@ def test_model_api_surface(golden):
         m(None, None, opt={"beam_size": 1}, mode="sample_sentences")
     for name in ("_prepare_feature", "get_logprobs_state", "beam_search", "init_hidden", "sample_images"):
         assert callable(getattr(m, name)), name
+
+
+@pytest.mark.parametrize("over", [dict(att_hid_size=50), dict(att_hid_size=516), dict(rnn_size=46), dict(rnn_size=2052, input_encoding_size=2052)])
+def test_sizes_the_attention_kernels_cannot_serve_are_refused_at_construction(golden, over):
+    """shapes outside the vector attention kernels' limits used to fail inside the first backward; they are refused up front."""
+    g = golden("subgc_train")
+    with pytest.raises(ValueError, match="att_hid_size"):
+        models.setup(g.opt(caption_model="topdown", **over))
+
+
+def test_bf16_storage_needs_8_element_rows(golden):
+    g = golden("subgc_train")
+    with pytest.raises(ValueError):
+        models.setup(g.opt(caption_model="topdown", compute_dtype="bf16", rnn_size=44, input_encoding_size=44))
