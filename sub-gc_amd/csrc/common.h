@@ -33,6 +33,16 @@ inline int check_launch(const char* what) {
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// gridDim.z of the per-column GCN kernels: their node / relation loop is strided over z, and a workgroup's loop is a chain of gather
+// latencies -- enough slices for ~2048 workgroups (4 slices left 9-25 nodes per workgroup: 2.3-3.6 TB/s)
+inline int gcn_zsplit(int col_groups, int B, int items) {
+    const int wg = col_groups * B > 0 ? col_groups * B : 1;
+    int z = (2048 + wg - 1) / wg;
+    if (z < 4) z = 4;
+    if (z > items) z = items;
+    return z < 1 ? 1 : z;
+}
+
 
 // gemm_skinny.hip: C[M,N] = act(A[M,K] W[N,K]^T + bias) for M <= 16 (weight-streaming bound); returns -100
 // when the shape is not covered (caller falls back to the tiled MFMA kernels).
@@ -83,6 +93,28 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
         for (int k = 0; k < N; ++k) v[k] += t[k];
     }
 }
+// Segment sums of two gather lists at once: sa += fa(ia[j]) for j in [a0, a1), sb += fb(ib[j]) for j in [b0, b1).  Up to four rows of EACH list
+// are requested before any is added (wave-uniform bounds: the skipped loads are scalar branches), additions in list order, so the result is
+// bit-identical to the plain loops -- which waited for every row before asking for the next (degree 2-3 per node: a chain of memory latencies).
+template <class FA, class FB>
+__device__ __forceinline__ void gather_pair(const int* __restrict__ ia, int a0, int a1, FA fa, const int* __restrict__ ib, int b0, int b1, FB fb,
+                                            float4& sa, float4& sb) {
+    constexpr int U = 4;
+    for (int ja = a0, jb = b0; ja < a1 || jb < b1; ja += U, jb += U) {
+        float4 xa[U], xb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ja + u < a1) xa[u] = fa(ia[ja + u]);
+            if (jb + u < b1) xb[u] = fb(ib[jb + u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ja + u < a1) { sa.x += xa[u].x; sa.y += xa[u].y; sa.z += xa[u].z; sa.w += xa[u].w; }
+            if (jb + u < b1) { sb.x += xb[u].x; sb.y += xb[u].y; sb.z += xb[u].z; sb.w += xb[u].w; }
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int GCN_ZSPLIT = 4;
 constexpr int TC = 128;
 
 template <bool SRC16>
@@ -190,8 +189,8 @@ __global__ __launch_bounds__(256) void gcn_nodes_fwd_bn_kernel(const void* __res
     for (int n = blockIdx.z; n < N; n += gridDim.z) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
         const int s0 = ps[n], s1 = ps[n + 1], o0 = po[n], o1 = po[n + 1];
-        for (int j = s0; j < s1; ++j) { const float4 x = apply_aff(A0, ldsrc<SRC16>(F0, base + (int64_t)es[j] * L)); a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
-        for (int j = o0; j < o1; ++j) { const float4 x = apply_aff(A1, ldsrc<SRC16>(F1, base + (int64_t)eo[j] * L)); c.x += x.x; c.y += x.y; c.z += x.z; c.w += x.w; }
+        gather_pair(es, s0, s1, [&](int e) { return apply_aff(A0, ldsrc<SRC16>(F0, base + (int64_t)e * L)); },
+                    eo, o0, o1, [&](int e) { return apply_aff(A1, ldsrc<SRC16>(F1, base + (int64_t)e * L)); }, a, c);
         const float da = (float)(s1 - s0) + 1e-7f, dc = (float)(o1 - o0) + 1e-7f;
         const float av[4] = {a.x / da, a.y / da, a.z / da, a.w / da}, cv[4] = {c.x / dc, c.y / dc, c.z / dc, c.w / dc};
         const int64_t o = ((int64_t)b * N + n) * L + col;
@@ -217,7 +216,7 @@ template <bool SRC16>
 __global__ __launch_bounds__(256) void gcn_edges_fwd_bn_kernel(const void* __restrict__ F2, const void* __restrict__ F3,
                                                                const float* __restrict__ aff2, const float* __restrict__ aff3,
                                                                const int64_t* __restrict__ rel_ind, const float* __restrict__ skip,
-                                                               float* __restrict__ Pout, uint16_t* __restrict__ Pout16, int B, int N, int K, int L) {
+                                                               float* __restrict__ Pout, uint16_t* __restrict__ Pout16, int B, int N, int K, int L, int vec) {
     extern __shared__ __attribute__((aligned(16))) float sm_f[];
     float* t2 = sm_f;
     float* t3 = sm_f + (size_t)N * TC;
@@ -230,29 +229,91 @@ __global__ __launch_bounds__(256) void gcn_edges_fwd_bn_kernel(const void* __res
         ns[k] = (int)(s < 0 ? 0 : (s >= N ? N - 1 : s));
         no[k] = (int)(o < 0 ? 0 : (o >= N ? N - 1 : o));
     }
-    for (int i = threadIdx.x; i < N * (TC / 4); i += blockDim.x) {
-        const int n = i / (TC / 4), c4 = (i % (TC / 4)) * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        if (c0 + c4 < L) {                                            // L % 4 == 0: a float4 is all in or all out
-            const int64_t g = ((int64_t)b * N + n) * L + c0 + c4;
-            a = apply_aff(load_aff(aff2, L, c0 + c4), ldsrc<SRC16>(F2, g));
-            c = apply_aff(load_aff(aff3, L, c0 + c4), ldsrc<SRC16>(F3, g));
+    const int items = N * (TC / 4);
+    for (int i0 = threadIdx.x; i0 < items; i0 += 4 * blockDim.x) {         // four node-row quads requested before the first is staged
+        float4 a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * blockDim.x;
+            a[u] = make_float4(0.f, 0.f, 0.f, 0.f); c[u] = a[u];
+            if (i < items) {
+                const int n = i / (TC / 4), c4 = (i % (TC / 4)) * 4;
+                if (c0 + c4 < L) {                                        // L % 4 == 0: a float4 is all in or all out
+                    const int64_t g = ((int64_t)b * N + n) * L + c0 + c4;
+                    a[u] = ldsrc<SRC16>(F2, g);
+                    c[u] = ldsrc<SRC16>(F3, g);
+                }
+            }
         }
-        a.x = fmaxf(a.x / cdiv1, 0.f); a.y = fmaxf(a.y / cdiv1, 0.f); a.z = fmaxf(a.z / cdiv1, 0.f); a.w = fmaxf(a.w / cdiv1, 0.f);
-        c.x = fmaxf(c.x / cdiv1, 0.f); c.y = fmaxf(c.y / cdiv1, 0.f); c.z = fmaxf(c.z / cdiv1, 0.f); c.w = fmaxf(c.w / cdiv1, 0.f);
-        *reinterpret_cast<float4*>(t2 + n * TC + c4) = a;
-        *reinterpret_cast<float4*>(t3 + n * TC + c4) = c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < items) {
+                const int n = i / (TC / 4), c4 = (i % (TC / 4)) * 4;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+                if (c0 + c4 < L) {
+                    x = apply_aff(load_aff(aff2, L, c0 + c4), a[u]);
+                    y = apply_aff(load_aff(aff3, L, c0 + c4), c[u]);
+                }
+                x.x = fmaxf(x.x / cdiv1, 0.f); x.y = fmaxf(x.y / cdiv1, 0.f); x.z = fmaxf(x.z / cdiv1, 0.f); x.w = fmaxf(x.w / cdiv1, 0.f);
+                y.x = fmaxf(y.x / cdiv1, 0.f); y.y = fmaxf(y.y / cdiv1, 0.f); y.z = fmaxf(y.z / cdiv1, 0.f); y.w = fmaxf(y.w / cdiv1, 0.f);
+                *reinterpret_cast<float4*>(t2 + n * TC + c4) = x;
+                *reinterpret_cast<float4*>(t3 + n * TC + c4) = y;
+            }
+        }
     }
     __syncthreads();
+    if (vec) {                                                             // 8 relation streams x 32 lanes x 4 columns: 16-byte LDS reads and stores
+        const int cl4 = (threadIdx.x & 31) * 4, st = threadIdx.x >> 5;
+        if (c0 + cl4 >= L) return;
+        for (int k0 = st; k0 < K; k0 += 32) {
+            float4 v[4], sk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 8 * u;
+                if (k < K) {
+                    const float4 x = *reinterpret_cast<const float4*>(t2 + ns[k] * TC + cl4), y = *reinterpret_cast<const float4*>(t3 + no[k] * TC + cl4);
+                    v[u] = make_float4((x.x + y.x) / 2.f, (x.y + y.y) / 2.f, (x.z + y.z) / 2.f, (x.w + y.w) / 2.f);
+                    if (skip) sk[u] = *reinterpret_cast<const float4*>(skip + ((int64_t)b * K + k) * L + c0 + cl4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 8 * u;
+                if (k < K) {
+                    float4 r = v[u];
+                    if (skip) { r.x += sk[u].x; r.y += sk[u].y; r.z += sk[u].z; r.w += sk[u].w; }
+                    const int64_t o = ((int64_t)b * K + k) * L + c0 + cl4;
+                    *reinterpret_cast<float4*>(Pout + o) = r;
+                    if (Pout16) *reinterpret_cast<uint2*>(Pout16 + o) = subgc_pack4(r.x, r.y, r.z, r.w);
+                }
+            }
+        }
+        return;
+    }
     const int cl = threadIdx.x & (TC - 1), half = threadIdx.x >> 7;
     const int col = c0 + cl;
     if (col >= L) return;
-    for (int k = half; k < K; k += 2) {
-        float v = (t2[ns[k] * TC + cl] + t3[no[k] * TC + cl]) / 2.f;
-        const int64_t o = ((int64_t)b * K + k) * L + col;
-        if (skip) v += skip[o];
-        Pout[o] = v;
-        if (Pout16) Pout16[o] = (uint16_t)subgc_f2bf(v);
+    for (int k0 = half; k0 < K; k0 += 8) {                                 // four relations per round: LDS reads and skip loads in flight together
+        float v[4], sk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 2 * u;
+            if (k < K) {
+                v[u] = (t2[ns[k] * TC + cl] + t3[no[k] * TC + cl]) / 2.f;
+                sk[u] = skip ? skip[((int64_t)b * K + k) * L + col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 2 * u;
+            if (k < K) {
+                const int64_t o = ((int64_t)b * K + k) * L + col;
+                const float r = skip ? v[u] + sk[u] : v[u];
+                Pout[o] = r;
+                if (Pout16) Pout16[o] = (uint16_t)subgc_f2bf(r);
+            }
+        }
     }
 }
 
@@ -281,10 +342,10 @@ __global__ __launch_bounds__(256) void gcn_edges_bwd_bn_kernel(const float* __re
     const float* dp = dP + (int64_t)b * K * L + col;
     for (int n = blockIdx.z; n < N; n += gridDim.z) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        for (int j = ps[n]; j < ps[n + 1]; ++j) { const float4 x = *reinterpret_cast<const float4*>(dp + (int64_t)es[j] * L); a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
-        for (int j = po[n]; j < po[n + 1]; ++j) { const float4 x = *reinterpret_cast<const float4*>(dp + (int64_t)eo[j] * L); c.x += x.x; c.y += x.y; c.z += x.z; c.w += x.w; }
         const int64_t o = ((int64_t)b * N + n) * L + col;
         const float4 f2 = apply_aff(A2, ldsrc<SRC16>(F2, o)), f3 = apply_aff(A3, ldsrc<SRC16>(F3, o));
+        auto row = [&](int e) { return *reinterpret_cast<const float4*>(dp + (int64_t)e * L); };
+        gather_pair(es, ps[n], ps[n + 1], row, eo, po[n], po[n + 1], row, a, c);
         float4 r2, r3;
         r2.x = (f2.x / cdiv1 > 0.f) ? a.x * 0.5f / cdiv1 : 0.f; r2.y = (f2.y / cdiv1 > 0.f) ? a.y * 0.5f / cdiv1 : 0.f;
         r2.z = (f2.z / cdiv1 > 0.f) ? a.z * 0.5f / cdiv1 : 0.f; r2.w = (f2.w / cdiv1 > 0.f) ? a.w * 0.5f / cdiv1 : 0.f;
@@ -494,7 +555,7 @@ SUBGC_API int subgc_gcn_nodes_fwd_bn(const void* F0, const void* F1, int f_bf16,
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, (f_bf16 ? 2.0 : 4.0) * B * L * 2.0 * K + 4.0 * B * L * (skip ? 2.0 : 1.0) * N);
     const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
-    const dim3 g((L / 4 + 255) / 256, B, GCN_ZSPLIT);
+    const dim3 g((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, N));
     if (f_bf16) hipLaunchKernelGGL((gcn_nodes_fwd_bn_kernel<true>), g, dim3(256), lds, s, F0, F1, aff0, aff1, ptr, edges, skip, Xout, Xout16, act, B, N, K, L);
     else hipLaunchKernelGGL((gcn_nodes_fwd_bn_kernel<false>), g, dim3(256), lds, s, F0, F1, aff0, aff1, ptr, edges, skip, Xout, Xout16, act, B, N, K, L);
     return subgc::check_launch("subgc_gcn_nodes_fwd_bn");
@@ -513,8 +574,9 @@ SUBGC_API int subgc_gcn_edges_fwd_bn(const void* F2, const void* F3, int f_bf16,
     if (rc) return rc;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, (f_bf16 ? 2.0 : 4.0) * B * L * 2.0 * N + 4.0 * B * L * (skip ? 2.0 : 1.0) * K);
     const dim3 g((L + TC - 1) / TC, B);
-    if (f_bf16) hipLaunchKernelGGL((gcn_edges_fwd_bn_kernel<true>), g, dim3(256), lds, s, F2, F3, aff2, aff3, rel_ind, skip, Pout, Pout16, B, N, K, L);
-    else hipLaunchKernelGGL((gcn_edges_fwd_bn_kernel<false>), g, dim3(256), lds, s, F2, F3, aff2, aff3, rel_ind, skip, Pout, Pout16, B, N, K, L);
+    const int vec = al16(Pout) && al16(skip) && al8(Pout16);
+    if (f_bf16) hipLaunchKernelGGL((gcn_edges_fwd_bn_kernel<true>), g, dim3(256), lds, s, F2, F3, aff2, aff3, rel_ind, skip, Pout, Pout16, B, N, K, L, vec);
+    else hipLaunchKernelGGL((gcn_edges_fwd_bn_kernel<false>), g, dim3(256), lds, s, F2, F3, aff2, aff3, rel_ind, skip, Pout, Pout16, B, N, K, L, vec);
     return subgc::check_launch("subgc_gcn_edges_fwd_bn");
 }
 
@@ -528,7 +590,7 @@ SUBGC_API int subgc_gcn_edges_bwd_bn(const float* dP, const void* F2, const void
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 2.0 * N) + (f_bf16 ? 2.0 : 4.0) * B * L * 2.0 * N);
     const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
-    const dim3 g((L / 4 + 255) / 256, B, GCN_ZSPLIT);
+    const dim3 g((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, N));
     if (f_bf16) hipLaunchKernelGGL((gcn_edges_bwd_bn_kernel<true>), g, dim3(256), lds, s, dP, F2, F3, aff2, aff3, ptr, edges, dF2, dF3, B, N, K, L);
     else hipLaunchKernelGGL((gcn_edges_bwd_bn_kernel<false>), g, dim3(256), lds, s, dP, F2, F3, aff2, aff3, ptr, edges, dF2, dF3, B, N, K, L);
     return subgc::check_launch("subgc_gcn_edges_bwd_bn");

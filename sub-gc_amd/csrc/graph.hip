@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256) void csr_build_kernel(const int64_t* __restric
 
 // ------------------------------------------------------------------ nodes <- relations
 // grid (L/256, B); thread = one feature column; CSR lists of the image in LDS.
-constexpr int GCN_ZSPLIT = 4;     // node / relation loop of the per-column kernels is strided over gridDim.z
 __global__ __launch_bounds__(256) void gcn_nodes_fwd_kernel(const float* __restrict__ F0, const float* __restrict__ F1,
                                                             const int32_t* __restrict__ ptr,
                                                             const int32_t* __restrict__ edges,
@@ -140,8 +139,8 @@ __global__ __launch_bounds__(256) void gcn_nodes_fwd_vec_kernel(const float* __r
     for (int n = blockIdx.z; n < N; n += gridDim.z) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
         const int s0 = ps[n], s1 = ps[n + 1], o0 = po[n], o1 = po[n + 1];
-        for (int j = s0; j < s1; ++j) { const float4 x = *reinterpret_cast<const float4*>(f0 + (int64_t)es[j] * L); a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
-        for (int j = o0; j < o1; ++j) { const float4 x = *reinterpret_cast<const float4*>(f1 + (int64_t)eo[j] * L); c.x += x.x; c.y += x.y; c.z += x.z; c.w += x.w; }
+        gather_pair(es, s0, s1, [&](int e) { return *reinterpret_cast<const float4*>(f0 + (int64_t)e * L); },
+                    eo, o0, o1, [&](int e) { return *reinterpret_cast<const float4*>(f1 + (int64_t)e * L); }, a, c);
         const float da = (float)(s1 - s0) + 1e-7f, dc = (float)(o1 - o0) + 1e-7f;
         float av[4] = {a.x / da, a.y / da, a.z / da, a.w / da}, cv[4] = {c.x / dc, c.y / dc, c.z / dc, c.w / dc};
         const int64_t o = ((int64_t)b * N + n) * L + col;
@@ -218,21 +217,37 @@ __global__ __launch_bounds__(256) void gcn_nodes_bwd_vec_kernel(const float* __r
     __syncthreads();
     const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (col >= L) return;
-    for (int k = blockIdx.z; k < K; k += gridDim.z) {
-        const int s = ns[k], o = no[k];
-        const int64_t is = ((int64_t)b * N + s) * L + col, io = ((int64_t)b * N + o) * L + col;
-        const uint32_t as = *reinterpret_cast<const uint32_t*>(act + is), ao = *reinterpret_cast<const uint32_t*>(act + io);
-        const float4 xs = *reinterpret_cast<const float4*>(dX + is), xo = *reinterpret_cast<const float4*>(dX + io);
-        const float xsv[4] = {xs.x, xs.y, xs.z, xs.w}, xov[4] = {xo.x, xo.y, xo.z, xo.w};
-        float gs[4], go[4];
+    const int kz = gridDim.z;
+    for (int k0 = blockIdx.z; k0 < K; k0 += 4 * kz) {                      // four relations' node rows requested before the first is used
+        int sn[4], on[4];
+        uint32_t as[4], ao[4];
+        float4 xs[4], xo[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            gs[e] = ((as >> (8 * e)) & 1u) ? xsv[e] * 0.5f / ds[s] : 0.f;
-            go[e] = ((ao >> (8 * e)) & 2u) ? xov[e] * 0.5f / dn_o[o] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * kz;
+            if (k < K) {
+                sn[u] = ns[k]; on[u] = no[k];
+                const int64_t is = ((int64_t)b * N + sn[u]) * L + col, io = ((int64_t)b * N + on[u]) * L + col;
+                as[u] = *reinterpret_cast<const uint32_t*>(act + is); ao[u] = *reinterpret_cast<const uint32_t*>(act + io);
+                xs[u] = *reinterpret_cast<const float4*>(dX + is); xo[u] = *reinterpret_cast<const float4*>(dX + io);
+            }
         }
-        const int64_t ok = ((int64_t)b * K + k) * L + col;
-        *reinterpret_cast<float4*>(dF0 + ok) = make_float4(gs[0], gs[1], gs[2], gs[3]);
-        *reinterpret_cast<float4*>(dF1 + ok) = make_float4(go[0], go[1], go[2], go[3]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * kz;
+            if (k < K) {
+                const float xsv[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w}, xov[4] = {xo[u].x, xo[u].y, xo[u].z, xo[u].w};
+                float gs[4], go[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gs[e] = ((as[u] >> (8 * e)) & 1u) ? xsv[e] * 0.5f / ds[sn[u]] : 0.f;
+                    go[e] = ((ao[u] >> (8 * e)) & 2u) ? xov[e] * 0.5f / dn_o[on[u]] : 0.f;
+                }
+                const int64_t ok = ((int64_t)b * K + k) * L + col;
+                *reinterpret_cast<float4*>(dF0 + ok) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+                *reinterpret_cast<float4*>(dF1 + ok) = make_float4(go[0], go[1], go[2], go[3]);
+            }
+        }
     }
 }
 
@@ -240,6 +255,7 @@ __global__ __launch_bounds__(256) void gcn_nodes_bwd_vec_kernel(const float* __r
 // grid (L/TC, B), TC = 128 columns; the image's F2/F3 node tiles [N x TC] are staged in LDS
 // (each node row is consumed by ~K/N relations per role), then every relation gathers from LDS.
 constexpr int TC = 128;
+template <bool VEC>
 __global__ __launch_bounds__(256) void gcn_edges_fwd_kernel(const float* __restrict__ F2, const float* __restrict__ F3,
                                                             const int64_t* __restrict__ rel_ind,
                                                             const float* __restrict__ skip, float* __restrict__ Pout,
@@ -256,33 +272,85 @@ __global__ __launch_bounds__(256) void gcn_edges_fwd_kernel(const float* __restr
         ns[k] = (int)(s < 0 ? 0 : (s >= N ? N - 1 : s));
         no[k] = (int)(o < 0 ? 0 : (o >= N ? N - 1 : o));
     }
-    for (int i = threadIdx.x; i < N * (TC / 4); i += blockDim.x) {
-        const int n = i / (TC / 4), c4 = (i % (TC / 4)) * 4;
-        const int64_t g = ((int64_t)b * N + n) * L + c0 + c4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        if (c0 + c4 + 3 < L) {
-            a = *reinterpret_cast<const float4*>(F2 + g);
-            c = *reinterpret_cast<const float4*>(F3 + g);
-        } else {
-            float* pa = &a.x; float* pc = &c.x;
-            for (int j = 0; j < 4; ++j)
-                if (c0 + c4 + j < L) { pa[j] = F2[g + j]; pc[j] = F3[g + j]; }
+    const int items = N * (TC / 4);
+    for (int i0 = threadIdx.x; i0 < items; i0 += 4 * blockDim.x) {         // four node-row quads requested before the first is staged
+        float4 a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * blockDim.x;
+            a[u] = make_float4(0.f, 0.f, 0.f, 0.f); c[u] = a[u];
+            if (i < items) {
+                const int n = i / (TC / 4), c4 = (i % (TC / 4)) * 4;
+                const int64_t g = ((int64_t)b * N + n) * L + c0 + c4;
+                if (c0 + c4 + 3 < L) {
+                    a[u] = *reinterpret_cast<const float4*>(F2 + g);
+                    c[u] = *reinterpret_cast<const float4*>(F3 + g);
+                } else {
+                    float* pa = &a[u].x; float* pc = &c[u].x;
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + c4 + j < L) { pa[j] = F2[g + j]; pc[j] = F3[g + j]; }
+                }
+            }
         }
-        // relu(x / c) is what every consumer needs: do it once per node element
-        a.x = fmaxf(a.x / cdiv1, 0.f); a.y = fmaxf(a.y / cdiv1, 0.f); a.z = fmaxf(a.z / cdiv1, 0.f); a.w = fmaxf(a.w / cdiv1, 0.f);
-        c.x = fmaxf(c.x / cdiv1, 0.f); c.y = fmaxf(c.y / cdiv1, 0.f); c.z = fmaxf(c.z / cdiv1, 0.f); c.w = fmaxf(c.w / cdiv1, 0.f);
-        *reinterpret_cast<float4*>(t2 + n * TC + c4) = a;
-        *reinterpret_cast<float4*>(t3 + n * TC + c4) = c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < items) {
+                const int n = i / (TC / 4), c4 = (i % (TC / 4)) * 4;
+                // relu(x / c) is what every consumer needs: do it once per node element
+                float4 x = a[u], y = c[u];
+                x.x = fmaxf(x.x / cdiv1, 0.f); x.y = fmaxf(x.y / cdiv1, 0.f); x.z = fmaxf(x.z / cdiv1, 0.f); x.w = fmaxf(x.w / cdiv1, 0.f);
+                y.x = fmaxf(y.x / cdiv1, 0.f); y.y = fmaxf(y.y / cdiv1, 0.f); y.z = fmaxf(y.z / cdiv1, 0.f); y.w = fmaxf(y.w / cdiv1, 0.f);
+                *reinterpret_cast<float4*>(t2 + n * TC + c4) = x;
+                *reinterpret_cast<float4*>(t3 + n * TC + c4) = y;
+            }
+        }
     }
     __syncthreads();
+    if (VEC) {                                                             // 8 relation streams x 32 lanes x 4 columns: 16-byte LDS reads and stores
+        const int cl4 = (threadIdx.x & 31) * 4, st = threadIdx.x >> 5;
+        if (c0 + cl4 >= L) return;
+        for (int k0 = st; k0 < K; k0 += 32) {
+            float4 v[4], sk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 8 * u;
+                if (k < K) {
+                    const float4 x = *reinterpret_cast<const float4*>(t2 + ns[k] * TC + cl4), y = *reinterpret_cast<const float4*>(t3 + no[k] * TC + cl4);
+                    v[u] = make_float4((x.x + y.x) / 2.f, (x.y + y.y) / 2.f, (x.z + y.z) / 2.f, (x.w + y.w) / 2.f);
+                    if (skip) sk[u] = *reinterpret_cast<const float4*>(skip + ((int64_t)b * K + k) * L + c0 + cl4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 8 * u;
+                if (k < K) {
+                    float4 r = v[u];
+                    if (skip) { r.x += sk[u].x; r.y += sk[u].y; r.z += sk[u].z; r.w += sk[u].w; }
+                    *reinterpret_cast<float4*>(Pout + ((int64_t)b * K + k) * L + c0 + cl4) = r;
+                }
+            }
+        }
+        return;
+    }
     const int cl = threadIdx.x & (TC - 1), half = threadIdx.x >> 7;   // 2 relation streams x 128 columns
     const int col = c0 + cl;
     if (col >= L) return;
-    for (int k = half; k < K; k += 2) {
-        float v = (t2[ns[k] * TC + cl] + t3[no[k] * TC + cl]) / 2.f;
-        const int64_t o = ((int64_t)b * K + k) * L + col;
-        if (skip) v += skip[o];
-        Pout[o] = v;
+    for (int k0 = half; k0 < K; k0 += 8) {                                 // four relations per round: LDS reads and skip loads in flight together
+        float v[4], sk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 2 * u;
+            if (k < K) {
+                v[u] = (t2[ns[k] * TC + cl] + t3[no[k] * TC + cl]) / 2.f;
+                sk[u] = skip ? skip[((int64_t)b * K + k) * L + col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 2 * u;
+            if (k < K) Pout[((int64_t)b * K + k) * L + col] = skip ? v[u] + sk[u] : v[u];
+        }
     }
 }
 
@@ -339,10 +407,10 @@ __global__ __launch_bounds__(256) void gcn_edges_bwd_vec_kernel(const float* __r
     const float* dp = dP + (int64_t)b * K * L + col;
     for (int n = blockIdx.z; n < N; n += gridDim.z) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        for (int j = ps[n]; j < ps[n + 1]; ++j) { const float4 x = *reinterpret_cast<const float4*>(dp + (int64_t)es[j] * L); a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
-        for (int j = po[n]; j < po[n + 1]; ++j) { const float4 x = *reinterpret_cast<const float4*>(dp + (int64_t)eo[j] * L); c.x += x.x; c.y += x.y; c.z += x.z; c.w += x.w; }
         const int64_t o = ((int64_t)b * N + n) * L + col;
         const float4 f2 = *reinterpret_cast<const float4*>(F2 + o), f3 = *reinterpret_cast<const float4*>(F3 + o);
+        auto row = [&](int e) { return *reinterpret_cast<const float4*>(dp + (int64_t)e * L); };
+        gather_pair(es, ps[n], ps[n + 1], row, eo, po[n], po[n + 1], row, a, c);
         float4 r2, r3;
         r2.x = (f2.x / cdiv1 > 0.f) ? a.x * 0.5f / cdiv1 : 0.f; r2.y = (f2.y / cdiv1 > 0.f) ? a.y * 0.5f / cdiv1 : 0.f;
         r2.z = (f2.z / cdiv1 > 0.f) ? a.z * 0.5f / cdiv1 : 0.f; r2.w = (f2.w / cdiv1 > 0.f) ? a.w * 0.5f / cdiv1 : 0.f;
@@ -618,9 +686,9 @@ SUBGC_API int subgc_gcn_nodes_fwd(const float* F0, const float* F1, const int32_
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + (skip ? 2.0 : 1.0) * N));
     const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
     if (gcn_vec_ok(L, F0, F1, skip, Xout) && (reinterpret_cast<uintptr_t>(act) & 3) == 0)
-        hipLaunchKernelGGL(gcn_nodes_fwd_vec_kernel, dim3((L / 4 + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, F0, F1, ptr, edges, skip, Xout, act, B, N, K, L);
+        hipLaunchKernelGGL(gcn_nodes_fwd_vec_kernel, dim3((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, N)), dim3(256), lds, s, F0, F1, ptr, edges, skip, Xout, act, B, N, K, L);
     else
-        hipLaunchKernelGGL(gcn_nodes_fwd_kernel, dim3((L + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, F0, F1, ptr, edges, skip, Xout, act, B, N, K, L);
+        hipLaunchKernelGGL(gcn_nodes_fwd_kernel, dim3((L + 255) / 256, B, subgc::gcn_zsplit((L + 255) / 256, B, N)), dim3(256), lds, s, F0, F1, ptr, edges, skip, Xout, act, B, N, K, L);
     return subgc::check_launch("subgc_gcn_nodes_fwd");
 }
 
@@ -633,9 +701,9 @@ SUBGC_API int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 2.0 * K));
     const size_t lds = sizeof(int) * (2 * K) + sizeof(float) * 2 * N;
     if (gcn_vec_ok(L, dX, dF0, dF1, nullptr) && (reinterpret_cast<uintptr_t>(act) & 3) == 0)
-        hipLaunchKernelGGL(gcn_nodes_bwd_vec_kernel, dim3((L / 4 + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
+        hipLaunchKernelGGL(gcn_nodes_bwd_vec_kernel, dim3((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, (K + 3) / 4)), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
     else
-        hipLaunchKernelGGL(gcn_nodes_bwd_kernel, dim3((L + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
+        hipLaunchKernelGGL(gcn_nodes_bwd_kernel, dim3((L + 255) / 256, B, subgc::gcn_zsplit((L + 255) / 256, B, K)), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
     return subgc::check_launch("subgc_gcn_nodes_bwd");
 }
 
@@ -647,10 +715,12 @@ SUBGC_API int subgc_gcn_edges_fwd(const float* F2, const float* F3, const int64_
     SUBGC_REQUIRE(L % 4 == 0, "gcn_edges_fwd: L must be a multiple of 4 (got %d)", L);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float) * 2 * (size_t)N * TC + sizeof(int) * 2 * K;
-    int rc = raise_lds((const void*)gcn_edges_fwd_kernel, lds, "gcn_edges_fwd");
+    const bool vec = gcn_vec_ok(L, Pout, skip, nullptr, nullptr);
+    int rc = vec ? raise_lds((const void*)gcn_edges_fwd_kernel<true>, lds, "gcn_edges_fwd") : raise_lds((const void*)gcn_edges_fwd_kernel<false>, lds, "gcn_edges_fwd");
     if (rc) return rc;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * N + (skip ? 2.0 : 1.0) * K));
-    hipLaunchKernelGGL(gcn_edges_fwd_kernel, dim3((L + TC - 1) / TC, B), dim3(256), lds, s, F2, F3, rel_ind, skip, Pout, B, N, K, L);
+    if (vec) hipLaunchKernelGGL(gcn_edges_fwd_kernel<true>, dim3((L + TC - 1) / TC, B), dim3(256), lds, s, F2, F3, rel_ind, skip, Pout, B, N, K, L);
+    else hipLaunchKernelGGL(gcn_edges_fwd_kernel<false>, dim3((L + TC - 1) / TC, B), dim3(256), lds, s, F2, F3, rel_ind, skip, Pout, B, N, K, L);
     return subgc::check_launch("subgc_gcn_edges_fwd");
 }
 
@@ -663,9 +733,9 @@ SUBGC_API int subgc_gcn_edges_bwd(const float* dP, const float* F2, const float*
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 4.0 * N));
     const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
     if (gcn_vec_ok(L, dP, F2, F3, dF2) && (reinterpret_cast<uintptr_t>(dF3) & 15) == 0)
-        hipLaunchKernelGGL(gcn_edges_bwd_vec_kernel, dim3((L / 4 + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, dP, F2, F3, ptr, edges, dF2, dF3, B, N, K, L);
+        hipLaunchKernelGGL(gcn_edges_bwd_vec_kernel, dim3((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, N)), dim3(256), lds, s, dP, F2, F3, ptr, edges, dF2, dF3, B, N, K, L);
     else
-        hipLaunchKernelGGL(gcn_edges_bwd_kernel, dim3((L + 255) / 256, B, GCN_ZSPLIT), dim3(256), lds, s, dP, F2, F3, ptr, edges, dF2, dF3, B, N, K, L);
+        hipLaunchKernelGGL(gcn_edges_bwd_kernel, dim3((L + 255) / 256, B, subgc::gcn_zsplit((L + 255) / 256, B, N)), dim3(256), lds, s, dP, F2, F3, ptr, edges, dF2, dF3, B, N, K, L);
     return subgc::check_launch("subgc_gcn_edges_bwd");
 }
 
