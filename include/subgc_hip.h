@@ -374,6 +374,9 @@ int subgc_attn_dv_accum(const float* alpha, int n_stride, const float* dctx, int
  * NULL): rows with active == 0 are written as zeros (the reference leaves `outputs` rows of the
  * steps after its early break at zero, AttModel.py:152,171-172).                              */
 int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, const int32_t* active, void* stream);
+/* lse[r] = log sum_c exp(x[r, c]) (one read of the row, nothing written back): the loss-only path keeps RAW logits and hands `lse` to
+ * subgc_masked_nll_fwd / subgc_nll_logsoftmax_bwd, which subtract it on the fly -- log_softmax (AttModel.py:336) without the write. */
+int subgc_row_lse_f32(const float* x, int64_t ldx, int rows, int V, float* lse, void* stream);
 /* dlogits = dout - exp(logp) * sum(dout); dlogits may alias dout (in place).                 */
 int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, void* dlogits, int64_t ld, int rows,
                                int V, const int32_t* active, int out_bf16, void* stream);
@@ -381,19 +384,22 @@ int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, void* dlogi
  * loss = num/den.  logp [S,T,V]; target, mask are [S,T] views of the [S,T+1] label/mask tensors
  * shifted by one (row strides t_stride / m_stride).  bwd writes dlogp (dense, zero elsewhere). */
 /* den_override (device float*, may be NULL): use *den_override as the denominator instead of the mask sum of the rows given
- * (the packed decoder hands in only the live rows; the reference divides by the sum of ALL mask entries). */
+ * (the packed decoder hands in only the live rows; the reference divides by the sum of ALL mask entries).
+ * lse (float [S*T], may be NULL): `logp` holds raw logits, the log-probability of row q is logp[q, w] - lse[q]. */
 int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask,
                          int64_t m_stride, float* loss, float* scratch2, int S, int T, int V, const float* den_override,
-                         void* stream);
+                         const float* lse, void* stream);
 int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
                          const float* scratch2, const float* dloss, float* dlogp, int S, int T, int V,
                          void* stream);
 /* masked-NLL backward fused through the log-softmax (the criterion applied directly to the decoder's
  * log-probabilities, as LossWrapper does): dlogits = dloss * mask/den * (softmax - onehot(target));
- * never materialises the dense dlogp.  scratch2 is the {num, den} pair written by masked_nll_fwd.  */
+ * never materialises the dense dlogp.  scratch2 is the {num, den} pair written by masked_nll_fwd.  lse (may be NULL): `logp` holds raw
+ * logits and lse their row log-sum-exp (subgc_row_lse_f32).  */
 int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask,
                              int64_t m_stride, const float* scratch2, const float* dloss, void* dlogits,
-                             int64_t ld_out, int S, int T, int V, const int32_t* active, int out_bf16, void* stream);
+                             int64_t ld_out, int S, int T, int V, const int32_t* active, int out_bf16, const float* lse,
+                             void* stream);
 /* step_active[t] = 1 for t = 0 and for t >= 1 while no earlier step had all labels[:, t] == 0
  * (AttModel.py:171-172), expanded to rows: active[s*T + t].                                  */
 int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream);

@@ -255,11 +255,11 @@ constexpr int MAXLEN = 512;
 // the row is held in registers between its single read and its single write (PER x 256 >= V)
 template <int PER>
 __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x, int64_t ldx, int rows, int V,
-                                                          const int32_t* __restrict__ active) {
+                                                          const int32_t* __restrict__ active, float* __restrict__ lse_out) {
     __shared__ float sm[16];
     const int r = blockIdx.x;
     float* p = x + (int64_t)r * ldx;
-    if (active && !active[r]) {
+    if (!lse_out && active && !active[r]) {
         for (int c = threadIdx.x; c < V; c += blockDim.x) p[c] = 0.f;
         return;
     }
@@ -278,6 +278,10 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(float* __restrict__ x,
     for (int j = 0; j < PER; ++j) sum += (threadIdx.x + j * 256 < V) ? expf(v[j] - mx) : 0.f;
     sum = block_sum(sum, sm);
     const float lse = mx + logf(sum);
+    if (lse_out) {                                                        // the row stays as it is: consumers subtract lse themselves
+        if (threadIdx.x == 0) lse_out[r] = lse;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int c = threadIdx.x + j * 256;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 __global__ __launch_bounds__(1024) void nll_fwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
                                                        int64_t t_stride, const float* __restrict__ mask, int64_t m_stride,
                                                        float* __restrict__ loss, float* __restrict__ scratch2, int S, int T, int V,
-                                                       const float* __restrict__ den_override) {
+                                                       const float* __restrict__ den_override, const float* __restrict__ lse) {
     __shared__ float sm[16];
     float num = 0.f, den = 0.f;
     for (int q = threadIdx.x; q < S * T; q += blockDim.x) {
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(1024) void nll_fwd_kernel(const float* __restrict__
         const float m = mask[(int64_t)s * m_stride + t];
         int64_t w = target[(int64_t)s * t_stride + t];
         w = w < 0 ? 0 : (w >= V ? V - 1 : w);
-        num += -logp[(int64_t)q * V + w] * m;
+        num += -(logp[(int64_t)q * V + w] - (lse ? lse[q] : 0.f)) * m;
         den += m;
     }
     num = block_sum(num, sm);
@@ -340,20 +344,34 @@ __global__ __launch_bounds__(256) void nll_logsoftmax_bwd_kernel(const float* __
                                                                  int64_t t_stride, const float* __restrict__ mask, int64_t m_stride,
                                                                  const float* __restrict__ scratch2, const float* __restrict__ dloss,
                                                                  void* __restrict__ dlogits, int64_t ldo, int T, int V,
-                                                                 const int32_t* __restrict__ active, int b16) {
+                                                                 const int32_t* __restrict__ active, int b16, const float* __restrict__ lse, int vec) {
     // b16: d(logits) is a GEMM operand only (weight gradient and d(hidden)): written bf16, half the bytes of the largest tensor
+    // lse != NULL: `logp` holds RAW logits and lse[r] their row log-sum-exp (subgc_row_lse_f32): exp(x - lse) is the same number
+    // vec: V % 4 == 0 and 16-byte aligned rows on both sides -> four columns per lane (16-byte loads, 8/16-byte stores)
     const int r = blockIdx.x, s = r / T, t = r % T;
     const float m = mask[(int64_t)s * m_stride + t];
     const int64_t d = (int64_t)r * ldo;
     if (m == 0.f || (active && !active[r])) {
-        for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, d + c, 0.f, b16);
+        if (vec) { const float z[4] = {0.f, 0.f, 0.f, 0.f}; for (int c = threadIdx.x * 4; c < V; c += blockDim.x * 4) subgc_store_act<4>(dlogits, d + c, z, b16); }
+        else for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, d + c, 0.f, b16);
         return;
     }
     int64_t w = target[(int64_t)s * t_stride + t];
     w = w < 0 ? 0 : (w >= V ? V - 1 : w);
     const float g = dloss[0] * m / scratch2[1];
     const float* lp = logp + (int64_t)r * V;
-    for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, d + c, g * (expf(lp[c]) - (c == (int)w ? 1.f : 0.f)), b16);
+    const float sub = lse ? lse[r] : 0.f;
+    if (vec) {
+        for (int c = threadIdx.x * 4; c < V; c += blockDim.x * 4) {
+            const float4 x = *reinterpret_cast<const float4*>(lp + c);
+            const int wi = (int)w - c;
+            const float o[4] = {g * (expf(x.x - sub) - (wi == 0 ? 1.f : 0.f)), g * (expf(x.y - sub) - (wi == 1 ? 1.f : 0.f)),
+                                g * (expf(x.z - sub) - (wi == 2 ? 1.f : 0.f)), g * (expf(x.w - sub) - (wi == 3 ? 1.f : 0.f))};
+            subgc_store_act<4>(dlogits, d + c, o, b16);
+        }
+        return;
+    }
+    for (int c = threadIdx.x; c < V; c += blockDim.x) store_one(dlogits, d + c, g * (expf(lp[c] - sub) - (c == (int)w ? 1.f : 0.f)), b16);
 }
 __global__ __launch_bounds__(256) void step_active_kernel(const int64_t* __restrict__ labels, int64_t l_stride, int S, int T,
                                                           int32_t* __restrict__ active) {
@@ -836,11 +854,26 @@ SUBGC_API int subgc_log_softmax_rows(float* x, int64_t ldx, int rows, int V, con
     subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * rows * (double)V * 2);
     SUBGC_REQUIRE(V <= 256 * 64, "log_softmax_rows: at most %d columns", 256 * 64);
     const int per = (V + 255) / 256;
-    if (per <= 4) hipLaunchKernelGGL(log_softmax_kernel<4>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
-    else if (per <= 16) hipLaunchKernelGGL(log_softmax_kernel<16>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
-    else if (per <= 40) hipLaunchKernelGGL(log_softmax_kernel<40>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
-    else hipLaunchKernelGGL(log_softmax_kernel<64>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active);
+    if (per <= 4) hipLaunchKernelGGL(log_softmax_kernel<4>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active, (float*)nullptr);
+    else if (per <= 16) hipLaunchKernelGGL(log_softmax_kernel<16>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active, (float*)nullptr);
+    else if (per <= 40) hipLaunchKernelGGL(log_softmax_kernel<40>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active, (float*)nullptr);
+    else hipLaunchKernelGGL(log_softmax_kernel<64>, dim3(rows), dim3(256), 0, s, x, ldx, rows, V, active, (float*)nullptr);
     return subgc::check_launch("subgc_log_softmax_rows");
+}
+SUBGC_API int subgc_row_lse_f32(const float* x, int64_t ldx, int rows, int V, float* lse, void* stream) {
+    SUBGC_REQUIRE(rows >= 0 && V > 0 && ldx >= V, "row_lse: bad sizes");
+    if (rows == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(x && lse, "row_lse: null pointer");
+    SUBGC_REQUIRE(V <= 256 * 64, "row_lse: at most %d columns", 256 * 64);
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * rows * (double)V);
+    float* xm = const_cast<float*>(x);                                    // the kernel does not write the row when lse_out is given
+    const int per = (V + 255) / 256;
+    if (per <= 4) hipLaunchKernelGGL(log_softmax_kernel<4>, dim3(rows), dim3(256), 0, s, xm, ldx, rows, V, (const int32_t*)nullptr, lse);
+    else if (per <= 16) hipLaunchKernelGGL(log_softmax_kernel<16>, dim3(rows), dim3(256), 0, s, xm, ldx, rows, V, (const int32_t*)nullptr, lse);
+    else if (per <= 40) hipLaunchKernelGGL(log_softmax_kernel<40>, dim3(rows), dim3(256), 0, s, xm, ldx, rows, V, (const int32_t*)nullptr, lse);
+    else hipLaunchKernelGGL(log_softmax_kernel<64>, dim3(rows), dim3(256), 0, s, xm, ldx, rows, V, (const int32_t*)nullptr, lse);
+    return subgc::check_launch("subgc_row_lse_f32");
 }
 SUBGC_API int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, void* dlogits, int64_t ld, int rows, int V,
                                          const int32_t* active, int out_bf16, void* stream) {
@@ -853,11 +886,12 @@ SUBGC_API int subgc_log_softmax_rows_bwd(const float* logp, const float* dout, v
     return subgc::check_launch("subgc_log_softmax_rows_bwd");
 }
 SUBGC_API int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
-                                   float* loss, float* scratch2, int S, int T, int V, const float* den_override, void* stream) {
+                                   float* loss, float* scratch2, int S, int T, int V, const float* den_override, const float* lse,
+                                   void* stream) {
     SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "masked_nll_fwd: bad sizes");
     SUBGC_REQUIRE(logp && target && mask && loss && scratch2, "masked_nll_fwd: null pointer");
     hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, target, t_stride, mask, m_stride, loss,
-                       scratch2, S, T, V, den_override);
+                       scratch2, S, T, V, den_override, lse);
     return subgc::check_launch("subgc_masked_nll_fwd");
 }
 SUBGC_API int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride, const float* scratch2,
@@ -873,13 +907,15 @@ SUBGC_API int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, cons
 }
 SUBGC_API int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, int64_t t_stride, const float* mask, int64_t m_stride,
                                        const float* scratch2, const float* dloss, void* dlogits, int64_t ld_out, int S, int T, int V,
-                                       const int32_t* active, int out_bf16, void* stream) {
+                                       const int32_t* active, int out_bf16, const float* lse, void* stream) {
     SUBGC_REQUIRE(S > 0 && T > 0 && V > 0 && ld_out >= V, "nll_logsoftmax_bwd: bad sizes");
     SUBGC_REQUIRE(logp && target && mask && scratch2 && dloss && dlogits, "nll_logsoftmax_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * S * T * (double)V * 2);
+    const int vec = V % 4 == 0 && ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(logp) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dlogits) & (out_bf16 ? 7 : 15)) == 0;
     hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3(S * T), dim3(256), 0, s, logp, target, t_stride, mask, m_stride, scratch2, dloss,
-                       dlogits, ld_out, T, V, active, out_bf16);
+                       dlogits, ld_out, T, V, active, out_bf16, lse, vec);
     return subgc::check_launch("subgc_nll_logsoftmax_bwd");
 }
 SUBGC_API int subgc_step_active(const int64_t* labels, int64_t l_stride, int S, int T, int32_t* active, void* stream) {

@@ -747,11 +747,20 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
     const int col = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < N)
-        for (int r = r0 + w; r < r1; r += 4) {
+    if (col < N) {
+        int r = r0 + w;
+        for (; r + 12 < r1; r += 16) {                                     // four rows requested before the first is added (same order of additions)
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(X + (int64_t)(r + 4 * u) * ldx + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; r < r1; r += 4) {
             const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)r * ldx + col);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+    }
     sm[w][lane] = acc;
     __syncthreads();
     if (w == 0 && col < N) {
@@ -793,11 +802,20 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
     const int col = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < N)
-        for (int r = r0 + w; r < r1; r += 4) {
+    if (col < N) {
+        int r = r0 + w;
+        for (; r + 12 < r1; r += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = subgc_load4_bf(X + (int64_t)(r + 4 * u) * ldx + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; r < r1; r += 4) {
             const float4 v = subgc_load4_bf(X + (int64_t)r * ldx + col);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+    }
     sm[w][lane] = acc;
     __syncthreads();
     if (w == 0 && col < N) {

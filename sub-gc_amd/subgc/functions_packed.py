@@ -150,17 +150,17 @@ class PackedDecoderLossFn(Function):
         elif T_live > 0:
             op = ot[T_live - 1]
             ops.gemm(Hout[op:rows], W[21], logits[op:rows], tb=True, bias=lg_b)
-        ops.log_softmax_rows_(logits[:rows])
+        lse = ops.row_lse(logits[:rows])                                  # log_softmax without the write: the loss needs lse and one logit per row
         # criterion over the packed rows: row ot[t] + s  <->  (sentence perm[s], step t); the denominator is the sum of ALL mask
         # entries (dead ones included: the early break can cut live mask entries off), which the plan kernel computed
         tgt_p, msk_p = tgt_all[:max(rows, 1)], msk_all[:max(rows, 1)]
-        loss, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p, den=plan.den)
+        loss, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p, den=plan.den, lse=lse)
 
         ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
         ctx.masks = (k_xt, k_out)
         ctx.flat_tokens = (tok_flat, k_flat)
         ctx.W, ctx.bf = W, bf
-        ctx.pr, ctx.params, ctx.aux = pr, P, (plan, tokens_p, lens_p, tgt_p, msk_p, nll)      # tokens_p: the words actually fed
+        ctx.pr, ctx.params, ctx.aux = pr, P, (plan, tokens_p, lens_p, tgt_p, msk_p, nll, lse)      # tokens_p: the words actually fed
         ctx.save_for_backward(fc_p, X_nodes, logits, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL)
         return loss
 
@@ -170,7 +170,7 @@ class PackedDecoderLossFn(Function):
         k_xt, k_out = ctx.masks
         tok_flat, k_flat = ctx.flat_tokens
         pr, P, W, bf = ctx.pr, ctx.params, ctx.W, ctx.bf
-        plan, labels_p, lens_p, tgt_p, msk_p, nll = ctx.aux
+        plan, labels_p, lens_p, tgt_p, msk_p, nll, lse = ctx.aux
         (fc_p, X_nodes, logp, xt, Gf, Wc1, Wc2, H1, H2, C1, C2, Hout, G1, G2, AH, AL) = ctx.saved_tensors
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b, emb, w1i, w1h, b1i, b1h, w2i, w2h, b2i, b2h,
          h2a_w, h2a_b, an_w, an_b, lg_w, lg_b) = P
@@ -204,7 +204,7 @@ class PackedDecoderLossFn(Function):
                 ops.copy2d(tmp, out_for(j).view(1, -1), accumulate=acc[j])
 
         dlogits = ops.empty_b16(max(rows, 1), V1, dev) if bf else new(max(rows, 1), V1)      # bf16: half the bytes of the largest tensor
-        ops.nll_logsoftmax_bwd(logp[:rows], tgt_p, msk_p, nll, dloss.contiguous(), dlogits[:rows], None, rows, 1, V1)
+        ops.nll_logsoftmax_bwd(logp[:rows], tgt_p, msk_p, nll, dloss.contiguous(), dlogits[:rows], None, rows, 1, V1, lse=lse)
         wgrad(21, dlogits[:rows], Hout[:rows])
         bgrad(22, dlogits[:rows])
         dHout = new(max(rows, 1), R); ops.gemm(dlogits[:rows], W[21], dHout[:rows])

@@ -765,14 +765,22 @@ def log_softmax_rows_bwd(logp, dout, dlogits, active=None):
     return dlogits
 
 
-def masked_nll_fwd(logp, target, mask, den=None):
+def row_lse(x):
+    """lse[r] = logsumexp(x[r, :]) without touching x (subgc_row_lse_f32)."""
+    rows, V = x.shape
+    lse = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("subgc_row_lse_f32", _ptr(x, torch.float32), ld(x), rows, V, _ptr(lse), _stream())
+    return lse
+
+
+def masked_nll_fwd(logp, target, mask, den=None, lse=None):
     """logp [S,T,V] contiguous; target/mask are [S,T] views (unit inner stride) of the label tensors.  `den` (device scalar):
-    the denominator to use instead of the mask sum of the rows given."""
+    the denominator to use instead of the mask sum of the rows given.  `lse` [S*T]: logp holds raw logits (row_lse)."""
     S, T, V = logp.shape
     loss = torch.empty((), device=logp.device, dtype=torch.float32)
     scratch = torch.empty(2, device=logp.device, dtype=torch.float32)
     call("subgc_masked_nll_fwd", _ptr(logp), _ptr(target, torch.int64), target.stride(0), _ptr(mask, torch.float32), mask.stride(0),
-         _ptr(loss), _ptr(scratch), S, T, V, _ptr(den, torch.float32), _stream())
+         _ptr(loss), _ptr(scratch), S, T, V, _ptr(den, torch.float32), _ptr(lse, torch.float32), _stream())
     return loss, scratch
 
 
@@ -887,9 +895,9 @@ def masked_nll_bwd(target, mask, scratch, dloss, S, T, V):
     return dlogp
 
 
-def nll_logsoftmax_bwd(logp, target, mask, scratch, dloss, dlogits, active, S, T, V):
+def nll_logsoftmax_bwd(logp, target, mask, scratch, dloss, dlogits, active, S, T, V, lse=None):
     call("subgc_nll_logsoftmax_bwd", _ptr(logp), _ptr(target, torch.int64), target.stride(0), _ptr(mask), mask.stride(0), _ptr(scratch),
-         _ptr(dloss), _ptr(dlogits), ld(dlogits), S, T, V, _ptr(active, torch.int32), int(is_b16(dlogits)), _stream())
+         _ptr(dloss), _ptr(dlogits), ld(dlogits), S, T, V, _ptr(active, torch.int32), int(is_b16(dlogits)), _ptr(lse, torch.float32), _stream())
     return dlogits
 
 
