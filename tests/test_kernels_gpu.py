@@ -367,6 +367,37 @@ def test_log_softmax_nll_step_active():
     close(dl, xr.grad, atol=1e-6)
 
 
+@pytest.mark.parametrize("V", [9488, 7001, 52])                       # four-columns-per-lane form, scalar form (V % 4 != 0), one short row
+@pytest.mark.parametrize("b16", [False, True])
+def test_criterion_on_raw_logits_with_row_lse_equals_the_log_softmax_path(V, b16):
+    """Loss-only path (functions_packed): logits stay raw, subgc_row_lse_f32 gives the row log-sum-exp, the criterion and its fused
+    backward subtract it on the fly -- same loss and d(logits) as log_softmax_rows_ + the plain calls, and as torch in fp64."""
+    rows = 37
+    x = rnd(rows, V, seed=V, scale=3.0)
+    g = torch.Generator().manual_seed(V)
+    tgt = torch.randint(0, V, (rows, 1), generator=g).to(DEV)
+    msk = (torch.rand(rows, 1, generator=g) > 0.25).float().to(DEV)
+    den = msk.sum().view(1) + 3.0                                     # the packed decoder's denominator covers rows this call does not see
+    lse = ops.row_lse(x)
+    close(lse, torch.logsumexp(x.double(), 1), atol=2e-5)
+    loss_a, sc_a = ops.masked_nll_fwd(x.view(rows, 1, V), tgt, msk, den=den, lse=lse)
+    lp = ops.log_softmax_rows_(x.clone())
+    loss_b, sc_b = ops.masked_nll_fwd(lp.view(rows, 1, V), tgt, msk, den=den)
+    close(loss_a, loss_b, atol=1e-6)
+    ref = -(torch.log_softmax(x.double(), 1).gather(1, tgt) * msk.double()).sum() / den.double()
+    close(loss_a, ref.view(()), atol=1e-5)
+    dt = torch.bfloat16 if b16 else torch.float32
+    ld = -(-V // 8) * 8
+    one = torch.tensor(0.7, device=DEV)
+    da = torch.zeros(rows, ld, device=DEV, dtype=dt)[:, :V]
+    db = torch.zeros(rows, ld, device=DEV, dtype=dt)[:, :V]
+    ops.nll_logsoftmax_bwd(x, tgt, msk, sc_a, one, da, None, rows, 1, V, lse=lse)
+    ops.nll_logsoftmax_bwd(lp, tgt, msk, sc_b, one, db, None, rows, 1, V)
+    assert torch.equal(da, db)                                        # exp(x - lse) IS exp(logp): bit-identical
+    want = 0.7 * msk.double() / den.double() * (torch.softmax(x.double(), 1) - torch.zeros(rows, V, device=DEV, dtype=torch.double).scatter_(1, tgt, 1.0))
+    close(da.float(), want, atol=2e-3 * float(want.abs().max()) if b16 else 1e-7, rtol=1e-2 if b16 else 1e-4)
+
+
 def test_decode_pick_greedy_topk_and_finished_masking():
     n, V, T = 6, 9488, 20
     logp = torch.log_softmax(rnd(n, V, seed=3, scale=2.0), 1)
