@@ -90,26 +90,10 @@ __global__ __launch_bounds__(256) void token_rows_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
                                                         int64_t tok_stride, const uint8_t* __restrict__ keep, float scale,
                                                         const float* __restrict__ dout, float* __restrict__ dtable, int n, int E,
-                                                        int rows, int vec) {
+                                                        int rows) {
     const int r = blockIdx.x;
     int64_t w = tok[(int64_t)r * tok_stride];
     w = w < 0 ? 0 : (w >= rows ? rows - 1 : w);
-    if (vec) {                                                            // E % 4 == 0, 16-byte aligned rows: four columns per lane
-        for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
-            const float4 tv = *reinterpret_cast<const float4*>(table + w * E + c);
-            const float4 gv = *reinterpret_cast<const float4*>(dout + (int64_t)r * E + c);
-            const uint32_t kv = keep ? *reinterpret_cast<const uint32_t*>(keep + (int64_t)r * E + c) : 0xffffffffu;
-            const float tt[4] = {tv.x, tv.y, tv.z, tv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (tt[e] <= 0.f) continue;
-                float g = gg[e];
-                if (keep) g = ((kv >> (8 * e)) & 0xffu) ? g * scale : 0.f;
-                if (g != 0.f) unsafeAtomicAdd(dtable + w * E + c + e, g);
-            }
-        }
-        return;
-    }
     for (int c = threadIdx.x; c < E; c += blockDim.x) {
         if (table[w * E + c] <= 0.f) continue;
         float g = dout[(int64_t)r * E + c];
@@ -692,10 +676,9 @@ SUBGC_API int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t to
     SUBGC_REQUIRE(n >= 0 && E > 0 && vocab_rows > 0, "embed_bwd: bad sizes");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(table && tok && dout && dtable, "embed_bwd: null pointer");
-    const int vec = E % 4 == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
+    // (a four-columns-per-lane form was measured: 114 -> 215 us on Full_GC_Kar -- a lane's four atomics land on one line back to back)
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, tok, tok_stride, keep, keep_scale, dout,
-                       dtable, n, E, vocab_rows, vec);
+                       dtable, n, E, vocab_rows);
     return subgc::check_launch("subgc_embed_bwd");
 }
 
