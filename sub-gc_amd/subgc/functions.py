@@ -56,6 +56,7 @@ class LinearFn(Function):
         ctx.save_for_backward(xa, W16, y if (relu or keep is not None) else None)
         if want16:
             ctx.mark_non_differentiable(y16)
+            ctx.set_materialize_grads(False)          # no zero tensor for the non-differentiable bf16 copy
             return y, y16
         return y
 
@@ -301,6 +302,7 @@ class GcnNodesBnFn(Function):
         ctx.dims, ctx.has_skip, ctx.training = (B, N, K, L), skip is not None, training
         if want16:
             ctx.mark_non_differentiable(out16)
+            ctx.set_materialize_grads(False)          # else autograd hands the backward a zero tensor for the bf16 copy (an ATen fill per call)
             return out, out16
         return out
 
@@ -333,6 +335,7 @@ class GcnEdgesBnFn(Function):
         ctx.dims, ctx.has_skip, ctx.training = (B, N, K, L), skip is not None, training
         if want16:
             ctx.mark_non_differentiable(out16)
+            ctx.set_materialize_grads(False)          # else autograd hands the backward a zero tensor for the bf16 copy (an ATen fill per call)
             return out, out16
         return out
 
