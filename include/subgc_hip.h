@@ -154,8 +154,10 @@ int subgc_csr_build(const int64_t* rel_ind, int B, int K, int N, int32_t* ptr, i
  */
 int subgc_gcn_nodes_fwd(const float* F0, const float* F1, const int32_t* ptr, const int32_t* edges,
                         const float* skip, float* Xout, uint8_t* act, int B, int N, int K, int L, void* stream);
+/* out_bf16 (nodes_bwd, edges_bwd_bn): the gradients are written bf16 -- the storage type of the unit outputs they belong to under
+ * compute_dtype = bf16 (their only consumers are GEMMs) -- instead of fp32 followed by a cast pass. */
 int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int64_t* rel_ind, const int32_t* ptr,
-                        float* dF0, float* dF1, int B, int N, int K, int L, void* stream);
+                        void* dF0, void* dF1, int out_bf16, int B, int N, int K, int L, void* stream);
 int subgc_gcn_edges_fwd(const float* F2, const float* F3, const int64_t* rel_ind, const float* skip,
                         float* Pout, int B, int N, int K, int L, void* stream);
 int subgc_gcn_edges_bwd(const float* dP, const float* F2, const float* F3, const int32_t* ptr,
@@ -199,7 +201,8 @@ int subgc_gcn_nodes_fwd_bn(const void* F0, const void* F1, int f_bf16, const flo
 int subgc_gcn_edges_fwd_bn(const void* F2, const void* F3, int f_bf16, const float* aff2, const float* aff3, const int64_t* rel_ind,
                            const float* skip, float* Pout, uint16_t* Pout16, int B, int N, int K, int L, void* stream);
 int subgc_gcn_edges_bwd_bn(const float* dP, const void* F2, const void* F3, int f_bf16, const float* aff2, const float* aff3,
-                           const int32_t* ptr, const int32_t* edges, float* dF2, float* dF3, int B, int N, int K, int L, void* stream);
+                           const int32_t* ptr, const int32_t* edges, void* dF2, void* dF3, int out_bf16, int B, int N, int K, int L,
+                           void* stream);
 
 /* ======================================================================================
  * sGPN (replaces gpn.py:152-185 gather + diagonal bmm + max/mean pooling, never materialising

@@ -321,8 +321,8 @@ template <bool SRC16>
 __global__ __launch_bounds__(256) void gcn_edges_bwd_bn_kernel(const float* __restrict__ dP, const void* __restrict__ F2,
                                                                const void* __restrict__ F3, const float* __restrict__ aff2,
                                                                const float* __restrict__ aff3, const int32_t* __restrict__ ptr,
-                                                               const int32_t* __restrict__ edges, float* __restrict__ dF2,
-                                                               float* __restrict__ dF3, int B, int N, int K, int L) {
+                                                               const int32_t* __restrict__ edges, void* __restrict__ dF2,
+                                                               void* __restrict__ dF3, int B, int N, int K, int L, int o16) {
     extern __shared__ int sm_i[];
     int* ps = sm_i; int* po = ps + (N + 1); int* es = po + (N + 1); int* eo = es + K;
     const int b = blockIdx.y;
@@ -351,8 +351,9 @@ __global__ __launch_bounds__(256) void gcn_edges_bwd_bn_kernel(const float* __re
         r2.z = (f2.z / cdiv1 > 0.f) ? a.z * 0.5f / cdiv1 : 0.f; r2.w = (f2.w / cdiv1 > 0.f) ? a.w * 0.5f / cdiv1 : 0.f;
         r3.x = (f3.x / cdiv1 > 0.f) ? c.x * 0.5f / cdiv1 : 0.f; r3.y = (f3.y / cdiv1 > 0.f) ? c.y * 0.5f / cdiv1 : 0.f;
         r3.z = (f3.z / cdiv1 > 0.f) ? c.z * 0.5f / cdiv1 : 0.f; r3.w = (f3.w / cdiv1 > 0.f) ? c.w * 0.5f / cdiv1 : 0.f;
-        *reinterpret_cast<float4*>(dF2 + o) = r2;
-        *reinterpret_cast<float4*>(dF3 + o) = r3;
+        const float o2[4] = {r2.x, r2.y, r2.z, r2.w}, o3[4] = {r3.x, r3.y, r3.z, r3.w};
+        subgc_store_act<4>(dF2, o, o2, o16);
+        subgc_store_act<4>(dF3, o, o3, o16);
     }
 }
 
@@ -581,17 +582,18 @@ SUBGC_API int subgc_gcn_edges_fwd_bn(const void* F2, const void* F3, int f_bf16,
 }
 
 SUBGC_API int subgc_gcn_edges_bwd_bn(const float* dP, const void* F2, const void* F3, int f_bf16, const float* aff2, const float* aff3,
-                                     const int32_t* ptr, const int32_t* edges, float* dF2, float* dF3, int B, int N, int K, int L, void* stream) {
+                                     const int32_t* ptr, const int32_t* edges, void* dF2, void* dF3, int out_bf16, int B, int N, int K, int L,
+                                     void* stream) {
     SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0 && L % 4 == 0, "gcn_edges_bwd_bn: bad sizes (L must be a multiple of 4)");
     if (B == 0) return SUBGC_OK;
     SUBGC_REQUIRE(dP && F2 && F3 && ptr && edges && dF2 && dF3, "gcn_edges_bwd_bn: null pointer");
-    SUBGC_REQUIRE(al16(dP) && (f_bf16 ? (al8(F2) && al8(F3)) : (al16(F2) && al16(F3))) && al16(dF2) && al16(dF3) && al16(aff2) && al16(aff3),
-                  "gcn_edges_bwd_bn: misaligned pointer");
+    SUBGC_REQUIRE(al16(dP) && (f_bf16 ? (al8(F2) && al8(F3)) : (al16(F2) && al16(F3))) && (out_bf16 ? (al8(dF2) && al8(dF3)) : (al16(dF2) && al16(dF3))) &&
+                      al16(aff2) && al16(aff3), "gcn_edges_bwd_bn: misaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 2.0 * N) + (f_bf16 ? 2.0 : 4.0) * B * L * 2.0 * N);
     const size_t lds = sizeof(int) * (2 * (N + 1) + 2 * K);
     const dim3 g((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, N));
-    if (f_bf16) hipLaunchKernelGGL((gcn_edges_bwd_bn_kernel<true>), g, dim3(256), lds, s, dP, F2, F3, aff2, aff3, ptr, edges, dF2, dF3, B, N, K, L);
-    else hipLaunchKernelGGL((gcn_edges_bwd_bn_kernel<false>), g, dim3(256), lds, s, dP, F2, F3, aff2, aff3, ptr, edges, dF2, dF3, B, N, K, L);
+    if (f_bf16) hipLaunchKernelGGL((gcn_edges_bwd_bn_kernel<true>), g, dim3(256), lds, s, dP, F2, F3, aff2, aff3, ptr, edges, dF2, dF3, B, N, K, L, out_bf16);
+    else hipLaunchKernelGGL((gcn_edges_bwd_bn_kernel<false>), g, dim3(256), lds, s, dP, F2, F3, aff2, aff3, ptr, edges, dF2, dF3, B, N, K, L, out_bf16);
     return subgc::check_launch("subgc_gcn_edges_bwd_bn");
 }

@@ -6,6 +6,7 @@
 // by CSR); graph_conv_unit.py:28-36 (bmm + normalise + ReLU, BatchNorm); graph_conv.py:24-33
 // (average of the two roles); gcn_backbone.py:43-47 (residual).
 #include "common.h"
+#include "bf16_util.h"
 
 #include <algorithm>
 
@@ -196,9 +197,10 @@ __global__ __launch_bounds__(256) void gcn_nodes_bwd_kernel(const float* __restr
     }
 }
 
+// o16: dF0 / dF1 are bf16 (the unit outputs they are gradients of were bf16 GEMM results: compute_dtype = bf16 without BatchNorm)
 __global__ __launch_bounds__(256) void gcn_nodes_bwd_vec_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ act,
                                                                 const int64_t* __restrict__ rel_ind, const int32_t* __restrict__ ptr,
-                                                                float* __restrict__ dF0, float* __restrict__ dF1, int B, int N, int K, int L) {
+                                                                void* __restrict__ dF0, void* __restrict__ dF1, int B, int N, int K, int L, int o16) {
     extern __shared__ int sm_i[];
     int* ns = sm_i; int* no = ns + K;
     float* ds = reinterpret_cast<float*>(no + K); float* dn_o = ds + N;
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(256) void gcn_nodes_bwd_vec_kernel(const float* __r
                     go[e] = ((ao[u] >> (8 * e)) & 2u) ? xov[e] * 0.5f / dn_o[on[u]] : 0.f;
                 }
                 const int64_t ok = ((int64_t)b * K + k) * L + col;
-                *reinterpret_cast<float4*>(dF0 + ok) = make_float4(gs[0], gs[1], gs[2], gs[3]);
-                *reinterpret_cast<float4*>(dF1 + ok) = make_float4(go[0], go[1], go[2], go[3]);
+                subgc_store_act<4>(dF0, ok, gs, o16);
+                subgc_store_act<4>(dF1, ok, go, o16);
             }
         }
     }
@@ -692,18 +694,21 @@ SUBGC_API int subgc_gcn_nodes_fwd(const float* F0, const float* F1, const int32_
     return subgc::check_launch("subgc_gcn_nodes_fwd");
 }
 
-SUBGC_API int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int64_t* rel_ind, const int32_t* ptr, float* dF0,
-                                  float* dF1, int B, int N, int K, int L, void* stream) {
+SUBGC_API int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int64_t* rel_ind, const int32_t* ptr, void* dF0,
+                                  void* dF1, int out_bf16, int B, int N, int K, int L, void* stream) {
     SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0, "gcn_nodes_bwd: bad sizes");
     if (B == 0) return SUBGC_OK;
     SUBGC_REQUIRE(dX && act && rel_ind && ptr && dF0 && dF1, "gcn_nodes_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 2.0 * K));
     const size_t lds = sizeof(int) * (2 * K) + sizeof(float) * 2 * N;
-    if (gcn_vec_ok(L, dX, dF0, dF1, nullptr) && (reinterpret_cast<uintptr_t>(act) & 3) == 0)
-        hipLaunchKernelGGL(gcn_nodes_bwd_vec_kernel, dim3((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, (K + 3) / 4)), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
+    const bool vec = gcn_vec_ok(L, dX, nullptr, nullptr, nullptr) && (reinterpret_cast<uintptr_t>(act) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(dF0) | reinterpret_cast<uintptr_t>(dF1)) & (out_bf16 ? 7 : 15)) == 0;
+    SUBGC_REQUIRE(vec || !out_bf16, "gcn_nodes_bwd: bf16 gradients need L %% 4 == 0 and aligned rows");
+    if (vec)
+        hipLaunchKernelGGL(gcn_nodes_bwd_vec_kernel, dim3((L / 4 + 255) / 256, B, subgc::gcn_zsplit((L / 4 + 255) / 256, B, (K + 3) / 4)), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L, out_bf16);
     else
-        hipLaunchKernelGGL(gcn_nodes_bwd_kernel, dim3((L + 255) / 256, B, subgc::gcn_zsplit((L + 255) / 256, B, K)), dim3(256), lds, s, dX, act, rel_ind, ptr, dF0, dF1, B, N, K, L);
+        hipLaunchKernelGGL(gcn_nodes_bwd_kernel, dim3((L + 255) / 256, B, subgc::gcn_zsplit((L + 255) / 256, B, K)), dim3(256), lds, s, dX, act, rel_ind, ptr, static_cast<float*>(dF0), static_cast<float*>(dF1), B, N, K, L);
     return subgc::check_launch("subgc_gcn_nodes_bwd");
 }
 

@@ -252,6 +252,61 @@ class GcnNodesFn(Function):
         return dF0, dF1, (dX if ctx.has_skip else None), None, None, None, None
 
 
+class GcnNodesB16Fn(Function):
+    """GcnNodesFn for bf16-STORED unit outputs (compute_dtype = bf16, no BatchNorm: Sub-GC presets): the normalise-on-load kernels with the
+    identity triple read the bf16 GEMM results as they are, d(y) leaves the backward in bf16 (what the Linear backward's GEMMs consume),
+    and the result's bf16 copy for the next layer's GEMM comes out of the same launch (`want16`) -- no fp32 unit outputs, no cast passes."""
+
+    @staticmethod
+    def forward(ctx, y0, y1, skip, rel_ind, ptr, edges, N, want16):
+        B, K, L = y0.shape
+        y0, y1 = y0.contiguous(), y1.contiguous()
+        ident = ops.identity_aff(L, y0.device)
+        out, out16, act = ops.gcn_nodes_fwd_bn(y0, y1, ident, ident, ptr, edges, skip.contiguous() if skip is not None else None, B, N, K, L, want16)
+        ctx.save_for_backward(act, rel_ind, ptr)
+        ctx.dims, ctx.has_skip = (B, N, K, L), skip is not None
+        if want16:
+            ctx.mark_non_differentiable(out16)
+            ctx.set_materialize_grads(False)
+            return out, out16
+        return out
+
+    @staticmethod
+    def backward(ctx, dX, *_unused):
+        act, rel_ind, ptr = ctx.saved_tensors
+        B, N, K, L = ctx.dims
+        dX = dX.contiguous()
+        dy0, dy1 = ops.gcn_nodes_bwd(dX, act, rel_ind, ptr, B, N, K, L, bf16=True)
+        return dy0, dy1, (dX if ctx.has_skip else None), None, None, None, None, None
+
+
+class GcnEdgesB16Fn(Function):
+    """GcnEdgesFn for bf16-stored unit outputs (see GcnNodesB16Fn)."""
+
+    @staticmethod
+    def forward(ctx, y2, y3, skip, rel_ind, ptr, edges, K, want16):
+        B, N, L = y2.shape
+        y2, y3 = y2.contiguous(), y3.contiguous()
+        ident = ops.identity_aff(L, y2.device)
+        out, out16 = ops.gcn_edges_fwd_bn(y2, y3, ident, ident, rel_ind, skip.contiguous() if skip is not None else None, B, N, K, L, want16)
+        ctx.save_for_backward(y2, y3, ptr, edges)
+        ctx.dims, ctx.has_skip = (B, N, K, L), skip is not None
+        if want16:
+            ctx.mark_non_differentiable(out16)
+            ctx.set_materialize_grads(False)
+            return out, out16
+        return out
+
+    @staticmethod
+    def backward(ctx, dP, *_unused):
+        y2, y3, ptr, edges = ctx.saved_tensors
+        B, N, K, L = ctx.dims
+        dP = dP.contiguous()
+        ident = ops.identity_aff(L, dP.device)
+        dy2, dy3 = ops.gcn_edges_bwd_bn(dP, y2, y3, ident, ident, ptr, edges, B, N, K, L, bf16=True)
+        return dy2, dy3, (dP if ctx.has_skip else None), None, None, None, None, None
+
+
 class GcnEdgesFn(Function):
     """relations <- nodes (units 2,3; LDS-staged gather)."""
 

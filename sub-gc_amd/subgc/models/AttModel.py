@@ -439,19 +439,26 @@ class AttModel(CaptionModel):
                 x16 = None
             x16n = p16n = None
             fuse = self.GCN_use_bn and L % 4 == 0
+            raw16 = w16 is not None and not self.GCN_use_bn and L % 8 == 0                  # bf16 storage, no BatchNorm: unit outputs stay bf16
             nxt_x = w16 is not None and l + 1 < self.GCN_layers and live_edges[l + 1]          # the next layer reads new_x as a GEMM operand
             nxt_p = w16 is not None and l + 1 < self.GCN_layers and live_nodes[l + 1]
             if live_nodes[l]:
-                y0, y1 = self._unit(l, 0, ps[0], p16, w16, fuse), self._unit(l, 1, ps[1], p16, w16, fuse)
+                y0, y1 = self._unit(l, 0, ps[0], p16, w16, fuse or raw16), self._unit(l, 1, ps[1], p16, w16, fuse or raw16)
                 if fuse:
                     r = F_.GcnNodesBnFn.apply(y0, y1, skip_x if res else None, rel_ind, ptr, edges, N, *self._bn_args(l, 0, 1), nxt_x)
+                    new_x, x16n = (r[0], r[1].view(B * N, L)) if nxt_x else (r, None)
+                elif raw16:
+                    r = F_.GcnNodesB16Fn.apply(y0, y1, skip_x if res else None, rel_ind, ptr, edges, N, nxt_x)
                     new_x, x16n = (r[0], r[1].view(B * N, L)) if nxt_x else (r, None)
                 else:
                     new_x = F_.GcnNodesFn.apply(y0, y1, skip_x if res else None, rel_ind, ptr, edges, N)
             if live_edges[l]:
-                y2, y3 = self._unit(l, 2, xs[0], x16, w16, fuse), self._unit(l, 3, xs[1], x16, w16, fuse)
+                y2, y3 = self._unit(l, 2, xs[0], x16, w16, fuse or raw16), self._unit(l, 3, xs[1], x16, w16, fuse or raw16)
                 if fuse:
                     r = F_.GcnEdgesBnFn.apply(y2, y3, skip_p if res else None, rel_ind, ptr, edges, K, *self._bn_args(l, 2, 3), nxt_p)
+                    new_p, p16n = (r[0], r[1].view(B * K, L)) if nxt_p else (r, None)
+                elif raw16:
+                    r = F_.GcnEdgesB16Fn.apply(y2, y3, skip_p if res else None, rel_ind, ptr, edges, K, nxt_p)
                     new_p, p16n = (r[0], r[1].view(B * K, L)) if nxt_p else (r, None)
                 else:
                     new_p = F_.GcnEdgesFn.apply(y2, y3, skip_p if res else None, rel_ind, ptr, edges, K)

@@ -334,10 +334,10 @@ def gcn_nodes_fwd(F0, F1, ptr, edges, skip, B, N, K, L, want_act=True):
     return out, act
 
 
-def gcn_nodes_bwd(dX, act, rel_ind, ptr, B, N, K, L):
-    dF0 = torch.empty(B, K, L, device=dX.device, dtype=torch.float32)
+def gcn_nodes_bwd(dX, act, rel_ind, ptr, B, N, K, L, bf16=False):
+    dF0 = torch.empty(B, K, L, device=dX.device, dtype=BF16 if bf16 else torch.float32)
     dF1 = torch.empty_like(dF0)
-    call("subgc_gcn_nodes_bwd", _ptr(dX), _ptr(act), _ptr(rel_ind), _ptr(ptr), _ptr(dF0), _ptr(dF1), B, N, K, L, _stream())
+    call("subgc_gcn_nodes_bwd", _ptr(dX), _ptr(act), _ptr(rel_ind), _ptr(ptr), _ptr(dF0), _ptr(dF1), int(bf16), B, N, K, L, _stream())
     return dF0, dF1
 
 
@@ -412,12 +412,26 @@ def gcn_edges_fwd_bn(F2, F3, aff2, aff3, rel_ind, skip, B, N, K, L, want16=False
     return out, out16
 
 
-def gcn_edges_bwd_bn(dP, F2, F3, aff2, aff3, ptr, edges, B, N, K, L):
-    dF2 = torch.empty(B, N, L, device=dP.device, dtype=torch.float32)
+def gcn_edges_bwd_bn(dP, F2, F3, aff2, aff3, ptr, edges, B, N, K, L, bf16=False):
+    dF2 = torch.empty(B, N, L, device=dP.device, dtype=BF16 if bf16 else torch.float32)
     dF3 = torch.empty_like(dF2)
     call("subgc_gcn_edges_bwd_bn", _ptr(dP, torch.float32), _ptr(F2), _ptr(F3), int(is_b16(F2)), _ptr(aff2, torch.float32), _ptr(aff3, torch.float32),
-         _ptr(ptr), _ptr(edges), _ptr(dF2), _ptr(dF3), B, N, K, L, _stream())
+         _ptr(ptr), _ptr(edges), _ptr(dF2), _ptr(dF3), int(bf16), B, N, K, L, _stream())
     return dF2, dF3
+
+
+_IDENT_AFF = {}
+
+
+def identity_aff(L, device):
+    """The (mean | scale | shift) triple of the normalise-on-load aggregation kernels that changes nothing: (0 | 1 | 0)."""
+    key = (L, device)
+    t = _IDENT_AFF.get(key)
+    if t is None:
+        t = torch.zeros(3, L, device=device, dtype=torch.float32)
+        t[1].fill_(1.0)
+        _IDENT_AFF[key] = t
+    return t
 
 
 def _pool_account(denom, G, L, fwd):

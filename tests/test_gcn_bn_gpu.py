@@ -134,3 +134,41 @@ def test_fused_bn_aggregation_fwd_bwd_matches_dense_reference(B, N, K, L, bf16):
     for a, t, name in zip(got, (y2, y3, skp, g2, b2, g3, b3), "y2 y3 skip g2 b2 g3 b3".split()):
         sc = float(t.grad.abs().max()) + 1e-12
         np.testing.assert_allclose(a.float().cpu().numpy(), t.grad.float().cpu().numpy(), atol=tol["atol"] * sc, rtol=tol["rtol"] * 5, err_msg=name)
+
+
+@pytest.mark.parametrize("B,N,K,L", [(3, 37, 65, 64), (2, 101, 301, 128)])
+def test_bf16_stored_unit_outputs_aggregate_like_their_fp32_values(B, N, K, L):
+    """compute_dtype = bf16 without BatchNorm (Sub-GC presets, Flickr shape): GcnNodesB16Fn / GcnEdgesB16Fn read the bf16 unit outputs
+    directly and write bf16 gradients -- same results as GcnNodesFn / GcnEdgesFn on the fp32 values of the same bf16 numbers, gradients
+    equal after rounding to bf16, the bf16 copy of the result equal to the rounded result."""
+    torch.manual_seed(B * N + 1)
+    rel = _graph(B, N, K, B).to(DEV)
+    ops.ensure_workspace(torch.device(DEV))
+    ptr, edges = ops.csr_build(rel, N)
+    BFT = torch.bfloat16
+
+    def pair(shape):
+        a16 = (torch.randn(*shape, device=DEV) * 2).to(BFT)
+        return a16.clone().requires_grad_(True), a16.float().requires_grad_(True)
+
+    (y0, y0f), (y1, y1f) = pair((B, K, L)), pair((B, K, L))
+    skip = torch.randn(B, N, L, device=DEV, requires_grad=True)
+    skipf = skip.detach().clone().requires_grad_(True)
+    out, out16 = F_.GcnNodesB16Fn.apply(y0, y1, skip, rel, ptr, edges, N, True)
+    ref = F_.GcnNodesFn.apply(y0f, y1f, skipf, rel, ptr, edges, N)
+    assert torch.equal(out, ref) and torch.equal(out16, ref.to(BFT))
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    assert y0.grad.dtype == BFT and torch.equal(y0.grad, y0f.grad.to(BFT)) and torch.equal(y1.grad, y1f.grad.to(BFT)) and torch.equal(skip.grad, skipf.grad)
+
+    (y2, y2f), (y3, y3f) = pair((B, N, L)), pair((B, N, L))
+    skp = torch.randn(B, K, L, device=DEV, requires_grad=True)
+    skpf = skp.detach().clone().requires_grad_(True)
+    outp = F_.GcnEdgesB16Fn.apply(y2, y3, skp, rel, ptr, edges, K, False)
+    refp = F_.GcnEdgesFn.apply(y2f, y3f, skpf, rel, ptr, edges, K)
+    assert torch.equal(outp, refp)
+    w = torch.randn_like(outp)
+    (outp * w).sum().backward()
+    (refp * w).sum().backward()
+    assert torch.equal(y2.grad, y2f.grad.to(BFT)) and torch.equal(y3.grad, y3f.grad.to(BFT)) and torch.equal(skp.grad, skpf.grad)
