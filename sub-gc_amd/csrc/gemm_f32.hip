@@ -607,7 +607,10 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
                                                                                                  : launch<128, 128, TA, TB, VEC>(a, s);
     const bool plain = !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows && (!a.m_dev || TA);
     if (plain && g_splitk && g_ws && big >= 16 && a.M > g_smallm) {
-        const int splits = choose_splits((int)big, (a.K + BK - 1) / BK);
+        // more than half a round of tiles and a short K: the K loop of a part does not get faster with twice the workgroups resident (the
+        // operand feed is shared), the planes and the reduce pass come on top -- 4736 x 512 x 1024 (148 tiles): 83 us in two parts, 62 us whole
+        const int kt_all = (a.K + BK - 1) / BK;
+        const int splits = (big >= 128 && kt_all <= 48) ? 1 : choose_splits((int)big, kt_all);
         if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
             return xm == 1 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 3 : 0>(a, s, splits)
                            : xm == 2 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s, splits) : launch_splitk<128, 128, TA, TB, VEC>(a, s, splits);
