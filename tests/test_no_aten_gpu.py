@@ -1,0 +1,67 @@
+"""Every FLOP and byte a training step moves on the device goes through the C ABI: one step (forward, backward, fused clip + Adam) of each
+BASELINE train config, watched with a TorchDispatchMode, issues no ATen op that launches a device kernel -- views, allocations and the
+pinned copy of the packed plan's row counts are all that is left to torch (boundary)."""
+import argparse
+import collections
+
+import pytest
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+import bench
+import subgc.models as models
+from subgc import parallel, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# ops that only make views / allocate / move the 17 plan counts to pinned memory
+HARMLESS = ("view", "reshape", "empty", "as_strided", "detach", "alias", "slice", "select", "transpose", "permute", "expand", "unsqueeze",
+            "squeeze", "_unsafe_view", "t.default", "unbind", "split", "narrow", "pin_memory", "is_pinned", "record_stream", "_reshape_alias",
+            "lift_fresh", "unfold", "chunk", "set_", "resize_", "stride", "sym_", "is_same_size", "_local_scalar_dense")
+
+
+class Watch(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.seen = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        r = func(*args, **(kwargs or {}))
+        name = str(func)
+        if not any(h in name for h in HARMLESS):
+            ts = [t for t in (list(args) + ([r] if torch.is_tensor(r) else [])) if torch.is_tensor(t)]
+            if any(t.is_cuda for t in ts):
+                host_copy = "copy_" in name and any(not t.is_cuda for t in ts)           # device -> pinned host: a DMA, not a kernel
+                if not host_copy:
+                    self.seen[name] += 1
+        return r
+
+
+@pytest.mark.parametrize("config", ["kar", "full_gc_kar", "flickr"])
+def test_train_step_issues_no_aten_device_kernel(config):
+    torch.manual_seed(3)
+    if config == "kar":
+        opt, data, B = bench.KAR, {}, 8
+    else:
+        cfg = bench.CONFIGS[config]
+        opt, data, B = cfg["opt"], cfg["data"], 8
+    m = models.setup(argparse.Namespace(**opt)).to(DEV).train()
+    lw = models.LossWrapper(m, None)
+    b = {k: v.to(DEV) for k, v in synthetic.make_train_batch(B, seed=5, **data).items()}
+    adam = parallel.FlatAdam(m)
+    one = torch.ones((), device=DEV)
+
+    def step():
+        m.flatten_grads()
+        out = lw(*bench.lw_args(b))
+        models.total_loss(out).backward(one)
+        adam.step()
+
+    step()
+    step()
+    torch.cuda.synchronize()
+    with Watch() as w:
+        step()
+    torch.cuda.synchronize()
+    assert not w.seen, dict(w.seen)
