@@ -251,6 +251,34 @@ def test_full_size_b32_train_matches_oracle_in_every_fp32_grade_gemm_mode(gemm_m
         close(gk, orc.P[k].grad, "grad " + k, atol=2e-5 + 2e-3 * float(orc.P[k].grad.abs().max()), rtol=5e-3)
 
 
+@pytest.mark.timeout(600)
+def test_bench_size_b128_train_matches_oracle():
+    """The bench workload itself (Sub_GC_Kar, 128 images = 640 sentences, 2560 sub-graphs; dropout off): loss and gradients of the packed
+    train step against the CPU oracle.  This is where the M = 640 split-K forms, the plane-consuming backward kernels and the full-round
+    128 x 128 tile launches carry the products -- the B = 2 / B = 32 comparisons above do not reach those dispatch branches."""
+    torch.manual_seed(0)
+    opt = argparse.Namespace(**KAR)
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    assert m.packed_decoder
+    batch = synthetic.make_train_batch(128, seed=0)
+    out, loss = run_train(m, batch)
+    orc = O.Oracle(opt, sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss")
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss")
+    for k in ("logit.weight", "logit.bias", "core.att_lstm.weight_ih", "core.att_lstm.weight_hh", "core.lang_lstm.weight_ih", "core.lang_lstm.weight_hh",
+              "core.attention.h2att.weight", "core.attention.alpha_net.weight", "embed.0.weight", "obj_v_proj.weight", "att_embed.0.weight", "ctx2att.weight",
+              "fc_embed.0.weight", "gcn_backbone.gcn.1.gcn_collect.collect_units.0.fc_rgt.weight", "gcn_backbone.gcn.0.gcn_collect.collect_units.3.fc_lft.weight",
+              "gpn_layer.gpn_fc.0.weight", "gpn_layer.read_out_proj.1.weight"):
+        g = orc.P[k].grad
+        close(m.P(k).grad, g, "grad " + k, atol=2e-5 + 2e-3 * float(g.abs().max()), rtol=5e-3)
+
+
 def test_size_independent_properties_at_bench_size():
     """B=128 (the bench workload): log-probs normalise, padded steps are zero, loss finite, dead params get no gradient."""
     torch.manual_seed(1)
