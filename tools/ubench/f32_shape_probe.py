@@ -10,7 +10,7 @@ def t(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / n
-for (M, N, K, tb) in [(4736, 512, 1024, True), (4736, 512, 1024, False), (8320, 512, 1024, True), (8320, 1024, 512, True), (640, 512, 1000, True), (640, 1000, 512, False), (2560, 512, 2048, True), (4204, 1000, 1024, True)]:
+for (M, N, K, tb) in [(877, 9488, 1000, True), (877, 4000, 3000, True), (877, 4000, 2000, True), (800, 9488, 1000, True), (700, 9488, 1000, True), (4736, 512, 1024, True), (4736, 512, 1024, False), (8320, 512, 1024, True), (8320, 1024, 512, True), (640, 512, 1000, True), (640, 1000, 512, False), (2560, 512, 2048, True), (4204, 1000, 1024, True)]:
     a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev) if tb else torch.randn(K, N, device=dev)
     o = torch.empty(M, N, device=dev)
     d = t(lambda: ops.gemm(a, b, o, tb=tb))
