@@ -352,6 +352,12 @@ int subgc_attn_bwd_planes(const void* u, const void* v, const float* ah, const f
 int subgc_attn_fwd(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a,
                    const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha,
                    int n_stride, int S, int A, int R, int bf16_bits, void* stream);
+/* subgc_attn_fwd whose query rows are still the split-K partial planes of the h2att product (AttModel.py:455 `self.h2att(h)`;
+ * subgc_gemm_*_planes): ah[s, :] = q_bias + sum_{p < n_planes} (q_planes + p * plane_stride)[s, :].  The summed rows are written to
+ * q_out [S, A] -- the `ah` the backward takes.  Saves the reduce pass of that product (17 launches per train step). */
+int subgc_attn_fwd_q(const void* u, const void* v, const float* q_planes, int n_planes, int64_t plane_stride, const float* q_bias,
+                     float* q_out, const float* w_a, const float* b_a, const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx,
+                     float* alpha, int n_stride, int S, int A, int R, int bf16_bits, void* stream);
 /* bf16_bits of subgc_attn_fwd / subgc_attn_bwd: bit 0 = the ctx (fwd) / dah (bwd) destination is bf16; bit 1 = u and v are
  * bf16 [rows, A] / [rows, R] (compute_dtype = bf16: the node features survive only as the tensors the GEMMs wrote).            */
 /* backward of one step: dctx [S,R] (ld lddctx) -> dah [S,A]; du, dv ACCUMULATE (+=) over steps;
@@ -493,6 +499,10 @@ int subgc_pick_lse_finish(const float* lse_part, int V, int S, int T, const int3
 int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
                          const int32_t* lens, int m, int B, int g, int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A,
                          int R, int bf16_bits, void* stream);
+/* subgc_attn_fwd_group with the query rows as partial planes (see subgc_attn_fwd_q); q_out [m, A]. */
+int subgc_attn_fwd_group_q(const void* u, const void* v, const float* q_planes, int n_planes, int64_t plane_stride, const float* q_bias,
+                           float* q_out, const float* w_a, const float* b_a, const int32_t* rows, const int32_t* lens, int m, int B, int g,
+                           int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A, int R, int bf16_bits, void* stream);
 int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,
                          int B, int g, int Nn, const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du,
                          float* dw_a, float* db_a, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, int dctx_planes,

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
                                                              const float* __restrict__ w_a, const float* __restrict__ b_a,
                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ lens, int m, int g,
                                                              int Nn, void* __restrict__ ctx, int64_t ldctx, float* __restrict__ alpha,
-                                                             int n_stride, int A, int R, int ctx_b16) {
+                                                             int n_stride, int A, int R, int ctx_b16, const subgc::QSrc qs) {
     __shared__ float e_s[G][GL];
     __shared__ int row_s[G], len_s[G];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -60,7 +60,11 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
             const bool ok = a4 < A4;
             w[c] = ok ? ld4(w_a + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < G; ++j) q_[j][c] = (ok && row_s[j] >= 0) ? ld4(ah + (int64_t)row_s[j] * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < G; ++j) {
+                const bool have = ok && row_s[j] >= 0;
+                q_[j][c] = have ? subgc_load_q(ah, qs, (int64_t)row_s[j] * A + a4 * 4, a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qs.out && have && wave == 0) st4(qs.out + (int64_t)row_s[j] * A + a4 * 4, q_[j][c]);   // the summed query, kept for the backward
+            }
         }
         const float ba = b_a[0];
         // One wave per SIMD and every node row a compulsory HBM / Infinity-Cache miss (~2 us): nothing hides a load but other loads,
@@ -401,10 +405,12 @@ inline int group_splits(int g) { return g >= 4 ? 2 : 1; }       // three per ima
         if (per <= 2) { CALL(2); } else if (per <= 3) { CALL(3); } else if (per <= 5) { CALL(5); } else { CALL(8); } \
     } while (0)
 
-SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
-                                   const int32_t* lens, int m, int B, int g, int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A,
-                                   int R, int bf16_bits, void* stream) {
+namespace {
+int attn_fwd_group_any(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
+                       const int32_t* lens, int m, int B, int g, int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A,
+                       int R, int bf16_bits, void* stream, subgc::QSrc qs) {
     const int ctx_b16 = bf16_bits & 1, uv16 = (bf16_bits >> 1) & 1;
+    SUBGC_REQUIRE(qs.n_planes >= 1 && qs.stride % 4 == 0 && al16(qs.bias) && al16(qs.out), "attn_fwd_group: query planes / bias / output must be 16-byte aligned");
     SUBGC_REQUIRE(B >= 0 && g >= 1 && g <= 8 && Nn >= 1 && Nn <= GL && m >= 0 && A > 0 && R > 0 && n_stride >= 0, "attn_fwd_group: bad sizes (g <= 8, Nn <= %d)", GL);
     if (B == 0 || m == 0) return SUBGC_OK;
     SUBGC_REQUIRE(u && v && ah && w_a && b_a && rows && lens && ctx, "attn_fwd_group: null pointer");
@@ -416,18 +422,35 @@ SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah
     const int splits = group_splits(g);
 #define SUBGC_FWD_G(G_)                                                                                                                              \
     do {                                                                                                                                               \
-        if (uv16) { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
-        else { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); \
-            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16); } \
+        if (uv16) { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); \
+            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); \
+            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); \
+            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, true, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); } \
+        else { if (ca == 1 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 1, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); \
+            else if (ca == 2 && cr == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<2, 1, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); \
+            else if (ca == 1) hipLaunchKernelGGL((attn_fwd_group_kernel<1, 2, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); \
+            else hipLaunchKernelGGL((attn_fwd_group_kernel<2, 2, false, G_>), dim3(B, splits), dim3(256), 0, s, u, v, ah, w_a, b_a, rows, lens, m, g, Nn, ctx, ldctx, alpha, n_stride, A, R, ctx_b16, qs); } \
     } while (0)
     SUBGC_G_DISPATCH(SUBGC_FWD_G);
 #undef SUBGC_FWD_G
     return subgc::check_launch("subgc_attn_fwd_group");
+}
+}  // namespace
+
+SUBGC_API int subgc_attn_fwd_group(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* rows,
+                                   const int32_t* lens, int m, int B, int g, int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A,
+                                   int R, int bf16_bits, void* stream) {
+    return attn_fwd_group_any(u, v, ah, w_a, b_a, rows, lens, m, B, g, Nn, ctx, ldctx, alpha, n_stride, A, R, bf16_bits, stream,
+                              subgc::QSrc{nullptr, nullptr, 1, 0});
+}
+// the query of row r = q_bias + sum of n_planes planes (q_planes + p * plane_stride)[r, :] (the h2att product left as split-K partial planes,
+// subgc_gemm_*_planes); the summed rows are written to q_out [m, A] for the backward
+SUBGC_API int subgc_attn_fwd_group_q(const void* u, const void* v, const float* q_planes, int n_planes, int64_t plane_stride, const float* q_bias,
+                                     float* q_out, const float* w_a, const float* b_a, const int32_t* rows, const int32_t* lens, int m, int B, int g,
+                                     int Nn, void* ctx, int64_t ldctx, float* alpha, int n_stride, int A, int R, int bf16_bits, void* stream) {
+    SUBGC_REQUIRE(n_planes >= 1 && n_planes <= 16 && q_out, "attn_fwd_group_q: 1 <= n_planes <= 16 and an output for the summed query");
+    return attn_fwd_group_any(u, v, q_planes, w_a, b_a, rows, lens, m, B, g, Nn, ctx, ldctx, alpha, n_stride, A, R, bf16_bits, stream,
+                              subgc::QSrc{q_bias, q_out, n_planes, plane_stride});
 }
 
 SUBGC_API int subgc_attn_bwd_group(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* rows, const int32_t* lens, int m,

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restric
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
                                                            const float* __restrict__ b_a, const int32_t* __restrict__ off,
                                                            const int32_t* __restrict__ len, void* __restrict__ ctx, int64_t ldctx,
-                                                           float* __restrict__ alpha, int n_stride, int A, int R, int ctx_b16) {
+                                                           float* __restrict__ alpha, int n_stride, int A, int R, int ctx_b16, const subgc::QSrc qs) {
     __shared__ float e_s[MAXLEN];
     const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l = min(len[s], MAXLEN), m0 = off[s];
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restric
     for (int c = 0; c < CA; ++c) {
         const int a4 = lane + c * 64;
         const bool ok = a4 < A4;
-        q[c] = ok ? ld4(ah + (int64_t)s * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        q[c] = ok ? subgc_load_q(ah, qs, (int64_t)s * A + a4 * 4, a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qs.out && ok && wave == 0) st4(qs.out + (int64_t)s * A + a4 * 4, q[c]);     // the summed query, kept for the backward
         w[c] = ok ? ld4(w_a + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // four of this wave's nodes at a time: their rows are requested together and their scores reduced over the lanes TOGETHER (four
@@ -310,16 +311,18 @@ namespace subgc {
 
 // return -100 when the vector form does not apply
 int attn_fwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
-                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, int uv_b16, hipStream_t s) {
-    if (A % 4 || R % 4 || ldctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(ctx)) return -100;
+                 const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, int uv_b16, hipStream_t s,
+                 QSrc qs) {
+    if (A % 4 || R % 4 || ldctx % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(ctx) || qs.stride % 4 || !al16(qs.bias) || !al16(qs.out))
+        return -100;
     const int ca = (A / 4 + 63) / 64, cr = (R / 4 + 255) / 256;
     if (ca > 2 || cr > 2) return -100;
 #define SUBGC_ATT_FWD(CA_, CR_)                                                                                                          \
     do {                                                                                                                                   \
         if (uv_b16) hipLaunchKernelGGL((attn_fwd_vec_kernel<CA_, CR_, true>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, \
-                                       alpha, n_stride, A, R, ctx_b16);                                                                   \
+                                       alpha, n_stride, A, R, ctx_b16, qs);                                                               \
         else hipLaunchKernelGGL((attn_fwd_vec_kernel<CA_, CR_, false>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, b_a, off, len, ctx, ldctx, \
-                                alpha, n_stride, A, R, ctx_b16);                                                                          \
+                                alpha, n_stride, A, R, ctx_b16, qs);                                                                      \
     } while (0)
     if (ca == 1 && cr == 1) SUBGC_ATT_FWD(1, 1);
     else if (ca == 2 && cr == 1) SUBGC_ATT_FWD(2, 1);

@@ -53,10 +53,14 @@ int gemm_bf16_nt_partials(const uint16_t* A, int64_t lda, const uint16_t* B, int
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N,
                    int K, int relu, hipStream_t stream, const float* add = nullptr, int64_t ldadd = 0);
 
+// The attention query of a row as the forward kernels take it: `ah` + n_planes - 1 further planes `stride` floats apart (the split-K
+// partial planes of the h2att product, summed on load) + bias; the summed row is written to `out` (the backward reads it).  The
+// default = one plane, no bias, nothing written: `ah` IS the query.
+struct QSrc { const float* bias; float* out; int n_planes; int64_t stride; };
 // attention_vec.hip: float4 forms of the per-step attention kernels; return -100 when they do not apply
 int attn_fwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const float* b_a, const int32_t* off,
                  const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int S, int A, int R, int ctx_b16, int uv_b16,
-                 hipStream_t s);
+                 hipStream_t s, QSrc qs = QSrc{nullptr, nullptr, 1, 0});
 int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                  const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
                  float* db_a, int S, int A, int R, int dah_b16, int uv_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s, int n_planes = 1,
@@ -65,6 +69,20 @@ int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64
                       const int32_t* len, float* dv, int S, int R, hipStream_t s);
 
 }  // namespace subgc
+
+// query chunk (four columns at `idx` = row * A + column) of a QSrc: planes summed in order, bias last
+__device__ __forceinline__ float4 subgc_load_q(const float* __restrict__ ah, const subgc::QSrc& qs, int64_t idx, int col) {
+    float4 a = *reinterpret_cast<const float4*>(ah + idx);
+    for (int p = 1; p < qs.n_planes; ++p) {
+        const float4 b = *reinterpret_cast<const float4*>(ah + p * qs.stride + idx);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (qs.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(qs.bias + col);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    return a;
+}
 
 #define SUBGC_REQUIRE(cond, ...)          \
     do {                                  \

@@ -802,6 +802,23 @@ SUBGC_API int subgc_attn_fwd(const void* u, const void* v, const float* ah, cons
     subgc::set_error("attn_fwd: needs att_hid_size, rnn_size %% 4 == 0 (<= 512 / <= 2048) and 16-byte aligned rows (A=%d R=%d)", A, R);
     return SUBGC_EINVAL;
 }
+// subgc_attn_fwd whose query rows arrive as the split-K partial planes of the h2att product: row s = q_bias + sum_p (q_planes + p * plane_stride)[s, :];
+// the summed rows are written to q_out [S, A] (the backward's `ah`)
+SUBGC_API int subgc_attn_fwd_q(const void* u, const void* v, const float* q_planes, int n_planes, int64_t plane_stride, const float* q_bias, float* q_out,
+                               const float* w_a, const float* b_a, const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha,
+                               int n_stride, int S, int A, int R, int bf16_bits, void* stream) {
+    const int ctx_bf16 = bf16_bits & 1, uv_bf16 = (bf16_bits >> 1) & 1;
+    SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride >= 0 && n_stride <= MAXLEN && n_planes >= 1 && n_planes <= 16, "attn_fwd_q: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(u && v && q_planes && q_out && w_a && b_a && off && len && ctx, "attn_fwd_q: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    if (const int rc = subgc::attn_fwd_vec(u, v, q_planes, w_a, b_a, off, len, ctx, ldctx, alpha, n_stride, S, A, R, ctx_bf16, uv_bf16, s,
+                                           subgc::QSrc{q_bias, q_out, n_planes, plane_stride}); rc != -100)
+        return rc;
+    subgc::set_error("attn_fwd_q: needs att_hid_size, rnn_size %% 4 == 0 (<= 512 / <= 2048) and 16-byte aligned rows (A=%d R=%d)", A, R);
+    return SUBGC_EINVAL;
+}
 namespace {
 int attn_bwd_any(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len, const float* alpha,
                  int n_stride, const float* dctx, int64_t lddctx, int n_planes, int64_t plane_stride, void* dah, float* du, float* dv, float* dw_a,

@@ -575,8 +575,8 @@ class Prepared:
     # the per-step attention calls, so that the decoder Functions do not care whether the sets are per sentence or shared per image
     shared = False
 
-    def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R):
-        ops.attn_fwd(self.u, self.v, ah, w_a, b_a, self.off, lens, ctx, alpha, m, A, R)
+    def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R, q=None):
+        ops.attn_fwd(self.u, self.v, ah, w_a, b_a, self.off, lens, ctx, alpha, m, A, R, q=q)
 
     def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep):
         ops.attn_bwd(self.u, self.v, ah, w_a, self.off, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep=dctx_keep)
@@ -638,8 +638,8 @@ class PreparedShared(Prepared):
         self.u = new(MR, c2a_w.size(0))
         ops.gemm(self.v, c2a_w, self.u, tb=True, bias=c2a_b)
 
-    def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R):
-        ops.attn_fwd_group(self.u, self.v, ah, w_a, b_a, self.rows, lens, m, self.B, self.g, self.N, ctx, alpha, A, R)
+    def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R, q=None):
+        ops.attn_fwd_group(self.u, self.v, ah, w_a, b_a, self.rows, lens, m, self.B, self.g, self.N, ctx, alpha, A, R, q=q)
 
     def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep):
         if dv is not None:
@@ -726,6 +726,7 @@ class DecoderFn(Function):
         AH = torch.empty(T, S, A, device=dev, dtype=torch.float32)
         AL = torch.empty(T, S, N, device=dev, dtype=torch.float32)
         pre = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
+        QP = torch.empty(8 * S * A, device=dev, dtype=torch.float32)           # split-K planes of the per-step query product
         Gx3 = Gx.view(T, S, 4 * R)
         logits = torch.empty(S * T, V1, device=dev, dtype=torch.float32)
         logits3 = logits.view(S, T, V1)
@@ -738,8 +739,8 @@ class DecoderFn(Function):
                 ops.gemm(xt[t], W[9][:, 2 * R:], Gx3[t], tb=True)
             ops.lstm_fwd_gemm(H1[t], Wc1, pre, Gx3[t], Gf, b1i, b1h, C1[t], C1[t + 1], H2[t][:, R:2 * R], H1[t + 1][:, R:], None, 1.0, None,
                               G1[t], S, R)
-            ops.gemm(H2[t][:, R:2 * R], W[17], AH[t], tb=True, bias=h2a_b)
-            pr.attn_fwd(AH[t], an_w, an_b, lens, H2[t][:, :R], AL[t], S, A, R)
+            nq, sq = ops.gemm_planes(H2[t][:, R:2 * R], W[17], QP, tb=True)      # the query product stays as split-K planes: the attention
+            pr.attn_fwd(AH[t], an_w, an_b, lens, H2[t][:, :R], AL[t], S, A, R, q=(QP, nq, sq, h2a_b))     # kernel sums them (+ bias) into AH[t]
             ops.lstm_fwd_gemm(H2[t], Wc2, pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
                               None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
         if ss is None:

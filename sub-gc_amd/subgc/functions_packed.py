@@ -126,6 +126,7 @@ class PackedDecoderLossFn(Function):
         Hout, G1, G2 = act(max(rows, 1), R), new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R)
         AH, AL = new(max(rows, 1), A), new(max(rows, 1), N)
         pre = new(S, 4 * R)
+        QP = new(8 * S * A)
         logits = new(max(rows, 1), V1)
         for t in range(T_live):
             m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
@@ -140,8 +141,9 @@ class PackedDecoderLossFn(Function):
                 ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True)
             ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
                               H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
-            ops.gemm(H2[o:o + m, R:2 * R], W[17], AH[o:o + m], tb=True, bias=h2a_b)
-            pr.attn_fwd(AH[o:o + m], an_w, an_b, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R)
+            nq, sq = ops.gemm_planes(H2[o:o + m, R:2 * R], W[17], QP, tb=True)   # the query product stays as split-K planes: the attention
+            pr.attn_fwd(AH[o:o + m], an_w, an_b, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R, q=(QP, nq, sq, h2a_b))   # kernel sums them (+ bias) into AH
+
             ops.lstm_fwd_gemm(H2[o:o + m], Wc2, pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R],
                               H2[o1:o1 + mn_, 2 * R:], None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R,
                               rows_h=mn_, rows_h2=mn_)

@@ -704,8 +704,16 @@ def _uv_b16(u, v, A, R):
     return int(b)
 
 
-def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R):
+def attn_fwd(u, v, ah, w_a, b_a, off, lens, ctx, alpha, S, A, R, q=None):
+    """`q` = (planes, n, stride, bias): the query rows are the n split-K partial planes `gemm_planes` left in `planes` (+ bias); the
+    summed rows are written to `ah` (subgc_attn_fwd_q)."""
     _attn_account(lens, S, A, R, 1)      # read u and v rows once
+    if q is not None:
+        planes, n, stride, bias = q
+        call("subgc_attn_fwd_q", _ptr(u), _ptr(v), _ptr(planes, torch.float32), int(n), int(stride), _ptr(bias, torch.float32), _ptr(ah, torch.float32),
+             _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0,
+             S, A, R, int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), _stream())
+        return
     call("subgc_attn_fwd", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32),
          _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, S, A, R, int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), _stream())
 
@@ -735,9 +743,15 @@ def attn_dv_accum(alpha, dctx, step_off, T, off, lens, dv, S, R):
          _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(dv, torch.float32), S, R, _stream())
 
 
-def attn_fwd_group(u, v, ah, w_a, b_a, rows, lens, m, B, g, Nn, ctx, alpha, A, R):
-    """Attention step over per-image shared sets (subgc_attn_fwd_group): ah / ctx / alpha hold the step's rows."""
+def attn_fwd_group(u, v, ah, w_a, b_a, rows, lens, m, B, g, Nn, ctx, alpha, A, R, q=None):
+    """Attention step over per-image shared sets (subgc_attn_fwd_group): ah / ctx / alpha hold the step's rows.  `q`: see attn_fwd."""
     _attn_account_group(B, Nn, A, R, 1)
+    if q is not None:
+        planes, n, stride, bias = q
+        call("subgc_attn_fwd_group_q", _ptr(u), _ptr(v), _ptr(planes, torch.float32), int(n), int(stride), _ptr(bias, torch.float32), _ptr(ah, torch.float32),
+             _ptr(w_a), _ptr(b_a), _ptr(rows, torch.int32), _ptr(lens, torch.int32), int(m), B, g, Nn, _ptr(ctx), ld(ctx), _ptr(alpha),
+             alpha.size(1) if alpha is not None else 0, A, R, int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), _stream())
+        return
     call("subgc_attn_fwd_group", _ptr(u), _ptr(v), _ptr(ah, torch.float32), _ptr(w_a), _ptr(b_a), _ptr(rows, torch.int32), _ptr(lens, torch.int32), int(m),
          B, g, Nn, _ptr(ctx), ld(ctx), _ptr(alpha), alpha.size(1) if alpha is not None else 0, A, R, int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), _stream())
 
