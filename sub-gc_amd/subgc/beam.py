@@ -181,9 +181,29 @@ class DeviceTables:
         z = lambda *s, dt: torch.zeros(*s, device=dev, dtype=dt)
         self.cap = bd * T                                                         # a group finishes at most bd beams per step
         self.seq, self.lps, self.sums = z(n, G, T, bd, dt=torch.int32), z(n, G, T, bd, dt=torch.float32), z(n, G, bd, dt=torch.float32)
-        self.done_cnt = z(n, G, dt=torch.int32)
-        self.done_seq, self.done_lps = z(n, G, self.cap, T, dt=torch.int32), z(n, G, self.cap, T, dt=torch.float32)
-        self.done_p, self.done_len = z(n, G, self.cap, dt=torch.float32), z(n, G, self.cap, dt=torch.int32)
+        # the finished-beam tables are views of ONE 4-byte buffer: `collect` brings them to the host with a single copy (five
+        # synchronising copies cost 0.15 ms of a 2.8 ms one-image search)
+        cap = self.cap
+        sizes = [n * G, n * G * cap * T, n * G * cap * T, n * G * cap, n * G * cap]
+        self.done_all = z(sum(sizes), dt=torch.int32)
+        parts, o = [], 0
+        for k in sizes:
+            parts.append(self.done_all[o:o + k]); o += k
+        self.done_cnt = parts[0].view(n, G)
+        self.done_seq, self.done_lps = parts[1].view(n, G, cap, T), parts[2].view(torch.float32).view(n, G, cap, T)
+        self.done_p, self.done_len = parts[3].view(torch.float32).view(n, G, cap), parts[4].view(n, G, cap)
+        self._sizes = sizes
+
+    def done_to_host(self):
+        """(cnt, seq, lps, p, len) as numpy arrays after ONE device -> host copy."""
+        n, G = self.done_cnt.shape
+        cap, T = self.cap, self.done_seq.size(3)
+        h = self.done_all.cpu().numpy()
+        out, o = [], 0
+        for k in self._sizes:
+            out.append(h[o:o + k]); o += k
+        return (out[0].reshape(n, G), out[1].reshape(n, G, cap, T), out[2].view(np.float32).reshape(n, G, cap, T),
+                out[3].view(np.float32).reshape(n, G, cap), out[4].reshape(n, G, cap))
 
 
 def _check(opt, eng):
@@ -254,9 +274,7 @@ class DeviceSearch:
         tb, T, G, bd, n, opt = self.tb, self.T, self.G, self.bd, self.eng.n, self.opt
         length_penalty = penalty_builder(opt.get("length_penalty", ""))
         # one read of the finished beams; ranking (:174-175) vectorised, python objects only for the beams that are kept
-        cnt = tb.done_cnt.cpu().numpy()
-        dseq, dlps = tb.done_seq.cpu().numpy(), tb.done_lps.cpu().numpy()
-        dp, dlen = tb.done_p.cpu().numpy(), tb.done_len.cpu().numpy()
+        cnt, dseq, dlps, dp, dlen = tb.done_to_host()
         valid = np.arange(tb.cap)[None, None, :] < cnt[:, :, None]
         if opt.get("length_penalty", "") == "":
             p = dp.astype(np.float64)
