@@ -137,6 +137,30 @@ def test_flickr_stress_shape_in_bf16_storage_matches_fp32_oracle():
 
 
 @pytest.mark.timeout(900)
+def test_flickr_bench_size_b64_train_matches_fp32_oracle():
+    """BASELINE config 5 at the size the bench line quotes (64 images = 320 sentences, N = 101, K = 301, D = 4096, L = 2048): the bf16
+    storage step (bf16 unit outputs through the aggregation, raw-logit criterion, query planes, split-K forms of this batch size) against
+    the fp32 CPU oracle -- losses at atol 5e-2, gradients by direction and norm."""
+    torch.manual_seed(9)
+    opt = argparse.Namespace(**dict(FLICKR, compute_dtype="bf16"))
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(64, vocab=7000, seed=1000, **FLICKR_DATA)
+    out, loss = run_train(m, batch)
+    orc = O.Oracle(argparse.Namespace(**FLICKR), sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss", atol=5e-2, rtol=0)
+    close(out["gpn_loss"], ref["gpn_loss"], "gpn_loss", atol=5e-2, rtol=0)
+    grads_roughly_equal(m, orc, ("logit.weight", "core.att_lstm.weight_ih", "core.lang_lstm.weight_hh", "embed.0.weight", "obj_v_proj.weight",
+                                 "gcn_backbone.gcn.0.gcn_collect.collect_units.3.fc_rgt.weight", "gcn_backbone.gcn.1.gcn_collect.collect_units.0.fc_lft.weight",
+                                 "att_embed.0.weight", "ctx2att.weight", "fc_embed.0.weight", "core.attention.h2att.weight"))
+
+
+@pytest.mark.timeout(900)
 def test_full_gc_kar_batch_256_properties_in_bf16_storage():
     """BASELINE config 3 at its stated size and precision (Full_GC_Kar, 256 images = 1280 sentences, bf16): size-independent
     properties -- log-probs normalise, padded steps are zero, the loss is finite and equals the packed path's, dead parameters get
