@@ -161,6 +161,33 @@ def test_flickr_bench_size_b64_train_matches_fp32_oracle():
 
 
 @pytest.mark.timeout(900)
+def test_full_gc_kar_bench_size_b256_train_matches_fp32_oracle():
+    """BASELINE config 3 at the size the bench line quotes (256 images = 1280 sentences, 4 GCN layers with BatchNorm over 16 640 relation /
+    9 472 node rows, attention sets shared per image): the bf16 storage train step against the fp32 CPU oracle in TRAIN mode (batch
+    statistics over the whole batch) -- loss at atol 5e-2, gradients by direction and norm, running statistics."""
+    torch.manual_seed(4)
+    opt = argparse.Namespace(**dict(FULLGC, compute_dtype="bf16"))
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _sharpen(sd, None)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    batch = synthetic.make_train_batch(256, seed=1000)
+    out, loss = run_train(m, batch)
+    assert out["gpn_loss"] is None
+    orc = O.Oracle(argparse.Namespace(**FULLGC), sd, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    ref["lang_loss"].backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss", atol=5e-2, rtol=0)
+    grads_roughly_equal(m, orc, ("logit.weight", "core.att_lstm.weight_ih", "core.lang_lstm.weight_hh", "embed.0.weight", "obj_v_proj.weight",
+                                 "gcn_backbone.gcn.0.gcn_collect.collect_units.0.fc_rgt.weight", "gcn_backbone.gcn.2.gcn_collect.collect_units.3.fc_lft.weight",
+                                 "gcn_backbone.gcn.3.gcn_collect.collect_units.1.fc_lft.weight", "att_embed.0.weight", "ctx2att.weight", "fc_embed.0.weight",
+                                 "core.attention.h2att.weight"), cos_min=0.99)
+    k = "gcn_backbone.gcn.1.gcn_collect.collect_units.2.bn.running_mean"
+    close(m.state_dict()[k], orc.buffers[k], "running_mean", atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.timeout(900)
 def test_full_gc_kar_batch_256_properties_in_bf16_storage():
     """BASELINE config 3 at its stated size and precision (Full_GC_Kar, 256 images = 1280 sentences, bf16): size-independent
     properties -- log-probs normalise, padded steps are zero, the loss is finite and equals the packed path's, dead parameters get
