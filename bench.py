@@ -139,7 +139,10 @@ def decode_bench(model_sd, dev, images, M):
     m = m.to(dev).eval()
     batches = [{k: v.to(dev) for k, v in synthetic.make_test_batch(M, seed=500 + i).items()} for i in range(images)]
     sopt = dict(sample_max=1, beam_size=1)
-    for b in batches[:min(images, 64)]:                   # untimed pass: the token loop is captured once per surviving-row count (hipGraph)
+    # untimed pass over a DISJOINT set of images (other seeds, same shape): the token loop is captured once per surviving-row count
+    # (hipGraph) and the allocator settles, but neither the Infinity Cache nor any input-keyed state has seen the timed images
+    warm = [{k: v.to(dev) for k, v in synthetic.make_test_batch(M, seed=9000 + i).items()} for i in range(min(images, 256))]
+    for b in warm[:min(images, 64)]:
         m(*synthetic.sample_args(b), opt=sopt, mode="sample")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -170,7 +173,7 @@ def decode_bench(model_sd, dev, images, M):
         us_step = 1e3 * e0.elapsed_time(e1) / 20 / steps
         gbps = bytes_step / (us_step * 1e-6) / 1e9
         traffic, pmc_name = None, None
-        for rnd in ("r03", "r02"):                       # committed PMC passes over the same loop (tools/pmc_decode.sh)
+        for rnd in ("r04", "r03", "r02"):                # committed PMC passes over the same loop (tools/pmc_decode.sh)
             pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_decode.json")
             if not os.path.exists(pmc_path):
                 continue
@@ -193,7 +196,7 @@ def decode_bench(model_sd, dev, images, M):
                                           "the 120 MB of weights fit the 256 MiB Infinity Cache, so the HBM roof is generous"}
     # the same images, decoded `group` at a time as one batch (sample_images): same tokens per image, weights streamed once per step
     group = min(256, images)                              # sized for 288 GB: 2560 sub-graph rows per decode step
-    m.sample_images(batches[:group], opt=sopt)
+    m.sample_images(warm[:group], opt=sopt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tokens = 0
@@ -206,7 +209,7 @@ def decode_bench(model_sd, dev, images, M):
     # test.sh decodes Sub_GC_Kar with --beam_size 2: the same images through beam search, one per call and batched
     bopt = dict(sample_max=1, beam_size=2)
     nb = min(images, 64)
-    for b in batches[:2]:
+    for b in warm[:2]:
         m(*synthetic.sample_args(b), opt=bopt, mode="sample")
     torch.cuda.synchronize()
     tb0 = time.perf_counter()
@@ -234,7 +237,7 @@ def pmc_traffic(config, batch, world, launches_per_step):
     if world != 1 or batch != CONFIGS[config]["batch"]:
         return None, "no PMC profile for this configuration"
     note = "no PMC profile for this configuration"
-    for rnd in ("r03", "r02"):                                      # newest committed pass whose launch count matches this build
+    for rnd in ("r04", "r03", "r02"):                               # newest committed pass whose launch count matches this build
         name = f"{rnd}_pmc_traffic.json" if config == "kar" else f"{rnd}_pmc_traffic_{config}.json"
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -262,11 +265,9 @@ def roofline_block(cfg, batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm
             "event_sampled_steps": f"{n_s} of the {steps} timed steps ({n_launch} launches)",
             "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
             "gemm_ms_per_step": round(gemm_ms / n_s, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
-            # whole step (all kernels + gaps) against the MFMA peak: with the GEMM FLOPs actually executed, and with
-            # the reference's nominal live-graph FLOPs (22.0 GFLOP/image; includes the masked-out decoder
-            # steps that the packed loss-only path never computes)
-            "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / cfg["peak"], 4),
-            "whole_step_frac_nominal": round(cfg["gflop_img"] * batch / (ms_per_step * 1e-3) / 1e3 / cfg["peak"], 4)}
+            # whole step (all kernels + gaps) against the MFMA peak, with the GEMM FLOPs the step actually EXECUTES (the reference's
+            # nominal live-graph FLOPs include masked-out decoder steps the packed path never computes: not a roofline figure)
+            "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / cfg["peak"], 4)}
 
 
 def train_config_leg(name, dev, steps=8, warmup=3):

@@ -236,7 +236,8 @@ int subgc_gpn_score_bwd(const float* hid, const uint8_t* keep, float keep_scale,
  * order: score descending, ties -> larger index first.  A sub-graph is dropped when an earlier
  * kept one has |A∩B|/|A∪B| > thres (evaluated in double like the reference).  The first
  * max_keep survivors are returned ASCENDING in original index: keep[0..*n_keep).  Node ids
- * must be < 64*SUBGC_NMS_WORDS.  scratch: M * (SUBGC_NMS_WORDS*8 + 8) bytes.                 */
+ * index the image's N nodes and must be < 64*SUBGC_NMS_WORDS: N > 64*SUBGC_NMS_WORDS is
+ * SUBGC_EINVAL (both forms).  scratch: M * (SUBGC_NMS_WORDS*8 + 8) bytes.                    */
 #define SUBGC_NMS_WORDS 4
 int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t idx_stride, const int32_t* len,
                        int M, int N, double thres, int max_keep, int64_t* keep, int32_t* n_keep,

@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
     int lmax = 0;
     int len_r[G], row_r[G];                                            // registers: the unrolled sentence loops index them statically
 #pragma unroll
-    for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); }
-    if (lmax == 0) return;
+    bool any_live = false;
+    for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); any_live |= row_r[j] >= 0; }
+    if (!any_live) return;                                             // a live sentence WITHOUT valid nodes still gets its (zero) ctx / alpha rows below
     const int64_t m0 = (int64_t)b * Nn;
     const int A4 = A >> 2, R4 = R >> 2;
     // scores: wave per node; the node's u chunk is loaded once and scored against every sentence's query
@@ -106,7 +107,11 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
     // softmax over the valid rows: wave w takes sentences w, w+4, ...; a lane holds rows lane and lane + 64
     for (int j = wave; j < G; j += 4) {
         const int l = len_s[j];
-        if (l == 0) continue;
+        if (l == 0) {                                                  // dead slot, or a live sentence over an empty set: weights (and, e_s being zero, ctx) = 0
+            if (alpha && row_s[j] >= 0)
+                for (int i = lane; i < n_stride; i += 64) alpha[(int64_t)row_s[j] * n_stride + i] = 0.f;
+            continue;
+        }
         const float e0 = lane < l ? e_s[j][lane] : -INFINITY, e1 = lane + 64 < l ? e_s[j][lane + 64] : -INFINITY;
         const float mx = wave_max(fmaxf(e0, e1));
         const float p0 = lane < l ? expf(e0 - mx) : 0.f, p1 = lane + 64 < l ? expf(e1 - mx) : 0.f;
@@ -185,8 +190,9 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
     int lmax = 0;
     int len_r[G], row_r[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); }
-    if (lmax == 0) return;
+    bool any_live = false;
+    for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); any_live |= row_r[j] >= 0; }
+    if (!any_live) return;                                             // live sentences over empty sets fall through: zero dah / dw_a / db_a, summed dctx_keep
     for (int i = t; i < G * GL; i += 256) {
         const int j = i / GL, k = i - j * GL;
         al_s[j][k] = (k < len_s[j]) ? alpha[(int64_t)row_s[j] * n_stride + k] : 0.f;
@@ -250,7 +256,10 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
     __syncthreads();
     // de_i = alpha_i (dalpha_i - sum_k alpha_k dalpha_k): wave w takes sentences w, w+4, ...
     for (int j = wave; j < G; j += 4) {
-        if (len_s[j] == 0) continue;
+        if (len_s[j] == 0) {
+            if (lane == 0 && db_a && row_s[j] >= 0) db_a[row_s[j]] = 0.f;
+            continue;
+        }
         const float a0 = al_s[j][lane], a1 = al_s[j][lane + 64], d0 = da_s[j][lane], d1 = da_s[j][lane + 64];
         const float dot = wave_sum(a0 * d0 + a1 * d1);
         const float e0 = a0 * (d0 - dot), e1 = a1 * (d1 - dot);
@@ -503,11 +512,7 @@ SUBGC_API int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const 
     SUBGC_REQUIRE(T <= 64, "attn_dv_accum_group: at most 64 steps");
     const int tg = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)T * g, 1024), (size_t)(140 * 1024) / per));
     const size_t lds = (size_t)tg * per;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)attn_dv_accum_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        subgc::set_error("attn_dv_accum_group: cannot raise the dynamic LDS limit to %zu", lds);
-        return SUBGC_ELAUNCH;
-    }
+    if (int rc = subgc::raise_lds_cached((const void*)attn_dv_accum_group_kernel, lds, "attn_dv_accum_group")) return rc;
     hipLaunchKernelGGL(attn_dv_accum_group_kernel, dim3(B, (R / 4 + 63) / 64), dim3(256), lds, s, alpha, n_stride, dctx, lddctx, step_off, T, rows, g, Nn,
                        dv, R, tg);
     return subgc::check_launch("subgc_attn_dv_accum_group");

@@ -369,11 +369,7 @@ int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64
     if (lds > 150 * 1024) return -100;
 #define SUBGC_ATT_DV(CR_)                                                                                                                 \
     do {                                                                                                                                  \
-        if (lds > 64 * 1024 &&                                                                                                            \
-            hipFuncSetAttribute((const void*)attn_dv_accum_kernel<CR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-            set_error("attn_dv_accum: cannot raise the dynamic LDS limit to %zu", lds);                                                  \
-            return SUBGC_ELAUNCH;                                                                                                         \
-        }                                                                                                                                 \
+        if (int rc = raise_lds_cached((const void*)attn_dv_accum_kernel<CR_>, lds, "attn_dv_accum")) return rc;                              \
         hipLaunchKernelGGL((attn_dv_accum_kernel<CR_>), dim3(S), dim3(256), lds, s, alpha, n_stride, dctx, lddctx, step_off, T, off, len, dv, R, tg); \
     } while (0)
     if (cr <= 1) SUBGC_ATT_DV(1); else if (cr <= 2) SUBGC_ATT_DV(2); else if (cr <= 4) SUBGC_ATT_DV(4); else SUBGC_ATT_DV(8);

@@ -33,6 +33,10 @@ inline int check_launch(const char* what) {
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// Dynamic LDS above 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize raised once per kernel AND device; the largest size granted
+// is remembered per (kernel, device), so a hot launch path pays one table look-up instead of a driver call (the GEMM files keep their own
+// per-instantiation bit masks).  > 160 KiB (the gfx950 LDS) is SUBGC_EINVAL with the kernel's name in the error text.
+int raise_lds_cached(const void* kernel, size_t bytes, const char* what);
 // gridDim.z of the per-column GCN kernels: their node / relation loop is strided over z, and a workgroup's loop is a chain of gather
 // latencies -- enough slices for ~2048 workgroups (4 slices left 9-25 nodes per workgroup: 2.3-3.6 TB/s)
 inline int gcn_zsplit(int col_groups, int B, int items) {

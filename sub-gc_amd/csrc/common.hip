@@ -1,7 +1,9 @@
 // Host-side plumbing: version, thread-local error text, HIP-event profiling hook.
 #include "common.h"
 
+#include <array>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace subgc {
@@ -13,6 +15,28 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int raise_lds_cached(const void* kernel, size_t bytes, const char* what) {
+    if (bytes <= 64 * 1024) return SUBGC_OK;
+    if (bytes > 160 * 1024) {
+        set_error("%s: needs %zu bytes of LDS (a gfx950 CU has 160 KiB)", what, bytes);
+        return SUBGC_EINVAL;
+    }
+    static std::mutex mu;
+    static std::unordered_map<const void*, std::array<size_t, 64>> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = granted[kernel][dev & 63];
+    if (bytes <= have) return SUBGC_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", what, bytes);
+        return SUBGC_ELAUNCH;
+    }
+    have = bytes;
+    return SUBGC_OK;
 }
 
 namespace {

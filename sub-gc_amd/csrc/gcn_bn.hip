@@ -475,12 +475,7 @@ inline int stat_rows_per_block(int M, int C) {
     const int slabs = std::max(1, 512 / col_groups);
     return std::max(16, (M + slabs - 1) / slabs);
 }
-inline int raise_lds(const void* fn, size_t bytes, const char* what) {
-    if (bytes <= 64 * 1024) return SUBGC_OK;
-    if (bytes > 160 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-        subgc::set_error("%s: needs %zu bytes of LDS", what, bytes);
-        return SUBGC_EINVAL;
-    }
+inline int raise_lds(const void* fn, size_t bytes, const char* what) { return subgc::raise_lds_cached(fn, bytes, what); }
     return SUBGC_OK;
 }
 

@@ -241,10 +241,7 @@ SUBGC_API int subgc_class_partials(const float* X, int64_t ldx, const int32_t* c
     SUBGC_REQUIRE(X && cls && part, "class_partials: null pointer");
     const int rpb = (M + slabs - 1) / slabs;
     const size_t lds = (size_t)C * 256 * sizeof(float);
-    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)class_partials_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        subgc::set_error("class_partials: cannot raise the dynamic LDS limit to %zu", lds);
-        return SUBGC_ELAUNCH;
-    }
+    if (int rc = subgc::raise_lds_cached((const void*)class_partials_kernel, lds, "class_partials")) return rc;
     hipLaunchKernelGGL(class_partials_kernel, dim3((L + 255) / 256, slabs), dim3(256), lds, (hipStream_t)stream, X, ldx, cls, M, L, C, rpb, part);
     return subgc::check_launch("subgc_class_partials");
 }

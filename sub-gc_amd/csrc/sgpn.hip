@@ -263,6 +263,9 @@ SUBGC_API int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t
                                  void* stream) {
     SUBGC_REQUIRE(M >= 0 && N > 0 && max_keep > 0, "subgraph_nms: bad sizes");
     SUBGC_REQUIRE(M <= 65536, "subgraph_nms: at most 65536 candidates (got %d)", M);
+    // idx rows are node lists over the image's N nodes (gpn.py:108-150: ids index the [N, .] node table), and a sub-graph is a bit mask
+    // of 64 * SUBGC_NMS_WORDS bits: more nodes than that would silently drop ids from the masks and change the kept set
+    SUBGC_REQUIRE(N <= 64 * W, "subgraph_nms: node ids must be < %d (64 * SUBGC_NMS_WORDS), got %d nodes per image", 64 * W, N);
     SUBGC_REQUIRE(keep && n_keep, "subgraph_nms: null output");
     hipStream_t s = (hipStream_t)stream;
     SUBGC_REQUIRE(M == 0 || (score && idx && len && scratch), "subgraph_nms: null pointer");
@@ -272,11 +275,7 @@ SUBGC_API int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t
     int32_t* order = (int32_t*)(masks + (size_t)M * W);
     int32_t* flag = order + M;
     const size_t lds = (size_t)((M + 15) / 16 * 16);
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        subgc::set_error("subgraph_nms: cannot get %zu bytes of LDS", lds);
-        return SUBGC_ELAUNCH;
-    }
+    if (int rc = subgc::raise_lds_cached((const void*)nms_kernel, lds, "subgraph_nms")) return rc;
     hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), lds, s, score, idx, idx_stride, len, M, N, thres, max_keep, keep, n_keep, masks,
                        order, flag, (const int32_t*)nullptr);
     return subgc::check_launch("subgc_subgraph_nms");
@@ -286,6 +285,7 @@ SUBGC_API int subgc_subgraph_nms_batched(const float* score, const int64_t* idx,
                                          const int32_t* offsets, int images, int total, int max_m, int N, double thres, int max_keep,
                                          int64_t* keep, int32_t* n_keep, void* scratch, size_t scratch_bytes, void* stream) {
     SUBGC_REQUIRE(images >= 0 && total >= 0 && max_m >= 0 && max_m <= 65536 && N > 0 && max_keep > 0, "subgraph_nms_batched: bad sizes");
+    SUBGC_REQUIRE(N <= 64 * W, "subgraph_nms_batched: node ids must be < %d (64 * SUBGC_NMS_WORDS), got %d nodes per image", 64 * W, N);
     if (images == 0) return SUBGC_OK;
     SUBGC_REQUIRE(offsets && keep && n_keep, "subgraph_nms_batched: null pointer");
     SUBGC_REQUIRE(total == 0 || (score && idx && len && scratch), "subgraph_nms_batched: null pointer");
@@ -295,11 +295,7 @@ SUBGC_API int subgc_subgraph_nms_batched(const float* score, const int64_t* idx,
     int32_t* order = (int32_t*)(masks + (size_t)total * W);
     int32_t* flag = order + total;
     const size_t lds = (size_t)((max_m + 15) / 16 * 16);
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        subgc::set_error("subgraph_nms_batched: cannot get %zu bytes of LDS", lds);
-        return SUBGC_ELAUNCH;
-    }
+    if (int rc = subgc::raise_lds_cached((const void*)nms_kernel, lds, "subgraph_nms_batched")) return rc;
     hipLaunchKernelGGL(nms_kernel, dim3(images), dim3(1024), lds, (hipStream_t)stream, score, idx, idx_stride, len, 0, N, thres, max_keep,
                        keep, n_keep, masks, order, flag, offsets);
     return subgc::check_launch("subgc_subgraph_nms_batched");

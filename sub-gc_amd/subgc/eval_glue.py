@@ -58,18 +58,30 @@ def rank_subgraphs(model, seqq, subgraph_score, keep_nms_ind, sct_mode=False):
 
 
 @torch.no_grad()
-def caption_images(model, images, infos, ix_to_word, eval_kwargs=None, group=256, shard=None):
+def caption_images(model, images, infos, ix_to_word, eval_kwargs=None, group=256, shard=False):
     """The testing branch of eval_split for a list of loader items: returns the `predictions` list
     (eval_utils.py:132-141): {'image_id', 'caption': [...], 'subgraph_score', 'sorted_subgraph_ind'} per image.
-    `shard` (default: on when torch.distributed runs with more than one rank): images round-robin across the ranks, every rank
-    captions its share, the predictions are gathered once at the end and every rank returns the full list."""
+
+    Single-process by default, like the reference's eval (one process, eval_utils.py:98-104): safe to call on rank 0 only
+    while the other ranks of a data-parallel job wait elsewhere.
+    `shard=True` makes the call COLLECTIVE: EVERY rank of the default process group must call it with the SAME
+    `images` / `infos` lists; images go round-robin across the ranks, every rank captions its share, the predictions are
+    gathered once at the end and every rank returns the full list.  The image ids are exchanged first and a mismatch (a caller
+    that already split its list per rank, or ranks evaluating different splits) raises on every rank instead of merging
+    results of different lists by index."""
     import torch.distributed as dist
     from . import parallel
     eval_kwargs = dict(eval_kwargs or {})
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if shard is None:
-        shard = world > 1
     if shard and world > 1:
+        ids = [info["id"] for info in infos]
+        if len(ids) != len(images):
+            raise ValueError("caption_images: one `infos` entry per image")
+        seen = [None] * world
+        dist.all_gather_object(seen, ids)
+        if any(s != ids for s in seen):
+            raise ValueError("caption_images(shard=True) is collective: every rank must pass the same image list "
+                             f"(rank {dist.get_rank()} has {len(ids)} images, the ranks hold {[len(s) for s in seen]})")
         mine, idx = parallel.shard_images(images, dist.get_rank(), world)
         local = caption_images(model, mine, [infos[i] for i in idx], ix_to_word, eval_kwargs, group, shard=False)
         return parallel.gather_by_index(local, idx, len(images))

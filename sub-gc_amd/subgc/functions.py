@@ -657,9 +657,13 @@ class PreparedShared(Prepared):
         return du[0] if du.size(0) == 1 else ops.add_n([du[k] for k in range(du.size(0))])
 
 
-def shared_sets_ok(g, N, A, R):
-    """Can the grouped attention kernels serve this shape? (csrc/attention_group.hip limits)"""
-    return 1 <= g <= 8 and N <= 128 and A % 4 == 0 and R % 4 == 0 and A <= 512 and R <= 1024
+PACKED_MAX_STEPS, PACKED_MAX_SENTENCES = 63, 16384      # csrc/plan.hip: subgc_live_plan / subgc_packed_rows
+
+
+def shared_sets_ok(g, N, A, R, T=1):
+    """Can the grouped attention kernels serve this shape? (csrc/attention_group.hip limits; T <= 64 is attn_dv_accum_group's step
+    table).  Shapes outside fall back to the per-sentence kernels on replicated rows (attention_vec.hip), not to an error."""
+    return 1 <= g <= 8 and N <= 128 and A % 4 == 0 and R % 4 == 0 and A <= 512 and R <= 1024 and T <= 64
 
 
 def make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W, rows=None):

@@ -587,7 +587,10 @@ class AttModel(CaptionModel):
         b5, T = seq.size(0), seq.size(1) - 1
         p = self.drop_prob_lm if self.training else 0.0
         hb = gpn_obj_ind.size(2) if gpn_obj_ind is not None else 1
-        packed = fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None
+        # the packed decoder's plan kernels keep a sentence's live steps in a 64-bit mask and the sentence order in LDS (csrc/plan.hip:
+        # T <= 63, S <= 16384); longer captions / larger shards run the unpacked DecoderFn (same kernels, every step of every sentence)
+        packed = (fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None
+                  and T <= F_.PACKED_MAX_STEPS and b5 <= F_.PACKED_MAX_SENTENCES)
         plan = None
         if packed:                                                                        # the packed decoder's row plan, read behind an event
             from ..functions_packed import PlanAhead
@@ -612,7 +615,7 @@ class AttModel(CaptionModel):
             lens = ops.row_count(mask_sel)
         meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit, "plan": plan}
         if (not self.gpn and self.share_attention_sets and self.injected_masks is None and b5 % B == 0
-                and F_.shared_sets_ok(b5 // B, N, self.att_hid_size, R)):
+                and F_.shared_sets_ok(b5 // B, N, self.att_hid_size, R, T)):
             meta["shared"] = {"B": B, "g": b5 // B, "rows": c["rows"]}                    # every sentence attends over its image's N node rows
         if self.bf16_storage:
             flat16 = self.weights_b16()

@@ -112,6 +112,62 @@ def test_two_rank_gloo_sharded_decode_equals_one_process():
                 np.testing.assert_array_equal(x, y)
 
 
+def _contract_worker(rank, world, port, q):
+    """caption_images' collective contract (round-3 advisor finding): the default is single-process -- rank 0 alone may call it
+    while rank 1 does something else, nothing hangs -- and `shard=True` with different lists per rank raises on EVERY rank
+    before any decode instead of merging results of different lists by index."""
+    _paths()
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from subgc import eval_glue, parallel
+    parallel.init_distributed("gloo")
+
+    class _Never:
+        gpn, training = True, False
+
+        def eval(self):
+            return self
+
+        def train(self, mode=True):
+            return self
+
+        def sample_images(self, images, opt=None):
+            return []
+
+    out = {}
+    if rank == 0:                                                       # rank 0 only, default arguments: no collective inside
+        out["alone"] = eval_glue.caption_images(_Never(), [], [], {}, KW)
+    dist.barrier()
+    images = [object()] * (3 if rank == 0 else 2)                       # "already split per rank": different lists
+    infos = [{"id": 10 * rank + i} for i in range(len(images))]
+    try:
+        eval_glue.caption_images(_Never(), images, infos, {}, KW, shard=True)
+        out["raised"] = False
+    except ValueError as e:
+        out["raised"] = "collective" in str(e)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_caption_images_is_single_process_by_default_and_checks_its_collective_contract():
+    _paths()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_contract_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(q, procs, 100)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == {"alone": [], "raised": True}
+    assert res[1][1] == {"raised": True}
+
+
 def test_gather_by_index_single_process_restores_order():
     _paths()
     from subgc import parallel
@@ -153,7 +209,7 @@ def _gpu_worker(rank, world, port, q):
     m, D = _gpu_model()
     images = [{k: v.to("cuda:0") for k, v in b.items()} for b in _images(D)]
     full = parallel.sample_images_sharded(m, images, KW, group_size=2)
-    preds = eval_glue.caption_images(m, images, [{"id": 50 + i} for i in range(len(images))], VOCAB, KW, group=2)
+    preds = eval_glue.caption_images(m, images, [{"id": 50 + i} for i in range(len(images))], VOCAB, KW, group=2, shard=True)
     q.put((rank, _np(full), [(p["image_id"], p["caption"], p["sorted_subgraph_ind"].tolist()) for p in preds]))
     dist.barrier()
     dist.destroy_process_group()
