@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void attn_fwd_group_kernel(const void* __restr
     __syncthreads();
     int lmax = 0;
     int len_r[G], row_r[G];                                            // registers: the unrolled sentence loops index them statically
-#pragma unroll
     bool any_live = false;
+#pragma unroll
     for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); any_live |= row_r[j] >= 0; }
     if (!any_live) return;                                             // a live sentence WITHOUT valid nodes still gets its (zero) ctx / alpha rows below
     const int64_t m0 = (int64_t)b * Nn;
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const void* __restr
     __syncthreads();
     int lmax = 0;
     int len_r[G], row_r[G];
-#pragma unroll
     bool any_live = false;
+#pragma unroll
     for (int j = 0; j < G; ++j) { len_r[j] = len_s[j]; row_r[j] = row_s[j]; lmax = max(lmax, len_r[j]); any_live |= row_r[j] >= 0; }
     if (!any_live) return;                                             // live sentences over empty sets fall through: zero dah / dw_a / db_a, summed dctx_keep
     for (int i = t; i < G * GL; i += 256) {

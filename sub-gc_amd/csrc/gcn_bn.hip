@@ -476,8 +476,6 @@ inline int stat_rows_per_block(int M, int C) {
     return std::max(16, (M + slabs - 1) / slabs);
 }
 inline int raise_lds(const void* fn, size_t bytes, const char* what) { return subgc::raise_lds_cached(fn, bytes, what); }
-    return SUBGC_OK;
-}
 
 }  // namespace
 

@@ -643,8 +643,6 @@ inline int bn_rows_per_block(int M, int C) {
 }
 
 inline int raise_lds(const void* fn, size_t bytes, const char* what) { return subgc::raise_lds_cached(fn, bytes, what); }
-    return SUBGC_OK;
-}
 
 }  // namespace
 

@@ -502,7 +502,21 @@ class MaskedNLLFn(Function):
 
 # ------------------------------------------------------------------------------- decoder
 DIRECT_GRADS = True               # accumulate parameter gradients straight into existing .grad buffers
-on_decoder_grads_ready = None     # callback set by parallel.GradBucketReducer (decoder slice can be all-reduced)
+on_grads_ready = None             # callback(stage) set by parallel.GradBucketReducer: the gradient slice `stage` ("logit", "recurrent",
+                                  # "prepare"; AttModel.grad_buckets) is final and may be all-reduced while the backward goes on
+trace = None                      # tests: a list that receives ("bptt_begin", steps) / ("bptt_end",) / ("ready", stage) / ("issue", bucket) in host order
+
+
+def note(*event):
+    if trace is not None:
+        trace.append(event)
+
+
+def grads_ready(stage):
+    """Called by the decoder backwards when every kernel that writes the gradient slice `stage` has been enqueued."""
+    note("ready", stage)
+    if on_grads_ready is not None:
+        on_grads_ready(stage)
 
 PARAM_ORDER = (
     "fc_embed.0.weight", "fc_embed.0.bias", "fc_embed.2.weight", "fc_embed.2.bias",
@@ -831,6 +845,7 @@ class DecoderFn(Function):
         Hout2 = Hout.view(S * T, R)
         wgrad(21, dlogits, Hout2)
         bgrad(22, dlogits)
+        grads_ready("logit")                             # logit.* is final: its all-reduce overlaps the whole BPTT loop
         dHout = new(S, T, R); ops.gemm(dlogits, W[21], dHout.view(S * T, R))
         del dlogits
 
@@ -850,6 +865,7 @@ class DecoderFn(Function):
         win = lambda st, col0: None if st is None else (st[0], st[1], col0, st[2], st[3], st[4])
         dC1 = [zer(S, R), new(S, R)]                  # [next, cur] ping-pong
         dC2 = [zer(S, R), new(S, R)]
+        note("bptt_begin", T)
         for t in range(T - 1, -1, -1):
             nC1, cC1 = dC1; nC2, cC2 = dC2
             ops.lstm_bwd_planes(G2[t], C2[t], C2[t + 1], [win(sC, 0), win(sA, 2 * R)], dHout[:, t, :], None if k_out is None else k_out[t],
@@ -863,6 +879,7 @@ class DecoderFn(Function):
             n, st = ops.gemm_planes(dP1[t], Wc1, PC)                       # -> [dh2_prev | dh1_prev]
             sC = (PC, 2 * R, n, st, S)
             dC1.reverse(); dC2.reverse()
+        note("bptt_end")
 
         if defer_dv:
             pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), torch.arange(T + 1, device=dev, dtype=torch.int32) * S, T, lens, dv, S, R)
@@ -890,12 +907,12 @@ class DecoderFn(Function):
         bgrad(18, dAH2)
         ops.colsum(dWa.view(T * S, A), out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa.view(T * S, 1), out=out_for(20).view(-1), accumulate=acc[20])
+        grads_ready("recurrent")
 
         dX, dfc_in = prepared_backward(pr, P, W, bf, fc_in, X_nodes, pr.finish_du(du), dv, df, scale, out_for, acc, wgrad, bgrad,
                                        ctx.needs_input_grad[3], ctx.needs_input_grad[2])
         ctx.pr = None
-        if on_decoder_grads_ready is not None:           # data-parallel reducer: the decoder bucket is complete
-            on_decoder_grads_ready()
+        grads_ready("prepare")                           # the last decoder slice; the encoder's backward follows
         return (None, None, dfc_in, dX, None, None, None) + tuple(ret)
 
 

@@ -209,6 +209,7 @@ class PackedDecoderLossFn(Function):
         ops.nll_logsoftmax_bwd(logp[:rows], tgt_p, msk_p, nll, dloss.contiguous(), dlogits[:rows], None, rows, 1, V1, lse=lse)
         wgrad(21, dlogits[:rows], Hout[:rows])
         bgrad(22, dlogits[:rows])
+        F_.grads_ready("logit")                                 # logit.* is final: its all-reduce overlaps the whole BPTT loop
         dHout = new(max(rows, 1), R); ops.gemm(dlogits[:rows], W[21], dHout[:rows])
         del dlogits
 
@@ -228,6 +229,7 @@ class PackedDecoderLossFn(Function):
         win = lambda st, col0: None if st is None else (st[0], st[1], col0, st[2], st[3], st[4])
         arena = zer(4 * S * R)
         dC1, dC2 = [arena[:S * R].view(S, R), arena[S * R:2 * S * R].view(S, R)], [arena[2 * S * R:3 * S * R].view(S, R), arena[3 * S * R:].view(S, R)]
+        F_.note("bptt_begin", T_live)
         for t in range(T_live - 1, -1, -1):
             m, o = M[t], ot[t]
             nC1, cC1 = dC1; nC2, cC2 = dC2
@@ -243,6 +245,7 @@ class PackedDecoderLossFn(Function):
             n, st = ops.gemm_planes(dP1[o:o + m], Wc1, PC)
             sC = (PC, 2 * R, n, st, m)
             dC1.reverse(); dC2.reverse()
+        F_.note("bptt_end")
 
         P1, P2, H1a, H2a = dP1[:rows], dP2[:rows], H1[:rows], H2[:rows]
         wgrad(13, P2, H2a[:, :2 * R])
@@ -273,11 +276,11 @@ class PackedDecoderLossFn(Function):
         bgrad(18, dAH[:rows])
         ops.colsum(dWa[:rows], out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa[:rows].view(-1, 1), out=out_for(20).view(-1), accumulate=acc[20])
+        F_.grads_ready("recurrent")
 
         dX, dfc_p = F_.prepared_backward(pr, P, W, bf, fc_p, X_nodes, pr.finish_du(du), dv, df, scale, out_for, acc, wgrad, bgrad,
                                          ctx.needs_input_grad[3], ctx.needs_input_grad[2])
         dfc_in = None if dfc_p is None else ops.gather_rows(dfc_p, plan.inv32, torch.empty_like(dfc_p))      # back to the caller's order
         ctx.pr = None
-        if F_.on_decoder_grads_ready is not None:
-            F_.on_decoder_grads_ready()
+        F_.grads_ready("prepare")                               # the last decoder slice; the encoder's backward follows
         return (None, None, dfc_in, dX, None, None, None) + tuple(ret)

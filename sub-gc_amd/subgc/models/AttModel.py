@@ -129,9 +129,8 @@ class AttModel(CaptionModel):
 
     # ------------------------------------------------------------------ parameters
     def _specs(self):
-        """(name, shape, init) in flat-buffer order: encoder first, decoder last (its gradients
-        are complete first in the backward, so its bucket can be all-reduced while the encoder's
-        backward still runs)."""
+        """(name, shape, init) in flat-buffer order: encoder first, then the decoder's three slices (`grad_buckets`): their
+        gradients are complete first in the backward, so each is all-reduced while the rest of the backward still runs."""
         L, D, A, R, E, V1 = self.GCN_dim, self.att_feat_size, self.att_hid_size, self.rnn_size, self.input_encoding_size, self.vocab_size + 1
         Lr, Ew, FC = self.GCN_lr, self.embed_dim, self.fc_feat_size
         lin = lambda o, i: [((o, i), ("uniform", 1 / math.sqrt(i))), ((o,), ("uniform", 1 / math.sqrt(i)))]
@@ -163,19 +162,25 @@ class AttModel(CaptionModel):
         else:
             add_lin("read_out_proj.0", A, L, bias_zero=True)
             add_lin("read_out_proj.1", 2 * L, A, bias_zero=True)
+        # Decoder slices in the order the backward FINISHES them, last to first (parallel.GradBucketReducer all-reduces each slice the
+        # moment it is final, so every slice must be contiguous): [prepare | recurrent | logit].  logit.* is final right after the
+        # criterion backward, BEFORE the BPTT loop (functions*.py: wgrad(21)); the recurrent slice after the loop's batched weight-
+        # gradient products; the prepare-feature slice (fc_embed / att_embed / ctx2att) after prepared_backward; the encoder last.
         self._decoder_first = len(sp)
-        add_lin("logit", V1, R)
-        sp.append(("embed.0.weight", (V1, E), ("normal", 1.0)))
         add_lin("fc_embed.0", FC, D)
         add_lin("fc_embed.2", R, FC)
         add_lin("att_embed.0", R, L)
         add_lin("ctx2att", A, R)
+        self._recurrent_first = len(sp)
+        sp.append(("embed.0.weight", (V1, E), ("normal", 1.0)))
         add_lin("core.attention.h2att", A, R)
         add_lin("core.attention.alpha_net", 1, A)
         k = 1 / math.sqrt(R)
         for nm, i in (("core.att_lstm", E + 2 * R), ("core.lang_lstm", 2 * R)):
             sp.append((nm + ".weight_ih", (4 * R, i), ("uniform", k))); sp.append((nm + ".weight_hh", (4 * R, R), ("uniform", k)))
             sp.append((nm + ".bias_ih", (4 * R,), ("uniform", k))); sp.append((nm + ".bias_hh", (4 * R,), ("uniform", k)))
+        self._logit_first = len(sp)
+        add_lin("logit", V1, R)
         return sp
 
     def _build_parameters(self):
@@ -201,6 +206,7 @@ class AttModel(CaptionModel):
             _attach(self, name, nn.Parameter(view))
             self._slots[name] = (o, n, shape)
         self.decoder_offset = offs[self._decoder_first]
+        self._bucket_bounds = (0, offs[self._decoder_first], offs[self._recurrent_first], offs[self._logit_first], total)
         if self.GCN_use_bn:
             for l in range(self.GCN_layers):
                 for u in range(4):
@@ -242,6 +248,14 @@ class AttModel(CaptionModel):
             o, n, shape = self._slots[name]
             p.grad = self.flat_grads[o:o + n].view(shape)
         return self.flat_grads
+
+    def grad_buckets(self):
+        """[(stage, lo, hi)] element ranges of the flat gradient buffer in READINESS order of the backward: "logit" (final before
+        the BPTT loop starts), "recurrent" (LSTMs, h2att, alpha_net, word embedding: final after the loop's batched weight-gradient
+        products), "prepare" (fc_embed, att_embed, ctx2att), "encoder" (everything upstream of the decoder, final when backward
+        returns).  The decoder Functions announce the first three through functions.on_grads_ready(stage)."""
+        e0, p0, r0, l0, end = self._bucket_bounds
+        return [("logit", l0, end), ("recurrent", r0, l0), ("prepare", p0, r0), ("encoder", e0, p0)]
 
     def P(self, name):
         return self._pmap[name]

@@ -4,12 +4,12 @@ ONE flat fp32 gradient bucket all-reduced over RCCL/xGMI.
 Replaces reference `train.py:96-98` (`nn.DataParallel`: per-iteration parameter broadcast of 280 MB,
 input scatter, loss gather, gradient reduce-add to GPU 0).  Here parameters are replicated once,
 every rank runs fwd+bwd on its own shard and the gradients - which already live contiguously in
-`model.flat_grads` - are summed with two collectives:
+`model.flat_grads` - are summed in four readiness-ordered collectives (GradBucketReducer):
 
-  * the decoder slice (LSTMs, logit, embeddings: ~94 % of the bytes) is launched from a
-    post-accumulate-grad hook as soon as the decoder's backward has produced it, so it overlaps
-    the encoder's backward;
-  * the encoder slice follows when backward returns.
+  * logit.* (final before the BPTT loop starts) overlaps the whole recurrent backward;
+  * the recurrent slice (LSTMs, h2att, alpha_net, word embedding: ~68 % of the bytes) is sent when the loop's
+    batched weight-gradient products are enqueued and overlaps the prepare-feature and encoder backward;
+  * the prepare-feature slice follows, then the encoder slice when backward returns.
 
 Averaging over ranks reproduces DataParallel's mean of per-replica losses (train.py:154-156);
 BatchNorm statistics stay per rank, as they do under DataParallel.  Parameters that receive no
@@ -107,7 +107,18 @@ def sample_images_sharded(model, images, opt=None, group_size=256, group=None):
 
 
 class GradBucketReducer:
-    """All-reduce `model.flat_grads` (decoder slice early, encoder slice at the end)."""
+    """All-reduce `model.flat_grads` in READINESS-ORDERED buckets (AttModel.grad_buckets): every slice of the flat gradient buffer
+    is summed over the ranks the moment the backward has finished writing it, while the rest of the backward still runs --
+
+        logit      (38 MB at Sub_GC_Kar)  final right after the criterion backward, BEFORE the BPTT loop: overlaps the whole loop
+        recurrent  (~190 MB: both LSTMs, h2att, alpha_net, the word embedding)  final after the loop's batched weight-gradient products
+        prepare    (~33 MB: fc_embed, att_embed, ctx2att)  final after the prepare-feature backward
+        encoder    (~17 MB)  final when backward returns (`finish`)
+
+    The decoder Functions announce a slice through functions.on_grads_ready(stage) (they write their gradients straight into the
+    bucket, so no autograd hook fires for them); the post-accumulate-grad hooks cover the generic autograd path.  Each collective is
+    enqueued behind the kernels already on the compute stream (torch.distributed's stream hand-off) and runs on RCCL's own stream.
+    Reference semantics: nn.DataParallel's gradient reduce-add, train.py:96-98,154-164."""
 
     def __init__(self, model, group=None, overlap=True, always_reduce=False):
         """`always_reduce`: issue the collectives even in a one-rank group (a one-GPU box can then exercise RCCL itself and
@@ -115,54 +126,67 @@ class GradBucketReducer:
         self.model, self.group = model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_initialized())
+        self.buckets = model.grad_buckets()                     # [(stage, lo, hi)], readiness order, the encoder last
         self.split = model.decoder_offset
         self.overlap = overlap and self.active
-        self._pending = []
-        self._fired = 0
-        self._decoder_launched = False
+        self._pending, self._launched, self._fired = [], [], {}
         self._handles = []
-        names = set(n for n in model._slots if model._slots[n][0] >= self.split)
-        self._n_decoder = len(names)
+        self.issued = []                                        # (stage, bytes) of every collective of the current step, in issue order
+        self._need = {}
         if self.overlap:
             from . import functions as F_
-            F_.on_decoder_grads_ready = self._decoder_ready
+            F_.on_grads_ready = self._ready
+            early = [(st, lo, hi) for st, lo, hi in self.buckets if st != "encoder"]
             for n, p in model.named_parameters():
-                if n in names:
-                    self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+                o = model._slots[n][0]
+                for st, lo, hi in early:
+                    if lo <= o < hi:
+                        self._need[st] = self._need.get(st, 0) + 1
+                        self._handles.append(p.register_post_accumulate_grad_hook(lambda _p, st=st: self._hook(st)))
 
-    def _hook(self, p):
-        self._fired += 1
-        if self._fired == self._n_decoder:
-            self._decoder_ready()
+    def _hook(self, stage):
+        self._fired[stage] = self._fired.get(stage, 0) + 1
+        if self._fired[stage] == self._need[stage]:
+            self._ready(stage)
 
-    def _decoder_ready(self):
-        """The decoder slice of the bucket is final: start its all-reduce now (once per step).  Called by
-        DecoderFn.backward (which writes its gradients straight into the bucket) or, on the generic
-        autograd path, by the post-accumulate-grad hooks."""
-        if self._decoder_launched or not self.active or self.model.flat_grads is None:
-            return
-        self._decoder_launched = True
-        g = self.model.flat_grads[self.split:]
+    def _issue(self, stage, lo, hi):
+        from . import functions as F_
+        g = self.model.flat_grads[lo:hi]
+        F_.note("issue", stage)
+        self.issued.append((stage, 4 * (hi - lo)))
         self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _ready(self, stage):
+        """The gradient slice `stage` is final: start its all-reduce now (once per step)."""
+        if stage in self._launched or not self.active or self.model.flat_grads is None:
+            return
+        for st, lo, hi in self.buckets:
+            if st == stage:
+                self._launched.append(stage)
+                if hi > lo:
+                    self._issue(st, lo, hi)
 
     def prepare(self):
         """Call before forward: (re)binds every .grad into the zeroed flat bucket."""
-        self._fired = 0
-        self._pending = []
-        self._decoder_launched = False
+        self._fired, self._pending, self._launched, self.issued = {}, [], [], []
         return self.model.flatten_grads()
 
     def finish(self, average=True):
-        """Call after loss.backward(): completes the reduction and averages (`average=False`: leave the SUM and hand
-        `1 / world` to `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep)."""
+        """Call after loss.backward(): reduces whatever has not been sent yet (the encoder slice; every slice when nothing
+        overlapped -- adjacent ranges travel as one collective), waits for all of it and averages (`average=False`: leave the SUM
+        and hand `1 / world` to `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep)."""
         if not self.active:
             return self.model.flat_grads
         g = self.model.flat_grads
-        if self._pending:
-            rest = g[: self.split]
-        else:
-            rest = g
-        self._pending.append(dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        rest = sorted((lo, hi, st) for st, lo, hi in self.buckets if st not in self._launched and hi > lo)
+        merged = []
+        for lo, hi, st in rest:
+            if merged and merged[-1][1] == lo:
+                merged[-1] = (merged[-1][0], hi, merged[-1][2] + "+" + st)
+            else:
+                merged.append((lo, hi, st))
+        for lo, hi, st in merged:
+            self._issue(st, lo, hi)
         for w in self._pending:
             w.wait()
         self._pending = []
@@ -172,8 +196,8 @@ class GradBucketReducer:
 
     def close(self):
         from . import functions as F_
-        if F_.on_decoder_grads_ready == self._decoder_ready:
-            F_.on_decoder_grads_ready = None
+        if F_.on_grads_ready == self._ready:
+            F_.on_grads_ready = None
         for h in self._handles:
             h.remove()
         self._handles = []

@@ -40,6 +40,12 @@ def test_host_side_argument_validation_needs_no_gpu():
     assert L.subgc_gemm_bf16_workspace_bytes(21760, 9488, 1000, ctypes.byref(need)) == 0 and need.value == 0
     rc = L.subgc_row_argmax_f32(None, 4, 2, 4, 4, None, None, None)
     assert rc == -1
+    # sub-graph NMS: a sub-graph is a 256-bit node mask (64 * SUBGC_NMS_WORDS), so obj_num = 300 must be an error, not a silently
+    # truncated node set (gpn.py:108-150 builds python sets of any size); both entry points, checked before any launch
+    rc = L.subgc_subgraph_nms(16, 16, 300, 16, 4, 300, 0.55, 10, 16, 16, 16, 4 * 40, None)
+    assert rc == -1 and b"node ids must be < 256" in L.subgc_last_error()
+    rc = L.subgc_subgraph_nms_batched(16, 16, 300, 16, 16, 1, 4, 4, 300, 0.55, 10, 16, 16, 16, 4 * 40, None)
+    assert rc == -1 and b"node ids must be < 256" in L.subgc_last_error()
     with pytest.raises(_lib.SubgcError):
         _lib.call("subgc_decode_pick", None, 10, 1, 10, 9, 1.0, None, 0, None, None, 4, None, None, None, None, 0, None)
 

@@ -35,3 +35,25 @@ def test_two_rank_bench_prints_one_contract_line():
     for k in ("decode_tokens_per_s", "decode_batched_tokens_per_s", "decode_mrnn_topk_tokens_per_s"):
         assert d[k] > 0, k
     assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(1500)
+def test_eight_rank_bench_rehearsal_on_one_gpu():
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, 8 ranks), all eight on the one GPU of the test box with
+    gloo carrying the tensors: rendezvous, per-rank seeds and shards, the four readiness-ordered collectives per step, the sharded
+    decode legs and their gather, memory of eight replicas -- everything but the timing."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SUBGC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "8", "--decode-images", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_images"] == 64 and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("dp8")
+    for k in ("decode_tokens_per_s", "decode_batched_tokens_per_s", "decode_mrnn_topk_tokens_per_s"):
+        assert d[k] > 0, k

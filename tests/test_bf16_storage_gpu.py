@@ -41,6 +41,42 @@ def grads_roughly_equal(m, orc, keys, cos_min=0.995):
         assert abs(float(g.norm()) / float(r.norm()) - 1.0) < 0.05, k
 
 
+def every_live_gradient_close(m, ref_grads, dead=(), rel=3e-2, cos_min=0.99, norm_tol=0.05, loose=(), loose_rel=None, where=""):
+    """EVERY parameter of the model against the fp32 reference gradient (round-3 review, weak #1a: the key lists above have no bias /
+    BatchNorm-affine / alpha_net entries and check direction and norm only -- a wrong scale on ONE small tensor would pass):
+      dead parameters (no path to the loss) are exactly zero where the reference has no gradient;
+      every other tensor:  max|g - r| <= rel * max|r|  (element-wise, relative to the tensor's own scale: catches a mis-scaled or
+      mis-placed slice of a small tensor that a cosine over a large one hides), cosine > cos_min, | ||g|| / ||r|| - 1 | < norm_tol.
+    `loose`: name fragments with their own `loose_rel` (stated per test with the reason).  All violations are reported at once."""
+    bad, n_checked = [], 0
+    for k, p in m.named_parameters():
+        r = ref_grads.get(k)
+        r = None if r is None else (torch.from_numpy(r) if isinstance(r, np.ndarray) else r).detach().float().cpu()
+        g = p.grad
+        assert g is not None and g.dtype == torch.float32, k
+        g = g.detach().float().cpu()
+        if k in dead or r is None:
+            if float(g.abs().max()) != 0.0:
+                bad.append((k, "dead parameter with a gradient", float(g.abs().max())))
+            continue
+        scale = float(r.abs().max())
+        if scale < 1e-10:
+            if float(g.abs().max()) > 1e-7:
+                bad.append((k, "reference gradient is zero", float(g.abs().max())))
+            continue
+        n_checked += 1
+        tol = rel
+        if loose_rel is not None and any(f in k for f in loose):
+            tol = loose_rel
+        err = float((g - r).abs().max()) / scale
+        c = cosine(g, r)
+        nr = float(g.norm()) / float(r.norm())
+        if err > tol or c < cos_min or abs(nr - 1.0) > norm_tol:
+            bad.append((k, f"max|g-r|/max|r| = {err:.4f} (tol {tol})", f"cos {c:.5f}", f"norm ratio {nr:.4f}"))
+    assert not bad, (where, bad)
+    return n_checked
+
+
 @pytest.mark.parametrize("name", ["subgc_train", "fullgc_train"])
 @pytest.mark.parametrize("packed", [True, False])
 def test_golden_train_cases_in_bf16_storage(golden, name, packed):
@@ -64,6 +100,11 @@ def test_golden_train_cases_in_bf16_storage(golden, name, packed):
     # the golden weights are sharpened (GCN x50, LSTM x3, logit x8) to make the fp32 parity tests bite; with one 2^-9 rounding
     # per product that also amplifies the bf16 noise of the small encoder gradients
     assert worst > 0.95, worst
+    # every live parameter (biases, BatchNorm affine, alpha_net included) element-wise against the reference's golden gradient; the
+    # encoder tensors sit behind the x50 GCN weights, where the bf16 rounding of the 512-wide hidden rows is amplified: 1e-1 there
+    n = every_live_gradient_close(m, grads, dead, rel=3e-2, cos_min=0.95, norm_tol=0.1, loose=("gcn_backbone", "obj_", "pred_", "sg_", "gpn_layer"),
+                                  loose_rel=1e-1, where=f"{name} packed={packed}")
+    assert n >= len(grads) - len(dead) - 2
     with torch.no_grad():
         outputs, gpn_loss, score = m(*synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
     close(outputs, ref["outputs"], "outputs", atol=5e-2, rtol=2e-2)
@@ -158,6 +199,8 @@ def test_flickr_bench_size_b64_train_matches_fp32_oracle():
     grads_roughly_equal(m, orc, ("logit.weight", "core.att_lstm.weight_ih", "core.lang_lstm.weight_hh", "embed.0.weight", "obj_v_proj.weight",
                                  "gcn_backbone.gcn.0.gcn_collect.collect_units.3.fc_rgt.weight", "gcn_backbone.gcn.1.gcn_collect.collect_units.0.fc_lft.weight",
                                  "att_embed.0.weight", "ctx2att.weight", "fc_embed.0.weight", "core.attention.h2att.weight"))
+    ref_g = {k: p.grad for k, p in orc.P.items()}
+    every_live_gradient_close(m, ref_g, {k for k, v in ref_g.items() if v is None}, rel=3e-2, cos_min=0.99, where="flickr B=64")
 
 
 @pytest.mark.timeout(900)
@@ -183,6 +226,8 @@ def test_full_gc_kar_bench_size_b256_train_matches_fp32_oracle():
                                  "gcn_backbone.gcn.0.gcn_collect.collect_units.0.fc_rgt.weight", "gcn_backbone.gcn.2.gcn_collect.collect_units.3.fc_lft.weight",
                                  "gcn_backbone.gcn.3.gcn_collect.collect_units.1.fc_lft.weight", "att_embed.0.weight", "ctx2att.weight", "fc_embed.0.weight",
                                  "core.attention.h2att.weight"), cos_min=0.99)
+    ref_g = {k: p.grad for k, p in orc.P.items()}
+    every_live_gradient_close(m, ref_g, {k for k, v in ref_g.items() if v is None}, rel=3e-2, cos_min=0.98, where="full_gc_kar B=256")
     k = "gcn_backbone.gcn.1.gcn_collect.collect_units.2.bn.running_mean"
     close(m.state_dict()[k], orc.buffers[k], "running_mean", atol=2e-2, rtol=2e-2)
 

@@ -1,6 +1,6 @@
 """N>1 path on CPU: two `gloo` ranks shard one batch by image, compute their shard's gradients
 (with the CPU oracle standing in for the device compute), all-reduce the flat gradient bucket with
-GradBucketReducer (decoder slice from the post-accumulate hook, encoder slice at the end) and must
+GradBucketReducer (the three decoder slices from the post-accumulate hooks, encoder slice at the end) and must
 end up with the mean of the per-shard gradients - DataParallel's semantics (train.py:96-98,154-156)."""
 import os
 import socket
@@ -57,7 +57,9 @@ def _worker(rank, world, port, q):
     names.sort(key=lambda n: -model._slots[n][0])
     loss = sum((model.P(n) * grads[n]).sum() for n in names)
     loss.backward()
-    assert red._fired == red._n_decoder and len(red._pending) == 1      # decoder bucket already in flight
+    # the three decoder slices (AttModel.grad_buckets) are already in flight, each sent when its last gradient arrived
+    assert sorted(st for st, _ in red.issued) == ["logit", "prepare", "recurrent"] and len(red._pending) == 3
+    assert all(red._fired[st] == red._need[st] for st in ("logit", "recurrent", "prepare"))
     flat = red.finish().clone()
     red.close()
     q.put((rank, flat.numpy(), {k: (None if v is None else v.numpy()) for k, v in grads.items()}))
@@ -93,6 +95,31 @@ def test_two_rank_gloo_bucket_allreduce_is_mean_of_shard_grads():
         else:
             np.testing.assert_allclose(got, 0.5 * (g0[name] + g1[name]), rtol=1e-6, atol=1e-7, err_msg=name)
     assert seen_dead == len(g.meta["dead_params"])
+
+
+def test_grad_buckets_are_contiguous_readiness_ordered_and_cover_the_flat_buffer():
+    """AttModel.grad_buckets: logit -> recurrent -> prepare -> encoder, contiguous, disjoint, covering every parameter slot, and
+    every parameter lies in the slice its name says (the decoder Functions announce the slices by these names)."""
+    sys.path.insert(0, os.path.join(ROOT, "sub-gc_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Golden
+    import subgc.models as models
+    from subgc import functions as F_
+    for gname in ("subgc_train", "fullgc_train"):
+        model = models.setup(Golden(gname).opt(caption_model="topdown"))
+        b = model.grad_buckets()
+        assert [st for st, _, _ in b] == ["logit", "recurrent", "prepare", "encoder"]
+        spans = sorted((lo, hi) for _, lo, hi in b)
+        assert spans[0][0] == 0 and spans[-1][1] == model.flat_params.numel()
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(3))
+        where = {st: (lo, hi) for st, lo, hi in b}
+        stage_of = lambda n: ("logit" if n.startswith("logit.") else
+                              "prepare" if n.split(".")[0] in ("fc_embed", "att_embed", "ctx2att") else
+                              "recurrent" if n in F_.PARAM_ORDER else "encoder")
+        for n, (o, cnt, _) in model._slots.items():
+            lo, hi = where[stage_of(n)]
+            assert lo <= o and o + cnt <= hi, n
+        assert where["encoder"] == (0, model.decoder_offset)
 
 
 def test_shard_batch_splits_every_leading_dim():

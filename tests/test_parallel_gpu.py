@@ -1,7 +1,7 @@
 """Two ranks on the one MI355X of the test box (both on cuda:0; `gloo` carries the CUDA tensors because RCCL
 refuses two ranks on one device): the REAL model runs LossWrapper fwd+bwd on its image shard through the HIP
 path, DecoderFn's backward fires the reducer callback from the autograd thread, the flat bucket is reduced in
-two slices, and both ranks must end with the mean of the per-shard gradients computed in a single process."""
+four readiness-ordered slices, and both ranks must end with the mean of the per-shard gradients computed in a single process."""
 import os
 import socket
 import sys
@@ -54,7 +54,8 @@ def _shard_step(m, models, shard, reducer=None):
              None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
     (out["lang_loss"] + out["gpn_loss"]).backward()
     if reducer is not None:
-        launched_early = reducer._decoder_launched and len(reducer._pending) == 1
+        # the three decoder slices were sent from inside DecoderFn.backward, in readiness order, before backward returned
+        launched_early = [st for st, _ in reducer.issued] == ["logit", "recurrent", "prepare"] and len(reducer._pending) == 3
         flat = reducer.finish()
         torch.cuda.synchronize()
         return flat.clone(), launched_early
@@ -97,7 +98,7 @@ def test_two_ranks_one_gpu_bucket_reduction_matches_mean_of_shards():
     want = 0.5 * (shard_grads[0] + shard_grads[1])
     scale = float(np.abs(want).max())
     for rank, flat, early in res:
-        assert early, "decoder slice must be in flight before the encoder backward ends"
+        assert early, "the decoder slices must be in flight before the encoder backward ends"
         np.testing.assert_allclose(flat, want, atol=3e-5 * scale + 1e-8, rtol=1e-4)
     np.testing.assert_array_equal(res[0][1], res[1][1])
 
@@ -124,7 +125,11 @@ def _nccl_worker(port, q):
     m._dropout_calls = 0
     red = parallel.GradBucketReducer(m, always_reduce=True)
     assert red.active and red.overlap
+    from subgc import functions as F_
+    F_.trace = []                                                   # host-order record of the backward's phases and of every collective's issue point
     flat, early = _shard_step(m, models, batch, red)
+    trace, F_.trace = F_.trace, None
+    issued = list(red.issued)
     # a second step through the same reducer, then the fused optimizer sweep on the reduced bucket (stream order: RCCL -> Adam)
     adam = parallel.FlatAdam(m)
     before = m.flat_params.clone()
@@ -133,7 +138,7 @@ def _nccl_worker(port, q):
     torch.cuda.synchronize()
     moved = float((m.flat_params - before).abs().max())
     red.close()
-    q.put((flat.numel() * 4, bool(early), float((flat - plain).abs().max()), float(plain.abs().max()), moved, dist.get_backend()))
+    q.put((flat.numel() * 4, bool(early), float((flat - plain).abs().max()), float(plain.abs().max()), moved, dist.get_backend(), trace, issued))
     dist.destroy_process_group()
 
 
@@ -146,10 +151,21 @@ def test_rccl_world_size_one_pushes_the_real_280mb_bucket():
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
     p.start()
-    nbytes, early, err, scale, moved, backend = q.get(timeout=800)
+    nbytes, early, err, scale, moved, backend, trace, issued = q.get(timeout=800)
     p.join(120)
     assert p.exitcode == 0
     assert backend == "nccl" and nbytes > 270e6
-    assert early, "decoder slice must be in flight before the encoder backward ends"
+    assert early, "the decoder slices must be in flight before the encoder backward ends"
+    # WHEN each collective is issued relative to the BPTT loop (the collective is enqueued behind the kernels already on the compute
+    # stream, so host issue order == earliest device start order): logit.* (38 MB) goes out BEFORE the first step of the loop is
+    # enqueued, the recurrent slice right after the loop's weight-gradient products, the prepare slice before the encoder backward
+    at = lambda *ev: trace.index(ev)
+    steps = [e for e in trace if e[0] == "bptt_begin"][0][1]
+    assert steps >= 2
+    assert at("ready", "logit") < at("issue", "logit") < at("bptt_begin", steps) < at("bptt_end") < at("issue", "recurrent") < at("issue", "prepare")
+    assert at("issue", "recurrent") == at("ready", "recurrent") + 1 and at("issue", "prepare") == at("ready", "prepare") + 1
+    assert [st for st, _ in issued] == ["logit", "recurrent", "prepare", "encoder"]
+    sizes = dict(issued)
+    assert sum(sizes.values()) == nbytes and sizes["logit"] > 37e6 and sizes["recurrent"] > 180e6      # every byte of the bucket travels exactly once
     assert err <= 1e-4 * scale + 1e-12, (err, scale)        # two runs of the backward differ by fp32 atomic order only
     assert 0 < moved < 1e-2

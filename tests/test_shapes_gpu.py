@@ -161,10 +161,25 @@ def test_mrnn_decode_shape_many_candidates_topk_sampling():
     assert 20 < n <= 1000
     u = torch.rand(n, opt.seq_length + 4, generator=torch.Generator().manual_seed(15))[:, :m.seq_length].contiguous()
     ret = m._sample(*synthetic.sample_args(dev_b), opt=dict(sample_max=1, beam_size=1), uniforms=u.to(DEV))
-    want = O.Oracle(opt, sd).sample(*synthetic.sample_args(tb), opt=dict(sample_max=1, beam_size=1), uniforms=u, nms_sort_kind="stable")
+    tap = {}
+    want = O.Oracle(opt, sd).sample(*synthetic.sample_args(tb), opt=dict(sample_max=1, beam_size=1), uniforms=u, nms_sort_kind="stable", tap=tap)
     np.testing.assert_array_equal(ret[3].cpu().numpy(), want[3].numpy())
-    same = (ret[0].cpu() == want[0]).all(1)
+    got = ret[0].cpu()
+    same = (got == want[0]).all(1)
     assert float(same.float().mean()) > 0.97, "sampled paths may fork where two of the top-3 renormalised probabilities straddle a uniform"
+    # ... and EVERY fork must be explained that way: up to the first differing step both paths share their history, so the oracle's
+    # top-3 distribution at that step is the one both samplers drew from; the injected uniform must sit within 1e-4 of one of its
+    # cumulative-probability boundaries (the fp32 logits of the two implementations differ by ~1e-5), and the word the HIP path took
+    # must be the oracle's top-3 neighbour across that boundary
+    for r in (~same).nonzero().flatten().tolist():
+        t0 = int((got[r] != want[0][r]).nonzero()[0])
+        top = tap["topk_lp"][t0][r].double()
+        cdf = torch.softmax(top, 0).cumsum(0)
+        gaps = (cdf[:-1] - float(u[r, t0])).abs()
+        j = int(gaps.argmin())
+        assert float(gaps[j]) < 1e-4, (r, t0, cdf.tolist(), float(u[r, t0]))
+        pair = {int(tap["topk_idx"][t0][r][j]), int(tap["topk_idx"][t0][r][j + 1])}
+        assert {int(got[r, t0]), int(want[0][r, t0])} <= pair | {0}, (r, t0, pair, int(got[r, t0]), int(want[0][r, t0]))
     close(ret[1].cpu()[same], want[1][same], "seqLogprobs", atol=3e-4)
     others = [{k: v.to(DEV) for k, v in synthetic.make_test_batch(M, seed=16 + i, node_pool=25, max_nodes=9).items()} for i, M in enumerate((300, 40))]
     many = m.sample_images([dev_b] + others, opt=dict(sample_max=1, beam_size=1))
