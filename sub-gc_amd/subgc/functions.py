@@ -130,6 +130,89 @@ def linear(x, W, b=None, add=None, keep=None, scale=1.0, relu=False, W16=None, x
     return y.view(*shp[:-1], W.size(0)) if x.dim() != 2 else y
 
 
+class UnitPairFn(Function):
+    """The two collection units that read the SAME source rows (graph_conv.py:24-25 units 0,1 read the relation rows, :31-32 units 2,3
+    the node rows; each unit = fc_rgt(fc_lft(x)), graph_conv_unit.py:28-30) as one Function:
+
+      forward   H = x [Wl_a ; Wl_b]^T + [bl_a ; bl_b]          ONE product, N = 2 * 512: the source is read once
+                y_a = H[:, :512] Wr_a^T + br_a,  y_b = H[:, 512:] Wr_b^T + br_b
+      backward  dH[:, :512] = dy_a Wr_a,  dH[:, 512:] = dy_b Wr_b
+                dx = dH [Wl_a ; Wl_b]                           ONE product, K = 2 * 512 (was two K = 512 products + an add)
+                d[Wl_a ; Wl_b] += dH^T x                        ONE product
+
+    `cat` = (Wl [2Lr, L], bl [2Lr], their gradient views or None, the bf16 twin of Wl or None): the two fc_lft parameters lie
+    side by side in the flat buffers (AttModel._specs), so the concatenations are views.  Under compute_dtype = bf16 (`W16r` given) H
+    and dH exist in bf16 only, x is taken as its bf16 copy `x16`, y is bf16 when `out_b16` (the fused aggregation reads it), d(x)
+    is fp32 (it joins the other gradient contributions of the source)."""
+
+    @staticmethod
+    def forward(ctx, x, x16, cat, Wl_a, bl_a, Wl_b, bl_b, Wr_a, br_a, Wr_b, br_b, W16r, out_b16):
+        Wl, bl, gWl, gbl, Wl16 = cat
+        dev = x.device
+        M, Lr2, L = x.size(0), Wl.size(0), Wr_a.size(0)
+        Lr = Lr2 // 2
+        bf = Wl16 is not None
+        ctx.bf, ctx.cat, ctx.Lr = bf, cat, Lr
+        ctx.params = (Wl_a, bl_a, Wl_b, bl_b, Wr_a, br_a, Wr_b, br_b)
+        if bf:
+            xa = x if ops.is_b16(x) else (x16 if x16 is not None else ops.as_b16(x))
+            H = ops.empty_b16(M, Lr2, dev)
+            ops.gemm(xa, Wl16, H, tb=True, bias=bl)
+            mk = (lambda: ops.empty_b16(M, L, dev)) if out_b16 else (lambda: torch.empty(M, L, device=dev, dtype=torch.float32))
+            ya, yb = mk(), mk()
+            ops.gemm(H[:, :Lr], W16r[0], ya, tb=True, bias=br_a)
+            ops.gemm(H[:, Lr:], W16r[1], yb, tb=True, bias=br_b)
+            ctx.save_for_backward(xa, H, Wl16, W16r[0], W16r[1])
+            return ya, yb
+        H = torch.empty(M, Lr2, device=dev, dtype=torch.float32)
+        ops.gemm(x, Wl, H, tb=True, bias=bl)
+        ya, yb = torch.empty(M, L, device=dev, dtype=torch.float32), torch.empty(M, L, device=dev, dtype=torch.float32)
+        ops.gemm(H[:, :Lr], Wr_a, ya, tb=True, bias=br_a)
+        ops.gemm(H[:, Lr:], Wr_b, yb, tb=True, bias=br_b)
+        ctx.save_for_backward(x, H, Wl, Wr_a, Wr_b)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        x, H, Wl, Wra, Wrb = ctx.saved_tensors
+        _, _, gWl, gbl, _ = ctx.cat
+        Wl_a, bl_a, Wl_b, bl_b, Wr_a, br_a, Wr_b, br_b = ctx.params
+        dev, Lr, bf = x.device, ctx.Lr, ctx.bf
+        M = x.size(0)
+        if bf:
+            dya, dyb = (d if ops.is_b16(d) else ops.as_b16(d.contiguous()) for d in (dya, dyb))
+            dH = ops.empty_b16(M, 2 * Lr, dev)
+        else:
+            dya, dyb = dya.contiguous(), dyb.contiguous()
+            dH = torch.empty(M, 2 * Lr, device=dev, dtype=torch.float32)
+        ops.gemm(dya, Wra, dH[:, :Lr])
+        ops.gemm(dyb, Wrb, dH[:, Lr:])
+        ret = [None] * 8
+        for i, (W, b, dy, Hh) in enumerate(((Wr_a, br_a, dya, H[:, :Lr]), (Wr_b, br_b, dyb, H[:, Lr:]))):
+            gW, gb = _direct(W, dev), _direct(b, dev)
+            if gW is not None:
+                ops.gemm(dy, Hh, gW, ta=True, accum=True)
+            else:
+                ret[4 + 2 * i] = torch.empty(W.shape, device=dev, dtype=torch.float32); ops.gemm(dy, Hh, ret[4 + 2 * i], ta=True)
+            if gb is not None:
+                ops.colsum(dy, out=gb, accumulate=True)
+            else:
+                ret[5 + 2 * i] = ops.colsum(dy)
+        direct = gWl is not None and DIRECT_GRADS
+        if direct:
+            ops.gemm(dH, x, gWl, ta=True, accum=True)
+            ops.colsum(dH, out=gbl, accumulate=True)
+        else:
+            dWl = torch.empty(2 * Lr, x.size(1), device=dev, dtype=torch.float32); ops.gemm(dH, x, dWl, ta=True)
+            dbl = ops.colsum(dH)
+            ret[0], ret[1], ret[2], ret[3] = dWl[:Lr], dbl[:Lr], dWl[Lr:], dbl[Lr:]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, x.size(1), device=dev, dtype=torch.float32)
+            ops.gemm(dH, Wl, dx)
+        return (dx, None, None) + tuple(ret) + (None, None)
+
+
 class ForkFn(Function):
     """x -> n aliases of x for n consumers; the backward adds their gradient contributions in ONE launch (subgc_add_n_f32) instead of
     autograd's chain of pairwise ATen adds."""

@@ -120,6 +120,8 @@ class AttModel(CaptionModel):
         # att_embed keep-mask across the 5 sentences of an image (each sentence's marginal is unchanged); 0 = the reference's
         # independent masks on replicated rows.  Not a reference option.
         self.share_attention_sets = g("share_attention_sets", 1) != 0
+        # the two GCN units that read the same source run as one paired Function (concatenated fc_lft; functions.UnitPairFn); 0 = one by one
+        self.pair_gcn_units = g("pair_gcn_units", 1) != 0
         self.dropout_seed = g("seed", 2019)
         self._dropout_calls = 0
         self.injected_masks = None       # tests inject {'fc','att','xt','out','gpn_hid'} keep-masks here
@@ -147,12 +149,16 @@ class AttModel(CaptionModel):
         sp.append(("sg_pred_embed.weight", (self.sg_pred_cnt, Ew), ("normal", 1.0)))
         add_lin("pred_emb_prj", L, Ew)
         for l in range(self.GCN_layers):
-            for u in range(4):
-                pre = f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}."
-                sp.append((pre + "fc_lft.weight", (Lr, L), ("normal", 0.001))); sp.append((pre + "fc_lft.bias", (Lr,), ("zero",)))
-                sp.append((pre + "fc_rgt.weight", (L, Lr), ("normal", 0.001))); sp.append((pre + "fc_rgt.bias", (L,), ("zero",)))
-                if self.GCN_use_bn:
-                    sp.append((pre + "bn.weight", (L,), ("one",))); sp.append((pre + "bn.bias", (L,), ("zero",)))
+            for ua in (0, 2):
+                # the two units of a pair read the same source rows (graph_conv.py:24-25, 31-32): their fc_lft weights (and biases) lie side
+                # by side, so [Wl_a ; Wl_b] is a VIEW and the pair's first product is one N = 2 * 512 launch (functions.UnitPairFn)
+                pa, pb = (f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}." for u in (ua, ua + 1))
+                sp.append((pa + "fc_lft.weight", (Lr, L), ("normal", 0.001))); sp.append((pb + "fc_lft.weight", (Lr, L), ("normal", 0.001)))
+                sp.append((pa + "fc_lft.bias", (Lr,), ("zero",))); sp.append((pb + "fc_lft.bias", (Lr,), ("zero",)))
+                for pre in (pa, pb):
+                    sp.append((pre + "fc_rgt.weight", (L, Lr), ("normal", 0.001))); sp.append((pre + "fc_rgt.bias", (L,), ("zero",)))
+                    if self.GCN_use_bn:
+                        sp.append((pre + "bn.weight", (L,), ("one",))); sp.append((pre + "bn.bias", (L,), ("zero",)))
         if self.gpn:
             if self.use_sGPN_score:
                 add_lin("gpn_layer.gpn_fc.0", A, 2 * L, bias_zero=True)
@@ -366,6 +372,43 @@ class AttModel(CaptionModel):
             self._nbt_pending[pre] = self._nbt_pending.get(pre, 0) + 1                # num_batches_tracked, folded into the buffer lazily
         return y.view(shp[0], shp[1], -1)
 
+    def _pair_cat(self, l, ua, flat16):
+        """([Wl_a ; Wl_b], [bl_a ; bl_b], their gradient views or None, the bf16 twin or None) of the unit pair (ua, ua + 1) of layer l
+        as views of the flat buffers; None when the two slots are not adjacent (L * 512 or 512 not a multiple of the 8-element slot
+        alignment) -- the caller then runs the units one by one."""
+        na, nb = (f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}.fc_lft." for u in (ua, ua + 1))
+        (ow, nw, shp), (ow2, _, _) = self._slots[na + "weight"], self._slots[nb + "weight"]
+        (ob, nbias, _), (ob2, _, _) = self._slots[na + "bias"], self._slots[nb + "bias"]
+        if ow2 != ow + nw or ob2 != ob + nbias:
+            return None
+        Lr, L = shp
+        fp, fg = self.flat_params, self.flat_grads
+        bound = fg is not None and all(self.P(n + k).grad is not None and self.P(n + k).grad.data_ptr() == fg[self._slots[n + k][0]:].data_ptr()
+                                       for n in (na, nb) for k in ("weight", "bias"))
+        return (fp[ow:ow + 2 * nw].view(2 * Lr, L), fp[ob:ob + 2 * nbias],
+                fg[ow:ow + 2 * nw].view(2 * Lr, L) if bound else None, fg[ob:ob + 2 * nbias] if bound else None,
+                None if flat16 is None or L % 8 else flat16[ow:ow + 2 * nw].view(2 * Lr, L))
+
+    def _unit_pair(self, l, ua, src, src16, flat16, fuse_bn, out_b16):
+        """Units (ua, ua + 1) of layer l on their common source `src` [B, n, L] -> (y_a, y_b) [B, n, L] (functions.UnitPairFn); the
+        per-unit path (`_unit`) when the pair cannot be formed (slots not adjacent, no bf16 twin, or a BatchNorm that is not fused into
+        the aggregation).  `fuse_bn` / `out_b16`: see `_unit` (raw outputs for the fused BatchNorm; bf16 outputs under compute_dtype = bf16)."""
+        cat = self._pair_cat(l, ua, flat16) if self.pair_gcn_units else None
+        if cat is None or (flat16 is not None and cat[4] is None) or (self.GCN_use_bn and not fuse_bn):
+            xs = F_.fork(src, 2)
+            w16 = None if flat16 is None else (lambda name: self.W16(name, flat16))
+            return self._unit(l, ua, xs[0], src16, w16, fuse_bn or out_b16), self._unit(l, ua + 1, xs[1], src16, w16, fuse_bn or out_b16)
+        pa, pb = (f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}." for u in (ua, ua + 1))
+        shp = src.shape
+        W16r = None if flat16 is None else (self.W16(pa + "fc_rgt.weight", flat16), self.W16(pb + "fc_rgt.weight", flat16))
+        ya, yb = F_.UnitPairFn.apply(src.reshape(-1, shp[-1]), src16, cat, self.P(pa + "fc_lft.weight"), self.P(pa + "fc_lft.bias"),
+                                     self.P(pb + "fc_lft.weight"), self.P(pb + "fc_lft.bias"), self.P(pa + "fc_rgt.weight"), self.P(pa + "fc_rgt.bias"),
+                                     self.P(pb + "fc_rgt.weight"), self.P(pb + "fc_rgt.bias"), W16r, bool(fuse_bn or out_b16) and flat16 is not None)
+        if self.GCN_use_bn and self.training:
+            for pre in (pa, pb):
+                self._nbt_pending[pre] = self._nbt_pending.get(pre, 0) + 1
+        return ya.view(shp[0], shp[1], -1), yb.view(shp[0], shp[1], -1)
+
     def _bn_args(self, l, ua, ub):
         """(gamma_a, beta_a, gamma_b, beta_b, (running_mean_a, running_var_a, running_mean_b, running_var_b), training) of two units."""
         pa, pb = (f"gcn_backbone.gcn.{l}.gcn_collect.collect_units.{u}.bn." for u in (ua, ub))
@@ -403,7 +446,7 @@ class AttModel(CaptionModel):
         ops.ensure_workspace(att_feats.device)          # scratch for the split-K form of the M=5B recurrent GEMMs
         needX, needP, live_nodes, live_edges = self._gcn_liveness()
         att2 = att_feats.reshape(B * N, D)
-        w16 = None
+        w16 = flat16 = None
         if self.bf16_storage:
             flat16 = self.weights_b16()
             w16 = lambda name: self.W16(name, flat16)
@@ -436,8 +479,9 @@ class AttModel(CaptionModel):
             new_x = new_p = None
             # a tensor that feeds several consumers is forked explicitly: the backward then adds the contributions in one launch
             s0 = (l // self.GCN_residual) * self.GCN_residual                                  # layer whose input the residual of this block adds
-            xs = F_.fork(x, (2 if live_edges[l] else 0) + (1 if (l == s0 and self._skip_used(s0, live_nodes)) else 0)) if x is not None else ()
-            ps = F_.fork(p, (2 if live_nodes[l] else 0) + (1 if (l == s0 and self._skip_used(s0, live_edges)) else 0)) if p is not None else ()
+            # (the two units of a pair take their common source as ONE consumer: functions.UnitPairFn)
+            xs = F_.fork(x, (1 if live_edges[l] else 0) + (1 if (l == s0 and self._skip_used(s0, live_nodes)) else 0)) if x is not None else ()
+            ps = F_.fork(p, (1 if live_nodes[l] else 0) + (1 if (l == s0 and self._skip_used(s0, live_edges)) else 0)) if p is not None else ()
             if l == s0:
                 skip_x = xs[-1] if (x is not None and self._skip_used(s0, live_nodes)) else None
                 skip_p = ps[-1] if (p is not None and self._skip_used(s0, live_edges)) else None
@@ -457,7 +501,7 @@ class AttModel(CaptionModel):
             nxt_x = w16 is not None and l + 1 < self.GCN_layers and live_edges[l + 1]          # the next layer reads new_x as a GEMM operand
             nxt_p = w16 is not None and l + 1 < self.GCN_layers and live_nodes[l + 1]
             if live_nodes[l]:
-                y0, y1 = self._unit(l, 0, ps[0], p16, w16, fuse or raw16), self._unit(l, 1, ps[1], p16, w16, fuse or raw16)
+                y0, y1 = self._unit_pair(l, 0, ps[0], p16, flat16, fuse, raw16)
                 if fuse:
                     r = F_.GcnNodesBnFn.apply(y0, y1, skip_x if res else None, rel_ind, ptr, edges, N, *self._bn_args(l, 0, 1), nxt_x)
                     new_x, x16n = (r[0], r[1].view(B * N, L)) if nxt_x else (r, None)
@@ -467,7 +511,7 @@ class AttModel(CaptionModel):
                 else:
                     new_x = F_.GcnNodesFn.apply(y0, y1, skip_x if res else None, rel_ind, ptr, edges, N)
             if live_edges[l]:
-                y2, y3 = self._unit(l, 2, xs[0], x16, w16, fuse or raw16), self._unit(l, 3, xs[1], x16, w16, fuse or raw16)
+                y2, y3 = self._unit_pair(l, 2, xs[0], x16, flat16, fuse, raw16)
                 if fuse:
                     r = F_.GcnEdgesBnFn.apply(y2, y3, skip_p if res else None, rel_ind, ptr, edges, K, *self._bn_args(l, 2, 3), nxt_p)
                     new_p, p16n = (r[0], r[1].view(B * K, L)) if nxt_p else (r, None)

@@ -7,7 +7,7 @@ every rank runs fwd+bwd on its own shard and the gradients - which already live 
 `model.flat_grads` - are summed in four readiness-ordered collectives (GradBucketReducer):
 
   * logit.* (final before the BPTT loop starts) overlaps the whole recurrent backward;
-  * the recurrent slice (LSTMs, h2att, alpha_net, word embedding: ~68 % of the bytes) is sent when the loop's
+  * the recurrent slice (LSTMs, h2att, alpha_net, word embedding: 54 % of the bytes) is sent when the loop's
     batched weight-gradient products are enqueued and overlaps the prepare-feature and encoder backward;
   * the prepare-feature slice follows, then the encoder slice when backward returns.
 
@@ -111,9 +111,9 @@ class GradBucketReducer:
     is summed over the ranks the moment the backward has finished writing it, while the rest of the backward still runs --
 
         logit      (38 MB at Sub_GC_Kar)  final right after the criterion backward, BEFORE the BPTT loop: overlaps the whole loop
-        recurrent  (~190 MB: both LSTMs, h2att, alpha_net, the word embedding)  final after the loop's batched weight-gradient products
-        prepare    (~33 MB: fc_embed, att_embed, ctx2att)  final after the prepare-feature backward
-        encoder    (~17 MB)  final when backward returns (`finish`)
+        recurrent  (152 MB: both LSTMs, h2att, alpha_net, the word embedding)  final after the loop's batched weight-gradient products
+        prepare    (31 MB: fc_embed, att_embed, ctx2att)  final after the prepare-feature backward
+        encoder    (59 MB: fusion projections, GCN units, sGPN)  final when backward returns (`finish`)
 
     The decoder Functions announce a slice through functions.on_grads_ready(stage) (they write their gradients straight into the
     bucket, so no autograd hook fires for them); the post-accumulate-grad hooks cover the generic autograd path.  Each collective is

@@ -166,6 +166,6 @@ def test_rccl_world_size_one_pushes_the_real_280mb_bucket():
     assert at("issue", "recurrent") == at("ready", "recurrent") + 1 and at("issue", "prepare") == at("ready", "prepare") + 1
     assert [st for st, _ in issued] == ["logit", "recurrent", "prepare", "encoder"]
     sizes = dict(issued)
-    assert sum(sizes.values()) == nbytes and sizes["logit"] > 37e6 and sizes["recurrent"] > 180e6      # every byte of the bucket travels exactly once
+    assert sum(sizes.values()) == nbytes and sizes["logit"] > 37e6 and sizes["recurrent"] > 150e6      # every byte of the bucket travels exactly once
     assert err <= 1e-4 * scale + 1e-12, (err, scale)        # two runs of the backward differ by fp32 atomic order only
     assert 0 < moved < 1e-2
