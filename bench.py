@@ -49,6 +49,12 @@ CONFIGS = {
                 kernel="gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", metric="images/sec (training fwd+bwd), Sub_GC_Kar",
                 workload="Sub_GC_Kar train fwd+bwd (BASELINE.json configs[1]): 128 images/GPU, 36+1 nodes, 64+1 relations, "
                          "2048-d region feats, 5 sentences/image, 2 pos + 2 neg sub-graphs/sentence, T=17, V+1=9488, dropout on"),
+    # the workload the reference trains for 30 of its 35 epochs (train.sh:10,21,31: --scheduled_sampling_start 0; train.py:126-132 raises
+    # ss_prob by 0.05 every 5 epochs up to 0.25; AttModel.py:158-167): the headline step with a quarter of the input words sampled
+    "kar_ss25": dict(opt=dict(KAR, sampling_prob=0.25), batch=128, data={}, dtype="f32", peak=MFMA_F32_PEAK_TFLOPS, gflop_img=MODEL_GFLOP_PER_IMAGE,
+                     kernel="gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", metric="images/sec (training fwd+bwd), Sub_GC_Kar, scheduled sampling 0.25",
+                     workload="Sub_GC_Kar train fwd+bwd as the headline, with scheduled sampling at its final probability ss_prob = 0.25 "
+                              "(train.sh:10, train.py:126-132, AttModel.py:158-167): per-step logits, multinomial draws, per-step embedding and x->gates"),
     "full_gc_kar": dict(opt=FULLGC, batch=256, data={}, dtype="bf16", peak=MFMA_BF16_PEAK_TFLOPS, gflop_img=3 * 9.01,
                         kernel="gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, bf16-stored operands)",
                         metric="images/sec (training fwd+bwd), Full_GC_Kar bf16",
@@ -448,7 +454,8 @@ def main():
     torch.manual_seed(1234)                     # identical replicas on every rank
     opt = argparse.Namespace(**cfg["opt"])
     model = models.setup(opt).to(dev).train()
-    model.ss_prob = a.ss_prob
+    if a.ss_prob > 0:
+        model.ss_prob = a.ss_prob
     lw = models.LossWrapper(model, None)
     batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=1000 + rank, **cfg["data"]).items()}
     red = parallel.GradBucketReducer(model)
@@ -636,6 +643,8 @@ def main():
             oc = {}
             for name in ("full_gc_kar", "flickr"):
                 oc[name + "_bf16"] = train_config_leg(name, dev, steps=8, warmup=3)
+            oc["kar_ss25"] = train_config_leg("kar_ss25", dev, steps=8, warmup=3)
+            oc["kar_ss25"]["vs_headline_step"] = round(oc["kar_ss25"]["ms_per_step"] / res["ms_per_step"], 4)
             if not a.no_decode:
                 oc["mrnn_decode_topk"] = mrnn_decode_leg(dev, images=6, M=500)[0]
             res["other_configs"] = oc

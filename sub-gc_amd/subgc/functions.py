@@ -775,7 +775,7 @@ def make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale
 def _cat_weights(w_ih_part, w_hh):
     """[W_ih(:, cols) | W_hh] as one K-contiguous operand so a recurrent step is ONE GEMM (fp32 or bf16 like its parts)."""
     R4, a = w_ih_part.shape
-    out = torch.empty(R4, a + w_hh.size(1), device=w_hh.device, dtype=w_hh.dtype)
+    out = ops.act_padded((R4, a + w_hh.size(1)), w_hh.device, ops.is_b16(w_hh))      # row pitch a multiple of 128 bytes (ops.PITCH)
     ops.copy2d(w_ih_part, out[:, :a])
     ops.copy2d(w_hh, out[:, a:])
     return out
@@ -817,11 +817,11 @@ class DecoderFn(Function):
         Wc1 = _cat_weights(W[9][:, :R], W[10])        # [4R, 2R]  x [h2_prev | h1_prev]
         Wc2 = _cat_weights(W[13], W[14])              # [4R, 3R]  x [ctx | h1 | h2_prev]
 
-        H1 = act(T + 1, S, 2 * R, zero=True)
-        H2 = act(T + 1, S, 3 * R, zero=True)
+        H1 = ops.act_padded((T + 1, S, 2 * R), dev, bf, zero_rows=(T + 1) * S)      # 128-byte row pitch: they are the recurrent GEMMs' operands
+        H2 = ops.act_padded((T + 1, S, 3 * R), dev, bf, zero_rows=(T + 1) * S)
         C1 = ops.zeros(T + 1, S, R, device=dev)
         C2 = ops.zeros(T + 1, S, R, device=dev)
-        Hout = act(S, T, R)
+        Hout = ops.act_padded((S, T, R), dev, bf)
         G1 = torch.empty(T, S, 4 * R, device=dev, dtype=torch.float32)
         G2 = torch.empty(T, S, 4 * R, device=dev, dtype=torch.float32)
         AH = torch.empty(T, S, A, device=dev, dtype=torch.float32)
@@ -845,7 +845,7 @@ class DecoderFn(Function):
             ops.lstm_fwd_gemm(H2[t], Wc2, pre, None, None, b2i, b2h, C2[t], C2[t + 1], H1[t + 1][:, :R], H2[t + 1][:, 2 * R:],
                               None if k_out is None else k_out[t], scale, Hout[:, t, :], G2[t], S, R)
         if ss is None:
-            ops.gemm(Hout.view(S * T, R), W[21], logits, tb=True, bias=lg_b)
+            ops.gemm(ops.flat_rows(Hout), W[21], logits, tb=True, bias=lg_b)
         else:
             ops.gemm(Hout[:, T - 1, :], W[21], logits3[:, T - 1, :], tb=True, bias=lg_b)
         active = ops.step_active(labels, T)
@@ -925,7 +925,7 @@ class DecoderFn(Function):
             dlogits = opnd(dlogits)
         else:
             return (None,) * (7 + len(P))
-        Hout2 = Hout.view(S * T, R)
+        Hout2 = ops.flat_rows(Hout)
         wgrad(21, dlogits, Hout2)
         bgrad(22, dlogits)
         grads_ready("logit")                             # logit.* is final: its all-reduce overlaps the whole BPTT loop
@@ -968,7 +968,7 @@ class DecoderFn(Function):
             pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), torch.arange(T + 1, device=dev, dtype=torch.int32) * S, T, lens, dv, S, R)
             del dCtx
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
-        H1a, H2a = H1[:T].view(T * S, 2 * R), H2[:T].view(T * S, 3 * R)
+        H1a, H2a = ops.flat_rows(H1[:T]), ops.flat_rows(H2[:T])
         wgrad(13, P2, H2a[:, :2 * R])
         wgrad(14, P2, H2a[:, 2 * R:])
         bgrad(15, P2, also=16)

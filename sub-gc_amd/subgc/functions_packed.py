@@ -114,16 +114,15 @@ class PackedDecoderLossFn(Function):
         Wc1 = F_._cat_weights(W[9][:, :R], W[10])
         Wc2 = F_._cat_weights(W[13], W[14])
 
-        H1 = act(rows + S, 2 * R)                              # packed [h2_{t-1} | h1_{t-1}], + S rows of slack after the last step
-        H2 = act(rows + S, 3 * R)                              # packed [ctx_t | h1_t | h2_{t-1}]
-        C1, C2 = new(T + 1, S, R), new(T + 1, S, R)
         # only the state entering step 0 is zero; every other row is written by the step before it is read (checked by the
         # SUBGC_POISON_EMPTY run of the GPU suite), so ~250 MB of fills per forward shrink to ~20 MB
         m0 = M[0] if T_live > 0 else 0
-        for buf in (H1[:m0], H2[:m0], C1[0], C2[0]):
-            if buf.numel():
-                ops.fill_(buf.view(torch.float32) if ops.is_b16(buf) else buf, 0.0)      # bf16 zero = all-zero bits (even element counts)
-        Hout, G1, G2 = act(max(rows, 1), R), new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R)
+        H1 = ops.act_padded((rows + S, 2 * R), dev, bf, zero_rows=m0)   # packed [h2_{t-1} | h1_{t-1}], + S rows of slack after the last step
+        H2 = ops.act_padded((rows + S, 3 * R), dev, bf, zero_rows=m0)   # packed [ctx_t | h1_t | h2_{t-1}]; both with a 128-byte row pitch (ops.PITCH)
+        C1, C2 = new(T + 1, S, R), new(T + 1, S, R)
+        for buf in (C1[0], C2[0]):
+            ops.fill_(buf, 0.0)
+        Hout, G1, G2 = ops.act_padded((max(rows, 1), R), dev, bf), new(max(rows, 1), 4 * R), new(max(rows, 1), 4 * R)
         AH, AL = new(max(rows, 1), A), new(max(rows, 1), N)
         pre = new(S, 4 * R)
         QP = new(8 * S * A)

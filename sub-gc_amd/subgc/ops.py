@@ -189,6 +189,40 @@ def act_buffer(shape, device, bf16, zero=False):
     return torch.empty(*shape, device=device, dtype=BF16)
 
 
+# Row pitch of the activation / weight-snapshot buffers the decoder allocates for its recurrent GEMMs, in elements (0 = unpadded).
+# bf16: a K-contiguous operand tile is 32 elements = 64 bytes per row; with R = 1000 the natural pitches (2000 / 4000 / 6000 bytes) put
+# half of those segments across two 128-byte lines, i.e. twice the L2 requests per LDS-DMA tile (tools/gemm_bf16_bench.py --pad 64:
+# 1280 x 4000 x 2000 52 -> 40 us).  Every kernel that writes these buffers takes a leading dimension, so the pad is free.
+PITCH = {"bf16": 64, "f32": 0}
+
+
+def pitch_of(cols, bf16):
+    q = PITCH["bf16" if bf16 else "f32"]
+    return (cols + q - 1) // q * q if q else cols
+
+
+def act_padded(shape, device, bf16, zero_rows=0):
+    """`act_buffer` with the last dimension's pitch rounded up to PITCH (a [..., cols] view of a [..., pitch] buffer); the first
+    `zero_rows` rows (of the flattened leading dimensions) are zeroed, pad columns included."""
+    *lead, cols = shape
+    ldp = pitch_of(cols, bf16)
+    if bf16 and cols % 8:
+        raise SubgcError(f"bf16 activation buffers need a last dimension that is a multiple of 8, got {tuple(shape)}")
+    base = torch.empty(*lead, ldp, device=device, dtype=BF16 if bf16 else torch.float32)
+    if zero_rows:
+        z = base.view(-1, ldp)[:zero_rows]
+        fill_(z.view(torch.float32) if bf16 else z, 0.0)
+    return base[..., :cols] if ldp != cols else base
+
+
+def flat_rows(t3):
+    """[T, S, C] (unit inner stride, stride(0) == S * stride(1)) -> the [T * S, C] view with the same row pitch."""
+    T, S, C = t3.shape
+    if t3.stride(2) != 1 or (T > 1 and t3.stride(0) != S * t3.stride(1)):
+        raise SubgcError(f"flat_rows: not a row-pitched [T, S, C] view: {tuple(t3.shape)} / {t3.stride()}")
+    return torch.as_strided(t3, (T * S, C), (t3.stride(1), 1), t3.storage_offset())
+
+
 def cast_bf16(x, out=None, m_dev=None):
     """bf16 copy of a 2-D fp32 view (subgc_cast_f32_bf16); the destination's columns are padded with zeros to a multiple of 8
     (a K-contiguous GEMM operand needs K % 8 == 0).  Returns the [rows, cols_pad] bf16 tensor."""
