@@ -645,6 +645,106 @@ int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, cons
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                          int step, float grad_scale, uint16_t* p_bf16, void* stream);
 
+/* ======================================================================================
+ * The teacher-forced recurrence as ONE call per direction (AttModel.py:157-175: the T-step loop around TopDownCore, :400-431).
+ * The per-step launch groups -- att-LSTM product + cell, h2att product (kept as planes), attention, lang-LSTM product + cell;
+ * backward: the two cell backwards, the attention backward and the three data-gradient products (kept as planes) -- are exactly
+ * the entry points above, issued from C with pointer arithmetic instead of from the host language once per step: ~10 library
+ * crossings per step x 17 steps become 2 per train step.  No kernel, no launch order and no argument differs from the
+ * step-by-step sequence (tests: packed == unpacked == goldens).
+ *
+ * Step t (0 <= t < T) owns m[t] rows (m non-increasing, m[T] = 0 or the rows the state after the last step is written to);
+ * in every step-packed array ([rows, .]: H1, H2, Gx, G1, G2, AH, AL, dP1, dP2, dAH, dWa, dBa, dCtx) its rows start at row0[t];
+ * Hout / dHout rows of step t start at element hout_off[t] / dhout_off[t] with row pitch ld_hout / ld_dhout (the unpacked
+ * decoder keeps them sentence-major [S, T, R]); C1, C2 are [T+1][S][R]; k_out (may be NULL) [T][S][R]; Gf, pre [S, 4R].
+ * H1 = [h2_{t-1} | h1_{t-1}] (ld ldH1), H2 = [ctx_t | h1_t | h2_{t-1}] (ld ldH2): bf16 when `bf16` (then Wc1, Wc2, Wq, Hout and
+ * dP1 / dP2 / dAH are bf16 too), else fp32.  Attention sets: per sentence (off, lens; shared = 0) or per image
+ * (rows_map, B, g, Nn; shared = 1: subgc_attn_*_group).  Host arrays (m, row0, hout_off, dhout_off) are read during the call only. */
+typedef struct SubgcRecurrence {
+    int32_t S;
+    int32_t T;
+    int32_t R;
+    int32_t A;
+    int32_t n_alpha;
+    int32_t bf16;
+    int32_t shared;
+    int32_t B;
+    int32_t g;
+    int32_t Nn;
+    int32_t gemm_flags;
+    int32_t uv_b16;
+    float keep_scale;
+    int32_t du_planes;
+    const int32_t* m;
+    const int64_t* row0;
+    const int64_t* hout_off;
+    const int64_t* dhout_off;
+    int64_t ld_hout;
+    int64_t ld_dhout;
+    void* H1;
+    int64_t ldH1;
+    void* H2;
+    int64_t ldH2;
+    void* Hout;
+    const void* Wc1;
+    int64_t ldW1;
+    const void* Wc2;
+    int64_t ldW2;
+    const void* Wq;
+    int64_t ldWq;
+    const float* b1i;
+    const float* b1h;
+    const float* b2i;
+    const float* b2h;
+    const float* bq;
+    float* pre;
+    const float* Gx;
+    const float* Gf;
+    float* C1;
+    float* C2;
+    float* G1;
+    float* G2;
+    float* AH;
+    float* AL;
+    const uint8_t* k_out;
+    float* QP;
+    size_t qp_bytes;
+    const void* u;
+    const void* v;
+    const float* w_a;
+    const float* b_a;
+    const int32_t* off;
+    const int32_t* lens;
+    const int32_t* rows_map;
+    const float* dHout;
+    void* dP1;
+    void* dP2;
+    void* dAH;
+    float* du;
+    int64_t du_plane_stride;
+    float* dv;
+    float* dWa;
+    float* dBa;
+    float* dCtx;
+    float* PA;
+    size_t pa_bytes;
+    float* PB;
+    size_t pb_bytes;
+    float* PC;
+    size_t pc_bytes;
+    float* dC1_in;
+    float* dC1_out;
+    float* dC2_in;
+    float* dC2_out;
+} SubgcRecurrence;
+int subgc_recurrence_sizeof(void);      /* sizeof(SubgcRecurrence): bindings that mirror the struct check their layout against it */
+/* forward: steps 0 .. T-1 in order.  workspace / ws_bytes: the split-K scratch of the cell products (as subgc_lstm_fwd_gemm). */
+int subgc_recurrence_fwd(const SubgcRecurrence* a, void* workspace, size_t ws_bytes, void* stream);
+/* backward: steps T-1 .. 0.  dC*_in: zeroed [S, R] (the cell-state gradient entering the last step), dC*_out: scratch [S, R]; the two
+ * swap roles every step.  dv != NULL: d(v) accumulates per step (dCtx unused); dv == NULL: this step's d(ctx) rows are kept in dCtx
+ * for one subgc_attn_dv_accum* after the loop (always so for shared sets). */
+int subgc_recurrence_bwd(const SubgcRecurrence* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

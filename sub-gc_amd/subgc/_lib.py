@@ -51,6 +51,28 @@ def parse_header(path=HEADER):
     return out
 
 
+def parse_struct(name, path=HEADER):
+    """ctypes.Structure mirror of `typedef struct <name> { ... } <name>;` in the header (one field per declaration; pointers of any
+    type become c_void_p): the header stays the single source of truth for the layout, like the prototypes."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    m = re.search(r"typedef\s+struct\s+" + name + r"\s*\{(.*?)\}\s*" + name + r"\s*;", src, flags=re.S)
+    if m is None:
+        raise SubgcError(f"{name} is not declared in subgc_hip.h")
+    fields = []
+    for decl in m.group(1).split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        if "*" in decl:
+            fields.append((decl.split("*")[-1].strip(), ctypes.c_void_p))
+        else:
+            ty, nm = decl.rsplit(" ", 1)
+            fields.append((nm, _SCALARS[ty.replace("const ", "").strip()]))
+    return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
 _lib = None
 _protos = None
 

@@ -681,6 +681,10 @@ class Prepared:
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum(alpha, dctx, step_off, T, self.off, lens, dv, S, R)
 
+    def recur_fields(self):
+        """The attention-set fields of ops.Recurrence (per-sentence sets)."""
+        return dict(shared=0, u=self.u, v=self.v, off=self.off, uv_b16=int(ops.is_b16(self.u)))
+
     def new_du(self, A):
         """Zeroed accumulator of d(u) for the backward's time loop."""
         return ops.zeros(self.u.size(0), A, device=self.u.device)
@@ -745,6 +749,9 @@ class PreparedShared(Prepared):
 
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum_group(alpha, dctx, step_off, T, self.rows, self.B, self.g, self.N, dv, R)
+
+    def recur_fields(self):
+        return dict(shared=1, u=self.u, v=self.v, rows_map=self.rows, B=self.B, g=self.g, Nn=self.N, uv_b16=int(ops.is_b16(self.u)))
 
     def new_du(self, A):
         """One zeroed d(u) plane per workgroup that serves an image (subgc_attn_group_du_planes)."""
@@ -831,7 +838,18 @@ class DecoderFn(Function):
         Gx3 = Gx.view(T, S, 4 * R)
         logits = torch.empty(S * T, V1, device=dev, dtype=torch.float32)
         logits3 = logits.view(S, T, V1)
-        for t in range(T):
+        rec = None
+        if ss is None and T > 0 and ops.recurrence_ok():
+            # the T steps as ONE library call (subgc_recurrence_fwd; see functions_packed.py): every step owns all S rows
+            ldh = Hout.stride(1)
+            rec = ops.Recurrence(S=S, T=T, R=R, A=A, n_alpha=N, bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current], keep_scale=float(scale),
+                                 m=[S] * (T + 1), row0=[t * S for t in range(T + 1)], hout_off=[t * ldh for t in range(T)], ld_hout=Hout.stride(0),
+                                 H1=H1, ldH1=H1.stride(1), H2=H2, ldH2=H2.stride(1), Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2),
+                                 Wq=W[17], ldWq=ops.ld(W[17]), b1i=b1i, b1h=b1h, b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre, Gx=Gx, Gf=Gf, C1=C1, C2=C2,
+                                 G1=G1, G2=G2, AH=AH, AL=AL, k_out=k_out, QP=QP, qp_bytes=QP.numel() * 4, w_a=an_w, b_a=an_b, lens=lens,
+                                 **pr.recur_fields())
+            ops.recurrence_fwd(rec, H1)
+        for t in range(T if rec is None else 0):
             if ss is not None:
                 if t >= 1:
                     ops.gemm(Hout[:, t - 1, :], W[21], logits3[:, t - 1, :], tb=True, bias=lg_b)    # raw logits of the previous step
@@ -949,7 +967,20 @@ class DecoderFn(Function):
         dC1 = [zer(S, R), new(S, R)]                  # [next, cur] ping-pong
         dC2 = [zer(S, R), new(S, R)]
         note("bptt_begin", T)
+        rec = None
+        if T > 0 and ops.recurrence_ok():
+            rec = ops.Recurrence(S=S, T=T, R=R, A=A, n_alpha=N, bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current], keep_scale=float(scale),
+                                 m=[S] * (T + 1), row0=[t * S for t in range(T + 1)], dhout_off=[t * R for t in range(T)], ld_dhout=T * R,
+                                 Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]), C1=C1, C2=C2, G1=G1, G2=G2,
+                                 AH=AH, AL=AL, k_out=k_out, w_a=an_w, lens=lens, dHout=dHout, dP1=dP1, dP2=dP2, dAH=dAH, du=du,
+                                 du_planes=du.size(0) if du.dim() == 3 else 1, du_plane_stride=du.stride(0) if du.dim() == 3 else 0,
+                                 dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, PA=PA, pa_bytes=PA.numel() * 4,
+                                 PB=PB, pb_bytes=PB.numel() * 4, PC=PC, pc_bytes=PC.numel() * 4, dC1_in=dC1[0], dC1_out=dC1[1], dC2_in=dC2[0],
+                                 dC2_out=dC2[1], **pr.recur_fields())
+            ops.recurrence_bwd(rec)
         for t in range(T - 1, -1, -1):
+            if rec is not None:
+                break
             nC1, cC1 = dC1; nC2, cC2 = dC2
             ops.lstm_bwd_planes(G2[t], C2[t], C2[t + 1], [win(sC, 0), win(sA, 2 * R)], dHout[:, t, :], None if k_out is None else k_out[t],
                                 scale, nC2, dP2[t], cC2, S, R)

@@ -127,7 +127,19 @@ class PackedDecoderLossFn(Function):
         pre = new(S, 4 * R)
         QP = new(8 * S * A)
         logits = new(max(rows, 1), V1)
-        for t in range(T_live):
+        # The T_live steps as ONE library call (subgc_recurrence_fwd: the same per-step entry points, issued from C with pointer
+        # arithmetic); the Python loop below remains for scheduled sampling (per-step logits / draws / embeddings) and for the bench's
+        # FLOP-accounting pass.
+        rec = None
+        if ss is None and T_live > 0 and ops.recurrence_ok():
+            rec = ops.Recurrence(S=S, T=T_live, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
+                                 keep_scale=float(scale), m=list(M[:T_live]) + [M[T_live] if T_live < T else 0], row0=ot[:T_live + 1],
+                                 hout_off=[o_ * ops.ld(Hout) for o_ in ot[:T_live]], ld_hout=ops.ld(Hout), H1=H1, ldH1=ops.ld(H1), H2=H2, ldH2=ops.ld(H2),
+                                 Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]), b1i=b1i, b1h=b1h,
+                                 b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre, Gx=Gx, Gf=Gf, C1=C1, C2=C2, G1=G1, G2=G2, AH=AH, AL=AL, k_out=k_out, QP=QP,
+                                 qp_bytes=QP.numel() * 4, w_a=an_w, b_a=an_b, lens=lens_p, **pr.recur_fields())
+            ops.recurrence_fwd(rec, H1)
+        for t in range(T_live if rec is None else 0):
             m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
             o1 = ot[t + 1]
             mn_ = max(mn, 1)                                    # row limit 0 means "all" in the C ABI: write 1 dummy row into the slack
@@ -229,7 +241,20 @@ class PackedDecoderLossFn(Function):
         arena = zer(4 * S * R)
         dC1, dC2 = [arena[:S * R].view(S, R), arena[S * R:2 * S * R].view(S, R)], [arena[2 * S * R:3 * S * R].view(S, R), arena[3 * S * R:].view(S, R)]
         F_.note("bptt_begin", T_live)
+        rec = None
+        if T_live > 0 and ops.recurrence_ok():
+            rec = ops.Recurrence(S=S, T=T_live, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
+                                 keep_scale=float(scale), m=list(M[:T_live]) + [0], row0=ot[:T_live + 1], dhout_off=[o_ * R for o_ in ot[:T_live]],
+                                 ld_dhout=R, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]), C1=C1, C2=C2, G1=G1, G2=G2,
+                                 AH=AH, AL=AL, k_out=k_out, w_a=an_w, lens=lens_p, dHout=dHout, dP1=dP1, dP2=dP2, dAH=dAH, du=du,
+                                 du_planes=du.size(0) if du.dim() == 3 else 1, du_plane_stride=du.stride(0) if du.dim() == 3 else 0,
+                                 dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, PA=PA, pa_bytes=PA.numel() * 4,
+                                 PB=PB, pb_bytes=PB.numel() * 4, PC=PC, pc_bytes=PC.numel() * 4, dC1_in=dC1[0], dC1_out=dC1[1], dC2_in=dC2[0],
+                                 dC2_out=dC2[1], **pr.recur_fields())
+            ops.recurrence_bwd(rec)
         for t in range(T_live - 1, -1, -1):
+            if rec is not None:
+                break
             m, o = M[t], ot[t]
             nC1, cC1 = dC1; nC2, cC2 = dC2
             ops.lstm_bwd_planes(G2[o:o + m], C2[t][:m], C2[t + 1][:m], [win(sC, 0), win(sA, 2 * R)], dHout[o:o + m],

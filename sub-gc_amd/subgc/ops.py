@@ -700,6 +700,62 @@ def gemm_planes(a, b, planes, *, ta=False, tb=False):
     return n.value, M * N
 
 
+RECURRENCE_IN_C = True        # the train decoder's T-step loops as one C call per direction (subgc_recurrence_fwd / _bwd); False = step by step from Python
+_RECUR_T = None
+
+
+class Recurrence:
+    """Argument block of subgc_recurrence_fwd / subgc_recurrence_bwd (include/subgc_hip.h: SubgcRecurrence, mirrored from the header).
+    Tensors go in as device pointers, python int lists (`m`, `row0`, `hout_off`, `dhout_off`) as host arrays owned by this object,
+    everything else by value; fields not given stay 0 / NULL."""
+
+    HOST = {"m": "c_int32", "row0": "c_int64", "hout_off": "c_int64", "dhout_off": "c_int64"}
+
+    def __init__(self, **fields):
+        import ctypes
+        global _RECUR_T
+        if _RECUR_T is None:
+            from ._lib import lib, parse_struct
+            _RECUR_T = parse_struct("SubgcRecurrence")
+            if ctypes.sizeof(_RECUR_T) != int(lib().subgc_recurrence_sizeof()):
+                raise SubgcError("SubgcRecurrence: the ctypes mirror and the library disagree about the struct layout")
+        self.st = _RECUR_T()
+        self._alive = []
+        self.set(**fields)
+
+    def set(self, **fields):
+        import ctypes
+        for k, v in fields.items():
+            if v is None:
+                setattr(self.st, k, 0)                                  # NULL pointer / zero
+            elif torch.is_tensor(v):
+                if not v.is_cuda:
+                    raise SubgcError(f"recurrence: {k} must be a device tensor")
+                setattr(self.st, k, v.data_ptr())
+            elif k in self.HOST:
+                arr = (getattr(ctypes, self.HOST[k]) * max(len(v), 1))(*[int(x) for x in v])
+                self._alive.append(arr)
+                setattr(self.st, k, ctypes.addressof(arr))
+            else:
+                setattr(self.st, k, v)
+        return self
+
+
+def recurrence_fwd(rec, like):
+    import ctypes
+    call("subgc_recurrence_fwd", ctypes.addressof(rec.st), *_ws(like), _stream())
+
+
+def recurrence_bwd(rec):
+    import ctypes
+    call("subgc_recurrence_bwd", ctypes.addressof(rec.st), _stream())
+
+
+def recurrence_ok():
+    """The C loops apply unless a measurement mode needs the per-call Python wrappers (FLOP accounting, GEMM dispatch switches)."""
+    return RECURRENCE_IN_C and not FLOPS["on"] and gemm_tune.f32_bits == 0
+
+
 def lstm_bwd_planes(gates, c_prev, c, srcs, dh_drop, keep, scale, dc, dpre, dc_prev, S, R):
     """lstm_bwd whose d(h) sources are column windows of split-K plane stacks: srcs = up to three (planes, N, col0, n, stride, rows)
     -- `planes` the flat buffer gemm_planes filled ([n][rows][N]), the window starts at column col0; n = 0 entries are skipped."""
