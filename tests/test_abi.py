@@ -50,6 +50,24 @@ def test_host_side_argument_validation_needs_no_gpu():
         _lib.call("subgc_decode_pick", None, 10, 1, 10, 9, 1.0, None, 0, None, None, 4, None, None, None, None, 0, None)
 
 
+def test_recurrence_struct_mirror_matches_the_library():
+    """SubgcRecurrence is mirrored from the header into a ctypes.Structure (one field per declaration): same size as the compiled
+    struct, and the entry points validate the block on the host."""
+    import ctypes
+    L = _lib.lib()
+    S = _lib.parse_struct("SubgcRecurrence")
+    assert ctypes.sizeof(S) == L.subgc_recurrence_sizeof() and len(S._fields_) > 60
+    assert L.subgc_recurrence_fwd(None, None, 0, None) == -1 and b"null argument block" in L.subgc_last_error()
+    blk = S()
+    blk.S, blk.T, blk.R, blk.A, blk.n_alpha = 4, 2, 8, 4, 3
+    assert L.subgc_recurrence_bwd(ctypes.addressof(blk), None) == -1 and b"null step tables" in L.subgc_last_error()
+    m = (ctypes.c_int32 * 3)(4, 5, 0)                                        # rows must not grow from step to step
+    r0 = (ctypes.c_int64 * 3)(0, 4, 9)
+    off = (ctypes.c_int32 * 1)(0)
+    blk.m, blk.row0, blk.off = ctypes.addressof(m), ctypes.addressof(r0), ctypes.addressof(off)
+    assert L.subgc_recurrence_fwd(ctypes.addressof(blk), None, 0, None) == -1 and b"non-increasing" in L.subgc_last_error()
+
+
 def test_product_path_refuses_cpu_tensors():
     with pytest.raises(_lib.SubgcError):
         ops.row_argmax(torch.zeros(2, 4))

@@ -60,3 +60,48 @@ def test_live_plan_counts_and_early_break():
     assert M == [5, 5, 4, 3, 2, 2, 0]
     assert float(den) == float(mask[:, 1:].sum())
     assert sorted(perm.tolist()[:2]) == [2, 4]
+
+
+@pytest.mark.parametrize("kind", ["subgc_f32", "subgc_bf16", "fullgc_bf16_shared", "fullgc_f32_dropout"])
+@pytest.mark.parametrize("packed", [True, False])
+def test_recurrence_issued_from_c_is_the_step_by_step_loop(kind, packed):
+    """subgc_recurrence_fwd / subgc_recurrence_bwd (one library crossing per direction) against the same T steps issued one entry
+    point at a time from Python (ops.RECURRENCE_IN_C = False): same kernels, same launch order, same arguments -- the loss and every
+    gradient of the flat bucket are BIT-identical wherever the kernels are (the split-K planes are summed in a fixed order; the only
+    atomics of the step, embed_bwd / pool_bwd / scatter_add, sit outside the loop and give the usual last-bit noise)."""
+    from subgc import ops
+    torch.manual_seed(0)
+    opt = dict(OPT)
+    if kind.startswith("fullgc"):
+        opt.update(use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1)
+    if "bf16" in kind:
+        opt.update(compute_dtype="bf16")
+    if "dropout" in kind:
+        opt.update(drop_prob_lm=0.5)
+    m = models.setup(argparse.Namespace(**opt)).to(DEV).train()
+    batch = synthetic.make_train_batch(6, D=256, vocab=300, n_obj_cls=60, seed=9, fc_size=256, min_len=2, max_len=16)
+    res = {}
+    for in_c in (False, True):
+        ops.RECURRENCE_IN_C = in_c
+        try:
+            m._dropout_calls = 0                                   # the same Philox stream for both runs
+            m.packed_decoder = packed
+            lw = models.LossWrapper(m, None)
+            b = {k: v.to(DEV) for k, v in batch.items()}
+            m.flatten_grads()
+            out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
+                     None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+            models.total_loss(out).backward()
+            torch.cuda.synchronize()
+            res[in_c] = (float(out["lang_loss"]), m.flat_grads.clone())
+        finally:
+            ops.RECURRENCE_IN_C = True
+    (l0, g0), (l1, g1) = res[False], res[True]
+    assert l0 == l1
+    lo, hi = next((lo, hi) for st, lo, hi in m.grad_buckets() if st == "recurrent")
+    emb_o, emb_n, _ = m._slots["embed.0.weight"]
+    same = torch.ones_like(g0, dtype=torch.bool)
+    same[emb_o:emb_o + emb_n] = False                              # embed_bwd accumulates with fp32 atomics
+    assert torch.equal(g0[lo:hi][same[lo:hi]], g1[lo:hi][same[lo:hi]]), "the recurrent slice must be bit-identical"
+    scale = float(g0.abs().max())
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=1e-6 * scale + 1e-9, rtol=1e-5)
