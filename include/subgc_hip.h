@@ -441,6 +441,26 @@ int subgc_packed_rows(const int64_t* labels, int64_t ld_labels, const int64_t* t
                       const int32_t* img, int N, int32_t* lens_p, int64_t* idx_p, int32_t* img_p, void* stream);
 int subgc_gpn_prep(const int64_t* gpn_obj_ind, const float* gpn_pool_mtx, const float* att_masks, int b5, int hb, int N,
                    int sentences_per_image, int64_t* idx, float* w, float* denom, int32_t* img, void* stream);
+/* The survivors of subgc_subgraph_nms_batched in image order (total = sum of n_keep, known to the caller from its one host read):
+ * keep[pos] = the kept candidate's index inside its image, glob[pos] = its row in the concatenated candidate arrays.                  */
+int subgc_nms_compact(const int64_t* keep_all, const int32_t* n_keep, const int32_t* offsets, int images, int total, int64_t* keep,
+                      int64_t* glob, void* stream);
+/* out[b][0 .. words) = the first `words` 4-byte words of the tensor at device address ptrs[b] (ptrs: device int64 [count]): block 0
+ * (counterpart 0) of every image's loader tensor stacked into one batch array -- the batched decode's input assembly
+ * (dataloader_test.py hands one image per item, eval_utils.py:98-104 loops over them).                                                */
+int subgc_gather_blocks(const int64_t* ptrs, int count, int64_t words, float* out, void* stream);
+/* Per-image early break of a BATCHED decode (the reference decodes one image per call and stops when none of ITS rows is unfinished,
+ * AttModel.py:318-319): image b = rows bounds[b] .. bounds[b+1] of seq [n, T] (int64) / seqlp [n, T]; log-probs after the image's break
+ * step are zeroed in place; out[2b] = break step (T-1 when the image never stopped), out[2b+1] = 1 when some step had no unfinished row. */
+int subgc_decode_batch_finish(const int64_t* seq, float* seqlp, const int32_t* bounds, int images, int T, int32_t* out, void* stream);
+/* The sGPN TEST branch's input views (gpn.py:84-96 reads counterpart 0 of the loader's five identical copies) for MANY images in one
+ * launch.  table (device, int64): [images + 1] candidate offsets (image b owns candidates offsets[b] .. offsets[b+1]), then 4 words per
+ * image: the device addresses of its gpn_obj_ind [5, 2, M_b, N] (int64), gpn_pool_mtx [5, 2, M_b, N, N] and att_masks [5, 2, M_b, N]
+ * tensors (contiguous) and its row in the node-state array.  -> idx [total, N] node lists, w [total, N] pooling weights (the diagonal of
+ * gpn_pool_mtx), denom [total] / lens [total] node counts (float / int32), img [total] owning row, offsets32 [images + 1] (optional:
+ * the offsets as int32, what subgc_subgraph_nms_batched takes).                                                                        */
+int subgc_gpn_test_prep(const int64_t* table, int images, int total, int N, int64_t* idx, float* w, float* denom, int32_t* lens,
+                        int32_t* img, int32_t* offsets32, void* stream);
 int subgc_gpn_select(const float* score, const int64_t* gpn_obj_ind, const float* att_masks, const float* read_out, int b5, int hb,
                      int N, int read_out_cols, int64_t* sel_idx, int32_t* lens, float* ro_sel, int32_t* sel,
                      int sentences_per_image, int32_t* img_s, void* stream);
@@ -625,6 +645,12 @@ int subgc_gather_rows_multi(int count, const float* s0, int64_t lds0, float* d0,
                             int64_t lds1, float* d1, int64_t ldd1, int c1, const float* s2, int64_t lds2, float* d2,
                             int64_t ldd2, int c2, const float* s3, int64_t lds3, float* d3, int64_t ldd3, int c3,
                             const int32_t* rows, int M, void* stream);
+/* ... and with int64 row ids (torch's index dtype; the NMS survivor list): columns are 4-byte words, so int64 / int32 tensors pass as
+ * their float32 views -- the decode-time selection of the kept sub-graphs' read-out rows, node lists, node counts and scores          */
+int subgc_gather_rows_multi_i64(int count, const float* s0, int64_t lds0, float* d0, int64_t ldd0, int c0, const float* s1,
+                                int64_t lds1, float* d1, int64_t ldd1, int c1, const float* s2, int64_t lds2, float* d2,
+                                int64_t ldd2, int c2, const float* s3, int64_t lds3, float* d3, int64_t ldd3, int c3,
+                                const int64_t* rows, int M, void* stream);
 int subgc_fill_f32(float* x, int64_t n, float value, void* stream);
 /* y[rows, cols] (ldy) += / = x[rows, cols] (ldx) */
 int subgc_copy2d_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, int accumulate,

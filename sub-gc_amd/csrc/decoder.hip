@@ -568,10 +568,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 // the same row gather for up to four tensors in ONE launch (blockIdx.y picks the tensor): the beam-search state fork
 struct GatherSet { const float* src[4]; float* dst[4]; int64_t lds[4], ldd[4]; int cols[4]; };
-__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet g, const int32_t* __restrict__ rows, int M) {
+template <typename IndexT>
+__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet g, const IndexT* __restrict__ rows, int M) {
     const int m = blockIdx.x, k = blockIdx.y;
     if (m >= M) return;
-    const int r = rows[m];
+    const int64_t r = (int64_t)rows[m];
     const float* __restrict__ src = g.src[k] + (int64_t)(r >= 0 ? r : 0) * g.lds[k];
     float* __restrict__ dst = g.dst[k] + (int64_t)m * g.ldd[k];
     for (int c = threadIdx.x; c < g.cols[k]; c += blockDim.x) dst[c] = r >= 0 ? src[c] : 0.f;
@@ -1017,8 +1018,22 @@ SUBGC_API int subgc_gather_rows_multi(int count, const float* s0, int64_t lds0, 
     for (int k = 0; k < count; ++k)
         SUBGC_REQUIRE(g.src[k] && g.dst[k] && g.cols[k] > 0 && g.lds[k] >= g.cols[k] && g.ldd[k] >= g.cols[k], "gather_rows_multi: bad tensor %d", k);
     SUBGC_REQUIRE(rows, "gather_rows_multi: null rows");
-    hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(M, count), dim3(256), 0, (hipStream_t)stream, g, rows, M);
+    hipLaunchKernelGGL(gather_rows_multi_kernel<int32_t>, dim3(M, count), dim3(256), 0, (hipStream_t)stream, g, rows, M);
     return subgc::check_launch("subgc_gather_rows_multi");
+}
+// the same gather with int64 row ids (the NMS survivor list, torch's index dtype): decode-time selection of the kept sub-graphs' read-out
+// rows / node lists / node counts / scores in one launch.  Columns are 4-byte words: int64 / int32 tensors pass as their float32 views.
+SUBGC_API int subgc_gather_rows_multi_i64(int count, const float* s0, int64_t lds0, float* d0, int64_t ldd0, int c0, const float* s1, int64_t lds1,
+                                          float* d1, int64_t ldd1, int c1, const float* s2, int64_t lds2, float* d2, int64_t ldd2, int c2,
+                                          const float* s3, int64_t lds3, float* d3, int64_t ldd3, int c3, const int64_t* rows, int M, void* stream) {
+    SUBGC_REQUIRE(count >= 1 && count <= 4 && M >= 0, "gather_rows_multi_i64: 1..4 tensors");
+    if (M == 0) return SUBGC_OK;
+    GatherSet g{{s0, s1, s2, s3}, {d0, d1, d2, d3}, {lds0, lds1, lds2, lds3}, {ldd0, ldd1, ldd2, ldd3}, {c0, c1, c2, c3}};
+    for (int k = 0; k < count; ++k)
+        SUBGC_REQUIRE(g.src[k] && g.dst[k] && g.cols[k] > 0 && g.lds[k] >= g.cols[k] && g.ldd[k] >= g.cols[k], "gather_rows_multi_i64: bad tensor %d", k);
+    SUBGC_REQUIRE(rows, "gather_rows_multi_i64: null rows");
+    hipLaunchKernelGGL(gather_rows_multi_kernel<int64_t>, dim3(M, count), dim3(256), 0, (hipStream_t)stream, g, rows, M);
+    return subgc::check_launch("subgc_gather_rows_multi_i64");
 }
 SUBGC_API int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* stream) {
     SUBGC_REQUIRE(n >= 0, "sumsq: bad size");

@@ -141,6 +141,36 @@ __global__ __launch_bounds__(64) void gpn_prep_kernel(const int64_t* __restrict_
     if (threadIdx.x == 0) { denom[g] = cnt; img[g] = s / spi; }
 }
 
+// Decode-time candidate views of MANY images in one launch (gpn.py:84-96: the test branch reads counterpart 0 of the loader's 5 identical
+// copies): candidate q of image b = slot q of its [2, M_b, N(, N)] counterpart-0 block (positive slots, then negative ones).
+__global__ __launch_bounds__(64) void gpn_test_prep_kernel(const int64_t* __restrict__ table, int images, int N, int64_t* __restrict__ idx,
+                                                           float* __restrict__ w, float* __restrict__ denom, int32_t* __restrict__ lens,
+                                                           int32_t* __restrict__ img, int32_t* __restrict__ offsets32) {
+    const int64_t* __restrict__ offs = table;                              // [images + 1] candidate offsets, then 4 words per image
+    const int g = blockIdx.x;
+    if (g <= images && threadIdx.x == 0 && offsets32) offsets32[g] = (int32_t)offs[g];
+    const int total = (int)offs[images];
+    if (g >= total) return;
+    int lo = 0, hi = images - 1;                                           // the image that owns candidate g (uniform over the workgroup)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (offs[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = table + (images + 1) + 4 * (int64_t)lo;
+    const int64_t* __restrict__ obj = reinterpret_cast<const int64_t*>(e[0]);
+    const float* __restrict__ pool = reinterpret_cast<const float*>(e[1]);
+    const float* __restrict__ msk = reinterpret_cast<const float*>(e[2]);
+    const int64_t q = g - offs[lo];
+    float cnt = 0.f;
+    for (int i = threadIdx.x; i < N; i += 64) {
+        idx[(int64_t)g * N + i] = obj[q * N + i];
+        w[(int64_t)g * N + i] = pool[(q * N + i) * N + i];
+        cnt += msk[q * N + i];
+    }
+    cnt = wave_sum(cnt);
+    if (threadIdx.x == 0) { denom[g] = cnt; lens[g] = (int32_t)cnt; img[g] = (int32_t)e[3]; }
+}
+
 __global__ __launch_bounds__(256) void gpn_select_kernel(const float* __restrict__ score, const int64_t* __restrict__ obj_ind,
                                                          const float* __restrict__ att_masks, const float* __restrict__ read_out, int b5,
                                                          int hb, int N, int W, int64_t* __restrict__ sel_idx, int32_t* __restrict__ lens,
@@ -275,6 +305,73 @@ SUBGC_API int subgc_gpn_prep(const int64_t* gpn_obj_ind, const float* gpn_pool_m
     hipLaunchKernelGGL(gpn_prep_kernel, dim3(2 * b5 * hb), dim3(64), 0, (hipStream_t)stream, gpn_obj_ind, gpn_pool_mtx, att_masks, b5, hb, N,
                        sentences_per_image, idx, w, denom, img);
     return subgc::check_launch("subgc_gpn_prep");
+}
+
+namespace {
+// Per-image early break of a BATCHED greedy / top-k decode (AttModel.py:318-319 breaks when no row of the ONE image of a call is
+// unfinished): image b = rows bounds[b] .. bounds[b+1]; a row is unfinished after step t while all its tokens up to t are > 0; the image
+// stops at the first step after which none of its rows is (brk, else T - 1); log-probs beyond that step are what the reference never
+// wrote: zeroed.  out[b] = (brk, any step stopped).
+__global__ __launch_bounds__(256) void decode_batch_finish_kernel(const int64_t* __restrict__ seq, float* __restrict__ seqlp, const int32_t* __restrict__ bounds,
+                                                                  int T, int32_t* __restrict__ out) {
+    __shared__ int alive_s[64];
+    __shared__ int brk_s, any_s;
+    const int b = blockIdx.x, r0 = bounds[b], r1 = bounds[b + 1];
+    for (int t = threadIdx.x; t < T; t += blockDim.x) alive_s[t] = 0;
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x)
+        for (int t = 0; t < T && seq[(int64_t)r * T + t] > 0; ++t) atomicOr(&alive_s[t], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int brk = T - 1, any = 0;
+        for (int t = 0; t < T; ++t)
+            if (!alive_s[t]) { brk = t; any = 1; break; }
+        brk_s = brk; any_s = any;
+        out[2 * b] = brk; out[2 * b + 1] = any;
+    }
+    __syncthreads();
+    const int brk = brk_s;
+    for (int i = threadIdx.x; i < (r1 - r0) * T; i += blockDim.x) {
+        const int t = i % T;
+        if (t > brk) seqlp[(int64_t)r0 * T + i] = 0.f;
+    }
+}
+}  // namespace
+
+namespace {
+// out[b][0 .. words) = the first `words` 4-byte words of the tensor at address ptrs[b]: block 0 (counterpart 0) of every image's loader
+// tensor, stacked into one batch array without a host-side concatenation
+__global__ __launch_bounds__(256) void gather_blocks_kernel(const int64_t* __restrict__ ptrs, int64_t words, float* __restrict__ out) {
+    const float* __restrict__ src = reinterpret_cast<const float*>(ptrs[blockIdx.y]);
+    float* __restrict__ dst = out + (int64_t)blockIdx.y * words;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+SUBGC_API int subgc_gather_blocks(const int64_t* ptrs, int count, int64_t words, float* out, void* stream) {
+    SUBGC_REQUIRE(count >= 0 && count <= 65535 && words >= 0, "gather_blocks: bad sizes");
+    if (count == 0 || words == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(ptrs && out, "gather_blocks: null pointer");
+    const unsigned gx = (unsigned)std::min<int64_t>((words + 255) / 256, 64);
+    hipLaunchKernelGGL(gather_blocks_kernel, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, ptrs, words, out);
+    return subgc::check_launch("subgc_gather_blocks");
+}
+
+SUBGC_API int subgc_decode_batch_finish(const int64_t* seq, float* seqlp, const int32_t* bounds, int images, int T, int32_t* out, void* stream) {
+    SUBGC_REQUIRE(images >= 0 && T > 0 && T <= 64, "decode_batch_finish: at most 64 steps");
+    if (images == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(seq && seqlp && bounds && out, "decode_batch_finish: null pointer");
+    hipLaunchKernelGGL(decode_batch_finish_kernel, dim3(images), dim3(256), 0, (hipStream_t)stream, seq, seqlp, bounds, T, out);
+    return subgc::check_launch("subgc_decode_batch_finish");
+}
+
+SUBGC_API int subgc_gpn_test_prep(const int64_t* table, int images, int total, int N, int64_t* idx, float* w, float* denom, int32_t* lens,
+                                  int32_t* img, int32_t* offsets32, void* stream) {
+    SUBGC_REQUIRE(images > 0 && total >= 0 && N > 0, "gpn_test_prep: bad sizes");
+    SUBGC_REQUIRE(table && (total == 0 || (idx && w && denom && lens && img)), "gpn_test_prep: null pointer");
+    hipLaunchKernelGGL(gpn_test_prep_kernel, dim3(std::max(total, images + 1)), dim3(64), 0, (hipStream_t)stream, table, images, N, idx, w, denom,
+                       lens, img, offsets32);
+    return subgc::check_launch("subgc_gpn_test_prep");
 }
 
 SUBGC_API int subgc_gpn_select(const float* score, const int64_t* gpn_obj_ind, const float* att_masks, const float* read_out, int b5, int hb,

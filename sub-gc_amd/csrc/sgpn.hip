@@ -281,6 +281,38 @@ SUBGC_API int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t
     return subgc::check_launch("subgc_subgraph_nms");
 }
 
+namespace {
+// survivors of the batched NMS in image order: pos = (kept of the images before b) + j  ->  keep[pos] = keep_all[offsets[b] + j] (index inside
+// the image), glob[pos] = offsets[b] + keep[pos] (row of the concatenated candidate arrays).  One workgroup; image counts are small.
+__global__ __launch_bounds__(256) void nms_compact_kernel(const int64_t* __restrict__ keep_all, const int32_t* __restrict__ n_keep,
+                                                          const int32_t* __restrict__ offsets, int images, int total, int64_t* __restrict__ keep,
+                                                          int64_t* __restrict__ glob) {
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int b = 0; b < images; ++b) {
+        const int base = base_s, nk = n_keep[b], g0 = offsets[b];
+        for (int j = threadIdx.x; j < nk && base + j < total; j += blockDim.x) {
+            const int64_t k = keep_all[g0 + j];
+            keep[base + j] = k;
+            glob[base + j] = k + g0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = base + nk;
+        __syncthreads();
+    }
+}
+}  // namespace
+
+SUBGC_API int subgc_nms_compact(const int64_t* keep_all, const int32_t* n_keep, const int32_t* offsets, int images, int total, int64_t* keep,
+                                int64_t* glob, void* stream) {
+    SUBGC_REQUIRE(images >= 0 && total >= 0, "nms_compact: bad sizes");
+    if (images == 0 || total == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(keep_all && n_keep && offsets && keep && glob, "nms_compact: null pointer");
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, keep_all, n_keep, offsets, images, total, keep, glob);
+    return subgc::check_launch("subgc_nms_compact");
+}
+
 SUBGC_API int subgc_subgraph_nms_batched(const float* score, const int64_t* idx, int64_t idx_stride, const int32_t* len,
                                          const int32_t* offsets, int images, int total, int max_m, int N, double thres, int max_keep,
                                          int64_t* keep, int32_t* n_keep, void* scratch, size_t scratch_bytes, void* stream) {

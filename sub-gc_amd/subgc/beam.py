@@ -99,9 +99,7 @@ class _BatchEngine:
 
     def refresh(self):
         """Re-derive the per-beam rows from `pr` and restart the recurrent state (hipGraph replay: `pr` was overwritten in place)."""
-        torch.index_select(self.pr.f, 0, self.rep, out=self.prb.f)
-        torch.index_select(self.pr.off, 0, self.rep, out=self.prb.off)
-        torch.index_select(self.pr.lens, 0, self.rep, out=self.prb.lens)
+        ops.take_rows([(self.pr.f, self.prb.f), (self.pr.off, self.prb.off), (self.pr.lens, self.prb.lens)], self.rep)      # one launch
         self.st.reset()
 
     def _topk(self, logits, kk):
@@ -178,7 +176,7 @@ class DeviceTables:
     """The tables of CaptionModel.py:106-109 for n sub-graphs x G groups, resident on the device."""
 
     def __init__(self, n, G, T, bd, dev):
-        z = lambda *s, dt: torch.zeros(*s, device=dev, dtype=dt)
+        z = lambda *s, dt: ops.zero_(torch.empty(*s, device=dev, dtype=dt))
         self.cap = bd * T                                                         # a group finishes at most bd beams per step
         self.seq, self.lps, self.sums = z(n, G, T, bd, dt=torch.int32), z(n, G, T, bd, dt=torch.float32), z(n, G, bd, dt=torch.float32)
         # the finished-beam tables are views of ONE 4-byte buffer: `collect` brings them to the host with a single copy (five
@@ -232,8 +230,8 @@ class DeviceSearch:
         self.constraint = opt.get("decoding_constraint", 0)
         n, rows, dev, G, bd, kk = eng.n, eng.rows, eng.dev, self.G, self.bd, self.kk
         self.tb = DeviceTables(n, G, T, bd, dev)
-        self.tok = torch.zeros(rows, device=dev, dtype=torch.long)
-        self.src = torch.zeros(rows, device=dev, dtype=torch.int32)
+        self.tok = ops.zero_(torch.empty(rows, device=dev, dtype=torch.long))
+        self.src = ops.zero_(torch.empty(rows, device=dev, dtype=torch.int32))
         self.tv = torch.empty(rows, kk, device=dev, dtype=torch.float32)
         self.ti = torch.empty(rows, kk, device=dev, dtype=torch.int32)
         if G > 1:
@@ -247,7 +245,7 @@ class DeviceSearch:
         tv, ti, tok, src = self.tv, self.ti, self.tok, self.src
         if not fresh_tables:
             for x in (tb.seq, tb.lps, tb.sums, tb.done_cnt, tok):
-                x.zero_()
+                ops.zero_(x)
         ops.row_topk(eng.st.step(tok, None, normalize=False), kk, tv, ti, log_softmax=True)      # <bos>, AttModel.py:223-227
         if G > 1:
             init = eng.snapshot()

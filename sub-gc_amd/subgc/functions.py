@@ -628,17 +628,22 @@ class Prepared:
     read (f1, f) are kept, every tensor a GEMM reads gets a bf16 twin written by its producer (`*16`), and the node features
     u, v are bf16 only (the attention kernels read them as such)."""
 
-    def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale, W=None):
+    def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale, W=None, into=None):
+        """`into` (decode, fp32 only): a namespace of fixed-address buffers f [S, R], u [S*N, A], v [S*N, R], off [S] that receive the
+        results in place (the captured decode graphs read them there); rows past the packed total keep whatever they held -- the
+        attention kernels never read them."""
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b) = P[:8]
         dev = fc_in.device
         S = fc_in.size(0)
         self.S, self.N = S, N
-        self.off, self.total, self.src_row, self.sent_of = ops.pack_rows(lens, idx, img, S, N)
+        self.off, self.total, self.src_row, self.sent_of = ops.pack_rows(lens, idx, img, S, N, off=None if into is None else into.off)
         self.lens = lens
         MR = S * N
         L = X_nodes.size(1)
         new = lambda r, c: torch.empty(r, c, device=dev, dtype=torch.float32)
         if W is not None and ops.is_b16(W[0]):
+            if into is not None:
+                raise ops.SubgcError("Prepared(into=...) is the fp32 decode form")
             w0, w2, wa, wc = W[0], W[2], W[4], W[6]
             self.fc16 = ops.as_b16(fc_in)
             self.Xg = None                                     # the gathered node rows only feed GEMMs: bf16 only
@@ -661,11 +666,11 @@ class Prepared:
         ops.gather_rows(X_nodes, self.src_row, self.Xg, m_dev=self.total)
         self.f1 = torch.empty(S, fc0_w.size(0), device=dev, dtype=torch.float32)
         ops.gemm(fc_in, fc0_w, self.f1, tb=True, bias=fc0_b, relu=True)
-        self.f = torch.empty(S, fc2_w.size(0), device=dev, dtype=torch.float32)
+        self.f = torch.empty(S, fc2_w.size(0), device=dev, dtype=torch.float32) if into is None else into.f
         ops.gemm(self.f1, fc2_w, self.f, tb=True, bias=fc2_b, relu=True, keep=keep_fc, keep_scale=scale)
-        self.v = ops.zeros(MR, att_w.size(0), device=dev)
+        self.v = ops.zeros(MR, att_w.size(0), device=dev) if into is None else into.v[:MR]
         ops.gemm(self.Xg, att_w, self.v, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
-        self.u = torch.empty(MR, c2a_w.size(0), device=dev, dtype=torch.float32)
+        self.u = torch.empty(MR, c2a_w.size(0), device=dev, dtype=torch.float32) if into is None else into.u[:MR]
         ops.gemm(self.v, c2a_w, self.u, tb=True, bias=c2a_b, m_dev=self.total)
 
 
@@ -786,6 +791,20 @@ def _cat_weights(w_ih_part, w_hh):
     ops.copy2d(w_ih_part, out[:, :a])
     ops.copy2d(w_hh, out[:, a:])
     return out
+
+
+_STEP_OFFSETS = {}
+
+
+def _step_offsets(T, S, dev):
+    """int32 [T + 1] = t * S on the device (the unpacked decoder's step table for dv_accum), built once per (T, S, device)."""
+    key = (T, S, str(dev))
+    t = _STEP_OFFSETS.get(key)
+    if t is None:
+        if len(_STEP_OFFSETS) > 32:
+            _STEP_OFFSETS.clear()
+        t = _STEP_OFFSETS[key] = torch.tensor([i * S for i in range(T + 1)], dtype=torch.int32).to(dev)
+    return t
 
 
 class DecoderFn(Function):
@@ -996,7 +1015,7 @@ class DecoderFn(Function):
         note("bptt_end")
 
         if defer_dv:
-            pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), torch.arange(T + 1, device=dev, dtype=torch.int32) * S, T, lens, dv, S, R)
+            pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), _step_offsets(T, S, dev), T, lens, dv, S, R)
             del dCtx
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
         H1a, H2a = ops.flat_rows(H1[:T]), ops.flat_rows(H2[:T])
@@ -1224,7 +1243,7 @@ class DecodeState:
             self._pick = (torch.zeros(2, ops.PICK_BEST_ELEMS, device=dev, dtype=torch.int64), torch.zeros(2, S, device=dev, dtype=torch.int32),
                           torch.empty(T, (V1 + 15) // 16, 16, 2, device=dev, dtype=torch.float32))
         best, unf, lse = self._pick
-        best.zero_()
+        ops.zero_(best)
         for t in range(T + 1):
             last = t == T
             hs = [self.H2[:, R:2 * R], self.H1n[:, R:]]

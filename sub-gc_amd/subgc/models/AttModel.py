@@ -724,10 +724,10 @@ class AttModel(CaptionModel):
         """Decode MANY images in one batch (not in the reference, whose loop is one image per call, eval_utils.py:98-104).
         `images`: list of dicts with the test loader's keys (att_feats [1,N,D], obj_dist, pred_dist, rel_ind, att_masks,
         gpn_obj_ind, gpn_pool_mtx -- the 5-counterpart layout of dataloader_test.py).  Returns one `_sample` tuple per image."""
-        att = torch.cat([im["att_feats"][:1] for im in images])
+        # counterpart 0 of every image's loader tensors, stacked into one batch by ONE table upload + four launches (subgc_gather_blocks)
+        att, obj, pred, rel = ops.stack_first([[im[k] for im in images] for k in ("att_feats", "obj_dist", "pred_dist", "rel_ind")])
         I, N, _ = att.shape
-        X2 = self._encode(att, torch.cat([im["obj_dist"][:1] for im in images]), torch.cat([im["pred_dist"][:1] for im in images]),
-                          torch.cat([im["rel_ind"][:1] for im in images])).reshape(I * N, self.GCN_dim).contiguous()
+        X2 = self._encode(att, obj, pred, rel).reshape(I * N, self.GCN_dim).contiguous()
         rows = [(i, im["gpn_obj_ind"], im["att_masks"], im["gpn_pool_mtx"]) for i, im in enumerate(images)]
         sel = sampling.select_subgraphs(self, X2, N, rows) if self.gpn else sampling.full_graph_rows(self, X2, N, rows)
         return sampling.decode(self, X2, N, sel, opt)

@@ -36,36 +36,34 @@ def _forced_pick(logp, tok, k, temp, t, seq, seqlp, it, unfinished, counts):
     counts[t] = unf.sum().int()
 
 
-def score_candidates(m, X2, N, images):
+def score_candidates(m, X2, N, images, fb=None):
     """The launch-only half of `select_subgraphs`: pool + score every candidate sub-graph of every image and run the node-set
-    NMS; nothing is read back.  -> namespace(idx, lens_i, img, read_out, score, sizes, offs, keep_all, n_keep)."""
+    NMS; nothing is read back.  -> namespace(idx, lens_i, img, read_out, score, sizes, offs, keep_all, n_keep).
+    Every device op is a C-ABI launch over the concatenation of all images (the per-image loader tensors are read in place through
+    ONE address table, subgc_gpn_test_prep); `fb` (_FrontBuffers of one image): results land in its static buffers."""
     dev, L = X2.device, m.GCN_dim
     for _, gpn_obj_ind, _, _ in images:
         if gpn_obj_ind.size(0) != 5:
             raise AssertionError("test branch of sGPN expects the 5 counterparts of ONE image (gpn.py:84)")
-    # per-image pieces are views (pos slots then neg slots; the pooling weights are the diagonal of gpn_pool_mtx); every
-    # device op below runs ONCE over the concatenation of all images, so the host cost does not grow with the image count
-    idx = torch.cat([g[0].reshape(-1, N) for _, g, _, _ in images]).contiguous()
-    w = torch.cat([p_[0].diagonal(dim1=-2, dim2=-1).reshape(-1, N) for _, _, _, p_ in images]).contiguous()
-    lens_all = torch.cat([a[0].reshape(-1, N) for _, _, a, _ in images]).sum(1)
-    sizes = [g.size(1) * g.size(2) for _, g, _, _ in images]
-    img = torch.from_numpy(np.repeat(np.asarray([r for r, _, _, _ in images], dtype=np.int32), sizes)).to(dev)
+    idx, w, lens_all, lens_i, img, offsets32, sizes, alive = ops.gpn_test_prep(images, N, dev, out=fb)
     G = idx.size(0)
-    read_out, _ = ops.pool_fwd(X2, idx, idx.stride(0), w, w.stride(0), 1, lens_all, img, G, N, L, want_argmax=False)
-    if m.use_sGPN_score:
+    read_out, _ = ops.pool_fwd(X2, idx, idx.stride(0), w, w.stride(0), 1, lens_all, img, G, N, L, want_argmax=False,
+                               out=None if fb is None else fb.read_out[:G])
+    if m.use_sGPN_score and G:
         hid = torch.empty(G, m.att_hid_size, device=dev)
         ops.gemm(read_out, m.P("gpn_layer.gpn_fc.0.weight"), hid, tb=True, bias=m.P("gpn_layer.gpn_fc.0.bias"), relu=True)
-        score, _ = ops.gpn_score_fwd(hid, None, 1.0, m.P("gpn_layer.gpn_fc.3.weight"), m.P("gpn_layer.gpn_fc.3.bias"), want_loss=False)
+        score, _ = ops.gpn_score_fwd(hid, None, 1.0, m.P("gpn_layer.gpn_fc.3.weight"), m.P("gpn_layer.gpn_fc.3.bias"), want_loss=False,
+                                     out=None if fb is None else fb.score[:G].view(G, 1))
         score = score.view(-1)
     else:
-        score = torch.ones(G, device=dev)
-    lens_i = lens_all.to(torch.int32)
+        score = ops.fill_(torch.empty(G, device=dev) if fb is None else fb.score[:G], 1.0)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     keep_all = n_keep = None
     if not m.sct:                                                                      # use_nms (AttModel.py:95); node-set NMS is per image (gpn.py:108-138)
-        keep_all, n_keep, _ = ops.subgraph_nms_batched(score, idx, lens_i, sizes, m.gpn_nms_thres, m.gpn_max_subg)
+        keep_all, n_keep, _ = ops.subgraph_nms_batched(score, idx, lens_i, sizes, m.gpn_nms_thres, m.gpn_max_subg, offsets=offsets32,
+                                                       keep=None if fb is None else fb.keep)
     return SimpleNamespace(idx=idx, lens_i=lens_i, img=img, read_out=read_out, score=score, sizes=sizes, offs=offs, keep_all=keep_all,
-                           n_keep=n_keep, G=G)
+                           n_keep=n_keep, G=G, offsets32=offsets32, alive=alive)
 
 
 def select_subgraphs(m, X2, N, images, front=None, kept=None):
@@ -79,27 +77,29 @@ def select_subgraphs(m, X2, N, images, front=None, kept=None):
     idx, lens_i, img, read_out, score, sizes, offs, keep_all, G = fr.idx, fr.lens_i, fr.img, fr.read_out, fr.score, fr.sizes, fr.offs, fr.keep_all, fr.G
     if not m.sct:
         kept = fr.n_keep.cpu().numpy().astype(np.int64) if kept is None else np.asarray(kept, dtype=np.int64)   # ONE host read for all images
-        g0 = np.repeat(offs[:-1], kept)                                                # first candidate of the owning image, per survivor
-        slot = g0 + (np.arange(int(kept.sum())) - np.repeat(np.cumsum(kept) - kept, kept))
-        hs = torch.from_numpy(np.stack([slot, g0])).to(dev)                            # one small upload
-        keep = keep_all[hs[0]]                                                         # survivors, image-local indices in original order
-        glob = keep + hs[1]
-    else:
+        n = int(kept.sum())
+        # survivors in image order: image-local indices (original order) and their global candidate rows -- one launch
+        keep, glob = ops.nms_compact(keep_all, fr.n_keep, fr.offsets32, len(sizes), n)
+    else:                                                                              # controllability mode (sct): every candidate, plumbing in torch
         kept = np.asarray(sizes, dtype=np.int64)
         glob = torch.arange(G, device=dev)
         keep = glob - torch.from_numpy(np.repeat(offs[:-1], kept)).to(dev)
     n = glob.numel()
-    fc = torch.empty(n, 2 * L, device=dev)
+    e = lambda *sh, dt=torch.float32: torch.empty(*sh, device=dev, dtype=dt)
+    fc = e(n, 2 * L)
+    lens_g, idx_g, img_g, score_g = e(n, dt=torch.int32), e(n, idx.size(1), dt=torch.int64), e(n, dt=torch.int32), e(n)
     if n:
-        h = torch.empty(n, m.att_hid_size, device=dev)
-        ops.gemm(read_out[glob], m.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
+        ro, h = e(n, 2 * L), e(n, m.att_hid_size)
+        ops.take_rows([(read_out, ro), (lens_i, lens_g), (idx if idx.is_contiguous() else idx.contiguous(), idx_g), (img, img_g)], glob)
+        ops.take_rows([(score if score.is_contiguous() else score.contiguous(), score_g)], glob)
+        ops.gemm(ro, m.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
         ops.gemm(h, m.P("gpn_layer.read_out_proj.1.weight"), fc, tb=True, bias=m.P("gpn_layer.read_out_proj.1.bias"))
-    lens_g, idx_g, img_g, score_g = lens_i[glob], idx[glob], img[glob], score[glob]
-    out, r0 = [], 0
+    out, r0 = _Selection(), 0
     for k_ in kept.tolist():                                                           # per-image results are row slices (views)
         r1 = r0 + k_
         out.append(dict(keep=keep[r0:r1], fc=fc[r0:r1], lens=lens_g[r0:r1], idx=idx_g[r0:r1], img=img_g[r0:r1], score=score_g[r0:r1]))
         r0 = r1
+    out.whole = dict(fc=fc, lens=lens_g, idx=idx_g, img=img_g)
     return out
 
 
@@ -107,26 +107,42 @@ def full_graph_rows(m, X2, N, images):
     """Full-GC baseline (AttModel.py:261-271): one row per image, mean-pooled read-out, attention over the first 36 nodes."""
     dev, L = X2.device, m.GCN_dim
     n = len(images)
-    ar = torch.arange(N, device=dev).view(1, N).expand(n, N).contiguous()
-    img = torch.tensor([im[0] for im in images], device=dev, dtype=torch.int32)
-    mean, _ = ops.pool_fwd(X2, ar, N, torch.ones(n, N, device=dev), N, 1, torch.full((n,), float(N), device=dev), img, n, N, L, want_argmax=False)
+    cache = m.__dict__.setdefault("_const_cache", {})
+    key = ("full_graph", str(dev), n, N)
+    c = cache.get(key)
+    if c is None:                                                                      # shape-only index tensors, built once per (batch, N)
+        ar = torch.arange(N, device=dev).view(1, N).expand(n, N).contiguous()
+        c = cache[key] = dict(ar=ar, ones=torch.ones(n, N, device=dev), full=torch.full((n,), float(N), device=dev),
+                              one=torch.ones(n, device=dev), zero=torch.zeros(n, device=dev, dtype=torch.long))
+    ar = c["ar"]
+    img = torch.tensor([im[0] for im in images], dtype=torch.int32).to(dev)            # one small upload
+    mean, _ = ops.pool_fwd(X2, ar, N, c["ones"], N, 1, c["full"], img, n, N, L, want_argmax=False)
     h = torch.empty(n, m.att_hid_size, device=dev)
     fc = torch.empty(n, 2 * L, device=dev)
     ops.gemm(mean[:, L:], m.P("read_out_proj.0.weight"), h, tb=True, bias=m.P("read_out_proj.0.bias"))
     ops.gemm(h, m.P("read_out_proj.1.weight"), fc, tb=True, bias=m.P("read_out_proj.1.bias"))
-    out = []
+    out = _Selection()
+    lens_all = torch.empty(n, device=dev, dtype=torch.int32)
     for i, (row, _g, att_masks, _p) in enumerate(images):
         mk = att_masks[0:1, 0, 0]
-        mk[:, :36].fill_(1.0)                                                          # writes into the caller's tensor, like :148-149
-        out.append(dict(fc=fc[i:i + 1], lens=mk.sum(1).to(torch.int32), idx=ar[i:i + 1], img=img[i:i + 1],
-                        score=torch.ones(1, device=dev), keep=torch.arange(1, device=dev)))
+        ops.fill2d_(mk[:, :36], 1.0)                                                   # writes into the caller's tensor, like :148-149
+        call_lens = ops.row_count(mk)
+        ops.copy_(lens_all[i:i + 1], call_lens)
+        out.append(dict(fc=fc[i:i + 1], lens=lens_all[i:i + 1], idx=ar[i:i + 1], img=img[i:i + 1], score=c["one"][i:i + 1], keep=c["zero"][i:i + 1]))
+    out.whole = dict(fc=fc, lens=lens_all, idx=ar, img=img)
     return out
 
 
+class _Selection(list):
+    """Per-image selection dicts (row slices) plus `whole`: the tensors they are slices of, in image order -- what a batched decode
+    reads instead of concatenating the slices again."""
+    whole = None
+
+
 class _FrontBuffers:
-    """Fixed-address copies of what the selection phase of ONE image leaves for the decode graph (node states, read-outs,
-    scores, node sets, NMS survivors).  The copies are queued BEFORE the one host read of a call (the survivor count), so
-    after that read the host issues a single graph replay: the survivor gathers, the read-out projection and the attention-set
+    """Fixed-address destinations of what the selection phase of ONE image leaves for the decode graph (node states, read-outs,
+    scores, node sets, NMS survivors): `score_candidates(fb=...)` writes them IN PLACE, so after the one host read of a call (the
+    survivor count) the host issues a single graph replay: the survivor gathers, the read-out projection and the attention-set
     preparation (`F_.Prepared`) run inside the graph instead of as ~25 eager launches with the GPU idling between them."""
 
     def __init__(self, m, G, N):
@@ -135,23 +151,21 @@ class _FrontBuffers:
         dev, L = m.flat_params.device, m.GCN_dim
         self.G, self.N = G, N
         self.X2, self.read_out = torch.empty(N, L, device=dev), torch.empty(G, 2 * L, device=dev)
-        self.keep, self.lens = torch.zeros(G, device=dev, dtype=torch.long), torch.zeros(G, device=dev, dtype=torch.int32)
-        self.idx, self.score = torch.zeros(G, N, device=dev, dtype=torch.long), torch.empty(G, device=dev)
+        self.keep, self.lens = ops.zero_(torch.empty(G, device=dev, dtype=torch.long)), ops.zero_(torch.empty(G, device=dev, dtype=torch.int32))
+        self.idx, self.score = ops.zero_(torch.empty(G, N, device=dev, dtype=torch.long)), torch.empty(G, device=dev)
+        self.img0 = ops.zero_(torch.empty(G, device=dev, dtype=torch.int32))       # every survivor belongs to the one image (row 0 of X2)
 
-    def load(self, X2, fr):
-        g = fr.G                                                                  # <= capacity; rows past g are never indexed (keep < g)
-        self.X2.copy_(X2); self.read_out[:g].copy_(fr.read_out); self.keep[:g].copy_(fr.keep_all[:g])
-        self.lens[:g].copy_(fr.lens_i); self.idx[:g].copy_(fr.idx); self.score[:g].copy_(fr.score)
+    def load(self, X2):
+        ops.copy_(self.X2, X2)                                                    # everything else was written in place
 
-    def prepared(self, m, n, P):
-        """(inside the capture) the first n NMS survivors -> F_.Prepared, their scores and indices."""
-        dev, L = self.X2.device, m.GCN_dim
+    def prepared(self, m, n, P, g):
+        """(inside the capture) the first n NMS survivors -> F_.Prepared in `g.pr`'s buffers, their scores / indices in g.score_out / keep_out."""
         keep = self.keep[:n]
-        h, fc = torch.empty(n, m.att_hid_size, device=dev), torch.empty(n, 2 * L, device=dev)
-        ops.gemm(self.read_out[keep], m.P("gpn_layer.read_out_proj.0.weight"), h, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
-        ops.gemm(h, m.P("gpn_layer.read_out_proj.1.weight"), fc, tb=True, bias=m.P("gpn_layer.read_out_proj.1.bias"))
-        pr = F_.Prepared(fc, self.X2, self.lens[keep], self.idx[keep], torch.zeros(n, device=dev, dtype=torch.int32), self.N, P, None, None, 1.0)
-        return pr, self.score[keep], keep
+        ops.take_rows([(self.read_out, g.ro_sel), (self.lens, g.pr.lens), (self.idx, g.idx_sel), (self.score, g.score_out)], keep)
+        ops.copy_(g.keep_out, keep)
+        ops.gemm(g.ro_sel, m.P("gpn_layer.read_out_proj.0.weight"), g.h_sel, tb=True, bias=m.P("gpn_layer.read_out_proj.0.bias"))
+        ops.gemm(g.h_sel, m.P("gpn_layer.read_out_proj.1.weight"), g.fc_sel, tb=True, bias=m.P("gpn_layer.read_out_proj.1.bias"))
+        F_.Prepared(g.fc_sel, self.X2, g.pr.lens, g.idx_sel, self.img0[:n], self.N, P, None, None, 1.0, into=g.pr)
 
 
 def _front_buffers(m, G, N):
@@ -168,9 +182,26 @@ def _front_buffers(m, G, N):
 
 def _load_prepared(dst, pr):
     rows = pr.u.size(0)
-    dst.f.copy_(pr.f)
-    dst.u[:rows].copy_(pr.u); dst.v[:rows].copy_(pr.v)
-    dst.off.copy_(pr.off); dst.lens.copy_(pr.lens)
+    ops.copy_(dst.f, pr.f)
+    ops.copy_(dst.u[:rows], pr.u); ops.copy_(dst.v[:rows], pr.v)
+    ops.copy_(dst.off, pr.off); ops.copy_(dst.lens, pr.lens)
+
+
+def _arena(dev, parts):
+    """One fp32-word buffer carved into typed views: parts = [(name, shape, dtype)], 8-byte types first.  -> (buffer, {name: view},
+    {name: (first word, words)}): the token loop zeroes / snapshots its small state tensors with ONE launch instead of one each."""
+    words, views, spans, o = 0, {}, {}, 0
+    for _, shape, dt in parts:
+        words += int(np.prod(shape)) * (2 if dt == torch.long else 1)
+    buf = torch.empty(max(words, 2), device=dev, dtype=torch.float32)
+    for name, shape, dt in parts:
+        n = int(np.prod(shape)) * (2 if dt == torch.long else 1)
+        if dt == torch.long and o % 2:
+            raise ValueError("arena: 8-byte parts first")
+        views[name] = buf[o:o + n].view(dt).view(*shape)
+        spans[name] = (o, n)
+        o += n
+    return buf, views, spans
 
 
 class _GraphedLoop:
@@ -178,23 +209,30 @@ class _GraphedLoop:
 
     The reference-shaped call decodes <= 10 rows per step: ~12 kernels of 5-30 us each, 21 steps -- launch-bound.  For a
     given row count the launch sequence is static (the early break is device-side), so it is captured once on buffers
-    of fixed address and replayed per image; the image's prepared features are copied into those buffers first.
+    of fixed address and replayed per image; the image's prepared features are written into those buffers first.
     Keyed by (rows, N, attention rows capacity, k, return_att) and by the version of the flat parameter buffer (the
-    K-concatenated LSTM weights inside DecodeState are snapshots of the parameters)."""
+    K-concatenated LSTM weights inside DecodeState are snapshots of the parameters).  Every launch inside the graph and around the
+    replay is a C-ABI kernel: the small state tensors live in one arena (one zero fill, one snapshot copy per image)."""
 
     def __init__(self, m, n, N, k, return_att, P, fb=None):
         dev = m.flat_params.device
-        T, R, A = m.seq_length, m.rnn_size, m.att_hid_size
+        T, R, A, L = m.seq_length, m.rnn_size, m.att_hid_size, m.GCN_dim
         self.n, self.N, self.T, self.k, self.return_att = n, N, T, k, return_att
         self.m, self.P, self.fb = m, P, fb                                        # fb: the graph starts from the selection's static buffers
-        if fb is not None:
-            self.score_out, self.keep_out = torch.empty(n, device=dev), torch.zeros(n, device=dev, dtype=torch.long)
         cap = n * N
-        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        z = lambda *s, dt=torch.float32: ops.zero_(torch.empty(*s, device=dev, dtype=dt))
+        # results first (seq, keep_out, seqlp, score_out: snapshot as one block), then the loop's scratch state
+        self.arena, v, sp = _arena(dev, [("seq", (n, T), torch.long), ("keep_out", (n,), torch.long), ("it", (n,), torch.long),
+                                         ("seqlp", (n, T), torch.float32), ("score_out", (n,), torch.float32),
+                                         ("unfinished", (n,), torch.int32), ("counts", (T,), torch.int32)])
+        self.views, self.result_words = v, sp["score_out"][0] + sp["score_out"][1]
+        self.seq, self.seqlp, self.it, self.unfinished, self.counts = v["seq"], v["seqlp"], v["it"], v["unfinished"], v["counts"]
+        self.score_out, self.keep_out = v["score_out"], v["keep_out"]
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
+        if fb is not None:
+            e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
+            self.ro_sel, self.h_sel, self.fc_sel, self.idx_sel = e(n, 2 * L), e(n, A), e(n, 2 * L), e(n, N, dt=torch.long)
         self.st = F_.DecodeState(self.pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots(), W16=m.decode_w16())
-        self.seq, self.seqlp = z(n, T, dt=torch.long), z(n, T)
-        self.it, self.unfinished, self.counts = z(n, dt=torch.long), z(n, dt=torch.int32), z(T, dt=torch.int32)
         self.AL = z(T + 1, n, N) if return_att else None
         self.u = z(T, n) if k else None
         self.topk_temp = m.topk_temp
@@ -206,13 +244,12 @@ class _GraphedLoop:
 
     def _loop(self):
         T = self.T
+        ops.fill_(self.arena, 0.0)                                               # seq, seqlp, it, unfinished, counts (and the result slots) in one launch
+        if self.AL is not None:
+            ops.fill_(self.AL, 0.0)
         if self.fb is not None:
-            pr, score, keep = self.fb.prepared(self.m, self.n, self.P)
-            _load_prepared(self.pr, pr)
-            self.score_out.copy_(score); self.keep_out.copy_(keep)
+            self.fb.prepared(self.m, self.n, self.P, self)
         self.st.reset()
-        for b in (self.seq, self.seqlp, self.it, self.unfinished, self.counts) + ((self.AL,) if self.AL is not None else ()):
-            b.zero_()
         if self.k == 0 and self.st.fused and self.st.xt_table is not None and getattr(self.m, "decode_fused_pick", True):
             # greedy: the pick rides in the logits / attention-LSTM launches (functions.DecodeState.greedy_loop)
             self.st.greedy_loop(T, self.seq, self.seqlp, self.counts, self.AL, self.it)
@@ -224,13 +261,29 @@ class _GraphedLoop:
             ops.decode_pick(logp, self.k, self.topk_temp, None if self.u is None else self.u[t], t, self.seq, self.seqlp, self.it,
                             self.unfinished, self.counts[t:t + 1], self.counts[t - 1:t] if t > 0 else None, raw=True)
 
-    def run(self, pr, uniforms):
+    def run(self, pr, uniforms, step_major=False):
+        """-> (seq, seqlp, counts, AL, score_out, keep_out): the results are one snapshot copy of the arena's result block.
+        `uniforms` (top-k sampling): [T, n] when `step_major` (drawn by `_uniforms`), else the caller's [n, T] (tests)."""
         if pr is not None:
             _load_prepared(self.pr, pr)
         if self.u is not None:
-            self.u.copy_(uniforms.t())
+            if step_major:
+                ops.copy_(self.u, uniforms)
+            else:
+                self.u.copy_(uniforms.t())                                       # injected uniforms: test plumbing in torch
         self.graph.replay()
-        return self.seq.clone(), self.seqlp.clone(), self.counts, (self.AL.clone() if self.AL is not None else None)
+        out = torch.empty(self.result_words, device=self.arena.device, dtype=torch.float32)
+        ops.copy_(out, self.arena[:self.result_words])
+        n, T = self.n, self.T
+        o = 0
+        seq = out[o:o + 2 * n * T].view(torch.long).view(n, T); o += 2 * n * T
+        keep_out = out[o:o + 2 * n].view(torch.long); o += 4 * n                  # (skips `it`)
+        seqlp = out[o:o + n * T].view(n, T); o += n * T
+        score_out = out[o:o + n]
+        AL = None
+        if self.AL is not None:
+            AL = ops.copy_(torch.empty_like(self.AL), self.AL)
+        return seq, seqlp, self.counts, AL, score_out, keep_out
 
 
 class _GraphedBeam:
@@ -240,13 +293,15 @@ class _GraphedBeam:
 
     def __init__(self, m, n, N, P, opt, fb=None):
         dev = m.flat_params.device
-        T, R, A = m.seq_length, m.rnn_size, m.att_hid_size
+        T, R, A, L = m.seq_length, m.rnn_size, m.att_hid_size, m.GCN_dim
         self.m, self.n, self.P, self.fb = m, n, P, fb
-        if fb is not None:
-            self.score_out, self.keep_out = torch.empty(n, device=dev), torch.zeros(n, device=dev, dtype=torch.long)
         cap = n * N
-        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        z = lambda *s, dt=torch.float32: ops.zero_(torch.empty(*s, device=dev, dtype=dt))
         self.pr = SimpleNamespace(S=n, N=N, f=z(n, R), u=z(cap, A), v=z(cap, R), off=z(n, dt=torch.int32), lens=z(n, dt=torch.int32))
+        if fb is not None:
+            e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
+            self.score_out, self.keep_out = e(n), z(n, dt=torch.long)
+            self.ro_sel, self.h_sel, self.fc_sel, self.idx_sel = e(n, 2 * L), e(n, A), e(n, 2 * L), e(n, N, dt=torch.long)
         self.eng = beam._BatchEngine(self.pr, P, N, int(opt.get("beam_size", 10)), m.xt_gates_table(), m.decode_snapshots())
         self.ds = beam.DeviceSearch(self.eng, T, opt)
         self._loop()                                                             # eager warm-up
@@ -257,9 +312,7 @@ class _GraphedBeam:
 
     def _loop(self):
         if self.fb is not None:
-            pr, score, keep = self.fb.prepared(self.m, self.n, self.P)
-            _load_prepared(self.pr, pr)
-            self.score_out.copy_(score); self.keep_out.copy_(keep)
+            self.fb.prepared(self.m, self.n, self.P, self)
         self.eng.refresh()
         self.ds.loop()
 
@@ -297,19 +350,20 @@ def _graphed_loop(m, n, N, k, return_att, P, fb=None):
 
 @torch.no_grad()
 def decode_one_image(m, X2, N, image, opt, uniforms=None, forced=None):
-    """The reference-shaped call (ONE image, sGPN + NMS): selection launches -> static buffers -> the one host read (how many
+    """The reference-shaped call (ONE image, sGPN + NMS): selection launches write into static buffers -> the one host read (how many
     sub-graphs survived) -> ONE graph replay that gathers the survivors, prepares their attention sets and runs the token
     loop / beam search.  Falls back to `select_subgraphs` + `decode` (same kernels, eager) whenever a graph does not apply."""
     T = m.seq_length
     beam_size = opt.get("beam_size", 1)
     return_att = opt.get("return_att", 0) == 1
     graphable = m.gpn and not m.sct and forced is None and getattr(m, "decode_hipgraph", True)
-    fr = score_candidates(m, X2, N, [image]) if m.gpn else None
+    G_in = int(image[1].size(1) * image[1].size(2)) if m.gpn else 0
+    fb = _front_buffers(m, G_in, N) if (graphable and G_in > 0) else None
+    fr = score_candidates(m, X2, N, [image], fb=fb) if m.gpn else None
     if not graphable or fr.G == 0:
         sel = select_subgraphs(m, X2, N, [image], front=fr) if m.gpn else full_graph_rows(m, X2, N, [image])
         return decode(m, X2, N, sel, opt, uniforms, forced)[0]
-    fb = _front_buffers(m, fr.G, N)
-    fb.load(X2, fr)                                                               # queued before the host read below
+    fb.load(X2)                                                                   # queued before the host read below
     n = int(fr.n_keep.item())
     if n == 0 or (beam_size > 1 and n * beam_size > 128) or (beam_size <= 1 and n > 16):
         return decode(m, X2, N, select_subgraphs(m, X2, N, [image], front=fr, kept=[n]), opt, uniforms, forced)[0]
@@ -319,24 +373,33 @@ def decode_one_image(m, X2, N, image, opt, uniforms=None, forced=None):
             g = _graphed_beam(m, n, N, P, opt, fb)
             seq, seqlp, done = g.run(None)
             m.done_beams = done
-            return (seq, seqlp, g.score_out.clone(), g.keep_out.clone())
+            return (seq, seqlp, ops.copy_(torch.empty_like(g.score_out), g.score_out), ops.copy_(torch.empty_like(g.keep_out), g.keep_out))
         k = m.the_k if m.topk_sampling else 0
-        if k and uniforms is None:
-            uniforms = torch.rand(n, T, device=X2.device)
+        own_u = bool(k) and uniforms is None
+        if own_u:
+            uniforms = _uniforms(m, n, T, X2.device)                              # step-major [T, n]
         g = _graphed_loop(m, n, N, k, return_att, P, fb)
     except RuntimeError as e:                                                     # capture unavailable here: same kernels, launched eagerly
         import warnings
         warnings.warn(f"hipGraph capture of the decode loop failed ({e}); decoding eagerly from now on")
         m.decode_hipgraph = False
         return decode(m, X2, N, select_subgraphs(m, X2, N, [image], front=fr, kept=[n]), opt, uniforms, forced)[0]
-    seq, seqlp, counts, AL = g.run(None, uniforms)
-    r = (seq, seqlp, g.score_out.clone(), g.keep_out.clone())
+    seq, seqlp, counts, AL, score_out, keep_out = g.run(None, uniforms, step_major=own_u if k else False)
+    r = (seq, seqlp, score_out, keep_out)
     if return_att:
         dead = (counts.cpu() == 0).nonzero()
         steps = int(dead[0]) + 1 if dead.numel() else T + 1
         n_max = int(g.pr.lens.max().item())
         r = r + (AL[:steps, :, :n_max].permute(1, 0, 2).contiguous(),)
     return r
+
+
+def _uniforms(m, n, T, dev):
+    """[T, n] (step-major) uniforms of a free-running top-k decode (AttModel.py:295-303 draws with torch.multinomial): counter-based Philox stream
+    keyed by torch's seed and a per-model call counter (subgc_uniform_f32) -- reproducible under torch.manual_seed, no torch RNG kernel."""
+    m.__dict__["_sample_calls"] = m.__dict__.get("_sample_calls", 0) + 1
+    seed = (int(torch.initial_seed()) * 1000003 + m.__dict__["_sample_calls"]) & 0xFFFFFFFFFFFFFFFF
+    return ops.uniform((T, n), seed ^ 0x3C6EF372FE94F82B, 0, dev)                     # step-major: row t = the draws of step t
 
 
 @torch.no_grad()
@@ -349,11 +412,15 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     beam_size = opt.get("beam_size", 1)
     sizes = [s["keep"].numel() for s in sel]
     n = sum(sizes)
+    z = lambda *s, dt=torch.float32: ops.zero_(torch.empty(*s, device=dev, dtype=dt))
     if n == 0:
-        z = lambda: (torch.zeros(0, T, device=dev, dtype=torch.long), torch.zeros(0, T, device=dev))
-        return [z() + (s["score"], s["keep"]) + ((torch.zeros(0, 0, 0, device=dev),) if return_att else ()) for s in sel]
-    cat = lambda k: torch.cat([s[k] for s in sel]).contiguous()
-    fc, lens_k, idx_k, img_k = cat("fc"), cat("lens"), cat("idx"), cat("img")
+        return [(z(0, T, dt=torch.long), z(0, T)) + (s["score"], s["keep"]) + ((z(0, 0, 0),) if return_att else ()) for s in sel]
+    whole = getattr(sel, "whole", None)
+    if whole is not None:                                                              # the selection's own tensors, already in image order
+        fc, lens_k, idx_k, img_k = whole["fc"], whole["lens"], whole["idx"], whole["img"]
+    else:
+        cat = lambda k: torch.cat([s[k] for s in sel]).contiguous()
+        fc, lens_k, idx_k, img_k = cat("fc"), cat("lens"), cat("idx"), cat("img")
     P = m._decoder_params()
     pr = F_.Prepared(fc, X2, lens_k, idx_k, img_k, N, P, None, None, 1.0)
     bounds = [0]
@@ -375,8 +442,9 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
         m.done_beams = done if len(sel) == 1 else [done[a:b] for a, b in zip(bounds, bounds[1:])]
         return [(seq[a:b], seqlp[a:b], s["score"], s["keep"]) for s, a, b in zip(sel, bounds, bounds[1:])]
     k = m.the_k if m.topk_sampling else 0
-    if k and uniforms is None and forced is None:
-        uniforms = torch.rand(n, T, device=dev)
+    own_u = bool(k) and uniforms is None and forced is None
+    if own_u:
+        uniforms = _uniforms(m, n, T, dev)                                             # step-major [T, n]
     graphed = None
     if len(sel) == 1 and forced is None and n <= 16 and getattr(m, "decode_hipgraph", True):
         # the reference-shaped call (one image, <= 10 rows): launch-bound, replayed as one hipGraph
@@ -387,15 +455,15 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
             warnings.warn(f"hipGraph capture of the decode loop failed ({e}); decoding eagerly from now on")
             m.decode_hipgraph = False
     if graphed is not None:
-        seq, seqlp, counts, AL = graphed.run(pr, uniforms)
+        seq, seqlp, counts, AL, _, _ = graphed.run(pr, uniforms, step_major=own_u)
     else:
         st = F_.DecodeState(pr, P, N, return_att, xt_table=m.xt_gates_table(), fuse_lstm=True, snapshots=m.decode_snapshots(), W16=m.decode_w16())
-        seq = torch.zeros(n, T, device=dev, dtype=torch.long)
-        seqlp = torch.zeros(n, T, device=dev)
-        it = torch.zeros(n, device=dev, dtype=torch.long)
-        unfinished = torch.zeros(n, device=dev, dtype=torch.int32)
-        counts = torch.zeros(T, device=dev, dtype=torch.int32)
-        AL = torch.zeros(T + 1, n, N, device=dev) if return_att else None
+        seq, seqlp, it = z(n, T, dt=torch.long), z(n, T), z(n, dt=torch.long)
+        unfinished, counts = z(n, dt=torch.int32), z(T, dt=torch.int32)
+        AL = z(T + 1, n, N) if return_att else None
+        ut = None
+        if uniforms is not None and forced is None:                                    # step-major: a contiguous row per step for the pick kernel
+            ut = uniforms if own_u else uniforms.t().contiguous()                      # (injected [n, T] uniforms: test plumbing in torch)
         for t in range(T + 1):
             logp = st.step(it, AL[t] if return_att else None, normalize=forced is not None)
             if t == T:
@@ -403,7 +471,7 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
             if forced is not None:
                 _forced_pick(logp, forced[:, t].contiguous(), k, m.topk_temp, t, seq, seqlp, it, unfinished, counts)
             else:
-                ops.decode_pick(logp, k, m.topk_temp, None if uniforms is None else uniforms[:, t].contiguous(), t, seq, seqlp, it,
+                ops.decode_pick(logp, k, m.topk_temp, None if ut is None else ut[t], t, seq, seqlp, it,
                                 unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
     if len(sel) == 1:
         steps = None
@@ -411,17 +479,13 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
             dead = (counts.cpu() == 0).nonzero()
             steps = [int(dead[0]) + 1 if dead.numel() else T + 1]
     else:
-        # per-image early break: image i stops after the first step at which none of ITS rows is unfinished; the
-        # reference writes nothing (tokens, log-probs, attention rows) beyond that step
-        alive = (seq > 0).int().cumprod(1)                                             # [n, T] row still unfinished after step t
-        row_img = torch.from_numpy(np.repeat(np.arange(len(sizes)), sizes)).to(dev)    # owning image of every row
-        per = torch.zeros(len(sizes), T, device=dev, dtype=alive.dtype).index_add_(0, row_img, alive)   # [I, T] unfinished rows per image
-        stopped = (per == 0).int()
-        brk = torch.where(stopped.any(1), stopped.argmax(1), torch.full_like(stopped[:, 0], T - 1).long())   # break step per image
-        tgrid = torch.arange(T, device=dev).view(1, T)
-        row_brk = brk[row_img]
-        seqlp = seqlp * (tgrid <= row_brk.view(-1, 1))
-        steps = [min(int(b) + 1, T) + (1 if int(b) == T - 1 and not bool(s.any()) else 0) for b, s in zip(brk.cpu(), stopped.cpu())]
+        # per-image early break: image i stops after the first step at which none of ITS rows is unfinished; the reference writes
+        # nothing (tokens, log-probs, attention rows) beyond that step: one launch masks the log-probs (subgc_decode_batch_finish)
+        brk = ops.decode_batch_finish(seq, seqlp, bounds)
+        steps = None
+        if return_att:
+            h = brk.cpu().tolist()                                                     # [I, 2]: break step, "some step had no unfinished row"
+            steps = [min(b + 1, T) + (1 if b == T - 1 and not any_ else 0) for b, any_ in h]
     out = []
     for i, (s, a, b) in enumerate(zip(sel, bounds, bounds[1:])):
         r = (seq[a:b], seqlp[a:b], s["score"], s["keep"])

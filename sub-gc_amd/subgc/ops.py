@@ -475,9 +475,9 @@ def _pool_account(denom, G, L, fwd):
         FLOPS["pool_bytes"] = FLOPS.get("pool_bytes", 0.0) + 4.0 * ((rows * L + 3.0 * G * L) if fwd else (3.0 * G * L + 2.0 * rows * L))
 
 
-def pool_fwd(X, idx, idx_stride, w, w_g, w_i, denom, img, G, N, L, want_argmax=True):
+def pool_fwd(X, idx, idx_stride, w, w_g, w_i, denom, img, G, N, L, want_argmax=True, out=None):
     _pool_account(denom, G, L, True)
-    out = torch.empty(G, 2 * L, device=X.device, dtype=torch.float32)
+    out = torch.empty(G, 2 * L, device=X.device, dtype=torch.float32) if out is None else out
     am = torch.empty(G, L, device=X.device, dtype=torch.int32) if want_argmax else None
     call("subgc_subgraph_pool_fwd", _ptr(X), _ptr(idx, torch.int64), idx_stride, _ptr(w, torch.float32), w_g, w_i,
          _ptr(denom, torch.float32), _ptr(img, torch.int32), _ptr(out), _ptr(am), G, N, L, _stream())
@@ -491,9 +491,9 @@ def pool_bwd(dout, idx, idx_stride, w, w_g, w_i, denom, img, am, dX, G, N, L):
     return dX
 
 
-def gpn_score_fwd(hid, keep, scale, w2, b2, want_loss=True):
+def gpn_score_fwd(hid, keep, scale, w2, b2, want_loss=True, out=None):
     G, H = hid.shape
-    score = torch.empty(G, 1, device=hid.device, dtype=torch.float32)
+    score = torch.empty(G, 1, device=hid.device, dtype=torch.float32) if out is None else out
     loss = torch.empty((), device=hid.device, dtype=torch.float32) if want_loss else None
     call("subgc_gpn_score_fwd", _ptr(hid), _ptr(keep, torch.uint8), float(scale), _ptr(w2), _ptr(b2), _ptr(score), _ptr(loss), G, H, _stream())
     return score, loss
@@ -523,27 +523,147 @@ def subgraph_nms(score, idx, lens, thres, max_keep):
     return keep, n_keep
 
 
-def subgraph_nms_batched(score, idx, lens, sizes, thres, max_keep):
+def subgraph_nms_batched(score, idx, lens, sizes, thres, max_keep, offsets=None, keep=None):
     """NMS of several images in ONE launch.  `sizes`: candidates per image (python ints, consecutive segments of score/idx/lens).
+    `offsets` (device int32 [images + 1], optional): the segment offsets when the caller already has them on the device
+    (subgc_gpn_test_prep writes them); `keep`: destination (int64, >= total elements).
     -> (keep int64 [total] with image b's kept indices (relative to its segment) at its segment start, n_keep int32 [images])."""
     total, N = idx.shape
     dev = score.device
     offs = [0]
     for n in sizes:
         offs.append(offs[-1] + int(n))
-    offsets = torch.tensor(offs, device=dev, dtype=torch.int32)
-    keep = torch.empty(max(total, 1), device=dev, dtype=torch.int64)
-    n_keep = torch.zeros(len(sizes), device=dev, dtype=torch.int32)
+    if offsets is None:
+        offsets = torch.tensor(offs, dtype=torch.int32).to(dev)                   # one small upload
+    keep = torch.empty(max(total, 1), device=dev, dtype=torch.int64) if keep is None else keep
+    n_keep = zero_(torch.empty(len(sizes), device=dev, dtype=torch.int32))
     scratch = torch.empty(max(total, 1) * (NMS_WORDS * 8 + 8), device=dev, dtype=torch.uint8)
     call("subgc_subgraph_nms_batched", _ptr(score, torch.float32), _ptr(idx, torch.int64), idx.stride(0), _ptr(lens, torch.int32),
-         _ptr(offsets), len(sizes), total, max(sizes) if sizes else 0, N, float(thres), int(max_keep), _ptr(keep), _ptr(n_keep),
+         _ptr(offsets, torch.int32), len(sizes), total, max(sizes) if sizes else 0, N, float(thres), int(max_keep), _ptr(keep, torch.int64), _ptr(n_keep),
          _ptr(scratch), scratch.numel(), _stream())
     return keep, n_keep, offs
 
 
-def pack_rows(lens, idx, img, S, N):
+def stack_first(groups):
+    """groups: lists of per-image tensors (same shape / dtype within a list, 4- or 8-byte dtypes, contiguous).  -> one stacked tensor
+    per list holding block [0] of every image ([I, *shape[1:]]), built by subgc_gather_blocks from ONE uploaded address table."""
+    dev = groups[0][0].device
+    ptrs, alive = [], []
+    for ts in groups:
+        for t in ts:
+            t = t if t.is_contiguous() else t.contiguous()
+            alive.append(t)
+            ptrs.append(t.data_ptr())
+    table = torch.tensor(ptrs, dtype=torch.int64).to(dev)
+    outs, o = [], 0
+    for ts in groups:
+        I, t0 = len(ts), ts[0]
+        words = t0[0].numel() * t0.element_size() // 4
+        out = torch.empty((I,) + tuple(t0.shape[1:]), device=dev, dtype=t0.dtype)
+        call("subgc_gather_blocks", _ptr(table[o:o + I], torch.int64), I, words, out.data_ptr(), _stream())
+        outs.append(out)
+        o += I
+    return outs
+
+
+def decode_batch_finish(seq, seqlp, bounds):
+    """The per-image early break of a batched decode (subgc_decode_batch_finish): zeroes seqlp beyond each image's break step in
+    place; `bounds`: python list of row bounds per image.  -> int32 [images, 2] on the device: (break step, stopped at all)."""
+    dev = seq.device
+    b = torch.tensor(bounds, dtype=torch.int32).to(dev)                             # one small upload
+    out = torch.empty(len(bounds) - 1, 2, device=dev, dtype=torch.int32)
+    if not (seq.is_contiguous() and seqlp.is_contiguous()):
+        raise SubgcError("decode_batch_finish: contiguous seq / seqlp")
+    call("subgc_decode_batch_finish", _ptr(seq, torch.int64), _ptr(seqlp, torch.float32), _ptr(b, torch.int32), len(bounds) - 1, seq.size(1), _ptr(out),
+         _stream())
+    return out
+
+
+def nms_compact(keep_all, n_keep, offsets32, images, total):
+    """-> (keep int64 [total], glob int64 [total]): the NMS survivors in image order (subgc_nms_compact)."""
+    dev = keep_all.device
+    keep = torch.empty(total, device=dev, dtype=torch.int64)
+    glob = torch.empty(total, device=dev, dtype=torch.int64)
+    call("subgc_nms_compact", _ptr(keep_all, torch.int64), _ptr(n_keep, torch.int32), _ptr(offsets32, torch.int32), int(images), int(total),
+         _ptr(keep), _ptr(glob), _stream())
+    return keep, glob
+
+
+def gpn_test_prep(items, N, device, out=None):
+    """The sGPN test branch's input views for a list of images in ONE launch (subgc_gpn_test_prep; gpn.py:84-96 reads counterpart 0
+    of the loader's five copies).  items: (row, gpn_obj_ind [5,2,M,N], att_masks [5,2,M,N], gpn_pool_mtx [5,2,M,N,N]) per image.
+    One small upload (the segment offsets and the three tensor addresses per image); no torch op touches the loader tensors.
+    `out`: namespace with idx / lens capacity buffers to write into (the one-image decode's static buffers).
+    -> (idx int64 [G,N], w [G,N], denom fp32 [G], lens int32 [G], img int32 [G], offsets32 int32 [images+1], sizes, keepalive)"""
+    sizes = [int(g.size(1) * g.size(2)) for _, g, _, _ in items]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    G, I = offs[-1], len(items)
+    alive, words = [], list(offs)
+    for row, g, a, p_ in items:
+        g, a, p_ = (t if t.is_contiguous() else t.contiguous() for t in (g, a, p_))
+        if g.dtype != torch.int64 or a.dtype != torch.float32 or p_.dtype != torch.float32:
+            raise SubgcError("gpn_test_prep: gpn_obj_ind int64, att_masks / gpn_pool_mtx fp32")
+        alive += [g, a, p_]
+        words += [g.data_ptr(), p_.data_ptr(), a.data_ptr(), int(row)]
+    table = torch.tensor(words, dtype=torch.int64).to(device)                        # the one upload of the selection phase
+    e = lambda *sh, dt=torch.float32: torch.empty(*sh, device=device, dtype=dt)
+    idx = out.idx[:G] if out is not None else e(max(G, 0), N, dt=torch.int64)
+    lens = out.lens[:G] if out is not None else e(G, dt=torch.int32)
+    w, denom, img, o32 = e(G, N), e(G), e(G, dt=torch.int32), e(I + 1, dt=torch.int32)
+    call("subgc_gpn_test_prep", _ptr(table, torch.int64), I, G, N, _ptr(idx, torch.int64), _ptr(w), _ptr(denom), _ptr(lens, torch.int32), _ptr(img, torch.int32),
+         _ptr(o32, torch.int32), _stream())
+    return idx, w, denom, lens, img, o32, sizes, (alive, table)
+
+
+def _words(t):
+    """A contiguous tensor of a 4- or 8-byte dtype as its [rows, 4-byte words] float32 view (bit-level row operations)."""
+    if not t.is_contiguous() or t.element_size() not in (4, 8):
+        raise SubgcError(f"need a contiguous 4- or 8-byte tensor, got {t.dtype} {tuple(t.shape)} / {t.stride()}")
+    t2 = t.view(t.size(0), -1) if t.dim() >= 1 and t.numel() else t.reshape(max(t.size(0) if t.dim() else 1, 0), -1)
+    return t2.view(torch.float32) if t2.dtype != torch.float32 else t2
+
+
+def zero_(t):
+    """t[...] = 0 for a contiguous tensor of any 4- or 8-byte dtype (all-zero bits; subgc_fill_f32 on the word view)."""
+    if t.numel():
+        fill_(_words(t.view(-1, 1) if t.dim() == 1 else t), 0.0)
+    return t
+
+
+def copy_(dst, src):
+    """Bit copy between contiguous tensors of one dtype and shape (subgc_copy2d_f32 on the word views)."""
+    if dst.dtype != src.dtype or dst.shape != src.shape:
+        raise SubgcError(f"copy_: {src.dtype} {tuple(src.shape)} -> {dst.dtype} {tuple(dst.shape)}")
+    if src.numel():
+        a, b = _words(src.view(1, -1)), _words(dst.view(1, -1))
+        call("subgc_copy2d_f32", _ptr(a), a.size(1), _ptr(b), b.size(1), 1, a.size(1), 0, _stream())
+    return dst
+
+
+def take_rows(pairs, rows):
+    """dst[m] = src[rows[m]] for up to four (src, dst) pairs of any 4- / 8-byte dtype in ONE launch, `rows` int64 on the device
+    (subgc_gather_rows_multi_i64): 1-D tensors count as one-column rows."""
+    if not 1 <= len(pairs) <= 4:
+        raise SubgcError("take_rows takes 1..4 (src, dst) pairs")
+    M = rows.numel()
+    args = []
+    for src, dst in list(pairs) + [(None, None)] * (4 - len(pairs)):
+        if src is None:
+            args += [None, 0, None, 0, 0]
+            continue
+        a = _words(src.view(-1, 1) if src.dim() == 1 else src)
+        b = _words(dst.view(-1, 1) if dst.dim() == 1 else dst)
+        if a.size(1) != b.size(1) or b.size(0) < M:
+            raise SubgcError("take_rows: row widths differ or the destination is too short")
+        args += [_ptr(a), a.stride(0), _ptr(b), b.stride(0), a.size(1)]
+    call("subgc_gather_rows_multi_i64", len(pairs), *args, _ptr(rows, torch.int64), M, _stream())
+
+
+def pack_rows(lens, idx, img, S, N, off=None):
     dev = lens.device
-    off = torch.empty(S, device=dev, dtype=torch.int32)
+    off = torch.empty(S, device=dev, dtype=torch.int32) if off is None else off
     total = torch.empty(1, device=dev, dtype=torch.int32)
     src = torch.empty(S * N, device=dev, dtype=torch.int32)
     sent = torch.empty(S * N, device=dev, dtype=torch.int32)
