@@ -230,6 +230,13 @@ def decode_bench(model_sd, dev, images, M):
     m.sample_images(batches[:nbb], opt=bopt)
     torch.cuda.synchronize()
     tb3 = time.perf_counter()
+    out["decode_batched_roofline"] = gemm_roofline_of(
+        lambda: [m.sample_images(batches[i:i + group], opt=sopt) for i in range(0, images, group)], "greedy_batched",
+        f"sample_images over {images} images, {group} per decode batch: encoder + scoring + NMS + token loop; every GEMM of one pass")
+    out["decode_batched_roofline"]["whole_pass_frac"] = round(out["decode_batched_roofline"]["gemm_gflop"] / 1e3 / (dt / 2) / MFMA_F32_PEAK_TFLOPS, 4)
+    out["decode_beam2_batched_roofline"] = gemm_roofline_of(lambda: m.sample_images(batches[:nbb], opt=bopt), "beam2_batched",
+                                                            f"sample_images with beam_size 2 over {nbb} images as one search")
+    out["decode_beam2_batched_roofline"]["whole_pass_frac"] = round(out["decode_beam2_batched_roofline"]["gemm_gflop"] / 1e3 / (tb3 - tb2) / MFMA_F32_PEAK_TFLOPS, 4)
     out.update({"decode_beam2_ms_per_image": round(1e3 * (tb1 - tb0) / nb, 3), "decode_beam2_batched_ms_per_image": round(1e3 * (tb3 - tb2) / nbb, 3),
                 "decode_beam2_config": f"beam_size 2 (test.sh Sub_GC_Kar), candidate bookkeeping on the device; batched = {nbb} images per search"})
     out.update({"decode_batched_tokens_per_s": round(tokens / dt, 1), "decode_batched_ms_per_image": round(1e3 * dt / (2 * images), 3),
@@ -260,6 +267,47 @@ def pmc_traffic(config, batch, world, launches_per_step):
         return round(p["traffic_bytes_per_launch"]), (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE x 2.0 (gfx950 halves wide reads; calibrated in "
                                                       "profiles/r02_pmc_calibration.txt) + WRITE_SIZE (exact), separate passes")
     return None, note
+
+
+def decode_pmc(leg):
+    """HBM bytes per GEMM launch of a decode leg from the committed PMC passes (tools/pmc_decode_legs.sh -> profiles/rNN_pmc_decode_legs.json)."""
+    for rnd in ("r04",):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_decode_legs.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f).get(leg)
+            if d:
+                return d, f"profiles/{rnd}_pmc_decode_legs.json"
+    return None, None
+
+
+def gemm_roofline_of(fn, leg, note):
+    """MFMA roofline block of a decode leg: `fn()` runs the leg's workload once.  One pass with every GEMM launch bracketed by HIP events
+    on its stream (subgc_prof_enable: launches, summed kernel time), one pass with the exact FLOP / algorithmic-byte accounting of
+    ops.gemm, both untimed; `traffic` from the committed PMC passes of the same workload when its launch count matches."""
+    _lib.prof_enable("gemm", True)
+    fn()
+    torch.cuda.synchronize()
+    _lib.prof_enable("gemm", False)
+    n_launch, gemm_ms, _ = _lib.prof_collect("gemm")
+    ops.FLOPS.update(on=True, gemm=0.0, gemm_bytes=0.0, gemm_calls=0)
+    fn()
+    torch.cuda.synchronize()
+    ops.FLOPS["on"] = False
+    flops, calls = ops.FLOPS["gemm"], max(ops.FLOPS["gemm_calls"], 1)
+    ach = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    pmc, src = decode_pmc(leg)
+    traffic, tnote = None, "no committed PMC pass for this leg (tools/pmc_decode_legs.sh)"
+    if pmc is not None:
+        if pmc.get("gemm_launches_per_pass") == n_launch:
+            traffic, tnote = round(pmc["traffic_bytes_per_launch"]), f"{src}: rocprofv3 --pmc FETCH_SIZE x 2.0 + WRITE_SIZE, separate passes over the same workload"
+        else:
+            tnote = f"{src} was taken with {pmc.get('gemm_launches_per_pass')} GEMM launches per pass, this run has {n_launch}"
+    return {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32; decode batch = the kept sub-graph rows of the step)",
+            "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": tnote,
+            "algorithmic_bytes_per_launch": round(ops.FLOPS["gemm_bytes"] / calls), "gemm_launches": n_launch, "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
+            "gemm_ms": round(gemm_ms, 3), "gemm_gflop": round(flops / 1e9, 2), "note": note}
 
 
 def roofline_block(cfg, batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm_ms, ms_per_step, traffic, traffic_note, steps):
@@ -352,14 +400,17 @@ def mrnn_decode_leg(dev, images=6, M=500, seed0=900, model_sd=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tf = tokens * DECODE_MFLOP_PER_TOKEN * 1e6 / dt / 1e12
+    if True:
+        roof = gemm_roofline_of(lambda: [m(*synthetic.sample_args(b), opt=sopt, mode="sample") for b in batches], "mrnn",
+                                f"the {images} timed calls again: every GEMM launch of encode + scoring + token loop (~900 kept rows per step)")
+        roof["whole_call_frac"] = round(roof["gemm_gflop"] / 1e3 / dt / MFMA_F32_PEAK_TFLOPS, 4)
+        roof["nominal_76_mflop_per_token_tflops"] = round(tf, 2)
     res = {"metric": "decode tokens/sec, Sub_GC_MRNN top-k sampling", "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": 1,
            "ms_per_step": round(1e3 * dt / images, 3), "step": "one image (one model call)", "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Sub_GC_MRNN decode (BASELINE.json configs[3], test.sh:20-30): {2 * M} candidate sub-graphs/image -> NMS 0.55 -> "
                                   f"keep <= 1000 -> top-k sampling k=3 T=0.6, 20 tokens, one image per call, {images} images",
                       "kept_subgraphs_per_image": round(rows / images, 1)},
-           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (decode batch = the image's kept sub-graphs, ~900 rows per token step)",
-                        "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                        "note": f"whole call (encode + score + node-set NMS + token loop) / {DECODE_MFLOP_PER_TOKEN} MFLOP per sentence-token (SURVEY 8d)"}}
+           "roofline": roof}
     del m, batches
     torch.cuda.empty_cache()
     return res, tokens, dt
@@ -404,15 +455,17 @@ def decode_bench_sharded(model_sd, dev, rank, world, per_rank=64, M=50):
     full = parallel.gather_by_index(local, idx, total)
     fence()
     tok2, dt2 = agg(sum(r[0].numel() for r in local), time.perf_counter() - t0)
+    roof2 = gemm_roofline_of(lambda: m.sample_images(mine, opt=sopt), "greedy_batched_sharded", f"rank 0's share ({per_rank} images) as one decode batch")
     del m, mine
     torch.cuda.empty_cache()
-    _, tok3, dt3 = mrnn_decode_leg(dev, images=3, M=500, seed0=900 + 16 * rank, model_sd=None)
+    leg3, tok3, dt3 = mrnn_decode_leg(dev, images=3, M=500, seed0=900 + 16 * rank, model_sd=None)
     fence()
     tok3, dt3 = agg(tok3, dt3)
     return {"decode_tokens_per_s": round(tok1 / dt1, 1), "decode_ms_per_image": round(1e3 * dt1 / per_rank, 3),
             "decode_config": f"greedy, {2 * M} candidate sub-graphs/image -> NMS 0.75 -> <=10 kept x 20 tokens, one image per call, {per_rank} images per "
                              f"rank round-robin over {world} ranks, one all_gather_object of the results at the end (timed)",
             "decode_batched_tokens_per_s": round(tok2 / dt2, 1), "decode_batched_config": f"sample_images: each rank's {per_rank} images as one decode batch, gathered at the end",
+            "decode_batched_roofline": roof2, "decode_mrnn_topk_roofline": leg3["roofline"],
             "decode_mrnn_topk_tokens_per_s": round(tok3 / dt3, 1),
             "decode_mrnn_topk_config": "test.sh Sub_GC_S_MRNN: 1000 candidates/image, NMS 0.55, keep <= 1000, top-k 3 @ 0.6, one image per call, 3 images per rank"}
 
