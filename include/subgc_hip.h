@@ -317,6 +317,16 @@ int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, 
                         int rows_h, int rows_h2, int bf16_bits, int gemm_flags, void* workspace, size_t ws_bytes,
                         void* stream);
 
+/* ... with a hipEvent_t (may be NULL) that `stream` waits for BETWEEN the product and the cell update: the g1 rows (x -> gates) may still
+ * be in production on another stream while the product runs (scheduled sampling, AttModel.py:157-167: the sampled words' embedding and
+ * x -> gates rows are computed beside the recurrent product instead of in front of it).                                                */
+int subgc_lstm_fwd_gemm_ev(const void* x, int64_t ldx, const void* w, int64_t ldw, int K, float* pre, int64_t ldpre,
+                           const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1,
+                           const float* c_prev, float* c, void* h, int64_t ldh, void* h2, int64_t ldh2,
+                           const uint8_t* keep, float keep_scale, void* hdrop, int64_t ldhd, float* gates, int S, int R,
+                           int rows_h, int rows_h2, int bf16_bits, int gemm_flags, void* workspace, size_t ws_bytes,
+                           void* event_before_cell, void* stream);
+
 /* dh (up to two sources summed: dh_a, dh_b, either may be NULL) and dc (may be NULL) ->
  * dpre [S,4R] and dc_prev.  dh_drop (optional) is a gradient that arrives through the dropout
  * mask (keep/keep_scale).                                                                    */
@@ -621,6 +631,13 @@ int subgc_caption_labels(const int64_t* captions, int64_t ld, int S, int seq_len
  * tok[r * tok_stride] = inverse-CDF draw (index order, u[r]) from softmax(logits[r, :V]); other rows keep their word.
  * `logits` may be raw or log-normalised (the draw is shift-invariant).                                              */
 int subgc_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* scheduled sampling on the rows that FIRE only: ss_plan lists, per step t >= 1, the rows r < live[t] whose selector uniform is below
+ * prob (fired [T, S] int32, ascending; count [T]; step 0 fires nothing); multinomial_rows_list draws for row rows[i] (i < *count) from the
+ * COMPACT logits row i -- with a gathered GEMM (subgc_gemm_f32 a_rows / m_dev) the previous step's logits exist only for those rows.   */
+int subgc_ss_plan(const float* sel_u, int64_t ld_sel, const int32_t* live, float prob, int T, int S, int32_t* fired, int32_t* count,
+                  void* stream);
+int subgc_multinomial_rows_list(const float* logits, int64_t ld, int max_rows, int V, const int32_t* rows, const int32_t* count,
+                                const float* u, int64_t* tok, int64_t tok_stride, void* stream);
 int subgc_multinomial_rows(const float* logits, int64_t ld, int rows, int V, const float* u, const float* sel_u,
                            float prob, int64_t* tok, int64_t tok_stride, void* stream);
 

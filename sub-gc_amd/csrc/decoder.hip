@@ -713,6 +713,16 @@ SUBGC_API int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int
                                   void* h, int64_t ldh, void* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, void* hdrop,
                                   int64_t ldhd, float* gates, int S, int R, int rows_h, int rows_h2, int bf16_bits, int gemm_flags,
                                   void* workspace, size_t ws_bytes, void* stream) {
+    return subgc_lstm_fwd_gemm_ev(x, ldx, w, ldw, K, pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd,
+                                  gates, S, R, rows_h, rows_h2, bf16_bits, gemm_flags, workspace, ws_bytes, nullptr, stream);
+}
+// ... with a hipEvent the stream waits for BETWEEN the product and the cell update: g1 (the x->gates rows) may still be in production on
+// another stream while the product runs (scheduled sampling: the sampled words' rows, functions_packed.py)
+SUBGC_API int subgc_lstm_fwd_gemm_ev(const void* x, int64_t ldx, const void* w, int64_t ldw, int K, float* pre, int64_t ldpre, const float* g1,
+                                     int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c,
+                                     void* h, int64_t ldh, void* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, void* hdrop,
+                                     int64_t ldhd, float* gates, int S, int R, int rows_h, int rows_h2, int bf16_bits, int gemm_flags,
+                                     void* workspace, size_t ws_bytes, void* event_before_cell, void* stream) {
     // bf16_bits: bit 0 = x and w are bf16 (subgc_gemm_bf16 arithmetic), bit 1 = the h destinations are bf16
     SUBGC_REQUIRE(S >= 0 && R > 0 && K > 0, "lstm_fwd_gemm: bad sizes");
     if (S == 0) return SUBGC_OK;
@@ -732,11 +742,19 @@ SUBGC_API int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int
                                     nullptr, nullptr, 0, nullptr, 1.f, 0, nullptr, workspace, ws_bytes, stream)
                   : subgc_gemm_f32(0, 1, S, 4 * R, K, static_cast<const float*>(x), ldx, static_cast<const float*>(w), ldw, pre, ldpre, nullptr, nullptr, 0,
                                    nullptr, 1.f, gemm_flags & ~15, nullptr, nullptr, nullptr, workspace, ws_bytes, stream);
-        return rc != SUBGC_OK ? rc
-                              : subgc_lstm_fwd(pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates,
-                                               S, R, rows_h, rows_h2, h_bf16, stream);
+        if (rc != SUBGC_OK) return rc;
+        if (event_before_cell && hipStreamWaitEvent(s, (hipEvent_t)event_before_cell, 0) != hipSuccess) {
+            subgc::set_error("lstm_fwd_gemm: hipStreamWaitEvent failed");
+            return SUBGC_ELAUNCH;
+        }
+        return subgc_lstm_fwd(pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2,
+                              h_bf16, stream);
     }
     if (rc != SUBGC_OK) return rc;
+    if (event_before_cell && hipStreamWaitEvent(s, (hipEvent_t)event_before_cell, 0) != hipSuccess) {
+        subgc::set_error("lstm_fwd_gemm: hipStreamWaitEvent failed");
+        return SUBGC_ELAUNCH;
+    }
     if (rows_h <= 0 || rows_h > S) rows_h = S;
     if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
     const int64_t n = (int64_t)S * R;

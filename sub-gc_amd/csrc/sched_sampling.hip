@@ -69,7 +69,92 @@ __global__ __launch_bounds__(256) void multinomial_rows_kernel(const float* __re
     if (threadIdx.x == 0) tok[(int64_t)r * tok_stride] = pick_s;
 }
 
+// the same draw for a LIST of rows: workgroup i < *count draws for sentence row rows[i] from the COMPACT logits row i (the loss-only
+// decoder computes the previous step's logits only for the rows whose selector fired: subgc_ss_plan + a gathered GEMM)
+__global__ __launch_bounds__(256) void multinomial_list_kernel(const float* __restrict__ logits, int64_t ld, int V, const int32_t* __restrict__ rows,
+                                                               const int32_t* __restrict__ count, const float* __restrict__ u,
+                                                               int64_t* __restrict__ tok, int64_t tok_stride) {
+    __shared__ float part[256];
+    __shared__ float smf[16];
+    __shared__ int pick_s;
+    if ((int)blockIdx.x >= *count) return;
+    const int r = rows[blockIdx.x];
+    const float* p = logits + (int64_t)blockIdx.x * ld;
+    const int CH = (V + 255) / 256;
+    const int lo = threadIdx.x * CH, hi = min(V, lo + CH);
+    float mx = -INFINITY;
+    for (int c = lo; c < hi; ++c) mx = fmaxf(mx, p[c]);
+    mx = block_max(mx, smf);
+    float s = 0.f;
+    for (int c = lo; c < hi; ++c) s += expf(p[c] - mx);
+    part[threadIdx.x] = s;
+    if (threadIdx.x == 0) pick_s = V - 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float run = 0.f;
+        for (int i = 0; i < 256; ++i) { const float v = part[i]; part[i] = run; run += v; }
+        smf[0] = run;
+    }
+    __syncthreads();
+    const float target = u[r] * smf[0];
+    const float before = part[threadIdx.x];
+    const float after = threadIdx.x == 255 ? INFINITY : part[threadIdx.x + 1];
+    if (lo < hi && target >= before && target < after) {
+        float run = before;
+        int pick = hi - 1;
+        for (int c = lo; c < hi; ++c) {
+            run += expf(p[c] - mx);
+            if (target < run) { pick = c; break; }
+        }
+        pick_s = pick;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tok[(int64_t)r * tok_stride] = pick_s;
+}
+
+// fired[t][0 .. count[t]) = the rows r < live[t] with sel[t][r] < prob, ascending (AttModel.py:158-160: sample_mask = uniform < ss_prob): one
+// workgroup per step, ordered compaction by wave ballots
+__global__ __launch_bounds__(256) void ss_plan_kernel(const float* __restrict__ sel, int64_t ld_sel, const int32_t* __restrict__ live, float prob, int S,
+                                                      int32_t* __restrict__ fired, int32_t* __restrict__ count) {
+    __shared__ int wave_base[4], total_s;
+    const int t = blockIdx.x, m = min(live[t], S), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) total_s = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < m; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        const bool hit = t > 0 && r < m && sel[(int64_t)t * ld_sel + r] < prob;       // step 0 always takes <bos>
+        const unsigned long long b = __ballot(hit);
+        if (lane == 0) wave_base[wave] = __popcll(b);
+        __syncthreads();
+        int base = total_s;
+        for (int w = 0; w < wave; ++w) base += wave_base[w];
+        if (hit) fired[(int64_t)t * S + base + __popcll(b & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (threadIdx.x == 0) total_s += wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[t] = total_s;
+}
+
 }  // namespace
+
+SUBGC_API int subgc_ss_plan(const float* sel_u, int64_t ld_sel, const int32_t* live, float prob, int T, int S, int32_t* fired, int32_t* count,
+                            void* stream) {
+    SUBGC_REQUIRE(T >= 0 && S > 0 && ld_sel >= S, "ss_plan: bad sizes");
+    if (T == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(sel_u && live && fired && count, "ss_plan: null pointer");
+    hipLaunchKernelGGL(ss_plan_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, sel_u, ld_sel, live, prob, S, fired, count);
+    return subgc::check_launch("subgc_ss_plan");
+}
+
+SUBGC_API int subgc_multinomial_rows_list(const float* logits, int64_t ld, int max_rows, int V, const int32_t* rows, const int32_t* count, const float* u,
+                                          int64_t* tok, int64_t tok_stride, void* stream) {
+    SUBGC_REQUIRE(max_rows >= 0 && V > 0 && ld >= V && tok_stride >= 1, "multinomial_rows_list: bad sizes");
+    if (max_rows == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(logits && rows && count && u && tok, "multinomial_rows_list: null pointer");
+    hipLaunchKernelGGL(multinomial_list_kernel, dim3(max_rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, rows, count, u, tok, tok_stride);
+    return subgc::check_launch("subgc_multinomial_rows_list");
+}
 
 SUBGC_API int subgc_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
     SUBGC_REQUIRE(n >= 0 && offset % 4 == 0, "uniform: bad arguments");

@@ -244,15 +244,22 @@ class AttModel(CaptionModel):
 
     def flatten_grads(self):
         """Point every .grad into one flat fp32 buffer (zeroed); dead parameters contribute zeros."""
-        if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
+        fresh = self.flat_grads is None or self.flat_grads.device != self.flat_params.device
+        if fresh:
             self.flat_grads = torch.zeros_like(self.flat_params)
         elif self.flat_grads.is_cuda:
             ops.fill_(self.flat_grads, 0.0)
         else:
             self.flat_grads.zero_()
-        for name, p in self._pmap.items():
-            o, n, shape = self._slots[name]
-            p.grad = self.flat_grads[o:o + n].view(shape)
+        # re-binding 100 .grad attributes costs ~0.25 ms of host time per step: keep the views, and only bind again when somebody
+        # replaced or dropped one (optimizer.zero_grad(set_to_none=True), p.grad = None)
+        views = self.__dict__.get("_grad_views")
+        if fresh or views is None or any(p.grad is not views[name] for name, p in self._pmap.items()):
+            views = {}
+            for name, p in self._pmap.items():
+                o, n, shape = self._slots[name]
+                views[name] = p.grad = self.flat_grads[o:o + n].view(shape)
+            self.__dict__["_grad_views"] = views
         return self.flat_grads
 
     def grad_buckets(self):
