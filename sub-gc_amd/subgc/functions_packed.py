@@ -25,6 +25,9 @@ from . import functions as F_
 from . import ops
 
 
+SS_FIRED_ROWS_ONLY = True     # scheduled sampling: draw-chain on the fired rows only, beside the recurrent product (False: every live row, in line)
+
+
 class Plan:
     """The packed decoder's row plan, built by ONE launch (subgc_live_plan): sentences ordered by live steps (a step t of sentence s
     is live iff mask_t[s, t'] > 0 for some t' >= t and the reference's early break, AttModel.py:171-172, has not happened), the
@@ -94,15 +97,26 @@ class PackedDecoderLossFn(Function):
         pr = F_.make_prepared(meta, fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale, W if bf else None, rows=plan.inv32)
 
         # scheduled sampling (AttModel.py:157-167; see functions.DecoderFn): input words, x->gates and logits go step by step
+        # Two forms.  `fast_ss` (fp32 operands): everything is first computed teacher-forced in the batched launches of the p = 0 path;
+        # at step t >= 1 only the rows whose selector FIRED (subgc_ss_plan: ~p of the live rows) get the previous step's logits (a
+        # gathered GEMM), a draw, a new embedding row and a new x -> gates row (gathered / scattered GEMM) -- and that chain runs on a
+        # SIDE stream beside the attention LSTM's recurrent product, which does not need x_t; only the cell update waits for it
+        # (subgc_lstm_fwd_gemm_ev).  The per-step form below (all live rows, in line) remains for bf16 operands.
         ss = meta.get("ss")
         tokens_p = labels_p
+        fast_ss = ss is not None and not bf and rows > 0 and T_live > 0 and SS_FIRED_ROWS_ONLY
         if ss is not None:
-            tokens_p = labels_p[:, :T].clone()
             sel_p, u_p = ss[1].index_select(1, perm).contiguous(), ss[2].index_select(1, perm).contiguous()
+            if not fast_ss:
+                tokens_p = labels_p[:, :T].clone()
         xt = act(max(rows, 1), E)
         Gx = new(max(rows, 1), 4 * R)
         tok_flat = k_flat = None
-        if ss is None and rows > 0:
+        if fast_ss:
+            fired, fcnt = ops.ss_plan(sel_p, plan.plan[:T], ss[0])
+            lg_c = new(S, V1)                                   # the fired rows' logits of the previous step, compact
+            side, ev_lang = ops.side_stream(dev), torch.cuda.Event()
+        if (ss is None or fast_ss) and rows > 0:
             # all T steps' input words in packed order -> ONE embedding launch (and one in the backward) instead of one per step;
             # the dropout keep-mask is random, so its first `rows` rows serve the packed rows as they are
             tok_flat = tok_all[:rows]
@@ -143,7 +157,19 @@ class PackedDecoderLossFn(Function):
             m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
             o1 = ot[t + 1]
             mn_ = max(mn, 1)                                    # row limit 0 means "all" in the C ABI: write 1 dummy row into the slack
-            if ss is not None:
+            ev_ss = None
+            if fast_ss and t >= 1:
+                op, mp = ot[t - 1], M[t - 1]
+                side.wait_event(ev_lang)                        # h2_{t-1} (Hout) is there
+                with torch.cuda.stream(side):
+                    ft, ct = fired[t], fcnt[t:t + 1]
+                    ops.gemm(Hout[op:op + mp], W[21], lg_c[:mp], tb=True, bias=lg_b, a_rows=ft[:mp], m_dev=ct)
+                    ops.multinomial_rows_list_(lg_c[:mp], ft, ct, u_p[t], tok_flat[o:o + m])
+                    ops.embed_fwd(emb, tok_flat[o:o + m], 1, None if k_flat is None else k_flat[o:o + m], scale, xt[o:o + m])
+                    ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True, a_rows=ft[:m], c_rows=ft[:m], m_dev=ct)
+                    ev_ss = torch.cuda.Event()
+                    ev_ss.record(side)
+            elif ss is not None and not fast_ss:
                 if t >= 1:                                      # raw logits of every row live at step t-1; draws for the rows still live now
                     op, mp = ot[t - 1], M[t - 1]
                     ops.gemm(Hout[op:op + mp], W[21], logits[op:op + mp], tb=True, bias=lg_b)
@@ -151,14 +177,17 @@ class PackedDecoderLossFn(Function):
                 ops.embed_fwd(emb, tokens_p[:, t], tokens_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[o:o + m])
                 ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True)
             ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
-                              H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
+                              H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_, event=ev_ss)
             nq, sq = ops.gemm_planes(H2[o:o + m, R:2 * R], W[17], QP, tb=True)   # the query product stays as split-K planes: the attention
             pr.attn_fwd(AH[o:o + m], an_w, an_b, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R, q=(QP, nq, sq, h2a_b))   # kernel sums them (+ bias) into AH
 
             ops.lstm_fwd_gemm(H2[o:o + m], Wc2, pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R],
                               H2[o1:o1 + mn_, 2 * R:], None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R,
                               rows_h=mn_, rows_h2=mn_)
-        if ss is None:
+            if fast_ss:
+                ev_lang = torch.cuda.Event()
+                ev_lang.record()
+        if ss is None or fast_ss:
             ops.gemm(Hout[:rows], W[21], logits[:rows], tb=True, bias=lg_b)
         elif T_live > 0:
             op = ot[T_live - 1]

@@ -66,6 +66,18 @@ def _ws(t):
 
 
 _CAPTURE_STREAMS = {}
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device for work that runs BESIDE the main launch sequence (scheduled sampling's per-step draw chain
+    next to the recurrent product); it gets its own split-K workspace like any stream (ensure_workspace)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return st
 
 
 class graph_capture:
@@ -774,9 +786,10 @@ def lstm_fwd(g0, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S,
          int(rows_h2), _same_storage(h, h2, hdrop), _stream())
 
 
-def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0):
+def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0, event=None):
     """gemm(x, w^T) + lstm_fwd with the split-K reduce folded into the cell kernel (subgc_lstm_fwd_gemm); `pre` [S, 4R] is scratch.
-    x, w both fp32 or both bf16; h / h2 / hdrop all fp32 or all bf16."""
+    x, w both fp32 or both bf16; h / h2 / hdrop all fp32 or all bf16.  `event` (torch.cuda.Event): the stream waits for it between the
+    product and the cell update (g1 may still be in production on another stream while the product runs)."""
     L = lambda t: ld(t) if t is not None else 0
     K = x.size(1)
     xb = int(is_b16(x))
@@ -787,10 +800,10 @@ def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdro
         FLOPS["gemm"] += 2.0 * S * 4 * R * K
         FLOPS["gemm_bytes"] += eb * (S * K + K * 4 * R) + 4.0 * S * 4 * R
         FLOPS["gemm_calls"] += 1
-    call("subgc_lstm_fwd_gemm", _ptr(x), ld(x), _ptr(w), ld(w), K, _ptr(pre, torch.float32), ld(pre),
+    call("subgc_lstm_fwd_gemm_ev", _ptr(x), ld(x), _ptr(w), ld(w), K, _ptr(pre, torch.float32), ld(pre),
          _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c), _ptr(h), L(h), _ptr(h2), L(h2),
          _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h), int(rows_h2),
-         xb | (_same_storage(h, h2, hdrop) << 1), GEMM_MODES[gemm_mode.current], *_ws(x), _stream())
+         xb | (_same_storage(h, h2, hdrop) << 1), GEMM_MODES[gemm_mode.current], *_ws(x), None if event is None else event.cuda_event, _stream())
 
 
 def gemm_planes(a, b, planes, *, ta=False, tb=False):
@@ -1178,6 +1191,23 @@ def multinomial_rows_(logits, u, sel_u, prob, tok):
     rows, V = logits.shape
     call("subgc_multinomial_rows", _ptr(logits, torch.float32), ld(logits), rows, V, _ptr(u, torch.float32), _ptr(sel_u, torch.float32),
          float(prob), _ptr(tok, torch.int64), tok.stride(0) if tok.dim() else 1, _stream())
+    return tok
+
+
+def ss_plan(sel_u, live, prob):
+    """Scheduled sampling's fired rows per step (subgc_ss_plan): sel_u fp32 [T, S] selector uniforms, live int32 [T] (device) live rows per
+    step.  -> (fired int32 [T, S], count int32 [T]): fired[t][:count[t]] = rows r < live[t] with sel_u[t][r] < prob (none at t = 0)."""
+    T, S = sel_u.shape
+    fired = torch.empty(T, S, device=sel_u.device, dtype=torch.int32)
+    count = torch.empty(T, device=sel_u.device, dtype=torch.int32)
+    call("subgc_ss_plan", _ptr(sel_u, torch.float32), sel_u.stride(0), _ptr(live, torch.int32), float(prob), T, S, _ptr(fired), _ptr(count), _stream())
+    return fired, count
+
+
+def multinomial_rows_list_(logits, rows, count, u, tok):
+    """tok[rows[i]] <- draw from softmax(logits[i]) for i < *count (compact logits rows; subgc_multinomial_rows_list)."""
+    call("subgc_multinomial_rows_list", _ptr(logits, torch.float32), ld(logits), logits.size(0), logits.size(1), _ptr(rows, torch.int32),
+         _ptr(count, torch.int32), _ptr(u, torch.float32), _ptr(tok, torch.int64), tok.stride(0) if tok.dim() else 1, _stream())
     return tok
 
 
