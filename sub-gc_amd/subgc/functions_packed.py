@@ -25,7 +25,13 @@ from . import functions as F_
 from . import ops
 
 
-SS_FIRED_ROWS_ONLY = True     # scheduled sampling: draw-chain on the fired rows only, beside the recurrent product (False: every live row, in line)
+# Scheduled sampling, second form (opt-in): the draw chain on the FIRED rows only (gathered logits product, list multinomial, gathered /
+# scattered x -> gates product) on a side stream beside the attention LSTM's recurrent product.  Built because round 3's review asked for
+# it; measured SLOWER than the in-line all-rows form and therefore off: 22.47 vs 21.61 ms per step at p = 0.25 (p = 0: 20.39).  Why
+# (tools/ss_probe.py, 161 fired rows of 640): the chain is 49 + 21 + 6 + 28 us of small launches per step on top of the complete batched
+# p = 0 work, against +76 us net for the in-line form, whose full-row products REPLACE their batched counterparts at ~80 % of their
+# efficiency; and the side stream buys nothing, because the recurrent product's 480 workgroups hold every CU slot until it ends.
+SS_FIRED_ROWS_ONLY = False
 
 
 class Plan:
