@@ -130,6 +130,37 @@ def linear(x, W, b=None, add=None, keep=None, scale=1.0, relu=False, W16=None, x
     return y.view(*shp[:-1], W.size(0)) if x.dim() != 2 else y
 
 
+class StageMark:
+    """Counts the marked tensors of one forward whose gradient has arrived; the last one announces the gradient slice `stage`
+    (grads_ready): every parameter gradient DOWNSTREAM of the marked tensors is final by then."""
+
+    def __init__(self, stage):
+        self.stage, self.pending = stage, 0
+
+    def __call__(self, x):
+        if x is None or not x.requires_grad:
+            return x
+        self.pending += 1
+        return StageMarkFn.apply(x, self)
+
+
+class StageMarkFn(Function):
+    """Identity whose backward tells its StageMark that this tensor's gradient is complete (it sits between a tensor and ALL its consumers)."""
+
+    @staticmethod
+    def forward(ctx, x, mark):
+        ctx.mark = mark
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        m = ctx.mark
+        m.pending -= 1
+        if m.pending == 0:
+            grads_ready(m.stage)
+        return g, None
+
+
 class UnitPairFn(Function):
     """The two collection units that read the SAME source rows (graph_conv.py:24-25 units 0,1 read the relation rows, :31-32 units 2,3
     the node rows; each unit = fc_rgt(fc_lft(x)), graph_conv_unit.py:28-30) as one Function:

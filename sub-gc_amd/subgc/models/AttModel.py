@@ -148,6 +148,7 @@ class AttModel(CaptionModel):
             add_lin("obj_emb_proj", L, Ew)
         sp.append(("sg_pred_embed.weight", (self.sg_pred_cnt, Ew), ("normal", 1.0)))
         add_lin("pred_emb_prj", L, Ew)
+        self._gcn_first = len(sp)            # [fusion projections | GCN units, sGPN]: the second part is final before the fusion backward runs
         for l in range(self.GCN_layers):
             for ua in (0, 2):
                 # the two units of a pair read the same source rows (graph_conv.py:24-25, 31-32): their fc_lft weights (and biases) lie side
@@ -212,7 +213,7 @@ class AttModel(CaptionModel):
             _attach(self, name, nn.Parameter(view))
             self._slots[name] = (o, n, shape)
         self.decoder_offset = offs[self._decoder_first]
-        self._bucket_bounds = (0, offs[self._decoder_first], offs[self._recurrent_first], offs[self._logit_first], total)
+        self._bucket_bounds = (0, offs[self._gcn_first], offs[self._decoder_first], offs[self._recurrent_first], offs[self._logit_first], total)
         if self.GCN_use_bn:
             for l in range(self.GCN_layers):
                 for u in range(4):
@@ -265,10 +266,11 @@ class AttModel(CaptionModel):
     def grad_buckets(self):
         """[(stage, lo, hi)] element ranges of the flat gradient buffer in READINESS order of the backward: "logit" (final before
         the BPTT loop starts), "recurrent" (LSTMs, h2att, alpha_net, word embedding: final after the loop's batched weight-gradient
-        products), "prepare" (fc_embed, att_embed, ctx2att), "encoder" (everything upstream of the decoder, final when backward
-        returns).  The decoder Functions announce the first three through functions.on_grads_ready(stage)."""
-        e0, p0, r0, l0, end = self._bucket_bounds
-        return [("logit", l0, end), ("recurrent", r0, l0), ("prepare", p0, r0), ("encoder", e0, p0)]
+        products), "prepare" (fc_embed, att_embed, ctx2att), "gcn" (GCN units and the sGPN / read-out layers: final when the gradient
+        reaches the fusion outputs, functions.StageMark), "fusion" (obj_v_proj and the class-embedding projections: final when backward
+        returns).  The decoder Functions announce the first three through functions.grads_ready(stage), `_encode`'s markers the fourth."""
+        f0, g0, p0, r0, l0, end = self._bucket_bounds
+        return [("logit", l0, end), ("recurrent", r0, l0), ("prepare", p0, r0), ("gcn", g0, p0), ("fusion", f0, g0)]
 
     def P(self, name):
         return self._pmap[name]
@@ -477,6 +479,11 @@ class AttModel(CaptionModel):
             p = self._class_proj("sg_pred_embed.weight", "pred_emb_prj", pc).view(B, K, L)
         if self.GCN_layers == 0:
             return x
+        if torch.is_grad_enabled() and F_.on_grads_ready is not None:
+            # data-parallel training: when the gradient has come back to the fusion outputs, every GCN / sGPN parameter gradient is
+            # final -- the "gcn" slice of the bucket goes out while the fusion layers' backward (obj_v_proj: the last product) still runs
+            mark = F_.StageMark("gcn")
+            x, p = mark(x), mark(p)
         rel_ind = rel_ind.contiguous()
         ptr, edges = ops.csr_build(rel_ind, N)
         skip_x, skip_p = x, p

@@ -4,12 +4,13 @@ ONE flat fp32 gradient bucket all-reduced over RCCL/xGMI.
 Replaces reference `train.py:96-98` (`nn.DataParallel`: per-iteration parameter broadcast of 280 MB,
 input scatter, loss gather, gradient reduce-add to GPU 0).  Here parameters are replicated once,
 every rank runs fwd+bwd on its own shard and the gradients - which already live contiguously in
-`model.flat_grads` - are summed in four readiness-ordered collectives (GradBucketReducer):
+`model.flat_grads` - are summed in five readiness-ordered collectives (GradBucketReducer):
 
   * logit.* (final before the BPTT loop starts) overlaps the whole recurrent backward;
   * the recurrent slice (LSTMs, h2att, alpha_net, word embedding: 54 % of the bytes) is sent when the loop's
     batched weight-gradient products are enqueued and overlaps the prepare-feature and encoder backward;
-  * the prepare-feature slice follows, then the encoder slice when backward returns.
+  * the prepare-feature slice follows, the GCN / sGPN slice when the gradient reaches the fusion outputs, and the
+    fusion projections' slice (13 MB) when backward returns.
 
 Averaging over ranks reproduces DataParallel's mean of per-replica losses (train.py:154-156);
 BatchNorm statistics stay per rank, as they do under DataParallel.  Parameters that receive no
@@ -113,7 +114,8 @@ class GradBucketReducer:
         logit      (38 MB at Sub_GC_Kar)  final right after the criterion backward, BEFORE the BPTT loop: overlaps the whole loop
         recurrent  (152 MB: both LSTMs, h2att, alpha_net, the word embedding)  final after the loop's batched weight-gradient products
         prepare    (31 MB: fc_embed, att_embed, ctx2att)  final after the prepare-feature backward
-        encoder    (59 MB: fusion projections, GCN units, sGPN)  final when backward returns (`finish`)
+        gcn        (46 MB: GCN units, sGPN / read-out layers)  final when the gradient reaches the fusion outputs (functions.StageMark)
+        fusion     (13 MB: obj_v_proj, class embeddings and their projections)  final when backward returns (`finish`)
 
     The decoder Functions announce a slice through functions.on_grads_ready(stage) (they write their gradients straight into the
     bucket, so no autograd hook fires for them); the post-accumulate-grad hooks cover the generic autograd path.  Each collective is
@@ -126,7 +128,7 @@ class GradBucketReducer:
         self.model, self.group = model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_initialized())
-        self.buckets = model.grad_buckets()                     # [(stage, lo, hi)], readiness order, the encoder last
+        self.buckets = model.grad_buckets()                     # [(stage, lo, hi)], readiness order, the fusion layers last
         self.split = model.decoder_offset
         self.overlap = overlap and self.active
         self._pending, self._launched, self._fired = [], [], {}
@@ -136,7 +138,7 @@ class GradBucketReducer:
         if self.overlap:
             from . import functions as F_
             F_.on_grads_ready = self._ready
-            early = [(st, lo, hi) for st, lo, hi in self.buckets if st != "encoder"]
+            early = [(st, lo, hi) for st, lo, hi in self.buckets if st != "fusion"]
             for n, p in model.named_parameters():
                 o = model._slots[n][0]
                 for st, lo, hi in early:
@@ -172,7 +174,7 @@ class GradBucketReducer:
         return self.model.flatten_grads()
 
     def finish(self, average=True):
-        """Call after loss.backward(): reduces whatever has not been sent yet (the encoder slice; every slice when nothing
+        """Call after loss.backward(): reduces whatever has not been sent yet (the fusion slice; every slice when nothing
         overlapped -- adjacent ranges travel as one collective), waits for all of it and averages (`average=False`: leave the SUM
         and hand `1 / world` to `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep)."""
         if not self.active:

@@ -1,6 +1,6 @@
 """N>1 path on CPU: two `gloo` ranks shard one batch by image, compute their shard's gradients
 (with the CPU oracle standing in for the device compute), all-reduce the flat gradient bucket with
-GradBucketReducer (the three decoder slices from the post-accumulate hooks, encoder slice at the end) and must
+GradBucketReducer (the three decoder slices from the post-accumulate hooks, the encoder slices at the end) and must
 end up with the mean of the per-shard gradients - DataParallel's semantics (train.py:96-98,154-156)."""
 import os
 import socket
@@ -98,7 +98,7 @@ def test_two_rank_gloo_bucket_allreduce_is_mean_of_shard_grads():
 
 
 def test_grad_buckets_are_contiguous_readiness_ordered_and_cover_the_flat_buffer():
-    """AttModel.grad_buckets: logit -> recurrent -> prepare -> encoder, contiguous, disjoint, covering every parameter slot, and
+    """AttModel.grad_buckets: logit -> recurrent -> prepare -> gcn -> fusion, contiguous, disjoint, covering every parameter slot, and
     every parameter lies in the slice its name says (the decoder Functions announce the slices by these names)."""
     sys.path.insert(0, os.path.join(ROOT, "sub-gc_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -108,18 +108,19 @@ def test_grad_buckets_are_contiguous_readiness_ordered_and_cover_the_flat_buffer
     for gname in ("subgc_train", "fullgc_train"):
         model = models.setup(Golden(gname).opt(caption_model="topdown"))
         b = model.grad_buckets()
-        assert [st for st, _, _ in b] == ["logit", "recurrent", "prepare", "encoder"]
+        assert [st for st, _, _ in b] == ["logit", "recurrent", "prepare", "gcn", "fusion"]
         spans = sorted((lo, hi) for _, lo, hi in b)
         assert spans[0][0] == 0 and spans[-1][1] == model.flat_params.numel()
-        assert all(spans[i][1] == spans[i + 1][0] for i in range(3))
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(4))
         where = {st: (lo, hi) for st, lo, hi in b}
         stage_of = lambda n: ("logit" if n.startswith("logit.") else
                               "prepare" if n.split(".")[0] in ("fc_embed", "att_embed", "ctx2att") else
-                              "recurrent" if n in F_.PARAM_ORDER else "encoder")
+                              "recurrent" if n in F_.PARAM_ORDER else
+                              "gcn" if n.split(".")[0] in ("gcn_backbone", "gpn_layer", "read_out_proj") else "fusion")
         for n, (o, cnt, _) in model._slots.items():
             lo, hi = where[stage_of(n)]
             assert lo <= o and o + cnt <= hi, n
-        assert where["encoder"] == (0, model.decoder_offset)
+        assert where["fusion"][0] == 0 and where["gcn"][1] == model.decoder_offset and where["fusion"][1] == where["gcn"][0]
 
 
 def test_shard_batch_splits_every_leading_dim():

@@ -1,7 +1,7 @@
 """Two ranks on the one MI355X of the test box (both on cuda:0; `gloo` carries the CUDA tensors because RCCL
 refuses two ranks on one device): the REAL model runs LossWrapper fwd+bwd on its image shard through the HIP
 path, DecoderFn's backward fires the reducer callback from the autograd thread, the flat bucket is reduced in
-four readiness-ordered slices, and both ranks must end with the mean of the per-shard gradients computed in a single process."""
+five readiness-ordered slices, and both ranks must end with the mean of the per-shard gradients computed in a single process."""
 import os
 import socket
 import sys
@@ -54,8 +54,9 @@ def _shard_step(m, models, shard, reducer=None):
              None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
     (out["lang_loss"] + out["gpn_loss"]).backward()
     if reducer is not None:
-        # the three decoder slices were sent from inside DecoderFn.backward, in readiness order, before backward returned
-        launched_early = [st for st, _ in reducer.issued] == ["logit", "recurrent", "prepare"] and len(reducer._pending) == 3
+        # the three decoder slices were sent from inside DecoderFn.backward and the GCN / sGPN slice from the fusion-output marker, in
+        # readiness order, before backward returned
+        launched_early = [st for st, _ in reducer.issued] == ["logit", "recurrent", "prepare", "gcn"] and len(reducer._pending) == 4
         flat = reducer.finish()
         torch.cuda.synchronize()
         return flat.clone(), launched_early
@@ -162,10 +163,11 @@ def test_rccl_world_size_one_pushes_the_real_280mb_bucket():
     at = lambda *ev: trace.index(ev)
     steps = [e for e in trace if e[0] == "bptt_begin"][0][1]
     assert steps >= 2
-    assert at("ready", "logit") < at("issue", "logit") < at("bptt_begin", steps) < at("bptt_end") < at("issue", "recurrent") < at("issue", "prepare")
+    assert (at("ready", "logit") < at("issue", "logit") < at("bptt_begin", steps) < at("bptt_end") < at("issue", "recurrent") < at("issue", "prepare")
+            < at("ready", "gcn") < at("issue", "gcn"))
     assert at("issue", "recurrent") == at("ready", "recurrent") + 1 and at("issue", "prepare") == at("ready", "prepare") + 1
-    assert [st for st, _ in issued] == ["logit", "recurrent", "prepare", "encoder"]
+    assert [st for st, _ in issued] == ["logit", "recurrent", "prepare", "gcn", "fusion"]
     sizes = dict(issued)
-    assert sum(sizes.values()) == nbytes and sizes["logit"] > 37e6 and sizes["recurrent"] > 150e6      # every byte of the bucket travels exactly once
+    assert sum(sizes.values()) == nbytes and sizes["logit"] > 37e6 and sizes["recurrent"] > 150e6 and sizes["fusion"] < 15e6      # every byte of the bucket travels exactly once
     assert err <= 1e-4 * scale + 1e-12, (err, scale)        # two runs of the backward differ by fp32 atomic order only
     assert 0 < moved < 1e-2
