@@ -124,7 +124,9 @@ class PackedDecoderLossFn(Function):
             side, ev_lang = ops.side_stream(dev), torch.cuda.Event()
         if (ss is None or fast_ss) and rows > 0:
             # all T steps' input words in packed order -> ONE embedding launch (and one in the backward) instead of one per step;
-            # the dropout keep-mask is random, so its first `rows` rows serve the packed rows as they are
+            # the dropout keep-mask is random, so its first `rows` rows serve the packed rows as they are (GENERATED masks only: a
+            # caller that injects masks -- the parity tests -- never gets here, AttModel._forward runs the unpacked decoder for them,
+            # where mask row (t, s) belongs to step t of sentence s)
             tok_flat = tok_all[:rows]
             k_flat = None if k_xt is None else k_xt.view(-1, E)[:rows]
             ops.embed_fwd(emb, tok_flat, 1, k_flat, scale, xt[:rows])
