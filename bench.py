@@ -342,7 +342,7 @@ def train_config_leg(name, dev, steps=8, warmup=3):
         out = lw(*lw_args(batch))
         loss = models.total_loss(out)
         loss.backward(one)
-        adam.step()
+        adam.step(zero_grad=True)
         return loss
 
     for _ in range(warmup):
@@ -525,7 +525,7 @@ def main():
         loss.backward(one)                                # d(loss) = 1, a resident scalar (no fill launch per step)
         red.finish(average=adam is None)                 # with the optimizer on, 1/world rides in its sweep
         if adam is not None:
-            adam.step(grad_scale=1.0 / world)
+            adam.step(grad_scale=1.0 / world, zero_grad=True)        # step + the iteration's optimizer.zero_grad() in one sweep
         return loss
 
     def timed_sampled(n_steps):

@@ -687,6 +687,11 @@ int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* stream);
 int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                          int step, float grad_scale, uint16_t* p_bf16, void* stream);
+/* the same sweep with `optimizer.zero_grad()` (train.py calls it once per iteration) folded in: g is left ZEROED
+ * instead of scaled and clipped, so the next iteration needs no fill pass over the gradient buffer.             */
+int subgc_clip_adam_step_zero(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
+                              float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              int step, float grad_scale, uint16_t* p_bf16, void* stream);
 
 /* ======================================================================================
  * The teacher-forced recurrence as ONE call per direction (AttModel.py:157-175: the T-step loop around TopDownCore, :400-431).

@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
 }
+template <bool ZERO>       // ZERO: the gradient is left ZEROED (optimizer.zero_grad() fused into the sweep) instead of scaled and clipped
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, const float* __restrict__ sumsq,
                                                         float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
     const float coef = gscale * (max_norm > 0.f ? max_norm / fmaxf(sqrtf(sumsq[0]) * gscale, max_norm) : 1.f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gi = g[i] * coef;
-        g[i] = gi;
+        g[i] = ZERO ? 0.f : gi;
         if (wd != 0.f) gi += wd * p[i];
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -615,6 +616,7 @@ __global__ __launch_bounds__(256) void sumsq_vec_kernel(const float4* __restrict
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
 }
+template <bool ZERO>
 __global__ __launch_bounds__(256) void clip_adam_vec_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                             float4* __restrict__ v, int64_t n4, const float* __restrict__ sumsq,
                                                             float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1,
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void clip_adam_vec_kernel(float4* __restrict__
             const float denom = sqrtf(vi) / rs2 + eps;
             pp[e] = pp[e] - step * (mi / denom);
         }
-        g[i] = G; m[i] = M; v[i] = V; p[i] = P;
+        g[i] = ZERO ? make_float4(0.f, 0.f, 0.f, 0.f) : G; m[i] = M; v[i] = V; p[i] = P;
         if (p16) *reinterpret_cast<uint2*>(p16 + 4 * i) = subgc_pack4(P.x, P.y, P.z, P.w);
     }
 }
@@ -1065,23 +1067,38 @@ SUBGC_API int subgc_sumsq_f32(const float* g, int64_t n, float* sumsq, void* str
     hipLaunchKernelGGL(sumsq_kernel, dim3(std::min(ew_grid(n), 1024)), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
     return subgc::check_launch("subgc_sumsq_f32");
 }
-SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, uint16_t* p_bf16,
-                                   void* stream) {
+namespace {
+template <bool ZERO>
+int clip_adam_launch(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float grad_scale, uint16_t* p_bf16, void* stream) {
     SUBGC_REQUIRE(n >= 0 && step >= 1 && grad_scale > 0.f, "clip_adam_step: bad arguments");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(p && g && m && v && sumsq, "clip_adam_step: null pointer");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (n % 4 == 0 && al(p) && al(g) && al(m) && al(v) && (reinterpret_cast<uintptr_t>(p_bf16) & 7) == 0) {
-        hipLaunchKernelGGL(clip_adam_vec_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(p),
+        hipLaunchKernelGGL(clip_adam_vec_kernel<ZERO>, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(p),
                            reinterpret_cast<float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n / 4, sumsq, max_norm, lr,
                            beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, p_bf16);
         return subgc::check_launch("subgc_clip_adam_step");
     }
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr, beta1,
+    hipLaunchKernelGGL(clip_adam_kernel<ZERO>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr, beta1,
                        beta2, eps, weight_decay, bc1, bc2, grad_scale, p_bf16);
     return subgc::check_launch("subgc_clip_adam_step");
+}
+}  // namespace
+
+SUBGC_API int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, uint16_t* p_bf16,
+                                   void* stream) {
+    return clip_adam_launch<false>(p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step, grad_scale, p_bf16, stream);
+}
+// the same sweep with optimizer.zero_grad() (train.py: called once per iteration) folded in: g is left ZEROED instead of scaled and clipped,
+// so the next step needs no fill pass over the gradient buffer
+SUBGC_API int subgc_clip_adam_step_zero(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm, float lr,
+                                        float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, uint16_t* p_bf16,
+                                        void* stream) {
+    return clip_adam_launch<true>(p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step, grad_scale, p_bf16, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -249,7 +249,11 @@ class AttModel(CaptionModel):
         if fresh:
             self.flat_grads = torch.zeros_like(self.flat_params)
         elif self.flat_grads.is_cuda:
-            ops.fill_(self.flat_grads, 0.0)
+            # FlatAdam.step(zero_grad=True) left the buffer zeroed through raw pointers (no torch version bump): nothing to fill, unless a
+            # torch op has written to it since (its version counter moved)
+            z = self.__dict__.pop("_grads_are_zero", None)
+            if z != (self.flat_grads.data_ptr(), self.flat_grads._version):
+                ops.fill_(self.flat_grads, 0.0)
         else:
             self.flat_grads.zero_()
         # re-binding 100 .grad attributes costs ~0.25 ms of host time per step: keep the views, and only bind again when somebody
@@ -655,6 +659,7 @@ class AttModel(CaptionModel):
         `need_outputs=False` (LossWrapper only wants the loss) `outputs` is None and the decoder runs packed."""
         B, N, _ = att_feats.shape
         dev = att_feats.device
+        self.__dict__.pop("_grads_are_zero", None)      # a backward may follow: "the optimizer left the gradient buffer zeroed" ends here
         L, R, E = self.GCN_dim, self.rnn_size, self.input_encoding_size
         b5, T = seq.size(0), seq.size(1) - 1
         p = self.drop_prob_lm if self.training else 0.0

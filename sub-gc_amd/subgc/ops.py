@@ -1291,6 +1291,6 @@ def sumsq(g, out):
     return out
 
 
-def clip_adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf16=None):
-    call("subgc_clip_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(max_norm), float(lr),
+def clip_adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf16=None, zero_grad=False):
+    call("subgc_clip_adam_step_zero" if zero_grad else "subgc_clip_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(max_norm), float(lr),
          float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), _ptr(p_bf16, BF16), _stream())

@@ -220,7 +220,10 @@ class FlatAdam:
         self.sumsq = torch.zeros(1, device=model.flat_params.device)
         self.t = 0
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, zero_grad=False):
+        """`zero_grad`: leave the gradient buffer ZEROED by the sweep itself (= this step followed by the `optimizer.zero_grad()` every
+        training iteration starts with, train.py) -- the next `flatten_grads` / `GradBucketReducer.prepare` then skips its fill pass over
+        the buffer.  Default: torch's semantics, the (scaled, clipped) gradients stay readable after the step."""
         from . import ops
         self.t += 1
         ops.fill_(self.sumsq, 0.0)
@@ -228,7 +231,8 @@ class FlatAdam:
         m = self.model
         snap = m.weights_b16() if getattr(m, "bf16_storage", False) else None     # compute_dtype = bf16: refreshed in the same sweep
         ops.clip_adam_step(m.flat_params, m.flat_grads, self.m, self.v, self.sumsq, self.clip, self.lr,
-                           self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale, p_bf16=snap)
+                           self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale, p_bf16=snap, zero_grad=zero_grad)
+        m.__dict__["_grads_are_zero"] = (m.flat_grads.data_ptr(), m.flat_grads._version) if zero_grad else None
         # the kernel wrote the weights through raw pointers: no torch version counter moved, so the decode-time snapshots
         # (x->gates table, K-concatenated LSTM matrices, captured hipGraphs) must be told explicitly
         m.invalidate_decode_caches()

@@ -451,6 +451,44 @@ def test_clip_adam_matches_torch():
     ops.sumsq(g, ss)
     ops.clip_adam_step(p, g, m, v, ss, 10.0, 5e-4, 0.9, 0.999, 1e-8, 0.0, 1)
     close(g, pr.grad, atol=1e-6); close(p, pr.detach(), atol=1e-6)
+    # the same sweep with the iteration's optimizer.zero_grad() folded in (subgc_clip_adam_step_zero): identical update, gradient zeroed
+    for n2 in (n, 10008):                                     # scalar and float4 forms
+        p2 = torch.cat([p0, p0[:n2 - n]]) if n2 > n else p0.clone()
+        g2 = torch.cat([g0, g0[:n2 - n]]) if n2 > n else g0.clone()
+        pa, ga = p2.clone(), g2.clone()
+        ma, va, mb, vb = (torch.zeros(n2, device=DEV) for _ in range(4))
+        s2 = torch.zeros(1, device=DEV); ops.sumsq(g2, s2)
+        ops.clip_adam_step(pa, ga, ma, va, s2, 10.0, 5e-4, 0.9, 0.999, 1e-8, 0.0, 1)
+        pb, gb = p2.clone(), g2.clone()
+        ops.clip_adam_step(pb, gb, mb, vb, s2, 10.0, 5e-4, 0.9, 0.999, 1e-8, 0.0, 1, zero_grad=True)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and float(gb.abs().max()) == 0.0 and float(ga.abs().max()) > 0
+
+
+def test_flat_adam_zero_grad_skips_the_next_fill_only_while_it_is_safe():
+    """FlatAdam.step(zero_grad=True) leaves the bucket zeroed; the next flatten_grads skips its fill pass -- but not after a forward
+    (a backward may have written gradients without a prepare in between) and not after a torch op wrote to the buffer."""
+    import argparse
+    from subgc import parallel
+    import subgc.models as models
+    from test_packed_gpu import OPT
+    torch.manual_seed(0)
+    m = models.setup(argparse.Namespace(**OPT)).to(DEV).train()
+    adam = parallel.FlatAdam(m)
+    g = m.flatten_grads()
+    g.fill_(1.0)
+    adam.step(zero_grad=True)
+    torch.cuda.synchronize()
+    assert float(g.abs().max()) == 0.0 and m.__dict__.get("_grads_are_zero") is not None
+    m.flatten_grads()
+    assert m.__dict__.get("_grads_are_zero") is None            # consumed
+    g.fill_(2.0); adam.step(zero_grad=True)
+    g.add_(3.0)                                                # a torch write after the sweep: the flag must not be trusted
+    m.flatten_grads(); torch.cuda.synchronize()
+    assert float(g.abs().max()) == 0.0
+    g.fill_(2.0); adam.step(zero_grad=False); torch.cuda.synchronize()
+    assert float(g.abs().max()) > 0.0                          # torch semantics by default: gradients stay readable
+    m.flatten_grads(); torch.cuda.synchronize()
+    assert float(g.abs().max()) == 0.0
 
 
 def test_gemm_splitk_plain_bias_and_accumulate():
