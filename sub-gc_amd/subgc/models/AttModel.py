@@ -396,8 +396,9 @@ class AttModel(CaptionModel):
             return None
         Lr, L = shp
         fp, fg = self.flat_params, self.flat_grads
-        bound = fg is not None and all(self.P(n + k).grad is not None and self.P(n + k).grad.data_ptr() == fg[self._slots[n + k][0]:].data_ptr()
-                                       for n in (na, nb) for k in ("weight", "bias"))
+        views = self.__dict__.get("_grad_views") or {}
+        bound = fg is not None and all(self.P(n + k).grad is not None and self.P(n + k).grad is views.get(n + k)
+                                       for n in (na, nb) for k in ("weight", "bias"))      # the .grad views flatten_grads bound into the flat buffer
         return (fp[ow:ow + 2 * nw].view(2 * Lr, L), fp[ob:ob + 2 * nbias],
                 fg[ow:ow + 2 * nw].view(2 * Lr, L) if bound else None, fg[ob:ob + 2 * nbias] if bound else None,
                 None if flat16 is None or L % 8 else flat16[ow:ow + 2 * nw].view(2 * Lr, L))

@@ -546,7 +546,7 @@ def subgraph_nms_batched(score, idx, lens, sizes, thres, max_keep, offsets=None,
     for n in sizes:
         offs.append(offs[-1] + int(n))
     if offsets is None:
-        offsets = torch.tensor(offs, dtype=torch.int32).to(dev)                   # one small upload
+        offsets = upload(offs, torch.int32, dev)                                  # one small upload
     keep = torch.empty(max(total, 1), device=dev, dtype=torch.int64) if keep is None else keep
     n_keep = zero_(torch.empty(len(sizes), device=dev, dtype=torch.int32))
     scratch = torch.empty(max(total, 1) * (NMS_WORDS * 8 + 8), device=dev, dtype=torch.uint8)
@@ -566,7 +566,7 @@ def stack_first(groups):
             t = t if t.is_contiguous() else t.contiguous()
             alive.append(t)
             ptrs.append(t.data_ptr())
-    table = torch.tensor(ptrs, dtype=torch.int64).to(dev)
+    table = upload(ptrs, torch.int64, dev)
     outs, o = [], 0
     for ts in groups:
         I, t0 = len(ts), ts[0]
@@ -582,12 +582,40 @@ def decode_batch_finish(seq, seqlp, bounds):
     """The per-image early break of a batched decode (subgc_decode_batch_finish): zeroes seqlp beyond each image's break step in
     place; `bounds`: python list of row bounds per image.  -> int32 [images, 2] on the device: (break step, stopped at all)."""
     dev = seq.device
-    b = torch.tensor(bounds, dtype=torch.int32).to(dev)                             # one small upload
+    b = upload(bounds, torch.int32, dev)                                            # one small upload
     out = torch.empty(len(bounds) - 1, 2, device=dev, dtype=torch.int32)
     if not (seq.is_contiguous() and seqlp.is_contiguous()):
         raise SubgcError("decode_batch_finish: contiguous seq / seqlp")
     call("subgc_decode_batch_finish", _ptr(seq, torch.int64), _ptr(seqlp, torch.float32), _ptr(b, torch.int32), len(bounds) - 1, seq.size(1), _ptr(out),
          _stream())
+    return out
+
+
+_PINNED = {}
+
+
+def upload(values, dtype, device):
+    """A small host list -> device tensor through a PINNED staging buffer and an asynchronous copy on the current stream.  (A pageable
+    `torch.tensor(...).to(device)` makes the host wait until the stream has drained -- in the one-image decode that is the whole previous
+    image's token loop.)  Two staging buffers per (device, dtype) alternate; every caller reads something back from the device
+    (survivor counts, finished beams) before it comes here a third time; an event per buffer makes that a guarantee."""
+    n = len(values)
+    key = (str(device), dtype)
+    ring = _PINNED.get(key)
+    if ring is None or ring[0][0][0].numel() < n:
+        cap = max(256, 1 << (max(n, 1) - 1).bit_length())
+        ring = _PINNED[key] = [[[torch.empty(cap, dtype=dtype).pin_memory(), None] for _ in range(2)], 0]
+    slots, turn = ring
+    ring[1] = turn ^ 1
+    buf, busy = slots[turn]
+    if busy is not None:
+        busy.synchronize()                                     # the copy that last read this staging buffer (long done in every caller's flow)
+    stage = buf[:n]
+    stage.copy_(torch.tensor(values, dtype=dtype))
+    out = stage.to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    slots[turn][1] = ev
     return out
 
 
@@ -619,7 +647,7 @@ def gpn_test_prep(items, N, device, out=None):
             raise SubgcError("gpn_test_prep: gpn_obj_ind int64, att_masks / gpn_pool_mtx fp32")
         alive += [g, a, p_]
         words += [g.data_ptr(), p_.data_ptr(), a.data_ptr(), int(row)]
-    table = torch.tensor(words, dtype=torch.int64).to(device)                        # the one upload of the selection phase
+    table = upload(words, torch.int64, device)                                      # the one upload of the selection phase (pinned, asynchronous)
     e = lambda *sh, dt=torch.float32: torch.empty(*sh, device=device, dtype=dt)
     idx = out.idx[:G] if out is not None else e(max(G, 0), N, dt=torch.int64)
     lens = out.lens[:G] if out is not None else e(G, dt=torch.int32)
