@@ -338,10 +338,19 @@ class AttModel(CaptionModel):
         out, off = {}, 0
         self._dropout_calls += 1
         seed = self._rng_seed()
-        for k, (shape, p) in shapes.items():
-            if p > 0:
-                out[k] = ops.dropout_mask(shape, p, seed, off, device)
-                off += (int(np.prod(shape)) + 3) // 4 * 4
+        live = [(k, shape, p) for k, (shape, p) in shapes.items() if p > 0]
+        if len({p for _, _, p in live}) == 1 and len(live) > 1:
+            # one keep probability (drop_prob_lm everywhere, gpn_drop_prob equal to it in every preset): the masks are consecutive
+            # 4-aligned segments of ONE Philox stream, so one launch over the concatenation produces the same bits as one launch each
+            sizes = [(int(np.prod(shape)) + 3) // 4 * 4 for _, shape, _ in live]
+            buf = ops.dropout_mask((sum(sizes),), live[0][2], seed, 0, device)
+            for (k, shape, _), n in zip(live, sizes):
+                out[k] = buf[off:off + int(np.prod(shape))].view(shape)
+                off += n
+            return out
+        for k, shape, p in live:
+            out[k] = ops.dropout_mask(shape, p, seed, off, device)
+            off += (int(np.prod(shape)) + 3) // 4 * 4
         return out
 
     # ------------------------------------------------------------------ encoder

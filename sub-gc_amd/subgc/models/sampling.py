@@ -115,7 +115,7 @@ def full_graph_rows(m, X2, N, images):
         c = cache[key] = dict(ar=ar, ones=torch.ones(n, N, device=dev), full=torch.full((n,), float(N), device=dev),
                               one=torch.ones(n, device=dev), zero=torch.zeros(n, device=dev, dtype=torch.long))
     ar = c["ar"]
-    img = torch.tensor([im[0] for im in images], dtype=torch.int32).to(dev)            # one small upload
+    img = ops.upload([im[0] for im in images], torch.int32, dev)                       # one small upload (pinned, asynchronous)
     mean, _ = ops.pool_fwd(X2, ar, N, c["ones"], N, 1, c["full"], img, n, N, L, want_argmax=False)
     h = torch.empty(n, m.att_hid_size, device=dev)
     fc = torch.empty(n, 2 * L, device=dev)

@@ -437,6 +437,13 @@ def test_dropout_mask_rate_and_determinism():
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert abs(float(a.float().mean()) - 0.5) < 5e-3
     assert abs(float(ops.dropout_mask((777, 333), 0.2, 9, 4, DEV).float().mean()) - 0.8) < 5e-3
+    # consecutive 4-aligned segments of one stream == one launch over the concatenation (AttModel._masks draws all of a forward's masks at once)
+    n1, n2, n3 = 1001, 640 * 37, 17 * 333
+    o2, o3 = (n1 + 3) // 4 * 4, (n1 + 3) // 4 * 4 + (n2 + 3) // 4 * 4
+    whole = ops.dropout_mask((o3 + n3,), 0.5, 77, 0, DEV)
+    assert torch.equal(whole[:n1], ops.dropout_mask((n1,), 0.5, 77, 0, DEV))
+    assert torch.equal(whole[o2:o2 + n2], ops.dropout_mask((n2,), 0.5, 77, o2, DEV))
+    assert torch.equal(whole[o3:o3 + n3], ops.dropout_mask((n3,), 0.5, 77, o3, DEV))
 
 
 def test_clip_adam_matches_torch():
