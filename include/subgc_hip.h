@@ -546,8 +546,9 @@ int subgc_attn_dv_accum_group(const float* alpha, int n_stride, const float* dct
  * greedy (k == 0): it = first argmax, lp = max.  top-k: lp' = log_softmax(logp/temp), keep the
  * k largest (ties -> smaller index), renormalise, draw by inverse CDF with uniform u[s];
  * lp = lp'[it].  Then unfinished &= it > 0; it *= unfinished; seq[s, t] = it; seqlp[s, t] = lp
- * (un-masked, like the reference); next_tok[s] = it; *n_unfinished accumulates the live count.
- * prev_count (device int32*, may be NULL): the live count after the previous step; when it is 0
+ * (un-masked, like the reference); next_tok[s] = it; *n_unfinished (zeroed by the caller) becomes
+ * NON-ZERO iff some row is still unfinished (a flag: plain stores, no same-address atomics).
+ * prev_count (device int32*, may be NULL): that flag after the previous step; when it is 0
  * the kernel writes nothing -- the reference has broken out of its loop (AttModel.py:318-319) --
  * so the whole decode loop runs without a host round trip.
  * raw_logits != 0: `logp` holds un-normalised logits; the kernel folds the log-softmax in (the greedy

@@ -498,7 +498,9 @@ __global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restric
         seq[(int64_t)r * T + t] = w;
         seqlp[(int64_t)r * T + t] = lp;
         next_tok[r] = w;
-        if (unf && n_unfinished) atomicAdd(n_unfinished, 1);
+        // a FLAG, not a count: every consumer only tests it against zero, and one same-address device atomic per row is what this
+        // kernel used to spend its time on (2560 rows x ~15 ns of memory-side serialisation = 38 of its 43 us)
+        if (unf && n_unfinished) *n_unfinished = 1;
     }
 }
 

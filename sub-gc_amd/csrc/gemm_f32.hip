@@ -542,6 +542,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 // Dispatch constants (measured).  The library reads NO environment variable and keeps no tunable state: what a
 // measurement script wants to switch off is a bit of the call's `flags` (SUBGC_GEMM_NO_SPLITK / SUBGC_GEMM_NO_SKINNY).
+constexpr int g_two_parts_min_kt = 32;  // two K parts for a tile count between one and two rounds of slots: K-tiles the product needs at least (round 4: 64 -> 32, see pick_tile)
 constexpr int g_smallm = 256;          // M <= this prefers the 64x64 split-K form: one 128x128 workgroup per CU is latency-bound
 constexpr int g_ragged64 = 1;          // ragged launches use 64x64 tiles
 constexpr int g_x3 = 0;                // arithmetic when a call names none: the fp32 matrix pipe
@@ -600,7 +601,7 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
         (!a.m_dev || TA) && g_ws && 2 * (size_t)a.M * a.N * sizeof(float) <= g_ws_bytes) {
         const int kt = (a.K + BK - 1) / BK;
         const double one = (double)((big + 511) / 512) * (kt + 3.0), two = (double)((2 * big + 511) / 512) * ((kt + 1) / 2 + 3.0) + 1.8;
-        if (kt >= 64 && two < 0.9 * one) return launch_splitk<128, 128, TA, TB, VEC>(a, s, 2);
+        if (kt >= g_two_parts_min_kt && two < 0.9 * one) return launch_splitk<128, 128, TA, TB, VEC>(a, s, 2);
     }
     // kernel variants: 3 = three-plane split with 16-deep stages (two workgroups per CU), 2 = single bf16 plane with 32-deep stages
     if (big >= 384) return xm == 1 ? launch<128, 128, TA, TB, VEC, VEC ? 3 : 0>(a, s) : xm == 2 ? launch<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s)
