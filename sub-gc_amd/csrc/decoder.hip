@@ -462,6 +462,32 @@ __global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restric
         sum = block_sum(sum, smf);
         const float lse = mx + logf(sum);
         int top_i[MAXK]; float top_v[MAXK];
+        if (k <= 3) {
+            // k <= 3 (the_k = 3, opts.py): ONE pass keeps every thread's own three best in registers (the global top-3 is a subset of
+            // their union), then three block arg-max rounds over one candidate per thread -- the k full passes over the 38 registers
+            // with their "after the previous pick" tests were 2.4x the greedy kernel (35 vs 15 us at 900 rows)
+            float l0 = -INFINITY, l1 = -INFINITY, l2 = -INFINITY;
+            int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int c = threadIdx.x + j * 256;        // ascending per thread: an equal value never displaces an earlier index
+                if (c < V) {
+                    const float v = x[j] - lse;
+                    if (v > l0) { l2 = l1; i2 = i1; l1 = l0; i1 = i0; l0 = v; i0 = c; }
+                    else if (v > l1) { l2 = l1; i2 = i1; l1 = v; i1 = c; }
+                    else if (v > l2) { l2 = v; i2 = c; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q < k) {                                  // k is uniform over the workgroup
+                    float bv = l0; int bi = i0;
+                    block_argmax(bv, bi, sv, si);
+                    top_i[q] = bi; top_v[q] = bv;
+                    if (bi == i0) { l0 = l1; i0 = i1; l1 = l2; i1 = i2; l2 = -INFINITY; i2 = 0x7fffffff; }    // the owner moves on to its next best
+                }
+            }
+        } else {
         float pv = INFINITY; int pi = -1;         // (value desc, index asc) is a total order: "after the previous pick" is one test
         for (int q = 0; q < k; ++q) {
             float bv = -INFINITY; int bi = 0x7fffffff;
@@ -475,6 +501,7 @@ __global__ __launch_bounds__(256) void decode_pick_kernel(const float* __restric
             block_argmax(bv, bi, sv, si);
             top_i[q] = bi; top_v[q] = bv;
             pv = bv; pi = bi;
+        }
         }
         // Categorical(logits=top): renormalise over the k, inverse CDF in top-k order
         float m2 = top_v[0];
