@@ -400,11 +400,10 @@ def mrnn_decode_leg(dev, images=6, M=500, seed0=900, model_sd=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tf = tokens * DECODE_MFLOP_PER_TOKEN * 1e6 / dt / 1e12
-    if True:
-        roof = gemm_roofline_of(lambda: [m(*synthetic.sample_args(b), opt=sopt, mode="sample") for b in batches], "mrnn",
-                                f"the {images} timed calls again: every GEMM launch of encode + scoring + token loop (~900 kept rows per step)")
-        roof["whole_call_frac"] = round(roof["gemm_gflop"] / 1e3 / dt / MFMA_F32_PEAK_TFLOPS, 4)
-        roof["nominal_76_mflop_per_token_tflops"] = round(tf, 2)
+    roof = gemm_roofline_of(lambda: [m(*synthetic.sample_args(b), opt=sopt, mode="sample") for b in batches], "mrnn",
+                            f"the {images} timed calls again: every GEMM launch of encode + scoring + token loop (~900 kept rows per step)")
+    roof["whole_call_frac"] = round(roof["gemm_gflop"] / 1e3 / dt / MFMA_F32_PEAK_TFLOPS, 4)
+    roof["nominal_76_mflop_per_token_tflops"] = round(tf, 2)
     res = {"metric": "decode tokens/sec, Sub_GC_MRNN top-k sampling", "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": 1,
            "ms_per_step": round(1e3 * dt / images, 3), "step": "one image (one model call)", "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Sub_GC_MRNN decode (BASELINE.json configs[3], test.sh:20-30): {2 * M} candidate sub-graphs/image -> NMS 0.55 -> "

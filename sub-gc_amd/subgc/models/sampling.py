@@ -364,6 +364,39 @@ def decode_one_image(m, X2, N, image, opt, uniforms=None, forced=None):
         sel = select_subgraphs(m, X2, N, [image], front=fr) if m.gpn else full_graph_rows(m, X2, N, [image])
         return decode(m, X2, N, sel, opt, uniforms, forced)[0]
     fb.load(X2)                                                                   # queued before the host read below
+    k = m.the_k if m.topk_sampling else 0
+    n_spec = min(int(m.gpn_max_subg), fr.G)
+    if (beam_size <= 1 and not return_att and uniforms is None and 0 < n_spec <= 16 and getattr(m, "decode_speculate", True)):
+        # SPECULATIVE replay: the NMS keeps at most gpn_max_subg sub-graphs and almost always exactly that many, so the token loop is
+        # queued for n_spec rows BEFORE the host knows the survivor count -- the count travels to pinned memory ahead of the replay in
+        # stream order, and the host reads it while the loop runs.  No host round trip sits between the selection and the loop any more
+        # (it cost the GPU ~35 us of idling per image), and the host may run a whole image ahead.  Rows are independent in the loop; when
+        # fewer sub-graphs survived, the surplus rows decoded stale candidates and are cut off, and the log-probs the reference would not
+        # have written after ITS early break (AttModel.py:318-319: taken over the real rows only) are zeroed (subgc_decode_batch_finish).
+        try:
+            g = _graphed_loop(m, n_spec, N, k, False, m._decoder_params(), fb)
+        except RuntimeError as e:
+            import warnings
+            warnings.warn(f"hipGraph capture of the decode loop failed ({e}); decoding eagerly from now on")
+            m.decode_hipgraph = False
+            n = int(fr.n_keep.item())
+            return decode(m, X2, N, select_subgraphs(m, X2, N, [image], front=fr, kept=[n]), opt, uniforms, forced)[0]
+        host_n = m.__dict__.get("_host_n")
+        if host_n is None:
+            host_n = m.__dict__["_host_n"] = torch.empty(1, dtype=torch.int32).pin_memory()
+        host_n.copy_(fr.n_keep, non_blocking=True)
+        arrived = torch.cuda.Event()
+        arrived.record()
+        seq, seqlp, _, _, score_out, keep_out = g.run(None, _uniforms(m, n_spec, T, X2.device) if k else None, step_major=True)
+        arrived.synchronize()
+        n = int(host_n[0])
+        if n == n_spec:
+            return (seq, seqlp, score_out, keep_out)
+        if n == 0:
+            return decode(m, X2, N, select_subgraphs(m, X2, N, [image], front=fr, kept=[0]), opt, uniforms, forced)[0]
+        seq, seqlp = seq[:n], seqlp[:n]
+        ops.decode_batch_finish(seq, seqlp, [0, n])
+        return (seq, seqlp, score_out[:n], keep_out[:n])
     n = int(fr.n_keep.item())
     if n == 0 or (beam_size > 1 and n * beam_size > 128) or (beam_size <= 1 and n > 16):
         return decode(m, X2, N, select_subgraphs(m, X2, N, [image], front=fr, kept=[n]), opt, uniforms, forced)[0]

@@ -186,7 +186,9 @@ def test_one_image_graph_path_over_varied_candidate_and_survivor_counts(golden):
     for rnd in range(2):
         for M, seed in cases:
             b = mk(M, seed)
-            for sopt in (dict(sample_max=1, beam_size=1, return_att=1), dict(sample_max=1, beam_size=2)):
+            # plain greedy takes the SPECULATIVE replay (loop queued for min(max_subg, candidates) rows before the survivor count is read;
+            # fewer survivors -> surplus rows cut, log-probs after the real rows' early break zeroed); return_att and beam 2 wait for the count
+            for sopt in (dict(sample_max=1, beam_size=1), dict(sample_max=1, beam_size=1, return_att=1), dict(sample_max=1, beam_size=2)):
                 a = mg(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")
                 e = me(*synthetic.sample_args({k: v.clone() for k, v in b.items()}), opt=sopt, mode="sample")
                 seen_n.add(a[0].size(0))
@@ -203,7 +205,7 @@ def test_one_image_graph_path_over_varied_candidate_and_survivor_counts(golden):
                             assert torch.equal(d["seq"], h["seq"]) and abs(d["p"] - h["p"]) < 1e-3
     assert len(seen_n) >= 3 and not me.__dict__.get("_graph_cache") and mg.__dict__.get("_graph_cache")
     # candidate counts 2..40 share ONE capacity class of static buffers, so graphs are keyed by survivors and mode only
-    assert len(mg._front_cache) == 1 and len(mg._graph_cache) <= 2 * len(seen_n)
+    assert len(mg._front_cache) == 1 and len(mg._graph_cache) <= 3 * len(seen_n)
 
 
 def test_empty_batches_are_no_ops():
