@@ -113,8 +113,6 @@ class PackedDecoderLossFn(Function):
         fast_ss = ss is not None and not bf and rows > 0 and T_live > 0 and SS_FIRED_ROWS_ONLY
         if ss is not None:
             sel_p, u_p = ss[1].index_select(1, perm).contiguous(), ss[2].index_select(1, perm).contiguous()
-            if not fast_ss:
-                tokens_p = labels_p[:, :T].clone()
         xt = act(max(rows, 1), E)
         Gx = new(max(rows, 1), 4 * R)
         tok_flat = k_flat = None
@@ -122,13 +120,16 @@ class PackedDecoderLossFn(Function):
             fired, fcnt = ops.ss_plan(sel_p, plan.plan[:T], ss[0])
             lg_c = new(S, V1)                                   # the fired rows' logits of the previous step, compact
             side, ev_lang = ops.side_stream(dev), torch.cuda.Event()
+        if rows > 0:
+            # the words actually fed, in packed order (ground truth; scheduled sampling overwrites the drawn ones in place) and the
+            # keep-mask rows that go with them: the backward's embedding gradient is ONE launch over them in every mode
+            tok_flat = tok_all[:rows]
+            k_flat = None if k_xt is None else k_xt.view(-1, E)[:rows]
         if (ss is None or fast_ss) and rows > 0:
             # all T steps' input words in packed order -> ONE embedding launch (and one in the backward) instead of one per step;
             # the dropout keep-mask is random, so its first `rows` rows serve the packed rows as they are (GENERATED masks only: a
             # caller that injects masks -- the parity tests -- never gets here, AttModel._forward runs the unpacked decoder for them,
             # where mask row (t, s) belongs to step t of sentence s)
-            tok_flat = tok_all[:rows]
-            k_flat = None if k_xt is None else k_xt.view(-1, E)[:rows]
             ops.embed_fwd(emb, tok_flat, 1, k_flat, scale, xt[:rows])
             ops.gemm(xt[:rows], W[9][:, 2 * R:], Gx[:rows], tb=True)
         Gf = new(S, 4 * R)
@@ -181,8 +182,8 @@ class PackedDecoderLossFn(Function):
                 if t >= 1:                                      # raw logits of every row live at step t-1; draws for the rows still live now
                     op, mp = ot[t - 1], M[t - 1]
                     ops.gemm(Hout[op:op + mp], W[21], logits[op:op + mp], tb=True, bias=lg_b)
-                    ops.multinomial_rows_(logits[op:op + m], u_p[t][:m], sel_p[t][:m], ss[0], tokens_p[:m, t])
-                ops.embed_fwd(emb, tokens_p[:, t], tokens_p.stride(0), None if k_xt is None else k_xt[t], scale, xt[o:o + m])
+                    ops.multinomial_rows_(logits[op:op + m], u_p[t][:m], sel_p[t][:m], ss[0], tok_flat[o:o + m])
+                ops.embed_fwd(emb, tok_flat[o:o + m], 1, None if k_flat is None else k_flat[o:o + m], scale, xt[o:o + m])
                 ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True)
             ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
                               H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_, event=ev_ss)
