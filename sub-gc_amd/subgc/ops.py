@@ -603,6 +603,9 @@ def upload(values, dtype, device):
     key = (str(device), dtype)
     ring = _PINNED.get(key)
     if ring is None or ring[0][0][0].numel() < n:
+        for _, busy in (ring[0] if ring is not None else ()):     # growing: the old staging buffers may still be the source of a copy in flight
+            if busy is not None:
+                busy.synchronize()
         cap = max(256, 1 << (max(n, 1) - 1).bit_length())
         ring = _PINNED[key] = [[[torch.empty(cap, dtype=dtype).pin_memory(), None] for _ in range(2)], 0]
     slots, turn = ring
