@@ -57,3 +57,25 @@ def test_eight_rank_bench_rehearsal_on_one_gpu():
     assert d["config"]["parallelism"].startswith("dp8")
     for k in ("decode_tokens_per_s", "decode_batched_tokens_per_s", "decode_mrnn_topk_tokens_per_s"):
         assert d[k] > 0, k
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("config,batch", [("full_gc_kar", 8), ("flickr", 4)])
+def test_two_rank_rehearsal_of_the_bf16_configs(config, batch):
+    """The other two train configs through the N > 1 path (two ranks on the one GPU, gloo): Full-GC has no sGPN, four BatchNorm layers
+    and shared attention sets, Flickr the 2048-d GCN -- both go through the readiness-ordered buckets (the `gcn` slice is announced by
+    the fusion-output markers of THEIR encoder graphs) and the fused Adam sweep with 1 / world folded in."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SUBGC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--steps", "2", "--warmup", "1",
+           "--batch", str(batch)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dtype"] == "bf16" and d["config"]["global_images"] == 2 * batch and d["value"] > 0
+    assert d["final_loss"] == d["final_loss"] and d["final_loss"] > 0            # finite
