@@ -105,3 +105,54 @@ def test_recurrence_issued_from_c_is_the_step_by_step_loop(kind, packed):
     assert torch.equal(g0[lo:hi][same[lo:hi]], g1[lo:hi][same[lo:hi]]), "the recurrent slice must be bit-identical"
     scale = float(g0.abs().max())
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=1e-6 * scale + 1e-9, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["subgc_f32", "fullgc_f32_bn", "subgc_bf16", "fullgc_bf16_bn"])
+def test_paired_gcn_units_equal_the_unit_by_unit_path(kind):
+    """functions.UnitPairFn (concatenated fc_lft: one N = 2 * 512 product, one K = 2 * 512 data-gradient product, one weight-gradient
+    product per pair) against the two units run one by one (`pair_gcn_units = 0`: graph_conv_unit.py:28-36 as four Linear launches per
+    pair): same loss and the same gradient for every parameter -- fp32 up to the summation order of the wider products, bf16 up to the
+    rounding of the differently accumulated bf16 intermediates."""
+    torch.manual_seed(0)
+    opt = dict(OPT)
+    if kind.startswith("fullgc"):
+        opt.update(use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1)
+    bf = "bf16" in kind
+    if bf:
+        opt.update(compute_dtype="bf16")
+    batch = synthetic.make_train_batch(6, D=256, vocab=300, n_obj_cls=60, seed=4, fc_size=256, min_len=2, max_len=16)
+    res, sd = {}, None
+    for pair in (0, 1):
+        torch.manual_seed(0)
+        m = models.setup(argparse.Namespace(**dict(opt, pair_gcn_units=pair)))
+        if sd is None:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            for k, v in sd.items():
+                if "gcn_collect" in k and "weight" in k and "bn" not in k:
+                    v.mul_(30.0)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        assert bool(m.pair_gcn_units) == bool(pair)
+        m.packed_decoder = True
+        lw = models.LossWrapper(m, None)
+        b = {k: v.to(DEV) for k, v in batch.items()}
+        m.flatten_grads()
+        out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
+                 None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+        models.total_loss(out).backward()
+        torch.cuda.synchronize()
+        loss = float(out["lang_loss"])
+        res[pair] = (loss, {k: p.grad.clone() for k, p in m.named_parameters()})
+    (l0, g0), (l1, g1) = res[0], res[1]
+    assert abs(l0 - l1) < (2e-2 if bf else 2e-5) * max(1.0, abs(l0))
+    for k in g0:
+        a, b = g0[k].double().flatten(), g1[k].double().flatten()
+        scale = float(a.abs().max())
+        if scale == 0.0:
+            assert float(b.abs().max()) == 0.0, k                        # dead parameters stay dead
+            continue
+        if bf:
+            cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+            assert cos > 0.99, (k, cos)
+        else:
+            np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=3e-5 * scale + 1e-9, rtol=3e-4, err_msg=k)
