@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmcd_$C
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmcd_$C -- python $R/tools/decode_bench.py 16 50 > $O/pmcd_$C.log 2>&1

@@ -1,10 +1,10 @@
-# End-of-round evidence (ROUND=r03 by default): the default bench line, the bf16 config lines, rocprofv3 kernel stats of the
+# End-of-round evidence (ROUND=r04 by default): the default bench line, the bf16 config lines, rocprofv3 kernel stats of the
 # train legs and of the one-image decode, and the two PMC passes behind roofline.traffic.  Everything lands in gpurun_out/ as
 # ${ROUND}_*; copy the summaries to profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 python $R/bench.py > $O/${ROUND}_bench_n1.log 2>&1; tail -1 $O/${ROUND}_bench_n1.log > $R/profiles/${ROUND}_bench_n1.json
 cp $R/profiles/${ROUND}_bench_n1.json $O/${ROUND}_bench_n1.json          # profiles/ on the box is not merged back, gpurun_out/ is
 for C in full_gc_kar flickr; do
@@ -41,3 +41,4 @@ for C in full_gc_kar flickr; do
 done
 cut -c1-700 $R/profiles/${ROUND}_bench_n1.json; cut -c1-400 $O/${ROUND}_bench_full_gc_kar.json; cut -c1-400 $O/${ROUND}_bench_flickr.json
 head -14 $O/${ROUND}_train_kernel_stats.txt | cut -c1-150; head -12 $O/${ROUND}_full_gc_kar_kernel_stats.txt | cut -c1-150; cat $O/${ROUND}_pmc_traffic.json | head -20
+ROUND=$ROUND bash $R/tools/pmc_decode_legs.sh > $O/${ROUND}_pmc_decode_legs.log 2>&1      # GEMM traffic + kernel stats of the three throughput decode legs
