@@ -18,8 +18,6 @@ Same kernels, same C ABI calls as functions.DecoderFn; only the row bookkeeping 
 """
 from __future__ import annotations
 
-import contextlib
-
 import torch
 from torch.autograd import Function
 
@@ -34,9 +32,6 @@ from . import ops
 # p = 0 work, against +76 us net for the in-line form, whose full-row products REPLACE their batched counterparts at ~80 % of their
 # efficiency; and the side stream buys nothing, because the recurrent product's 480 workgroups hold every CU slot until it ends.
 SS_FIRED_ROWS_ONLY = False
-# Scheduled sampling, in-line form: the step's draw chain on a second stream beside the attention LSTM's recurrent product (the chain
-# only feeds that LSTM's CELL update).  Measured in DESIGN section 8.0.
-SS_SIDE_STREAM = True
 
 
 class Plan:
@@ -167,7 +162,6 @@ class PackedDecoderLossFn(Function):
                                  b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre, Gx=Gx, Gf=Gf, C1=C1, C2=C2, G1=G1, G2=G2, AH=AH, AL=AL, k_out=k_out, QP=QP,
                                  qp_bytes=QP.numel() * 4, w_a=an_w, b_a=an_b, lens=lens_p, **pr.recur_fields())
             ops.recurrence_fwd(rec, H1)
-        side_l = ev_lang_l = None
         for t in range(T_live if rec is None else 0):
             m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
             o1 = ot[t + 1]
@@ -185,24 +179,12 @@ class PackedDecoderLossFn(Function):
                     ev_ss = torch.cuda.Event()
                     ev_ss.record(side)
             elif ss is not None and not fast_ss:
-                # the draw chain of step t (previous step's logits -> draws -> embedding -> x -> gates) needs h2_{t-1} and feeds only the CELL
-                # update of the attention LSTM, not its recurrent product: with SS_SIDE_STREAM it runs on a second stream beside that product
-                # (two machine-filling launches whose tail rounds overlap) and the cell kernel waits for it (subgc_lstm_fwd_gemm_ev)
-                beside = SS_SIDE_STREAM and t >= 1
-                if beside:
-                    if side_l is None:
-                        side_l = ops.side_stream(dev)
-                    side_l.wait_event(ev_lang_l)
-                with (torch.cuda.stream(side_l) if beside else contextlib.nullcontext()):
-                    if t >= 1:                                  # raw logits of every row live at step t-1; draws for the rows still live now
-                        op, mp = ot[t - 1], M[t - 1]
-                        ops.gemm(Hout[op:op + mp], W[21], logits[op:op + mp], tb=True, bias=lg_b)
-                        ops.multinomial_rows_(logits[op:op + m], u_p[t][:m], sel_p[t][:m], ss[0], tok_flat[o:o + m])
-                    ops.embed_fwd(emb, tok_flat[o:o + m], 1, None if k_flat is None else k_flat[o:o + m], scale, xt[o:o + m])
-                    ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True)
-                    if beside:
-                        ev_ss = torch.cuda.Event()
-                        ev_ss.record(side_l)
+                if t >= 1:                                      # raw logits of every row live at step t-1; draws for the rows still live now
+                    op, mp = ot[t - 1], M[t - 1]
+                    ops.gemm(Hout[op:op + mp], W[21], logits[op:op + mp], tb=True, bias=lg_b)
+                    ops.multinomial_rows_(logits[op:op + m], u_p[t][:m], sel_p[t][:m], ss[0], tok_flat[o:o + m])
+                ops.embed_fwd(emb, tok_flat[o:o + m], 1, None if k_flat is None else k_flat[o:o + m], scale, xt[o:o + m])
+                ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True)
             ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
                               H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_, event=ev_ss)
             nq, sq = ops.gemm_planes(H2[o:o + m, R:2 * R], W[17], QP, tb=True)   # the query product stays as split-K planes: the attention
@@ -214,9 +196,6 @@ class PackedDecoderLossFn(Function):
             if fast_ss:
                 ev_lang = torch.cuda.Event()
                 ev_lang.record()
-            elif ss is not None and SS_SIDE_STREAM:
-                ev_lang_l = torch.cuda.Event()
-                ev_lang_l.record()
         if ss is None or fast_ss:
             ops.gemm(Hout[:rows], W[21], logits[:rows], tb=True, bias=lg_b)
         elif T_live > 0:
