@@ -561,10 +561,34 @@ int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t
 }
 
 template <bool A_KM, bool B_KM>
-int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out) {
+int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out, bool may_cut_rows = true) {
     const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
                        (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias));
     const int force = (a.flags & SUBGC_GEMM_TILE128) ? 128 : (a.flags & SUBGC_GEMM_TILE256) ? 256 : 0;      // measurement scripts: tile A/B timing
+    // Row cut (round 4).  A tile count a few tiles above whole rounds of the 256 CUs costs a whole extra round: Full_GC_Kar's 16 640 relation
+    // rows x 1024 columns are 65 x 4 = 260 tiles of 256 x 256 -- 1.016 rounds, timed like two (86 us against 45 for 16 384 rows).  When the
+    // rows beyond the last whole round are few, the whole rounds go out as one launch and the remaining rows as a second one with its own
+    // plan (small tiles, split K): two disjoint row ranges of the same product.  A stored row-major (not K-major), no device-side row count.
+    if (may_cut_rows && !partials_only && !A_KM && !a.m_dev && force == 0) {
+        const int64_t tn = subgc::cdiv(a.N, 256), tm = subgc::cdiv(a.M, 256);
+        if (tn <= 256 && 256 % tn == 0) {
+            const int64_t per_round = 256 / tn;                                   // row tiles of one full round
+            const int64_t whole = tm / per_round * per_round;                     // row tiles in whole rounds
+            const int64_t M1 = whole * 256, rest = a.M - M1;
+            if (whole >= per_round && rest > 0 && rest <= 2 * 256 && rest * 8 <= M1) {
+                Args head = a, tail = a;
+                head.M = (int)M1;
+                tail.M = (int)rest;
+                tail.A = a.A + M1 * a.lda;
+                if (a.C32) tail.C32 = a.C32 + M1 * a.ldc32;
+                if (a.C16) tail.C16 = a.C16 + M1 * a.ldc16;
+                if (a.add) tail.add = a.add + M1 * a.ldadd;
+                if (a.keep) tail.keep = a.keep + M1 * (int64_t)a.N;
+                if (int rc = run<A_KM, B_KM>(head, ws, ws_bytes, s, false, splits_out, false)) return rc;
+                return run<A_KM, B_KM>(tail, ws, ws_bytes, s, false, nullptr, false);
+            }
+        }
+    }
     Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes, a.C32 != nullptr);
     if (partials_only) {                                        // the LSTM cell kernel adds row-major planes: 128x128 split form only
         pl = Plan{0, 1, 0.0};

@@ -128,3 +128,26 @@ def test_cast_transpose_and_copy_kernels():
     xb = torch.randn(777, 4000, generator=g).to(DEV).to(BF)
     cs = ops.colsum(xb)
     np.testing.assert_allclose(cs.cpu().numpy(), xb.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode,M,N,K", [("nt", 16640, 1024, 512), ("nn", 16640, 1024, 1024), ("nt", 16900, 1024, 264), ("nt", 8448, 512, 256)])
+def test_gemm_bf16_row_cut_shapes(mode, M, N, K):
+    """Shapes whose 256 x 256 tile count is a whole number of 256-workgroup rounds plus a sliver (Full_GC_Kar's 16640-row GCN products:
+    260 tiles) run as two launches, the whole rounds and the remaining rows with their own plan (gemm_bf16.hip run()); every epilogue
+    operand is row-offset with them."""
+    a, b, ref = operands(mode, M, N, K, seed=11, lda_pad=8, ldb_pad=8)
+    bias, add = rnd(N, seed=5), rnd(M, N, seed=6)
+    keep = (torch.rand(M, N, generator=torch.Generator().manual_seed(7)) < 0.5).to(torch.uint8).to(DEV)
+    want = torch.relu(ref + bias.double() + add.double()) * keep.double() * 2.0
+    out = torch.full((M, N), float("nan"), device=DEV)
+    o16 = torch.empty(M, N + 64, device=DEV, dtype=BF)[:, :N]
+    ops.gemm(a, b, out, tb=mode == "nt", bias=bias, add=add, relu=True, keep=keep, keep_scale=2.0, out16=o16)
+    scale = float(want.abs().max())
+    assert float((out.double() - want).abs().max()) < 2e-5 * scale
+    assert torch.equal(o16, out.to(BF))
+    plain = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(a, b, plain, tb=mode == "nt")
+    assert float((plain.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    acc = add.clone()
+    ops.gemm(a, b, acc, tb=mode == "nt", accum=True)
+    assert float((acc.double() - ref - add.double()).abs().max()) < 2e-5 * float(ref.abs().max())
