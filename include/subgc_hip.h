@@ -117,6 +117,17 @@ int subgc_gemm_workspace_bytes(int M, int N, int K, size_t* bytes);
  * it 256-row slabs are merged with atomics.                                                                              */
 int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
                      const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
+/* Weight gradient AND bias gradient of one linear layer in one call (the backward of every nn.Linear / nn.LSTMCell product of
+ * models/AttModel.py:363-366,376-377,386,411-413,421-423,453 and models/lib/graph_conv_unit.py:29-30; autograd's
+ * `grad_weight = grad_output.t().mm(input)` and `grad_bias = grad_output.sum(0)`):
+ *   dW[M, N] (+)= dY^T X   and   db[M] (+)= sum_k dY[k, :]      with dY stored [K, M], X stored [K, N] (rows = samples).
+ * The workgroups that own tile column 0 of dW add up the dY tiles they stage anyway, so dY is not read a second time and the separate
+ * column-sum launches (subgc_colsum_f32 + its finish pass) disappear; sums are formed in a fixed order (no float atomics).
+ * flags: SUBGC_GEMM_ACCUM (dW is added to) and the SUBGC_GEMM_MODE_* bits (the opt-in arithmetics run as the two separate passes);
+ * db_accumulate: db is added to; m_dev: device-side bound on K (live rows); workspace as subgc_gemm_f32 (its last 32 M bytes hold
+ * the split-K forms' partial column sums).                                                                                        */
+int subgc_gemm_f32_wgrad(int M, int N, int K, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
+                         float* db, int flags, int db_accumulate, const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
 /* the same over bf16 rows: bias gradients from bf16-stored gate / logit gradients */
 int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, float* out, int accumulate,
                       const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
@@ -599,6 +610,11 @@ int subgc_gemm_bf16(int transA, int transB, int M, int N, int K, const uint16_t*
                     const float* add, int64_t ldadd, const uint8_t* keep, float keep_scale, int flags,
                     const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
 int subgc_gemm_bf16_workspace_bytes(int M, int N, int K, size_t* bytes);
+/* subgc_gemm_f32_wgrad over bf16-STORED dY [K, M] and X [K, N]: dW[M, N] (+)= dY^T X and db[M] (+)= sum_k dY[k, :], both fp32; the column
+ * sums are read from the tile images of dY already in LDS (workgroups of tile column 0), fixed summation order.  Alignment rules of
+ * subgc_gemm_bf16 (bases 16 bytes, lddy / ldx multiples of 8); flags: SUBGC_GEMM_ACCUM for dW, db_accumulate for db.                 */
+int subgc_gemm_bf16_wgrad(int M, int N, int K, const uint16_t* dY, int64_t lddy, const uint16_t* X, int64_t ldx, float* dW, int64_t lddw,
+                          float* db, int flags, int db_accumulate, const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
 /* y[r, :cols_pad] = bf16(x[r, :cols]) with zero padding columns (cols_pad % 8 == 0, ldy % 8 == 0); rows bounded by *m_dev */
 int subgc_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, int cols_pad,
                         const int32_t* m_dev, void* stream);

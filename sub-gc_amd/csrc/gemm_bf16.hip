@@ -34,7 +34,13 @@ struct Args {
     int64_t lda, ldb, ldc32, ldc16, ldadd;
     int M, N, K, flags;
     float keep_scale;
+    // subgc_gemm_bf16_wgrad (K-major A only): column sums of the stored A -- the bias gradient beside the weight gradient
+    float* cs_out = nullptr;         // [M] (cs_accum: added to)
+    float* cs_part = nullptr;        // [splits][M] partial sums of the split-K form (tail of the caller's workspace)
+    int cs_accum = 0;
 };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;                                         // K per LDS stage
 constexpr int ROWB = BK * 2;                                   // bytes per LDS row of a K-contiguous image
@@ -237,10 +243,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename G, bool A_KM, bool B_KM>
+// CS: the workgroup also sums the columns of its K-major A tiles (cs[e] = sum over this thread's k-rows of tile column 8 c + e, c =
+// t % (TBM / 8)): one ds_read_b128 of the landed image per thread and 16 k-rows (issued before the first 16-deep step, consumed behind its
+// wait), nothing extra from memory.  `do_cs` is workgroup-uniform (tile column 0).
+template <typename G, bool A_KM, bool B_KM, bool CS = false>
 __device__ __forceinline__ void mainloop_dma(const Args& p, unsigned char* smem, int M, int K, int m0, int n0, int kt0, int kt1,
-                                             f32x16 (&acc)[G::MA][G::NB]) {
+                                             f32x16 (&acc)[G::MA][G::NB], float* cs = nullptr, bool do_cs = false) {
 #if defined(__HIP_DEVICE_COMPILE__)       // gfx950 builtins inside: hipcc's host pass gets an empty body
+    static_assert(!CS || A_KM, "column sums are read from the K-major image of A");
+    constexpr int CS_PER = G::TBM * 4 / G::NT;                  // (16-byte chunk, k-row) pairs of the A image per thread: 2 (128 x 128), 1 (256 x 256)
+    if constexpr (CS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    }
+    const uint32_t cs_off = CS ? (uint32_t)swz_km<G::TBM>((int)threadIdx.x / (G::TBM / 8), (int)threadIdx.x % (G::TBM / 8)) : 0u;
     if (kt1 <= kt0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int MA = G::MA, NB = G::NB;
@@ -291,7 +307,29 @@ __device__ __forceinline__ void mainloop_dma(const Args& p, unsigned char* smem,
     };
     auto compute = [&](const unsigned char* st) {
         static_assert(BK == 32, "two 16-deep steps per stage");
+        u32x4 q[CS_PER];
+        if constexpr (CS) {
+            if (do_cs) {
+                const uint32_t addr = (uint32_t)(uintptr_t)SUBGC_LDS(st) + cs_off;
+#pragma unroll
+                for (int j = 0; j < CS_PER; ++j)                // k-rows k and k + 16: the swizzle only depends on k & 3
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[j]) : "v"(addr), "n"(j * 16 * (G::TBM * 2)));
+            }
+        }
         step(st, std::integral_constant<int, 0>{});
+        if constexpr (CS) {
+            if (do_cs) {                                        // the step's own lgkmcnt(0) covered these reads (LDS returns in order)
+                if constexpr (CS_PER == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]));
+#pragma unroll
+                for (int j = 0; j < CS_PER; ++j)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        cs[2 * d] += __uint_as_float(q[j][d] << 16);
+                        cs[2 * d + 1] += __uint_as_float(q[j][d] & 0xffff0000u);
+                    }
+            }
+        }
         step(st, std::integral_constant<int, 1>{});
     };
     auto issue = [&](int f) {                                  // full tile f (0-based in this unit) -> stage f % NSTAGE
@@ -385,7 +423,27 @@ __device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[G::MA][G::NB],
     }
 }
 
-template <typename G, bool A_KM, bool B_KM>
+// The column sums a workgroup's threads hold after mainloop_dma<.., CS = true>: thread t has columns 8 (t % (TBM/8)) .. +7 over its k-rows;
+// the NT / (TBM/8) row groups meet in LDS (everybody is past the last stage read after the barrier) and thread m < TBM stores column
+// m0 + m.  Fixed summation order.
+template <typename G>
+__device__ __forceinline__ void colsum_store(unsigned char* smem, const float (&cs)[8], int m0, int M, float* dst, bool accum) {
+    constexpr int CH = G::TBM / 8, GR = G::NT / CH;
+    float* red = reinterpret_cast<float*>(smem);
+    const int t = threadIdx.x;
+    __syncthreads();
+    float* mine = red + (t / CH) * G::TBM + (t % CH) * 8;
+    *reinterpret_cast<float4*>(mine) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    *reinterpret_cast<float4*>(mine + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+    __syncthreads();
+    if (t < G::TBM && m0 + t < M) {
+        float v = 0.f;
+        for (int g = 0; g < GR; ++g) v += red[g * G::TBM + t];
+        dst[m0 + t] = accum ? dst[m0 + t] + v : v;
+    }
+}
+
+template <typename G, bool A_KM, bool B_KM, bool CS = false>
 __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = (p.m_dev && !A_KM) ? min(p.M, *p.m_dev) : p.M;
@@ -397,7 +455,11 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
     const int m0 = tm * G::TBM, n0 = tn * G::TBN;
     f32x16 acc[G::MA][G::NB];
     zero_acc(acc);
-    mainloop_dma<G, A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+    if constexpr (CS) {
+        float cs[8];
+        mainloop_dma<G, A_KM, B_KM, true>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc, cs, n0 == 0);
+        if (n0 == 0) colsum_store<G>(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);
+    } else mainloop_dma<G, A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
     // vector form: every quad is whole (N % 4 == 0) and every row start 16 / 8 bytes aligned
     const bool vec = p.N % 4 == 0 && (!p.C32 || (p.ldc32 % 4 == 0 && aligned16(p.C32))) && (!p.C16 || (p.ldc16 % 4 == 0 && aligned8(p.C16))) &&
@@ -447,7 +509,7 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
     });
 }
 
-template <typename G, bool A_KM, bool B_KM>
+template <typename G, bool A_KM, bool B_KM, bool CS = false>
 __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_splitk_kernel(const Args p, float* __restrict__ ws, int splits, int kt_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
@@ -462,7 +524,11 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
     const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
     f32x16 acc[G::MA][G::NB];
     zero_acc(acc);
-    mainloop_dma<G, A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
+    if constexpr (CS) {
+        float cs[8];
+        mainloop_dma<G, A_KM, B_KM, true>(p, smem, p.M, K, m0, n0, kt0, kt1, acc, cs, n0 == 0);
+        if (n0 == 0) colsum_store<G>(smem, cs, m0, p.M, p.cs_part + (size_t)part * p.M, false);    // an empty part stores zeros
+    } else mainloop_dma<G, A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     float* out = ws + (size_t)part * p.M * p.N;                 // raw partial plane [M][N]; N % 4 == 0 on this path
     for_each_quad<G>(acc, m0, n0, p.M, p.N, [&](int m, int n, Quad& x) {
         *reinterpret_cast<float4*>(out + (size_t)m * p.N + n) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
@@ -472,8 +538,16 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
 // C = epilogue(bias + sum_parts ws[part]); fp32 and / or bf16 destination
 __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ C32,
                                                                 int64_t ldc32, uint16_t* __restrict__ C16, int64_t ldc16,
-                                                                const float* __restrict__ bias, int accum, int relu) {
+                                                                const float* __restrict__ bias, int accum, int relu,
+                                                                const float* __restrict__ cs_part = nullptr, float* __restrict__ cs_out = nullptr,
+                                                                int cs_accum = 0) {
     const size_t plane = (size_t)M * N;
+    if (cs_part != nullptr)                                     // column sums of A that came with a weight gradient: parts added in order
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += cs_part[(size_t)s * M + m];
+            cs_out[m] = cs_accum ? cs_out[m] + v : v;
+        }
     const int n4 = N >> 2;                                      // N % 4 == 0 on this path
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / n4;
@@ -544,19 +618,41 @@ int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t
     const int64_t tiles = subgc::cdiv(a.M, G::TBM) * subgc::cdiv(a.N, G::TBN);
     const int kt = (int)subgc::cdiv(a.K, BK);
     static uint64_t attr_a = 0, attr_b = 0;
+    bool with_cs = false;
+    if constexpr (A_KM && G::TBM == 256) with_cs = a.cs_out != nullptr && !partials_only;
     if (splits <= 1) {
+        if constexpr (A_KM && G::TBM == 256) {
+            if (with_cs) {
+                static uint64_t attr_c = 0;
+                if (int rc = raise_lds(gemm_bf16_kernel<G, A_KM, B_KM, true>, G::LDS, attr_c)) return rc;
+                hipLaunchKernelGGL((gemm_bf16_kernel<G, A_KM, B_KM, true>), dim3((unsigned)tiles), dim3(G::NT), G::LDS, s, a);
+                return subgc::check_launch("subgc_gemm_bf16_wgrad");
+            }
+        }
         if (int rc = raise_lds(gemm_bf16_kernel<G, A_KM, B_KM>, G::LDS, attr_a)) return rc;
         hipLaunchKernelGGL((gemm_bf16_kernel<G, A_KM, B_KM>), dim3((unsigned)tiles), dim3(G::NT), G::LDS, s, a);
         return subgc::check_launch("subgc_gemm_bf16");
     }
-    if (int rc = raise_lds(gemm_bf16_splitk_kernel<G, A_KM, B_KM>, G::LDS, attr_b)) return rc;
-    hipLaunchKernelGGL((gemm_bf16_splitk_kernel<G, A_KM, B_KM>), dim3((unsigned)(tiles * splits)), dim3(G::NT), G::LDS, s, a, ws, splits,
-                       (kt + splits - 1) / splits);
+    bool launched = false;
+    if constexpr (A_KM && G::TBM == 256) {
+        if (with_cs) {
+            static uint64_t attr_d = 0;
+            if (int rc = raise_lds(gemm_bf16_splitk_kernel<G, A_KM, B_KM, true>, G::LDS, attr_d)) return rc;
+            hipLaunchKernelGGL((gemm_bf16_splitk_kernel<G, A_KM, B_KM, true>), dim3((unsigned)(tiles * splits)), dim3(G::NT), G::LDS, s, a, ws, splits,
+                               (kt + splits - 1) / splits);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        if (int rc = raise_lds(gemm_bf16_splitk_kernel<G, A_KM, B_KM>, G::LDS, attr_b)) return rc;
+        hipLaunchKernelGGL((gemm_bf16_splitk_kernel<G, A_KM, B_KM>), dim3((unsigned)(tiles * splits)), dim3(G::NT), G::LDS, s, a, ws, splits,
+                           (kt + splits - 1) / splits);
+    }
     if (partials_only) return subgc::check_launch("subgc_gemm_bf16(split-K, partials)");
     const int64_t n = (int64_t)a.M * a.N / 4;
     hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws,
                        splits, a.M, a.N, a.C32, a.ldc32, a.C16, a.ldc16, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0,
-                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0);
+                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum);
     return subgc::check_launch("subgc_gemm_bf16(split-K)");
 }
 
@@ -605,6 +701,17 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
         if (pl.big) pl.splits = 1;
     }
     if (splits_out) *splits_out = pl.splits;
+    if constexpr (A_KM) {
+        // Column sums ride the 256 x 256 workgroups for free (measured: 254 us with, 266 us without on 14000 x 4000 x 2000); in the 128 x 128
+        // geometry the extra read + adds show (a quarter of the workgroups own tile column 0 at N = 512: 46 + 7 us against 34 + 5 + 9.6 for
+        // the separate column-sum pass), so those plans run the two passes -- still one call.
+        if (a.cs_out && !pl.big) {
+            Args b = a;
+            b.cs_out = nullptr;
+            if (int rc = launch<G128, A_KM, B_KM>(b, ws, pl.splits, partials_only, s)) return rc;
+            return subgc_colsum_bf16(a.A, a.lda, a.K, a.M, a.cs_out, a.cs_accum, a.m_dev, ws, ws_bytes, s);   // the planes are consumed: ws is free (stream order)
+        }
+    }
     return pl.big ? launch<G256, A_KM, B_KM>(a, ws, pl.splits, partials_only, s) : launch<G128, A_KM, B_KM>(a, ws, pl.splits, partials_only, s);
 }
 
@@ -647,6 +754,34 @@ SUBGC_API int subgc_gemm_bf16(int transA, int transB, int M, int N, int K, const
     float* ws = static_cast<float*>(workspace);
     if (!transA && transB) return run<false, false>(a, ws, ws_bytes, s, false, nullptr);
     if (!transA && !transB) return run<false, true>(a, ws, ws_bytes, s, false, nullptr);
+    return run<true, true>(a, ws, ws_bytes, s, false, nullptr);
+}
+
+// Weight gradient and bias gradient in one call (see subgc_gemm_f32_wgrad): dW[M,N] (+)= dY^T X, db[M] (+)= column sums of dY; dY [K, M]
+// and X [K, N] stored bf16.  Needs the split-K plan's preconditions for its partial sums (N % 4 == 0 is checked by the plan itself).
+SUBGC_API int subgc_gemm_bf16_wgrad(int M, int N, int K, const uint16_t* dY, int64_t lddy, const uint16_t* X, int64_t ldx, float* dW, int64_t lddw,
+                                    float* db, int flags, int db_accumulate, const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream) {
+    if (M == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(db != nullptr && dY != nullptr, "gemm_bf16_wgrad: null operand");
+    SUBGC_REQUIRE(!workspace || aligned16(workspace), "gemm_bf16_wgrad: workspace must be 16-byte aligned");
+    if (N == 0 || K == 0) {
+        if (N > 0)
+            if (int rc = subgc_gemm_bf16(1, 0, M, N, K, dY, lddy, X, ldx, dW, lddw, nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, flags, m_dev, workspace,
+                                         ws_bytes, stream)) return rc;
+        return subgc_colsum_bf16(dY, lddy, K, M, db, db_accumulate, m_dev, workspace, ws_bytes, stream);
+    }
+    if (int rc = check(1, 0, M, N, K, dY, lddy, X, ldx)) return rc;
+    SUBGC_REQUIRE(dW && lddw >= N, "gemm_bf16_wgrad: no / too narrow destination");
+    Args a{dY, X, dW, nullptr, nullptr, nullptr, nullptr, m_dev, lddy, ldx, lddw, 0, 0, M, N, K, flags, 1.f};
+    a.cs_out = db; a.cs_accum = db_accumulate ? 1 : 0;
+    float* ws = static_cast<float*>(workspace);
+    const size_t cs_bytes = ((size_t)8 * M * sizeof(float) + 15) & ~(size_t)15;
+    if (ws && ws_bytes > cs_bytes) {                            // the split-K form's partial sums live behind its planes
+        ws_bytes = (ws_bytes - cs_bytes) & ~(size_t)15;
+        a.cs_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_bytes);
+    } else { ws = nullptr; ws_bytes = 0; }
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
     return run<true, true>(a, ws, ws_bytes, s, false, nullptr);
 }
 

@@ -44,6 +44,11 @@ struct GemmArgs {
     int no_splitk;                   // SUBGC_GEMM_NO_SPLITK of this call (measurement scripts)
     int planes_only = 0;             // subgc_gemm_f32_planes: split-K forms leave their partial planes in `ws` (no reduce pass)
     int* splits_out = nullptr;       // ... and report how many (1 = the plain kernel wrote C)
+    // subgc_gemm_f32_wgrad (transposed-A forms only): column sums of the stored A -- sum_k A[k][m], the bias gradient next to the
+    // weight gradient dY^T x -- taken from the staging registers of the workgroups of tile column 0
+    float* cs_out = nullptr;         // [M] destination (cs_accum: added to)
+    float* cs_part = nullptr;        // [splits][M] partial sums of the split-K forms (tail of the caller's workspace)
+    int cs_accum = 0;
 };
 
 constexpr int BK = 32;
@@ -83,6 +88,18 @@ struct Stage {
     unsigned okmask;           // rowok & (k in range), decided per tile
     int64_t ld_;
     int extent;                // nrows (logical rows of this operand)
+    float4 cs;                 // K-major A only: running sum over k of this thread's four columns (every r[v] holds the same four)
+
+    // add the tile in the staging registers to `cs`; MASKED as store() masks, raw as store_raw() does not (steady state: every k is
+    // in range and a column beyond the matrix only feeds a sum that is never stored)
+    template <bool MASKED>
+    __device__ __forceinline__ void colsum_add() {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool on = !MASKED || ((okmask >> v) & 1u);
+            cs.x += on ? r[v].x : 0.f; cs.y += on ? r[v].y : 0.f; cs.z += on ? r[v].z : 0.f; cs.w += on ? r[v].w : 0.f;
+        }
+    }
 
     template <bool VEC>
     __device__ __forceinline__ void init(const float* src, int64_t ld, int row0, int nrows, const int32_t* rows_idx) {
@@ -211,9 +228,10 @@ __device__ __forceinline__ void frag(const float* lds, int r0, int c, int lane, 
 //   * the barrier sits BEFORE the last chunk's MFMAs and is immediately followed by the fetch of the
 //     next tile's first fragments, so the matrix pipe has a full chunk of work queued while the
 //     workgroup re-synchronises.
-template <int BM, int BN, bool TA, bool TB, bool VEC, int MT, int NT>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int MT, int NT, bool CS = false>
 __device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, int K, int m0, int n0, int kt0, int kt1,
-                                         f32x16 (&acc)[MT][NT]) {
+                                         f32x16 (&acc)[MT][NT], float4* colsum = nullptr) {
+    static_assert(!CS || TA, "column sums of A are taken from its K-major staging registers");
     constexpr int WM = BM / 2, WN = BN / 2, NC = BK / 8;
     constexpr bool A_KM = TA, B_KM = !TB;
     using SA = Stage<BM, A_KM>;
@@ -223,6 +241,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int32_t* arows = TA ? nullptr : p.a_rows;
+    if constexpr (CS) *colsum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kt1 <= kt0) return;
     SA sa; SB sb;
     sa.template init<VEC>(p.A, p.lda, m0, M, arows);
@@ -230,6 +249,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, 
     sa.template load<VEC>(m0, kt0 * BK, K);
     sb.template load<VEC>(n0, kt0 * BK, K);
     sa.store(lA0); sb.store(lB0);
+    if constexpr (CS) { sa.cs = make_float4(0.f, 0.f, 0.f, 0.f); sa.template colsum_add<true>(); }
     if (kt0 + 1 < kt1) {
         sa.template load<VEC>(m0, (kt0 + 1) * BK, K);
         sb.template load<VEC>(n0, (kt0 + 1) * BK, K);
@@ -263,6 +283,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, 
             }
             if (c == 1 && has_next) {                            // drain staging regs -> other LDS stage, refill them
                 if (STEADY) { sa.store_raw(lAn); sb.store_raw(lBn); } else { sa.store(lAn); sb.store(lBn); }
+                if constexpr (CS) { if (STEADY) sa.template colsum_add<false>(); else sa.template colsum_add<true>(); }
                 if (STEADY) {
                     sa.load_interior((kt + 2) * BK);
                     sb.load_interior((kt + 2) * BK);
@@ -308,6 +329,25 @@ __device__ __forceinline__ void mainloop(const GemmArgs& p, float* smem, int M, 
     }
     for (; kt < kt1; ++kt) ktile(kt, std::false_type{});
     __syncthreads();      // a following unit (stream-K) re-uses the LDS stages
+    if constexpr (CS) *colsum = sa.cs;
+}
+
+// Column sums of the K-major A tile a workgroup staged (mainloop<.., CS = true>): thread t summed columns 4 (t % (BM/4)) .. +3 over the
+// k-rows t / (BM/4) + 256/(BM/4) j of every tile; the 256/(BM/4) row groups meet in LDS (free after the main loop's last barrier) and
+// thread m < BM stores column m0 + m.  Deterministic: fixed order inside a thread, fixed order over the groups.
+template <int BM>
+__device__ __forceinline__ void colsum_store(float* smem, const float4& cs, int m0, int M, float* dst, bool accum) {
+    constexpr int G = 256 / (BM / 4);
+    const int t = threadIdx.x;
+    *reinterpret_cast<float4*>(smem + (t / (BM / 4)) * BM + (t % (BM / 4)) * 4) = cs;
+    __syncthreads();
+    if (t < BM && m0 + t < M) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) v += smem[g * BM + t];
+        dst[m0 + t] = accum ? dst[m0 + t] + v : v;
+    }
+    __syncthreads();
 }
 
 // Epilogue.  Every main loop issues its MFMAs with the operands SWAPPED (B fragment first), so an accumulator tile holds C^T:
@@ -412,7 +452,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 }
 
 // data-parallel form: one workgroup per output tile
-template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0, bool CS = false>
 __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -434,6 +474,10 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kern
     } else if constexpr (XM != 0) {
         mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
         if (threadIdx.x >= 256) return;                          // staging waves hold no accumulators
+    } else if constexpr (CS) {
+        float4 cs;
+        mainloop<BM, BN, TA, TB, VEC, MT, NT, true>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc, &cs);
+        if (n0 == 0) colsum_store<BM>(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);           // workgroup-uniform
     } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
     epilogue<BM, BN, MT, NT>(p, M, m0, n0, acc);
 }
@@ -444,7 +488,7 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kern
 // device-scope fp32 atomics are executed memory-side on this chip and cost more than the GEMM saves),
 // and splitk_reduce_kernel sums the parts and applies the (bias / accumulate) epilogue.  Both launches
 // are stream-ordered; the workspace is just-written and comes back out of L2 / Infinity Cache.
-template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0, bool CS = false>
 __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -469,6 +513,10 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_spli
     } else if constexpr (XM != 0) {
         mainloop_x3_ws<BM, BN, TA, TB, MT, NT, (XM == 1 ? 6 : 1)>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
         if (threadIdx.x >= 256) return;
+    } else if constexpr (CS) {
+        float4 cs;
+        mainloop<BM, BN, TA, TB, VEC, MT, NT, true>(p, smem, p.M, K, m0, n0, kt0, kt1, acc, &cs);
+        if (n0 == 0) colsum_store<BM>(smem, cs, m0, p.M, p.cs_part + (size_t)part * p.M, false);   // an empty part stores zeros
     } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     // raw partial tile -> ws[part][m][n] (accumulators hold C^T quads, see epilogue)
     float* out = ws + (size_t)part * p.M * p.N;
@@ -484,8 +532,15 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_spli
 
 // C = [C +] bias + sum_parts ws[part]   (float4 along N when N % 4 == 0 and C is 16-byte aligned)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ C,
-                                                            int64_t ldc, const float* __restrict__ bias, int accum, int vec) {
+                                                            int64_t ldc, const float* __restrict__ bias, int accum, int vec,
+                                                            const float* __restrict__ cs_part = nullptr, float* __restrict__ cs_out = nullptr, int cs_accum = 0) {
     const size_t plane = (size_t)M * N;
+    if (cs_part != nullptr)                                      // the column sums of A that came with the weight gradient, parts added in order
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += cs_part[(size_t)s * M + m];
+            cs_out[m] = cs_accum ? cs_out[m] + v : v;
+        }
     if (vec) {
         const int n4 = N >> 2;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -535,6 +590,14 @@ int launch(const GemmArgs& a, hipStream_t s) {
     dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
     if (a.splits_out) *a.splits_out = 1;
     static uint64_t attr_set = 0;
+    if constexpr (TA && XM == 0) {
+        if (a.cs_out) {
+            static uint64_t attr_set_cs = 0;
+            if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, 0, true>, lds, attr_set_cs)) return rc;
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, 0, true>), grid, dim3(256), lds, s, a);
+            return subgc::check_launch("subgc_gemm_f32_wgrad");
+        }
+    }
     if (int rc = raise_lds(gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, VEC, XM>), grid, dim3(XM ? 512 : 256), lds, s, a);
     return subgc::check_launch("subgc_gemm_f32");
@@ -570,15 +633,27 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits, bool reduce = tr
     const int tiles = (int)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM));
     const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
     static uint64_t attr_set = 0;
-    if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
-    hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, a.ws, splits, per);
+    bool with_cs = false;
+    if constexpr (TA && XM == 0) {
+        if (a.cs_out) {
+            static uint64_t attr_set_cs = 0;
+            if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, 0, true>, lds, attr_set_cs)) return rc;
+            hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, 0, true>), dim3(tiles * splits), dim3(256), lds, s, a, a.ws, splits, per);
+            with_cs = true;
+        }
+    }
+    if (!with_cs) {
+        if (int rc = raise_lds(gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>, lds, attr_set)) return rc;
+        hipLaunchKernelGGL((gemm_f32_splitk_kernel<BM, BN, TA, TB, VEC, XM>), dim3(tiles * splits), dim3(XM ? 512 : 256), lds, s, a, a.ws, splits, per);
+    }
     if (a.splits_out) *a.splits_out = splits;
     if (!reduce || a.planes_only) return subgc::check_launch("subgc_gemm_f32(split-K, partials)");   // the consumer sums the planes itself
     const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)a.ws,
-                       splits, a.M, a.N, a.C, a.ldc, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0, vec);
+                       splits, a.M, a.N, a.C, a.ldc, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0, vec,
+                       with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum);
     return subgc::check_launch("subgc_gemm_f32(split-K)");
 }
 
@@ -662,6 +737,39 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     }
     if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);
     if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
+    return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
+}
+
+// Weight gradient and bias gradient of one linear layer in one call: dW[M,N] (+)= dY^T x and db[M] (+)= column sums of dY, with dY
+// stored [K, M] and x [K, N].  The workgroups of tile column 0 sum the dY tiles they stage anyway (registers, no extra read of dY);
+// split-K forms leave [parts][M] partial sums in the tail of the workspace and the reduce pass adds them in order.
+SUBGC_API int subgc_gemm_f32_wgrad(int M, int N, int K, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
+                                   float* db, int flags, int db_accumulate, const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream) {
+    SUBGC_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32_wgrad: negative size M=%d N=%d K=%d", M, N, K);
+    SUBGC_REQUIRE((workspace != nullptr || ws_bytes == 0) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                  "gemm_f32_wgrad: workspace must be 16-byte aligned (NULL with 0 bytes = none)");
+    if (M == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(dY && db && (N == 0 || (X && dW)), "gemm_f32_wgrad: null operand");
+    SUBGC_REQUIRE(lddy >= M && ldx >= N && lddw >= N, "gemm_f32_wgrad: leading dimension too small");
+    const int mode_bits = (flags >> 4) & 3;
+    const int xmode = mode_bits ? mode_bits - 1 : g_x3;
+    const size_t cs_bytes = ((size_t)8 * M * sizeof(float) + 15) & ~(size_t)15;
+    if (N == 0 || xmode != 0 || K == 0) {                    // no product (or one of the opt-in arithmetics, which stage through other loops): two passes
+        if (N > 0)
+            if (int rc = subgc_gemm_f32(1, 0, M, N, K, dY, lddy, X, ldx, dW, lddw, nullptr, nullptr, 0, nullptr, 1.f, flags, nullptr, nullptr, m_dev,
+                                        workspace, ws_bytes, stream)) return rc;
+        return subgc_colsum_f32(dY, lddy, K, M, db, db_accumulate, m_dev, workspace, ws_bytes, stream);
+    }
+    GemmArgs a{dY, X, dW, nullptr, nullptr, nullptr, nullptr, nullptr, m_dev, lddy, ldx, lddw, 0, M, N, K, flags & 15, 1.f,
+               static_cast<float*>(workspace), ws_bytes, 0, (flags & SUBGC_GEMM_NO_SPLITK) ? 1 : 0};
+    a.cs_out = db; a.cs_accum = db_accumulate ? 1 : 0;
+    if (workspace && ws_bytes > cs_bytes) {                      // partial sums of the split-K forms live behind the planes
+        a.ws_bytes = (ws_bytes - cs_bytes) & ~(size_t)15;
+        a.cs_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + a.ws_bytes);
+    } else { a.ws = nullptr; a.ws_bytes = 0; }
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = aligned16(dY) && lddy % 4 == 0 && M % 4 == 0 && aligned16(X) && ldx % 4 == 0 && N % 4 == 0;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
     return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
 }
 

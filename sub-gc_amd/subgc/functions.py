@@ -22,6 +22,30 @@ def _direct(p, dev):
     return g if ok else None
 
 
+def _weight_bias_grads(dz, x, w_shape, gW, gb, need_w, need_b):
+    """dW = dz^T x and db = column sums of dz for one linear layer -> (dW, db) as autograd wants them (None where the gradient was
+    accumulated straight into the parameter's .grad view).  Both wanted: ONE launch (ops.wgrad)."""
+    dW = db = None
+    dev = dz.device
+    if need_w and need_b and FOLD_BIAS_SUMS:
+        oW = gW if gW is not None else torch.empty(w_shape, device=dev, dtype=torch.float32)
+        ob = gb if gb is not None else torch.empty(w_shape[0], device=dev, dtype=torch.float32)
+        ops.wgrad(dz, x, oW, ob.view(-1), accum=gW is not None, db_accum=gb is not None)
+        return (None if gW is not None else oW), (None if gb is not None else ob)
+    if need_w:
+        if gW is not None:                # accumulate in the GEMM epilogue: no temporary, no separate `+=` pass by autograd
+            ops.gemm(dz, x, gW, ta=True, accum=True)
+        else:
+            dW = torch.empty(w_shape, device=dev, dtype=torch.float32)
+            ops.gemm(dz, x, dW, ta=True)
+    if need_b:
+        if gb is not None:
+            ops.colsum(dz, out=gb, accumulate=True)
+        else:
+            db = ops.colsum(dz)
+    return dW, db
+
+
 # ------------------------------------------------------------------------------- linear
 class LinearFn(Function):
     """y = [dropout]([relu](x W^T + b [+ add])) on 2-D row-major x (any leading dim).
@@ -72,17 +96,7 @@ class LinearFn(Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(x.size(0), W.size(1), device=dev, dtype=torch.float32)
                 ops.gemm(dz, W, dx)
-            if ctx.needs_input_grad[1]:
-                if gW is not None:            # accumulate in the GEMM epilogue: no temporary, no separate `+=` pass by autograd
-                    ops.gemm(dz, x, gW, ta=True, accum=True)
-                else:
-                    dW = torch.empty_like(W)
-                    ops.gemm(dz, x, dW, ta=True)
-            if ctx.has_b and ctx.needs_input_grad[2]:
-                if gb is not None:
-                    ops.colsum(dz, out=gb, accumulate=True)
-                else:
-                    db = ops.colsum(dz)
+            dW, db = _weight_bias_grads(dz, x, W.shape, gW, gb, ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2])
             if ctx.has_add and ctx.needs_input_grad[3]:
                 dadd = dz
             return dx, dW, db, dadd, None, None, None, None, None, None, None
@@ -104,17 +118,7 @@ class LinearFn(Function):
             dx = ops.empty_b16(x.size(0), W.size(1), dev) if ctx.x_b16 else torch.empty(x.size(0), W.size(1), device=dev, dtype=torch.float32)
             ops.gemm(dz, W, dx)
         Wm = ctx.param_objs[0]
-        if ctx.needs_input_grad[1]:
-            if gW is not None:
-                ops.gemm(dz, x, gW, ta=True, accum=True)
-            else:
-                dW = torch.empty(Wm.shape, device=dev, dtype=torch.float32)
-                ops.gemm(dz, x, dW, ta=True)
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            if gb is not None:
-                ops.colsum(dz, out=gb, accumulate=True)
-            else:
-                db = ops.colsum(dz)
+        dW, db = _weight_bias_grads(dz, x, Wm.shape, gW, gb, ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2])
         if dz32 is not None:
             dadd = dz32
         return dx, dW, db, dadd, None, None, None, None, None, None, None
@@ -220,22 +224,10 @@ class UnitPairFn(Function):
         ops.gemm(dyb, Wrb, dH[:, Lr:])
         ret = [None] * 8
         for i, (W, b, dy, Hh) in enumerate(((Wr_a, br_a, dya, H[:, :Lr]), (Wr_b, br_b, dyb, H[:, Lr:]))):
-            gW, gb = _direct(W, dev), _direct(b, dev)
-            if gW is not None:
-                ops.gemm(dy, Hh, gW, ta=True, accum=True)
-            else:
-                ret[4 + 2 * i] = torch.empty(W.shape, device=dev, dtype=torch.float32); ops.gemm(dy, Hh, ret[4 + 2 * i], ta=True)
-            if gb is not None:
-                ops.colsum(dy, out=gb, accumulate=True)
-            else:
-                ret[5 + 2 * i] = ops.colsum(dy)
+            ret[4 + 2 * i], ret[5 + 2 * i] = _weight_bias_grads(dy, Hh, W.shape, _direct(W, dev), _direct(b, dev), True, True)
         direct = gWl is not None and DIRECT_GRADS
-        if direct:
-            ops.gemm(dH, x, gWl, ta=True, accum=True)
-            ops.colsum(dH, out=gbl, accumulate=True)
-        else:
-            dWl = torch.empty(2 * Lr, x.size(1), device=dev, dtype=torch.float32); ops.gemm(dH, x, dWl, ta=True)
-            dbl = ops.colsum(dH)
+        dWl, dbl = _weight_bias_grads(dH, x, (2 * Lr, x.size(1)), gWl if direct else None, gbl if direct else None, True, True)
+        if not direct:
             ret[0], ret[1], ret[2], ret[3] = dWl[:Lr], dbl[:Lr], dWl[Lr:], dbl[Lr:]
         dx = None
         if ctx.needs_input_grad[0]:
@@ -330,16 +322,7 @@ class ClassTableFn(Function):
                 ops.gemm(dtab, W, ge, accum=True)
             else:
                 demb = torch.empty_like(emb); ops.gemm(dtab, W, demb)
-        if ctx.needs_input_grad[1]:
-            if gW is not None:
-                ops.gemm(dtab, emb, gW, ta=True, accum=True)
-            else:
-                dW = torch.empty_like(W); ops.gemm(dtab, emb, dW, ta=True)
-        if ctx.needs_input_grad[2]:
-            if gb is not None:
-                ops.colsum(dtab, out=gb, accumulate=True)
-            else:
-                db = ops.colsum(dtab)
+        dW, db = _weight_bias_grads(dtab, emb, W.shape, gW, gb, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return demb, dW, db, None
 
 
@@ -616,6 +599,7 @@ class MaskedNLLFn(Function):
 
 # ------------------------------------------------------------------------------- decoder
 DIRECT_GRADS = True               # accumulate parameter gradients straight into existing .grad buffers
+FOLD_BIAS_SUMS = True             # a layer's bias gradient rides its weight-gradient product (ops.wgrad); False: separate column-sum launches
 on_grads_ready = None             # callback(stage) set by parallel.GradBucketReducer: the gradient slice `stage` ("logit", "recurrent",
                                   # "prepare"; AttModel.grad_buckets) is final and may be all-reduced while the backward goes on
 trace = None                      # tests: a list that receives ("bptt_begin", steps) / ("bptt_end",) / ("ready", stage) / ("issue", bucket) in host order
@@ -965,9 +949,15 @@ class DecoderFn(Function):
                 ret[i] = dst[i]
             return dst[i]
 
-        def wgrad(i, dy, x, cols=None):                  # dW_i[:, cols] (+)= dy^T x
+        def wgrad(i, dy, x, cols=None, bias=None, m_dev=None):      # dW_i[:, cols] (+)= dy^T x  [and db_bias (+)= column sums of dy, same launch]
             o = out_for(i)
-            ops.gemm(dy, x, o if cols is None else o[:, cols[0]:cols[1]], ta=True, accum=acc[i])
+            o = o if cols is None else o[:, cols[0]:cols[1]]
+            if bias is None or not FOLD_BIAS_SUMS:
+                ops.gemm(dy, x, o, ta=True, accum=acc[i], m_dev=m_dev)
+                if bias is not None:
+                    bgrad(bias, dy, m_dev=m_dev)
+            else:
+                ops.wgrad(dy, x, o, out_for(bias).view(-1), accum=acc[i], db_accum=acc[bias], m_dev=m_dev)
 
         def bgrad(i, x, m_dev=None, also=None):          # db_i (+)= column sums of x  (also: a second bias with the same gradient)
             if also is None:
@@ -994,8 +984,7 @@ class DecoderFn(Function):
         else:
             return (None,) * (7 + len(P))
         Hout2 = ops.flat_rows(Hout)
-        wgrad(21, dlogits, Hout2)
-        bgrad(22, dlogits)
+        wgrad(21, dlogits, Hout2, bias=22)
         grads_ready("logit")                             # logit.* is final: its all-reduce overlaps the whole BPTT loop
         dHout = new(S, T, R); ops.gemm(dlogits, W[21], dHout.view(S * T, R))
         del dlogits
@@ -1050,15 +1039,13 @@ class DecoderFn(Function):
             del dCtx
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
         H1a, H2a = ops.flat_rows(H1[:T]), ops.flat_rows(H2[:T])
-        wgrad(13, P2, H2a[:, :2 * R])
-        wgrad(14, P2, H2a[:, 2 * R:])
-        bgrad(15, P2, also=16)
-        wgrad(9, P1, H1a[:, :R], cols=(0, R))
+        wgrad(13, P2, H2a[:, :2 * R], bias=15)             # b_ih and b_hh have the same gradient: one sum rides each product
+        wgrad(14, P2, H2a[:, 2 * R:], bias=16)
+        wgrad(9, P1, H1a[:, :R], cols=(0, R), bias=11)
         dGf = opnd(ops.colsum(dP1.view(T, S * 4 * R)).view(S, 4 * R))
         wgrad(9, dGf, pr.f16 if bf else pr.f, cols=(R, 2 * R))
         wgrad(9, P1, xt.view(T * S, E), cols=(2 * R, 2 * R + E))
-        wgrad(10, P1, H1a[:, R:])
-        bgrad(11, P1, also=12)
+        wgrad(10, P1, H1a[:, R:], bias=12)
         df = new(S, R); ops.gemm(dGf, W[9][:, R:2 * R], df)
         dxt = new(T * S, E); ops.gemm(P1, W[9][:, 2 * R:], dxt)
         d_emb = out_for(8, zero=True)
@@ -1067,8 +1054,7 @@ class DecoderFn(Function):
         for t in range(T):
             ops.embed_bwd(emb, toks[:, t], toks.stride(0), None if k_xt is None else k_xt[t], scale, dxt3[t], d_emb)
         dAH2 = dAH.view(T * S, A)
-        wgrad(17, dAH2, H2a[:, R:2 * R])
-        bgrad(18, dAH2)
+        wgrad(17, dAH2, H2a[:, R:2 * R], bias=18)
         ops.colsum(dWa.view(T * S, A), out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa.view(T * S, 1), out=out_for(20).view(-1), accumulate=acc[20])
         grads_ready("recurrent")
@@ -1090,11 +1076,9 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
     if bf:
         du16 = ops.as_b16(du)                                              # dead rows are zero: cast them all, bound the products
         ops.gemm(du16, W[6], dv, accum=True, m_dev=tot)                    # u = v W_c^T + b_c
-        ops.gemm(du16, pr.v16, out_for(6), ta=True, accum=acc[6], m_dev=tot)
-        bgrad(7, du, m_dev=tot)
+        wgrad(6, du16, pr.v16, bias=7, m_dev=tot)
         dzv = ops.relu_bwd(dv, pr.v, scale, bf16=True)
-        ops.gemm(dzv, pr.Xg16, out_for(4), ta=True, accum=acc[4], m_dev=tot)
-        bgrad(5, dzv, m_dev=tot)
+        wgrad(4, dzv, pr.Xg16, bias=5, m_dev=tot)
         dX = None
         if need_dX:
             dXg = new(pr.Xg16.size(0), pr.Xg16.size(1)); ops.gemm(dzv, W[4], dXg, m_dev=tot)
@@ -1104,22 +1088,18 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
                 dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
                 ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
         dz2 = ops.relu_bwd(df, pr.f, scale, bf16=True)
-        wgrad(2, dz2, pr.f116)
-        bgrad(3, dz2)
+        wgrad(2, dz2, pr.f116, bias=3)
         df1 = new(pr.S, pr.f1.size(1)); ops.gemm(dz2, W[2], df1)
         dz1 = ops.relu_bwd(df1, pr.f1, 1.0, bf16=True)
-        wgrad(0, dz1, pr.fc16)
-        bgrad(1, dz1)
+        wgrad(0, dz1, pr.fc16, bias=1)
         dfc_in = None
         if need_dfc:
             dfc_in = new(pr.S, fc_in.size(1)); ops.gemm(dz1, W[0], dfc_in)
         return dX, dfc_in
     ops.gemm(du, P[6], dv, accum=True, m_dev=tot)                          # u = v W_c^T + b_c
-    ops.gemm(du, pr.v, out_for(6), ta=True, accum=acc[6], m_dev=tot)
-    bgrad(7, du, m_dev=tot)
+    wgrad(6, du, pr.v, bias=7, m_dev=tot)
     dzv = ops.relu_bwd(dv, pr.v, scale)
-    ops.gemm(dzv, pr.Xg, out_for(4), ta=True, accum=acc[4], m_dev=tot)
-    bgrad(5, dzv, m_dev=tot)
+    wgrad(4, dzv, pr.Xg, bias=5, m_dev=tot)
     dX = None
     if need_dX:
         dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
@@ -1129,12 +1109,10 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
             dX = ops.zeros(X_nodes.size(0), X_nodes.size(1), device=dev)
             ops.scatter_add_rows(dXg, pr.src_row, dX, m_dev=tot)
     dz2 = ops.relu_bwd(df, pr.f, scale)
-    wgrad(2, dz2, pr.f1)
-    bgrad(3, dz2)
+    wgrad(2, dz2, pr.f1, bias=3)
     df1 = new(pr.S, pr.f1.size(1)); ops.gemm(dz2, fc2_w, df1)
     dz1 = ops.relu_bwd(df1, pr.f1, 1.0)
-    wgrad(0, dz1, fc_in)
-    bgrad(1, dz1)
+    wgrad(0, dz1, fc_in, bias=1)
     dfc_in = None
     if need_dfc:
         dfc_in = new(pr.S, fc_in.size(1)); ops.gemm(dz1, fc0_w, dfc_in)

@@ -242,9 +242,15 @@ class PackedDecoderLossFn(Function):
                 ret[i] = dst[i]
             return dst[i]
 
-        def wgrad(i, dy, x, cols=None):
+        def wgrad(i, dy, x, cols=None, bias=None, m_dev=None):      # dW_i[:, cols] (+)= dy^T x  [and db_bias (+)= column sums of dy, same launch]
             o = out_for(i)
-            ops.gemm(dy, x, o if cols is None else o[:, cols[0]:cols[1]], ta=True, accum=acc[i])
+            o = o if cols is None else o[:, cols[0]:cols[1]]
+            if bias is None or not F_.FOLD_BIAS_SUMS:
+                ops.gemm(dy, x, o, ta=True, accum=acc[i], m_dev=m_dev)
+                if bias is not None:
+                    bgrad(bias, dy, m_dev=m_dev)
+            else:
+                ops.wgrad(dy, x, o, out_for(bias).view(-1), accum=acc[i], db_accum=acc[bias], m_dev=m_dev)
 
         def bgrad(i, x, m_dev=None, also=None):
             if also is None:
@@ -256,8 +262,7 @@ class PackedDecoderLossFn(Function):
 
         dlogits = ops.empty_b16(max(rows, 1), V1, dev) if bf else new(max(rows, 1), V1)      # bf16: half the bytes of the largest tensor
         ops.nll_logsoftmax_bwd(logp[:rows], tgt_p, msk_p, nll, dloss.contiguous(), dlogits[:rows], None, rows, 1, V1, lse=lse)
-        wgrad(21, dlogits[:rows], Hout[:rows])
-        bgrad(22, dlogits[:rows])
+        wgrad(21, dlogits[:rows], Hout[:rows], bias=22)
         F_.grads_ready("logit")                                 # logit.* is final: its all-reduce overlaps the whole BPTT loop
         dHout = new(max(rows, 1), R); ops.gemm(dlogits[:rows], W[21], dHout[:rows])
         del dlogits
@@ -310,10 +315,9 @@ class PackedDecoderLossFn(Function):
         F_.note("bptt_end")
 
         P1, P2, H1a, H2a = dP1[:rows], dP2[:rows], H1[:rows], H2[:rows]
-        wgrad(13, P2, H2a[:, :2 * R])
-        wgrad(14, P2, H2a[:, 2 * R:])
-        bgrad(15, P2, also=16)
-        wgrad(9, P1, H1a[:, :R], cols=(0, R))
+        wgrad(13, P2, H2a[:, :2 * R], bias=15)             # b_ih and b_hh have the same gradient: one sum rides each product
+        wgrad(14, P2, H2a[:, 2 * R:], bias=16)
+        wgrad(9, P1, H1a[:, :R], cols=(0, R), bias=11)
         step_off = plan.offs                                    # int32 [T+1] on the device; steps past T_live repeat `rows`
         if defer_dv:
             pr.dv_accum(AL, dCtx, step_off, max(T_live, 1), lens_p, dv, S, R)
@@ -323,8 +327,7 @@ class PackedDecoderLossFn(Function):
         dGf = opnd(dGf)
         wgrad(9, dGf, pr.f16 if bf else pr.f, cols=(R, 2 * R))
         wgrad(9, P1, xt[:rows], cols=(2 * R, 2 * R + E))
-        wgrad(10, P1, H1a[:, R:])
-        bgrad(11, P1, also=12)
+        wgrad(10, P1, H1a[:, R:], bias=12)
         df = new(S, R); ops.gemm(dGf, W[9][:, R:2 * R], df)
         dxt = new(max(rows, 1), E); ops.gemm(P1, W[9][:, 2 * R:], dxt[:rows])
         d_emb = out_for(8, zero=True)
@@ -334,8 +337,7 @@ class PackedDecoderLossFn(Function):
             ops.embed_bwd(emb, labels_p[:, t], labels_p.stride(0), None if k_xt is None else k_xt[t], scale, dxt[ot[t]:ot[t + 1]], d_emb)
         if tok_flat is not None:
             ops.embed_bwd(emb, tok_flat, 1, k_flat, scale, dxt[:rows], d_emb)
-        wgrad(17, dAH[:rows], H2a[:, R:2 * R])
-        bgrad(18, dAH[:rows])
+        wgrad(17, dAH[:rows], H2a[:, R:2 * R], bias=18)
         ops.colsum(dWa[:rows], out=out_for(19).view(-1), accumulate=acc[19])
         ops.colsum(dBa[:rows].view(-1, 1), out=out_for(20).view(-1), accumulate=acc[20])
         F_.grads_ready("recurrent")

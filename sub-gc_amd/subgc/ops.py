@@ -341,6 +341,32 @@ def _gemm_b16(a, b, out, ta, tb, bias, add, keep, keep_scale, relu, accum, a_row
     return out
 
 
+def wgrad(dy, x, dW, db, accum=False, db_accum=False, m_dev=None):
+    """Weight AND bias gradient of one linear layer in one call: dW (+)= dy^T x, db (+)= column sums of dy (subgc_gemm_f32_wgrad /
+    subgc_gemm_bf16_wgrad: the workgroups of dW's tile column 0 add up the dy tiles they stage anyway -- no second read of dy, no
+    column-sum launches).  dy [rows, M], x [rows, N] (both fp32 or both bf16), dW fp32 [M, N], db fp32 [M]; m_dev bounds the rows."""
+    K, M = dy.shape
+    N = x.size(1)
+    if x.size(0) != K or dW.size(0) != M or dW.size(1) != N or db.numel() != M or not db.is_contiguous():
+        raise SubgcError(f"wgrad shape mismatch: dy={tuple(dy.shape)} x={tuple(x.shape)} dW={tuple(dW.shape)} db={tuple(db.shape)}")
+    b16 = is_b16(dy)
+    if b16 != is_b16(x):
+        raise SubgcError(f"wgrad needs both operands in one storage type, got {dy.dtype} / {x.dtype}")
+    if FLOPS["on"]:
+        ke = min(K, int(m_dev.item())) if m_dev is not None else K
+        FLOPS["gemm"] += 2.0 * M * N * ke
+        FLOPS["gemm_bytes"] += (2.0 if b16 else 4.0) * (M * ke + ke * N) + 4.0 * M * N * (2 if accum else 1)
+        FLOPS["gemm_calls"] += 1
+    if b16:
+        call("subgc_gemm_bf16_wgrad", M, N, K, _ptr(dy, BF16), ld(dy), _ptr(x, BF16), ld(x), _ptr(dW, torch.float32), ld(dW), _ptr(db, torch.float32),
+             (ACCUM if accum else 0) | gemm_tune.b16_bits, int(db_accum), _ptr(m_dev, torch.int32), *_ws(dy), _stream())
+    else:
+        call("subgc_gemm_f32_wgrad", M, N, K, _ptr(dy, torch.float32), ld(dy), _ptr(x, torch.float32), ld(x), _ptr(dW, torch.float32), ld(dW),
+             _ptr(db, torch.float32), (ACCUM if accum else 0) | GEMM_MODES[gemm_mode.current] | gemm_tune.f32_bits, int(db_accum),
+             _ptr(m_dev, torch.int32), *_ws(dy), _stream())
+    return dW, db
+
+
 def colsum(x, out=None, accumulate=False, m_dev=None):
     out = torch.empty(x.size(1), device=x.device, dtype=torch.float32) if out is None else out
     if is_b16(x):
