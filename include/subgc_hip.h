@@ -95,6 +95,9 @@ int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* 
 #define SUBGC_GEMM_NO_SKINNY (1 << 7)
 #define SUBGC_GEMM_TILE128 (1 << 6)
 #define SUBGC_GEMM_TILE256 (1 << 7)
+#define SUBGC_GEMM_SPLITS(n) (((n) & 15) << 8)    /* subgc_gemm_bf16: force n K parts (0 = the cost model decides) */
+#define SUBGC_GEMM_SPLITS_OF(flags) (((flags) >> 8) & 15)
+#define SUBGC_GEMM_NO_ROW_CUT (1 << 12)            /* subgc_gemm_bf16: one launch even for near-whole-round tile counts */
 #define SUBGC_GEMM_MODE_F32 (1 << 4)
 #define SUBGC_GEMM_MODE_BF16X3 (2 << 4)
 #define SUBGC_GEMM_MODE_BF16R (3 << 4)

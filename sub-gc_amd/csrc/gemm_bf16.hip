@@ -665,7 +665,7 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
     // rows x 1024 columns are 65 x 4 = 260 tiles of 256 x 256 -- 1.016 rounds, timed like two (86 us against 45 for 16 384 rows).  When the
     // rows beyond the last whole round are few, the whole rounds go out as one launch and the remaining rows as a second one with its own
     // plan (small tiles, split K): two disjoint row ranges of the same product.  A stored row-major (not K-major), no device-side row count.
-    if (may_cut_rows && !partials_only && !A_KM && !a.m_dev && force == 0) {
+    if (may_cut_rows && !partials_only && !A_KM && !a.m_dev && force == 0 && SUBGC_GEMM_SPLITS_OF(a.flags) == 0 && !(a.flags & SUBGC_GEMM_NO_ROW_CUT)) {
         const int64_t tn = subgc::cdiv(a.N, 256), tm = subgc::cdiv(a.M, 256);
         if (tn <= 256 && 256 % tn == 0) {
             const int64_t per_round = 256 / tn;                                   // row tiles of one full round
@@ -699,6 +699,10 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
     } else if (force == 128 || force == 256) {
         pl.big = force == 256;
         if (pl.big) pl.splits = 1;
+    }
+    if (const int fs = SUBGC_GEMM_SPLITS_OF(a.flags); fs > 0 && !partials_only) {        // measurement scripts: K parts of this call
+        SUBGC_REQUIRE(fs == 1 || (ws != nullptr && plain && (size_t)fs * a.M * a.N * sizeof(float) <= ws_bytes), "gemm_bf16: forced split needs the plain epilogue and %d planes of workspace", fs);
+        pl.splits = fs;
     }
     if (splits_out) *splits_out = pl.splits;
     if constexpr (A_KM) {
