@@ -52,6 +52,8 @@ inline int gcn_zsplit(int col_groups, int B, int items) {
 // when the shape is not covered (caller falls back to the tiled MFMA kernels).
 int gemm_nt_partials(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, int gemm_flags, float* ws, size_t ws_bytes,
                      hipStream_t s, int* splits);
+// a weight / bias gradient over NO rows: what is not accumulated into becomes zero (gemm_f32.hip; shared by both wgrad entry points)
+int wgrad_no_rows(float* dW, int64_t lddw, float* db, int M, int N, bool accum_w, bool accum_b, hipStream_t s);
 int gemm_bf16_nt_partials(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, float* ws, size_t ws_bytes,
                           hipStream_t s, int* splits);
 int gemm_skinny_nt(const float* A, int64_t lda, const float* W, int64_t ldb, float* C, int64_t ldc, const float* bias, int M, int N,

@@ -766,14 +766,12 @@ SUBGC_API int subgc_gemm_bf16(int transA, int transB, int M, int N, int K, const
 SUBGC_API int subgc_gemm_bf16_wgrad(int M, int N, int K, const uint16_t* dY, int64_t lddy, const uint16_t* X, int64_t ldx, float* dW, int64_t lddw,
                                     float* db, int flags, int db_accumulate, const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream) {
     if (M == 0) return SUBGC_OK;
-    SUBGC_REQUIRE(db != nullptr && dY != nullptr, "gemm_bf16_wgrad: null operand");
+    SUBGC_REQUIRE(M > 0 && N >= 0 && K >= 0, "gemm_bf16_wgrad: negative size M=%d N=%d K=%d", M, N, K);
+    SUBGC_REQUIRE(db != nullptr && (N == 0 || dW != nullptr), "gemm_bf16_wgrad: null destination");
     SUBGC_REQUIRE(!workspace || aligned16(workspace), "gemm_bf16_wgrad: workspace must be 16-byte aligned");
-    if (N == 0 || K == 0) {
-        if (N > 0)
-            if (int rc = subgc_gemm_bf16(1, 0, M, N, K, dY, lddy, X, ldx, dW, lddw, nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, flags, m_dev, workspace,
-                                         ws_bytes, stream)) return rc;
-        return subgc_colsum_bf16(dY, lddy, K, M, db, db_accumulate, m_dev, workspace, ws_bytes, stream);
-    }
+    if (K == 0) return subgc::wgrad_no_rows(dW, lddw, db, M, N, (flags & SUBGC_GEMM_ACCUM) != 0, db_accumulate != 0, (hipStream_t)stream);
+    SUBGC_REQUIRE(dY != nullptr, "gemm_bf16_wgrad: null operand");
+    if (N == 0) return subgc_colsum_bf16(dY, lddy, K, M, db, db_accumulate, m_dev, workspace, ws_bytes, stream);
     if (int rc = check(1, 0, M, N, K, dY, lddy, X, ldx)) return rc;
     SUBGC_REQUIRE(dW && lddw >= N, "gemm_bf16_wgrad: no / too narrow destination");
     Args a{dY, X, dW, nullptr, nullptr, nullptr, nullptr, m_dev, lddy, ldx, lddw, 0, 0, M, N, K, flags, 1.f};

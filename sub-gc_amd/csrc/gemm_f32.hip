@@ -740,6 +740,18 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
     return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
 }
 
+namespace subgc {
+int wgrad_no_rows(float* dW, int64_t lddw, float* db, int M, int N, bool accum_w, bool accum_b, hipStream_t s) {
+    if (!accum_b && M > 0 && hipMemsetAsync(db, 0, sizeof(float) * (size_t)M, s) != hipSuccess) { set_error("wgrad: clearing the bias gradient failed"); return SUBGC_ELAUNCH; }
+    if (!accum_w && M > 0 && N > 0 &&
+        hipMemset2DAsync(dW, sizeof(float) * (size_t)lddw, 0, sizeof(float) * (size_t)N, (size_t)M, s) != hipSuccess) {
+        set_error("wgrad: clearing the weight gradient failed");
+        return SUBGC_ELAUNCH;
+    }
+    return SUBGC_OK;
+}
+}  // namespace subgc
+
 // Weight gradient and bias gradient of one linear layer in one call: dW[M,N] (+)= dY^T x and db[M] (+)= column sums of dY, with dY
 // stored [K, M] and x [K, N].  The workgroups of tile column 0 sum the dY tiles they stage anyway (registers, no extra read of dY);
 // split-K forms leave [parts][M] partial sums in the tail of the workspace and the reduce pass adds them in order.
@@ -749,12 +761,14 @@ SUBGC_API int subgc_gemm_f32_wgrad(int M, int N, int K, const float* dY, int64_t
     SUBGC_REQUIRE((workspace != nullptr || ws_bytes == 0) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
                   "gemm_f32_wgrad: workspace must be 16-byte aligned (NULL with 0 bytes = none)");
     if (M == 0) return SUBGC_OK;
-    SUBGC_REQUIRE(dY && db && (N == 0 || (X && dW)), "gemm_f32_wgrad: null operand");
+    SUBGC_REQUIRE(db && (N == 0 || dW), "gemm_f32_wgrad: null destination");
+    if (K == 0) return subgc::wgrad_no_rows(dW, lddw, db, M, N, (flags & SUBGC_GEMM_ACCUM) != 0, db_accumulate != 0, (hipStream_t)stream);
+    SUBGC_REQUIRE(dY && (N == 0 || X), "gemm_f32_wgrad: null operand");
     SUBGC_REQUIRE(lddy >= M && ldx >= N && lddw >= N, "gemm_f32_wgrad: leading dimension too small");
     const int mode_bits = (flags >> 4) & 3;
     const int xmode = mode_bits ? mode_bits - 1 : g_x3;
     const size_t cs_bytes = ((size_t)8 * M * sizeof(float) + 15) & ~(size_t)15;
-    if (N == 0 || xmode != 0 || K == 0) {                    // no product (or one of the opt-in arithmetics, which stage through other loops): two passes
+    if (N == 0 || xmode != 0) {                              // no product (or one of the opt-in arithmetics, which stage through other loops): two passes
         if (N > 0)
             if (int rc = subgc_gemm_f32(1, 0, M, N, K, dY, lddy, X, ldx, dW, lddw, nullptr, nullptr, 0, nullptr, 1.f, flags, nullptr, nullptr, m_dev,
                                         workspace, ws_bytes, stream)) return rc;

@@ -117,3 +117,30 @@ def test_linear_backward_is_the_same_with_and_without_the_fold():
                 F_.FOLD_BIAS_SUMS = True
         assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
         assert float((out[True][2] - out[False][2]).abs().max()) < 1e-5 * float(out[False][2].abs().max())
+
+
+@pytest.mark.parametrize("store", ["f32", "bf16"])
+def test_wgrad_degenerate_sizes(store):
+    """No rows: both gradients are zero (written) or untouched (accumulated); no input columns: only the bias gradient exists."""
+    dt = BF if store == "bf16" else torch.float32
+    M, N = 64, 128
+    dy, x = torch.empty(0, M, device=DEV, dtype=dt), torch.empty(0, N, device=DEV, dtype=dt)
+    dW, db = torch.full((M, N), 3.0, device=DEV), torch.full((M,), 5.0, device=DEV)
+    ops.wgrad(dy, x, dW, db, accum=True, db_accum=True)
+    assert float(dW.min()) == 3.0 == float(dW.max()) and float(db.min()) == 5.0 == float(db.max())
+    ops.wgrad(dy, x, dW, db)
+    assert float(dW.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+    dy = rnd(100, M, seed=1).to(dt)
+    db = torch.full((M,), float("nan"), device=DEV)
+    ops.wgrad(dy, torch.empty(100, 0, device=DEV, dtype=dt), torch.empty(M, 0, device=DEV), db)
+    assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-4
+
+
+def test_wgrad_rejects_mismatched_operands():
+    dy, x = rnd(100, 64, seed=1), rnd(100, 32, seed=2)
+    with pytest.raises(ops.SubgcError):
+        ops.wgrad(dy, x.to(BF), torch.empty(64, 32, device=DEV), torch.empty(64, device=DEV))
+    with pytest.raises(ops.SubgcError):
+        ops.wgrad(dy, x[:50], torch.empty(64, 32, device=DEV), torch.empty(64, device=DEV))
+    with pytest.raises(ops.SubgcError):
+        ops.wgrad(dy, x, torch.empty(64, 32, device=DEV), torch.empty(32, device=DEV))
