@@ -38,6 +38,10 @@ extern "C" {
 
 #define SUBGC_ABI_VERSION 1
 int subgc_version(void);
+/* Stream ordering without a host round trip: everything enqueued on `signaller` so far completes before anything enqueued on `waiter`
+ * from now on starts (hipEventRecord + hipStreamWaitEvent on a pooled event).  Used to run a layer's weight-gradient product on a side
+ * stream beside the data-gradient chain of the backward (ops.wgrad_forked) and to join the side streams again.                        */
+int subgc_stream_wait(void* waiter, void* signaller);
 const char* subgc_last_error(void);
 /* name of the gfx target the kernels were compiled for ("gfx950") */
 const char* subgc_arch(void);

@@ -115,3 +115,29 @@ SUBGC_API int subgc_prof_collect(int family, int64_t* launches, double* total_ms
     f.recs.clear();
     return SUBGC_OK;
 }
+
+// `waiter` waits (on the device) for everything enqueued on `signaller` so far: one pooled hipEvent per signalling stream, recorded there
+// and waited for here.  Re-recording a pooled event is safe: hipStreamWaitEvent captures the record that is current at the call.
+SUBGC_API int subgc_stream_wait(void* waiter, void* signaller) {
+    if (waiter == signaller) return SUBGC_OK;
+    static std::mutex mu;
+    static std::unordered_map<void*, hipEvent_t> pool;
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = pool.find(signaller);
+        if (it == pool.end()) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                subgc::set_error("stream_wait: hipEventCreate failed");
+                return SUBGC_ELAUNCH;
+            }
+            pool.emplace(signaller, ev);
+        } else ev = it->second;
+    }
+    if (hipEventRecord(ev, (hipStream_t)signaller) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, ev, 0) != hipSuccess) {
+        subgc::set_error("stream_wait: %s", hipGetErrorString(hipGetLastError()));
+        return SUBGC_ELAUNCH;
+    }
+    return SUBGC_OK;
+}
+

@@ -30,7 +30,8 @@ def _weight_bias_grads(dz, x, w_shape, gW, gb, need_w, need_b):
     if need_w and need_b and FOLD_BIAS_SUMS:
         oW = gW if gW is not None else torch.empty(w_shape, device=dev, dtype=torch.float32)
         ob = gb if gb is not None else torch.empty(w_shape[0], device=dev, dtype=torch.float32)
-        ops.wgrad(dz, x, oW, ob.view(-1), accum=gW is not None, db_accum=gb is not None)
+        # both destinations are .grad views: nothing reads them before the slice is announced -> beside the chain, on a side stream
+        (ops.wgrad_forked if (gW is not None and gb is not None) else ops.wgrad)(dz, x, oW, ob.view(-1), accum=gW is not None, db_accum=gb is not None)
         return (None if gW is not None else oW), (None if gb is not None else ob)
     if need_w:
         if gW is not None:                # accumulate in the GEMM epilogue: no temporary, no separate `+=` pass by autograd
@@ -612,6 +613,7 @@ def note(*event):
 
 def grads_ready(stage):
     """Called by the decoder backwards when every kernel that writes the gradient slice `stage` has been enqueued."""
+    ops.join_forks()                                         # weight-gradient products that ran beside the chain (ops.wgrad_forked)
     note("ready", stage)
     if on_grads_ready is not None:
         on_grads_ready(stage)

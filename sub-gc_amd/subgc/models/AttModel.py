@@ -245,6 +245,7 @@ class AttModel(CaptionModel):
 
     def flatten_grads(self):
         """Point every .grad into one flat fp32 buffer (zeroed); dead parameters contribute zeros."""
+        ops.join_forks()                  # no weight-gradient product of an earlier backward may still be writing the buffer
         fresh = self.flat_grads is None or self.flat_grads.device != self.flat_params.device
         if fresh:
             self.flat_grads = torch.zeros_like(self.flat_params)

@@ -22,11 +22,18 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_OVERRIDE = [None]        # raw handle of the side stream a forked call runs on (wgrad_forked); None: the caller's current stream
+
+
 def _stream_of(idx):
+    if _OVERRIDE[0] is not None:
+        return _OVERRIDE[0]
     return _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(idx).cuda_stream
 
 
 def _stream():
+    if _OVERRIDE[0] is not None:
+        return _OVERRIDE[0]
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
@@ -365,6 +372,73 @@ def wgrad(dy, x, dW, db, accum=False, db_accum=False, m_dev=None):
              _ptr(db, torch.float32), (ACCUM if accum else 0) | GEMM_MODES[gemm_mode.current] | gemm_tune.f32_bits, int(db_accum),
              _ptr(m_dev, torch.int32), *_ws(dy), _stream())
     return dW, db
+
+
+# ---- weight gradients beside the backward's data-gradient chain (opt-in; measured, no gain -- DESIGN 8.0) -----------------------------------
+# Nothing downstream of a layer's backward reads its parameter gradients before the slice they live in is announced (functions.grads_ready)
+# or the backward returns, while the NEXT kernel of the chain needs only the data gradient.  The weight-gradient products of the encoder are
+# short, half-filling launches (32 tiles x 8 K parts of 512 workgroup slots for a 1024 x 512 GCN matrix); FORK_WGRADS = True runs them on one
+# of two side streams BESIDE the chain.  Stand-alone that pays (12 x (dx product + weight gradient), bf16: 1072 -> 765 us); inside the real
+# backward 1.7 ms per Full_GC_Kar step run two kernels deep (tools/overlap_report.py) and the step does not get shorter -- the chain's own
+# kernels (add_n, the BatchNorm and aggregation backwards) already fill the memory system, the co-running kernels just share it -- while
+# the two extra stream-ordering calls per product cost the host-bound configs 0.1 ms.  Off.
+FORK_WGRADS = False
+_FORK_SIDES = 2
+_FORKS = {}               # device index -> {"sides": [(torch stream, raw handle)], "next": i, "used": {raw handles}, "held": [tensors], "armed": bool}
+
+
+def _fork_state(idx):
+    st = _FORKS.get(idx)
+    if st is None:
+        sides = []
+        for _ in range(_FORK_SIDES):
+            ts = torch.cuda.Stream(device=idx)
+            with torch.cuda.stream(ts):
+                ensure_workspace(torch.device("cuda", idx))        # its own split-K scratch, allocated before any fork
+            sides.append((ts, ts.cuda_stream))
+        st = _FORKS[idx] = {"sides": sides, "next": 0, "used": set(), "held": [], "armed": False}
+    return st
+
+
+def join_forks(device=None):
+    """The caller's current stream waits for every weight-gradient product forked since the last join (functions.grads_ready, the end of the
+    backward, FlatAdam.step, flatten_grads): after it, the parameter gradients are ordered like any other result of the stream."""
+    for idx, st in _FORKS.items():
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        if st["used"]:
+            main = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(idx).cuda_stream
+            for raw in st["used"]:
+                call("subgc_stream_wait", main, raw)
+            st["used"] = set()
+        st["held"] = []
+        st["armed"] = False
+
+
+def wgrad_forked(dy, x, dW, db, accum=False, db_accum=False, m_dev=None):
+    """ops.wgrad on a side stream (two per device, alternating), ordered behind everything the current stream has enqueued so far.  Only
+    inside a running backward (the engine's end-of-pass callback is the last join); the operands stay referenced until the join so that
+    the allocator cannot hand their memory to a later kernel of the main stream.  Destinations must not be read before `join_forks`."""
+    if not FORK_WGRADS or _OVERRIDE[0] is not None:
+        return wgrad(dy, x, dW, db, accum=accum, db_accum=db_accum, m_dev=m_dev)
+    idx = dy.device.index
+    st = _fork_state(idx)
+    if not st["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_forks)
+        except RuntimeError:                                   # not inside a backward pass: nothing would join
+            return wgrad(dy, x, dW, db, accum=accum, db_accum=db_accum, m_dev=m_dev)
+        st["armed"] = True
+    _, raw = st["sides"][st["next"]]
+    st["next"] = (st["next"] + 1) % len(st["sides"])
+    call("subgc_stream_wait", raw, _stream_of(idx))
+    st["used"].add(raw)
+    st["held"].append((dy, x, m_dev))
+    _OVERRIDE[0] = raw
+    try:
+        return wgrad(dy, x, dW, db, accum=accum, db_accum=db_accum, m_dev=m_dev)
+    finally:
+        _OVERRIDE[0] = None
 
 
 def colsum(x, out=None, accumulate=False, m_dev=None):

@@ -177,6 +177,8 @@ class GradBucketReducer:
         """Call after loss.backward(): reduces whatever has not been sent yet (the fusion slice; every slice when nothing
         overlapped -- adjacent ranges travel as one collective), waits for all of it and averages (`average=False`: leave the SUM
         and hand `1 / world` to `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep)."""
+        from . import ops
+        ops.join_forks()
         if not self.active:
             return self.model.flat_grads
         g = self.model.flat_grads
@@ -226,6 +228,7 @@ class FlatAdam:
         the buffer.  Default: torch's semantics, the (scaled, clipped) gradients stay readable after the step."""
         from . import ops
         self.t += 1
+        ops.join_forks()
         ops.fill_(self.sumsq, 0.0)
         ops.sumsq(self.model.flat_grads, self.sumsq)
         m = self.model
