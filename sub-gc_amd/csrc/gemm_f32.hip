@@ -735,6 +735,31 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
         const int rc = subgc::gemm_skinny_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, (flags & SUBGC_GEMM_RELU) ? 1 : 0, s, add, ldadd);
         if (rc != -100) return rc;      // -100: shape not covered by the weight-streaming form
     }
+    // Row cut (round 4, as in gemm_bf16.hip): a tile count a few tiles above whole rounds of the 512 workgroup slots costs a whole extra round --
+    // Sub_GC_Kar's 8320 relation rows x 1024 columns are 65 x 8 = 520 tiles of 128 x 128, 1.016 rounds (106 us against 70 for 8192 rows).  Few
+    // rows beyond the last whole round: the whole rounds go out as one launch, the remaining rows as a second one with its own tile choice.
+    if (!transA && !a_rows && !c_rows && !m_dev && !(flags & SUBGC_GEMM_NO_ROW_CUT)) {
+        const int64_t tn = subgc::cdiv(N, 128), tm = subgc::cdiv(M, 128);
+        if (tn <= 512 && 512 % tn == 0) {
+            const int64_t per_round = 512 / tn, whole = tm / per_round * per_round, M1 = whole * 128, rest = M - M1;
+            if (whole >= per_round && rest > 0 && rest <= 256 && rest * 16 <= M1) {
+                GemmArgs head = a, tail = a;
+                head.M = (int)M1;
+                tail.M = (int)rest;
+                tail.A = A + M1 * lda;
+                tail.C = C + M1 * ldc;
+                if (add) tail.add = add + M1 * ldadd;
+                if (keep) tail.keep = keep + M1 * ldc;              // the mask shares the destination's leading dimension (epilogue)
+                const bool vt = vec && aligned16(tail.A);
+                int rc;
+                if (transB) rc = vec ? pick_tile<false, true, true>(head, s) : pick_tile<false, true, false>(head, s);
+                else rc = vec ? pick_tile<false, false, true>(head, s) : pick_tile<false, false, false>(head, s);
+                if (rc) return rc;
+                if (transB) return vt ? pick_tile<false, true, true>(tail, s) : pick_tile<false, true, false>(tail, s);
+                return vt ? pick_tile<false, false, true>(tail, s) : pick_tile<false, false, false>(tail, s);
+            }
+        }
+    }
     if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);
     if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
     return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);

@@ -665,3 +665,26 @@ def test_column_sums_slab_partials_and_atomic_fallback(M, N, bf):
     rows = M // 3
     m_dev = torch.tensor([rows], dtype=torch.int32, device=DEV)
     torch.testing.assert_close(ops.colsum(x, m_dev=m_dev).double(), x[:rows].double().sum(0), atol=2e-3 * (M ** 0.5) / 30, rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode,M,N,K", [("nt", 8320, 1024, 512), ("nn", 8320, 1024, 512), ("nt", 8200, 512, 96), ("nt", 16520, 2048, 64)])
+def test_gemm_f32_row_cut_shapes(mode, M, N, K):
+    """Tile counts a few tiles above whole rounds of the 512 workgroup slots (Sub_GC_Kar's 8320 relation rows x 1024 columns: 520 tiles of
+    128 x 128) run as two launches -- the whole rounds and the remaining rows (gemm_f32.hip, subgc_gemm_f32); every epilogue operand is
+    row-offset with them."""
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K + 4, generator=g).to(DEV)[:, :K]
+    b = (torch.randn(N, K + 8, generator=g).to(DEV)[:, :K]) if mode == "nt" else (torch.randn(K, N + 8, generator=g).to(DEV)[:, :N])
+    bias, add = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    keep = (torch.rand(M, N, generator=g) < 0.5).to(torch.uint8).to(DEV)
+    ref = a.double() @ (b.double().t() if mode == "nt" else b.double())
+    want = torch.relu(ref + bias.double() + add.double()) * keep.double() * 2.0
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(a, b, out, tb=mode == "nt", bias=bias, add=add, relu=True, keep=keep, keep_scale=2.0)
+    assert float((out.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+    plain = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(a, b, plain, tb=mode == "nt")
+    assert float((plain.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    acc = add.clone()
+    ops.gemm(a, b, acc, tb=mode == "nt", accum=True)
+    assert float((acc.double() - ref - add.double()).abs().max()) < 2e-5 * float(ref.abs().max())
