@@ -489,6 +489,7 @@ def main():
     ap.add_argument("--pitch-f32", type=int, default=-1, help="experiment: row pitch (elements) of the fp32 recurrent operands (ops.PITCH['f32']; 32 = 128 bytes)")
     ap.add_argument("--no-fold-bias", action="store_true", help="experiment: bias gradients as separate column-sum launches (functions.FOLD_BIAS_SUMS = False)")
     ap.add_argument("--fork-wgrads", action="store_true", help="experiment: the encoder's weight-gradient products on side streams beside the backward chain (ops.FORK_WGRADS = True)")
+    ap.add_argument("--no-pair-launches", action="store_true", help="experiment: the two same-shape products of a GCN unit pair as two launches (ops.PAIR_LAUNCHES = False)")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -511,6 +512,8 @@ def main():
     model = models.setup(opt).to(dev).train()
     if a.pitch_f32 >= 0:
         ops.PITCH["f32"] = a.pitch_f32
+    if a.no_pair_launches:
+        ops.PAIR_LAUNCHES = False
     if a.fork_wgrads:
         ops.FORK_WGRADS = True
     if a.no_fold_bias:

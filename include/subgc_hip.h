@@ -617,6 +617,15 @@ int subgc_gemm_bf16(int transA, int transB, int M, int N, int K, const uint16_t*
                     const float* add, int64_t ldadd, const uint8_t* keep, float keep_scale, int flags,
                     const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
 int subgc_gemm_bf16_workspace_bytes(int M, int N, int K, size_t* bytes);
+/* Two subgc_gemm_bf16 products of the SAME shape, layout, leading dimensions and epilogue in ONE launch: (A1, B1 -> C*_1) in the first half
+ * of the grid, (A2, B2 -> C*_2) in the second.  For the two collection units of a GCN pair (models/lib/graph_conv.py:24-25,31-32; each
+ * unit graph_conv_unit.py:28-30): their d(H) = dy W_rgt halves and their fc_rgt weight gradients are half-filling launches one by one;
+ * tile choice, K parts and row cut are planned for both together.  Epilogue: bias1 / bias2, SUBGC_GEMM_RELU, SUBGC_GEMM_ACCUM; either
+ * kind of destination may be absent (for both problems alike).                                                                        */
+int subgc_gemm_bf16_pair(int transA, int transB, int M, int N, int K, const uint16_t* A1, const uint16_t* A2, int64_t lda,
+                         const uint16_t* B1, const uint16_t* B2, int64_t ldb, float* C32_1, float* C32_2, int64_t ldc32, uint16_t* C16_1,
+                         uint16_t* C16_2, int64_t ldc16, const float* bias1, const float* bias2, int flags, void* workspace, size_t ws_bytes,
+                         void* stream);
 /* subgc_gemm_f32_wgrad over bf16-STORED dY [K, M] and X [K, N]: dW[M, N] (+)= dY^T X and db[M] (+)= sum_k dY[k, :], both fp32; the column
  * sums are read from the tile images of dY already in LDS (workgroups of tile column 0), fixed summation order.  Alignment rules of
  * subgc_gemm_bf16 (bases 16 bytes, lddy / ldx multiples of 8); flags: SUBGC_GEMM_ACCUM for dW, db_accumulate for db.                 */

@@ -38,7 +38,22 @@ struct Args {
     float* cs_out = nullptr;         // [M] (cs_accum: added to)
     float* cs_part = nullptr;        // [splits][M] partial sums of the split-K form (tail of the caller's workspace)
     int cs_accum = 0;
+    // subgc_gemm_bf16_pair: a SECOND problem of the same shape, layout and epilogue in the same launch (the second half of the grid)
+    const uint16_t* A2 = nullptr; const uint16_t* B2 = nullptr; float* C32b = nullptr; uint16_t* C16b = nullptr; const float* bias2 = nullptr;
+    int nprob = 1;
 };
+
+// Pair launches: workgroups [0, nwg/2) work on problem 0, [nwg/2, nwg) on problem 1.  Rewrites `q` to the workgroup's problem, `b` to its
+// problem-local workgroup id and `nwg` to the problem's workgroup count; returns the problem index.  (The XCD of workgroup b is still
+// (b + const) % 8: the contiguous-chunk-per-XCD property of xcd_chunked_id holds, only the XCD's identity is rotated.)
+__device__ __forceinline__ int select_problem(Args& q, int& b, int& nwg) {
+    if (q.nprob != 2) return 0;
+    nwg >>= 1;
+    if (b < nwg) return 0;
+    b -= nwg;
+    q.A = q.A2; q.B = q.B2; q.C32 = q.C32b; q.C16 = q.C16b; q.bias = q.bias2;
+    return 1;
+}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -444,14 +459,17 @@ __device__ __forceinline__ void colsum_store(unsigned char* smem, const float (&
 }
 
 template <typename G, bool A_KM, bool B_KM, bool CS = false>
-__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_kernel(const Args p) {
+__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_kernel(const Args p_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Args p = p_in;
+    int wg = blockIdx.x, nwg = gridDim.x;
+    select_problem(p, wg, nwg);
     const int M = (p.m_dev && !A_KM) ? min(p.M, *p.m_dev) : p.M;
     const int K = (p.m_dev && A_KM) ? min(p.K, *p.m_dev) : p.K;
     const int tiles_m = (M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN, live = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= live) return;
+    if (wg >= live) return;
     int tm, tn;
-    tile_of(xcd_chunked_id(blockIdx.x, live), tiles_m, tiles_n, tm, tn);
+    tile_of(xcd_chunked_id(wg, live), tiles_m, tiles_n, tm, tn);
     const int m0 = tm * G::TBM, n0 = tn * G::TBN;
     f32x16 acc[G::MA][G::NB];
     zero_acc(acc);
@@ -510,10 +528,13 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
 }
 
 template <typename G, bool A_KM, bool B_KM, bool CS = false>
-__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_splitk_kernel(const Args p, float* __restrict__ ws, int splits, int kt_per_split) {
+__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_splitk_kernel(const Args p_in, float* __restrict__ ws, int splits, int kt_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Args p = p_in;
+    int wg = blockIdx.x, nwg = gridDim.x;
+    if (select_problem(p, wg, nwg)) ws += (size_t)splits * p.M * p.N;          // the second problem's planes follow the first's
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
-    const int u = xcd_chunked_id(blockIdx.x, gridDim.x);
+    const int u = xcd_chunked_id(wg, nwg);
     const int tile = u / splits, part = u - tile * splits;
     int tm, tn;
     tile_of(tile, tiles_m, tiles_n, tm, tn);
@@ -540,8 +561,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __r
                                                                 int64_t ldc32, uint16_t* __restrict__ C16, int64_t ldc16,
                                                                 const float* __restrict__ bias, int accum, int relu,
                                                                 const float* __restrict__ cs_part = nullptr, float* __restrict__ cs_out = nullptr,
-                                                                int cs_accum = 0) {
+                                                                int cs_accum = 0, float* __restrict__ C32b = nullptr, uint16_t* __restrict__ C16b = nullptr,
+                                                                const float* __restrict__ bias2 = nullptr) {
     const size_t plane = (size_t)M * N;
+    if (blockIdx.y == 1) { ws += (size_t)splits * plane; C32 = C32b; C16 = C16b; bias = bias2; }     // pair launch: grid.y = problem
     if (cs_part != nullptr)                                     // column sums of A that came with a weight gradient: parts added in order
         for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
             float v = 0.f;
@@ -579,18 +602,18 @@ using G256 = Geo<256, 256, 2, 2>;
 // a workgroup spends c us per 32-deep K-tile and e us in its prologue + epilogue (e is dominated by the result bytes: halve it
 // for a bf16-only destination); `slots` workgroups run at a time; a split costs the partial planes' round trip at ~3 TB/s + a launch.
 struct Plan { int big; int splits; double cost; };
-inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool out32 = true) {
+inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool out32 = true, int nprob = 1) {
     const int kt = (int)subgc::cdiv(K, BK);
     Plan best{0, 1, 1e30};
     for (int big = 0; big < 2; ++big) {
-        const int64_t tiles = big ? subgc::cdiv(M, 256) * subgc::cdiv(N, 256) : subgc::cdiv(M, 128) * subgc::cdiv(N, 128);
+        const int64_t tiles = nprob * (big ? subgc::cdiv(M, 256) * subgc::cdiv(N, 256) : subgc::cdiv(M, 128) * subgc::cdiv(N, 128));
         const int slots = big ? 256 : 512;
         const double c = big ? 0.85 : 0.67, e = (big ? 24.0 : 12.0) * (out32 ? 1.0 : 0.55);
         for (int s = 1; s <= 8; ++s) {
-            if (s > 1 && (!may_split || (kt + s - 1) / s < 12 || (size_t)s * M * N * sizeof(float) > ws_bytes)) break;
+            if (s > 1 && (!may_split || (kt + s - 1) / s < 12 || (size_t)nprob * s * M * N * sizeof(float) > ws_bytes)) break;
             const int per = (kt + s - 1) / s;
             const int64_t rounds = (tiles * s + slots - 1) / slots;
-            const double tail = s > 1 ? 3.0 + (double)(s + 1) * M * N * 4.0 / 3.0e6 : 0.0;       // us: planes written + read back
+            const double tail = s > 1 ? 3.0 + (double)nprob * (s + 1) * M * N * 4.0 / 3.0e6 : 0.0;       // us: planes written + read back
             const double cost = rounds * (per * c + (s > 1 ? e * 0.7 : e)) + tail;
             if (cost < best.cost - 1e-9) best = Plan{big, s, cost};
         }
@@ -615,7 +638,7 @@ int raise_lds(KernelT kernel, size_t lds, uint64_t& done) {
 
 template <typename G, bool A_KM, bool B_KM>
 int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t s) {
-    const int64_t tiles = subgc::cdiv(a.M, G::TBM) * subgc::cdiv(a.N, G::TBN);
+    const int64_t tiles = a.nprob * subgc::cdiv(a.M, G::TBM) * subgc::cdiv(a.N, G::TBN);          // pair launches: both problems' tiles
     const int kt = (int)subgc::cdiv(a.K, BK);
     static uint64_t attr_a = 0, attr_b = 0;
     bool with_cs = false;
@@ -650,25 +673,27 @@ int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t
     }
     if (partials_only) return subgc::check_launch("subgc_gemm_bf16(split-K, partials)");
     const int64_t n = (int64_t)a.M * a.N / 4;
-    hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws,
+    hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048), (unsigned)a.nprob), dim3(256), 0, s, (const float*)ws,
                        splits, a.M, a.N, a.C32, a.ldc32, a.C16, a.ldc16, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0,
-                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum);
+                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum, a.C32b, a.C16b, a.bias2);
     return subgc::check_launch("subgc_gemm_bf16(split-K)");
 }
 
 template <bool A_KM, bool B_KM>
 int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out, bool may_cut_rows = true) {
     const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
-                       (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias));
+                       (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias)) &&
+                       (a.nprob == 1 || ((!a.C32b || aligned16(a.C32b)) && (!a.C16b || (reinterpret_cast<uintptr_t>(a.C16b) & 7) == 0) &&
+                                         (!a.bias2 || aligned16(a.bias2))));
     const int force = (a.flags & SUBGC_GEMM_TILE128) ? 128 : (a.flags & SUBGC_GEMM_TILE256) ? 256 : 0;      // measurement scripts: tile A/B timing
     // Row cut (round 4).  A tile count a few tiles above whole rounds of the 256 CUs costs a whole extra round: Full_GC_Kar's 16 640 relation
     // rows x 1024 columns are 65 x 4 = 260 tiles of 256 x 256 -- 1.016 rounds, timed like two (86 us against 45 for 16 384 rows).  When the
     // rows beyond the last whole round are few, the whole rounds go out as one launch and the remaining rows as a second one with its own
     // plan (small tiles, split K): two disjoint row ranges of the same product.  A stored row-major (not K-major), no device-side row count.
     if (may_cut_rows && !partials_only && !A_KM && !a.m_dev && force == 0 && SUBGC_GEMM_SPLITS_OF(a.flags) == 0 && !(a.flags & SUBGC_GEMM_NO_ROW_CUT)) {
-        const int64_t tn = subgc::cdiv(a.N, 256), tm = subgc::cdiv(a.M, 256);
+        const int64_t tn = subgc::cdiv(a.N, 256) * a.nprob, tm = subgc::cdiv(a.M, 256);       // a pair: both problems' tile columns share a round
         if (tn <= 256 && 256 % tn == 0) {
-            const int64_t per_round = 256 / tn;                                   // row tiles of one full round
+            const int64_t per_round = 256 / tn;                                   // row tiles (of each problem) in one full round
             const int64_t whole = tm / per_round * per_round;                     // row tiles in whole rounds
             const int64_t M1 = whole * 256, rest = a.M - M1;
             if (whole >= per_round && rest > 0 && rest <= 2 * 256 && rest * 8 <= M1) {
@@ -680,12 +705,17 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
                 if (a.C16) tail.C16 = a.C16 + M1 * a.ldc16;
                 if (a.add) tail.add = a.add + M1 * a.ldadd;
                 if (a.keep) tail.keep = a.keep + M1 * (int64_t)a.N;
+                if (a.nprob == 2) {
+                    tail.A2 = a.A2 + M1 * a.lda;
+                    if (a.C32b) tail.C32b = a.C32b + M1 * a.ldc32;
+                    if (a.C16b) tail.C16b = a.C16b + M1 * a.ldc16;
+                }
                 if (int rc = run<A_KM, B_KM>(head, ws, ws_bytes, s, false, splits_out, false)) return rc;
                 return run<A_KM, B_KM>(tail, ws, ws_bytes, s, false, nullptr, false);
             }
         }
     }
-    Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes, a.C32 != nullptr);
+    Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes, a.C32 != nullptr, a.nprob);
     if (partials_only) {                                        // the LSTM cell kernel adds row-major planes: 128x128 split form only
         pl = Plan{0, 1, 0.0};
         const int64_t tiles = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
@@ -701,7 +731,7 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
         if (pl.big) pl.splits = 1;
     }
     if (const int fs = SUBGC_GEMM_SPLITS_OF(a.flags); fs > 0 && !partials_only) {        // measurement scripts: K parts of this call
-        SUBGC_REQUIRE(fs == 1 || (ws != nullptr && plain && (size_t)fs * a.M * a.N * sizeof(float) <= ws_bytes), "gemm_bf16: forced split needs the plain epilogue and %d planes of workspace", fs);
+        SUBGC_REQUIRE(fs == 1 || (ws != nullptr && plain && (size_t)a.nprob * fs * a.M * a.N * sizeof(float) <= ws_bytes), "gemm_bf16: forced split needs the plain epilogue and %d planes of workspace", fs);
         pl.splits = fs;
     }
     if (splits_out) *splits_out = pl.splits;
@@ -784,6 +814,31 @@ SUBGC_API int subgc_gemm_bf16_wgrad(int M, int N, int K, const uint16_t* dY, int
     } else { ws = nullptr; ws_bytes = 0; }
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * M * (double)N * K);
+    return run<true, true>(a, ws, ws_bytes, s, false, nullptr);
+}
+
+// Two products of the SAME shape, layout and epilogue in one launch (the two units of a GCN pair: d(H) halves, fc_rgt weight gradients): the
+// grid's first half works on (A1, B1 -> C1), the second on (A2, B2 -> C2); tile choice, K parts and the row cut are planned for both
+// together, so two half-filling launches become one that fills the chip.  Epilogue: bias / ReLU / ACCUM, fp32 and / or bf16 destinations.
+SUBGC_API int subgc_gemm_bf16_pair(int transA, int transB, int M, int N, int K, const uint16_t* A1, const uint16_t* A2, int64_t lda,
+                                   const uint16_t* B1, const uint16_t* B2, int64_t ldb, float* C32_1, float* C32_2, int64_t ldc32, uint16_t* C16_1,
+                                   uint16_t* C16_2, int64_t ldc16, const float* bias1, const float* bias2, int flags, void* workspace, size_t ws_bytes,
+                                   void* stream) {
+    if (M == 0 || N == 0) return SUBGC_OK;
+    if (int rc = check(transA, transB, M, N, K, A1, lda, B1, ldb)) return rc;
+    if (int rc = check(transA, transB, M, N, K, A2, lda, B2, ldb)) return rc;
+    SUBGC_REQUIRE((C32_1 || C16_1) && (C32_1 != nullptr) == (C32_2 != nullptr) && (C16_1 != nullptr) == (C16_2 != nullptr), "gemm_bf16_pair: the two problems need the same kinds of destination");
+    SUBGC_REQUIRE((!C32_1 || ldc32 >= N) && (!C16_1 || ldc16 >= N), "gemm_bf16_pair: destination leading dimension too small");
+    SUBGC_REQUIRE(!(flags & SUBGC_GEMM_ACCUM) || C32_1, "gemm_bf16_pair: accumulate needs the fp32 destination");
+    SUBGC_REQUIRE((bias1 != nullptr) == (bias2 != nullptr), "gemm_bf16_pair: bias for both problems or for none");
+    SUBGC_REQUIRE(!workspace || aligned16(workspace), "gemm_bf16_pair: workspace must be 16-byte aligned");
+    Args a{A1, B1, C32_1, C16_1, bias1, nullptr, nullptr, nullptr, lda, ldb, ldc32, ldc16, 0, M, N, K, flags, 1.f};
+    a.A2 = A2; a.B2 = B2; a.C32b = C32_2; a.C16b = C16_2; a.bias2 = bias2; a.nprob = 2;
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 4.0 * M * (double)N * K);
+    float* ws = static_cast<float*>(workspace);
+    if (!transA && transB) return run<false, false>(a, ws, ws_bytes, s, false, nullptr);
+    if (!transA && !transB) return run<false, true>(a, ws, ws_bytes, s, false, nullptr);
     return run<true, true>(a, ws, ws_bytes, s, false, nullptr);
 }
 

@@ -221,11 +221,17 @@ class UnitPairFn(Function):
         else:
             dya, dyb = dya.contiguous(), dyb.contiguous()
             dH = torch.empty(M, 2 * Lr, device=dev, dtype=torch.float32)
-        ops.gemm(dya, Wra, dH[:, :Lr])
-        ops.gemm(dyb, Wrb, dH[:, Lr:])
+        ops.gemm_pair(dya, dyb, Wra, Wrb, dH[:, :Lr], dH[:, Lr:])            # bf16: one launch for both halves (two half-filling products)
         ret = [None] * 8
-        for i, (W, b, dy, Hh) in enumerate(((Wr_a, br_a, dya, H[:, :Lr]), (Wr_b, br_b, dyb, H[:, Lr:]))):
-            ret[4 + 2 * i], ret[5 + 2 * i] = _weight_bias_grads(dy, Hh, W.shape, _direct(W, dev), _direct(b, dev), True, True)
+        gWa, gba, gWb, gbb = _direct(Wr_a, dev), _direct(br_a, dev), _direct(Wr_b, dev), _direct(br_b, dev)
+        if bf and ops.PAIR_LAUNCHES and all(g is not None for g in (gWa, gba, gWb, gbb)):
+            # the two fc_rgt weight gradients: same shape, same K -> one launch (32 tiles x 8 K parts each fill half the chip); the bias sums follow
+            ops.gemm_pair(dya, dyb, H[:, :Lr], H[:, Lr:], gWa, gWb, ta=True, accum=True)
+            ops.colsum(dya, out=gba, accumulate=True)
+            ops.colsum(dyb, out=gbb, accumulate=True)
+        else:
+            for i, (W, b, dy, Hh) in enumerate(((Wr_a, br_a, dya, H[:, :Lr]), (Wr_b, br_b, dyb, H[:, Lr:]))):
+                ret[4 + 2 * i], ret[5 + 2 * i] = _weight_bias_grads(dy, Hh, W.shape, _direct(W, dev), _direct(b, dev), True, True)
         direct = gWl is not None and DIRECT_GRADS
         dWl, dbl = _weight_bias_grads(dH, x, (2 * Lr, x.size(1)), gWl if direct else None, gbl if direct else None, True, True)
         if not direct:

@@ -348,6 +348,35 @@ def _gemm_b16(a, b, out, ta, tb, bias, add, keep, keep_scale, relu, accum, a_row
     return out
 
 
+PAIR_LAUNCHES = True      # the two same-shape products of a GCN unit pair in one launch (subgc_gemm_bf16_pair); False: two subgc_gemm_bf16 calls
+
+
+def gemm_pair(a1, a2, b1, b2, out1, out2, *, ta=False, tb=False, bias1=None, bias2=None, relu=False, accum=False):
+    """out_i = epilogue(op(a_i) @ op(b_i)) for two bf16 problems of the same shape in ONE launch (subgc_gemm_bf16_pair); shapes, leading
+    dimensions or storage types that differ (or fp32 operands) run as two `gemm` calls."""
+    same = (PAIR_LAUNCHES and is_b16(a1) and is_b16(a2) and is_b16(b1) and is_b16(b2) and a1.shape == a2.shape and b1.shape == b2.shape and out1.shape == out2.shape
+            and out1.dtype == out2.dtype and ld(a1) == ld(a2) and ld(b1) == ld(b2) and ld(out1) == ld(out2) and (bias1 is None) == (bias2 is None))
+    if not same:
+        gemm(a1, b1, out1, ta=ta, tb=tb, bias=bias1, relu=relu, accum=accum)
+        gemm(a2, b2, out2, ta=ta, tb=tb, bias=bias2, relu=relu, accum=accum)
+        return out1, out2
+    M = a1.size(1) if ta else a1.size(0)
+    K = a1.size(0) if ta else a1.size(1)
+    N = b1.size(0) if tb else b1.size(1)
+    if K != (b1.size(1) if tb else b1.size(0)) or out1.size(0) < M or out1.size(1) != N:
+        raise SubgcError(f"gemm_pair shape mismatch: op(a)=[{M},{K}] op(b)=[..,{N}] out={tuple(out1.shape)}")
+    o16 = is_b16(out1)
+    if FLOPS["on"]:
+        FLOPS["gemm"] += 4.0 * M * N * K
+        FLOPS["gemm_bytes"] += 2.0 * (2.0 * (M * K + K * N) + M * N * (2.0 if o16 else 4.0 * (2 if accum else 1)))
+        FLOPS["gemm_calls"] += 1
+    call("subgc_gemm_bf16_pair", int(ta), int(tb), M, N, K, _ptr(a1, BF16), _ptr(a2, BF16), ld(a1), _ptr(b1, BF16), _ptr(b2, BF16), ld(b1),
+         None if o16 else _ptr(out1, torch.float32), None if o16 else _ptr(out2, torch.float32), 0 if o16 else ld(out1),
+         _ptr(out1, BF16) if o16 else None, _ptr(out2, BF16) if o16 else None, ld(out1) if o16 else 0, _ptr(bias1, torch.float32), _ptr(bias2, torch.float32),
+         (RELU if relu else 0) | (ACCUM if accum else 0) | gemm_tune.b16_bits, *_ws(a1), _stream())
+    return out1, out2
+
+
 def wgrad(dy, x, dW, db, accum=False, db_accum=False, m_dev=None):
     """Weight AND bias gradient of one linear layer in one call: dW (+)= dy^T x, db (+)= column sums of dy (subgc_gemm_f32_wgrad /
     subgc_gemm_bf16_wgrad: the workgroups of dW's tile column 0 add up the dy tiles they stage anyway -- no second read of dy, no

@@ -151,3 +151,32 @@ def test_gemm_bf16_row_cut_shapes(mode, M, N, K):
     acc = add.clone()
     ops.gemm(a, b, acc, tb=mode == "nt", accum=True)
     assert float((acc.double() - ref - add.double()).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("mode,M,N,K", [("nn", 16640, 512, 1024), ("tn", 1024, 512, 16640), ("nn", 9472, 512, 1024), ("tn", 1024, 512, 9472),
+                                        ("nt", 700, 1000, 264), ("nn", 300, 72, 40), ("tn", 2048, 512, 6464), ("nt", 16640, 1024, 512)])
+def test_gemm_bf16_pair_equals_two_single_launches(mode, M, N, K):
+    """subgc_gemm_bf16_pair: two products of one shape in one launch (first / second half of the grid; planned together: tile, K parts, row
+    cut) -- the same kernels on the same operands: bit for bit the results of two subgc_gemm_bf16 calls whenever both plan alike, and within
+    summation-order rounding otherwise; against fp64 in any case."""
+    ops_ab = [operands(mode, M, N, K, seed=31 + 7 * i, lda_pad=8, ldb_pad=8) for i in range(2)]
+    (a1, b1, r1), (a2, b2, r2) = ops_ab
+    bias1, bias2 = rnd(N, seed=5), rnd(N, seed=6)
+    for dst in ("f32", "bf16"):
+        mk = (lambda: torch.full((M, N), float("nan"), device=DEV)) if dst == "f32" else (lambda: torch.empty(M, N + 8, device=DEV, dtype=BF)[:, :N])
+        o1, o2, s1, s2 = mk(), mk(), mk(), mk()
+        use_bias = mode != "tn"
+        ops.gemm_pair(a1, a2, b1, b2, o1, o2, ta=mode == "tn", tb=mode == "nt", bias1=bias1 if use_bias else None, bias2=bias2 if use_bias else None, relu=use_bias)
+        ops.gemm(a1, b1, s1, ta=mode == "tn", tb=mode == "nt", bias=bias1 if use_bias else None, relu=use_bias)
+        ops.gemm(a2, b2, s2, ta=mode == "tn", tb=mode == "nt", bias=bias2 if use_bias else None, relu=use_bias)
+        for o, s_, ref, bias in ((o1, s1, r1, bias1), (o2, s2, r2, bias2)):
+            want = torch.relu(ref + bias.double()) if use_bias else ref
+            tol = (2e-5 if dst == "f32" else 2.0 ** -8) * float(want.abs().max())
+            assert float((o.double() - want).abs().max()) < tol
+            assert float((o.double() - s_.double()).abs().max()) <= tol
+    if mode == "tn":                                            # accumulate into both (the weight-gradient use)
+        p1, p2 = rnd(M, N, seed=8), rnd(M, N, seed=9)
+        q1, q2 = p1.clone(), p2.clone()
+        ops.gemm_pair(a1, a2, b1, b2, q1, q2, ta=True, accum=True)
+        assert float((q1.double() - p1.double() - r1).abs().max()) < 2e-5 * float(r1.abs().max())
+        assert float((q2.double() - p2.double() - r2).abs().max()) < 2e-5 * float(r2.abs().max())
