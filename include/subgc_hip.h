@@ -124,6 +124,10 @@ int subgc_gemm_workspace_bytes(int M, int N, int K, size_t* bytes);
  * it 256-row slabs are merged with atomics.                                                                              */
 int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
                      const int32_t* m_dev, void* workspace, size_t ws_bytes, void* stream);
+/* column sums of up to three bf16 matrices of ONE shape and leading dimension in two launches instead of six (a GCN unit pair's three bias
+ * gradients); X1 / X2 and their destinations are ignored beyond n                                                                    */
+int subgc_colsum_bf16_set(int n, const uint16_t* X0, const uint16_t* X1, const uint16_t* X2, int64_t ldx, int M, int N, float* out0,
+                          float* out1, float* out2, int accumulate, void* workspace, size_t ws_bytes, void* stream);
 /* Weight gradient AND bias gradient of one linear layer in one call (the backward of every nn.Linear / nn.LSTMCell product of
  * models/AttModel.py:363-366,376-377,386,411-413,421-423,453 and models/lib/graph_conv_unit.py:29-30; autograd's
  * `grad_weight = grad_output.t().mm(input)` and `grad_bias = grad_output.sum(0)`):

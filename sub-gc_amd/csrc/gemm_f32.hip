@@ -922,7 +922,8 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
     }
 }
 // out[c] (+)= sum over slabs of part[slab][c], fixed order; 256 threads = 64 columns x 4 waves (wave w: slabs w, w+4, ...)
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int slabs, int N, float* __restrict__ out, int accumulate) {
+struct ColsumSet { const uint16_t* x[3]; float* out[3]; };        // subgc_colsum_bf16_set: up to three matrices of one shape
+__device__ __forceinline__ void colsum_finish_body(const float* __restrict__ part, int slabs, int N, float* __restrict__ out, int accumulate) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
     float s = 0.f;
@@ -944,9 +945,16 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
         out[c] = accumulate ? out[c] + t : t;
     }
 }
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int slabs, int N, float* __restrict__ out, int accumulate) {
+    colsum_finish_body(part, slabs, N, out, accumulate);
+}
+// ... and the finish pass of such a set (blockIdx.y = matrix)
+__global__ __launch_bounds__(256) void colsum_finish_set_kernel(const float* __restrict__ part, int slabs, int N, ColsumSet set, int accumulate) {
+    colsum_finish_body(part + (size_t)blockIdx.y * slabs * N, slabs, N, set.out[blockIdx.y], accumulate);
+}
 // bf16 rows (the bf16-stored gate / logit gradients): a lane owns 4 adjacent columns (8 bytes)
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ X, int64_t ldx, int M, int N,
-                                                          float* __restrict__ out, const int32_t* m_dev, int rows_per_block, float* __restrict__ part) {
+__device__ __forceinline__ void colsum_bf16_body(const uint16_t* __restrict__ X, int64_t ldx, int M, int N, float* __restrict__ out,
+                                                 const int32_t* m_dev, int rows_per_block, float* __restrict__ part) {
     __shared__ float4 sm[4][64];
     if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -975,6 +983,14 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
         if (part) *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + col) = t;
         else { atomicAdd(out + col, t.x); atomicAdd(out + col + 1, t.y); atomicAdd(out + col + 2, t.z); atomicAdd(out + col + 3, t.w); }
     }
+}
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ X, int64_t ldx, int M, int N,
+                                                          float* __restrict__ out, const int32_t* m_dev, int rows_per_block, float* __restrict__ part) {
+    colsum_bf16_body(X, ldx, M, N, out, m_dev, rows_per_block, part);
+}
+// up to three matrices of ONE shape in one launch (blockIdx.z = matrix; its slab partials at part + z * slabs * N) ...
+__global__ __launch_bounds__(256) void colsum_bf16_set_kernel(ColsumSet set, int64_t ldx, int M, int N, int rows_per_block, float* __restrict__ part, int slabs) {
+    colsum_bf16_body(set.x[blockIdx.z], ldx, M, N, nullptr, nullptr, rows_per_block, part + (size_t)blockIdx.z * slabs * N);
 }
 // any N / ld (the 7001-column logit gradients of the Flickr vocabulary): one column per lane
 __global__ __launch_bounds__(256) void colsum_bf16_scalar_kernel(const uint16_t* __restrict__ X, int64_t ldx, int M, int N,
@@ -1035,6 +1051,30 @@ SUBGC_API int subgc_colsum_bf16(const uint16_t* X, int64_t ldx, int M, int N, fl
         hipLaunchKernelGGL(colsum_bf16_scalar_kernel, grid, dim3(256), 0, s, X, ldx, M, N, out, m_dev, rows_per_block);
     }
     return subgc::check_launch("subgc_colsum_bf16");
+}
+
+// Column sums of up to three bf16 matrices of ONE shape and leading dimension in two launches instead of six (a GCN unit pair's three bias
+// gradients: d(y_a), d(y_b), d(H)).  Falls back to single calls when the slab plan needs more scratch than the workspace has.
+SUBGC_API int subgc_colsum_bf16_set(int n, const uint16_t* X0, const uint16_t* X1, const uint16_t* X2, int64_t ldx, int M, int N, float* out0,
+                                    float* out1, float* out2, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    SUBGC_REQUIRE(n >= 1 && n <= 3 && M >= 0 && N >= 0 && ldx >= N, "colsum_bf16_set: bad sizes");
+    if (N == 0) return SUBGC_OK;
+    const uint16_t* X[3] = {X0, X1, X2};
+    float* out[3] = {out0, out1, out2};
+    for (int i = 0; i < n; ++i) SUBGC_REQUIRE(X[i] && out[i], "colsum_bf16_set: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    bool vec = N % 4 == 0 && ldx % 4 == 0 && M > 0;
+    for (int i = 0; i < n; ++i) vec = vec && (reinterpret_cast<uintptr_t>(X[i]) & 7) == 0;
+    ColsumPlan pl = vec ? colsum_plan(M, N, workspace, ws_bytes / (size_t)n) : ColsumPlan{256, 0, nullptr};
+    if (!pl.part) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = subgc_colsum_bf16(X[i], ldx, M, N, out[i], accumulate, nullptr, workspace, ws_bytes, stream)) return rc;
+        return SUBGC_OK;
+    }
+    ColsumSet set{{X0, X1, X2}, {out0, out1, out2}};
+    hipLaunchKernelGGL(colsum_bf16_set_kernel, dim3((N / 4 + 63) / 64, pl.slabs, n), dim3(256), 0, s, set, ldx, M, N, pl.rows_per_block, pl.part, pl.slabs);
+    hipLaunchKernelGGL(colsum_finish_set_kernel, dim3((N + 63) / 64, n), dim3(256), 0, s, (const float*)pl.part, pl.slabs, N, set, accumulate);
+    return subgc::check_launch("subgc_colsum_bf16_set");
 }
 
 SUBGC_API int subgc_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,

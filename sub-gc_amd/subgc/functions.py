@@ -224,18 +224,19 @@ class UnitPairFn(Function):
         ops.gemm_pair(dya, dyb, Wra, Wrb, dH[:, :Lr], dH[:, Lr:])            # bf16: one launch for both halves (two half-filling products)
         ret = [None] * 8
         gWa, gba, gWb, gbb = _direct(Wr_a, dev), _direct(br_a, dev), _direct(Wr_b, dev), _direct(br_b, dev)
-        if bf and ops.PAIR_LAUNCHES and all(g is not None for g in (gWa, gba, gWb, gbb)):
-            # the two fc_rgt weight gradients: same shape, same K -> one launch (32 tiles x 8 K parts each fill half the chip); the bias sums follow
+        direct = gWl is not None and DIRECT_GRADS
+        if bf and ops.PAIR_LAUNCHES and direct and gbl is not None and all(g is not None for g in (gWa, gba, gWb, gbb)):
+            # the two fc_rgt weight gradients: same shape, same K -> one launch (32 tiles x 8 K parts each fill half the chip); the pair's three
+            # bias sums (d(y_a), d(y_b), d(H)) as one set: two launches where they are of one shape
             ops.gemm_pair(dya, dyb, H[:, :Lr], H[:, Lr:], gWa, gWb, ta=True, accum=True)
-            ops.colsum(dya, out=gba, accumulate=True)
-            ops.colsum(dyb, out=gbb, accumulate=True)
+            ops.gemm(dH, x, gWl, ta=True, accum=True)
+            ops.colsum_set((dya, dyb, dH), (gba, gbb, gbl.view(-1)), accumulate=True)
         else:
             for i, (W, b, dy, Hh) in enumerate(((Wr_a, br_a, dya, H[:, :Lr]), (Wr_b, br_b, dyb, H[:, Lr:]))):
                 ret[4 + 2 * i], ret[5 + 2 * i] = _weight_bias_grads(dy, Hh, W.shape, _direct(W, dev), _direct(b, dev), True, True)
-        direct = gWl is not None and DIRECT_GRADS
-        dWl, dbl = _weight_bias_grads(dH, x, (2 * Lr, x.size(1)), gWl if direct else None, gbl if direct else None, True, True)
-        if not direct:
-            ret[0], ret[1], ret[2], ret[3] = dWl[:Lr], dbl[:Lr], dWl[Lr:], dbl[Lr:]
+            dWl, dbl = _weight_bias_grads(dH, x, (2 * Lr, x.size(1)), gWl if direct else None, gbl if direct else None, True, True)
+            if not direct:
+                ret[0], ret[1], ret[2], ret[3] = dWl[:Lr], dbl[:Lr], dWl[Lr:], dbl[Lr:]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, x.size(1), device=dev, dtype=torch.float32)

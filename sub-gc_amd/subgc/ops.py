@@ -470,6 +470,26 @@ def wgrad_forked(dy, x, dW, db, accum=False, db_accum=False, m_dev=None):
         _OVERRIDE[0] = None
 
 
+def colsum_set(xs, outs, accumulate=False):
+    """Column sums of several matrices: bf16 ones of one shape and leading dimension go three at a time through subgc_colsum_bf16_set (two
+    launches per group instead of two per matrix); everything else through `colsum`."""
+    groups = {}
+    for x, o in zip(xs, outs):
+        key = (tuple(x.shape), ld(x)) if (is_b16(x) and PAIR_LAUNCHES) else id(x)
+        groups.setdefault(key, []).append((x, o))
+    for key, items in groups.items():
+        while items:
+            chunk, items = items[:3], items[3:]
+            if len(chunk) == 1 or not isinstance(key, tuple):
+                for x, o in chunk:
+                    colsum(x, out=o, accumulate=accumulate)
+                continue
+            x0 = chunk[0][0]
+            px = [_ptr(x, BF16) for x, _ in chunk] + [None] * (3 - len(chunk))
+            po = [_ptr(o, torch.float32) for _, o in chunk] + [None] * (3 - len(chunk))
+            call("subgc_colsum_bf16_set", len(chunk), px[0], px[1], px[2], ld(x0), x0.size(0), x0.size(1), po[0], po[1], po[2], int(accumulate), *_ws(x0), _stream())
+
+
 def colsum(x, out=None, accumulate=False, m_dev=None):
     out = torch.empty(x.size(1), device=x.device, dtype=torch.float32) if out is None else out
     if is_b16(x):

@@ -180,3 +180,15 @@ def test_gemm_bf16_pair_equals_two_single_launches(mode, M, N, K):
         ops.gemm_pair(a1, a2, b1, b2, q1, q2, ta=True, accum=True)
         assert float((q1.double() - p1.double() - r1).abs().max()) < 2e-5 * float(r1.abs().max())
         assert float((q2.double() - p2.double() - r2).abs().max()) < 2e-5 * float(r2.abs().max())
+
+
+def test_colsum_set_equals_single_column_sums():
+    """subgc_colsum_bf16_set: up to three bf16 matrices of one shape in two launches -- the slab plan and summation order of the single
+    call, so bit for bit its result; mixed shapes fall back to single calls."""
+    xs = [rnd(16640, 1024, seed=i).to(BF) for i in range(3)] + [rnd(16640, 512, seed=9).to(BF), rnd(700, 1032, seed=10)[:, :1024].to(BF)]
+    for acc in (False, True):
+        outs = [rnd(x.size(1), seed=20 + i) for i, x in enumerate(xs)]
+        want = [ops.colsum(x, out=o.clone(), accumulate=acc) for x, o in zip(xs, outs)]
+        ops.colsum_set(xs, outs, accumulate=acc)
+        for o, w in zip(outs, want):
+            assert torch.equal(o, w)
