@@ -196,8 +196,7 @@ class UnitPairFn(Function):
             ops.gemm(xa, Wl16, H, tb=True, bias=bl)
             mk = (lambda: ops.empty_b16(M, L, dev)) if out_b16 else (lambda: torch.empty(M, L, device=dev, dtype=torch.float32))
             ya, yb = mk(), mk()
-            ops.gemm(H[:, :Lr], W16r[0], ya, tb=True, bias=br_a)
-            ops.gemm(H[:, Lr:], W16r[1], yb, tb=True, bias=br_b)
+            ops.gemm_pair(H[:, :Lr], H[:, Lr:], W16r[0], W16r[1], ya, yb, tb=True, bias1=br_a, bias2=br_b)      # both units' fc_rgt: one launch
             ctx.save_for_backward(xa, H, Wl16, W16r[0], W16r[1])
             return ya, yb
         H = torch.empty(M, Lr2, device=dev, dtype=torch.float32)
