@@ -115,6 +115,13 @@ int subgc_gemm_f32(int transA, int transB, int M, int N, int K,
                    const uint8_t* keep, float keep_scale, int flags,
                    const int32_t* a_rows, const int32_t* c_rows, const int32_t* m_dev,
                    void* workspace, size_t ws_bytes, void* stream);
+/* Two subgc_gemm_f32 products of the SAME shape, layout, leading dimensions and epilogue in ONE launch: (A1, B1 -> C1) in the first half of
+ * the grid, (A2, B2 -> C2) in the second (the two collection units of a GCN pair, models/lib/graph_conv.py:24-25,31-32: their d(H) halves and
+ * their fc_rgt weight gradients are half-filling launches one by one).  Epilogue: bias1 / bias2, SUBGC_GEMM_ACCUM; SUBGC_GEMM_MODE_* as
+ * subgc_gemm_f32.                                                                                                                       */
+int subgc_gemm_f32_pair(int transA, int transB, int M, int N, int K, const float* A1, const float* A2, int64_t lda, const float* B1,
+                        const float* B2, int64_t ldb, float* C1, float* C2, int64_t ldc, const float* bias1, const float* bias2, int flags,
+                        void* workspace, size_t ws_bytes, void* stream);
 /* the most scratch subgc_gemm_f32 can use for a shape (0: it never splits) */
 int subgc_gemm_workspace_bytes(int M, int N, int K, size_t* bytes);
 

@@ -49,7 +49,20 @@ struct GemmArgs {
     float* cs_out = nullptr;         // [M] destination (cs_accum: added to)
     float* cs_part = nullptr;        // [splits][M] partial sums of the split-K forms (tail of the caller's workspace)
     int cs_accum = 0;
+    // subgc_gemm_f32_pair: a SECOND problem of the same shape, layout and epilogue in the same launch (the second half of the grid)
+    const float* A2 = nullptr; const float* B2 = nullptr; float* C2 = nullptr; const float* bias2 = nullptr;
+    int nprob = 1;
 };
+
+// Pair launches (see gemm_bf16.hip): workgroups [0, nwg/2) work on problem 0, [nwg/2, nwg) on problem 1
+__device__ __forceinline__ int select_problem(GemmArgs& q, int& b, int& nwg) {
+    if (q.nprob != 2) return 0;
+    nwg >>= 1;
+    if (b < nwg) return 0;
+    b -= nwg;
+    q.A = q.A2; q.B = q.B2; q.C = q.C2; q.bias = q.bias2;
+    return 1;
+}
 
 constexpr int BK = 32;
 constexpr int KPAD = 4;
@@ -453,18 +466,21 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 
 // data-parallel form: one workgroup per output tile
 template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0, bool CS = false>
-__global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kernel(const GemmArgs p_in) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    GemmArgs p = p_in;
+    int wg = blockIdx.x, nwg = gridDim.x;
+    select_problem(p, wg, nwg);
     // m_dev bounds the ROWS of the stored A: M when A is [M,K], K when A is stored transposed [K,M]
     const int M = (p.m_dev && !TA) ? min(p.M, *p.m_dev) : p.M;
     const int K = (p.m_dev && TA) ? min(p.K, *p.m_dev) : p.K;
     // The tile sequence is laid over the LIVE rows (device-side count): with a ragged row count the grid is sized
     // for the allocation, and mapping it over p.M would put every live tile on the first one or two XCDs.
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, live = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= live) return;
+    if (wg >= live) return;
     int tm, tn;
-    tile_of(xcd_chunked_id(blockIdx.x, live), tiles_m, tiles_n, tm, tn);
+    tile_of(xcd_chunked_id(wg, live), tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     f32x16 acc[MT][NT];
     zero_acc(acc);
@@ -489,11 +505,14 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kern
 // and splitk_reduce_kernel sums the parts and applies the (bias / accumulate) epilogue.  Both launches
 // are stream-ordered; the workspace is just-written and comes back out of L2 / Infinity Cache.
 template <int BM, int BN, bool TA, bool TB, bool VEC, int XM = 0, bool CS = false>
-__global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_splitk_kernel(const GemmArgs p, float* __restrict__ ws, int splits, int kt_per_split) {
+__global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_splitk_kernel(const GemmArgs p_in, float* __restrict__ ws, int splits, int kt_per_split) {
     constexpr int MT = BM / 64, NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    GemmArgs p = p_in;
+    int wg = blockIdx.x, nwg = gridDim.x;
+    if (select_problem(p, wg, nwg)) ws += (size_t)splits * p.M * p.N;          // the second problem's planes follow the first's
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
-    const int u = xcd_chunked_id(blockIdx.x, gridDim.x);         // parts of one tile stay on one XCD, back to back
+    const int u = xcd_chunked_id(wg, nwg);                       // parts of one tile stay on one XCD, back to back
     const int tile = u / splits, part = u - tile * splits;
     int tm, tn;
     tile_of(tile, tiles_m, tiles_n, tm, tn);
@@ -533,8 +552,10 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_spli
 // C = [C +] bias + sum_parts ws[part]   (float4 along N when N % 4 == 0 and C is 16-byte aligned)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ C,
                                                             int64_t ldc, const float* __restrict__ bias, int accum, int vec,
-                                                            const float* __restrict__ cs_part = nullptr, float* __restrict__ cs_out = nullptr, int cs_accum = 0) {
+                                                            const float* __restrict__ cs_part = nullptr, float* __restrict__ cs_out = nullptr, int cs_accum = 0,
+                                                            float* __restrict__ C2 = nullptr, const float* __restrict__ bias2 = nullptr) {
     const size_t plane = (size_t)M * N;
+    if (blockIdx.y == 1) { ws += (size_t)splits * plane; C = C2; bias = bias2; }          // pair launch: grid.y = problem
     if (cs_part != nullptr)                                      // the column sums of A that came with the weight gradient, parts added in order
         for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
             float v = 0.f;
@@ -587,7 +608,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
     const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
-    dim3 grid((unsigned)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));
+    dim3 grid((unsigned)(a.nprob * subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM)));          // pair launches: both problems' tiles
     if (a.splits_out) *a.splits_out = 1;
     static uint64_t attr_set = 0;
     if constexpr (TA && XM == 0) {
@@ -630,7 +651,7 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits, bool reduce = tr
     using SA = Stage<BM, TA>;
     using SB = Stage<BN, !TB>;
     const size_t lds = XM >= 3 ? x16_lds_bytes(BM, BN, XM == 3 ? 3 : 1) : XM ? x3_lds_bytes(BM, BN, XM == 1 ? 3 : 1) : sizeof(float) * 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
-    const int tiles = (int)(subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM));
+    const int tiles = (int)(a.nprob * subgc::cdiv(a.N, BN) * subgc::cdiv(a.M, BM));
     const int kt = (a.K + BK - 1) / BK, per = (kt + splits - 1) / splits;
     static uint64_t attr_set = 0;
     bool with_cs = false;
@@ -649,11 +670,12 @@ int launch_splitk(const GemmArgs& a, hipStream_t s, int splits, bool reduce = tr
     if (a.splits_out) *a.splits_out = splits;
     if (!reduce || a.planes_only) return subgc::check_launch("subgc_gemm_f32(split-K, partials)");   // the consumer sums the planes itself
     const int vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
-                    (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+                    (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+                    (a.nprob == 1 || (((reinterpret_cast<uintptr_t>(a.C2) & 15) == 0) && (!a.bias2 || (reinterpret_cast<uintptr_t>(a.bias2) & 15) == 0)));
     const int64_t n = (int64_t)a.M * a.N / (vec ? 4 : 1);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const float*)a.ws,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048), (unsigned)a.nprob), dim3(256), 0, s, (const float*)a.ws,
                        splits, a.M, a.N, a.C, a.ldc, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0, vec,
-                       with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum);
+                       with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum, a.C2, a.bias2);
     return subgc::check_launch("subgc_gemm_f32(split-K)");
 }
 
@@ -661,7 +683,7 @@ template <bool TA, bool TB, bool VEC>
 int pick_tile(const GemmArgs& a, hipStream_t s) {
     // 256 CUs: the big tile when it yields >= ~1.5 workgroups per CU; otherwise split-K over big tiles
     // when the epilogue is a plain (bias / accumulate) one and a workspace was registered; else small tiles.
-    const int64_t big = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
+    const int64_t big = a.nprob * subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);                  // pair launches: the tiles of both problems
     // bf16x3-split form (gemm_x3.h): vector-addressable operands, no gathered A rows, 128x128 tiles
     const int xm = (VEC && !a.a_rows) ? a.xmode : 0;
     float* const g_ws = a.ws;
@@ -673,7 +695,7 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
     // Between one and two rounds of 512 workgroup slots the second round is nearly empty and its tiles run alone on their CUs
     // (the 600-tile logit weight gradient: 98 -> 111 TFLOP/s with two K parts); the same cost model decides.
     if (big >= 384 && big < 1024 && g_splitk && xm == 0 && !a.add && !a.keep && !(a.flags & SUBGC_GEMM_RELU) && !a.a_rows && !a.c_rows &&
-        (!a.m_dev || TA) && g_ws && 2 * (size_t)a.M * a.N * sizeof(float) <= g_ws_bytes) {
+        (!a.m_dev || TA) && g_ws && 2 * (size_t)a.nprob * a.M * a.N * sizeof(float) <= g_ws_bytes) {
         const int kt = (a.K + BK - 1) / BK;
         const double one = (double)((big + 511) / 512) * (kt + 3.0), two = (double)((2 * big + 511) / 512) * ((kt + 1) / 2 + 3.0) + 1.8;
         if (kt >= g_two_parts_min_kt && two < 0.9 * one) return launch_splitk<128, 128, TA, TB, VEC>(a, s, 2);
@@ -687,23 +709,55 @@ int pick_tile(const GemmArgs& a, hipStream_t s) {
         // operand feed is shared), the planes and the reduce pass come on top -- 4736 x 512 x 1024 (148 tiles): 83 us in two parts, 62 us whole
         const int kt_all = (a.K + BK - 1) / BK;
         const int splits = (big >= 128 && kt_all <= 48) ? 1 : choose_splits((int)big, kt_all);
-        if (splits > 1 && big * splits >= 200 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
+        if (splits > 1 && big * splits >= 200 && (size_t)splits * a.nprob * a.M * a.N * sizeof(float) <= g_ws_bytes)
             return xm == 1 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 3 : 0>(a, s, splits)
                            : xm == 2 ? launch_splitk<128, 128, TA, TB, VEC, VEC ? 2 : 0>(a, s, splits) : launch_splitk<128, 128, TA, TB, VEC>(a, s, splits);
     }
     if (plain && g_splitk && g_ws) {
         // small contractions (the per-step h2att projection and its data gradient): split K over 64x64 tiles
         // until ~2 workgroups per CU exist; each part keeps >= 4 K-tiles
-        const int small = (int)(subgc::cdiv(a.M, 64) * subgc::cdiv(a.N, 64)), kt = (a.K + BK - 1) / BK;
+        const int small = (int)(a.nprob * subgc::cdiv(a.M, 64) * subgc::cdiv(a.N, 64)), kt = (a.K + BK - 1) / BK;
         int splits = 1;
         while (small * (splits + 1) <= 768 && kt / (splits + 1) >= 4 && splits < 8) ++splits;
-        if (splits > 1 && small * splits >= 128 && (size_t)splits * a.M * a.N * sizeof(float) <= g_ws_bytes)
+        if (splits > 1 && small * splits >= 128 && (size_t)splits * a.nprob * a.M * a.N * sizeof(float) <= g_ws_bytes)
             return launch_splitk<64, 64, TA, TB, VEC>(a, s, splits);
     }
     return launch<64, 64, TA, TB, VEC>(a, s);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Tile / split choice for one call -- with the row cut in front of it (round 4, as in gemm_bf16.hip): a tile count a few tiles above whole rounds
+// of the 512 workgroup slots costs a whole extra round -- Sub_GC_Kar's 8320 relation rows x 1024 columns are 65 x 8 = 520 tiles of
+// 128 x 128, 1.016 rounds (106 us against 70 for 8192 rows).  Few rows beyond the last whole round: the whole rounds go out as one launch,
+// the remaining rows as a second one with its own tile choice.  A pair's two problems share the rounds.
+int dispatch(const GemmArgs& a, int transA, int transB, bool vec, int flags, hipStream_t s) {
+    if (!transA && !a.a_rows && !a.c_rows && !a.m_dev && !(flags & SUBGC_GEMM_NO_ROW_CUT)) {
+        const int64_t tn = subgc::cdiv(a.N, 128) * a.nprob, tm = subgc::cdiv(a.M, 128);
+        if (tn <= 512 && 512 % tn == 0) {
+            const int64_t per_round = 512 / tn, whole = tm / per_round * per_round, M1 = whole * 128, rest = a.M - M1;
+            if (whole >= per_round && rest > 0 && rest <= 256 && rest * 16 <= M1) {
+                GemmArgs head = a, tail = a;
+                head.M = (int)M1;
+                tail.M = (int)rest;
+                tail.A = a.A + M1 * a.lda;
+                tail.C = a.C + M1 * a.ldc;
+                if (a.add) tail.add = a.add + M1 * a.ldadd;
+                if (a.keep) tail.keep = a.keep + M1 * a.ldc;          // the mask shares the destination's leading dimension (epilogue)
+                if (a.nprob == 2) { tail.A2 = a.A2 + M1 * a.lda; tail.C2 = a.C2 + M1 * a.ldc; }
+                int rc;
+                if (transB) rc = vec ? pick_tile<false, true, true>(head, s) : pick_tile<false, true, false>(head, s);
+                else rc = vec ? pick_tile<false, false, true>(head, s) : pick_tile<false, false, false>(head, s);
+                if (rc) return rc;
+                if (transB) return vec ? pick_tile<false, true, true>(tail, s) : pick_tile<false, true, false>(tail, s);
+                return vec ? pick_tile<false, false, true>(tail, s) : pick_tile<false, false, false>(tail, s);
+            }
+        }
+    }
+    if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);
+    if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
+    return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
+}
 
 }  // namespace
 
@@ -735,34 +789,31 @@ SUBGC_API int subgc_gemm_f32(int transA, int transB, int M, int N, int K, const 
         const int rc = subgc::gemm_skinny_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, (flags & SUBGC_GEMM_RELU) ? 1 : 0, s, add, ldadd);
         if (rc != -100) return rc;      // -100: shape not covered by the weight-streaming form
     }
-    // Row cut (round 4, as in gemm_bf16.hip): a tile count a few tiles above whole rounds of the 512 workgroup slots costs a whole extra round --
-    // Sub_GC_Kar's 8320 relation rows x 1024 columns are 65 x 8 = 520 tiles of 128 x 128, 1.016 rounds (106 us against 70 for 8192 rows).  Few
-    // rows beyond the last whole round: the whole rounds go out as one launch, the remaining rows as a second one with its own tile choice.
-    if (!transA && !a_rows && !c_rows && !m_dev && !(flags & SUBGC_GEMM_NO_ROW_CUT)) {
-        const int64_t tn = subgc::cdiv(N, 128), tm = subgc::cdiv(M, 128);
-        if (tn <= 512 && 512 % tn == 0) {
-            const int64_t per_round = 512 / tn, whole = tm / per_round * per_round, M1 = whole * 128, rest = M - M1;
-            if (whole >= per_round && rest > 0 && rest <= 256 && rest * 16 <= M1) {
-                GemmArgs head = a, tail = a;
-                head.M = (int)M1;
-                tail.M = (int)rest;
-                tail.A = A + M1 * lda;
-                tail.C = C + M1 * ldc;
-                if (add) tail.add = add + M1 * ldadd;
-                if (keep) tail.keep = keep + M1 * ldc;              // the mask shares the destination's leading dimension (epilogue)
-                const bool vt = vec && aligned16(tail.A);
-                int rc;
-                if (transB) rc = vec ? pick_tile<false, true, true>(head, s) : pick_tile<false, true, false>(head, s);
-                else rc = vec ? pick_tile<false, false, true>(head, s) : pick_tile<false, false, false>(head, s);
-                if (rc) return rc;
-                if (transB) return vt ? pick_tile<false, true, true>(tail, s) : pick_tile<false, true, false>(tail, s);
-                return vt ? pick_tile<false, false, true>(tail, s) : pick_tile<false, false, false>(tail, s);
-            }
-        }
-    }
-    if (!transA && transB) return vec ? pick_tile<false, true, true>(a, s) : pick_tile<false, true, false>(a, s);
-    if (!transA && !transB) return vec ? pick_tile<false, false, true>(a, s) : pick_tile<false, false, false>(a, s);
-    return vec ? pick_tile<true, false, true>(a, s) : pick_tile<true, false, false>(a, s);
+    return dispatch(a, transA, transB, vec, flags, s);
+}
+
+// Two products of the SAME shape, layout and epilogue in one launch (see subgc_gemm_bf16_pair): the grid's first half works on
+// (A1, B1 -> C1), the second on (A2, B2 -> C2); tile choice, K parts and the row cut are made for both together.  Epilogue: bias, ACCUM.
+SUBGC_API int subgc_gemm_f32_pair(int transA, int transB, int M, int N, int K, const float* A1, const float* A2, int64_t lda, const float* B1,
+                                  const float* B2, int64_t ldb, float* C1, float* C2, int64_t ldc, const float* bias1, const float* bias2, int flags,
+                                  void* workspace, size_t ws_bytes, void* stream) {
+    SUBGC_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32_pair: negative size M=%d N=%d K=%d", M, N, K);
+    SUBGC_REQUIRE((workspace != nullptr || ws_bytes == 0) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                  "gemm_f32_pair: workspace must be 16-byte aligned (NULL with 0 bytes = none)");
+    if (M == 0 || N == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(A1 && A2 && B1 && B2 && C1 && C2, "gemm_f32_pair: null operand");
+    SUBGC_REQUIRE(!(transA && transB), "gemm_f32_pair: transA && transB not supported");
+    SUBGC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "gemm_f32_pair: leading dimension too small");
+    SUBGC_REQUIRE((bias1 != nullptr) == (bias2 != nullptr), "gemm_f32_pair: bias for both problems or for none");
+    const int mode_bits = (flags >> 4) & 3;
+    GemmArgs a{A1, B1, C1, bias1, nullptr, nullptr, nullptr, nullptr, nullptr, lda, ldb, ldc, 0, M, N, K, flags & 15, 1.f,
+               static_cast<float*>(workspace), ws_bytes, mode_bits ? mode_bits - 1 : g_x3, (flags & SUBGC_GEMM_NO_SPLITK) ? 1 : 0};
+    a.A2 = A2; a.B2 = B2; a.C2 = C2; a.bias2 = bias2; a.nprob = 2;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vecA = aligned16(A1) && aligned16(A2) && lda % 4 == 0 && (transA ? M % 4 == 0 : K % 4 == 0);
+    const bool vecB = aligned16(B1) && aligned16(B2) && ldb % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0);
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 4.0 * M * (double)N * K);
+    return dispatch(a, transA, transB, vecA && vecB, flags, s);
 }
 
 namespace subgc {

@@ -202,8 +202,7 @@ class UnitPairFn(Function):
         H = torch.empty(M, Lr2, device=dev, dtype=torch.float32)
         ops.gemm(x, Wl, H, tb=True, bias=bl)
         ya, yb = torch.empty(M, L, device=dev, dtype=torch.float32), torch.empty(M, L, device=dev, dtype=torch.float32)
-        ops.gemm(H[:, :Lr], Wr_a, ya, tb=True, bias=br_a)
-        ops.gemm(H[:, Lr:], Wr_b, yb, tb=True, bias=br_b)
+        ops.gemm_pair(H[:, :Lr], H[:, Lr:], Wr_a, Wr_b, ya, yb, tb=True, bias1=br_a, bias2=br_b)
         ctx.save_for_backward(x, H, Wl, Wr_a, Wr_b)
         return ya, yb
 

@@ -352,10 +352,12 @@ PAIR_LAUNCHES = True      # the two same-shape products of a GCN unit pair in on
 
 
 def gemm_pair(a1, a2, b1, b2, out1, out2, *, ta=False, tb=False, bias1=None, bias2=None, relu=False, accum=False):
-    """out_i = epilogue(op(a_i) @ op(b_i)) for two bf16 problems of the same shape in ONE launch (subgc_gemm_bf16_pair); shapes, leading
-    dimensions or storage types that differ (or fp32 operands) run as two `gemm` calls."""
-    same = (PAIR_LAUNCHES and is_b16(a1) and is_b16(a2) and is_b16(b1) and is_b16(b2) and a1.shape == a2.shape and b1.shape == b2.shape and out1.shape == out2.shape
-            and out1.dtype == out2.dtype and ld(a1) == ld(a2) and ld(b1) == ld(b2) and ld(out1) == ld(out2) and (bias1 is None) == (bias2 is None))
+    """out_i = epilogue(op(a_i) @ op(b_i)) for two problems of the same shape in ONE launch (subgc_gemm_bf16_pair / subgc_gemm_f32_pair);
+    shapes, leading dimensions or storage types that differ run as two `gemm` calls."""
+    b16 = is_b16(a1)
+    same = (PAIR_LAUNCHES and all(is_b16(t) == b16 for t in (a2, b1, b2)) and a1.shape == a2.shape and b1.shape == b2.shape and out1.shape == out2.shape
+            and out1.dtype == out2.dtype and ld(a1) == ld(a2) and ld(b1) == ld(b2) and ld(out1) == ld(out2) and (bias1 is None) == (bias2 is None)
+            and (b16 or (not relu and out1.dtype == torch.float32 and a1.dtype == torch.float32 and b1.dtype == torch.float32)))
     if not same:
         gemm(a1, b1, out1, ta=ta, tb=tb, bias=bias1, relu=relu, accum=accum)
         gemm(a2, b2, out2, ta=ta, tb=tb, bias=bias2, relu=relu, accum=accum)
@@ -367,9 +369,15 @@ def gemm_pair(a1, a2, b1, b2, out1, out2, *, ta=False, tb=False, bias1=None, bia
         raise SubgcError(f"gemm_pair shape mismatch: op(a)=[{M},{K}] op(b)=[..,{N}] out={tuple(out1.shape)}")
     o16 = is_b16(out1)
     if FLOPS["on"]:
+        esz = 2.0 if b16 else 4.0
         FLOPS["gemm"] += 4.0 * M * N * K
-        FLOPS["gemm_bytes"] += 2.0 * (2.0 * (M * K + K * N) + M * N * (2.0 if o16 else 4.0 * (2 if accum else 1)))
+        FLOPS["gemm_bytes"] += 2.0 * (esz * (M * K + K * N) + M * N * (2.0 if o16 else 4.0 * (2 if accum else 1)))
         FLOPS["gemm_calls"] += 1
+    if not b16:
+        call("subgc_gemm_f32_pair", int(ta), int(tb), M, N, K, _ptr(a1, torch.float32), _ptr(a2, torch.float32), ld(a1), _ptr(b1, torch.float32),
+             _ptr(b2, torch.float32), ld(b1), _ptr(out1, torch.float32), _ptr(out2, torch.float32), ld(out1), _ptr(bias1, torch.float32),
+             _ptr(bias2, torch.float32), (ACCUM if accum else 0) | GEMM_MODES[gemm_mode.current] | gemm_tune.f32_bits, *_ws(a1), _stream())
+        return out1, out2
     call("subgc_gemm_bf16_pair", int(ta), int(tb), M, N, K, _ptr(a1, BF16), _ptr(a2, BF16), ld(a1), _ptr(b1, BF16), _ptr(b2, BF16), ld(b1),
          None if o16 else _ptr(out1, torch.float32), None if o16 else _ptr(out2, torch.float32), 0 if o16 else ld(out1),
          _ptr(out1, BF16) if o16 else None, _ptr(out2, BF16) if o16 else None, ld(out1) if o16 else 0, _ptr(bias1, torch.float32), _ptr(bias2, torch.float32),

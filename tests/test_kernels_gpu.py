@@ -688,3 +688,29 @@ def test_gemm_f32_row_cut_shapes(mode, M, N, K):
     acc = add.clone()
     ops.gemm(a, b, acc, tb=mode == "nt", accum=True)
     assert float((acc.double() - ref - add.double()).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("mode,M,N,K", [("nn", 8320, 512, 1024), ("nt", 8320, 1024, 512), ("nn", 4736, 512, 1024), ("tn", 1024, 512, 8320),
+                                        ("nt", 640, 1000, 264), ("nn", 300, 72, 40), ("nt", 8320, 512, 1024)])
+def test_gemm_f32_pair_equals_two_single_launches(mode, M, N, K):
+    """subgc_gemm_f32_pair: two fp32 products of one shape in one launch (halves of the grid; tile, K parts and row cut chosen for both
+    together) against fp64 and against two subgc_gemm_f32 calls."""
+    g = torch.Generator().manual_seed(M + N + K)
+    mk_a = lambda: torch.randn(*((K, M + 4) if mode == "tn" else (M, K + 4)), generator=g).to(DEV)[:, :(M if mode == "tn" else K)]
+    mk_b = lambda: torch.randn(*((N, K + 8) if mode == "nt" else (K, N + 8)), generator=g).to(DEV)[:, :(K if mode == "nt" else N)]
+    a1, a2, b1, b2 = mk_a(), mk_a(), mk_b(), mk_b()
+    bias1, bias2 = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    ref = lambda a, b: (a.double().t() if mode == "tn" else a.double()) @ (b.double().t() if mode == "nt" else b.double())
+    r1, r2 = ref(a1, b1) + bias1.double(), ref(a2, b2) + bias2.double()
+    o1, o2 = torch.full((M, N), float("nan"), device=DEV), torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_pair(a1, a2, b1, b2, o1, o2, ta=mode == "tn", tb=mode == "nt", bias1=bias1, bias2=bias2)
+    s1, s2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.gemm(a1, b1, s1, ta=mode == "tn", tb=mode == "nt", bias=bias1)
+    ops.gemm(a2, b2, s2, ta=mode == "tn", tb=mode == "nt", bias=bias2)
+    for o, s_, r in ((o1, s1, r1), (o2, s2, r2)):
+        tol = 2e-5 * float(r.abs().max())
+        assert float((o.double() - r).abs().max()) < tol and float((o - s_).abs().max()) <= tol
+    p1, p2 = o1.clone(), o2.clone()
+    ops.gemm_pair(a1, a2, b1, b2, p1, p2, ta=mode == "tn", tb=mode == "nt", accum=True)
+    assert float((p1.double() - o1.double() - r1 + bias1.double()).abs().max()) < 4e-5 * float(r1.abs().max())
+    assert float((p2.double() - o2.double() - r2 + bias2.double()).abs().max()) < 4e-5 * float(r2.abs().max())
