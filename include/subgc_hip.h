@@ -217,6 +217,15 @@ int subgc_bn_bwd(const float* dY, const float* X, const float* gamma, const floa
  *     normalised values.  L % 4 == 0.
  *   subgc_bn_bwd_fused: dY = d(normalised) [M, C] fp32 -> dX in X's storage type (dx_bf16) and dgamma / dbeta [C] (accumulate != 0:
  *     added to what is there); mean = aff[0:C].  workspace: 2/3 of the forward's.                                              */
+/*   subgc_bn_stats_pair / subgc_bn_bwd_fused_pair: the TWO units a fused aggregation consumes (same M, C, storage type) in two launches
+ *     instead of four each (training mode; workspace: twice the single call's).                                                    */
+int subgc_bn_stats_pair(const void* X0, const void* X1, int x_bf16, int M, int C, const float* gamma0, const float* gamma1, const float* beta0,
+                        const float* beta1, float* rmean0, float* rmean1, float* rvar0, float* rvar1, float* aff0, float* aff1, float* rstd0,
+                        float* rstd1, float momentum, float eps, void* workspace, size_t ws_bytes, void* stream);
+int subgc_bn_bwd_fused_pair(const float* dY0, const float* dY1, const void* X0, const void* X1, int x_bf16, int M, int C, const float* gamma0,
+                            const float* gamma1, const float* mean0, const float* mean1, const float* rstd0, const float* rstd1, void* dX0,
+                            void* dX1, int dx_bf16, float* dgamma0, float* dgamma1, float* dbeta0, float* dbeta1, int accumulate,
+                            void* workspace, size_t ws_bytes, void* stream);
 int subgc_bn_stats_workspace_bytes(int M, int C, size_t* bytes);
 int subgc_bn_stats(const void* X, int x_bf16, int M, int C, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float* aff, float* rstd, int training, float momentum, float eps, void* workspace,

@@ -42,7 +42,7 @@ __device__ __forceinline__ float4 apply_aff(const Aff4& a, float4 x) {
 // ------------------------------------------------------------------ statistics
 // grid (C/256, slabs): part[slab][{sum (x - p), sum (x - p)^2, p}][C], p = the slab's first row (shifted-data sums)
 template <bool SRC16>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ X, int M, int C, int rpb, float* __restrict__ part) {
+__device__ __forceinline__ void bn_stats_body(const void* __restrict__ X, int M, int C, int rpb, float* __restrict__ part) {
     __shared__ float4 ss[4][64], sq[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
@@ -79,12 +79,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ 
         *reinterpret_cast<float4*>(o + 2 * C) = p;
     }
 }
+template <bool SRC16>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ X, int M, int C, int rpb, float* __restrict__ part) {
+    bn_stats_body<SRC16>(X, M, C, rpb, part);
+}
+// the two units of a GCN pair in one launch (blockIdx.z = unit; its slab partials at part + z * slabs * 3 C)
+struct BnPair { const void* X[2]; const float* gamma[2]; const float* beta[2]; float* rmean[2]; float* rvar[2]; float* aff[2]; float* rstd[2]; };
+template <bool SRC16>
+__global__ __launch_bounds__(256) void bn_stats_pair_kernel(BnPair a, int M, int C, int rpb, float* __restrict__ part, int slabs) {
+    bn_stats_body<SRC16>(a.X[blockIdx.z], M, C, rpb, part + (size_t)blockIdx.z * slabs * 3 * C);
+}
 // grid C/64 x 1024 threads: wave w takes slabs w, w+16, ...  Two sweeps over the (L2-resident) partials, no division in the loops:
 // the batch mean from the slab means, then M2 = sum_k [M2_k + n_k (mean_k - mean)^2] (Chan's formula for many groups), in double.
 // A sweep requests FIN_U slabs' partials before it consumes any: with one load in flight per wave the kernel was a chain of L2
 // latencies (128 slabs, 4 waves: 23.7 us -- 3.5 x the pass over the data it finishes).
 constexpr int FIN_WAVES = 16, FIN_U = 8;
-__global__ __launch_bounds__(FIN_WAVES * 64) void bn_stats_finish_kernel(const float* __restrict__ part, int slabs, int rpb, int M, int C,
+__device__ __forceinline__ void bn_stats_finish_body(const float* __restrict__ part, int slabs, int rpb, int M, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ aff, float* __restrict__ rstd_out, float momentum, float eps) {
@@ -152,6 +162,17 @@ __global__ __launch_bounds__(FIN_WAVES * 64) void bn_stats_finish_kernel(const f
     rstd_out[c] = rs;
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1 ? (float)(m2 / (double)(M - 1)) : var_b);
+}
+__global__ __launch_bounds__(FIN_WAVES * 64) void bn_stats_finish_kernel(const float* __restrict__ part, int slabs, int rpb, int M, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float* __restrict__ aff, float* __restrict__ rstd_out, float momentum, float eps) {
+    bn_stats_finish_body(part, slabs, rpb, M, C, gamma, beta, running_mean, running_var, aff, rstd_out, momentum, eps);
+}
+__global__ __launch_bounds__(FIN_WAVES * 64) void bn_stats_finish_pair_kernel(const float* __restrict__ part, int slabs, int rpb, int M, int C, BnPair a,
+                                                                   float momentum, float eps) {
+    const int z = blockIdx.y;
+    bn_stats_finish_body(part + (size_t)z * slabs * 3 * C, slabs, rpb, M, C, a.gamma[z], a.beta[z], a.rmean[z], a.rvar[z], a.aff[z], a.rstd[z], momentum, eps);
 }
 __global__ __launch_bounds__(256) void bn_eval_aff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -360,7 +381,7 @@ __global__ __launch_bounds__(256) void gcn_edges_bwd_bn_kernel(const float* __re
 // ------------------------------------------------------------------ BatchNorm backward
 // grid (C/256, slabs): part[slab][{sum dy * xhat, sum dy}][C]
 template <bool SRC16>
-__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __restrict__ dY, const void* __restrict__ X, int M, int C,
+__device__ __forceinline__ void bn_bwd_reduce2_body(const float* __restrict__ dY, const void* __restrict__ X, int M, int C,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd, int rpb,
                                                              float* __restrict__ part) {
     __shared__ float4 sg[4][64], sb[4][64];
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __rest
 // grid (C/256, row slabs): every workgroup first adds the reduce pass's slab partials of ITS columns (wave w: slabs w, w+4, ...;
 // the four waves combined in a fixed order, so every workgroup gets the same totals), then streams its rows
 template <bool SRC16, bool DX16>
-__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restrict__ dY, const void* __restrict__ X, void* __restrict__ dX,
+__device__ __forceinline__ void bn_bwd_apply2_body(const float* __restrict__ dY, const void* __restrict__ X, void* __restrict__ dX,
                                                             int M, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ part, int slabs,
                                                             int rpb, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
@@ -477,6 +498,33 @@ inline int stat_rows_per_block(int M, int C) {
 }
 inline int raise_lds(const void* fn, size_t bytes, const char* what) { return subgc::raise_lds_cached(fn, bytes, what); }
 
+template <bool SRC16>
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __restrict__ dY, const void* __restrict__ X, int M, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, int rpb,
+                                                             float* __restrict__ part) {
+    bn_bwd_reduce2_body<SRC16>(dY, X, M, C, mean, rstd, rpb, part);
+}
+template <bool SRC16, bool DX16>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restrict__ dY, const void* __restrict__ X, void* __restrict__ dX,
+                                                            int M, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ part, int slabs,
+                                                            int rpb, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    bn_bwd_apply2_body<SRC16, DX16>(dY, X, dX, M, C, mean, rstd, gamma, part, slabs, rpb, dgamma, dbeta, accumulate);
+}
+// both units of a GCN pair (blockIdx.z = unit; partials at part + z * slabs * 2 C)
+struct BnPairBwd { const float* dY[2]; const void* X[2]; void* dX[2]; const float* mean[2]; const float* rstd[2]; const float* gamma[2]; float* dgamma[2]; float* dbeta[2]; };
+template <bool SRC16>
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_pair_kernel(BnPairBwd a, int M, int C, int rpb, float* __restrict__ part, int slabs) {
+    const int z = blockIdx.z;
+    bn_bwd_reduce2_body<SRC16>(a.dY[z], a.X[z], M, C, a.mean[z], a.rstd[z], rpb, part + (size_t)z * slabs * 2 * C);
+}
+template <bool SRC16, bool DX16>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_pair_kernel(BnPairBwd a, int M, int C, const float* __restrict__ part, int slabs, int rpb, int accumulate) {
+    const int z = blockIdx.z;
+    bn_bwd_apply2_body<SRC16, DX16>(a.dY[z], a.X[z], a.dX[z], M, C, a.mean[z], a.rstd[z], a.gamma[z], part + (size_t)z * slabs * 2 * C, slabs, rpb, a.dgamma[z],
+                                    a.dbeta[z], accumulate);
+}
+
 }  // namespace
 
 SUBGC_API int subgc_bn_stats_workspace_bytes(int M, int C, size_t* bytes) {
@@ -536,6 +584,56 @@ SUBGC_API int subgc_bn_bwd_fused(const float* dY, const void* X, int x_bf16, int
     else { if (dx_bf16) SUBGC_BN_APPLY(false, true); else SUBGC_BN_APPLY(false, false); }
 #undef SUBGC_BN_APPLY
     return subgc::check_launch("subgc_bn_bwd_fused");
+}
+
+// The two units of a GCN pair (same M, C, storage type) through subgc_bn_stats in two launches instead of four
+SUBGC_API int subgc_bn_stats_pair(const void* X0, const void* X1, int x_bf16, int M, int C, const float* gamma0, const float* gamma1, const float* beta0,
+                                  const float* beta1, float* rmean0, float* rmean1, float* rvar0, float* rvar1, float* aff0, float* aff1, float* rstd0,
+                                  float* rstd1, float momentum, float eps, void* workspace, size_t ws_bytes, void* stream) {
+    SUBGC_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_stats_pair: M > 0 and C a positive multiple of 4 (got M=%d C=%d)", M, C);
+    SUBGC_REQUIRE(X0 && X1 && gamma0 && gamma1 && beta0 && beta1 && aff0 && aff1 && rstd0 && rstd1, "bn_stats_pair: null pointer");
+    SUBGC_REQUIRE(x_bf16 ? (al8(X0) && al8(X1)) : (al16(X0) && al16(X1)), "bn_stats_pair: X must be 16-byte (fp32) / 8-byte (bf16) aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = stat_rows_per_block(M, C), slabs = (M + rpb - 1) / rpb;
+    SUBGC_REQUIRE(workspace && al16(workspace) && ws_bytes >= (size_t)2 * slabs * 3 * C * sizeof(float), "bn_stats_pair: workspace of %zu bytes required",
+                  (size_t)2 * slabs * 3 * C * sizeof(float));
+    float* part = static_cast<float*>(workspace);
+    BnPair a{{X0, X1}, {gamma0, gamma1}, {beta0, beta1}, {rmean0, rmean1}, {rvar0, rvar1}, {aff0, aff1}, {rstd0, rstd1}};
+    const dim3 g((C + 255) / 256, slabs, 2);
+    if (x_bf16) hipLaunchKernelGGL((bn_stats_pair_kernel<true>), g, dim3(256), 0, s, a, M, C, rpb, part, slabs);
+    else hipLaunchKernelGGL((bn_stats_pair_kernel<false>), g, dim3(256), 0, s, a, M, C, rpb, part, slabs);
+    hipLaunchKernelGGL(bn_stats_finish_pair_kernel, dim3((C + 63) / 64, 2), dim3(FIN_WAVES * 64), 0, s, (const float*)part, slabs, rpb, M, C, a, momentum, eps);
+    return subgc::check_launch("subgc_bn_stats_pair");
+}
+
+// ... and through subgc_bn_bwd_fused in two launches instead of four
+SUBGC_API int subgc_bn_bwd_fused_pair(const float* dY0, const float* dY1, const void* X0, const void* X1, int x_bf16, int M, int C, const float* gamma0,
+                                      const float* gamma1, const float* mean0, const float* mean1, const float* rstd0, const float* rstd1, void* dX0,
+                                      void* dX1, int dx_bf16, float* dgamma0, float* dgamma1, float* dbeta0, float* dbeta1, int accumulate,
+                                      void* workspace, size_t ws_bytes, void* stream) {
+    SUBGC_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_fused_pair: M > 0 and C a positive multiple of 4");
+    SUBGC_REQUIRE(dY0 && dY1 && X0 && X1 && gamma0 && gamma1 && mean0 && mean1 && rstd0 && rstd1 && dX0 && dX1 && dgamma0 && dgamma1 && dbeta0 && dbeta1,
+                  "bn_bwd_fused_pair: null pointer");
+    SUBGC_REQUIRE(al16(dY0) && al16(dY1) && (x_bf16 ? (al8(X0) && al8(X1)) : (al16(X0) && al16(X1))) && (dx_bf16 ? (al8(dX0) && al8(dX1)) : (al16(dX0) && al16(dX1))) &&
+                      al16(dgamma0) && al16(dgamma1) && al16(dbeta0) && al16(dbeta1) && al16(mean0) && al16(mean1) && al16(rstd0) && al16(rstd1) && al16(gamma0) &&
+                      al16(gamma1), "bn_bwd_fused_pair: misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = stat_rows_per_block(M, C), slabs = (M + rpb - 1) / rpb;
+    SUBGC_REQUIRE(workspace && al16(workspace) && ws_bytes >= (size_t)2 * slabs * 2 * C * sizeof(float), "bn_bwd_fused_pair: workspace of %zu bytes required",
+                  (size_t)2 * slabs * 2 * C * sizeof(float));
+    float* part = static_cast<float*>(workspace);
+    BnPairBwd a{{dY0, dY1}, {X0, X1}, {dX0, dX1}, {mean0, mean1}, {rstd0, rstd1}, {gamma0, gamma1}, {dgamma0, dgamma1}, {dbeta0, dbeta1}};
+    const dim3 g((C + 255) / 256, slabs, 2);
+    if (x_bf16) hipLaunchKernelGGL((bn_bwd_reduce2_pair_kernel<true>), g, dim3(256), 0, s, a, M, C, rpb, part, slabs);
+    else hipLaunchKernelGGL((bn_bwd_reduce2_pair_kernel<false>), g, dim3(256), 0, s, a, M, C, rpb, part, slabs);
+    const int col_groups = (C + 255) / 256;
+    const int rpb2 = std::max(8, (int)(((int64_t)M * col_groups + 1023) / 1024));
+    const dim3 g2(col_groups, (M + rpb2 - 1) / rpb2, 2);
+#define SUBGC_BN_APPLY(S16, D16) hipLaunchKernelGGL((bn_bwd_apply2_pair_kernel<S16, D16>), g2, dim3(256), 0, s, a, M, C, (const float*)part, slabs, rpb2, accumulate)
+    if (x_bf16) { if (dx_bf16) SUBGC_BN_APPLY(true, true); else SUBGC_BN_APPLY(true, false); }
+    else { if (dx_bf16) SUBGC_BN_APPLY(false, true); else SUBGC_BN_APPLY(false, false); }
+#undef SUBGC_BN_APPLY
+    return subgc::check_launch("subgc_bn_bwd_fused_pair");
 }
 
 SUBGC_API int subgc_gcn_nodes_fwd_bn(const void* F0, const void* F1, int f_bf16, const float* aff0, const float* aff1, const int32_t* ptr,

@@ -443,6 +443,18 @@ def _bn_back(dFh, y, gamma, beta, aff, rstd):
     return ops.bn_bwd_fused(dFh.view(M, C), y.view(M, C), gamma, aff, rstd, dg, db, False).view(y.shape), dg, db
 
 
+def _bn_back_pair(dFa, dFb, ya, yb, ga, ba, gb_, bb, affa, affb, rstda, rstdb):
+    """`_bn_back` for the two units of one fused aggregation: two launches instead of four when both write their affine gradients in place."""
+    dev = dFa.device
+    dirs = [_direct(t, dev) for t in (ga, ba, gb_, bb)]
+    if ops.PAIR_LAUNCHES and all(d is not None for d in dirs) and ya.shape == yb.shape and ya.dtype == yb.dtype:
+        M, C = ya.numel() // ya.size(-1), ya.size(-1)
+        dxa, dxb = ops.bn_bwd_fused_pair(dFa.view(M, C), dFb.view(M, C), ya.view(M, C), yb.view(M, C), ga, gb_, affa, affb, rstda, rstdb,
+                                         dirs[0], dirs[2], dirs[1], dirs[3], True)
+        return (dxa.view(ya.shape), None, None), (dxb.view(yb.shape), None, None)
+    return _bn_back(dFa, ya, ga, ba, affa, rstda), _bn_back(dFb, yb, gb_, bb, affb, rstdb)
+
+
 class GcnNodesBnFn(Function):
     """nodes <- relations (GcnNodesFn) with the BatchNorm1d of the two collection units (graph_conv_unit.py:31-32) fused in: y0, y1
     are the RAW unit outputs (fp32, or bf16 under compute_dtype = bf16); the batch statistics are one pass, the aggregation kernel
@@ -452,8 +464,7 @@ class GcnNodesBnFn(Function):
     def forward(ctx, y0, y1, skip, rel_ind, ptr, edges, N, g0, b0, g1, b1, stats, training, want16):
         B, K, L = y0.shape
         y0, y1 = y0.contiguous(), y1.contiguous()
-        aff0, rstd0 = ops.bn_stats(y0.view(B * K, L), g0, b0, stats[0], stats[1], training)
-        aff1, rstd1 = ops.bn_stats(y1.view(B * K, L), g1, b1, stats[2], stats[3], training)
+        (aff0, rstd0), (aff1, rstd1) = ops.bn_stats_pair(y0.view(B * K, L), y1.view(B * K, L), g0, b0, stats[0], stats[1], g1, b1, stats[2], stats[3], training)
         out, out16, act = ops.gcn_nodes_fwd_bn(y0, y1, aff0, aff1, ptr, edges, skip.contiguous() if skip is not None else None, B, N, K, L, want16)
         ctx.save_for_backward(y0, y1, aff0, rstd0, aff1, rstd1, act, rel_ind, ptr)
         ctx.params = (g0, b0, g1, b1)
@@ -473,8 +484,7 @@ class GcnNodesBnFn(Function):
         g0, b0, g1, b1 = ctx.params
         dX = dX.contiguous()
         dF0, dF1 = ops.gcn_nodes_bwd(dX, act, rel_ind, ptr, B, N, K, L)
-        dy0, dg0, db0 = _bn_back(dF0, y0, g0, b0, aff0, rstd0)
-        dy1, dg1, db1 = _bn_back(dF1, y1, g1, b1, aff1, rstd1)
+        (dy0, dg0, db0), (dy1, dg1, db1) = _bn_back_pair(dF0, dF1, y0, y1, g0, b0, g1, b1, aff0, aff1, rstd0, rstd1)
         return dy0, dy1, (dX if ctx.has_skip else None), None, None, None, None, dg0, db0, dg1, db1, None, None, None
 
 
@@ -485,8 +495,7 @@ class GcnEdgesBnFn(Function):
     def forward(ctx, y2, y3, skip, rel_ind, ptr, edges, K, g2, b2, g3, b3, stats, training, want16):
         B, N, L = y2.shape
         y2, y3 = y2.contiguous(), y3.contiguous()
-        aff2, rstd2 = ops.bn_stats(y2.view(B * N, L), g2, b2, stats[0], stats[1], training)
-        aff3, rstd3 = ops.bn_stats(y3.view(B * N, L), g3, b3, stats[2], stats[3], training)
+        (aff2, rstd2), (aff3, rstd3) = ops.bn_stats_pair(y2.view(B * N, L), y3.view(B * N, L), g2, b2, stats[0], stats[1], g3, b3, stats[2], stats[3], training)
         out, out16 = ops.gcn_edges_fwd_bn(y2, y3, aff2, aff3, rel_ind, skip.contiguous() if skip is not None else None, B, N, K, L, want16)
         ctx.save_for_backward(y2, y3, aff2, rstd2, aff3, rstd3, ptr, edges)
         ctx.params = (g2, b2, g3, b3)
@@ -506,8 +515,7 @@ class GcnEdgesBnFn(Function):
         g2, b2, g3, b3 = ctx.params
         dP = dP.contiguous()
         dF2, dF3 = ops.gcn_edges_bwd_bn(dP, y2, y3, aff2, aff3, ptr, edges, B, N, K, L)
-        dy2, dg2, db2 = _bn_back(dF2, y2, g2, b2, aff2, rstd2)
-        dy3, dg3, db3 = _bn_back(dF3, y3, g3, b3, aff3, rstd3)
+        (dy2, dg2, db2), (dy3, dg3, db3) = _bn_back_pair(dF2, dF3, y2, y3, g2, b2, g3, b3, aff2, aff3, rstd2, rstd3)
         return dy2, dy3, (dP if ctx.has_skip else None), None, None, None, None, dg2, db2, dg3, db3, None, None, None
 
 

@@ -589,6 +589,34 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, momentum=0.1, 
     return aff, rstd
 
 
+def bn_stats_pair(x0, x1, gamma0, beta0, rm0, rv0, gamma1, beta1, rm1, rv1, training, momentum=0.1, eps=1e-5):
+    """`bn_stats` for the two units a fused aggregation consumes (same shape and storage type, training mode) in two launches instead of
+    four (subgc_bn_stats_pair) -> ((aff0, rstd0), (aff1, rstd1))."""
+    if (not training or not PAIR_LAUNCHES or x0.shape != x1.shape or x0.dtype != x1.dtype or rm0 is None or rm1 is None):
+        return bn_stats(x0, gamma0, beta0, rm0, rv0, training, momentum, eps), bn_stats(x1, gamma1, beta1, rm1, rv1, training, momentum, eps)
+    M, C = x0.shape
+    if x0.stride(0) != C or x0.stride(1) != 1 or x1.stride(0) != C or x1.stride(1) != 1:
+        raise SubgcError("bn_stats_pair: contiguous rows needed")
+    aff0, aff1 = torch.empty(3, C, device=x0.device, dtype=torch.float32), torch.empty(3, C, device=x0.device, dtype=torch.float32)
+    rstd0, rstd1 = torch.empty(C, device=x0.device, dtype=torch.float32), torch.empty(C, device=x0.device, dtype=torch.float32)
+    f32 = torch.float32
+    call("subgc_bn_stats_pair", _ptr(x0), _ptr(x1), int(is_b16(x0)), M, C, _ptr(gamma0, f32), _ptr(gamma1, f32), _ptr(beta0, f32), _ptr(beta1, f32),
+         _ptr(rm0, f32), _ptr(rm1, f32), _ptr(rv0, f32), _ptr(rv1, f32), _ptr(aff0), _ptr(aff1), _ptr(rstd0), _ptr(rstd1), float(momentum), float(eps),
+         *_ws(x0), _stream())
+    return (aff0, rstd0), (aff1, rstd1)
+
+
+def bn_bwd_fused_pair(dy0, dy1, x0, x1, gamma0, gamma1, aff0, aff1, rstd0, rstd1, dg0, dg1, db0, db1, accumulate):
+    """`bn_bwd_fused` for both units in two launches instead of four (subgc_bn_bwd_fused_pair) -> (dx0, dx1)."""
+    M, C = x0.shape
+    dx0, dx1 = torch.empty_like(x0), torch.empty_like(x1)
+    f32 = torch.float32
+    call("subgc_bn_bwd_fused_pair", _ptr(dy0, f32), _ptr(dy1, f32), _ptr(x0), _ptr(x1), int(is_b16(x0)), M, C, _ptr(gamma0, f32), _ptr(gamma1, f32),
+         _ptr(aff0, f32), _ptr(aff1, f32), _ptr(rstd0, f32), _ptr(rstd1, f32), _ptr(dx0), _ptr(dx1), int(is_b16(dx0)), _ptr(dg0, f32), _ptr(dg1, f32),
+         _ptr(db0, f32), _ptr(db1, f32), int(accumulate), *_ws(x0), _stream())
+    return dx0, dx1
+
+
 def bn_bwd_fused(dy, x, gamma, aff, rstd, dgamma, dbeta, accumulate):
     """-> d(x) in x's storage type; dgamma / dbeta [C] written (or added to)."""
     M, C = x.shape

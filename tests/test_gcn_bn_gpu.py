@@ -172,3 +172,34 @@ def test_bf16_stored_unit_outputs_aggregate_like_their_fp32_values(B, N, K, L):
     (outp * w).sum().backward()
     (refp * w).sum().backward()
     assert torch.equal(y2.grad, y2f.grad.to(BFT)) and torch.equal(y3.grad, y3f.grad.to(BFT)) and torch.equal(skp.grad, skpf.grad)
+
+
+@pytest.mark.parametrize("M,C,bf16", [(16640, 1024, True), (9472, 1024, True), (4736, 1024, False), (37, 8, False)])
+def test_bn_pair_launches_equal_the_single_calls(M, C, bf16):
+    """subgc_bn_stats_pair / subgc_bn_bwd_fused_pair: the two units a fused aggregation consumes, two launches instead of four each -- the
+    slab plans and summation orders of the single calls, so their results bit for bit (statistics, running statistics, d(x), affine
+    gradients written or accumulated)."""
+    g = torch.Generator().manual_seed(M + C)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    xs = [(mk(M, C) * 2 + 1), (mk(M, C) * 0.5 - 2)]
+    if bf16:
+        xs = [x.to(torch.bfloat16) for x in xs]
+    gam, bet = [mk(C), mk(C)], [mk(C), mk(C)]
+    run = lambda: ([torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)], [torch.ones(C, device=DEV), torch.ones(C, device=DEV)])
+    rm_s, rv_s = run()
+    single = [ops.bn_stats(xs[i], gam[i], bet[i], rm_s[i], rv_s[i], True) for i in range(2)]
+    rm_p, rv_p = run()
+    pair = ops.bn_stats_pair(xs[0], xs[1], gam[0], bet[0], rm_p[0], rv_p[0], gam[1], bet[1], rm_p[1], rv_p[1], True)
+    for i in range(2):
+        assert torch.equal(single[i][0], pair[i][0]) and torch.equal(single[i][1], pair[i][1])
+        assert torch.equal(rm_s[i], rm_p[i]) and torch.equal(rv_s[i], rv_p[i])
+    dys = [mk(M, C), mk(M, C)]
+    for acc in (False, True):
+        base = [mk(C), mk(C), mk(C), mk(C)]
+        dg_s, db_s = [base[0].clone(), base[1].clone()], [base[2].clone(), base[3].clone()]
+        dx_s = [ops.bn_bwd_fused(dys[i], xs[i], gam[i], single[i][0], single[i][1], dg_s[i], db_s[i], acc) for i in range(2)]
+        dg_p, db_p = [base[0].clone(), base[1].clone()], [base[2].clone(), base[3].clone()]
+        dx_p = ops.bn_bwd_fused_pair(dys[0], dys[1], xs[0], xs[1], gam[0], gam[1], pair[0][0], pair[1][0], pair[0][1], pair[1][1], dg_p[0], dg_p[1],
+                                     db_p[0], db_p[1], acc)
+        for i in range(2):
+            assert torch.equal(dx_s[i], dx_p[i]) and torch.equal(dg_s[i], dg_p[i]) and torch.equal(db_s[i], db_p[i])
