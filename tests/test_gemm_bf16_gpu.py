@@ -192,3 +192,31 @@ def test_colsum_set_equals_single_column_sums():
         ops.colsum_set(xs, outs, accumulate=acc)
         for o, w in zip(outs, want):
             assert torch.equal(o, w)
+
+
+def test_gemm_pair_falls_back_to_two_calls_when_the_problems_differ():
+    """Different shapes / leading dimensions / storage types cannot share a launch: `ops.gemm_pair` then issues two `ops.gemm` calls, and with
+    `ops.PAIR_LAUNCHES = False` always does -- same results either way."""
+    a1, b1, r1 = operands("nt", 512, 256, 128, seed=1)
+    a2, b2, r2 = operands("nt", 384, 256, 128, seed=2)                       # other M
+    o1, o2 = torch.empty(512, 256, device=DEV), torch.empty(384, 256, device=DEV)
+    ops.gemm_pair(a1, a2, b1, b2, o1, o2, tb=True)
+    assert float((o1.double() - r1).abs().max()) < 2e-5 * float(r1.abs().max()) and float((o2.double() - r2).abs().max()) < 2e-5 * float(r2.abs().max())
+    a3, b3, r3 = operands("nt", 512, 256, 128, seed=3, lda_pad=8)            # same shape, other leading dimension
+    o3 = torch.empty(512, 256, device=DEV)
+    ops.gemm_pair(a1, a3, b1, b3, o1, o3, tb=True)
+    assert float((o3.double() - r3).abs().max()) < 2e-5 * float(r3.abs().max())
+    f1, f2 = a1.float(), a3.float().contiguous()                             # fp32 operands: the fp32 pair kernel
+    g1, g2 = b1.float(), b3.float().contiguous()
+    p1, p2 = torch.empty(512, 256, device=DEV), torch.empty(512, 256, device=DEV)
+    ops.gemm_pair(f1, f2, g1, g2, p1, p2, tb=True)
+    assert float((p1.double() - r1).abs().max()) < 2e-5 * float(r1.abs().max()) and float((p2.double() - r3).abs().max()) < 2e-5 * float(r3.abs().max())
+    ops.PAIR_LAUNCHES = False
+    try:
+        q1, q2 = torch.empty(512, 256, device=DEV), torch.empty(512, 256, device=DEV)
+        ops.gemm_pair(a1, a1, b1, b1, q1, q2, tb=True)
+    finally:
+        ops.PAIR_LAUNCHES = True
+    s1, s2 = torch.empty(512, 256, device=DEV), torch.empty(512, 256, device=DEV)
+    ops.gemm_pair(a1, a1, b1, b1, s1, s2, tb=True)
+    assert torch.equal(q1, q2) and torch.equal(s1, s2) and float((q1 - s1).abs().max()) <= 2e-5 * float(r1.abs().max())
