@@ -156,3 +156,51 @@ def test_paired_gcn_units_equal_the_unit_by_unit_path(kind):
             assert cos > 0.99, (k, cos)
         else:
             np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=3e-5 * scale + 1e-9, rtol=3e-4, err_msg=k)
+
+
+def _with_lengths(batch, lengths, vocab=300):
+    """The batch with caption j cut / extended to lengths[j] words (labels [.., 0, w1..wn, 0..], masks = n + 2 ones, as the loader builds them)."""
+    b = {k: v.clone() for k, v in batch.items()}
+    g = torch.Generator().manual_seed(11)
+    T2 = b["labels"].size(1)
+    b["labels"].zero_()
+    b["masks"].zero_()
+    for j, n in enumerate(lengths):
+        b["labels"][j, 1:n + 1] = torch.randint(1, vocab + 1, (n,), generator=g)
+        b["masks"][j, :n + 2] = 1
+    assert T2 >= max(lengths) + 2
+    return b
+
+
+@pytest.mark.parametrize("case", ["one_image", "one_empty_caption", "all_empty", "all_full_length", "one_word_each"])
+@pytest.mark.parametrize("packed", [True, False])
+def test_degenerate_caption_lengths_match_the_oracle(case, packed):
+    """Edge cases of the teacher-forced loop (models/AttModel.py:157-175: the early break on an all-zero label column; the criterion's mask
+    of len + 2 ones): a single image, a caption without words next to full ones, a batch of empty captions (the loop breaks at step 1),
+    captions that use every step, one word each -- loss and gradients against the CPU oracle, packed and unpacked decoder."""
+    from oracle import subgc_oracle as O
+    torch.manual_seed(0)
+    opt = argparse.Namespace(**OPT)
+    m = models.setup(opt)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    B = 1 if case == "one_image" else 3
+    batch = synthetic.make_train_batch(B, D=256, vocab=300, n_obj_cls=60, seed=7, fc_size=256, min_len=3, max_len=12)
+    batch = {k: torch.as_tensor(v) for k, v in batch.items()}
+    S = batch["labels"].size(0)
+    lengths = {"one_image": [4, 9, 1, 16, 7][:S], "one_empty_caption": [0] + [5 + (j % 7) for j in range(S - 1)], "all_empty": [0] * S,
+               "all_full_length": [16] * S, "one_word_each": [1] * S}[case]
+    batch = _with_lengths(batch, lengths)
+    loss, grads = grads_of(m, batch, packed)
+    orc = O.Oracle(opt, sd, requires_grad=True)
+    orc.training = True
+    ref = O.loss_wrapper(orc, batch)
+    (ref["lang_loss"] + ref["gpn_loss"]).backward()
+    assert abs(loss - float(ref["lang_loss"])) < 1e-4 * max(1.0, abs(float(ref["lang_loss"])))
+    for k, p in m.named_parameters():
+        want = orc.P[k].grad
+        if want is None:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want.numpy(), atol=2e-4 * max(scale, 1e-3) + 2e-6, rtol=5e-3, err_msg=f"{case} {k}")
