@@ -9,8 +9,8 @@ import bench
 import subgc.models as models
 from subgc import synthetic, ops
 DEV = "cuda:0"
-for cfgname in ("full_gc_kar", "flickr"):
-    cfg = bench.CONFIGS[cfgname]
+for cfgname in (sys.argv[1:] or ("full_gc_kar", "flickr")):
+    cfg = bench.CONFIGS[cfgname] if cfgname != "kar" else {"opt": bench.KAR, "batch": 128, "data": {}}
     torch.manual_seed(5)
     m = models.setup(argparse.Namespace(**cfg["opt"])).to(DEV).train()
     lw = models.LossWrapper(m, None)
@@ -22,7 +22,8 @@ for cfgname in ("full_gc_kar", "flickr"):
     seen = collections.Counter()
     real = ops.call
     def spy(name, *a):
-        if name in ("subgc_cast_f32_bf16", "subgc_fill_f32", "subgc_add_n_f32", "subgc_copy2d_b16", "subgc_colsum_bf16", "subgc_colsum_f32", "subgc_transpose_f32_bf16"):
+        if name in ("subgc_cast_f32_bf16", "subgc_fill_f32", "subgc_add_n_f32", "subgc_copy2d_b16", "subgc_colsum_bf16", "subgc_colsum_f32", "subgc_transpose_f32_bf16",
+                    "subgc_copy2d_f32", "subgc_gather_rows_f32", "subgc_scatter_add_rows_f32", "subgc_fill2d_f32", "subgc_relu_bwd"):
             st = [f for f in traceback.extract_stack() if "subgc" in f.filename and "ops.py" not in f.filename and "_casts" not in f.filename]
             where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[-2:][::-1])
             shape = (a[4], a[5]) if name == "subgc_cast_f32_bf16" else ""
