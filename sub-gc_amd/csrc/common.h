@@ -99,23 +99,39 @@ __device__ __forceinline__ float4 subgc_load_q(const float* __restrict__ ah, con
     } while (0)
 
 // ---- device helpers ------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions on the DPP path (gfx9 family: quad_perm / row_half_mirror / row_mirror inside a 16-lane row, row_bcast:15 / :31
+// across rows, the total read from lane 63): six VALU moves of a few cycles each.  The __shfl_xor butterfly they replace compiles to six
+// DEPENDENT ds_bpermute exchanges through the LDS crossbar -- ~1 us per lone reduction when nothing else is ready to issue.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float v, float other) {      // lane <- DPP source lane of v; `other` where the row is masked off
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, other), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
-// sum over the 64 lanes of N values at once: the six exchange steps are shared, so the N ds_bpermute chains overlap instead of running
-// back to back (a lone wave_sum is six DEPENDENT cross-lane exchanges, ~1 us when nothing else is ready to issue)
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_or<0xB1, 0xF>(v, 0.f);      // quad_perm [1,0,3,2]
+    v += dpp_or<0x4E, 0xF>(v, 0.f);      // quad_perm [2,3,0,1]
+    v += dpp_or<0x141, 0xF>(v, 0.f);     // row_half_mirror: every lane of an 8-group holds the group's sum
+    v += dpp_or<0x140, 0xF>(v, 0.f);     // row_mirror: ... of a 16-lane row, the row's sum
+    v += dpp_or<0x142, 0xA>(v, 0.f);     // row_bcast:15 into rows 1 and 3
+    v += dpp_or<0x143, 0xC>(v, 0.f);     // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// sum over the 64 lanes of N values at once: the N chains interleave
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float t[N];
+    for (int k = 0; k < N; ++k) v[k] += dpp_or<0xB1, 0xF>(v[k], 0.f);
 #pragma unroll
-        for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], o, 64);
+    for (int k = 0; k < N; ++k) v[k] += dpp_or<0x4E, 0xF>(v[k], 0.f);
 #pragma unroll
-        for (int k = 0; k < N; ++k) v[k] += t[k];
-    }
+    for (int k = 0; k < N; ++k) v[k] += dpp_or<0x141, 0xF>(v[k], 0.f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_or<0x140, 0xF>(v[k], 0.f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_or<0x142, 0xA>(v[k], 0.f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_or<0x143, 0xC>(v[k], 0.f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[k]), 63));
 }
 // Segment sums of two gather lists at once: sa += fa(ia[j]) for j in [a0, a1), sb += fb(ib[j]) for j in [b0, b1).  Up to four rows of EACH list
 // are requested before any is added (wave-uniform bounds: the skipped loads are scalar branches), additions in list order, so the result is
@@ -140,9 +156,13 @@ __device__ __forceinline__ void gather_pair(const int* __restrict__ ia, int a0, 
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_or<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_or<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // block-wide sum through LDS scratch (>= 16 floats); every thread gets the result
 __device__ __forceinline__ float block_sum(float v, float* sm) {

@@ -714,3 +714,16 @@ def test_gemm_f32_pair_equals_two_single_launches(mode, M, N, K):
     ops.gemm_pair(a1, a2, b1, b2, p1, p2, ta=mode == "tn", tb=mode == "nt", accum=True)
     assert float((p1.double() - o1.double() - r1 + bias1.double()).abs().max()) < 4e-5 * float(r1.abs().max())
     assert float((p2.double() - o2.double() - r2 + bias2.double()).abs().max()) < 4e-5 * float(r2.abs().max())
+
+
+def test_wave_reductions_on_the_dpp_path():
+    """wave_sum / wave_max (common.h: quad_perm, row mirrors, row_bcast, readlane 63 instead of six ds_bpermute exchanges) through the kernels
+    that are nothing but such reductions: row sums of 64-column blocks (subgc_colsum's scalar form is block-based, so use row log-sum-exp: a
+    wave_max and a wave_sum per row) against fp64, on rows whose maximum sits in every lane position and with negative values only."""
+    V = 9488
+    x = torch.randn(130, V, device=DEV) * 3 - 20.0                          # all negative: a max seeded with 0 would be wrong
+    for r in range(128):
+        x[r, (r * 73) % V] = -0.5 + r * 1e-3                               # the row maximum visits many lane / wave positions
+    lse = ops.row_lse(x)
+    want = torch.logsumexp(x.double(), dim=1)
+    assert float((lse.double() - want).abs().max()) < 1e-5
