@@ -27,10 +27,15 @@ else:
     batches = [{k: v.to(dev) for k, v in synthetic.make_test_batch(50, seed=500 + i).items()} for i in range(256)]
     sopt = dict(sample_max=1, beam_size=2 if leg == "beam2_batched" else 1)
     fn = lambda: m.sample_images(batches, opt=sopt)
+from subgc import _lib
 with torch.no_grad():
     fn()
     torch.cuda.synchronize()
+    _lib.prof_enable("gemm")                       # counts the GEMM CALLS (a call may be two main kernels: row cut, gemm_*.hip)
     for _ in range(passes):
         fn()
     torch.cuda.synchronize()
+    calls = _lib.prof_collect("gemm")[0]
+    _lib.prof_enable("gemm", False)
 print(leg, "done", passes, "passes")
+print("gemm_calls_per_pass", calls // passes)

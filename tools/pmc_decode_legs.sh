@@ -35,10 +35,16 @@ for leg in ("greedy_batched", "beam2_batched", "mrnn"):
     f, fd = load(leg, "FETCH_SIZE"); w, wd = load(leg, "WRITE_SIZE")
     mains = sum(v for k, v in fd.items() if k != "splitk_reduce_kernel")
     passes = $PASSES + 1
-    out[leg] = {"gemm_main_dispatches": mains, "passes_profiled": passes, "gemm_launches_per_pass": mains // passes,
-                "dispatches_not_in_a_whole_pass": mains - (mains // passes) * passes,
-                "traffic_bytes_per_launch": (2.0 * 1024 * sum(f.values()) + 1024 * sum(w.values())) / max(mains, 1),
-                "fetch_bytes_per_launch": 2.0 * 1024 * sum(f.values()) / max(mains, 1), "write_bytes_per_launch": 1024 * sum(w.values()) / max(mains, 1),
+    calls = None                                   # GEMM calls per pass as the leg itself counted them (a call may be two main kernels: row cut)
+    for line in open("$O/pmcl_%s_FETCH_SIZE.log" % leg, errors="replace"):
+        if line.startswith("gemm_calls_per_pass"):
+            calls = int(line.split()[1])
+    per_pass = calls if calls else mains // passes
+    launches = per_pass * passes
+    out[leg] = {"gemm_main_dispatches": mains, "passes_profiled": passes, "gemm_launches_per_pass": per_pass,
+                "main_kernels_per_launch": mains / max(launches, 1),
+                "traffic_bytes_per_launch": (2.0 * 1024 * sum(f.values()) + 1024 * sum(w.values())) / max(launches, 1),
+                "fetch_bytes_per_launch": 2.0 * 1024 * sum(f.values()) / max(launches, 1), "write_bytes_per_launch": 1024 * sum(w.values()) / max(launches, 1),
                 "kernel_dispatches": fd}
 json.dump(out, open("$O/${ROUND}_pmc_decode_legs.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
