@@ -7,7 +7,7 @@ O=$R/gpurun_out
 ROUND=${ROUND:-r04}
 python $R/bench.py > $O/${ROUND}_bench_n1.log 2>&1; tail -1 $O/${ROUND}_bench_n1.log > $R/profiles/${ROUND}_bench_n1.json
 cp $R/profiles/${ROUND}_bench_n1.json $O/${ROUND}_bench_n1.json          # profiles/ on the box is not merged back, gpurun_out/ is
-for C in full_gc_kar flickr; do
+for C in full_gc_kar flickr kar_ss25; do
   python $R/bench.py --config $C --steps 10 --warmup 3 > $O/${ROUND}_bench_$C.log 2>&1; tail -1 $O/${ROUND}_bench_$C.log > $O/${ROUND}_bench_$C.json
 done
 prof() {  # name, command...
@@ -28,8 +28,8 @@ LPS=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1
 ALG=$(python -c "import json;print(json.load(open('$R/profiles/${ROUND}_bench_n1.json'))['roofline']['algorithmic_bytes_per_launch'])")
 python $R/tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) \
    --launches-per-step $LPS --alg-bytes-per-launch $ALG > $O/${ROUND}_pmc_traffic.json 2> $O/${ROUND}_pmc_traffic.err
-# the same two PMC passes for the bf16 configs
-for C in full_gc_kar flickr; do
+# the same two PMC passes for the bf16 configs and the scheduled-sampling leg
+for C in full_gc_kar flickr kar_ss25; do
   for P in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_${C}_$P
     rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/pmc_${C}_$P -- python $R/bench.py --config $C --steps 3 --warmup 2 --no-cpu-baseline --no-decode --packed-only > $O/pmc_${C}_$P.log 2>&1
