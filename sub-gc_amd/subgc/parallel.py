@@ -131,7 +131,7 @@ class GradBucketReducer:
         self.buckets = model.grad_buckets()                     # [(stage, lo, hi)], readiness order, the fusion layers last
         self.split = model.decoder_offset
         self.overlap = overlap and self.active
-        self._pending, self._launched, self._fired = [], [], {}
+        self._pending, self._launched, self._fired, self._announced = [], [], {}, set()
         self._handles = []
         self.issued = []                                        # (stage, bytes) of every collective of the current step, in issue order
         self._need = {}
@@ -159,38 +159,47 @@ class GradBucketReducer:
         self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _ready(self, stage):
-        """The gradient slice `stage` is final: start its all-reduce now (once per step)."""
-        if stage in self._launched or not self.active or self.model.flat_grads is None:
+        """The gradient slice `stage` is final.  Its all-reduce starts now IF every slice before it in the canonical order
+        (`self.buckets`) is already out; otherwise it is only marked and goes out when its predecessors have (or in `finish`).
+        RCCL pairs collectives across ranks by issue order, so the sequence has to be rank-invariant: always the canonical one,
+        whatever subset of the announcements a rank's backward happened to make (advisor finding, round 4)."""
+        if not self.active or self.model.flat_grads is None or stage in self._launched:
             return
+        self._announced.add(stage)
         for st, lo, hi in self.buckets:
-            if st == stage:
-                self._launched.append(stage)
-                if hi > lo:
-                    self._issue(st, lo, hi)
+            if st in self._launched:
+                continue
+            if st not in self._announced or st == "fusion":      # the fusion slice is final only when backward returns
+                break
+            self._launched.append(st)
+            if hi > lo:
+                self._issue(st, lo, hi)
 
     def prepare(self):
         """Call before forward: (re)binds every .grad into the zeroed flat bucket."""
-        self._fired, self._pending, self._launched, self.issued = {}, [], [], []
+        self._fired, self._pending, self._launched, self.issued, self._announced = {}, [], [], [], set()
         return self.model.flatten_grads()
 
     def finish(self, average=True):
         """Call after loss.backward(): reduces whatever has not been sent yet (the fusion slice; every slice when nothing
-        overlapped -- adjacent ranges travel as one collective), waits for all of it and averages (`average=False`: leave the SUM
-        and hand `1 / world` to `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep)."""
+        overlapped), waits for all of it and averages (`average=False`: leave the SUM and hand `1 / world` to
+        `FlatAdam.step(grad_scale=...)`, which folds it into its own sweep).
+
+        The collective SEQUENCE must be the same on every rank (RCCL matches collectives by issue order, not by name): which
+        buckets went out early is rank-local state (a marker that never fired on one rank -- no gradient reached it, an early
+        return in a backward), so the leftovers are issued ONE BY ONE in the canonical `self.buckets` order, never merged and
+        never re-sorted -- every rank then issues the five slices with the same sizes; a rank that announced a slice early has
+        merely issued it sooner.  With overlap on, the early order IS the canonical order (logit, recurrent, prepare, gcn), so a
+        rank that missed an announcement still lines up (`_ready` holds a slice back until its predecessors are out)."""
         from . import ops
         ops.join_forks()
         if not self.active:
             return self.model.flat_grads
         g = self.model.flat_grads
-        rest = sorted((lo, hi, st) for st, lo, hi in self.buckets if st not in self._launched and hi > lo)
-        merged = []
-        for lo, hi, st in rest:
-            if merged and merged[-1][1] == lo:
-                merged[-1] = (merged[-1][0], hi, merged[-1][2] + "+" + st)
-            else:
-                merged.append((lo, hi, st))
-        for lo, hi, st in merged:
-            self._issue(st, lo, hi)
+        for st, lo, hi in self.buckets:
+            if st not in self._launched and hi > lo:
+                self._launched.append(st)
+                self._issue(st, lo, hi)
         for w in self._pending:
             w.wait()
         self._pending = []

@@ -97,6 +97,58 @@ def test_two_rank_gloo_bucket_allreduce_is_mean_of_shard_grads():
     assert seen_dead == len(g.meta["dead_params"])
 
 
+def _skew_worker(rank, world, port, q):
+    """Rank 0 announces every slice like a normal backward; rank 1 never announces `recurrent` (a marker that did not fire) and
+    announces `prepare` and `gcn` anyway.  Both must issue the SAME collective sequence (canonical order, same sizes)."""
+    for p in (os.path.join(ROOT, "sub-gc_amd"), ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from conftest import Golden
+    from subgc import parallel
+    from subgc import functions as F_
+    import subgc.models as models
+    parallel.init_distributed("gloo")
+    model = models.setup(Golden("subgc_train").opt(caption_model="topdown"))
+    red = parallel.GradBucketReducer(model)
+    flat = red.prepare()
+    torch.manual_seed(rank)
+    flat.copy_(torch.randn_like(flat))
+    mine = flat.clone()
+    order = ["logit", "recurrent", "prepare", "gcn"] if rank == 0 else ["logit", "prepare", "gcn"]
+    early = []
+    for st in order:
+        F_.grads_ready(st)
+        early.append([s for s, _ in red.issued])
+    out = red.finish().clone()
+    red.close()
+    q.put((rank, [s for s, _ in red.issued], [b for _, b in red.issued], early, mine.numpy(), out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_collective_sequence_is_rank_invariant_when_one_rank_misses_an_announcement():
+    """Advisor finding (round 4): which slices went out early is rank-local; the issue ORDER and SIZES must not be."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_skew_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, seq0, by0, early0, g0, o0), (_, seq1, by1, early1, g1, o1) = res
+    canon = ["logit", "recurrent", "prepare", "gcn", "fusion"]
+    assert seq0 == canon and seq1 == canon and by0 == by1
+    assert early0[-1] == canon[:4]                                      # rank 0 sent four slices from inside the backward
+    assert early1[-1] == ["logit"]                                      # rank 1 held `prepare` / `gcn` back behind the missing `recurrent`
+    np.testing.assert_array_equal(o0, o1)
+    np.testing.assert_allclose(o0, 0.5 * (g0 + g1), rtol=1e-6, atol=1e-7)
+
+
 def test_grad_buckets_are_contiguous_readiness_ordered_and_cover_the_flat_buffer():
     """AttModel.grad_buckets: logit -> recurrent -> prepare -> gcn -> fusion, contiguous, disjoint, covering every parameter slot, and
     every parameter lies in the slice its name says (the decoder Functions announce the slices by these names)."""
