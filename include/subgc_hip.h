@@ -624,6 +624,29 @@ int subgc_beam_step(const float* tv, const int32_t* ti, int32_t* seq, float* lps
  * sorted[r] = that score (may be NULL).  n <= 8192 (an image has at most 2M candidate sub-graphs).     */
 int subgc_rank_desc_f32(const float* score, int n, int64_t* order, float* sorted, void* stream);
 
+/* The same ranking for MANY images in one launch (misc/eval_utils.py:105-115, the body of the one-image-per-call loop): image i
+ * owns rows seg[i] .. seg[i+1]-1 (<= max_rows <= 8192 each) of a decode batch.  order[seg[i]+r] = image-LOCAL index of its r-th best
+ * row (score descending, ties keep input order = subgc_rank_desc_f32); score_sorted / keep_sorted / seq_sorted [rows, T] are the
+ * image's scores, kept sub-graph indices (`keep_nms_ind[sort_ind]`) and token rows (`seqq[sort_ind]`) in that order, narrowed to
+ * int32.  identity != 0: no sorting (Full-GC, :112-115: sort_ind = arange).                                                   */
+int subgc_eval_rank_rows(const float* score, const int64_t* keep, const int64_t* seq, int T, const int32_t* seg, int I,
+                         int max_rows, int identity, int32_t* order, float* score_sorted, int32_t* keep_sorted,
+                         int32_t* seq_sorted, void* stream);
+
+/* Grounding material, integer part (misc/grd_utils.py:36-47, collected per image at misc/eval_utils.py:143-146).  For image i the
+ * chosen caption is row g = seg[i] + order[seg[i] + pick[i]] of the decode batch (pick NULL: 0 = the best-ranked sentence; a
+ * consensus re-ranker passes its own subg_index; order NULL: identity, the Full-GC branch :44-46).  n_words[i] = the words
+ * decode_sequence emits for it = tokens of seq[g, :T] before the first 0.  For word position j < n_words[i]:
+ *   att2[i, j] = FIRST arg-max over the N columns of AL[j, g, :]   (`torch.max(att_weights[row], dim=1)[1][:len(words)]`; AL is the
+ *                decode loop's time-major attention buffer [T1, rows, N], strides ld_t / ld_row in elements -- columns past the
+ *                image's n_max are zero, so the arg-max over N columns equals the one over the clipped tensor),
+ *   node[i, j] = idx[g, att2[i, j]]   (`obj_ind_this[att2_ind[wd_j]]`: the sub-graph's node list -> full-graph node id = box row;
+ *                Full-GC: idx rows are arange).
+ * Positions j >= n_words[i] hold -1.  att2, node: int32 [I, T1]; T <= 64.                                                      */
+int subgc_grounding_argmax(const float* AL, int64_t ld_t, int64_t ld_row, int N, int T1, const int64_t* seq, int T,
+                           const int64_t* idx, int64_t ld_idx, const int32_t* seg, const int32_t* order, const int32_t* pick,
+                           int I, int32_t* att2, int32_t* node, int32_t* n_words, void* stream);
+
 /* ---- bf16-operand GEMM (BASELINE configs 3 / 5: "bf16") ---------------------------------------------------------------
  * C = epilogue(op(A) . op(B)) with A, B STORED as bf16 (raw uint16 bit patterns), fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16; the result goes to C32 (fp32) and / or C16 (bf16, round-to-nearest-even) -- either may be NULL.

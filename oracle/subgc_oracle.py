@@ -579,6 +579,34 @@ def rank_subgraphs(gpn, seqq, subgraph_score, keep_nms_ind, sct_mode=False):
     return seqq, subgraph_score, keep_nms_ind, torch.arange(subgraph_score.size(0)).type_as(keep_nms_ind)
 
 
+def grounding_argmax(att_weights, sort_ind, subg_index, n_words, obj_ind_this):
+    """misc/grd_utils.py:36-47, the integer part: for the caption ranked `subg_index` the arg-max attention column of each of its
+    first `n_words` word positions (`torch.max(att_weights[row], dim=1)[1][:len(grd_wd)]`, :42 / :46) and the full-graph node
+    each stands for (`obj_ind_this[att2_ind[wd_j]]`, :56).  att_weights [n, steps, n_max]; sort_ind: eval_utils.py:106-113 (None:
+    the Full-GC branch indexes att_weights[subg_index] directly, :46); obj_ind_this: the chosen sub-graph's node ids in the full
+    graph, ascending (:41 `graph_mask[1].nonzero()[0]`; Full-GC: arange(36), :45).  -> (att2_ind, node_ind) int64 arrays.
+    PINNED by tests/golden/grd_out.npz: what the reference's own get_grounding_material returned (make_golden.py grd_cases)."""
+    row = int(subg_index) if sort_ind is None else int(sort_ind[subg_index])
+    att2 = torch.max(att_weights[row], dim=1)[1][:n_words]
+    obj = np.asarray(obj_ind_this)
+    return att2.numpy().astype(np.int64), obj[att2.numpy()].astype(np.int64)
+
+
+def grounding_material(sents, subg_index, att2_node, boxes, wd_to_lemma, lemma_det_id_dict, det_id_to_det_wd):
+    """misc/grd_utils.py:38,49-58: words of the chosen sentence -> lemma -> detection class; the box of each grounded word's node."""
+    out = {'clss': [], 'idx_in_sent': [], 'bbox': []}
+    grd_wd = sents[subg_index].split()
+    for wd_j in range(len(grd_wd)):
+        if grd_wd[wd_j] not in wd_to_lemma:
+            continue
+        lemma = wd_to_lemma[grd_wd[wd_j]]
+        if lemma in lemma_det_id_dict:
+            out['bbox'].append(boxes[att2_node[wd_j]].tolist())
+            out['clss'].append(det_id_to_det_wd[lemma_det_id_dict[lemma]])
+            out['idx_in_sent'].append(wd_j)
+    return out
+
+
 # --------------------------------------------------------------------------- batch assembly (dataloaders/dataloader.py:139-157,225-367)
 # PINNED: tests/golden/loader_*.npz hold what the reference's own `DataLoader.__getitem__` returned for fabricated dataset
 # entries (make_golden.py loader_cases: h5py stubbed so the module imports, object made with object.__new__), for the

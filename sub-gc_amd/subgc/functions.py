@@ -837,6 +837,29 @@ def _step_offsets(T, S, dev):
     return t
 
 
+def tap_prepared(tap, pr, c2a_b):
+    """Debug tap (model.tap, tests only): the prepared features in the reference's layout -- p_fc [S, R], p_att [S, n_max, R] (pad
+    rows 0), pp_att [S, n_max, A] (pad rows = ctx2att's bias: the reference projects the zero rows, AttModel.py:364-366).
+    Plumbing in torch, never on the product path."""
+    tap["p_fc"] = pr.f.detach().clone()
+    lens = pr.lens.long().cpu()
+    S, n_max = pr.S, int(lens.max()) if lens.numel() else 0
+    v, u = pr.v.float(), pr.u.float()
+    if pr.shared:
+        B, g, N = pr.B, pr.g, pr.N
+        img = torch.arange(S, device=v.device) // g
+        tap["p_att"] = v.view(B, N, -1)[img][:, :n_max].clone()
+        tap["pp_att"] = u.view(B, N, -1)[img][:, :n_max].clone()
+        return
+    off = pr.off.long().cpu()
+    pa = v.new_zeros(S, n_max, v.size(1))
+    pp = c2a_b.detach().float().view(1, 1, -1).expand(S, n_max, -1).clone()
+    for s_ in range(S):
+        n, o = int(lens[s_]), int(off[s_])
+        pa[s_, :n] = v[o:o + n]; pp[s_, :n] = u[o:o + n]
+    tap["p_att"], tap["pp_att"] = pa, pp
+
+
 class DecoderFn(Function):
     """Teacher-forced attention-LSTM decoder -> log-probabilities [S, T, V+1]."""
 
@@ -918,6 +941,13 @@ class DecoderFn(Function):
         active = ops.step_active(labels, T)
         ops.log_softmax_rows_(logits, active)
 
+        tap = meta.get("tap")
+        if tap is not None:                          # debug only (model.tap): per-step intermediates in the oracle's / golden files' names
+            tap_prepared(tap, pr, c2a_b)
+            f32 = lambda t: t.float().clone()
+            tap.update(step_h_att=f32(H2[:T, :, R:2 * R]), step_ctx=f32(H2[:T, :, :R]), step_h_lang=f32(H1[1:T + 1, :, :R]),
+                       step_c_att=C1[1:].clone(), step_c_lang=C2[1:].clone(), step_alpha=AL.clone(),
+                       step_logp=logits3.permute(1, 0, 2).clone(), fed_tokens=tokens[:, :T].t().clone())
         crit = meta.get("crit")                      # (target [S,T] view, mask [S,T] view): criterion fused in
         if crit is not None:
             loss, nll_scratch = ops.masked_nll_fwd(logits.view(S, T, V1), crit[0], crit[1])

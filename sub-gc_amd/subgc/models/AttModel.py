@@ -126,6 +126,11 @@ class AttModel(CaptionModel):
         self._dropout_calls = 0
         self.injected_masks = None       # tests inject {'fc','att','xt','out','gpn_hid'} keep-masks here
         self.injected_ss = None          # tests inject (selector uniforms [T,S], draw uniforms [T,S]) for scheduled sampling
+        # debug tap (tests only): set to a dict and the next `model(...)` / `_sample` call files its intermediates there under the
+        # oracle's / golden files' names (fusion_x, gcn_x_layer{l}, x_obj_out, read_out, att_sel, fc_sel, p_fc, p_att, pp_att,
+        # step_{h_att,c_att,h_lang,c_lang,alpha,ctx,logp}); None (default): no cost.  The train forward then runs the unpacked
+        # decoder, the decode the eager (not graph-replayed) loop -- same kernels.
+        self.__dict__["tap"] = None
         self.__dict__["_nbt_pending"] = {}
         self._build_parameters()
 
@@ -489,9 +494,14 @@ class AttModel(CaptionModel):
             x = F_.linear(att2, self.P("obj_v_proj.weight"), self.P("obj_v_proj.bias"), **lin16("obj_v_proj.weight"))
         x = x.view(B, N, L)
         p = None
-        if needP[0] or self.GCN_layers == 0:
+        tap = self.__dict__.get("tap")
+        if needP[0] or self.GCN_layers == 0 or tap is not None:
             pc = ops.row_argmax(pred_dist.reshape(B * K, -1), skip=1 if self.pred_emb_type == 1 else 0, i32=True)
             p = self._class_proj("sg_pred_embed.weight", "pred_emb_prj", pc).view(B, K, L)
+        if tap is not None:
+            tap["fusion_x"], tap["fusion_p"] = x.detach().clone(), p.detach().clone()
+            if not needP[0] and self.GCN_layers > 0:
+                p = None                                            # computed for the tap only: the live graph does not read it
         if self.GCN_layers == 0:
             return x
         if torch.is_grad_enabled() and F_.on_grads_ready is not None:
@@ -550,6 +560,13 @@ class AttModel(CaptionModel):
                 else:
                     new_p = F_.GcnEdgesFn.apply(y2, y3, skip_p if res else None, rel_ind, ptr, edges, K)
             x, p = new_x, new_p
+            if tap is not None:                                     # dead outputs (None) are simply absent
+                if x is not None:
+                    tap[f"gcn_x_layer{l}"] = x.detach().float().clone()
+                if p is not None:
+                    tap[f"gcn_p_layer{l}"] = p.detach().float().clone()
+        if tap is not None:
+            tap["x_obj_out"] = x.detach().float().clone()
         return x
 
     # ------------------------------------------------------------------ sGPN
@@ -591,6 +608,10 @@ class AttModel(CaptionModel):
         # gpn.py:63-78: first max over the hb positive scores, that sub-graph's node list / node count / read-out row (.detach())
         sel_idx, lens, ro_sel, img_s = ops.gpn_select(score, gpn_obj_ind, att_masks, read_out.detach(), spi)
         fc = self._read_out_proj(ro_sel, "gpn_layer.")
+        tap = self.__dict__.get("tap")
+        if tap is not None:                                         # att_sel: the reference's gathered node rows (pads = the dummy node's row)
+            tap.update(read_out=read_out.detach().clone(), fc_sel=fc.detach().clone(), sel_idx=sel_idx.clone(), sel_lens=lens.clone(),
+                       att_sel=X2.detach().view(B, N, L)[img_s.long().view(-1, 1), sel_idx].clone())
         return gpn_loss, score, sel_idx, lens, fc, img_s
 
     def _consts(self, dev, B, b5, N):
@@ -677,7 +698,8 @@ class AttModel(CaptionModel):
         hb = gpn_obj_ind.size(2) if gpn_obj_ind is not None else 1
         # the packed decoder's plan kernels keep a sentence's live steps in a 64-bit mask and the sentence order in LDS (csrc/plan.hip:
         # T <= 63, S <= 16384); longer captions / larger shards run the unpacked DecoderFn (same kernels, every step of every sentence)
-        packed = (fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None
+        tap = self.__dict__.get("tap")
+        packed = (fused_crit is not None and not need_outputs and self.packed_decoder and self.injected_masks is None and tap is None
                   and T <= F_.PACKED_MAX_STEPS and b5 <= F_.PACKED_MAX_SENTENCES)
         plan = None
         if packed:                                                                        # the packed decoder's row plan, read behind an event
@@ -701,7 +723,7 @@ class AttModel(CaptionModel):
             ops.fill2d_(mask_sel[:, :36], 1.0)                                            # in place on the caller's tensor
             sel_idx = c["ar_b5"]
             lens = ops.row_count(mask_sel)
-        meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit, "plan": plan}
+        meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit, "plan": plan, "tap": tap}
         if (not self.gpn and self.share_attention_sets and self.injected_masks is None and b5 % B == 0
                 and F_.shared_sets_ok(b5 // B, N, self.att_hid_size, R, T)):
             meta["shared"] = {"B": B, "g": b5 // B, "rows": c["rows"]}                    # every sentence attends over its image's N node rows
@@ -750,17 +772,18 @@ class AttModel(CaptionModel):
         return sampling.decode_one_image(self, X2, N, (0, gpn_obj_ind, att_masks, gpn_pool_mtx), opt, uniforms, forced)
 
     @torch.no_grad()
-    def sample_images(self, images, opt={}):
+    def sample_images(self, images, opt={}, batch_out=None):
         """Decode MANY images in one batch (not in the reference, whose loop is one image per call, eval_utils.py:98-104).
         `images`: list of dicts with the test loader's keys (att_feats [1,N,D], obj_dist, pred_dist, rel_ind, att_masks,
-        gpn_obj_ind, gpn_pool_mtx -- the 5-counterpart layout of dataloader_test.py).  Returns one `_sample` tuple per image."""
+        gpn_obj_ind, gpn_pool_mtx -- the 5-counterpart layout of dataloader_test.py).  Returns one `_sample` tuple per image.
+        `batch_out`: see sampling.decode (the whole batch's tensors for the batched eval glue)."""
         # counterpart 0 of every image's loader tensors, stacked into one batch by ONE table upload + four launches (subgc_gather_blocks)
         att, obj, pred, rel = ops.stack_first([[im[k] for im in images] for k in ("att_feats", "obj_dist", "pred_dist", "rel_ind")])
         I, N, _ = att.shape
         X2 = self._encode(att, obj, pred, rel).reshape(I * N, self.GCN_dim).contiguous()
         rows = [(i, im["gpn_obj_ind"], im["att_masks"], im["gpn_pool_mtx"]) for i, im in enumerate(images)]
         sel = sampling.select_subgraphs(self, X2, N, rows) if self.gpn else sampling.full_graph_rows(self, X2, N, rows)
-        return sampling.decode(self, X2, N, sel, opt)
+        return sampling.decode(self, X2, N, sel, opt, batch_out=batch_out)
 
 
 class TopDownModel(AttModel):

@@ -99,7 +99,11 @@ def select_subgraphs(m, X2, N, images, front=None, kept=None):
         r1 = r0 + k_
         out.append(dict(keep=keep[r0:r1], fc=fc[r0:r1], lens=lens_g[r0:r1], idx=idx_g[r0:r1], img=img_g[r0:r1], score=score_g[r0:r1]))
         r0 = r1
-    out.whole = dict(fc=fc, lens=lens_g, idx=idx_g, img=img_g)
+    out.whole = dict(fc=fc, lens=lens_g, idx=idx_g, img=img_g, score=score_g, keep=keep)
+    tap = m.__dict__.get("tap")
+    if tap is not None:                                                                # debug tap (tests): golden-file names
+        tap.update(read_out=read_out.clone(), score_all=score.clone().view(-1), keep_ind=keep.clone(), subgraph_score_raw=score_g.clone(), fc_sel=fc.clone(),
+                   sel_idx=idx_g.clone(), sel_lens=lens_g.clone(), att_sel=X2.view(-1, N, L)[img_g.long().view(-1, 1), idx_g].clone())
     return out
 
 
@@ -129,7 +133,7 @@ def full_graph_rows(m, X2, N, images):
         call_lens = ops.row_count(mk)
         ops.copy_(lens_all[i:i + 1], call_lens)
         out.append(dict(fc=fc[i:i + 1], lens=lens_all[i:i + 1], idx=ar[i:i + 1], img=img[i:i + 1], score=c["one"][i:i + 1], keep=c["zero"][i:i + 1]))
-    out.whole = dict(fc=fc, lens=lens_all, idx=ar, img=img)
+    out.whole = dict(fc=fc, lens=lens_all, idx=ar, img=img, score=c["one"], keep=c["zero"])
     return out
 
 
@@ -356,7 +360,7 @@ def decode_one_image(m, X2, N, image, opt, uniforms=None, forced=None):
     T = m.seq_length
     beam_size = opt.get("beam_size", 1)
     return_att = opt.get("return_att", 0) == 1
-    graphable = m.gpn and not m.sct and forced is None and getattr(m, "decode_hipgraph", True)
+    graphable = m.gpn and not m.sct and forced is None and getattr(m, "decode_hipgraph", True) and m.__dict__.get("tap") is None
     G_in = int(image[1].size(1) * image[1].size(2)) if m.gpn else 0
     fb = _front_buffers(m, G_in, N) if (graphable and G_in > 0) else None
     fr = score_candidates(m, X2, N, [image], fb=fb) if m.gpn else None
@@ -436,9 +440,13 @@ def _uniforms(m, n, T, dev):
 
 
 @torch.no_grad()
-def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
+def decode(m, X2, N, sel, opt, uniforms=None, forced=None, batch_out=None):
     """Greedy / top-k / beam decode of the selected sub-graphs of one or many images as ONE batch.
-    Returns one result tuple per image: (seq, seqLogprobs, score, keep[, att_weights])."""
+    Returns one result tuple per image: (seq, seqLogprobs, score, keep[, att_weights]).
+    `batch_out` (a dict, optional): also receives the WHOLE batch's tensors in image order -- seq, seqlp, score, keep, idx (node
+    lists), lens, bounds (python list of row boundaries) and, with return_att, AL (the loop's time-major attention buffer
+    [T + 1, rows, N]) -- what the batched eval glue reads (eval_glue.caption_images: one ranking / grounding launch and one host copy
+    per decode batch instead of per-image tensor slicing).  `batch_out["skip_att"]`: do not cut the per-image att_weights tensors."""
     dev = X2.device
     T = m.seq_length
     return_att = opt.get("return_att", 0) == 1
@@ -447,6 +455,8 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
     n = sum(sizes)
     z = lambda *s, dt=torch.float32: ops.zero_(torch.empty(*s, device=dev, dtype=dt))
     if n == 0:
+        if batch_out is not None:
+            batch_out.update(rows=0, bounds=[0] * (len(sel) + 1))
         return [(z(0, T, dt=torch.long), z(0, T)) + (s["score"], s["keep"]) + ((z(0, 0, 0),) if return_att else ()) for s in sel]
     whole = getattr(sel, "whole", None)
     if whole is not None:                                                              # the selection's own tensors, already in image order
@@ -473,13 +483,16 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
         else:
             seq, seqlp, done = beam.beam_decode(pr, P, N, T, opt, xt_table=m.xt_gates_table())
         m.done_beams = done if len(sel) == 1 else [done[a:b] for a, b in zip(bounds, bounds[1:])]
+        if batch_out is not None:
+            batch_out.update(_batch_view(sel, whole, seq, seqlp, None, idx_k, lens_k, bounds))
         return [(seq[a:b], seqlp[a:b], s["score"], s["keep"]) for s, a, b in zip(sel, bounds, bounds[1:])]
     k = m.the_k if m.topk_sampling else 0
     own_u = bool(k) and uniforms is None and forced is None
     if own_u:
         uniforms = _uniforms(m, n, T, dev)                                             # step-major [T, n]
     graphed = None
-    if len(sel) == 1 and forced is None and n <= 16 and getattr(m, "decode_hipgraph", True):
+    tap = m.__dict__.get("tap")
+    if len(sel) == 1 and forced is None and n <= 16 and getattr(m, "decode_hipgraph", True) and tap is None:
         # the reference-shaped call (one image, <= 10 rows): launch-bound, replayed as one hipGraph
         try:
             graphed = _graphed_loop(m, n, N, k, return_att, P)
@@ -497,8 +510,18 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
         ut = None
         if uniforms is not None and forced is None:                                    # step-major: a contiguous row per step for the pick kernel
             ut = uniforms if own_u else uniforms.t().contiguous()                      # (injected [n, T] uniforms: test plumbing in torch)
+        if tap is not None:
+            F_.tap_prepared(tap, pr, P[7])
+            if AL is None:
+                AL = z(T + 1, n, N)
+            steps_tap = {k: [] for k in ("h_att", "h_lang", "c_att", "c_lang", "alpha", "logp")}
         for t in range(T + 1):
-            logp = st.step(it, AL[t] if return_att else None, normalize=forced is not None)
+            logp = st.step(it, AL[t] if (return_att or tap is not None) else None, normalize=forced is not None)
+            if tap is not None:                                                        # state after core step t, in the oracle's names
+                R = st.R
+                for k, v_ in (("h_att", st.H1[:, R:]), ("h_lang", st.H1[:, :R]), ("c_att", st.C1[0]), ("c_lang", st.C2[0]), ("alpha", AL[t]),
+                              ("logp", logp if forced is not None else torch.log_softmax(logp, 1))):
+                    steps_tap[k].append(v_.clone())
             if t == T:
                 break
             if forced is not None:
@@ -506,9 +529,14 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
             else:
                 ops.decode_pick(logp, k, m.topk_temp, None if ut is None else ut[t], t, seq, seqlp, it,
                                 unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
+    if tap is not None and graphed is None:
+        tap.update({"step_" + k: torch.stack(v_, 0) for k, v_ in steps_tap.items()})
+        if not return_att:
+            AL = None
+    want_att = return_att and not (batch_out is not None and batch_out.get("skip_att"))
     if len(sel) == 1:
         steps = None
-        if return_att:
+        if want_att:
             dead = (counts.cpu() == 0).nonzero()
             steps = [int(dead[0]) + 1 if dead.numel() else T + 1]
     else:
@@ -516,14 +544,26 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None):
         # nothing (tokens, log-probs, attention rows) beyond that step: one launch masks the log-probs (subgc_decode_batch_finish)
         brk = ops.decode_batch_finish(seq, seqlp, bounds)
         steps = None
-        if return_att:
+        if want_att:
             h = brk.cpu().tolist()                                                     # [I, 2]: break step, "some step had no unfinished row"
             steps = [min(b + 1, T) + (1 if b == T - 1 and not any_ else 0) for b, any_ in h]
+    skip_att = False
+    if batch_out is not None:
+        skip_att = bool(batch_out.pop("skip_att", False))
+        batch_out.update(_batch_view(sel, whole, seq, seqlp, AL if return_att else None, idx_k, lens_k, bounds))
     out = []
     for i, (s, a, b) in enumerate(zip(sel, bounds, bounds[1:])):
         r = (seq[a:b], seqlp[a:b], s["score"], s["keep"])
-        if return_att:
+        if return_att and not skip_att:
             n_max = int(s["lens"].max().item()) if b > a else 0
             r = r + (AL[:steps[i], a:b, :n_max].permute(1, 0, 2).contiguous(),)
         out.append(r)
     return out
+
+
+def _batch_view(sel, whole, seq, seqlp, AL, idx_k, lens_k, bounds):
+    if whole is not None and "score" in whole:
+        score, keep = whole["score"], whole["keep"]
+    else:
+        score, keep = torch.cat([s["score"].reshape(-1) for s in sel]), torch.cat([s["keep"].reshape(-1) for s in sel])
+    return dict(rows=seq.size(0), seq=seq, seqlp=seqlp, score=score.reshape(-1), keep=keep.reshape(-1), idx=idx_k, lens=lens_k, bounds=list(bounds), AL=AL)

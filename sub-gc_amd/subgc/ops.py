@@ -1443,6 +1443,56 @@ def rank_desc(score):
     return srt, order
 
 
+def eval_collect(score, keep, seq, bounds, identity=False, AL=None, idx=None, pick=None):
+    """The eval loop's per-image work for a whole decode batch (misc/eval_utils.py:105-121; grounding: misc/grd_utils.py:36-47):
+    one ranking launch (subgc_eval_rank_rows), one grounding launch when `AL` (the decode loop's attention buffer [T1, rows, N]) and
+    `idx` (the kept sub-graphs' node lists [rows, N]) are given, and ONE device -> host copy of everything.
+    score [rows] fp32, keep [rows] int64, seq [rows, T] int64, bounds: python list of the I + 1 row boundaries of the images,
+    pick: optional per-image subg_index list (default 0 = the best-ranked caption).
+    -> dict of host numpy arrays: order / score / keep (int64) / seq (int64) [rows...], and with grounding att2 / node [I, T1], n_words [I]."""
+    import numpy as np
+    dev = score.device
+    rows, T = seq.shape
+    I = len(bounds) - 1
+    if bounds[-1] != rows or score.numel() != rows or keep.numel() != rows:
+        raise SubgcError("eval_collect: bounds / score / keep do not cover the rows of seq")
+    ground = AL is not None
+    T1 = AL.size(0) if ground else 0
+    seg = upload(list(bounds) + ([0] * I if pick is None else [int(p) for p in pick]), torch.int32, dev)
+    words = 3 * rows + rows * T + (2 * I * T1 + I if ground else 0)
+    arena = torch.empty(max(words, 1), device=dev, dtype=torch.int32)
+    o = 0
+    order = arena[o:o + rows]; o += rows
+    score_s = arena[o:o + rows].view(torch.float32); o += rows
+    keep_s = arena[o:o + rows]; o += rows
+    seq_s = arena[o:o + rows * T]; o += rows * T
+    max_rows = max([b - a for a, b in zip(bounds, bounds[1:])] + [0])
+    if I and rows:
+        call("subgc_eval_rank_rows", _ptr(score.contiguous(), torch.float32), _ptr(keep.contiguous(), torch.int64), _ptr(seq.contiguous(), torch.int64),
+             T, _ptr(seg), I, max_rows, int(bool(identity)), _ptr(order), _ptr(score_s), _ptr(keep_s), _ptr(seq_s), _stream())
+    if ground:
+        att2 = arena[o:o + I * T1]; o += I * T1
+        node = arena[o:o + I * T1]; o += I * T1
+        nw = arena[o:o + I]; o += I
+        if AL.stride(2) != 1 or idx.stride(1) != 1:
+            raise SubgcError("eval_collect: AL / idx need unit inner strides")
+        if I:
+            call("subgc_grounding_argmax", _ptr(AL, torch.float32), AL.stride(0), AL.stride(1), AL.size(2), T1, _ptr(seq.contiguous(), torch.int64), T,
+                 _ptr(idx, torch.int64), idx.stride(0), _ptr(seg), _ptr(order) if (rows and not identity) else None,
+                 _ptr(seg[I + 1:]) if pick is not None else None, I, _ptr(att2), _ptr(node), _ptr(nw), _stream())
+    host = arena.cpu().numpy()                                        # the one copy (synchronises the stream)
+    o = 0
+    out = {"order": host[o:o + rows].astype(np.int64)}; o += rows
+    out["score"] = host[o:o + rows].view(np.float32).copy(); o += rows
+    out["keep"] = host[o:o + rows].astype(np.int64); o += rows
+    out["seq"] = host[o:o + rows * T].reshape(rows, T).astype(np.int64); o += rows * T
+    if ground:
+        out["att2"] = host[o:o + I * T1].reshape(I, T1).copy(); o += I * T1
+        out["node"] = host[o:o + I * T1].reshape(I, T1).copy(); o += I * T1
+        out["n_words"] = host[o:o + I].copy()
+    return out
+
+
 def dropout_mask(shape, p, seed, offset, device):
     keep = torch.empty(shape, device=device, dtype=torch.uint8)
     call("subgc_dropout_mask", _ptr(keep), keep.numel(), float(p), int(seed), int(offset), _stream())

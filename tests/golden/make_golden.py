@@ -427,6 +427,94 @@ def eval_cases(meta):
     save("eval_glue", out=dict(seq=seq, **out))
 
 
+def grd_cases(meta):
+    """Grounding material (misc/grd_utils.py:13-58), collected by the eval loop at misc/eval_utils.py:143-146.  The reference's
+    OWN `get_grounding_material` is run on the outputs of its own `_sample(..., return_att=1)` (ranked like eval_utils.py:105-115,
+    sentences by its decode_sequence); the files it opens by image id (sub-graph node masks, detector boxes, image sizes, the
+    consensus re-ranker's choice) are fabricated in the scratch directory from the synthetic test batch, the word -> lemma ->
+    detection-class dictionaries make most words groundable nouns.  Stored: boxes / sizes / picks, sentences, and what the
+    reference appended to grd_output (bbox, idx_in_sent, clss) -- the boxes identify the arg-max node of every grounded word."""
+    import misc.utils as U
+    from misc.grd_utils import get_grounding_material
+    from models.AttModel import TopDownModel
+    with np.load(os.path.join(HERE, "subgc_beam_weights.npz")) as z:
+        w = {k: z[k].copy() for k in z.files}
+    w["logit.bias"][0] += 0.5                                    # sentences of 0 .. 20 words
+    with np.load(os.path.join(HERE, "fullgc_train_weights.npz")) as z:
+        wf = {k: z[k].copy() for k in z.files}
+    t = dict(test_LSTM=1, gpn_nms_thres=0.75, gpn_max_subg=10)
+    fo = dict(use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1)
+    V = TINY["vocab_size"]
+    vocab = {str(i): f"w{i}" for i in range(1, V + 1)}
+    wd_to_lemma = {f"w{i}": f"l{i}" for i in range(1, V + 1) if i % 7}              # every 7th word is unknown to the lemmatiser (:51-53)
+    lemma_det = {f"l{i}": i for i in range(1, V + 1) if i % 3}                       # two lemmas in three are detection classes
+    det_wd = {i: f"cls{i}" for i in range(1, V + 1)}
+    cases = [("subgc", ref_opt(**t), w, True, [(24, 14, 900, 0), (5, None, 901, 0), (30, 10, 902, 2), (12, 12, 903, 1)]),
+             ("fullgc", ref_opt(**fo), wf, False, [(2, None, 910, 0), (3, None, 911, 0)])]
+    os.makedirs("data/flickr30k_graph_mask_1000_rm_duplicate", exist_ok=True)
+    os.makedirs("data/flickr30k_sg_output_64", exist_ok=True)
+    os.makedirs("m/run", exist_ok=True)
+    rng = np.random.default_rng(77)
+    out, info = {}, {}
+    for name, opt, weights, gpn, imgs in cases:
+        torch.manual_seed(3)
+        model = TopDownModel(opt)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        model.eval()
+        wh, rerank, grd_output, listing = {}, {}, {}, []
+        for k_img, (M, pool, seed, pick) in enumerate(imgs):
+            img_id = 5000 + 100 * (0 if gpn else 1) + k_img
+            batch = synthetic.make_test_batch(M, D=opt.att_feat_size, seed=seed, fc_size=opt.att_feat_size, node_pool=pool)
+            boxes = rng.random((36, 4)) * 500
+            wh[img_id] = (int(rng.integers(300, 900)), int(rng.integers(300, 900)))
+            rerank[img_id] = [pick, 0, 1]
+            oi, am = batch["gpn_obj_ind"][0].numpy(), batch["att_masks"][0].numpy()          # [2, M, N]
+            mask_list = [("gt", np.zeros(36, bool))] * 5                                      # the first 5 entries are the GT sub-graphs (:40)
+            for half in range(2):
+                for j in range(M):
+                    nm = np.zeros(36, bool)
+                    nm[oi[half, j][am[half, j] > 0]] = True
+                    mask_list.append((5 + half * M + j, nm))
+            np.savez(f"data/flickr30k_graph_mask_1000_rm_duplicate/{img_id}.npz", feat=np.array({"subgraph_mask_list": mask_list}, dtype=object))
+            np.savez(f"data/flickr30k_sg_output_64/{img_id}.npz", feat=np.array({"boxes": boxes}, dtype=object))
+            listing.append((img_id, batch, boxes, pick, M, pool, seed))
+        np.save("data/flickr30k_img_wh.npy", np.array(wh, dtype=object))
+        np.save("m/run/consensus_rerank_ind.npy", np.array(rerank, dtype=object))
+        for img_id, batch, boxes, pick, M, pool, seed in listing:
+            with torch.no_grad():
+                seqq, _, score, keep, att = model(*synthetic.sample_args({k: v.clone() for k, v in batch.items()}),
+                                                  opt=dict(sample_max=1, beam_size=1, return_att=1), mode="sample")
+            if gpn:                                                                           # eval_utils.py:106-110
+                assert len(set(score.tolist())) == score.numel()                              # no ties: stable and unstable sorts agree
+                sorted_score, sort_ind = torch.sort(score, descending=True)
+                seq, sorted_ind = seqq[sort_ind], keep[sort_ind]
+            else:                                                                             # :112-115
+                sort_ind = torch.arange(score.size(0)).type_as(keep)
+                seq, sorted_ind = seqq, keep
+            sents = U.decode_sequence(vocab, seq)
+            for consensus in (False, True):
+                grd_output = {img_id: []}
+                get_grounding_material("m/run/infos.pkl", {"infos": [{"id": img_id}]}, sents, sorted_ind, att, sort_ind, wd_to_lemma,
+                                       lemma_det, det_wd, grd_output, use_full_graph=not gpn, grd_sGPN_consensus=consensus)
+                r = grd_output[img_id][0]
+                tag = f"{name}_{img_id}_{int(consensus)}"
+                out[tag + "_bbox"] = np.array(r["bbox"], np.float64).reshape(-1, 4)
+                out[tag + "_idx_in_sent"] = np.array(r["idx_in_sent"], np.int64)
+                out[tag + "_clss"] = np.array(r["clss"])
+            out[f"{name}_{img_id}_sents"] = np.array(sents)
+            out[f"{name}_{img_id}_boxes"] = boxes
+            out[f"{name}_{img_id}_sorted_ind"] = np_(sorted_ind)
+            info.setdefault(name, []).append(dict(id=img_id, M=M, pool=pool, seed=seed, pick=pick, wh=list(wh[img_id]),
+                                                  n_sents=len(sents), n_grounded=int(len(r["bbox"]))))
+        assert sum(i["n_grounded"] for i in info[name]) > 5, info[name]
+    meta["grd"] = dict(kind="grounding", vocab=vocab, wd_to_lemma=wd_to_lemma, lemma_det_id_dict=lemma_det,
+                       det_id_to_det_wd={str(k): v for k, v in det_wd.items()}, cases=info,
+                       opt={"subgc": {k: v for k, v in vars(cases[0][1]).items() if "path" not in k},
+                            "fullgc": {k: v for k, v in vars(cases[1][1]).items() if "path" not in k}},
+                       weights={"subgc": "subgc_beam (+0.5 on logit.bias[0])", "fullgc": "fullgc_train"})
+    save("grd", out=out)
+
+
 def main():
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     enter_scratch()
@@ -435,6 +523,13 @@ def main():
         with open(os.path.join(HERE, "meta.json")) as f:
             meta = json.load(f)
         eval_cases(meta)
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        return
+    if "--only-grd" in sys.argv:
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        grd_cases(meta)
         with open(os.path.join(HERE, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, sort_keys=True, default=str)
         return
@@ -488,6 +583,7 @@ def main():
         json.dump(meta, f, indent=1, sort_keys=True, default=str)
     ss_case(w, meta)
     loader_cases(meta)
+    grd_cases(meta)
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True, default=str)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
