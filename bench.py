@@ -490,6 +490,8 @@ def main():
     ap.add_argument("--no-fold-bias", action="store_true", help="experiment: bias gradients as separate column-sum launches (functions.FOLD_BIAS_SUMS = False)")
     ap.add_argument("--fork-wgrads", action="store_true", help="experiment: the encoder's weight-gradient products on side streams beside the backward chain (ops.FORK_WGRADS = True)")
     ap.add_argument("--no-pair-launches", action="store_true", help="experiment: the two same-shape products of a GCN unit pair as two launches (ops.PAIR_LAUNCHES = False)")
+    ap.add_argument("--share-attention-sets", type=int, default=-1, help="Full-GC configs: 1 = attention sets once per image (ties the att_embed dropout mask "
+                    "across an image's sentences: NOT the reference's semantics), 0 = the reference's independent masks on replicated rows (model default)")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -509,6 +511,8 @@ def main():
     _lib.lib()
     torch.manual_seed(1234)                     # identical replicas on every rank
     opt = argparse.Namespace(**cfg["opt"])
+    if a.share_attention_sets >= 0:
+        opt.share_attention_sets = a.share_attention_sets
     model = models.setup(opt).to(dev).train()
     if a.pitch_f32 >= 0:
         ops.PITCH["f32"] = a.pitch_f32

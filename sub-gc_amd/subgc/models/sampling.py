@@ -519,9 +519,9 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None, batch_out=None):
             logp = st.step(it, AL[t] if (return_att or tap is not None) else None, normalize=forced is not None)
             if tap is not None:                                                        # state after core step t, in the oracle's names
                 R = st.R
-                for k, v_ in (("h_att", st.H1[:, R:]), ("h_lang", st.H1[:, :R]), ("c_att", st.C1[0]), ("c_lang", st.C2[0]), ("alpha", AL[t]),
-                              ("logp", logp if forced is not None else torch.log_softmax(logp, 1))):
-                    steps_tap[k].append(v_.clone())
+                for key_, v_ in (("h_att", st.H1[:, R:]), ("h_lang", st.H1[:, :R]), ("c_att", st.C1[0]), ("c_lang", st.C2[0]), ("alpha", AL[t]),
+                                 ("logp", logp if forced is not None else torch.log_softmax(logp, 1))):
+                    steps_tap[key_].append(v_.clone())
             if t == T:
                 break
             if forced is not None:
@@ -530,7 +530,7 @@ def decode(m, X2, N, sel, opt, uniforms=None, forced=None, batch_out=None):
                 ops.decode_pick(logp, k, m.topk_temp, None if ut is None else ut[t], t, seq, seqlp, it,
                                 unfinished, counts[t:t + 1], counts[t - 1:t] if t > 0 else None, raw=True)
     if tap is not None and graphed is None:
-        tap.update({"step_" + k: torch.stack(v_, 0) for k, v_ in steps_tap.items()})
+        tap.update({"step_" + key_: torch.stack(v_, 0) for key_, v_ in steps_tap.items()})
         if not return_att:
             AL = None
     want_att = return_att and not (batch_out is not None and batch_out.get("skip_att"))
