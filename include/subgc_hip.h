@@ -778,6 +778,7 @@ int subgc_clip_adam_step_zero(float* p, float* g, float* m, float* v, int64_t n,
  * step-by-step sequence (tests: packed == unpacked == goldens).
  *
  * Step t (0 <= t < T) owns m[t] rows (m non-increasing, m[T] = 0 or the rows the state after the last step is written to);
+ * BOTH host tables m and row0 therefore hold T + 1 entries and say so in n_m / n_row0 (checked);
  * in every step-packed array ([rows, .]: H1, H2, Gx, G1, G2, AH, AL, dP1, dP2, dAH, dWa, dBa, dCtx) its rows start at row0[t];
  * Hout / dHout rows of step t start at element hout_off[t] / dhout_off[t] with row pitch ld_hout / ld_dhout (the unpacked
  * decoder keeps them sentence-major [S, T, R]); C1, C2 are [T+1][S][R]; k_out (may be NULL) [T][S][R]; Gf, pre [S, 4R].
@@ -799,6 +800,8 @@ typedef struct SubgcRecurrence {
     int32_t uv_b16;
     float keep_scale;
     int32_t du_planes;
+    int32_t n_m;                 /* entries of m[]    (host array): >= T + 1 -- the forward reads m[T], the rows the last step's state goes to */
+    int32_t n_row0;              /* entries of row0[] (host array): >= T + 1 -- the forward reads row0[T], where those rows start              */
     const int32_t* m;
     const int64_t* row0;
     const int64_t* hout_off;

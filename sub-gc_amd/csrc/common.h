@@ -102,11 +102,22 @@ __device__ __forceinline__ float4 subgc_load_q(const float* __restrict__ ah, con
 // Wave-wide reductions on the DPP path (gfx9 family: quad_perm / row_half_mirror / row_mirror inside a 16-lane row, row_bcast:15 / :31
 // across rows, the total read from lane 63): six VALU moves of a few cycles each.  The __shfl_xor butterfly they replace compiles to six
 // DEPENDENT ds_bpermute exchanges through the LDS crossbar -- ~1 us per lone reduction when nothing else is ready to issue.
+// PRECONDITION (unlike the butterfly, which gave every ACTIVE lane the sum over the active lanes): ALL 64 LANES ACTIVE.  The total is
+// read from lane 63 and the row_bcast steps pull from lanes 15 / 31 / 47: in a partial wave (blockDim not a multiple of 64, a call under
+// a lane-dependent branch or after an early return of some lanes) those registers are stale and every lane receives garbage.  Callers
+// keep their reductions wave-uniform (inactive work contributes the identity: 0 for sums, -inf / the value itself for maxima); builds with
+// -DSUBGC_DEBUG_EXEC trap when the rule is broken.  gfx9-family DPP controls only (this library targets gfx950 alone).
+#ifdef SUBGC_DEBUG_EXEC
+#define SUBGC_ASSERT_FULL_WAVE() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define SUBGC_ASSERT_FULL_WAVE() do { } while (0)
+#endif
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_or(float v, float other) {      // lane <- DPP source lane of v; `other` where the row is masked off
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, other), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
 __device__ __forceinline__ float wave_sum(float v) {
+    SUBGC_ASSERT_FULL_WAVE();
     v += dpp_or<0xB1, 0xF>(v, 0.f);      // quad_perm [1,0,3,2]
     v += dpp_or<0x4E, 0xF>(v, 0.f);      // quad_perm [2,3,0,1]
     v += dpp_or<0x141, 0xF>(v, 0.f);     // row_half_mirror: every lane of an 8-group holds the group's sum
@@ -118,6 +129,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // sum over the 64 lanes of N values at once: the N chains interleave
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+    SUBGC_ASSERT_FULL_WAVE();
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] += dpp_or<0xB1, 0xF>(v[k], 0.f);
 #pragma unroll
@@ -156,6 +168,7 @@ __device__ __forceinline__ void gather_pair(const int* __restrict__ ia, int a0, 
 }
 
 __device__ __forceinline__ float wave_max(float v) {
+    SUBGC_ASSERT_FULL_WAVE();
     v = fmaxf(v, dpp_or<0xB1, 0xF>(v, v));
     v = fmaxf(v, dpp_or<0x4E, 0xF>(v, v));
     v = fmaxf(v, dpp_or<0x141, 0xF>(v, v));

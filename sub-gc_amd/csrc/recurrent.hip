@@ -21,6 +21,8 @@ int check_common(const SubgcRecurrence* a, const char* what) {
     SUBGC_REQUIRE(a, "%s: null argument block", what);
     SUBGC_REQUIRE(a->S > 0 && a->T >= 0 && a->T <= 4096 && a->R > 0 && a->A > 0 && a->n_alpha > 0, "%s: bad sizes", what);
     SUBGC_REQUIRE(a->T == 0 || (a->m && a->row0), "%s: null step tables", what);
+    SUBGC_REQUIRE(a->T == 0 || (a->n_m >= a->T + 1 && a->n_row0 >= a->T + 1), "%s: m[] and row0[] need T + 1 = %d entries (got %d, %d)", what,
+                  a->T + 1, a->n_m, a->n_row0);
     SUBGC_REQUIRE(!a->shared || (a->rows_map && a->B > 0 && a->g > 0 && a->Nn > 0), "%s: shared attention sets need rows_map, B, g, Nn", what);
     SUBGC_REQUIRE(a->shared || a->off, "%s: per-sentence attention sets need their offsets", what);
     for (int t = 0; t < a->T; ++t)

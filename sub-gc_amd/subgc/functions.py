@@ -16,9 +16,13 @@ from . import ops
 
 
 def _direct(p, dev):
-    """The existing .grad buffer of a leaf parameter if gradients may be accumulated into it in place, else None."""
+    """The existing .grad buffer of a leaf parameter if gradients may be accumulated into it in place, else None.  A caller that gets a
+    buffer WILL write it through raw pointers (no torch version bump): `ops.GRAD_WRITES` is moved so that "the optimizer left the flat
+    gradient buffer zeroed" (AttModel.flatten_grads' fast path) ends here, whatever entry point the backward came from."""
     g = getattr(p, "grad", None) if (p is not None and DIRECT_GRADS) else None
     ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == dev and p.is_leaf
+    if ok:
+        ops.GRAD_WRITES[0] += 1
     return g if ok else None
 
 
@@ -212,6 +216,17 @@ class UnitPairFn(Function):
         _, _, gWl, gbl, _ = ctx.cat
         Wl_a, bl_a, Wl_b, bl_b, Wr_a, br_a, Wr_b, br_b = ctx.params
         dev, Lr, bf = x.device, ctx.Lr, ctx.bf
+        if gWl is not None:
+            # the concatenated gradient views were captured at FORWARD time: if a .grad was re-bound since (flatten_grads on a fresh
+            # buffer, zero_grad(set_to_none=True), p.grad = None) they point into a stale buffer -- accumulate there and the gradients
+            # are silently lost.  Still the live views iff the four .grad tensors alias them slot for slot; otherwise hand the
+            # gradients to autograd like the non-direct branch does.
+            ga, gb_, gba_, gbb_ = (_direct(q, dev) for q in (Wl_a, Wl_b, bl_a, bl_b))
+            live = (ga is not None and gb_ is not None and gba_ is not None and gbb_ is not None
+                    and ga.data_ptr() == gWl.data_ptr() and gb_.data_ptr() == gWl[Lr:].data_ptr()
+                    and gba_.data_ptr() == gbl.data_ptr() and gbb_.data_ptr() == gbl[Lr:].data_ptr())
+            if not live:
+                gWl = gbl = None
         M = x.size(0)
         if bf:
             dya, dyb = (d if ops.is_b16(d) else ops.as_b16(d.contiguous()) for d in (dya, dyb))
@@ -983,6 +998,7 @@ class DecoderFn(Function):
         # AttModel.flatten_grads) the kernels accumulate straight into it and autograd gets None --
         # no temporary, no separate "+=" pass over 280 MB.
         dst, acc, ret = [], [], []
+        ops.GRAD_WRITES[0] += 1
         for prm in P:
             g = prm.grad if DIRECT_GRADS else None
             ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == dev

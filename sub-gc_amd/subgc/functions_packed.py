@@ -231,6 +231,7 @@ class PackedDecoderLossFn(Function):
         act = lambda r, c: ops.act_buffer((r, c), dev, bf)      # gradients that only GEMMs (and bias sums) read
         opnd = (lambda t: ops.as_b16(t)) if bf else (lambda t: t)
         dst, acc, ret = [], [], []
+        ops.GRAD_WRITES[0] += 1                                 # raw-pointer gradient writes follow (AttModel.flatten_grads' zero marker)
         for prm in P:                                           # accumulate straight into the flat gradient bucket when it exists
             g = prm.grad if F_.DIRECT_GRADS else None
             ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == dev

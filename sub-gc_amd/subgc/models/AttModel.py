@@ -116,10 +116,14 @@ class AttModel(CaptionModel):
         if self.bf16_storage and (self.rnn_size % 8 or self.input_encoding_size % 8 or self.att_hid_size % 8 or self.GCN_dim % 8):
             raise ValueError("compute_dtype=bf16 needs rnn_size, input_encoding_size, att_hid_size and gcn_dim to be multiples of 8")
         # Full-GC only: compute the attention sets (att_embed / ctx2att over the node rows) ONCE per image and let the image's
-        # sentences share them (functions.PreparedShared) instead of the reference's x5 replication.  With dropout on this ties the
-        # att_embed keep-mask across the 5 sentences of an image (each sentence's marginal is unchanged); 0 = the reference's
-        # independent masks on replicated rows.  Not a reference option.
-        self.share_attention_sets = g("share_attention_sets", 1) != 0
+        # sentences share them (functions.PreparedShared) instead of the reference's x5 replication (gcn_backbone.py:50-51 ->
+        # AttModel.py:113-119).  That is the reference's arithmetic exactly when att_embed's Dropout is inactive (eval mode,
+        # drop_prob_lm = 0); with dropout ON the reference draws an INDEPENDENT keep-mask for each of the 5 replicated copies, and
+        # sharing would tie them within an image.  -1 (default, "auto"): share only when that changes nothing, i.e. a training forward
+        # with dropout keeps the reference's five independent masks on replicated rows; 1: always share (tied masks: each sentence's
+        # marginal is unchanged, the joint distribution is not the reference's; 13 % faster on Full_GC_Kar, reported beside the
+        # default by bench.py); 0: never.  Not a reference option.
+        self.share_attention_sets = int(g("share_attention_sets", -1))
         # the two GCN units that read the same source run as one paired Function (concatenated fc_lft; functions.UnitPairFn); 0 = one by one
         self.pair_gcn_units = g("pair_gcn_units", 1) != 0
         self.dropout_seed = g("seed", 2019)
@@ -257,8 +261,10 @@ class AttModel(CaptionModel):
         elif self.flat_grads.is_cuda:
             # FlatAdam.step(zero_grad=True) left the buffer zeroed through raw pointers (no torch version bump): nothing to fill, unless a
             # torch op has written to it since (its version counter moved)
+            # (no torch version bump, and no raw-pointer gradient write since: ops.GRAD_WRITES -- a backward that reached the buffer
+            # through any entry point, not only `_forward`, moves it)
             z = self.__dict__.pop("_grads_are_zero", None)
-            if z != (self.flat_grads.data_ptr(), self.flat_grads._version):
+            if z != (self.flat_grads.data_ptr(), self.flat_grads._version, ops.GRAD_WRITES[0]):
                 ops.fill_(self.flat_grads, 0.0)
         else:
             self.flat_grads.zero_()
@@ -724,7 +730,8 @@ class AttModel(CaptionModel):
             sel_idx = c["ar_b5"]
             lens = ops.row_count(mask_sel)
         meta = {"N": N, "p": p, "masks": masks, "crit": fused_crit, "plan": plan, "tap": tap}
-        if (not self.gpn and self.share_attention_sets and self.injected_masks is None and b5 % B == 0
+        share = self.share_attention_sets == 1 or (self.share_attention_sets < 0 and p == 0.0)      # auto: only where it is exact
+        if (not self.gpn and share and self.injected_masks is None and b5 % B == 0
                 and F_.shared_sets_ok(b5 // B, N, self.att_hid_size, R, T)):
             meta["shared"] = {"B": B, "g": b5 // B, "rows": c["rows"]}                    # every sentence attends over its image's N node rows
         if self.bf16_storage:

@@ -39,6 +39,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+GRAD_WRITES = [0]          # moved by every gradient writer that goes through raw pointers (functions._direct, the decoder backwards)
 _WS = {}
 WS_MBYTES = 160
 
@@ -1074,20 +1075,58 @@ class Recurrence:
 
     def set(self, **fields):
         import ctypes
+        exp = _recurrence_field_types()
         for k, v in fields.items():
             if v is None:
                 setattr(self.st, k, 0)                                  # NULL pointer / zero
             elif torch.is_tensor(v):
                 if not v.is_cuda:
                     raise SubgcError(f"recurrence: {k} must be a device tensor")
+                want = exp.get(k)
+                if want is None:
+                    raise SubgcError(f"recurrence: {k} is not a pointer field of SubgcRecurrence")
+                if want != "any" and v.dtype != want:
+                    raise SubgcError(f"recurrence: {k} is declared {want} in subgc_hip.h, got {v.dtype}")
+                if want == "any" and v.dtype not in (torch.float32, torch.bfloat16, torch.uint16, torch.int16):
+                    raise SubgcError(f"recurrence: {k} must be fp32 or bf16 storage, got {v.dtype}")
+                if v.dim() >= 2 and v.stride(-1) != 1:
+                    raise SubgcError(f"recurrence: {k} needs unit inner stride (shape {tuple(v.shape)}, stride {v.stride()})")
+                if v.dim() <= 1 and not v.is_contiguous():
+                    raise SubgcError(f"recurrence: {k} must be contiguous")
                 setattr(self.st, k, v.data_ptr())
             elif k in self.HOST:
                 arr = (getattr(ctypes, self.HOST[k]) * max(len(v), 1))(*[int(x) for x in v])
                 self._alive.append(arr)
                 setattr(self.st, k, ctypes.addressof(arr))
+                if k in ("m", "row0"):
+                    setattr(self.st, "n_" + k, len(v))                  # the library checks >= T + 1 (it reads m[T] / row0[T])
             else:
                 setattr(self.st, k, v)
         return self
+
+
+_RECUR_TYPES = None
+
+
+def _recurrence_field_types():
+    """field -> expected torch dtype of every POINTER member of SubgcRecurrence, read from the header (`const float*` -> float32,
+    `const int32_t*` -> int32, `const uint8_t*` -> uint8, `void*` -> "any": fp32 or bf16 storage by the `bf16` flags)."""
+    global _RECUR_TYPES
+    if _RECUR_TYPES is None:
+        import re
+        from ._lib import HEADER
+        src = open(HEADER).read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        body = re.search(r"typedef\s+struct\s+SubgcRecurrence\s*\{(.*?)\}\s*SubgcRecurrence\s*;", src, flags=re.S).group(1)
+        table = {"float": torch.float32, "int32_t": torch.int32, "int64_t": torch.int64, "uint8_t": torch.uint8, "uint16_t": "any", "void": "any"}
+        out = {}
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if "*" in decl:
+                ty = decl.split("*")[0].replace("const", "").strip()
+                out[decl.split("*")[-1].strip()] = table[ty]
+        _RECUR_TYPES = out
+    return _RECUR_TYPES
 
 
 def recurrence_fwd(rec, like):

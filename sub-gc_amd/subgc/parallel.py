@@ -244,7 +244,8 @@ class FlatAdam:
         snap = m.weights_b16() if getattr(m, "bf16_storage", False) else None     # compute_dtype = bf16: refreshed in the same sweep
         ops.clip_adam_step(m.flat_params, m.flat_grads, self.m, self.v, self.sumsq, self.clip, self.lr,
                            self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale, p_bf16=snap, zero_grad=zero_grad)
-        m.__dict__["_grads_are_zero"] = (m.flat_grads.data_ptr(), m.flat_grads._version) if zero_grad else None
+        from . import ops as _ops
+        m.__dict__["_grads_are_zero"] = (m.flat_grads.data_ptr(), m.flat_grads._version, _ops.GRAD_WRITES[0]) if zero_grad else None
         # the kernel wrote the weights through raw pointers: no torch version counter moved, so the decode-time snapshots
         # (x->gates table, K-concatenated LSTM matrices, captured hipGraphs) must be told explicitly
         m.invalidate_decode_caches()

@@ -65,6 +65,11 @@ def test_recurrence_struct_mirror_matches_the_library():
     r0 = (ctypes.c_int64 * 3)(0, 4, 9)
     off = (ctypes.c_int32 * 1)(0)
     blk.m, blk.row0, blk.off = ctypes.addressof(m), ctypes.addressof(r0), ctypes.addressof(off)
+    # the forward reads m[T] and row0[T]: both tables must SAY they hold T + 1 entries (round-4 advisor finding)
+    assert L.subgc_recurrence_fwd(ctypes.addressof(blk), None, 0, None) == -1 and b"T + 1 = 3 entries (got 0, 0)" in L.subgc_last_error()
+    blk.n_m, blk.n_row0 = 3, 2
+    assert L.subgc_recurrence_fwd(ctypes.addressof(blk), None, 0, None) == -1 and b"(got 3, 2)" in L.subgc_last_error()
+    blk.n_row0 = 3
     assert L.subgc_recurrence_fwd(ctypes.addressof(blk), None, 0, None) == -1 and b"non-increasing" in L.subgc_last_error()
 
 

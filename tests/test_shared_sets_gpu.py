@@ -2,7 +2,9 @@
 over the same node rows (reference AttModel.py:140-149 on the x5 replicated features of gcn_backbone.py:50-51), so att_embed /
 ctx2att run once per image and one workgroup serves the image's sentences.  With dropout off the result must equal the replicated
 (per-sentence) path: loss, log-probabilities and every gradient; the golden Full-GC cases run through it as well (test_parity_gpu /
-test_bf16_storage_gpu build their models with the default share_attention_sets = 1)."""
+test_bf16_storage_gpu run with dropout off, where the default "auto" mode shares).  With dropout ON the reference draws five INDEPENDENT
+att_embed keep-masks per image (gcn_backbone.py:50-51 -> AttModel.py:113-119): the default then runs the replicated path, pinned here
+against the oracle with injected per-sentence masks; share_attention_sets = 1 (tied masks) is an explicit opt-in."""
 import numpy as np
 import pytest
 import torch
@@ -62,11 +64,11 @@ def test_shared_sets_equal_replicated_sets(golden, packed, dtype, ragged):
             np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), atol=3e-5 * sc + 1e-9, rtol=2e-3, err_msg=k)
 
 
-def test_shared_mode_is_what_the_full_gc_train_path_runs(golden):
-    """The default Full-GC training forward builds PreparedShared (and injected keep-masks switch it off: those are per sentence)."""
+def test_auto_mode_shares_only_where_it_is_the_reference_arithmetic(golden):
+    """default (-1): PreparedShared when att_embed's dropout is inactive (p = 0 here; eval mode likewise), the reference's replicated
+    rows with independent masks when it is active; 1 forces sharing (tied masks), 0 forbids it; injected masks are per sentence."""
     from subgc import functions as F_
     g = golden("fullgc_train")
-    m = build(g, g.group("weights"), True, drop_prob_lm=0.0)
     seen = []
     orig = F_.make_prepared
 
@@ -77,9 +79,57 @@ def test_shared_mode_is_what_the_full_gc_train_path_runs(golden):
 
     F_.make_prepared = spy
     try:
+        for p_drop, share in ((0.0, -1), (0.5, -1), (0.5, 1), (0.0, 0), (0.5, 0)):
+            m = build(g, g.group("weights"), True, drop_prob_lm=p_drop, share_attention_sets=share)
+            assert m.share_attention_sets == share
+            run_train(m, _batch(g, 2, 3, False))
+        m = build(g, g.group("weights"), True, drop_prob_lm=0.5)                     # the default of a model built without the option
+        assert m.share_attention_sets == -1
         run_train(m, _batch(g, 2, 3, False))
-        m.share_attention_sets = False
-        run_train(m, _batch(g, 2, 3, False))
+        m.eval()
+        with torch.no_grad():
+            m(*synthetic.forward_args({k: v.to(DEV) for k, v in _batch(g, 2, 3, False).items()}))
     finally:
         F_.make_prepared = orig
-    assert seen == ["PreparedShared", "Prepared"]
+    assert seen == ["PreparedShared", "Prepared", "PreparedShared", "Prepared", "Prepared", "Prepared", "PreparedShared"], seen
+
+
+def test_fullgc_train_with_independent_per_sentence_masks_matches_oracle(golden):
+    """The default Full-GC training path under dropout: every sentence of an image has its OWN att_embed keep-mask (injected here, so
+    the oracle can apply the same ones), as the reference draws them on the x5 replicated node rows.  Loss and every gradient."""
+    from oracle import subgc_oracle as O
+    g = golden("fullgc_train")
+    w = g.group("weights")
+    p = 0.5
+    m = build(g, w, True, drop_prob_lm=p)
+    batch = g.tensors("inputs")
+    S, T, N = batch["labels"].size(0), batch["labels"].size(1) - 1, 37
+    o = g.meta["opt"]
+    R, E = o["rnn_size"], o["input_encoding_size"]
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *s: (torch.rand(*s, generator=gen) >= p).to(torch.uint8)
+    masks = {"fc": mk(S, R), "att": mk(S * N, R), "xt": mk(T, S, E), "out": mk(T, S, R)}
+    # five sentences of one image must really differ in their att mask (that is the point of the test)
+    a = masks["att"].view(S, N, R)
+    assert not torch.equal(a[0], a[1])
+    m.injected_masks = {k: v.to(DEV) for k, v in masks.items()}
+    out, loss = run_train(m, {k: v.clone() for k, v in batch.items()})
+    lens = torch.full((S,), 36, dtype=torch.long)                                     # AttModel.py:148-149: masks forced to ones on [:, :36]
+    off = torch.cumsum(lens, 0) - lens
+    att = torch.zeros(S, N, R, dtype=torch.uint8)
+    for s_ in range(S):
+        att[s_, :36] = masks["att"][int(off[s_]): int(off[s_]) + 36]
+    om = {"fc": masks["fc"].float(), "att": att.float(), "xt": masks["xt"].permute(1, 0, 2).float(), "out": masks["out"].permute(1, 0, 2).float()}
+    orc = O.Oracle(g.opt(drop_prob_lm=p), w, requires_grad=True); orc.training = True
+    ref = O.loss_wrapper(orc, {k: v.clone() for k, v in batch.items()}, masks=om)
+    ref["lang_loss"].backward()
+    close(out["lang_loss"], ref["lang_loss"], "lang_loss (independent masks)")
+    top = max(float(pp.grad.abs().max()) for pp in orc.P.values() if pp.grad is not None)
+    n = 0
+    for k, pp in m.named_parameters():
+        gk = orc.P[k].grad
+        if gk is None or float(gk.abs().max()) < 1e-5 * top:
+            continue
+        close(pp.grad, gk, "grad " + k, atol=2e-4 * max(1.0, float(gk.abs().max())), rtol=2e-3)
+        n += 1
+    assert n >= 30, n
