@@ -725,6 +725,26 @@ def main():
             if not a.no_decode:
                 oc["mrnn_decode_topk"] = mrnn_decode_leg(dev, images=6, M=500)[0]
             res["other_configs"] = oc
+    if world > 1:
+        # first-contact evidence for the readiness-ordered buckets: two extra untimed steps with the reducer's event brackets
+        # on EVERY rank (a collective is a collective): when each slice could start, when the compute stream got past it, what the step
+        # paid for communication.  Rank 0 reports its own view and the max exposed time over the ranks.
+        red.timing = True
+        comm = None
+        for _ in range(2):
+            step()
+            torch.cuda.synchronize()
+            comm = red.report()
+        red.timing = False
+        red._ev = None
+        ex = torch.tensor([comm["exposed_ms"] if comm else 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            res["communication"] = {"rccl_ranks": world, "backend": dist.get_backend(), "rehearsal_not_rccl": rehearsal,
+                                    "grad_bytes_per_rank": int(model.flat_params.numel()) * 4, "collectives_per_step": len(red.issued),
+                                    "overlap": red.overlap, "rank0": comm, "exposed_ms_max_over_ranks": round(float(ex.item()), 3),
+                                    "note": "HIP events on the compute stream: issue_ms = the slice's gradients are final (collective may start), done_by_ms = "
+                                            "compute stream past the wait; exposed = last wait end - backward end"}
     sd = None
     if world > 1 and headline and not a.no_decode:                        # every rank decodes its share; rank 0 prints
         sd = decode_bench_sharded(model.state_dict(), dev, rank, world, per_rank=a.decode_images)

@@ -122,10 +122,14 @@ class GradBucketReducer:
     enqueued behind the kernels already on the compute stream (torch.distributed's stream hand-off) and runs on RCCL's own stream.
     Reference semantics: nn.DataParallel's gradient reduce-add, train.py:96-98,154-164."""
 
-    def __init__(self, model, group=None, overlap=True, always_reduce=False):
+    def __init__(self, model, group=None, overlap=True, always_reduce=False, timing=False):
         """`always_reduce`: issue the collectives even in a one-rank group (a one-GPU box can then exercise RCCL itself and
-        the stream ordering between the backward kernels and the all-reduce; the sum over one rank is the identity)."""
+        the stream ordering between the backward kernels and the all-reduce; the sum over one rank is the identity).
+        `timing`: bracket the step with HIP events on the compute stream (`report()`): when each slice's collective could start,
+        and how long the compute stream then WAITED for the collectives after the backward's last kernel = the exposed communication."""
         self.model, self.group = model, group
+        self.timing = bool(timing)
+        self._ev = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_initialized())
         self.buckets = model.grad_buckets()                     # [(stage, lo, hi)], readiness order, the fusion layers last
@@ -156,6 +160,10 @@ class GradBucketReducer:
         g = self.model.flat_grads[lo:hi]
         F_.note("issue", stage)
         self.issued.append((stage, 4 * (hi - lo)))
+        if self._ev is not None:                                # fires when every kernel enqueued so far is done: the collective may start
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._ev["issue"].append(e)
         self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _ready(self, stage):
@@ -178,7 +186,11 @@ class GradBucketReducer:
     def prepare(self):
         """Call before forward: (re)binds every .grad into the zeroed flat bucket."""
         self._fired, self._pending, self._launched, self.issued, self._announced = {}, [], [], [], set()
-        return self.model.flatten_grads()
+        flat = self.model.flatten_grads()
+        if self.timing and self.active and flat.is_cuda:
+            self._ev = {"start": torch.cuda.Event(enable_timing=True), "issue": [], "bwd_end": None, "waited": []}
+            self._ev["start"].record()
+        return flat
 
     def finish(self, average=True):
         """Call after loss.backward(): reduces whatever has not been sent yet (the fusion slice; every slice when nothing
@@ -200,12 +212,32 @@ class GradBucketReducer:
             if st not in self._launched and hi > lo:
                 self._launched.append(st)
                 self._issue(st, lo, hi)
+        if self._ev is not None:                                # the backward's last kernel (and the last slice's issue point)
+            self._ev["bwd_end"] = torch.cuda.Event(enable_timing=True)
+            self._ev["bwd_end"].record()
         for w in self._pending:
             w.wait()
+            if self._ev is not None:                            # the compute stream is past this collective
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self._ev["waited"].append(e)
         self._pending = []
         if average and self.world > 1:
             g.mul_(1.0 / self.world)
         return g
+
+    def report(self):
+        """(timing=True; call after a device synchronisation) -> {"buckets": [{stage, bytes, issue_ms, done_by_ms}], "backward_end_ms",
+        "exposed_ms"}: times on the compute stream since `prepare()`.  issue_ms = when the slice's last gradient kernel had finished
+        (the collective's earliest start); done_by_ms = when the compute stream got past the wait for it; exposed_ms = what the step
+        paid for communication = end of the last wait - end of the backward's own kernels."""
+        ev = self._ev
+        if ev is None or ev["bwd_end"] is None:
+            return None
+        t = lambda e: round(ev["start"].elapsed_time(e), 3)
+        rows = [{"stage": st, "bytes": nb, "issue_ms": t(ei), "done_by_ms": t(ew)} for (st, nb), ei, ew in zip(self.issued, ev["issue"], ev["waited"])]
+        end = t(ev["bwd_end"])
+        return {"buckets": rows, "backward_end_ms": end, "exposed_ms": round((rows[-1]["done_by_ms"] if rows else end) - end, 3)}
 
     def close(self):
         from . import functions as F_

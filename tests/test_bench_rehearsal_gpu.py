@@ -35,6 +35,13 @@ def test_two_rank_bench_prints_one_contract_line():
     for k in ("decode_tokens_per_s", "decode_batched_tokens_per_s", "decode_mrnn_topk_tokens_per_s"):
         assert d[k] > 0, k
     assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
+    # first-contact evidence block of an N > 1 run: ranks, backend, every collective's issue point and the exposed communication
+    c = d["communication"]
+    assert c["rccl_ranks"] == 2 and c["backend"] == "gloo" and c["rehearsal_not_rccl"] is True and c["collectives_per_step"] == 5
+    assert [b["stage"] for b in c["rank0"]["buckets"]] == ["logit", "recurrent", "prepare", "gcn", "fusion"]
+    assert sum(b["bytes"] for b in c["rank0"]["buckets"]) == c["grad_bytes_per_rank"]
+    t = [b["issue_ms"] for b in c["rank0"]["buckets"]]
+    assert t == sorted(t) and t[0] > 0 and c["rank0"]["backward_end_ms"] >= t[-1] and c["exposed_ms_max_over_ranks"] >= 0
 
 
 @pytest.mark.timeout(1500)

@@ -48,7 +48,7 @@ def _model_and_batch():
 
 def _shard_step(m, models, shard, reducer=None):
     lw = models.LossWrapper(m, None)
-    b = {k: v.to("cuda:0") for k, v in shard.items()}
+    b = {k: v.to(m.flat_params.device) for k, v in shard.items()}
     (reducer.prepare() if reducer is not None else m.flatten_grads())
     out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
              None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
@@ -171,3 +171,55 @@ def test_rccl_world_size_one_pushes_the_real_280mb_bucket():
     assert sum(sizes.values()) == nbytes and sizes["logit"] > 37e6 and sizes["recurrent"] > 150e6 and sizes["fusion"] < 15e6      # every byte of the bucket travels exactly once
     assert err <= 1e-4 * scale + 1e-12, (err, scale)        # two runs of the backward differ by fp32 atomic order only
     assert 0 < moved < 1e-2
+
+
+def _rccl2_worker(rank, port, q):
+    """Two ranks on TWO devices over the real `nccl` (= RCCL) backend: the golden model, one shard each, readiness-ordered buckets."""
+    _setup_paths()
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from conftest import Golden
+    from subgc import parallel, synthetic
+    import subgc.models as models
+    r, local, w = parallel.init_distributed("nccl")
+    g = Golden("subgc_train")
+    opt = g.opt(caption_model="topdown", gpn_drop_prob=0.0)
+    m = models.setup(opt)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g.group("weights").items()})
+    m = m.to(f"cuda:{local}").train()
+    batch = synthetic.make_train_batch(4, D=opt.att_feat_size, vocab=opt.vocab_size, seed=9, fc_size=opt.att_feat_size)
+    plain, _ = _shard_step(m, models, parallel.shard_batch(batch, rank, 2))
+    red = parallel.GradBucketReducer(m, timing=True)
+    flat, early = _shard_step(m, models, parallel.shard_batch(batch, rank, 2), red)
+    torch.cuda.synchronize()
+    rep = red.report()
+    red.close()
+    q.put((rank, plain.cpu().numpy(), flat.cpu().numpy(), bool(early), dist.get_backend(), rep))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_rccl_on_two_devices():
+    """The real thing where the box has it: two processes, two GPUs, backend nccl (RCCL over xGMI).  Skipped on the one-GPU test box
+    (tests/test_parallel_cpu.py covers the same reducer with two gloo ranks; the world-size-1 test above covers RCCL itself)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl2_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=800) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, p0, f0, e0, be, rep0), (_, p1, f1, e1, _, rep1) = res
+    assert be == "nccl" and e0 and e1
+    np.testing.assert_array_equal(f0, f1)
+    scale = float(np.abs(p0).max())
+    np.testing.assert_allclose(f0, 0.5 * (p0 + p1), atol=3e-5 * scale + 1e-8, rtol=1e-4)
+    for rep in (rep0, rep1):
+        assert [b["stage"] for b in rep["buckets"]] == ["logit", "recurrent", "prepare", "gcn", "fusion"] and rep["exposed_ms"] >= 0
