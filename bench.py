@@ -492,6 +492,9 @@ def main():
     ap.add_argument("--no-pair-launches", action="store_true", help="experiment: the two same-shape products of a GCN unit pair as two launches (ops.PAIR_LAUNCHES = False)")
     ap.add_argument("--share-attention-sets", type=int, default=-1, help="Full-GC configs: 1 = attention sets once per image (ties the att_embed dropout mask "
                     "across an image's sentences: NOT the reference's semantics), 0 = the reference's independent masks on replicated rows (model default)")
+    ap.add_argument("--plan-side-stream", action="store_true", help="experiment: declare the batch resident (model.inputs_resident): the packed decoder's row "
+                    "plan runs on a side stream instead of queueing behind the previous step (measured: no gain, round 5)")
+    ap.add_argument("--chains", type=int, default=-1, help="experiment: ops.RECURRENCE_CHAINS (2 = the recurrence as two interleaved chains on two streams, 0 = one chain)")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -516,6 +519,9 @@ def main():
     model = models.setup(opt).to(dev).train()
     if a.pitch_f32 >= 0:
         ops.PITCH["f32"] = a.pitch_f32
+    model.inputs_resident = bool(a.plan_side_stream)
+    if a.chains >= 0:
+        ops.RECURRENCE_CHAINS = a.chains
     if a.no_pair_launches:
         ops.PAIR_LAUNCHES = False
     if a.fork_wgrads:

@@ -871,6 +871,16 @@ int subgc_recurrence_fwd(const SubgcRecurrence* a, void* workspace, size_t ws_by
  * swap roles every step.  dv != NULL: d(v) accumulates per step (dCtx unused); dv == NULL: this step's d(ctx) rows are kept in dCtx
  * for one subgc_attn_dv_accum* after the loop (always so for shared sets). */
 int subgc_recurrence_bwd(const SubgcRecurrence* a, void* stream);
+/* TWO independent chains of the same recurrence on two streams, their steps interleaved in issue order (a, b, a, b, ...).  The rows of a
+ * decoder batch are independent of each other (AttModel.py:157-175 is row-wise throughout), so a batch cut at a row boundary h is two
+ * recurrences: chain a = rows [0, h) of every step, chain b = rows [h, m[t]) -- block b is block a with its row pointers advanced by h
+ * (row0[t] + h, Gf / pre / lens / off / C1 / C2 / k_out / the dC ping-pong by h rows, Hout / dHout offsets by h rows), its own plane
+ * buffers (QP; PA, PB, PC), its own workspace, and m_b[t] = m[t] - h while positive.  While one chain sits in a cell / attention
+ * kernel (bandwidth- or latency-bound, a few microseconds) the other's product has the matrix pipes, and a kernel boundary of one chain
+ * is covered by the other's running kernel.  Ordering against the caller's stream (fork before, join after) is the caller's job. */
+int subgc_recurrence_fwd_pair(const SubgcRecurrence* a, void* ws_a, size_t ws_a_bytes, void* stream_a, const SubgcRecurrence* b,
+                              void* ws_b, size_t ws_b_bytes, void* stream_b);
+int subgc_recurrence_bwd_pair(const SubgcRecurrence* a, void* stream_a, const SubgcRecurrence* b, void* stream_b);
 
 #ifdef __cplusplus
 }

@@ -731,9 +731,9 @@ class Prepared:
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum(alpha, dctx, step_off, T, self.off, lens, dv, S, R)
 
-    def recur_fields(self):
-        """The attention-set fields of ops.Recurrence (per-sentence sets)."""
-        return dict(shared=0, u=self.u, v=self.v, off=self.off, uv_b16=int(ops.is_b16(self.u)))
+    def recur_fields(self, r0=0):
+        """The attention-set fields of ops.Recurrence (per-sentence sets); r0: first sentence row of the chain the block is for."""
+        return dict(shared=0, u=self.u, v=self.v, off=self.off[r0:], uv_b16=int(ops.is_b16(self.u)))
 
     def new_du(self, A):
         """Zeroed accumulator of d(u) for the backward's time loop."""
@@ -800,7 +800,9 @@ class PreparedShared(Prepared):
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum_group(alpha, dctx, step_off, T, self.rows, self.B, self.g, self.N, dv, R)
 
-    def recur_fields(self):
+    def recur_fields(self, r0=0):
+        if r0:
+            raise ops.SubgcError("shared attention sets run as one chain (an image's sentences share d(u) planes)")
         return dict(shared=1, u=self.u, v=self.v, rows_map=self.rows, B=self.B, g=self.g, Nn=self.N, uv_b16=int(ops.is_b16(self.u)))
 
     def new_du(self, A):

@@ -40,9 +40,29 @@ class Plan:
     live-row counts per step and their prefix, the criterion's denominator.  The T counts are the one thing the HOST needs (launch
     dimensions); they travel to pinned memory behind an event."""
 
-    def __init__(self, labels, mask_t):
+    def __init__(self, labels, mask_t, ahead=False):
+        """`ahead` (AttModel.inputs_resident, opt-in): the plan kernel and its copy run on a SIDE stream that does not wait for the
+        caller's stream.  The plan depends on the label / mask INPUTS alone; on the caller's stream it queues behind the whole previous
+        train step, so the host -- which must read the T counts before it can size the decoder's launches -- drains the GPU once per
+        step.  Only legal when the caller guarantees that `labels` / `mask_t` are complete in device memory when forward is called
+        (a prefetching loader that synchronises its copy stream; bench.py's resident batch); the plan's device outputs are handed back to
+        the caller's stream through an event."""
         S, T = mask_t.shape
         self.T = T
+        if ahead and labels.is_cuda:
+            main = torch.cuda.current_stream(labels.device)
+            side = ops.plan_stream(labels.device)
+            with torch.cuda.stream(side):
+                self.perm32, self.perm, self.inv32, self.plan, self.den = ops.live_plan(labels, mask_t)
+                self.host = _pinned_counts(T)
+                self.host.copy_(self.plan[:T], non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record(side)
+            main.wait_event(self.event)                                         # the decoder's kernels read perm / offs / den on the caller's stream
+            for t_ in (self.perm32, self.perm, self.inv32, self.plan, self.den):
+                t_.record_stream(main)
+            self.offs = self.plan[T:]
+            return
         self.perm32, self.perm, self.inv32, self.plan, self.den = ops.live_plan(labels, mask_t)
         self.offs = self.plan[T:]                                              # int32 [T+1] on the device
         self.host = torch.empty(T, dtype=torch.int32).pin_memory()
@@ -54,6 +74,16 @@ class Plan:
         """-> list of live rows per step (blocks until the counts have arrived)."""
         self.event.synchronize()
         return [int(c) for c in self.host.tolist()]
+
+
+_PINNED_COUNTS = {}
+
+
+def _pinned_counts(T):
+    """Two alternating pinned [T] buffers (a fresh pin_memory() per step costs ~30 us of host time)."""
+    ring = _PINNED_COUNTS.setdefault(T, [[torch.empty(T, dtype=torch.int32).pin_memory() for _ in range(2)], 0])
+    ring[1] ^= 1
+    return ring[0][ring[1]]
 
 
 # `Plan` issued at the START of the model's forward: the counts travel while the host is still enqueueing the encoder, so the decoder
@@ -154,14 +184,32 @@ class PackedDecoderLossFn(Function):
         # arithmetic); the Python loop below remains for scheduled sampling (per-step logits / draws / embeddings) and for the bench's
         # FLOP-accounting pass.
         rec = None
+        h_cut = 0
         if ss is None and T_live > 0 and ops.recurrence_ok():
-            rec = ops.Recurrence(S=S, T=T_live, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
-                                 keep_scale=float(scale), m=list(M[:T_live]) + [M[T_live] if T_live < T else 0], row0=ot[:T_live + 1],
-                                 hout_off=[o_ * ops.ld(Hout) for o_ in ot[:T_live]], ld_hout=ops.ld(Hout), H1=H1, ldH1=ops.ld(H1), H2=H2, ldH2=ops.ld(H2),
-                                 Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]), b1i=b1i, b1h=b1h,
-                                 b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre, Gx=Gx, Gf=Gf, C1=C1, C2=C2, G1=G1, G2=G2, AH=AH, AL=AL, k_out=k_out, QP=QP,
-                                 qp_bytes=QP.numel() * 4, w_a=an_w, b_a=an_b, lens=lens_p, **pr.recur_fields())
-            ops.recurrence_fwd(rec, H1)
+            def fwd_block(r0, Mc, QPc):
+                """Argument block of the chain that owns rows [r0, r0 + Mc[t]) of every step (r0 = 0: the whole batch or chain a)."""
+                Tc = sum(1 for m_ in Mc if m_ > 0)
+                # the entry after the last step: where that step's state rows go.  A chain that ends before the batch does has no next
+                # rows of its own: its one dummy row goes to the slack behind the last step, never into the other chain's rows
+                nxt_m = Mc[Tc] if Tc < len(Mc) else 0
+                nxt_row = (ot[Tc] + r0) if nxt_m > 0 else rows
+                return ops.Recurrence(S=S, T=Tc, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
+                                      keep_scale=float(scale), m=list(Mc[:Tc]) + [nxt_m], row0=[o_ + r0 for o_ in ot[:Tc]] + [nxt_row],
+                                      hout_off=[(o_ + r0) * ops.ld(Hout) for o_ in ot[:Tc]], ld_hout=ops.ld(Hout), H1=H1, ldH1=ops.ld(H1), H2=H2,
+                                      ldH2=ops.ld(H2), Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]),
+                                      b1i=b1i, b1h=b1h, b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre[r0:], Gx=Gx, Gf=Gf[r0:], C1=C1[:, r0:], C2=C2[:, r0:],
+                                      G1=G1, G2=G2, AH=AH, AL=AL, k_out=None if k_out is None else k_out[:, r0:], QP=QPc, qp_bytes=QPc.numel() * 4,
+                                      w_a=an_w, b_a=an_b, lens=lens_p[r0:], **pr.recur_fields(r0))
+            h_cut = 0 if pr.shared else ops.chain_cut(M[:T_live])
+            if h_cut:
+                # two chains (ops.RECURRENCE_CHAINS): rows [0, h) and [h, m[t]) of every step as independent recurrences on two streams
+                Ma = [min(m_, h_cut) for m_ in M] 
+                Mb = [max(m_ - h_cut, 0) for m_ in M]
+                rec = fwd_block(0, Ma, QP)
+                ops.recurrence_pair("subgc_recurrence_fwd_pair", rec, fwd_block(h_cut, Mb, new(8 * S * A)), H1, True)
+            else:
+                rec = fwd_block(0, list(M), QP)
+                ops.recurrence_fwd(rec, H1)
         for t in range(T_live if rec is None else 0):
             m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
             o1 = ot[t + 1]
@@ -208,6 +256,7 @@ class PackedDecoderLossFn(Function):
         loss, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p, den=plan.den, lse=lse)
 
         ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
+        ctx.h_cut = h_cut
         ctx.masks = (k_xt, k_out)
         ctx.flat_tokens = (tok_flat, k_flat)
         ctx.W, ctx.bf = W, bf
@@ -287,15 +336,29 @@ class PackedDecoderLossFn(Function):
         F_.note("bptt_begin", T_live)
         rec = None
         if T_live > 0 and ops.recurrence_ok():
-            rec = ops.Recurrence(S=S, T=T_live, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
-                                 keep_scale=float(scale), m=list(M[:T_live]) + [0], row0=ot[:T_live + 1], dhout_off=[o_ * R for o_ in ot[:T_live]],
-                                 ld_dhout=R, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]), C1=C1, C2=C2, G1=G1, G2=G2,
-                                 AH=AH, AL=AL, k_out=k_out, w_a=an_w, lens=lens_p, dHout=dHout, dP1=dP1, dP2=dP2, dAH=dAH, du=du,
-                                 du_planes=du.size(0) if du.dim() == 3 else 1, du_plane_stride=du.stride(0) if du.dim() == 3 else 0,
-                                 dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, PA=PA, pa_bytes=PA.numel() * 4,
-                                 PB=PB, pb_bytes=PB.numel() * 4, PC=PC, pc_bytes=PC.numel() * 4, dC1_in=dC1[0], dC1_out=dC1[1], dC2_in=dC2[0],
-                                 dC2_out=dC2[1], **pr.recur_fields())
-            ops.recurrence_bwd(rec)
+            def bwd_block(r0, Mc, planes, cells):
+                Tc = sum(1 for m_ in Mc if m_ > 0)
+                PA_, PB_, PC_ = planes
+                c1, c2 = cells
+                return ops.Recurrence(S=S, T=Tc, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
+                                      keep_scale=float(scale), m=list(Mc[:Tc]) + [0], row0=[o_ + r0 for o_ in ot[:Tc]] + [rows],
+                                      dhout_off=[(o_ + r0) * R for o_ in ot[:Tc]], ld_dhout=R, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2),
+                                      Wq=W[17], ldWq=ops.ld(W[17]), C1=C1[:, r0:], C2=C2[:, r0:], G1=G1, G2=G2, AH=AH, AL=AL,
+                                      k_out=None if k_out is None else k_out[:, r0:], w_a=an_w, lens=lens_p[r0:], dHout=dHout, dP1=dP1, dP2=dP2,
+                                      dAH=dAH, du=du, du_planes=du.size(0) if du.dim() == 3 else 1, du_plane_stride=du.stride(0) if du.dim() == 3 else 0,
+                                      dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, PA=PA_, pa_bytes=PA_.numel() * 4,
+                                      PB=PB_, pb_bytes=PB_.numel() * 4, PC=PC_, pc_bytes=PC_.numel() * 4, dC1_in=c1[0][r0:], dC1_out=c1[1][r0:],
+                                      dC2_in=c2[0][r0:], dC2_out=c2[1][r0:], **pr.recur_fields(r0))
+            h_cut = getattr(ctx, "h_cut", 0) if ops.RECURRENCE_CHAINS >= 2 else 0
+            if h_cut:
+                Ma = [min(m_, h_cut) for m_ in M]
+                Mb = [max(m_ - h_cut, 0) for m_ in M]
+                rec = bwd_block(0, Ma, (PA, PB, PC), (dC1, dC2))
+                rec_b = bwd_block(h_cut, Mb, (new(8 * S * 3 * R), new(8 * S * R), new(8 * S * 2 * R)), (dC1, dC2))
+                ops.recurrence_pair("subgc_recurrence_bwd_pair", rec, rec_b, dHout, False)
+            else:
+                rec = bwd_block(0, list(M), (PA, PB, PC), (dC1, dC2))
+                ops.recurrence_bwd(rec)
         for t in range(T_live - 1, -1, -1):
             if rec is not None:
                 break

@@ -135,6 +135,10 @@ class AttModel(CaptionModel):
         # step_{h_att,c_att,h_lang,c_lang,alpha,ctx,logp}); None (default): no cost.  The train forward then runs the unpacked
         # decoder, the decode the eager (not graph-replayed) loop -- same kernels.
         self.__dict__["tap"] = None
+        # opt-in: the caller guarantees that the tensors handed to forward are complete in device memory when the call is made (a loader
+        # that synchronises its upload stream; a resident batch).  The packed decoder's row plan then runs on a side stream instead of
+        # queueing behind the previous train step, and the host no longer drains the GPU once per step (functions_packed.Plan).
+        self.__dict__["inputs_resident"] = False
         self.__dict__["_nbt_pending"] = {}
         self._build_parameters()
 
@@ -710,7 +714,7 @@ class AttModel(CaptionModel):
         plan = None
         if packed:                                                                        # the packed decoder's row plan, read behind an event
             from ..functions_packed import PlanAhead
-            plan = PlanAhead(seq.contiguous(), fused_crit[1])
+            plan = PlanAhead(seq.contiguous(), fused_crit[1], ahead=bool(self.__dict__.get("inputs_resident", False)))
         masks = self._masks({"fc": ((b5, R), p), "att": ((b5 * N, R), p), "xt": ((T, b5, E), p), "out": ((T, b5, R), p),
                              "gpn_hid": ((2 * b5 * hb, self.att_hid_size), self.gpn_drop_prob if (self.gpn and self.use_sGPN_score) else 0.0)}, dev)
         X = self._encode(att_feats, obj_dist, pred_dist, rel_ind)
