@@ -494,6 +494,7 @@ def main():
                     "across an image's sentences: NOT the reference's semantics), 0 = the reference's independent masks on replicated rows (model default)")
     ap.add_argument("--plan-side-stream", action="store_true", help="experiment: declare the batch resident (model.inputs_resident): the packed decoder's row "
                     "plan runs on a side stream instead of queueing behind the previous step (measured: no gain, round 5)")
+    ap.add_argument("--dedup", type=int, default=-1, help="experiment (Full-GC): opt.dedup_att_embed (1 = att_embed once per node row + masked gather per copy, 0 = on the replicated rows)")
     ap.add_argument("--chains", type=int, default=-1, help="experiment: ops.RECURRENCE_CHAINS (2 = the recurrence as two interleaved chains on two streams, 0 = one chain)")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
@@ -516,6 +517,8 @@ def main():
     opt = argparse.Namespace(**cfg["opt"])
     if a.share_attention_sets >= 0:
         opt.share_attention_sets = a.share_attention_sets
+    if a.dedup >= 0:
+        opt.dedup_att_embed = a.dedup
     model = models.setup(opt).to(dev).train()
     if a.pitch_f32 >= 0:
         ops.PITCH["f32"] = a.pitch_f32

@@ -732,6 +732,11 @@ int subgc_relu_bwd(const float* dy, const void* y, float scale, void* dz, int64_
 /* dst[m, :] = src[rows[m], :] for m < min(M, *m_dev); negative rows give zero rows               */
 int subgc_gather_rows(const float* src, int64_t lds, const int32_t* rows, void* dst, int64_t ldd,
                       int M, int L, const int32_t* m_dev, int out_bf16, void* stream);
+/* dst[m, :] = src[rows[m], :] * (keep ? keep[m, :] * scale : 1) for m < min(M, *m_dev): nn.Dropout applied to GATHERED copies of shared
+ * rows, every copy with its own keep-mask row (AttModel.py:113-119 on the x5 replicated node rows of gcn_backbone.py:50-51: one
+ * att_embed product over the unique rows serves all copies).  bf16_bits: bit 0 = dst is bf16, bit 1 = src is bf16; keep may be NULL. */
+int subgc_gather_rows_keep(const void* src, int64_t lds, const int32_t* rows, const uint8_t* keep, int64_t ldk, float scale,
+                           void* dst, int64_t ldd, int M, int L, const int32_t* m_dev, int bf16_bits, void* stream);
 /* the same gather for `count` (1..4) tensors in one launch: dst_k[m, :c_k] = src_k[rows[m], :c_k] -- the state fork of beam
  * search (CaptionModel.py:76-90: h and c of both LSTMs follow the surviving beams), four tensors per step            */
 int subgc_gather_rows_multi(int count, const float* s0, int64_t lds0, float* d0, int64_t ldd0, int c0, const float* s1,

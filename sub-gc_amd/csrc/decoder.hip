@@ -595,6 +595,25 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     const int r = rows[m];
     for (int c = threadIdx.x; c < L; c += blockDim.x) store_one(dst, (int64_t)m * ldd + c, r >= 0 ? src[(int64_t)r * lds_ + c] : 0.f, b16);
 }
+// dst[m, :] = src[rows[m], :] * keep[m, :] * scale: nn.Dropout on gathered copies of shared rows -- the replicated node rows of the
+// Full-GC attention sets (gcn_backbone.py:50-51 x5 copies, each with its OWN keep-mask, AttModel.py:113-119) from ONE att_embed
+// product over the unique rows.  src / dst fp32 or bf16 (bit 0 of b16: dst, bit 1: src); four columns per lane.
+__global__ __launch_bounds__(256) void gather_rows_keep_kernel(const void* __restrict__ src, int64_t lds_, const int32_t* __restrict__ rows,
+                                                               const uint8_t* __restrict__ keep, int64_t ldk, float scale,
+                                                               void* __restrict__ dst, int64_t ldd, int M, int L,
+                                                               const int32_t* __restrict__ m_dev, int b16) {
+    if (m_dev) M = min(M, *m_dev);
+    const int m = blockIdx.x;
+    if (m >= M) return;
+    const int r = rows[m];
+    const int src16 = (b16 >> 1) & 1, dst16 = b16 & 1;
+    for (int c = threadIdx.x; c < L; c += blockDim.x) {
+        float x = 0.f;
+        if (r >= 0) x = src16 ? subgc_bf2f(static_cast<const uint16_t*>(src)[(int64_t)r * lds_ + c]) : static_cast<const float*>(src)[(int64_t)r * lds_ + c];
+        if (keep) x = keep[(int64_t)m * ldk + c] ? x * scale : 0.f;
+        store_one(dst, (int64_t)m * ldd + c, x, dst16);
+    }
+}
 // the same row gather for up to four tensors in ONE launch (blockIdx.y picks the tensor): the beam-search state fork
 struct GatherSet { const float* src[4]; float* dst[4]; int64_t lds[4], ldd[4]; int cols[4]; };
 template <typename IndexT>
@@ -1057,6 +1076,15 @@ SUBGC_API int subgc_gather_rows(const float* src, int64_t lds, const int32_t* ro
     SUBGC_REQUIRE(src && rows && dst, "gather_rows: null pointer");
     hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dst, ldd, M, L, m_dev, out_bf16);
     return subgc::check_launch("subgc_gather_rows");
+}
+SUBGC_API int subgc_gather_rows_keep(const void* src, int64_t lds, const int32_t* rows, const uint8_t* keep, int64_t ldk, float scale, void* dst,
+                                     int64_t ldd, int M, int L, const int32_t* m_dev, int bf16_bits, void* stream) {
+    SUBGC_REQUIRE(M >= 0 && L > 0 && lds >= L && ldd >= L && (!keep || ldk >= L), "gather_rows_keep: bad sizes");
+    if (M == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(src && rows && dst, "gather_rows_keep: null pointer");
+    hipLaunchKernelGGL(gather_rows_keep_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, src, lds, rows, keep, ldk, scale, dst, ldd, M, L, m_dev,
+                       bf16_bits);
+    return subgc::check_launch("subgc_gather_rows_keep");
 }
 SUBGC_API int subgc_gather_rows_multi(int count, const float* s0, int64_t lds0, float* d0, int64_t ldd0, int c0, const float* s1, int64_t lds1,
                                       float* d1, int64_t ldd1, int c1, const float* s2, int64_t lds2, float* d2, int64_t ldd2, int c2,

@@ -673,10 +673,17 @@ class Prepared:
     read (f1, f) are kept, every tensor a GEMM reads gets a bf16 twin written by its producer (`*16`), and the node features
     u, v are bf16 only (the attention kernels read them as such)."""
 
-    def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale, W=None, into=None):
+    dedup = False
+
+    def __init__(self, fc_in, X_nodes, lens, idx, img, N, P, keep_fc, keep_att, scale, W=None, into=None, dedup=False):
         """`into` (decode, fp32 only): a namespace of fixed-address buffers f [S, R], u [S*N, A], v [S*N, R], off [S] that receive the
         results in place (the captured decode graphs read them there); rows past the packed total keep whatever they held -- the
-        attention kernels never read them."""
+        attention kernels never read them.
+        `dedup` (Full-GC training under dropout): every node row of an image is in the attention set of each of its 5 sentences
+        (AttModel.py:140-149 on the x5 replicated rows of gcn_backbone.py:50-51), so relu(att_embed(x)) is computed ONCE per node row
+        ([B*N] instead of [5*B*N] rows in the forward product, the weight gradient and the data gradient) and each sentence's copy is
+        gathered with ITS OWN dropout keep-mask row (subgc_gather_rows_keep): the reference's five independent masks, a fifth of the
+        att_embed FLOPs.  v, u and everything downstream are per sentence, as in the replicated path."""
         (fc0_w, fc0_b, fc2_w, fc2_b, att_w, att_b, c2a_w, c2a_b) = P[:8]
         dev = fc_in.device
         S = fc_in.size(0)
@@ -686,14 +693,16 @@ class Prepared:
         MR = S * N
         L = X_nodes.size(1)
         new = lambda r, c: torch.empty(r, c, device=dev, dtype=torch.float32)
+        self.dedup = bool(dedup) and into is None
         if W is not None and ops.is_b16(W[0]):
             if into is not None:
                 raise ops.SubgcError("Prepared(into=...) is the fp32 decode form")
             w0, w2, wa, wc = W[0], W[2], W[4], W[6]
             self.fc16 = ops.as_b16(fc_in)
             self.Xg = None                                     # the gathered node rows only feed GEMMs: bf16 only
-            self.Xg16 = ops.empty_b16(MR, L, dev)
-            ops.gather_rows(X_nodes, self.src_row, self.Xg16, m_dev=self.total)
+            if not self.dedup:
+                self.Xg16 = ops.empty_b16(MR, L, dev)
+                ops.gather_rows(X_nodes, self.src_row, self.Xg16, m_dev=self.total)
             self.f1, self.f116 = new(S, fc0_w.size(0)), ops.empty_b16(S, fc0_w.size(0), dev)
             ops.gemm(self.fc16, w0, self.f1, tb=True, bias=fc0_b, relu=True, out16=self.f116)
             self.f, self.f16 = new(S, fc2_w.size(0)), ops.empty_b16(S, fc2_w.size(0), dev)
@@ -702,19 +711,31 @@ class Prepared:
             # attention kernels read them as such (half the bytes of the two largest per-step reads), the ReLU backward takes its
             # sign test from the bf16 v (same exponent range as fp32), and no fp32 copy is ever stored
             self.v16 = ops.empty_b16(MR, att_w.size(0), dev, zero=True)
-            ops.gemm(self.Xg16, wa, self.v16, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
+            if self.dedup:
+                self.Xu16 = ops.as_b16(X_nodes)                # the unique node rows
+                r16 = ops.empty_b16(X_nodes.size(0), att_w.size(0), dev)
+                ops.gemm(self.Xu16, wa, r16, tb=True, bias=att_b, relu=True)
+                ops.gather_rows_keep(r16, self.src_row, keep_att, scale, self.v16, m_dev=self.total)
+            else:
+                ops.gemm(self.Xg16, wa, self.v16, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
             self.v = self.v16
             self.u = ops.empty_b16(MR, c2a_w.size(0), dev)
             ops.gemm(self.v16, wc, self.u, tb=True, bias=c2a_b, m_dev=self.total)
             return
-        self.Xg = torch.empty(MR, L, device=dev, dtype=torch.float32)
-        ops.gather_rows(X_nodes, self.src_row, self.Xg, m_dev=self.total)
+        if not self.dedup:
+            self.Xg = torch.empty(MR, L, device=dev, dtype=torch.float32)
+            ops.gather_rows(X_nodes, self.src_row, self.Xg, m_dev=self.total)
         self.f1 = torch.empty(S, fc0_w.size(0), device=dev, dtype=torch.float32)
         ops.gemm(fc_in, fc0_w, self.f1, tb=True, bias=fc0_b, relu=True)
         self.f = torch.empty(S, fc2_w.size(0), device=dev, dtype=torch.float32) if into is None else into.f
         ops.gemm(self.f1, fc2_w, self.f, tb=True, bias=fc2_b, relu=True, keep=keep_fc, keep_scale=scale)
         self.v = ops.zeros(MR, att_w.size(0), device=dev) if into is None else into.v[:MR]
-        ops.gemm(self.Xg, att_w, self.v, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
+        if self.dedup:
+            r = new(X_nodes.size(0), att_w.size(0))
+            ops.gemm(X_nodes, att_w, r, tb=True, bias=att_b, relu=True)
+            ops.gather_rows_keep(r, self.src_row, keep_att, scale, self.v, m_dev=self.total)
+        else:
+            ops.gemm(self.Xg, att_w, self.v, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
         self.u = torch.empty(MR, c2a_w.size(0), device=dev, dtype=torch.float32) if into is None else into.u[:MR]
         ops.gemm(self.v, c2a_w, self.u, tb=True, bias=c2a_b, m_dev=self.total)
 
@@ -825,7 +846,7 @@ def shared_sets_ok(g, N, A, R, T=1):
 def make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W, rows=None):
     sh = meta.get("shared")
     if sh is None:
-        return Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W)
+        return Prepared(fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale, W, dedup=bool(meta.get("dedup_att_embed")))
     if rows is None:
         rows = sh["rows"]
     return PreparedShared(fc_in, X_nodes, lens, rows, sh["B"], sh["g"], N, P, k_fc, k_att, scale, W)
@@ -1140,9 +1161,21 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
         du16 = ops.as_b16(du)                                              # dead rows are zero: cast them all, bound the products
         ops.gemm(du16, W[6], dv, accum=True, m_dev=tot)                    # u = v W_c^T + b_c
         wgrad(6, du16, pr.v16, bias=7, m_dev=tot)
-        dzv = ops.relu_bwd(dv, pr.v, scale, bf16=True)
-        wgrad(4, dzv, pr.Xg16, bias=5, m_dev=tot)
         dX = None
+        if pr.dedup:
+            # d(relu(att_embed)) of every COPY, summed onto the unique node rows (5 copies per row: fp32 atomics), then ONE weight-gradient
+            # and ONE data-gradient product over the unique rows
+            dzs = ops.relu_bwd(dv, pr.v, scale)
+            dz = ops.zeros(X_nodes.size(0), dzs.size(1), device=dev)
+            ops.scatter_add_rows(dzs, pr.src_row, dz, m_dev=tot)
+            dz16 = ops.as_b16(dz)
+            wgrad(4, dz16, pr.Xu16, bias=5)
+            if need_dX:
+                dX = new(X_nodes.size(0), X_nodes.size(1)); ops.gemm(dz16, W[4], dX)
+            need_dX = False
+        else:
+            dzv = ops.relu_bwd(dv, pr.v, scale, bf16=True)
+            wgrad(4, dzv, pr.Xg16, bias=5, m_dev=tot)
         if need_dX:
             dXg = new(pr.Xg16.size(0), pr.Xg16.size(1)); ops.gemm(dzv, W[4], dXg, m_dev=tot)
             if pr.shared:
@@ -1162,8 +1195,16 @@ def prepared_backward(pr, P, W, bf, fc_in, X_nodes, du, dv, df, scale, out_for, 
     ops.gemm(du, P[6], dv, accum=True, m_dev=tot)                          # u = v W_c^T + b_c
     wgrad(6, du, pr.v, bias=7, m_dev=tot)
     dzv = ops.relu_bwd(dv, pr.v, scale)
-    wgrad(4, dzv, pr.Xg, bias=5, m_dev=tot)
     dX = None
+    if pr.dedup:
+        dz = ops.zeros(X_nodes.size(0), dzv.size(1), device=dev)
+        ops.scatter_add_rows(dzv, pr.src_row, dz, m_dev=tot)
+        wgrad(4, dz, X_nodes, bias=5)
+        if need_dX:
+            dX = new(X_nodes.size(0), X_nodes.size(1)); ops.gemm(dz, att_w, dX)
+        need_dX = False
+    else:
+        wgrad(4, dzv, pr.Xg, bias=5, m_dev=tot)
     if need_dX:
         dXg = new(pr.Xg.size(0), pr.Xg.size(1)); ops.gemm(dzv, att_w, dXg, m_dev=tot)
         if pr.shared:

@@ -124,6 +124,7 @@ class AttModel(CaptionModel):
         # marginal is unchanged, the joint distribution is not the reference's; 13 % faster on Full_GC_Kar, reported beside the
         # default by bench.py); 0: never.  Not a reference option.
         self.share_attention_sets = int(g("share_attention_sets", -1))
+        self.dedup_att_embed = g("dedup_att_embed", 1) != 0          # 0: att_embed on the replicated rows themselves (measurement / tests)
         # the two GCN units that read the same source run as one paired Function (concatenated fc_lft; functions.UnitPairFn); 0 = one by one
         self.pair_gcn_units = g("pair_gcn_units", 1) != 0
         self.dropout_seed = g("seed", 2019)
@@ -738,6 +739,10 @@ class AttModel(CaptionModel):
         if (not self.gpn and share and self.injected_masks is None and b5 % B == 0
                 and F_.shared_sets_ok(b5 // B, N, self.att_hid_size, R, T)):
             meta["shared"] = {"B": B, "g": b5 // B, "rows": c["rows"]}                    # every sentence attends over its image's N node rows
+        elif not self.gpn and self.dedup_att_embed and b5 >= 2 * B:
+            # Full-GC on replicated rows (the reference's independent per-sentence dropout masks): att_embed's Linear + ReLU once per
+            # NODE row, each sentence's copy gathered through its own keep-mask (functions.Prepared, dedup)
+            meta["dedup_att_embed"] = True
         if self.bf16_storage:
             flat16 = self.weights_b16()
             meta["W16"] = [self.W16(n, flat16) for n in F_.PARAM_ORDER]

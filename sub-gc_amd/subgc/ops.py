@@ -1637,6 +1637,13 @@ def gather_rows(src, rows, dst, m_dev=None):
     return dst
 
 
+def gather_rows_keep(src, rows, keep, scale, dst, m_dev=None):
+    """dst[m] = src[rows[m]] * keep[m] * scale (keep: uint8 [M, L] or None); src / dst fp32 or bf16."""
+    call("subgc_gather_rows_keep", _ptr(src), ld(src), _ptr(rows, torch.int32), _ptr(keep, torch.uint8), ld(keep) if keep is not None else 0, float(scale),
+         _ptr(dst), ld(dst), dst.size(0), dst.size(1), _ptr(m_dev, torch.int32), int(is_b16(dst)) | (int(is_b16(src)) << 1), _stream())
+    return dst
+
+
 def gather_rows_multi(pairs, rows):
     """dst[m] = src[rows[m]] for up to four (src, dst) pairs of 2-D views in one launch (subgc_gather_rows_multi)."""
     if not 1 <= len(pairs) <= 4:

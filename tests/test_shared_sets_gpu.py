@@ -133,3 +133,35 @@ def test_fullgc_train_with_independent_per_sentence_masks_matches_oracle(golden)
         close(pp.grad, gk, "grad " + k, atol=2e-4 * max(1.0, float(gk.abs().max())), rtol=2e-3)
         n += 1
     assert n >= 30, n
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("packed", [True, False])
+def test_dedup_att_embed_equals_the_replicated_product(golden, dtype, packed):
+    """Full-GC under dropout (independent per-sentence masks): relu(att_embed(x)) once per NODE row + a masked gather per copy
+    (functions.Prepared, dedup) against the product over the replicated rows themselves -- same Philox masks, same loss, same gradients."""
+    g = golden("fullgc_train")
+    res = {}
+    for dd in (1, 0):
+        m = build(g, g.group("weights"), True, compute_dtype=dtype, drop_prob_lm=0.5, dedup_att_embed=dd)
+        assert m.dedup_att_embed == bool(dd)
+        m.packed_decoder = packed
+        m._dropout_calls = 0
+        batch = _batch(g, 4, 21, True)
+        out, loss = run_train(m, batch)
+        res[dd] = (float(out["lang_loss"]), {k: p.grad.clone().cpu() for k, p in m.named_parameters()})
+    (l1, g1), (l0, g0) = res[1], res[0]
+    assert abs(l1 - l0) < (2e-2 if dtype == "bf16" else 2e-5) * max(1.0, abs(l0))
+    top = max(float(v.abs().max()) for v in g0.values())
+    n = 0
+    for k in g0:
+        sc = float(g0[k].abs().max())
+        if sc < 1e-5 * top or k == "pred_emb_prj.bias" or k.endswith(("fc_rgt.bias", "fc_lft.bias")):
+            continue                                              # a constant shift in front of a BatchNorm: true gradient zero, rounding noise
+        if dtype == "bf16":
+            a, b = g1[k].double().flatten(), g0[k].double().flatten()
+            assert float((a @ b) / (a.norm() * b.norm() + 1e-30)) > 0.99, k
+        else:
+            np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), atol=3e-5 * sc + 1e-9, rtol=2e-3, err_msg=k)
+        n += 1
+    assert n >= 30
