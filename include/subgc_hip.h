@@ -59,6 +59,10 @@ const char* subgc_arch(void);
 #define SUBGC_FAM_SOFTMAX 6
 int subgc_prof_enable(int family, int on);
 int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* total_work);
+/* busy_ms of the LAST subgc_prof_collect(family): the length of the union of the launches' [start, stop] intervals (events of all
+ * streams on one clock).  Equals total_ms while the family's launches run one after the other; smaller when launches of two streams
+ * overlap (subgc_recurrence_*_pair) -- the wall time during which the family held the device, the denominator of a roofline.     */
+int subgc_prof_last_busy(int family, double* busy_ms);
 
 /* ======================================================================================
  * Dense contractions (MFMA v_mfma_f32_32x32x2_f32; exact fp32)

@@ -1,6 +1,7 @@
 // Host-side plumbing: version, thread-local error text, HIP-event profiling hook.
 #include "common.h"
 
+#include <algorithm>
 #include <array>
 #include <mutex>
 #include <unordered_map>
@@ -51,6 +52,7 @@ struct Family {
     std::vector<Rec> pool;  // recycled event pairs
 };
 Family g_fam[kFamilies];
+double g_busy[kFamilies] = {};      // busy (interval-union) milliseconds of the last subgc_prof_collect per family
 std::mutex g_mu;
 }  // namespace
 
@@ -92,23 +94,48 @@ SUBGC_API int subgc_prof_enable(int family, int on) {
     return SUBGC_OK;
 }
 
+SUBGC_API int subgc_prof_last_busy(int family, double* busy_ms) {
+    using namespace subgc;
+    SUBGC_REQUIRE(family > 0 && family < kFamilies && busy_ms, "prof_last_busy: bad arguments");
+    std::lock_guard<std::mutex> lk(g_mu);
+    *busy_ms = g_busy[family];
+    return SUBGC_OK;
+}
+
 SUBGC_API int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* total_work) {
     using namespace subgc;
     SUBGC_REQUIRE(family > 0 && family < kFamilies, "prof_collect: bad family %d", family);
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
     double ms = 0, work = 0;
+    // busy time = length of the UNION of the launches' [start, stop] intervals: equal to the sum while launches run one after the
+    // other, smaller when launches of two streams overlap (the recurrence's two chains) -- the wall time the family held the device
+    std::vector<std::pair<float, float>> iv;
+    iv.reserve(f.recs.size());
     for (Rec& r : f.recs) {
         if (hipEventSynchronize(r.b) != hipSuccess) {
             set_error("prof_collect: hipEventSynchronize failed");
             return SUBGC_ELAUNCH;
         }
-        float t = 0.f;
+        float t = 0.f, t0 = 0.f;
         (void)hipEventElapsedTime(&t, r.a, r.b);
+        (void)hipEventElapsedTime(&t0, f.recs.front().a, r.a);          // start relative to the first launch's start (any stream)
+        iv.emplace_back(t0, t0 + t);
         ms += t;
         work += r.work;
-        f.pool.push_back(r);
     }
+    for (Rec& r : f.recs) f.pool.push_back(r);
+    std::sort(iv.begin(), iv.end());
+    double busy = 0;
+    float lo = 0.f, hi = 0.f;
+    bool open = false;
+    for (auto& x : iv) {
+        if (!open) { lo = x.first; hi = x.second; open = true; }
+        else if (x.first <= hi) { if (x.second > hi) hi = x.second; }
+        else { busy += hi - lo; lo = x.first; hi = x.second; }
+    }
+    if (open) busy += hi - lo;
+    g_busy[family] = busy;
     if (launches) *launches = (int64_t)f.recs.size();
     if (total_ms) *total_ms = ms;
     if (total_work) *total_work = work;

@@ -122,3 +122,10 @@ def prof_collect(family):
     n = ctypes.c_int64(0); ms = ctypes.c_double(0); work = ctypes.c_double(0)
     call("subgc_prof_collect", FAM[family], ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work))
     return n.value, ms.value, work.value
+
+
+def prof_last_busy(family):
+    """Busy (interval-union) milliseconds of the family's launches at the last prof_collect: the wall time they held the device."""
+    ms = ctypes.c_double(0)
+    call("subgc_prof_last_busy", FAM[family], ctypes.byref(ms))
+    return ms.value
