@@ -124,6 +124,8 @@ class AttModel(CaptionModel):
         # marginal is unchanged, the joint distribution is not the reference's; 13 % faster on Full_GC_Kar, reported beside the
         # default by bench.py); 0: never.  Not a reference option.
         self.share_attention_sets = int(g("share_attention_sets", -1))
+        if g("recurrence_chains") is not None:                       # opt-in: the packed recurrence as two interleaved chains (ops.RECURRENCE_CHAINS)
+            ops.RECURRENCE_CHAINS = int(g("recurrence_chains"))
         self.dedup_att_embed = g("dedup_att_embed", 1) != 0          # 0: att_embed on the replicated rows themselves (measurement / tests)
         # the two GCN units that read the same source run as one paired Function (concatenated fc_lft; functions.UnitPairFn); 0 = one by one
         self.pair_gcn_units = g("pair_gcn_units", 1) != 0

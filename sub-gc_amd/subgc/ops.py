@@ -1143,7 +1143,13 @@ def recurrence_bwd(rec):
 
 # Two interleaved chains of the train decoder's recurrence (subgc_recurrence_*_pair): rows [0, h) of every step on the caller's stream,
 # rows [h, m[t]) on a side stream.  0 = one chain (every launch of the loop in one queue).
-RECURRENCE_CHAINS = 2
+# OPT-IN (opt.recurrence_chains = 2 / bench.py --chains 2).  Measured (round 5, A/B in one job, two repeats): Sub_GC_Kar 19.90 -> 19.70 ms
+# (-1.0 %), Full_GC_Kar 16.05 -> 15.76 (-1.8 %), Flickr (320 rows) +0.6 % -- the step gets a little shorter because one chain's cell /
+# attention kernels run under the other's product, but every overlapped product takes longer (the chip's memory system is shared: GEMM
+# launch durations sum to 20.5 ms instead of 17.3), so the GEMM family holds the device for 18.1 ms instead of 17.4 and the roofline
+# fraction of the dominant kernel DROPS (0.669 -> 0.643) while the value rises 1 %.  Off by default: the contract line keeps one queue and
+# clean per-launch durations; DESIGN 8.
+RECURRENCE_CHAINS = 0
 _CHAIN_STREAMS = {}
 
 

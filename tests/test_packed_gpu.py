@@ -236,7 +236,7 @@ def test_two_chain_recurrence_equals_the_single_chain(kind):
             m._dropout_calls = 0
             res[chains] = grads_of(m, batch, True)
         finally:
-            ops.RECURRENCE_CHAINS, ops.recurrence_pair = 2, orig
+            ops.RECURRENCE_CHAINS, ops.recurrence_pair = 0, orig
     assert [s[0] for s in seen] == ["subgc_recurrence_fwd_pair", "subgc_recurrence_bwd_pair"], seen
     _, Ta, Tb, ma, mb = seen[0]
     assert Ta == 17 and 0 < Tb < Ta and ma[0] == 256 and mb[0] == 640 - 256 and all(x <= 256 for x in ma), (Ta, Tb, ma, mb)
