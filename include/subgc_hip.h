@@ -424,6 +424,21 @@ int subgc_attn_bwd(const void* u, const void* v, const float* ah, const float* w
                    const int32_t* len, const float* alpha, int n_stride, const float* dctx, int64_t lddctx,
                    void* dah, float* du, float* dv, float* dw_a, float* db_a, int S, int A, int R,
                    int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream);
+/* Deferred d(u) (the same idea as the deferred d(v)): subgc_attn_bwd_planes_de is subgc_attn_bwd_planes that does NOT touch d(u) but
+ * files the step's d(e) rows, de_keep [S, n_stride] (entries i >= len untouched); after the time loop ONE call of subgc_attn_du_accum
+ * forms
+ *   du[off[s] + i, a] = w_a[a] * sum over steps t < T with s < step_off[t+1] - step_off[t] of
+ *                       de[step_off[t] + s, i] * (1 - tanh^2(u[off[s] + i, a] + ah[step_off[t] + s, a]))            (overwrites du)
+ * from the kept d(e) rows and the query rows ah [rows, A] the forward saved (layout of de / ah: as alpha / dctx of
+ * subgc_attn_dv_accum).  Every d(u) row is written once instead of read and written at every step (Full-GC: 36 node rows x 512 x 8 bytes
+ * per sentence and step were the largest stream of the backward attention kernel); the price is one more tanh per (step, node, column).
+ * u: fp32 or bf16 (uv_bf16) [sum len, A]; the accumulation order over t differs from the per-step form (fp32 either way).           */
+int subgc_attn_bwd_planes_de(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                             const float* alpha, int n_stride, const float* dctx, int64_t lddctx, int dctx_planes, int64_t plane_stride,
+                             void* dah, float* de_keep, float* dv, float* dw_a, float* db_a, int S, int A, int R, int bf16_bits,
+                             float* dctx_keep, int64_t ldkeep, void* stream);
+int subgc_attn_du_accum(const void* u, int uv_bf16, const float* ah, const float* de, int n_stride, const int32_t* step_off, int T,
+                        const int32_t* off, const int32_t* len, const float* w_a, float* du, int S, int A, void* stream);
 /* dv[off[s] + i, :] = sum over steps t < T with s < step_off[t+1] - step_off[t] of
  *                     alpha[step_off[t] + s, i] * dctx[step_off[t] + s, :]              (overwrites dv)
  * alpha [rows, n_stride] and dctx [rows, >= R] (ld lddctx) hold the live sentences of step t as rows step_off[t] ..
@@ -862,6 +877,7 @@ typedef struct SubgcRecurrence {
     float* dWa;
     float* dBa;
     float* dCtx;
+    float* dE;                   /* per-sentence sets only, may be NULL: deferred d(u) -- step t files d(e) rows at dE + row0[t] * n_alpha, du is not touched */
     float* PA;
     size_t pa_bytes;
     float* PB;

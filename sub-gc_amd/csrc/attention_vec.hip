@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
                                                            const float* __restrict__ dctx, int64_t lddctx, void* __restrict__ dah,
                                                            float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
                                                            float* __restrict__ db_a, int A, int R, int dah_b16,
-                                                           float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride) {
+                                                           float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride,
+                                                           float* __restrict__ de_keep) {
+    // de_keep != NULL (then du == NULL): d(u) is deferred too -- this step only files its d(e) row (de_keep [S, n_stride]); after the time
+    // loop subgc_attn_du_accum forms d(u) from the kept d(e) and query rows of all steps.  Read-modify-writing all of d(u) at every step
+    // is the largest memory stream of this kernel when the sets are long (Full-GC: 36 rows x 512 x 8 bytes per sentence and step).
     // n_planes > 1: d(ctx) arrives as the split-K partial planes of the data-gradient GEMM (dctx + q * plane_stride), summed on load
     // dv == NULL: d(v) is deferred -- the caller keeps every step's d(ctx) rows (dctx_keep, written here by wave 0) and alpha
     // and calls subgc_attn_dv_accum once after the time loop instead of read-modify-writing all of d(v) at every step
@@ -191,7 +195,11 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
     float dot = 0.f;
     for (int i = 0; i < l; ++i) dot += al_s[i] * da_s[i];
     __syncthreads();
-    for (int i = t; i < l; i += 256) al_s[i] = al_s[i] * (da_s[i] - dot);     // de_i
+    for (int i = t; i < l; i += 256) {
+        const float de = al_s[i] * (da_s[i] - dot);                            // de_i
+        al_s[i] = de;
+        if (de_keep) de_keep[(int64_t)s * n_stride + i] = de;
+    }
     __syncthreads();
     if (t == 0 && db_a) {
         float desum = 0.f;
@@ -208,13 +216,16 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
             for (int i = grp; i < l; i += 2) {
                 const int64_t o = (int64_t)(m0 + i) * A + a4 * 4;
                 const float4 x = ldx<UV16>(u, o);
-                float4 d = ld4(du + o);
+                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (du) d = ld4(du + o);
                 const float de = al_s[i];
                 const float t0 = subgc_tanh(x.x + ha.x), t1 = subgc_tanh(x.y + ha.y), t2 = subgc_tanh(x.z + ha.z), t3 = subgc_tanh(x.w + ha.w);
                 const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
                 const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
-                d.x += p0; d.y += p1; d.z += p2; d.w += p3;
-                st4(du + o, d);
+                if (du) {
+                    d.x += p0; d.y += p1; d.z += p2; d.w += p3;
+                    st4(du + o, d);
+                }
                 dsum.x += p0; dsum.y += p1; dsum.z += p2; dsum.w += p3;
                 wsum.x += de * t0; wsum.y += de * t1; wsum.z += de * t2; wsum.w += de * t3;
             }
@@ -303,6 +314,59 @@ __global__ __launch_bounds__(256) void attn_dv_accum_kernel(const float* __restr
     }
 }
 
+// d(u) of ALL time steps in one pass (deferred form of attn_bwd's accumulation):
+//   du[m0 + i, a] = w_a[a] * sum over the steps t at which sentence s is live of de_t[s, i] * (1 - tanh^2(u[m0 + i, a] + ah_t[s, a]))
+// One workgroup per sentence; the live steps' query rows ah_t[s, :] and d(e) rows are staged in LDS `tg` steps at a time; thread
+// (a4 = t % 128 (+128 c), grp = t / 128) owns four hidden columns and every second node.  Each d(u) row is written once (per step
+// group) instead of read and written at every step; the price is one more tanh per (step, node, column) -- VALU work the chip has to spare.
+template <int CA, bool UV16>
+__global__ __launch_bounds__(256) void attn_du_accum_kernel(const void* __restrict__ u, const float* __restrict__ ah, const float* __restrict__ de,
+                                                            int n_stride, const int32_t* __restrict__ step_off, int T,
+                                                            const int32_t* __restrict__ off, const int32_t* __restrict__ len,
+                                                            const float* __restrict__ w_a, float* __restrict__ du, int A, int tg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char du_lds[];
+    const int s = blockIdx.x, t = threadIdx.x;
+    const int l = min(len[s], MAXLEN), m0 = off[s], A4 = A >> 2;
+    float4* h_s = reinterpret_cast<float4*>(du_lds);                      // [tg][A4]
+    float* e_s = reinterpret_cast<float*>(h_s + (size_t)tg * A4);         // [tg][n_stride]
+    bool first = true;
+    for (int t0 = 0; t0 < T; t0 += tg) {
+        __syncthreads();
+        int nl = 0;
+        for (int tt = t0; tt < min(T, t0 + tg); ++tt) {
+            const int o = step_off[tt], m = step_off[tt + 1] - o;
+            if (s >= m) continue;
+            const int64_t flat = (int64_t)o + s;
+            for (int c = t; c < A4; c += 256) h_s[(size_t)nl * A4 + c] = ld4(ah + flat * A + c * 4);
+            for (int i = t; i < l; i += 256) e_s[nl * n_stride + i] = de[flat * n_stride + i];
+            ++nl;
+        }
+        __syncthreads();
+        if (nl == 0 && !first) continue;
+#pragma unroll
+        for (int c = 0; c < CA; ++c) {
+            const int a4 = (t & 127) + c * 128, grp = t >> 7;
+            if (a4 >= A4) continue;
+            const float4 wa = ld4(w_a + a4 * 4);
+            for (int i = grp; i < l; i += 2) {
+                const int64_t o = (int64_t)(m0 + i) * A + a4 * 4;
+                const float4 x = ldx<UV16>(u, o);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < nl; ++k) {
+                    const float4 ha = h_s[(size_t)k * A4 + a4];
+                    const float e = e_s[k * n_stride + i];
+                    const float t0_ = subgc_tanh(x.x + ha.x), t1 = subgc_tanh(x.y + ha.y), t2 = subgc_tanh(x.z + ha.z), t3 = subgc_tanh(x.w + ha.w);
+                    acc.x += e * (1.f - t0_ * t0_); acc.y += e * (1.f - t1 * t1); acc.z += e * (1.f - t2 * t2); acc.w += e * (1.f - t3 * t3);
+                }
+                acc.x *= wa.x; acc.y *= wa.y; acc.z *= wa.z; acc.w *= wa.w;
+                if (!first) { const float4 p = ld4(du + o); acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+                st4(du + o, acc);
+            }
+        }
+        first = false;
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -335,7 +399,7 @@ int attn_fwd_vec(const void* u, const void* v, const float* ah, const float* w_a
 int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                  const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
                  float* db_a, int S, int A, int R, int dah_b16, int uv_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s, int n_planes,
-                 int64_t plane_stride) {
+                 int64_t plane_stride, float* de_keep) {
     if (A % 4 || R % 4 || lddctx % 4 || ldkeep % 4 || plane_stride % 4 || !al16(u) || !al16(v) || !al16(ah) || !al16(w_a) || !al16(dctx) || !al16(dah) || !al16(du) ||
         !al16(dv) || !al16(dw_a) || !al16(dctx_keep))
         return -100;
@@ -344,9 +408,9 @@ int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a
 #define SUBGC_ATT_BWD(CA_, CR_)                                                                                                          \
     do {                                                                                                                                   \
         if (uv_b16) hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, true>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
-                                       dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride); \
+                                       dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep); \
         else hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, false>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
-                                dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride);        \
+                                dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep); \
     } while (0)
     if (ca == 1) {
         if (cr <= 1) SUBGC_ATT_BWD(1, 1); else if (cr <= 2) SUBGC_ATT_BWD(1, 2); else if (cr <= 4) SUBGC_ATT_BWD(1, 4); else SUBGC_ATT_BWD(1, 8);
@@ -375,6 +439,27 @@ int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64
     if (cr <= 1) SUBGC_ATT_DV(1); else if (cr <= 2) SUBGC_ATT_DV(2); else if (cr <= 4) SUBGC_ATT_DV(4); else SUBGC_ATT_DV(8);
 #undef SUBGC_ATT_DV
     return check_launch("subgc_attn_dv_accum");
+}
+
+// -100 when the float4 form does not apply
+int attn_du_accum_vec(const void* u, int uv_b16, const float* ah, const float* de, int n_stride, const int32_t* step_off, int T, const int32_t* off,
+                      const int32_t* len, const float* w_a, float* du, int S, int A, hipStream_t s) {
+    if (A % 4 || !al16(u) || !al16(ah) || !al16(w_a) || !al16(du)) return -100;
+    const int ca = (A / 4 + 127) / 128;
+    if (ca > 2) return -100;
+    const size_t per_step = (size_t)A * 4 + (size_t)n_stride * 4;
+    const int tg = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, (size_t)(72 * 1024) / per_step));   // <= 72 KB: two workgroups per CU
+    const size_t lds = (size_t)tg * per_step;
+    if (lds > 150 * 1024) return -100;
+#define SUBGC_ATT_DU(CA_, B16_)                                                                                                            \
+    do {                                                                                                                                  \
+        if (int rc = raise_lds_cached((const void*)attn_du_accum_kernel<CA_, B16_>, lds, "attn_du_accum")) return rc;                       \
+        hipLaunchKernelGGL((attn_du_accum_kernel<CA_, B16_>), dim3(S), dim3(256), lds, s, u, ah, de, n_stride, step_off, T, off, len, w_a, du, A, tg); \
+    } while (0)
+    if (ca == 1) { if (uv_b16) SUBGC_ATT_DU(1, true); else SUBGC_ATT_DU(1, false); }
+    else { if (uv_b16) SUBGC_ATT_DU(2, true); else SUBGC_ATT_DU(2, false); }
+#undef SUBGC_ATT_DU
+    return check_launch("subgc_attn_du_accum");
 }
 
 }  // namespace subgc

@@ -70,7 +70,9 @@ int attn_fwd_vec(const void* u, const void* v, const float* ah, const float* w_a
 int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
                  const float* alpha, int n_stride, const float* dctx, int64_t lddctx, void* dah, float* du, float* dv, float* dw_a,
                  float* db_a, int S, int A, int R, int dah_b16, int uv_b16, float* dctx_keep, int64_t ldkeep, hipStream_t s, int n_planes = 1,
-                 int64_t plane_stride = 0);
+                 int64_t plane_stride = 0, float* de_keep = nullptr);
+int attn_du_accum_vec(const void* u, int uv_b16, const float* ah, const float* de, int n_stride, const int32_t* step_off, int T, const int32_t* off,
+                      const int32_t* len, const float* w_a, float* du, int S, int A, hipStream_t s);
 int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T, const int32_t* off,
                       const int32_t* len, float* dv, int S, int R, hipStream_t s);
 

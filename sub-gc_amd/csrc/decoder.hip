@@ -891,16 +891,17 @@ SUBGC_API int subgc_attn_fwd_q(const void* u, const void* v, const float* q_plan
 namespace {
 int attn_bwd_any(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len, const float* alpha,
                  int n_stride, const float* dctx, int64_t lddctx, int n_planes, int64_t plane_stride, void* dah, float* du, float* dv, float* dw_a,
-                 float* db_a, int S, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream) {
+                 float* db_a, int S, int A, int R, int bf16_bits, float* dctx_keep, int64_t ldkeep, void* stream, float* de_keep = nullptr) {
     const int dah_bf16 = bf16_bits & 1, uv_bf16 = (bf16_bits >> 1) & 1;      // bit 0: dah destination, bit 1: u and v are bf16
     SUBGC_REQUIRE(S >= 0 && A > 0 && R > 0 && n_stride > 0 && n_stride <= MAXLEN && n_planes >= 1, "attn_bwd: bad sizes");
     if (S == 0) return SUBGC_OK;
-    SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && du && dw_a, "attn_bwd: null pointer");
+    SUBGC_REQUIRE(u && v && ah && w_a && off && len && alpha && dctx && dah && dw_a, "attn_bwd: null pointer");
+    SUBGC_REQUIRE((du != nullptr) != (de_keep != nullptr), "attn_bwd: exactly one of du (accumulated per step) and de_keep (deferred: subgc_attn_du_accum)");
     SUBGC_REQUIRE(!dctx_keep || ldkeep >= R, "attn_bwd: dctx_keep rows too short");
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
     if (const int rc = subgc::attn_bwd_vec(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, S, A, R, dah_bf16,
-                                           uv_bf16, dctx_keep, ldkeep, s, n_planes, plane_stride);
+                                           uv_bf16, dctx_keep, ldkeep, s, n_planes, plane_stride, de_keep);
         rc != -100)
         return rc;
     subgc::set_error("attn_bwd: needs att_hid_size, rnn_size %% 4 == 0 (<= 1024 / <= 2048) and 16-byte aligned rows (A=%d R=%d)", A, R);
@@ -919,6 +920,27 @@ SUBGC_API int subgc_attn_bwd_planes(const void* u, const void* v, const float* a
                                     float* dctx_keep, int64_t ldkeep, void* stream) {
     return attn_bwd_any(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dctx_planes, plane_stride, dah, du, dv, dw_a, db_a, S, A, R, bf16_bits,
                         dctx_keep, ldkeep, stream);
+}
+
+// subgc_attn_bwd_planes with d(u) DEFERRED: the step files its d(e) row in de_keep [S, n_stride] instead of read-modify-writing d(u)
+SUBGC_API int subgc_attn_bwd_planes_de(const void* u, const void* v, const float* ah, const float* w_a, const int32_t* off, const int32_t* len,
+                                       const float* alpha, int n_stride, const float* dctx, int64_t lddctx, int dctx_planes, int64_t plane_stride,
+                                       void* dah, float* de_keep, float* dv, float* dw_a, float* db_a, int S, int A, int R, int bf16_bits,
+                                       float* dctx_keep, int64_t ldkeep, void* stream) {
+    return attn_bwd_any(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dctx_planes, plane_stride, dah, nullptr, dv, dw_a, db_a, S, A, R, bf16_bits,
+                        dctx_keep, ldkeep, stream, de_keep);
+}
+
+SUBGC_API int subgc_attn_du_accum(const void* u, int uv_bf16, const float* ah, const float* de, int n_stride, const int32_t* step_off, int T,
+                                  const int32_t* off, const int32_t* len, const float* w_a, float* du, int S, int A, void* stream) {
+    SUBGC_REQUIRE(S >= 0 && A > 0 && T >= 1 && n_stride > 0 && n_stride <= MAXLEN, "attn_du_accum: bad sizes");
+    if (S == 0) return SUBGC_OK;
+    SUBGC_REQUIRE(u && ah && de && step_off && off && len && w_a && du, "attn_du_accum: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    subgc::ProfScope prof(SUBGC_FAM_ATTN, s, 0.0);
+    const int rc = subgc::attn_du_accum_vec(u, uv_bf16, ah, de, n_stride, step_off, T, off, len, w_a, du, S, A, s);
+    SUBGC_REQUIRE(rc != -100, "attn_du_accum: needs A %% 4 == 0, A <= 1024 and 16-byte aligned rows");
+    return rc;
 }
 
 SUBGC_API int subgc_attn_dv_accum(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T,

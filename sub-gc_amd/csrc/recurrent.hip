@@ -115,9 +115,10 @@ int check_bwd(const SubgcRecurrence* a) {
     if (int rc = check_common(a, "recurrence_bwd")) return rc;
     if (a->T == 0) return SUBGC_OK;
     SUBGC_REQUIRE(a->Wc1 && a->Wc2 && a->Wq && a->C1 && a->C2 && a->G1 && a->G2 && a->AH && a->AL && a->u && a->v && a->w_a && a->lens && a->dHout &&
-                      a->dhout_off && a->dP1 && a->dP2 && a->dAH && a->du && a->dWa && a->dBa && a->PA && a->PB && a->PC && a->dC1_in && a->dC1_out &&
-                      a->dC2_in && a->dC2_out,
+                      a->dhout_off && a->dP1 && a->dP2 && a->dAH && (a->du || a->dE) && a->dWa && a->dBa && a->PA && a->PB && a->PC && a->dC1_in &&
+                      a->dC1_out && a->dC2_in && a->dC2_out,
                   "recurrence_bwd: null pointer");
+    SUBGC_REQUIRE(!a->dE || !a->shared, "recurrence_bwd: deferred d(u) (dE) is the per-sentence form");
     SUBGC_REQUIRE(a->dv || a->dCtx, "recurrence_bwd: either dv (accumulated per step) or dCtx (kept for one dv_accum pass)");
     SUBGC_REQUIRE(!a->shared || !a->dv, "recurrence_bwd: shared attention sets always defer d(v)");
     return SUBGC_OK;
@@ -172,8 +173,11 @@ int bwd_step(const SubgcRecurrence* a, BwdState& st, int t, void* stream) {
     rc = a->shared ? subgc_attn_bwd_group(a->u, a->v, a->AH + o * A, a->w_a, a->rows_map, a->lens, m, a->B, a->g, a->Nn, a->AL + o * a->n_alpha,
                                           a->n_alpha, st.sA.p, st.sA.ld, dAHt, a->du, a->dWa + o * A, a->dBa + o, A, R, dbits, keep, R, st.sA.n, st.sA.stride,
                                           a->du_planes, a->du_plane_stride, stream)
-                   : subgc_attn_bwd_planes(a->u, a->v, a->AH + o * A, a->w_a, a->off, a->lens, a->AL + o * a->n_alpha, a->n_alpha, st.sA.p, st.sA.ld, st.sA.n,
-                                           st.sA.stride, dAHt, a->du, a->dv, a->dWa + o * A, a->dBa + o, m, A, R, dbits, keep, R, stream);
+                   : a->dE ? subgc_attn_bwd_planes_de(a->u, a->v, a->AH + o * A, a->w_a, a->off, a->lens, a->AL + o * a->n_alpha, a->n_alpha, st.sA.p, st.sA.ld,
+                                                      st.sA.n, st.sA.stride, dAHt, a->dE + o * a->n_alpha, a->dv, a->dWa + o * A, a->dBa + o, m, A, R, dbits,
+                                                      keep, R, stream)
+                           : subgc_attn_bwd_planes(a->u, a->v, a->AH + o * A, a->w_a, a->off, a->lens, a->AL + o * a->n_alpha, a->n_alpha, st.sA.p, st.sA.ld,
+                                                   st.sA.n, st.sA.stride, dAHt, a->du, a->dv, a->dWa + o * A, a->dBa + o, m, A, R, dbits, keep, R, stream);
     if (rc != SUBGC_OK) return rc;
     int nb = 0;
     rc = planes(dAHt, A, A, a->Wq, a->ldWq, R, m, a->PB, a->pb_bytes, &nb);                      // h1_t also feeds the attention query

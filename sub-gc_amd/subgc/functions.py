@@ -628,6 +628,7 @@ class MaskedNLLFn(Function):
 
 # ------------------------------------------------------------------------------- decoder
 DIRECT_GRADS = True               # accumulate parameter gradients straight into existing .grad buffers
+DEFER_DU = True                   # per-sentence attention sets: d(u) formed once after the BPTT loop (subgc_attn_du_accum) instead of read-modify-written per step
 FOLD_BIAS_SUMS = True             # a layer's bias gradient rides its weight-gradient product (ops.wgrad); False: separate column-sum launches
 on_grads_ready = None             # callback(stage) set by parallel.GradBucketReducer: the gradient slice `stage` ("logit", "recurrent",
                                   # "prepare"; AttModel.grad_buckets) is final and may be all-reduced while the backward goes on
@@ -746,11 +747,16 @@ class Prepared:
     def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R, q=None):
         ops.attn_fwd(self.u, self.v, ah, w_a, b_a, self.off, lens, ctx, alpha, m, A, R, q=q)
 
-    def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep):
-        ops.attn_bwd(self.u, self.v, ah, w_a, self.off, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep=dctx_keep)
+    def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep, de_keep=None):
+        ops.attn_bwd(self.u, self.v, ah, w_a, self.off, lens, alpha, dctx, dah, None if de_keep is not None else du, dv, dwa, dba, m, A, R,
+                     dctx_keep=dctx_keep, de_keep=de_keep)
 
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum(alpha, dctx, step_off, T, self.off, lens, dv, S, R)
+
+    def du_accum(self, ah, de, step_off, T, lens, w_a, du, S, A):
+        """deferred d(u): one pass over the kept d(e) / query rows of all steps (subgc_attn_du_accum), every d(u) row written once"""
+        ops.attn_du_accum(self.u, ah, de, step_off, T, self.off, lens, w_a, du, S, A)
 
     def recur_fields(self, r0=0):
         """The attention-set fields of ops.Recurrence (per-sentence sets); r0: first sentence row of the chain the block is for."""
@@ -813,9 +819,9 @@ class PreparedShared(Prepared):
     def attn_fwd(self, ah, w_a, b_a, lens, ctx, alpha, m, A, R, q=None):
         ops.attn_fwd_group(self.u, self.v, ah, w_a, b_a, self.rows, lens, m, self.B, self.g, self.N, ctx, alpha, A, R, q=q)
 
-    def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep):
-        if dv is not None:
-            raise ops.SubgcError("shared attention sets: d(v) is always deferred to dv_accum")
+    def attn_bwd(self, ah, w_a, lens, alpha, dctx, dah, du, dv, dwa, dba, m, A, R, dctx_keep, de_keep=None):
+        if dv is not None or de_keep is not None:
+            raise ops.SubgcError("shared attention sets: d(v) is always deferred to dv_accum, d(u) never")
         ops.attn_bwd_group(self.u, self.v, ah, w_a, self.rows, lens, m, self.B, self.g, self.N, alpha, dctx, dah, du, dwa, dba, A, R, dctx_keep)
 
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
@@ -1077,7 +1083,10 @@ class DecoderFn(Function):
         # d(v) = sum_t alpha_t^T d(ctx_t) is formed ONCE after the loop from the kept d(ctx) rows (subgc_attn_dv_accum) instead of
         # being read and written at every step: on Full-GC (36 nodes per sentence) that was 380 of a step's 830 MB
         defer_dv = pr.shared or (R % 4 == 0 and A % 4 == 0 and A <= 1024 and R <= 2048 and T > 0)      # the float4 forms' limits
-        du = pr.new_du(A)
+        # d(u) deferred the same way (per-sentence sets): the steps file their d(e) rows, one pass after the loop writes every d(u) row once
+        defer_du = DEFER_DU and not pr.shared and defer_dv and A % 4 == 0 and A <= 1024 and T > 0
+        dE = new(T, S, AL.size(2)) if defer_du else None
+        du = new(pr.u.size(0), A) if defer_du else pr.new_du(A)
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(T, S, R) if defer_dv else None
         dWa, dBa = new(T, S, A), new(T, S)                     # per-(step, sentence) partials of alpha_net's gradient
@@ -1097,7 +1106,7 @@ class DecoderFn(Function):
                                  Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]), C1=C1, C2=C2, G1=G1, G2=G2,
                                  AH=AH, AL=AL, k_out=k_out, w_a=an_w, lens=lens, dHout=dHout, dP1=dP1, dP2=dP2, dAH=dAH, du=du,
                                  du_planes=du.size(0) if du.dim() == 3 else 1, du_plane_stride=du.stride(0) if du.dim() == 3 else 0,
-                                 dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, PA=PA, pa_bytes=PA.numel() * 4,
+                                 dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, dE=dE, PA=PA, pa_bytes=PA.numel() * 4,
                                  PB=PB, pb_bytes=PB.numel() * 4, PC=PC, pc_bytes=PC.numel() * 4, dC1_in=dC1[0], dC1_out=dC1[1], dC2_in=dC2[0],
                                  dC2_out=dC2[1], **pr.recur_fields())
             ops.recurrence_bwd(rec)
@@ -1110,7 +1119,7 @@ class DecoderFn(Function):
             n, st = ops.gemm_planes(dP2[t], Wc2, PA)                       # -> [dctx | dh1 | dh2_prev]
             sA = (PA, 3 * R, n, st, S)
             pr.attn_bwd(AH[t], an_w, lens, AL[t], win(sA, 0), dAH[t], du, None if defer_dv else dv, dWa[t], dBa[t], S, A, R,
-                        dCtx[t] if defer_dv else None)
+                        dCtx[t] if defer_dv else None, **({"de_keep": dE[t]} if defer_du else {}))
             n, st = ops.gemm_planes(dAH[t], W[17], PB)                     # h1 also feeds the attention query
             ops.lstm_bwd_planes(G1[t], C1[t], C1[t + 1], [win(sA, R), (PB, R, 0, n, st, S), win(sC, R)], None, None, 1.0, nC1, dP1[t], cC1, S, R)
             n, st = ops.gemm_planes(dP1[t], Wc1, PC)                       # -> [dh2_prev | dh1_prev]
@@ -1120,6 +1129,8 @@ class DecoderFn(Function):
 
         if defer_dv:
             pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), _step_offsets(T, S, dev), T, lens, dv, S, R)
+        if defer_du:
+            pr.du_accum(AH[:T].view(T * S, A), dE.view(T * S, dE.size(2)), _step_offsets(T, S, dev), T, lens, an_w, du, S, A)
             del dCtx
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
         H1a, H2a = ops.flat_rows(H1[:T]), ops.flat_rows(H2[:T])

@@ -320,7 +320,9 @@ class PackedDecoderLossFn(Function):
         dP1, dP2, dAH = act(max(rows, 1), 4 * R), act(max(rows, 1), 4 * R), act(max(rows, 1), A)
         # d(v) is formed once after the loop from the kept d(ctx) rows (see DecoderFn.backward)
         defer_dv = pr.shared or (R % 4 == 0 and A % 4 == 0 and A <= 1024 and R <= 2048 and T_live > 0)      # the float4 forms' limits
-        du = pr.new_du(A)
+        defer_du = F_.DEFER_DU and not pr.shared and defer_dv and T_live > 0      # see DecoderFn.backward
+        dE = new(max(rows, 1), AL.size(1)) if defer_du else None
+        du = new(pr.u.size(0), A) if defer_du else pr.new_du(A)
         dv = new(pr.v.size(0), R) if defer_dv else zer(pr.v.size(0), R)
         dCtx = new(max(rows, 1), R) if defer_dv else None
         dWa, dBa = new(max(rows, 1), A), new(max(rows, 1))     # per-(step, sentence) partials of alpha_net's gradient
@@ -346,7 +348,7 @@ class PackedDecoderLossFn(Function):
                                       Wq=W[17], ldWq=ops.ld(W[17]), C1=C1[:, r0:], C2=C2[:, r0:], G1=G1, G2=G2, AH=AH, AL=AL,
                                       k_out=None if k_out is None else k_out[:, r0:], w_a=an_w, lens=lens_p[r0:], dHout=dHout, dP1=dP1, dP2=dP2,
                                       dAH=dAH, du=du, du_planes=du.size(0) if du.dim() == 3 else 1, du_plane_stride=du.stride(0) if du.dim() == 3 else 0,
-                                      dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, PA=PA_, pa_bytes=PA_.numel() * 4,
+                                      dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, dE=dE, PA=PA_, pa_bytes=PA_.numel() * 4,
                                       PB=PB_, pb_bytes=PB_.numel() * 4, PC=PC_, pc_bytes=PC_.numel() * 4, dC1_in=c1[0][r0:], dC1_out=c1[1][r0:],
                                       dC2_in=c2[0][r0:], dC2_out=c2[1][r0:], **pr.recur_fields(r0))
             h_cut = getattr(ctx, "h_cut", 0) if ops.RECURRENCE_CHAINS >= 2 else 0
@@ -369,7 +371,7 @@ class PackedDecoderLossFn(Function):
             n, st = ops.gemm_planes(dP2[o:o + m], Wc2, PA)
             sA = (PA, 3 * R, n, st, m)
             pr.attn_bwd(AH[o:o + m], an_w, lens_p, AL[o:o + m], win(sA, 0), dAH[o:o + m], du, None if defer_dv else dv,
-                        dWa[o:o + m], dBa[o:o + m], m, A, R, dCtx[o:o + m] if defer_dv else None)
+                        dWa[o:o + m], dBa[o:o + m], m, A, R, dCtx[o:o + m] if defer_dv else None, **({"de_keep": dE[o:o + m]} if defer_du else {}))
             n, st = ops.gemm_planes(dAH[o:o + m], W[17], PB)
             ops.lstm_bwd_planes(G1[o:o + m], C1[t][:m], C1[t + 1][:m], [win(sA, R), (PB, R, 0, n, st, m), win(sC, R)], None, None, 1.0, nC1[:m],
                                 dP1[o:o + m], cC1[:m], m, R)
@@ -386,6 +388,8 @@ class PackedDecoderLossFn(Function):
         if defer_dv:
             pr.dv_accum(AL, dCtx, step_off, max(T_live, 1), lens_p, dv, S, R)
             del dCtx
+        if defer_du:
+            pr.du_accum(AH, dE, step_off, max(T_live, 1), lens_p, an_w, du, S, A)
         dGf = new(S, 4 * R)                                     # d(fc->gates) = sum over each sentence's live steps of dP1: one launch
         ops.packed_time_sum(dP1, step_off, T_live, S, dGf)
         dGf = opnd(dGf)

@@ -1273,11 +1273,19 @@ def _dctx_args(dctx):
     return _ptr(dctx, torch.float32), ld(dctx), 1, 0
 
 
-def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R, dctx_keep=None):
+def attn_bwd(u, v, ah, w_a, off, lens, alpha, dctx, dah, du, dv, dw_a, db_a, S, A, R, dctx_keep=None, de_keep=None):
     """dv None: d(v) is deferred to one `attn_dv_accum` after the time loop; `dctx_keep` [S, R] then receives this step's d(ctx) rows.
+    `de_keep` [S, n] (then du is not touched): d(u) is deferred likewise to one `attn_du_accum`.
     `dctx`: a 2-D view or a plane-stack window (see _dctx_args): the split-K planes of the data-gradient GEMM are summed on load."""
     _attn_account(lens, S, A, R, 3 if dv is not None else 2)      # read u, v; read-modify-write du (and dv)
     dp, dl, dn, ds = _dctx_args(dctx)
+    if de_keep is not None:
+        if de_keep.stride(0) != alpha.size(1) or alpha.stride(0) != alpha.size(1):
+            raise SubgcError("attn_bwd: de_keep rows must have alpha's pitch")
+        call("subgc_attn_bwd_planes_de", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
+             alpha.size(1), dp, dl, dn, ds, _ptr(dah), _ptr(de_keep, torch.float32), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R,
+             int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
+        return
     call("subgc_attn_bwd_planes", _ptr(u), _ptr(v), _ptr(ah), _ptr(w_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(alpha),
          alpha.size(1), dp, dl, dn, ds, _ptr(dah), _ptr(du), _ptr(dv), _ptr(dw_a), _ptr(db_a), S, A, R,
          int(is_b16(dah)) | (_uv_b16(u, v, A, R) << 1), _ptr(dctx_keep, torch.float32), ld(dctx_keep) if dctx_keep is not None else 0, _stream())
@@ -1288,6 +1296,13 @@ def attn_dv_accum(alpha, dctx, step_off, T, off, lens, dv, S, R):
     rows step_off[t] .. step_off[t+1]-1; dv [sum lens, R] is overwritten."""
     call("subgc_attn_dv_accum", _ptr(alpha, torch.float32), alpha.size(1), _ptr(dctx, torch.float32), ld(dctx), _ptr(step_off, torch.int32), int(T),
          _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(dv, torch.float32), S, R, _stream())
+
+
+def attn_du_accum(u, ah, de, step_off, T, off, lens, w_a, du, S, A):
+    """d(u) of all time steps in one pass (subgc_attn_du_accum): ah [rows, A] (the query rows the forward saved), de [rows, n] hold step
+    t's live sentences as rows step_off[t] .. step_off[t+1]-1; du [sum lens, A] is overwritten."""
+    call("subgc_attn_du_accum", _ptr(u), int(is_b16(u)), _ptr(ah, torch.float32), _ptr(de, torch.float32), de.size(1), _ptr(step_off, torch.int32), int(T),
+         _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(w_a, torch.float32), _ptr(du, torch.float32), S, A, _stream())
 
 
 def attn_fwd_group(u, v, ah, w_a, b_a, rows, lens, m, B, g, Nn, ctx, alpha, A, R, q=None):

@@ -249,3 +249,55 @@ def test_two_chain_recurrence_equals_the_single_chain(kind):
         assert float((a @ b) / (a.norm() * b.norm())) > 0.9995
     else:
         np.testing.assert_allclose(g2.cpu().numpy(), g0.cpu().numpy(), atol=2e-5 * scale + 1e-9, rtol=2e-4)
+
+
+@pytest.mark.parametrize("kind", ["subgc_f32", "subgc_bf16", "fullgc_f32_dropout", "fullgc_bf16_dropout"])
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("in_c", [True, False])
+def test_deferred_du_equals_the_per_step_accumulation(kind, packed, in_c):
+    """functions.DEFER_DU (subgc_attn_bwd_planes_de + one subgc_attn_du_accum after the BPTT loop) against d(u) read-modify-written at
+    every step: the same sums in a different order -- loss identical, every gradient equal to fp32 rounding (ctx2att / att_embed and
+    everything upstream of them are what d(u) feeds).  Per-sentence sets only (Sub-GC, and Full-GC under dropout = replicated rows)."""
+    from subgc import ops
+    from subgc import functions as F_
+    torch.manual_seed(0)
+    opt = dict(OPT)
+    if kind.startswith("fullgc"):
+        opt.update(use_gpn=0, noun_fuse=0, pred_emb_type=2, gcn_layers=4, gcn_residual=1, gcn_bn=1)
+    if "bf16" in kind:
+        opt.update(compute_dtype="bf16")
+    if "dropout" in kind:
+        opt.update(drop_prob_lm=0.5)
+    m = models.setup(argparse.Namespace(**opt)).to(DEV).train()
+    batch = synthetic.make_train_batch(6, D=256, vocab=300, n_obj_cls=60, seed=9, fc_size=256, min_len=1, max_len=16)
+    res = {}
+    for defer in (False, True):
+        F_.DEFER_DU, ops.RECURRENCE_IN_C = defer, in_c
+        try:
+            m._dropout_calls = 0
+            res[defer] = grads_of(m, batch, packed) if m.gpn else _grads_fullgc(m, batch, packed)
+        finally:
+            F_.DEFER_DU, ops.RECURRENCE_IN_C = True, True
+    (l0, g0), (l1, g1) = res[False], res[True]
+    assert l0 == l1
+    scale = float(g0.abs().max())
+    if "bf16" in kind:
+        a, b = g1.double(), g0.double()
+        assert float((a @ b) / (a.norm() * b.norm())) > 0.9999
+        np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=2e-3 * scale)
+    else:
+        np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=2e-6 * scale + 1e-9, rtol=1e-4)
+    lo, hi = next((lo, hi) for st, lo, hi in m.grad_buckets() if st == "prepare")
+    assert float(g1[lo:hi].abs().max()) > 0                                # ctx2att / att_embed gradients are there at all
+
+
+def _grads_fullgc(model, batch, packed):
+    model.packed_decoder = packed
+    lw = models.LossWrapper(model, None)
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    model.flatten_grads()
+    out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
+             None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+    out["lang_loss"].backward()
+    torch.cuda.synchronize()
+    return float(out["lang_loss"]), model.flat_grads.clone()
