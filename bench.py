@@ -507,6 +507,8 @@ def main():
                     "plan runs on a side stream instead of queueing behind the previous step (measured: no gain, round 5)")
     ap.add_argument("--dedup", type=int, default=-1, help="experiment (Full-GC): opt.dedup_att_embed (1 = att_embed once per node row + masked gather per copy, 0 = on the replicated rows)")
     ap.add_argument("--chains", type=int, default=-1, help="experiment: ops.RECURRENCE_CHAINS (2 = the recurrence as two interleaved chains on two streams, 0 = one chain)")
+    ap.add_argument("--fuse-mid", type=int, default=-1, help="experiment: ops.FUSE_MID (1 = cell 1 + query product + attention of a decoder step as one launch per direction, "
+                    "3 = one workgroup per CU, 0 = the three launches)")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -536,6 +538,8 @@ def main():
     model.inputs_resident = bool(a.plan_side_stream)
     if a.chains >= 0:
         ops.RECURRENCE_CHAINS = a.chains
+    if a.fuse_mid >= 0:
+        ops.FUSE_MID = a.fuse_mid
     if a.no_pair_launches:
         ops.PAIR_LAUNCHES = False
     if a.fork_wgrads:

@@ -57,6 +57,7 @@ const char* subgc_arch(void);
 #define SUBGC_FAM_GCN 4
 #define SUBGC_FAM_POOL 5
 #define SUBGC_FAM_SOFTMAX 6
+#define SUBGC_FAM_MID 7       /* the fused row-local middle of a train-decoder step: subgc_mid_fwd / subgc_mid_bwd (work = the query product's flops) */
 int subgc_prof_enable(int family, int on);
 int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* total_work);
 /* busy_ms of the LAST subgc_prof_collect(family): the length of the union of the launches' [start, stop] intervals (events of all
@@ -698,6 +699,8 @@ int subgc_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, i
                         const int32_t* m_dev, void* stream);
 /* y[c, r] = bf16(x[r, c]) (the W^T snapshots: every data-gradient product becomes an x W^T one) */
 int subgc_transpose_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, void* stream);
+/* y[c, r] = x[r, c], fp32 (the K-major copy of the h2att weight that subgc_mid_fwd streams under fp32 operands) */
+int subgc_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, void* stream);
 int subgc_copy2d_b16(const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, void* stream);
 
 /* ---- on-device batch assembly (dataloaders/dataloader.py:269-367) ----------------------------------------
@@ -792,6 +795,24 @@ int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, cons
 int subgc_clip_adam_step_zero(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
                               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                               int step, float grad_scale, uint16_t* p_bf16, void* stream);
+
+/* ---- the row-local middle of a train-decoder step as one launch (csrc/recurrent_mid.hip) ----------------------------------------------
+ * replaces, per step: subgc_lstm_fwd (attention LSTM cell, AttModel.py:411-413) + the h2att product (:453) + subgc_attn_fwd_q (:453-466).
+ * Between the two gate products of a step everything is local to a sentence row, so a workgroup that owns a few rows runs cell update,
+ * query product (matrix pipe, Wq streamed from L2) and attention back to back with the rows' h1 / query / scores in LDS.
+ * Cell arguments as subgc_lstm_fwd (g0 = `parts` pre-activation planes `plane_stride` floats apart, e.g. the split-K planes of the gate
+ * product; g1 / g2 / b0 / b1 additive terms; h, h2 destinations with row limits; gates = the saved activated gates), query arguments
+ * Wq = the h2att weight as the product streams it: bf16 operands -> [A, R] (rows K-contiguous, matrix pipe), fp32 operands -> its
+ * TRANSPOSE [R, A] (K-major, VALU form: subgc_transpose_f32); bq [A], q_out [m, A] (the summed query rows, read by the backward),
+ * attention arguments as subgc_attn_fwd.  fp32 operands: m <= 1024.
+ * bf16_bits: bit 0 = h / h2 / ctx destinations and Wq are bf16, bit 1 = u and v are bf16 (both or neither).  flags: bit 0 = one
+ * workgroup per CU (LDS request above half a CU).  debug_stamps (NULL in
+ * production): [workgroups][8] int64 wall-clock stamps at the phase boundaries (tools/mid_probe.py).  Needs R % 8 == 0, A % 4 == 0, A <= 512, m <= 4096, 16-byte aligned rows.        */
+int subgc_mid_fwd(const float* g0, int64_t ld0, int parts, int64_t plane_stride, const float* g1, int64_t ld1, const float* g2, int64_t ld2,
+                  const float* b0, const float* b1, const float* c_prev, float* c, void* h, int64_t ldh, int rows_h, void* h2, int64_t ldh2,
+                  int rows_h2, float* gates, const void* Wq, int64_t ldWq, const float* bq, float* q_out, const void* u, const void* v,
+                  const float* w_a, const float* b_a, const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha,
+                  int n_stride, int m, int R, int A, int bf16_bits, int flags, int64_t* debug_stamps, void* stream);
 
 /* ======================================================================================
  * The teacher-forced recurrence as ONE call per direction (AttModel.py:157-175: the T-step loop around TopDownCore, :400-431).
@@ -888,6 +909,11 @@ typedef struct SubgcRecurrence {
     float* dC1_out;
     float* dC2_in;
     float* dC2_out;
+    int32_t fuse_mid;            /* bit 0: cell 1 + query product + attention (and their backward) as ONE launch per step and direction (subgc_mid_fwd /
+                                    subgc_mid_bwd; per-sentence attention sets only -- shared sets keep the three launches); bit 1: one workgroup per CU */
+    int32_t pad_;
+    const void* WqT;             /* fuse_mid backward: the transposed query weight [R, A] (K-contiguous for d(h1) += d(query) Wq), stored like Wq */
+    int64_t ldWqT;
 } SubgcRecurrence;
 int subgc_recurrence_sizeof(void);      /* sizeof(SubgcRecurrence): bindings that mirror the struct check their layout against it */
 /* forward: steps 0 .. T-1 in order.  workspace / ws_bytes: the split-K scratch of the cell products (as subgc_lstm_fwd_gemm). */

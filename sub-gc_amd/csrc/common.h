@@ -76,6 +76,13 @@ int attn_du_accum_vec(const void* u, int uv_b16, const float* ah, const float* d
 int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T, const int32_t* off,
                       const int32_t* len, float* dv, int S, int R, hipStream_t s);
 
+// recurrent_mid.hip: cell 1 + query product + attention of a step's rows in one launch (and its backward); -100 = shape not covered
+int mid_fwd(const float* g0, int64_t ld0, int parts, int64_t plane, const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0,
+            const float* b1, const float* c_prev, float* c, void* h, int64_t ldh, int rows_h, void* h2, int64_t ldh2, int rows_h2, float* gates,
+            const void* Wq, int64_t ldw, const float* bq, float* q_out, const void* u, const void* v, const float* w_a, const float* b_a,
+            const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int m, int R, int A, int b16, int uv16,
+            int flags, hipStream_t s, long long* stamps = nullptr);
+
 }  // namespace subgc
 
 // query chunk (four columns at `idx` = row * A + column) of a QSrc: planes summed in order, bias last

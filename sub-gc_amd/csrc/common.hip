@@ -41,7 +41,7 @@ int raise_lds_cached(const void* kernel, size_t bytes, const char* what) {
 }
 
 namespace {
-constexpr int kFamilies = 8;
+constexpr int kFamilies = 8;      // families 1 .. 7 (SUBGC_FAM_*)
 struct Rec {
     hipEvent_t a, b;
     double work;

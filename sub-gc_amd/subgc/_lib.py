@@ -111,7 +111,7 @@ def call(name, *args):
         raise SubgcError(f"{name} failed with code {rc}: {lib().subgc_last_error().decode()}")
 
 
-FAM = {"gemm": 1, "attn": 2, "lstm": 3, "gcn": 4, "pool": 5, "softmax": 6}
+FAM = {"gemm": 1, "attn": 2, "lstm": 3, "gcn": 4, "pool": 5, "softmax": 6, "mid": 7}
 
 
 def prof_enable(family, on=True):

@@ -760,7 +760,7 @@ class Prepared:
 
     def recur_fields(self, r0=0):
         """The attention-set fields of ops.Recurrence (per-sentence sets); r0: first sentence row of the chain the block is for."""
-        return dict(shared=0, u=self.u, v=self.v, off=self.off[r0:], uv_b16=int(ops.is_b16(self.u)))
+        return dict(shared=0, u=self.u, v=self.v, off=self.off[r0:], uv_b16=int(ops.is_b16(self.u)), fuse_mid=int(ops.FUSE_MID))
 
     def new_du(self, A):
         """Zeroed accumulator of d(u) for the backward's time loop."""
@@ -856,6 +856,19 @@ def make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale
     if rows is None:
         rows = sh["rows"]
     return PreparedShared(fc_in, X_nodes, lens, rows, sh["B"], sh["g"], N, P, k_fc, k_att, scale, W)
+
+
+def fused_mid_weights(pr, wq, bf, forward):
+    """SubgcRecurrence fields of the fused middle (ops.FUSE_MID, csrc/recurrent_mid.hip): the TRANSPOSED h2att weight `WqT` [R, A] for the
+    direction that streams it -- fp32 operands: the forward's K-major form; bf16 operands: the backward's K-contiguous rows of
+    d(h1) += d(query) Wq.  `wq`: the fp32 master [A, R].  One 1-2 MB transpose per forward / backward call."""
+    if not (ops.FUSE_MID & 1) or pr.shared or bool(bf) == bool(forward):
+        return {}
+    if bf:
+        wt = ops.transpose_bf16(wq, out=ops.empty_b16(wq.size(1), wq.size(0), wq.device))
+    else:
+        wt = ops.transpose_f32(wq)
+    return dict(WqT=wt, ldWqT=ops.ld(wt))
 
 
 def _cat_weights(w_ih_part, w_hh):
@@ -963,7 +976,7 @@ class DecoderFn(Function):
                                  H1=H1, ldH1=H1.stride(1), H2=H2, ldH2=H2.stride(1), Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2),
                                  Wq=W[17], ldWq=ops.ld(W[17]), b1i=b1i, b1h=b1h, b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre, Gx=Gx, Gf=Gf, C1=C1, C2=C2,
                                  G1=G1, G2=G2, AH=AH, AL=AL, k_out=k_out, QP=QP, qp_bytes=QP.numel() * 4, w_a=an_w, b_a=an_b, lens=lens,
-                                 **pr.recur_fields())
+                                 **pr.recur_fields(), **fused_mid_weights(pr, h2a_w, bf, True))
             ops.recurrence_fwd(rec, H1)
         for t in range(T if rec is None else 0):
             if ss is not None:

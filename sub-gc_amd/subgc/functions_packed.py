@@ -199,7 +199,7 @@ class PackedDecoderLossFn(Function):
                                       ldH2=ops.ld(H2), Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]),
                                       b1i=b1i, b1h=b1h, b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre[r0:], Gx=Gx, Gf=Gf[r0:], C1=C1[:, r0:], C2=C2[:, r0:],
                                       G1=G1, G2=G2, AH=AH, AL=AL, k_out=None if k_out is None else k_out[:, r0:], QP=QPc, qp_bytes=QPc.numel() * 4,
-                                      w_a=an_w, b_a=an_b, lens=lens_p[r0:], **pr.recur_fields(r0))
+                                      w_a=an_w, b_a=an_b, lens=lens_p[r0:], **pr.recur_fields(r0), **F_.fused_mid_weights(pr, h2a_w, bf, True))
             h_cut = 0 if pr.shared else ops.chain_cut(M[:T_live])
             if h_cut:
                 # two chains (ops.RECURRENCE_CHAINS): rows [0, h) and [h, m[t]) of every step as independent recurrences on two streams

@@ -271,6 +271,15 @@ def transpose_bf16(x, out=None):
     return out
 
 
+def transpose_f32(x, out=None):
+    """out[c, r] = x[r, c], fp32 (subgc_transpose_f32)."""
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, rows, device=x.device, dtype=torch.float32)
+    call("subgc_transpose_f32", _ptr(x, torch.float32), ld(x), _ptr(out, torch.float32), ld(out), rows, cols, _stream())
+    return out
+
+
 def _ptr(t, dtype=None):
     if t is None:
         return None
@@ -1021,6 +1030,33 @@ def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdro
          _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c), _ptr(h), L(h), _ptr(h2), L(h2),
          _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h), int(rows_h2),
          xb | (_same_storage(h, h2, hdrop) << 1), GEMM_MODES[gemm_mode.current], *_ws(x), None if event is None else event.cuda_event, _stream())
+
+
+# The row-local middle of a train-decoder step -- attention-LSTM cell update, h2att query product, attention -- as ONE launch per step
+# (csrc/recurrent_mid.hip; SubgcRecurrence.fuse_mid).  Bit 0: on (per-sentence attention sets, forward), bit 1: one workgroup per CU.
+# OPT-IN (bench.py --fuse-mid 1): built for round 4's review (item 1: fuse the recurrence's cell / attention work into fewer launches),
+# correct (tests/test_mid_gpu.py, test_packed_gpu.py), and SLOWER than the three launches it replaces -- measured with in-kernel stamps
+# (tools/mid_probe.py, profiles/r05_mid_probe.txt): Kar 640 rows 57 us against 42-46, Full_GC_Kar 1280 rows 97 against 75-79, Flickr 47
+# against 43-47.  Why: (1) the cell phase is bound by the CHIP's memory bandwidth (159 MB of planes / gate terms per step: 28 us fused or
+# not); (2) every workgroup has to stream the whole query weight (1 MB bf16 / 2 MB fp32) for its 3-5 rows: 256 CUs reading the same
+# megabytes saturate the L2s at ~13 TB/s aggregate = 20 us (bf16) / 33 us (fp32), against 15 / 19 us for the chip-wide split-K product;
+# (3) a workgroup alone on its CU walks its phases serially, so the attention part (25 + 5 + 11 us on Full-GC) is no faster than the
+# 1280-workgroup launch (36 us).  DESIGN 8.
+FUSE_MID = 0
+
+
+def mid_fwd(g0, parts, plane, g1, g2, b0, b1, c_prev, c, h, h2, gates, wq, bq, q_out, u, v, w_a, b_a, off, lens, ctx, alpha, m, R, A,
+            rows_h=0, rows_h2=0, flags=0, stamps=None):
+    """subgc_mid_fwd: lstm_fwd (g0 = `parts` planes `plane` floats apart) + q = h wq^T + bq (-> q_out) + attn_fwd in one launch."""
+    L = lambda t: ld(t) if t is not None else 0
+    if FLOPS["on"]:
+        FLOPS["gemm"] += 2.0 * m * A * R
+        FLOPS["gemm_bytes"] += (2.0 if is_b16(wq) else 4.0) * (m * R + A * R) + 4.0 * m * A
+    call("subgc_mid_fwd", _ptr(g0, torch.float32), ld(g0), int(parts), int(plane), _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev),
+         _ptr(c), _ptr(h), ld(h), int(rows_h), _ptr(h2), L(h2), int(rows_h2), _ptr(gates), _ptr(wq), ld(wq), _ptr(bq, torch.float32),
+         _ptr(q_out, torch.float32), _ptr(u), _ptr(v), _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(ctx), ld(ctx),
+         _ptr(alpha), alpha.size(1) if alpha is not None else 0, int(m), int(R), int(A), int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), int(flags),
+         _ptr(stamps, torch.int64), _stream())
 
 
 def gemm_planes(a, b, planes, *, ta=False, tb=False):

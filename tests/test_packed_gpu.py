@@ -64,12 +64,18 @@ def test_live_plan_counts_and_early_break():
 
 @pytest.mark.parametrize("kind", ["subgc_f32", "subgc_bf16", "fullgc_bf16_shared", "fullgc_f32_dropout"])
 @pytest.mark.parametrize("packed", [True, False])
-def test_recurrence_issued_from_c_is_the_step_by_step_loop(kind, packed):
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_recurrence_issued_from_c_is_the_step_by_step_loop(kind, packed, fuse):
     """subgc_recurrence_fwd / subgc_recurrence_bwd (one library crossing per direction) against the same T steps issued one entry
     point at a time from Python (ops.RECURRENCE_IN_C = False): same kernels, same launch order, same arguments -- the loss and every
     gradient of the flat bucket are BIT-identical wherever the kernels are (the split-K planes are summed in a fixed order; the only
-    atomics of the step, embed_bwd / pool_bwd / scatter_add, sit outside the loop and give the usual last-bit noise)."""
+    atomics of the step, embed_bwd / pool_bwd / scatter_add, sit outside the loop and give the usual last-bit noise).
+    fuse = 1: the C-issued loop with the row-local middle of every step as one launch per direction (ops.FUSE_MID, csrc/recurrent_mid.hip:
+    the 512-wide query products run inside that launch with another summation order) against the same step-by-step loop: equal to
+    rounding (fp32: 1e-5 of the gradient scale; bf16 operands: the products see the same bf16 inputs, 2e-3)."""
     from subgc import ops
+    fuse_before = ops.FUSE_MID
+    ops.FUSE_MID = fuse
     torch.manual_seed(0)
     opt = dict(OPT)
     if kind.startswith("fullgc"):
@@ -96,7 +102,15 @@ def test_recurrence_issued_from_c_is_the_step_by_step_loop(kind, packed):
             res[in_c] = (float(out["lang_loss"]), m.flat_grads.clone())
         finally:
             ops.RECURRENCE_IN_C = True
+            if in_c:
+                ops.FUSE_MID = fuse_before
     (l0, g0), (l1, g1) = res[False], res[True]
+    if fuse and "shared" not in kind:
+        bf = "bf16" in kind
+        assert abs(l0 - l1) <= (2e-3 if bf else 1e-5) * max(abs(l0), 1.0)
+        scale = float(g0.abs().max())
+        np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=(3e-3 if bf else 1e-5) * scale + 1e-9, rtol=2e-2 if bf else 1e-4)
+        return
     assert l0 == l1
     lo, hi = next((lo, hi) for st, lo, hi in m.grad_buckets() if st == "recurrent")
     emb_o, emb_n, _ = m._slots["embed.0.weight"]
