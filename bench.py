@@ -659,6 +659,13 @@ def main():
                     gbps = work_ / (ms_ * 1e-3) / 1e9
                     hbm[f_] = {"launches_per_step": n_ // 2, "ms_per_step": round(ms_ / 2, 3), "algorithmic_MB_per_step": round(work_ / 2 / 1e6, 1),
                                "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)}
+                    if f_ == "lstm":
+                        # what the cell launches really move: the split-K planes of the gate products (summed on load instead of by a
+                        # reduce pass), the x->gates / fc->gates terms and the gates saved for the backward ride on top of the 12-14
+                        # floats per hidden unit of the algorithmic count -- the kernels run near the memory roof on THOSE bytes
+                        mv = _lib.prof_last_moved(f_)
+                        hbm[f_].update(moved_MB_per_step=round(mv / 2 / 1e6, 1), moved_GBps=round(mv / (ms_ * 1e-3) / 1e9, 1),
+                                       moved_frac_of_8TBps=round(mv / (ms_ * 1e-3) / 1e9 / 8000.0, 4))
             res["hbm_bound_kernels"] = hbm
         if world == 1 and adam is not None:
             # the metric's literal scope, fwd + bwd without the parameter update, timed the same way (the headline includes the update)

@@ -64,6 +64,9 @@ int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* 
  * streams on one clock).  Equals total_ms while the family's launches run one after the other; smaller when launches of two streams
  * overlap (subgc_recurrence_*_pair) -- the wall time during which the family held the device, the denominator of a roofline.     */
 int subgc_prof_last_busy(int family, double* busy_ms);
+/* bytes the family's launches of the LAST subgc_prof_collect actually moved, where an entry point reports them separately from its
+ * algorithmic `work` (the LSTM cell kernels: split-K planes of the gate products, additive gate terms and saved gates included) */
+int subgc_prof_last_moved(int family, double* moved_bytes);
 
 /* ======================================================================================
  * Dense contractions (MFMA v_mfma_f32_32x32x2_f32; exact fp32)
@@ -909,10 +912,10 @@ typedef struct SubgcRecurrence {
     float* dC1_out;
     float* dC2_in;
     float* dC2_out;
-    int32_t fuse_mid;            /* bit 0: cell 1 + query product + attention (and their backward) as ONE launch per step and direction (subgc_mid_fwd /
-                                    subgc_mid_bwd; per-sentence attention sets only -- shared sets keep the three launches); bit 1: one workgroup per CU */
+    int32_t fuse_mid;            /* bit 0: cell 1 + query product + attention of a FORWARD step as ONE launch (subgc_mid_fwd; per-sentence attention
+                                    sets only -- shared sets keep the three launches; opt-in: measured slower, ops.FUSE_MID); bit 1: one workgroup per CU */
     int32_t pad_;
-    const void* WqT;             /* fuse_mid backward: the transposed query weight [R, A] (K-contiguous for d(h1) += d(query) Wq), stored like Wq */
+    const void* WqT;             /* fuse_mid with fp32 operands: the TRANSPOSED query weight [R, A] (K-major, subgc_transpose_f32); unused under bf16 */
     int64_t ldWqT;
 } SubgcRecurrence;
 int subgc_recurrence_sizeof(void);      /* sizeof(SubgcRecurrence): bindings that mirror the struct check their layout against it */

@@ -213,21 +213,32 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
         float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f), wsum = dsum;
         if (a4 < A4) {
             const float4 wa = ld4(w_a + a4 * 4), ha = ld4(ah + (int64_t)s * A + a4 * 4);
-            for (int i = grp; i < l; i += 2) {
-                const int64_t o = (int64_t)(m0 + i) * A + a4 * 4;
-                const float4 x = ldx<UV16>(u, o);
-                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (du) d = ld4(du + o);
-                const float de = al_s[i];
-                const float t0 = subgc_tanh(x.x + ha.x), t1 = subgc_tanh(x.y + ha.y), t2 = subgc_tanh(x.z + ha.z), t3 = subgc_tanh(x.w + ha.w);
-                const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
-                const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
-                if (du) {
-                    d.x += p0; d.y += p1; d.z += p2; d.w += p3;
-                    st4(du + o, d);
+            // four of this group's nodes at a time: their u (and d(u)) rows are requested together, the sums keep the node order
+            constexpr int UN = 4;
+            for (int i0 = grp; i0 < l; i0 += 2 * UN) {
+                float4 x[UN], d[UN];
+#pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    const int i = i0 + 2 * k;
+                    const int64_t o = (int64_t)(m0 + (i < l ? i : grp)) * A + a4 * 4;      // past the end: a valid row, its result is dropped
+                    x[k] = ldx<UV16>(u, o);
+                    d[k] = du ? ld4(du + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                dsum.x += p0; dsum.y += p1; dsum.z += p2; dsum.w += p3;
-                wsum.x += de * t0; wsum.y += de * t1; wsum.z += de * t2; wsum.w += de * t3;
+#pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    const int i = i0 + 2 * k;
+                    if (i >= l) break;
+                    const float de = al_s[i];
+                    const float t0 = subgc_tanh(x[k].x + ha.x), t1 = subgc_tanh(x[k].y + ha.y), t2 = subgc_tanh(x[k].z + ha.z), t3 = subgc_tanh(x[k].w + ha.w);
+                    const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
+                    const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
+                    if (du) {
+                        d[k].x += p0; d[k].y += p1; d[k].z += p2; d[k].w += p3;
+                        st4(du + (int64_t)(m0 + i) * A + a4 * 4, d[k]);
+                    }
+                    dsum.x += p0; dsum.y += p1; dsum.z += p2; dsum.w += p3;
+                    wsum.x += de * t0; wsum.y += de * t1; wsum.z += de * t2; wsum.w += de * t3;
+                }
             }
         }
         __syncthreads();

@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...);
 
 // RAII bracket: records a hipEvent pair around a launch when profiling of `family` is on.
 struct ProfScope {
-    ProfScope(int family, hipStream_t s, double work);
+    ProfScope(int family, hipStream_t s, double work, double moved = -1.0);      // moved: bytes the launch really moves (default: = work)
     ~ProfScope();
     int slot;
     hipStream_t stream;
@@ -33,6 +33,13 @@ inline int check_launch(const char* what) {
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// bytes an LSTM cell forward launch over n = rows x R hidden units moves: `parts` pre-activation planes + the additive gate terms (4 floats
+// per unit each), c_prev, c, the h destinations (fp32 or bf16) and the saved gates -- against the 12 floats per unit of the algorithmic count
+inline double lstm_fwd_moved_bytes(int64_t n, int parts, bool g1, bool g2, bool c_prev, bool h2, bool hdrop, bool gates, int h_bf16) {
+    const double hb = h_bf16 ? 2.0 : 4.0;
+    return (double)n * (4.0 * 4 * ((parts < 1 ? 1 : parts) + (g1 ? 1 : 0) + (g2 ? 1 : 0)) + (c_prev ? 4.0 : 0.0) + 4.0 + hb * (1 + (h2 ? 1 : 0) + (hdrop ? 1 : 0)) +
+                       (gates ? 16.0 : 0.0));
+}
 // Dynamic LDS above 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize raised once per kernel AND device; the largest size granted
 // is remembered per (kernel, device), so a hot launch path pays one table look-up instead of a driver call (the GEMM files keep their own
 // per-instantiation bit masks).  > 160 KiB (the gfx950 LDS) is SUBGC_EINVAL with the kernel's name in the error text.

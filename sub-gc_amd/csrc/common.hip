@@ -45,6 +45,7 @@ constexpr int kFamilies = 8;      // families 1 .. 7 (SUBGC_FAM_*)
 struct Rec {
     hipEvent_t a, b;
     double work;
+    double moved;
 };
 struct Family {
     bool on = false;
@@ -53,10 +54,11 @@ struct Family {
 };
 Family g_fam[kFamilies];
 double g_busy[kFamilies] = {};      // busy (interval-union) milliseconds of the last subgc_prof_collect per family
+double g_moved[kFamilies] = {};     // bytes the launches of the last subgc_prof_collect actually moved (>= the algorithmic `work` of the HBM families)
 std::mutex g_mu;
 }  // namespace
 
-ProfScope::ProfScope(int family, hipStream_t s, double work) : slot(-1), stream(s) {
+ProfScope::ProfScope(int family, hipStream_t s, double work, double moved) : slot(-1), stream(s) {
     if (family <= 0 || family >= kFamilies || !g_fam[family].on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
@@ -68,6 +70,7 @@ ProfScope::ProfScope(int family, hipStream_t s, double work) : slot(-1), stream(
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     }
     r.work = work;
+    r.moved = moved < 0 ? work : moved;
     (void)hipEventRecord(r.a, s);
     f.recs.push_back(r);
     slot = family * 1000000 + (int)f.recs.size() - 1;
@@ -102,12 +105,20 @@ SUBGC_API int subgc_prof_last_busy(int family, double* busy_ms) {
     return SUBGC_OK;
 }
 
+SUBGC_API int subgc_prof_last_moved(int family, double* moved_bytes) {
+    using namespace subgc;
+    SUBGC_REQUIRE(family > 0 && family < kFamilies && moved_bytes, "prof_last_moved: bad arguments");
+    std::lock_guard<std::mutex> lk(g_mu);
+    *moved_bytes = g_moved[family];
+    return SUBGC_OK;
+}
+
 SUBGC_API int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* total_work) {
     using namespace subgc;
     SUBGC_REQUIRE(family > 0 && family < kFamilies, "prof_collect: bad family %d", family);
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
-    double ms = 0, work = 0;
+    double ms = 0, work = 0, moved = 0;
     // busy time = length of the UNION of the launches' [start, stop] intervals: equal to the sum while launches run one after the
     // other, smaller when launches of two streams overlap (the recurrence's two chains) -- the wall time the family held the device
     std::vector<std::pair<float, float>> iv;
@@ -123,6 +134,7 @@ SUBGC_API int subgc_prof_collect(int family, int64_t* launches, double* total_ms
         iv.emplace_back(t0, t0 + t);
         ms += t;
         work += r.work;
+        moved += r.moved;
     }
     for (Rec& r : f.recs) f.pool.push_back(r);
     std::sort(iv.begin(), iv.end());
@@ -136,6 +148,7 @@ SUBGC_API int subgc_prof_collect(int family, int64_t* launches, double* total_ms
     }
     if (open) busy += hi - lo;
     g_busy[family] = busy;
+    g_moved[family] = moved;
     if (launches) *launches = (int64_t)f.recs.size();
     if (total_ms) *total_ms = ms;
     if (total_work) *total_work = work;

@@ -744,7 +744,7 @@ SUBGC_API int subgc_lstm_fwd(const float* g0, int64_t ld0, const float* g1, int6
     SUBGC_REQUIRE(g0 && c && h, "lstm_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)S * R;
-    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12);
+    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12, subgc::lstm_fwd_moved_bytes(n, 1, g1 != nullptr, g2 != nullptr, c_prev != nullptr, h2 != nullptr, hdrop != nullptr, gates != nullptr, h_bf16));
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = R % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && ldh % 4 == 0 && ldh2 % 4 == 0 && ldhd % 4 == 0 && al(g0) &&
                      al(g1) && al(g2) && al(b0) && al(b1) && al(c_prev) && al(c) && al(h) && al(h2) && al(hdrop) && al(gates) &&
@@ -808,7 +808,7 @@ SUBGC_API int subgc_lstm_fwd_gemm_ev(const void* x, int64_t ldx, const void* w, 
     if (rows_h <= 0 || rows_h > S) rows_h = S;
     if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
     const int64_t n = (int64_t)S * R;
-    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12);
+    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12, subgc::lstm_fwd_moved_bytes(n, parts, g1 != nullptr, g2 != nullptr, c_prev != nullptr, h2 != nullptr, hdrop != nullptr, gates != nullptr, h_bf16));
     hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, (int64_t)4 * R, g1, ld1, g2, ld2, b0, b1,
                        c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, parts, (int64_t)S * 4 * R, h_bf16);
     return subgc::check_launch("subgc_lstm_fwd_gemm");
@@ -818,7 +818,9 @@ int lstm_bwd_launch(const float* gates, const float* c_prev, const float* c, Pla
                     const uint8_t* keep, float keep_scale, const float* dc, void* dpre, float* dc_prev, int S, int R, int dpre_bf16, hipStream_t s,
                     const char* what) {
     const int64_t n = (int64_t)S * R;
-    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 14);
+    // moved: the four saved gates, c, c_prev, dc (read) + every d(h) source plane + d(gates) (fp32 or bf16) and dc_prev (written)
+    const double planes_in = (sa.p ? sa.n : 0) + (sb.p ? sb.n : 0) + (sc.p ? sc.n : 0) + (dh_drop ? 1 + (keep ? 0.25 : 0.0) : 0.0);
+    subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 14, 4.0 * n * (4 + 1 + (c_prev ? 1 : 0) + (dc ? 1 : 0) + planes_in + (dpre_bf16 ? 2.0 : 4.0) + 1));
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     auto src_ok = [&](const PlaneSrc& a) { return !a.p || (al(a.p) && a.ld % 4 == 0 && a.stride % 4 == 0); };
     const bool vec = R % 4 == 0 && ldd % 4 == 0 && al(gates) && al(c_prev) && al(c) && src_ok(sa) && src_ok(sb) && src_ok(sc) &&

@@ -1,29 +1,30 @@
-// The ROW-LOCAL middle of a train-decoder step as ONE launch per direction (reference: TopDownCore.forward, AttModel.py:400-431, and
-// Attention.forward, :445-471, at the batch sizes of training).
+// The ROW-LOCAL middle of a train-decoder step as ONE launch (reference: TopDownCore.forward, AttModel.py:400-431, and
+// Attention.forward, :445-471, at the batch sizes of training).  OPT-IN (ops.FUSE_MID / SubgcRecurrence.fuse_mid): correct, measured
+// SLOWER than the three launches it replaces -- kept as the evidence behind that statement (profiles/r05_mid_probe.txt).
 //
 // A step of the recurrence is  product -> cell -> query product -> attention -> product -> cell.  The two gate products are
 // all-to-all over the hidden dimension (every output column needs the whole input row of every sentence) and stay chip-wide GEMM
 // launches.  Everything BETWEEN them is local to a sentence row: the attention LSTM's cell update of row s needs the gate
 // pre-activations of row s, the query h2att(h1[s]) needs h1[s], the attention of sentence s needs its query and its own node set,
-// and the context goes to row s of the next product's operand.  Cutting the step at the all-to-all seams only
-// (MI355X_MICROARCH.md: a dependent kernel boundary is ~1.5 us + the predecessor's drain, an in-launch grid barrier 4-7 us, so
-// all-to-all seams stay launches and everything else should not be one) gives
+// and the context goes to row s of the next product's operand.  Cutting the forward step at the all-to-all seams only gives
 //
-//     forward :  [gate product 1] [cell 1 + query + attention]  [gate product 2] [cell 2]                       6 -> 4 launches
-//     backward:  [cell 2 bwd] [d product 2] [attention bwd + d(query) product + cell 1 bwd] [d product 1]        6 -> 4 launches
+//     [gate product 1] [cell 1 + query + attention]  [gate product 2] [cell 2]                                   6 -> 4 launches
 //
-// and the split-K planes of the 512-wide query products, the query rows' round trip and two launch ramps per step and direction
-// disappear.  A workgroup owns RB consecutive sentence rows (RB = ceil(rows / 256): one workgroup per CU, all CUs busy) and walks
-// the phases with its rows' state in LDS:
-//   1. cell: gate planes + x->gates + fc->gates + biases -> (i, f, g, o), c, h1 -- h1 to its two operand slots, to G1 (saved gates) and
-//      to LDS (the query product's operand: fp32, or bf16 under compute_dtype = bf16, the same rounding the operand slot gets);
-//   2. query: q = h1 Wq^T + b on the matrix pipe as a reduction engine (gemm_skinny.hip's scheme): the <= 16 rows are ONE MFMA operand
-//      tile, a wave owns 4 x 16 query columns over the whole K, so there is no cross-wave reduction; Wq (1 MB bf16 / 2 MB fp32) is
-//      streamed from L2 by every workgroup through a register ring whose first loads are issued BEFORE the cell phase;
-//   3. attention over the rows' node sets exactly as attention_vec.hip does it (same arithmetic order), the (sentence, node) pairs
-//      of all RB rows flattened so that every wave has four rows of u in flight; the context goes to the product operand slot.
-// The backward kernel mirrors it: attention backward (d(ctx) planes summed on load) -> d(query) rows in LDS -> d(h1) += d(query) Wq
-// (the transposed copy WqT [R, A] makes it the same K-contiguous stream) -> cell backward with the other d(h1) plane sources.
+// and the split-K planes of the 512-wide query product, the query rows' round trip and two launch boundaries per step disappear.
+// A workgroup (16 waves) owns RB consecutive sentence rows (RB = ceil(rows / 256): one workgroup per CU, all CUs busy) and walks the
+// phases with its rows' state in LDS:
+//   1. cell: gate planes + x->gates + fc->gates + biases -> (i, f, g, o), c, h1 -- h1 to its two operand slots, the gates to G1 and h1 to
+//      LDS (the query product's operand: fp32, or bf16 under compute_dtype = bf16 with the rounding the operand slot gets);
+//   2. query: q = h1 Wq^T + b.  bf16 operands: the matrix pipe as a reduction engine (gemm_skinny.hip's scheme) -- the <= 16 rows are ONE
+//      MFMA operand tile, a wave owns 2 x 16 query columns over the whole K, no cross-wave reduction.  fp32 operands: plain FMAs on the
+//      K-MAJOR weight (the fp32 matrix pipe runs at the VALU's rate and would spend 80 % of it on the padding of a 16-row tile).
+//      Either way every workgroup streams the WHOLE weight (1 MB bf16 / 2 MB fp32) from L2;
+//   3. attention over the rows' node sets as attention_vec.hip does it (same arithmetic order), the (sentence, node) pairs of all RB
+//      rows flattened so that every wave has four rows of u in flight; the context goes to the product operand slot.
+// What the stamps say (tools/mid_probe.py): phase 1 is bound by the CHIP's memory bandwidth (159 MB per step at 1280 rows: 28 us fused or
+// not); phase 2 saturates the L2s (256 CUs x the same megabytes = ~13 TB/s aggregate: 20 us bf16 / 33 us fp32, against 15 / 19 us for the
+// chip-wide split-K product); phase 3 of a workgroup alone on its CU is no faster than the 1280-workgroup launch.  The backward
+// (attention backward -> d(query) Wq -> cell backward) has the same three problems and was not built.
 #include "common.h"
 #include "bf16_util.h"
 

@@ -129,3 +129,10 @@ def prof_last_busy(family):
     ms = ctypes.c_double(0)
     call("subgc_prof_last_busy", FAM[family], ctypes.byref(ms))
     return ms.value
+
+
+def prof_last_moved(family):
+    """Bytes the family's launches at the last prof_collect actually moved (LSTM cells: split-K planes, gate terms, saved gates included)."""
+    b = ctypes.c_double(0)
+    call("subgc_prof_last_moved", FAM[family], ctypes.byref(b))
+    return b.value

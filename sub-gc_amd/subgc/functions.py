@@ -859,15 +859,11 @@ def make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale
 
 
 def fused_mid_weights(pr, wq, bf, forward):
-    """SubgcRecurrence fields of the fused middle (ops.FUSE_MID, csrc/recurrent_mid.hip): the TRANSPOSED h2att weight `WqT` [R, A] for the
-    direction that streams it -- fp32 operands: the forward's K-major form; bf16 operands: the backward's K-contiguous rows of
-    d(h1) += d(query) Wq.  `wq`: the fp32 master [A, R].  One 1-2 MB transpose per forward / backward call."""
-    if not (ops.FUSE_MID & 1) or pr.shared or bool(bf) == bool(forward):
+    """SubgcRecurrence fields of the fused middle (ops.FUSE_MID, csrc/recurrent_mid.hip; forward only): under fp32 operands the K-major
+    TRANSPOSE `WqT` [R, A] of the h2att weight `wq` [A, R] that the fused launch streams (one 2 MB transpose per forward call)."""
+    if not (ops.FUSE_MID & 1) or pr.shared or bf or not forward:
         return {}
-    if bf:
-        wt = ops.transpose_bf16(wq, out=ops.empty_b16(wq.size(1), wq.size(0), wq.device))
-    else:
-        wt = ops.transpose_f32(wq)
+    wt = ops.transpose_f32(wq)
     return dict(WqT=wt, ldWqT=ops.ld(wt))
 
 
