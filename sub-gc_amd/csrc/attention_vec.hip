@@ -78,10 +78,15 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restric
     __syncthreads();
     float mx = -INFINITY;
     for (int i = 0; i < l; ++i) mx = fmaxf(mx, e_s[i]);
-    float den = 0.f;
-    for (int i = 0; i < l; ++i) den += expf(e_s[i] - mx);
     __syncthreads();
-    for (int i = t; i < l; i += 256) e_s[i] = expf(e_s[i] - mx) / den;
+    // every exponential ONCE (it used to be evaluated by all 256 threads inside the sum: a quarter of the kernel's VALU instructions on
+    // 37-node sets); the sum below adds the same values in the same order, so the weights are bit for bit what they were
+    for (int i = t; i < l; i += 256) e_s[i] = expf(e_s[i] - mx);
+    __syncthreads();
+    float den = 0.f;
+    for (int i = 0; i < l; ++i) den += e_s[i];
+    __syncthreads();
+    for (int i = t; i < l; i += 256) e_s[i] = e_s[i] / den;
     __syncthreads();
     if (alpha)
         for (int i = t; i < n_stride; i += 256) alpha[(int64_t)s * n_stride + i] = i < l ? e_s[i] : 0.f;
