@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 PASSES=${PASSES:-2}
 for LEG in greedy_batched beam2_batched mrnn; do
   for C in FETCH_SIZE WRITE_SIZE; do
