@@ -121,7 +121,7 @@ class AttModel(CaptionModel):
         # drop_prob_lm = 0); with dropout ON the reference draws an INDEPENDENT keep-mask for each of the 5 replicated copies, and
         # sharing would tie them within an image.  -1 (default, "auto"): share only when that changes nothing, i.e. a training forward
         # with dropout keeps the reference's five independent masks on replicated rows; 1: always share (tied masks: each sentence's
-        # marginal is unchanged, the joint distribution is not the reference's; 13 % faster on Full_GC_Kar, reported beside the
+        # marginal is unchanged, the joint distribution is not the reference's; 7-8 % faster on Full_GC_Kar, reported beside the
         # default by bench.py); 0: never.  Not a reference option.
         self.share_attention_sets = int(g("share_attention_sets", -1))
         if g("recurrence_chains") is not None:                       # opt-in: the packed recurrence as two interleaved chains (ops.RECURRENCE_CHAINS)
