@@ -63,3 +63,37 @@ def test_mid_fwd_matches_the_three_launches(S, R, A, nmax, parts, bf):
     torch.testing.assert_close(a["al"], b["al"], **(dict(atol=1e-4, rtol=1e-3) if not bf else tol))
     torch.testing.assert_close(f(a["H"][:, :R]), f(b["H"][:, :R]), **(dict(atol=1e-4, rtol=1e-3) if not bf else dict(atol=2e-2, rtol=2e-2)))
     assert torch.all(b["al"].sum(1)[lens > 0].sub(1).abs() < 1e-5)
+
+
+def test_transpose_f32_and_refusals():
+    """subgc_transpose_f32 (the K-major weight of the fp32 fused product) on shapes that are not multiples of its 64 x 64 tile; subgc_mid_fwd
+    refuses what it does not cover with an error instead of a wrong answer (fp32 operands beyond 1024 rows, query widths above 512)."""
+    from subgc import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for rows, cols in ((512, 1000), (65, 3), (1, 130)):
+        x = torch.randn(rows, cols, generator=g).to(dev)
+        assert torch.equal(ops.transpose_f32(x), x.t().contiguous())
+    S, R, A = 1100, 64, 32
+    z = lambda *s: torch.zeros(*s, device=dev)
+    lens, off = torch.ones(S, dtype=torch.int32, device=dev), torch.arange(S, dtype=torch.int32, device=dev)
+    with pytest.raises(ops.SubgcError, match="not covered"):
+        ops.mid_fwd(z(S, 4 * R), 1, 0, None, None, None, None, None, z(S, R), z(S, 3 * R)[:, R:2 * R], None, z(S, 4 * R), z(R, A), z(A), z(S, A), z(S, A), z(S, R),
+                    z(A), z(1), off, lens, z(S, 3 * R)[:, :R], z(S, 2), S, R, A)
+
+
+def test_cell_kernels_report_moved_bytes():
+    """subgc_prof_last_moved: the LSTM cell launches report the bytes they really move (planes, gate terms, saved gates) beside the 12-float
+    algorithmic count of the bench's hbm_bound_kernels block."""
+    from subgc import _lib, ops
+    dev = torch.device("cuda:0")
+    S, R = 64, 128
+    z = lambda *s: torch.zeros(*s, device=dev)
+    _lib.prof_enable("lstm", True)
+    ops.lstm_fwd(z(S, 4 * R), z(S, 4 * R), z(S, 4 * R), z(4 * R), z(4 * R), z(S, R), z(S, R), z(S, R), z(S, R), None, 1.0, None, z(S, 4 * R), S, R)
+    torch.cuda.synchronize()
+    _lib.prof_enable("lstm", False)
+    n, ms, work = _lib.prof_collect("lstm")
+    moved = _lib.prof_last_moved("lstm")
+    assert n == 1 and work == 4.0 * S * R * 12
+    assert moved == S * R * (4.0 * 4 * 3 + 4 + 4 + 4 * 2 + 16)          # three 4-gate inputs, c_prev, c, two fp32 h copies, the saved gates
