@@ -122,7 +122,10 @@ __device__ __forceinline__ void ldk(const uint8_t* p, bool (&o)[VW]) {
     else o[0] = *p != 0;
 }
 
-template <int VW>
+// PARTS > 0: the number of pre-activation planes is a compile-time constant, so every plane's load is issued before any is added (a
+// runtime trip count made the sum a chain of dependent round trips: three planes = three memory latencies per thread); the additions
+// keep their order, the result is bit for bit that of the generic form (PARTS = 0)
+template <int VW, int PARTS = 0>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ g0, int64_t ld0, const float* __restrict__ g1,
                                                        int64_t ld1, const float* __restrict__ g2, int64_t ld2,
                                                        const float* __restrict__ b0, const float* __restrict__ b1,
@@ -144,10 +147,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         const int col = k * R + j;
         float t[VW];
         ldv<VW>(g0 + (int64_t)s * ld0 + col, pre[k]);
-        for (int pt = 1; pt < parts; ++pt) {
-            ldv<VW>(g0 + pt * plane + (int64_t)s * ld0 + col, t);
+        if (PARTS > 0) {
+            float tp[PARTS > 1 ? PARTS - 1 : 1][VW];
 #pragma unroll
-            for (int e = 0; e < VW; ++e) pre[k][e] += t[e];
+            for (int pt = 1; pt < PARTS; ++pt) ldv<VW>(g0 + pt * plane + (int64_t)s * ld0 + col, tp[pt - 1]);
+#pragma unroll
+            for (int pt = 1; pt < PARTS; ++pt)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) pre[k][e] += tp[pt - 1][e];
+        } else {
+            for (int pt = 1; pt < parts; ++pt) {
+                ldv<VW>(g0 + pt * plane + (int64_t)s * ld0 + col, t);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) pre[k][e] += t[e];
+            }
         }
         if (g1) { ldv<VW>(g1 + (int64_t)s * ld1 + col, t);
 #pragma unroll
@@ -809,8 +822,19 @@ SUBGC_API int subgc_lstm_fwd_gemm_ev(const void* x, int64_t ldx, const void* w, 
     if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
     const int64_t n = (int64_t)S * R;
     subgc::ProfScope prof(SUBGC_FAM_LSTM, s, 4.0 * n * 12, subgc::lstm_fwd_moved_bytes(n, parts, g1 != nullptr, g2 != nullptr, c_prev != nullptr, h2 != nullptr, hdrop != nullptr, gates != nullptr, h_bf16));
-    hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, (int64_t)4 * R, g1, ld1, g2, ld2, b0, b1,
-                       c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, parts, (int64_t)S * 4 * R, h_bf16);
+#define SUBGC_LSTM_FWD_PARTS(P_)                                                                                                                         \
+    hipLaunchKernelGGL((lstm_fwd_kernel<4, P_>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, (int64_t)4 * R, g1, ld1, g2, ld2, b0, \
+                       b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2, parts, (int64_t)S * 4 * R, h_bf16)
+    switch (parts) {
+        case 2: SUBGC_LSTM_FWD_PARTS(2); break;
+        case 3: SUBGC_LSTM_FWD_PARTS(3); break;
+        case 4: SUBGC_LSTM_FWD_PARTS(4); break;
+        case 5: SUBGC_LSTM_FWD_PARTS(5); break;
+        case 6: SUBGC_LSTM_FWD_PARTS(6); break;
+        case 8: SUBGC_LSTM_FWD_PARTS(8); break;
+        default: SUBGC_LSTM_FWD_PARTS(0); break;
+    }
+#undef SUBGC_LSTM_FWD_PARTS
     return subgc::check_launch("subgc_lstm_fwd_gemm");
 }
 namespace {
