@@ -145,11 +145,21 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
 #pragma unroll
     for (int c = 0; c < CR64; ++c) {
         g[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane + c * 64 < R4)
-            for (int q = 0; q < n_planes; ++q) {
-                const float4 x = ld4(dctx + q * plane_stride + (int64_t)s * lddctx + (lane + c * 64) * 4);
-                g[c].x += x.x; g[c].y += x.y; g[c].z += x.z; g[c].w += x.w;
+        if (lane + c * 64 < R4) {
+            // the planes of a chunk are requested together (see subgc_load_q); added in plane order
+            constexpr int MAXQ = 4;
+            float4 x[MAXQ];
+            const float* base = dctx + (int64_t)s * lddctx + (lane + c * 64) * 4;
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) x[q] = ld4(base + (q < n_planes ? q : n_planes - 1) * plane_stride);
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q)
+                if (q < n_planes) { g[c].x += x[q].x; g[c].y += x[q].y; g[c].z += x[q].z; g[c].w += x[q].w; }
+            for (int q = MAXQ; q < n_planes; ++q) {
+                const float4 y = ld4(base + q * plane_stride);
+                g[c].x += y.x; g[c].y += y.y; g[c].z += y.z; g[c].w += y.w;
             }
+        }
     }
     if (dctx_keep && wave == 0) {
 #pragma unroll

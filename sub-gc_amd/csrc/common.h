@@ -94,8 +94,18 @@ int mid_fwd(const float* g0, int64_t ld0, int parts, int64_t plane, const float*
 
 // query chunk (four columns at `idx` = row * A + column) of a QSrc: planes summed in order, bias last
 __device__ __forceinline__ float4 subgc_load_q(const float* __restrict__ ah, const subgc::QSrc& qs, int64_t idx, int col) {
-    float4 a = *reinterpret_cast<const float4*>(ah + idx);
-    for (int p = 1; p < qs.n_planes; ++p) {
+    // the planes are REQUESTED together (a runtime-length loop of load + add is one memory latency per plane at the head of every
+    // attention launch: 4-8 planes on the 512-wide query product); planes past the count re-read the last one and are not added, the
+    // additions keep the plane order
+    constexpr int MAXQ = 8;
+    float4 x[MAXQ];
+#pragma unroll
+    for (int p = 0; p < MAXQ; ++p) x[p] = *reinterpret_cast<const float4*>(ah + (p < qs.n_planes ? p : qs.n_planes - 1) * qs.stride + idx);
+    float4 a = x[0];
+#pragma unroll
+    for (int p = 1; p < MAXQ; ++p)
+        if (p < qs.n_planes) { a.x += x[p].x; a.y += x[p].y; a.z += x[p].z; a.w += x[p].w; }
+    for (int p = MAXQ; p < qs.n_planes; ++p) {
         const float4 b = *reinterpret_cast<const float4*>(ah + p * qs.stride + idx);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
