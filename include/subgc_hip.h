@@ -110,6 +110,8 @@ int subgc_prof_last_moved(int family, double* moved_bytes);
 #define SUBGC_GEMM_SPLITS(n) (((n) & 15) << 8)    /* subgc_gemm_bf16: force n K parts (0 = the cost model decides) */
 #define SUBGC_GEMM_SPLITS_OF(flags) (((flags) >> 8) & 15)
 #define SUBGC_GEMM_NO_ROW_CUT (1 << 12)            /* subgc_gemm_bf16: one launch even for near-whole-round tile counts */
+#define SUBGC_GEMM_TILE_P8 (1 << 13)               /* subgc_gemm_bf16: force the 256 x 256 x 64 eight-phase form (measurement scripts) */
+#define SUBGC_GEMM_NO_P8 (1 << 14)                 /* subgc_gemm_bf16: never choose the eight-phase form (A/B timing) */
 #define SUBGC_GEMM_MODE_F32 (1 << 4)
 #define SUBGC_GEMM_MODE_BF16X3 (2 << 4)
 #define SUBGC_GEMM_MODE_BF16R (3 << 4)

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -418,24 +419,31 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MA][NB]) {
 // columns per register quad, i.e. one 16-byte (fp32) or 8-byte (bf16) store per quad instead of four scalar stores that a
 // column-per-lane layout needs (64 dword stores per lane and tile made the store issue as long as the whole K loop at K = 1000).
 struct Quad { float v[4]; };
-template <typename G, typename F>
-__device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, F&& f) {
+// one row of 32 x 32 tiles (fixed a): instantiated per a through a fold, so the accumulator index is a constant whatever the unroller decides
+// (with MA = 4 and the full epilogue as the body, "#pragma unroll" over a was declined and the accumulators went through scratch)
+template <typename G, int A, typename F>
+__device__ __forceinline__ void quads_of_row(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, F& f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave / G::WN) * (32 * G::MA), wn = (wave % G::WN) * (32 * G::NB);
+    const int m = m0 + wm + A * 32 + (lane & 31);
+    if (m >= M) return;
 #pragma unroll
-    for (int a = 0; a < G::MA; ++a) {
-        const int m = m0 + wm + a * 32 + (lane & 31);
-        if (m >= M) continue;
+    for (int b = 0; b < G::NB; ++b)
 #pragma unroll
-        for (int b = 0; b < G::NB; ++b)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn + b * 32 + 8 * q + 4 * (lane >> 5);
-                if (n >= N) continue;
-                Quad x{{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]}};
-                f(m, n, x);
-            }
-    }
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn + b * 32 + 8 * q + 4 * (lane >> 5);
+            if (n >= N) continue;
+            Quad x{{acc[A][b][4 * q], acc[A][b][4 * q + 1], acc[A][b][4 * q + 2], acc[A][b][4 * q + 3]}};
+            f(m, n, x);
+        }
+}
+template <typename G, typename F, int... As>
+__device__ __forceinline__ void for_each_quad_seq(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, F& f, std::integer_sequence<int, As...>) {
+    (quads_of_row<G, As>(acc, m0, n0, M, N, f), ...);
+}
+template <typename G, typename F>
+__device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, F&& f) {
+    for_each_quad_seq<G>(acc, m0, n0, M, N, f, std::make_integer_sequence<int, G::MA>{});
 }
 
 // The column sums a workgroup's threads hold after mainloop_dma<.., CS = true>: thread t has columns 8 (t % (TBM/8)) .. +7 over its k-rows;
@@ -458,26 +466,9 @@ __device__ __forceinline__ void colsum_store(unsigned char* smem, const float (&
     }
 }
 
-template <typename G, bool A_KM, bool B_KM, bool CS = false>
-__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_kernel(const Args p_in) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Args p = p_in;
-    int wg = blockIdx.x, nwg = gridDim.x;
-    select_problem(p, wg, nwg);
-    const int M = (p.m_dev && !A_KM) ? min(p.M, *p.m_dev) : p.M;
-    const int K = (p.m_dev && A_KM) ? min(p.K, *p.m_dev) : p.K;
-    const int tiles_m = (M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN, live = tiles_m * tiles_n;
-    if (wg >= live) return;
-    int tm, tn;
-    tile_of(xcd_chunked_id(wg, live), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * G::TBM, n0 = tn * G::TBN;
-    f32x16 acc[G::MA][G::NB];
-    zero_acc(acc);
-    if constexpr (CS) {
-        float cs[8];
-        mainloop_dma<G, A_KM, B_KM, true>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc, cs, n0 == 0);
-        if (n0 == 0) colsum_store<G>(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);
-    } else mainloop_dma<G, A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+// bias / residual / ReLU / keep-mask / accumulate, results to fp32 and / or bf16 (one 16-byte / 8-byte store per accumulator quad)
+template <typename G>
+__device__ __forceinline__ void store_tile(const Args& p, const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M) {
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
     // vector form: every quad is whole (N % 4 == 0) and every row start 16 / 8 bytes aligned
     const bool vec = p.N % 4 == 0 && (!p.C32 || (p.ldc32 % 4 == 0 && aligned16(p.C32))) && (!p.C16 || (p.ldc16 % 4 == 0 && aligned8(p.C16))) &&
@@ -525,6 +516,29 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
             if (p.C16) p.C16[row * p.ldc16 + col] = (uint16_t)f2bf(v);
         }
     });
+}
+
+template <typename G, bool A_KM, bool B_KM, bool CS = false>
+__global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_bf16_kernel(const Args p_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Args p = p_in;
+    int wg = blockIdx.x, nwg = gridDim.x;
+    select_problem(p, wg, nwg);
+    const int M = (p.m_dev && !A_KM) ? min(p.M, *p.m_dev) : p.M;
+    const int K = (p.m_dev && A_KM) ? min(p.K, *p.m_dev) : p.K;
+    const int tiles_m = (M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN, live = tiles_m * tiles_n;
+    if (wg >= live) return;
+    int tm, tn;
+    tile_of(xcd_chunked_id(wg, live), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * G::TBM, n0 = tn * G::TBN;
+    f32x16 acc[G::MA][G::NB];
+    zero_acc(acc);
+    if constexpr (CS) {
+        float cs[8];
+        mainloop_dma<G, A_KM, B_KM, true>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc, cs, n0 == 0);
+        if (n0 == 0) colsum_store<G>(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);
+    } else mainloop_dma<G, A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
+    store_tile<G>(p, acc, m0, n0, M);
 }
 
 template <typename G, bool A_KM, bool B_KM, bool CS = false>
@@ -595,20 +609,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __r
     }
 }
 
+using GP8 = Geo<256, 256, 4, 2>;                                // 2 x 4 waves of 128 x 64: the accumulator geometry of gemm_bf16_p8.h (its LDS is laid out there)
+
+#include "gemm_bf16_p8.h"
+
+template <bool A_KM, bool B_KM, bool CS = false>
+__global__ __launch_bounds__(p8::NT) void gemm_bf16_p8_kernel(const Args p_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Args p = p_in;
+    int wg = blockIdx.x, nwg = gridDim.x;
+    select_problem(p, wg, nwg);
+    const int M = (p.m_dev && !A_KM) ? min(p.M, *p.m_dev) : p.M;
+    const int K = (p.m_dev && A_KM) ? min(p.K, *p.m_dev) : p.K;
+    const int tiles_m = (M + 255) / 256, tiles_n = (p.N + 255) / 256, live = tiles_m * tiles_n;
+    if (wg >= live) return;
+    int tm, tn;
+    tile_of(xcd_chunked_id(wg, live), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    f32x16 acc[4][2];
+    zero_acc(acc);
+    if constexpr (CS) {
+        float cs[2][8];
+        p8::mainloop<A_KM, B_KM, true>(p, smem, M, K, m0, n0, 0, (K + p8::KT - 1) / p8::KT, acc, cs, n0 == 0);
+        if (n0 == 0) p8::colsum_store(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);
+    } else p8::mainloop<A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + p8::KT - 1) / p8::KT, acc);
+    store_tile<GP8>(p, acc, m0, n0, M);
+}
+
+template <bool A_KM, bool B_KM, bool CS = false>
+__global__ __launch_bounds__(p8::NT) void gemm_bf16_p8_splitk_kernel(const Args p_in, float* __restrict__ ws, int splits, int kt_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Args p = p_in;
+    int wg = blockIdx.x, nwg = gridDim.x;
+    if (select_problem(p, wg, nwg)) ws += (size_t)splits * p.M * p.N;
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    const int u = xcd_chunked_id(wg, nwg);
+    const int tile = u / splits, part = u - tile * splits;
+    int tm, tn;
+    tile_of(tile, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int K = (A_KM && p.m_dev) ? min(p.K, *p.m_dev) : p.K;
+    const int kt_all = (K + p8::KT - 1) / p8::KT;
+    if (A_KM && p.m_dev) kt_per_split = (kt_all + splits - 1) / splits;
+    const int kt0 = min(kt_all, part * kt_per_split), kt1 = min(kt_all, kt0 + kt_per_split);
+    f32x16 acc[4][2];
+    zero_acc(acc);
+    if constexpr (CS) {
+        float cs[2][8];
+        p8::mainloop<A_KM, B_KM, true>(p, smem, p.M, K, m0, n0, kt0, kt1, acc, cs, n0 == 0);
+        if (n0 == 0) p8::colsum_store(smem, cs, m0, p.M, p.cs_part + (size_t)part * p.M, false);   // an empty part stores zeros
+    } else p8::mainloop<A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
+    float* out = ws + (size_t)part * p.M * p.N;
+    for_each_quad<GP8>(acc, m0, n0, p.M, p.N, [&](int m, int n, Quad& x) {
+        *reinterpret_cast<float4*>(out + (size_t)m * p.N + n) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    });
+}
+
 using G128 = Geo<128, 128, 2, 2>;
 using G256 = Geo<256, 256, 2, 2>;
 
 // Cost model of a launch, in microseconds, from measured constants (tools/gemm_bf16_bench.py with SUBGC_BF16_TILE=128 / 256):
 // a workgroup spends c us per 32-deep K-tile and e us in its prologue + epilogue (e is dominated by the result bytes: halve it
 // for a bf16-only destination); `slots` workgroups run at a time; a split costs the partial planes' round trip at ~3 TB/s + a launch.
-struct Plan { int big; int splits; double cost; };
-inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool out32 = true, int nprob = 1) {
+struct Plan { int big; int splits; double cost; };            // big: 0 = 128 x 128 ring, 1 = 256 x 256 ring, 2 = 256 x 256 eight-phase (gemm_bf16_p8.h)
+// Round 6: the eight-phase form.  Measured (tools/p8_probe.py, tools/gemm_bf16_sweep.py): 1.37 us per 64-deep K-tile and workgroup with all CUs
+// busy (0.685 per 32 deep; 1.56 when B is K-major: its sub-tile images are 64-byte row pieces), 19 us per tile round outside the K loop
+// with an fp32 destination, 16 with bf16 only.
+inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool out32 = true, int nprob = 1, bool allow_p8 = false, bool b_km_only = false) {
     const int kt = (int)subgc::cdiv(K, BK);
     Plan best{0, 1, 1e30};
-    for (int big = 0; big < 2; ++big) {
+    for (int big = 0; big < (allow_p8 ? 3 : 2); ++big) {
         const int64_t tiles = nprob * (big ? subgc::cdiv(M, 256) * subgc::cdiv(N, 256) : subgc::cdiv(M, 128) * subgc::cdiv(N, 128));
         const int slots = big ? 256 : 512;
-        const double c = big ? 0.85 : 0.67, e = (big ? 24.0 : 12.0) * (out32 ? 1.0 : 0.55);
+        const double c = big == 2 ? (b_km_only ? 0.78 : 0.685) : big ? 0.85 : 0.67;
+        const double e = big == 2 ? (out32 ? 19.0 : 16.0) : (big ? 24.0 : 12.0) * (out32 ? 1.0 : 0.55);
         for (int s = 1; s <= 8; ++s) {
             if (s > 1 && (!may_split || (kt + s - 1) / s < 12 || (size_t)nprob * s * M * N * sizeof(float) > ws_bytes)) break;
             const int per = (kt + s - 1) / s;
@@ -680,6 +754,56 @@ int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t
 }
 
 template <bool A_KM, bool B_KM>
+int launch_p8(const Args& a, float* ws, int splits, bool partials_only, hipStream_t s) {
+    const int64_t tiles = a.nprob * subgc::cdiv(a.M, 256) * subgc::cdiv(a.N, 256);
+    const int kt = (int)subgc::cdiv(a.K, p8::KT);
+    static uint64_t attr_a = 0, attr_b = 0;
+    bool with_cs = false;
+    if constexpr (A_KM) with_cs = a.cs_out != nullptr && !partials_only;
+    if (splits <= 1) {
+        if constexpr (A_KM) {
+            if (with_cs) {
+                static uint64_t attr_c = 0;
+                if (int rc = raise_lds(gemm_bf16_p8_kernel<A_KM, B_KM, true>, p8::LDS_BYTES, attr_c)) return rc;
+                hipLaunchKernelGGL((gemm_bf16_p8_kernel<A_KM, B_KM, true>), dim3((unsigned)tiles), dim3(p8::NT), p8::LDS_BYTES, s, a);
+                return subgc::check_launch("subgc_gemm_bf16_wgrad(p8)");
+            }
+        }
+        if (int rc = raise_lds(gemm_bf16_p8_kernel<A_KM, B_KM>, p8::LDS_BYTES, attr_a)) return rc;
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<A_KM, B_KM>), dim3((unsigned)tiles), dim3(p8::NT), p8::LDS_BYTES, s, a);
+        return subgc::check_launch("subgc_gemm_bf16(p8)");
+    }
+    bool launched = false;
+    if constexpr (A_KM) {
+        if (with_cs) {
+            static uint64_t attr_d = 0;
+            if (int rc = raise_lds(gemm_bf16_p8_splitk_kernel<A_KM, B_KM, true>, p8::LDS_BYTES, attr_d)) return rc;
+            hipLaunchKernelGGL((gemm_bf16_p8_splitk_kernel<A_KM, B_KM, true>), dim3((unsigned)(tiles * splits)), dim3(p8::NT), p8::LDS_BYTES, s, a, ws, splits,
+                               (kt + splits - 1) / splits);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        if (int rc = raise_lds(gemm_bf16_p8_splitk_kernel<A_KM, B_KM>, p8::LDS_BYTES, attr_b)) return rc;
+        hipLaunchKernelGGL((gemm_bf16_p8_splitk_kernel<A_KM, B_KM>), dim3((unsigned)(tiles * splits)), dim3(p8::NT), p8::LDS_BYTES, s, a, ws, splits,
+                           (kt + splits - 1) / splits);
+    }
+    if (partials_only) return subgc::check_launch("subgc_gemm_bf16(p8, split-K, partials)");
+    const int64_t n = (int64_t)a.M * a.N / 4;
+    hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048), (unsigned)a.nprob), dim3(256), 0, s, (const float*)ws,
+                       splits, a.M, a.N, a.C32, a.ldc32, a.C16, a.ldc16, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0,
+                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum, a.C32b, a.C16b, a.bias2);
+    return subgc::check_launch("subgc_gemm_bf16(p8, split-K)");
+}
+
+// the eight-phase loop addresses its operands with 32-bit byte offsets; a K-contiguous operand is masked in 16-byte chunks (K % 8 == 0), a
+// K-major one in whole k-rows (any K)
+inline bool p8_ok(const Args& a, bool a_km, bool b_km) {
+    const int64_t ea = (a_km ? (int64_t)a.K : (int64_t)a.M) * a.lda * 2, eb = (b_km ? (int64_t)a.K : (int64_t)a.N) * a.ldb * 2;
+    return ((a_km && b_km) || a.K % 8 == 0) && ea < 0x7ff00000ll && eb < 0x7ff00000ll;
+}
+
+template <bool A_KM, bool B_KM>
 int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out, bool may_cut_rows = true) {
     const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
                        (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias)) &&
@@ -715,7 +839,8 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
             }
         }
     }
-    Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes, a.C32 != nullptr, a.nprob);
+    const bool p8_able = p8_ok(a, A_KM, B_KM) && !(a.flags & SUBGC_GEMM_NO_P8);
+    Plan pl = plan_for(a.M, a.N, a.K, ws != nullptr && plain, ws_bytes, a.C32 != nullptr, a.nprob, p8_able, B_KM && !A_KM);
     if (partials_only) {                                        // the LSTM cell kernel adds row-major planes: 128x128 split form only
         pl = Plan{0, 1, 0.0};
         const int64_t tiles = subgc::cdiv(a.M, 128) * subgc::cdiv(a.N, 128);
@@ -729,6 +854,10 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
     } else if (force == 128 || force == 256) {
         pl.big = force == 256;
         if (pl.big) pl.splits = 1;
+    } else if (a.flags & SUBGC_GEMM_TILE_P8) {
+        SUBGC_REQUIRE(p8_ok(a, A_KM, B_KM), "gemm_bf16: the eight-phase form needs K %% 8 == 0 (K-contiguous operands) and operands below 2 GiB");
+        pl.big = 2;
+        pl.splits = 1;
     }
     if (const int fs = SUBGC_GEMM_SPLITS_OF(a.flags); fs > 0 && !partials_only) {        // measurement scripts: K parts of this call
         SUBGC_REQUIRE(fs == 1 || (ws != nullptr && plain && (size_t)a.nprob * fs * a.M * a.N * sizeof(float) <= ws_bytes), "gemm_bf16: forced split needs the plain epilogue and %d planes of workspace", fs);
@@ -739,13 +868,14 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
         // Column sums ride the 256 x 256 workgroups for free (measured: 254 us with, 266 us without on 14000 x 4000 x 2000); in the 128 x 128
         // geometry the extra read + adds show (a quarter of the workgroups own tile column 0 at N = 512: 46 + 7 us against 34 + 5 + 9.6 for
         // the separate column-sum pass), so those plans run the two passes -- still one call.
-        if (a.cs_out && !pl.big) {
+        if (a.cs_out && pl.big == 0) {
             Args b = a;
             b.cs_out = nullptr;
             if (int rc = launch<G128, A_KM, B_KM>(b, ws, pl.splits, partials_only, s)) return rc;
             return subgc_colsum_bf16(a.A, a.lda, a.K, a.M, a.cs_out, a.cs_accum, a.m_dev, ws, ws_bytes, s);   // the planes are consumed: ws is free (stream order)
         }
     }
+    if (pl.big == 2) return launch_p8<A_KM, B_KM>(a, ws, pl.splits, partials_only, s);
     return pl.big ? launch<G256, A_KM, B_KM>(a, ws, pl.splits, partials_only, s) : launch<G128, A_KM, B_KM>(a, ws, pl.splits, partials_only, s);
 }
 

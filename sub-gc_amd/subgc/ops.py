@@ -160,14 +160,16 @@ def set_gemm_mode(mode):
 
 class gemm_tune:
     """Measurement-script switches of the GEMM dispatch, handed over per call in `flags` (the library keeps no tunable state):
-    `with ops.gemm_tune(no_splitk=True, no_skinny=True): ...` for subgc_gemm_f32, `tile=128|256` for subgc_gemm_bf16."""
+    `with ops.gemm_tune(no_splitk=True, no_skinny=True): ...` for subgc_gemm_f32, `tile=128|256|"p8"`, `no_p8`, `splits=n` for subgc_gemm_bf16."""
 
     f32_bits = 0
     b16_bits = 0
 
-    def __init__(self, no_splitk=False, no_skinny=False, tile=0):
+    TILE_BITS = {0: 0, 128: 64, 256: 128, "p8": 1 << 13}                      # SUBGC_GEMM_TILE128 / TILE256 / TILE_P8
+
+    def __init__(self, no_splitk=False, no_skinny=False, tile=0, no_p8=False, splits=0):
         self.f32 = (64 if no_splitk else 0) | (128 if no_skinny else 0)      # SUBGC_GEMM_NO_SPLITK | SUBGC_GEMM_NO_SKINNY
-        self.b16 = {0: 0, 128: 64, 256: 128}[tile]                            # SUBGC_GEMM_TILE128 / SUBGC_GEMM_TILE256
+        self.b16 = self.TILE_BITS[tile] | ((1 << 14) if no_p8 else 0) | ((splits & 15) << 8)    # ... | SUBGC_GEMM_NO_P8 | SUBGC_GEMM_SPLITS(n)
 
     def __enter__(self):
         self.prev = (gemm_tune.f32_bits, gemm_tune.b16_bits)

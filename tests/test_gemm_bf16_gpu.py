@@ -220,3 +220,66 @@ def test_gemm_pair_falls_back_to_two_calls_when_the_problems_differ():
     s1, s2 = torch.empty(512, 256, device=DEV), torch.empty(512, 256, device=DEV)
     ops.gemm_pair(a1, a1, b1, b1, s1, s2, tb=True)
     assert torch.equal(q1, q2) and torch.equal(s1, s2) and float((q1 - s1).abs().max()) <= 2e-5 * float(r1.abs().max())
+
+
+# ---- the 256 x 256 x 64 eight-phase form (csrc/gemm_bf16_p8.h), forced through the per-call flag bits -------------------------------
+P8_SHAPES = [("nt", 1280, 4000, 3000), ("nt", 300, 512, 1000), ("nn", 1280, 3000, 4000), ("nn", 200, 1000, 512), ("tn", 4000, 2000, 2176),
+             ("tn", 9488, 1000, 1357), ("nt", 129, 130, 72), ("nn", 5, 8, 8), ("tn", 24, 48, 8), ("nt", 4736, 1024, 2048), ("tn", 512, 1000, 21760),
+             ("nt", 257, 513, 64), ("nt", 256, 256, 128), ("nn", 511, 264, 200), ("tn", 264, 504, 1003), ("nt", 1000, 9488, 1000)]
+
+
+@pytest.mark.parametrize("mode,M,N,K", P8_SHAPES)
+def test_gemm_bf16_eight_phase_form_matches_fp64_product(mode, M, N, K):
+    """Every layout, ragged M / N edges (rows past the operand are fed as zeros by the DMA's range check), K tails that end inside a 64-deep
+    buffer (K % 64 in {8, 16, 40, 56}), one- and two-buffer K loops, odd and even K-tile counts."""
+    a, b, ref = operands(mode, M, N, K, seed=M + N + K, lda_pad=8, ldb_pad=16)
+    scale = float(ref.abs().max())
+    out = torch.full((M, N), float("nan"), device=DEV)
+    with ops.gemm_tune(tile="p8"):
+        ops.gemm(a, b, out, ta=mode == "tn", tb=mode == "nt")
+    assert float((out.double() - ref).abs().max()) < 2e-5 * scale
+    o16 = torch.empty(M, N + 4, device=DEV, dtype=BF)[:, :N]
+    with ops.gemm_tune(tile="p8"):
+        ops.gemm(a, b, o16, ta=mode == "tn", tb=mode == "nt")
+    assert float((o16.double() - ref).abs().max()) < 2.0 ** -8 * scale
+
+
+@pytest.mark.parametrize("mode,M,N,K,splits", [("nt", 1280, 4000, 3000, 3), ("nn", 1280, 2000, 4000, 2), ("tn", 4000, 1000, 14593, 4),
+                                                ("tn", 1024, 512, 16640, 8), ("nt", 700, 1000, 1000, 2)])
+def test_gemm_bf16_eight_phase_split_k(mode, M, N, K, splits):
+    """K parts of the eight-phase form: a part's range ends where the next one starts (the DMA masks at the part's end, not only at K), the
+    planes are summed by the shared reduce kernel with the epilogue."""
+    a, b, ref = operands(mode, M, N, K, seed=M + K)
+    bias = rnd(N, seed=9)
+    want = ref + bias.double()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    with ops.gemm_tune(tile="p8", splits=splits):
+        ops.gemm(a, b, out, ta=mode == "tn", tb=mode == "nt", bias=bias)
+    assert float((out.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+def test_gemm_bf16_eight_phase_epilogues_row_count_and_repeatability():
+    M, N, K = 700, 1000, 512
+    a, b, ref = operands("nt", M, N, K, seed=3)
+    bias, add = rnd(N, seed=5), rnd(M, N, seed=6)
+    keep = (torch.rand(M, N, generator=torch.Generator().manual_seed(7)) < 0.5).to(torch.uint8).to(DEV)
+    want = torch.relu(ref + bias.double() + add.double()) * keep.double() * 2.0
+    out, o16 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=BF)
+    with ops.gemm_tune(tile="p8"):
+        ops.gemm(a, b, out, tb=True, bias=bias, add=add, relu=True, keep=keep, keep_scale=2.0, out16=o16)
+        assert float((out.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+        assert torch.equal(o16, out.to(BF))
+        live = 437
+        m_dev = torch.tensor([live], device=DEV, dtype=torch.int32)
+        o2 = torch.full((M, N), 7.0, device=DEV)
+        ops.gemm(a, b, o2, tb=True, m_dev=m_dev)
+        assert float((o2[:live].double() - ref[:live]).abs().max()) < 2e-5 * float(ref.abs().max())
+        assert float((o2[live:] - 7.0).abs().max()) == 0.0
+        # the hand-placed waits order every LDS read behind the DMA that fills it: repeated launches under load are bit-identical
+        big_a, big_b, _ = operands("nt", 2048, 2304, 1000, seed=21)
+        first = torch.empty(2048, 2304, device=DEV)
+        ops.gemm(big_a, big_b, first, tb=True)
+        for _ in range(20):
+            again = torch.empty(2048, 2304, device=DEV)
+            ops.gemm(big_a, big_b, again, tb=True)
+            assert torch.equal(first, again)

@@ -177,3 +177,35 @@ def test_forked_weight_gradients_equal_the_in_line_ones():
     b[lo:lo + emb.numel()] = 0
     assert torch.equal(a, b)                                   # ... everything else is bit for bit the same
     assert float(b.abs().max()) > 0
+
+
+@pytest.mark.parametrize("K,M,N,splits", [(7000, 9488, 1000, 0), (7000, 4000, 1000, 3), (16640, 1024, 512, 8), (333, 200, 72, 0), (2176, 4000, 2000, 2),
+                                            (12001, 1024, 1024, 4), (65, 264, 40, 0)])
+def test_wgrad_eight_phase_form(K, M, N, splits):
+    """The 256 x 256 x 64 eight-phase form of the bf16 weight gradient (csrc/gemm_bf16_p8.h), forced: column sums read from the landed K-major
+    images of dY in the phases that read the same image, whole and split K (partial sums behind the planes), ragged rows."""
+    pad = lambda n: n + 8 + (-n) % 8
+    dy, x = rnd(K, pad(M), seed=K + M).to(BF)[:, :M], rnd(K, pad(N), seed=K + N + 1).to(BF)[:, :N]
+    wantW, wantb = dy.double().t() @ x.double(), dy.double().sum(0)
+    sw, sb = float(wantW.abs().max()), float(wantb.abs().max())
+    with ops.gemm_tune(tile="p8", splits=splits):
+        dW, db = torch.full((M, N), float("nan"), device=DEV), torch.full((M,), float("nan"), device=DEV)
+        ops.wgrad(dy, x, dW, db)
+        assert float((dW.double() - wantW).abs().max()) < 2e-5 * sw
+        assert float((db.double() - wantb).abs().max()) < 2e-5 * max(sb, K ** 0.5)
+        dW2, db2 = rnd(M, N, seed=3), rnd(M, seed=4)
+        w0, b0 = dW2.clone(), db2.clone()
+        ops.wgrad(dy, x, dW2, db2, accum=True, db_accum=True)
+        assert float((dW2.double() - w0.double() - wantW).abs().max()) < 2e-5 * sw
+        assert float((db2.double() - b0.double() - wantb).abs().max()) < 2e-5 * max(sb, K ** 0.5)
+        again_W, again_b = torch.empty_like(dW), torch.empty_like(db)
+        ops.wgrad(dy, x, again_W, again_b)
+        assert torch.equal(again_W, dW) and torch.equal(again_b, db)         # fixed summation orders
+        live = K // 3
+        g = dy.clone(); g[live:] = float("nan")
+        h = x.clone(); h[live:] = float("nan")
+        m_dev = torch.tensor([live], device=DEV, dtype=torch.int32)
+        ops.wgrad(g, h, dW, db, m_dev=m_dev)
+        wW, wb = dy[:live].double().t() @ x[:live].double(), dy[:live].double().sum(0)
+        assert float((dW.double() - wW).abs().max()) < 2e-5 * max(float(wW.abs().max()), 1.0)
+        assert float((db.double() - wb).abs().max()) < 2e-5 * max(float(wb.abs().max()), K ** 0.5)

@@ -58,9 +58,10 @@ def main():
     ap.add_argument("--shape", default="")
     ap.add_argument("--pad", type=int, default=0, help="row pitch of every operand rounded up to this many elements (64 = 128-byte aligned rows)")
     ap.add_argument("--out16", action="store_true", help="bf16 destination (what torch.mm on bf16 tensors writes) instead of fp32")
-    ap.add_argument("--tile", type=int, default=0, choices=(0, 128, 256), help="force the workgroup tile (SUBGC_GEMM_TILE128 / TILE256 flag bits)")
+    ap.add_argument("--tile", default="0", choices=("0", "128", "256", "p8"), help="force the workgroup form (SUBGC_GEMM_TILE128 / TILE256 / TILE_P8 flag bits)")
+    ap.add_argument("--no-p8", action="store_true", help="forbid the eight-phase form (SUBGC_GEMM_NO_P8)")
     a = ap.parse_args()
-    ops.gemm_tune.b16_bits = {0: 0, 128: 64, 256: 128}[a.tile]
+    ops.gemm_tune.b16_bits = ops.gemm_tune.TILE_BITS[a.tile if a.tile == "p8" else int(a.tile)] | ((1 << 14) if a.no_p8 else 0)
     sh = shapes(a.config)
     if a.shape:
         sh = [("custom",) + tuple(int(x) if i else x for i, x in enumerate(s.split(","))) + (1,) for s in a.shape.split(";")]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does the bf16 GEMM's cost model (gemm_bf16.hip plan_for) pick the fastest form?  Records every subgc_gemm_bf16 / _wgrad call of ONE real
 train step of a bf16 config (shape, leading dimensions, epilogue), then replays each distinct shape stand-alone under the plan's own choice
-and under every forced (tile, K parts) form the call's epilogue allows (SUBGC_GEMM_TILE128 / TILE256 / SUBGC_GEMM_SPLITS(n) flag bits).
+and under every forced (tile, K parts) form the call's epilogue allows (SUBGC_GEMM_TILE128 / TILE256 / TILE_P8 / SUBGC_GEMM_SPLITS(n) flag bits).
 
     python tools/gemm_bf16_sweep.py [--config full_gc_kar|flickr] [--min-us 15]
 """
@@ -40,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="full_gc_kar", choices=["full_gc_kar", "flickr"])
     ap.add_argument("--min-us", type=float, default=0.0)
+    ap.add_argument("--top", type=int, default=3, help="how many of the fastest forced forms to list per shape")
     a = ap.parse_args()
     cfg = bench.CONFIGS[a.config]
     torch.manual_seed(1234)
@@ -99,9 +100,9 @@ def main():
         best, best_name = auto, "auto"
         plain = not ha and not hk
         res = []
-        for tile, tbit in ((128, 64), (256, 128)):
+        for tile, tbit in ((128, 64), (256, 128), ("p8", 1 << 13)):
             for sp in (1, 2, 3, 4, 6, 8):
-                if sp > 1 and (not plain or tile == 256 and mode != "tn" and False):
+                if sp > 1 and not plain:
                     continue
                 if sp > 1 and (K + 31) // 32 // sp < 12:
                     continue
@@ -117,7 +118,7 @@ def main():
         auto = min(auto, timeit(run))                      # again, warm: the first timing of a shape also pays its allocations' first touch
         if best > auto:
             best, best_name = auto, "auto"
-        rows.append((cnt * auto, cnt, key, auto, best, best_name, sorted(res)[:3]))
+        rows.append((cnt * auto, cnt, key, auto, best, best_name, sorted(res)[:a.top]))
     rows.sort(key=lambda r: -r[0])
     tot_auto = sum(r[1] * r[3] for r in rows)
     tot_best = sum(r[1] * r[4] for r in rows)
