@@ -509,6 +509,7 @@ def main():
     ap.add_argument("--chains", type=int, default=-1, help="experiment: ops.RECURRENCE_CHAINS (2 = the recurrence as two interleaved chains on two streams, 0 = one chain)")
     ap.add_argument("--fuse-mid", type=int, default=-1, help="experiment: ops.FUSE_MID (1 = cell 1 + query product + attention of a decoder step as one launch per direction, "
                     "3 = one workgroup per CU, 0 = the three launches)")
+    ap.add_argument("--no-p8", action="store_true", help="experiment (bf16 configs): SUBGC_GEMM_NO_P8 on every subgc_gemm_bf16 call -- the ring forms only (A/B of the eight-phase form)")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -538,6 +539,8 @@ def main():
     model.inputs_resident = bool(a.plan_side_stream)
     if a.chains >= 0:
         ops.RECURRENCE_CHAINS = a.chains
+    if a.no_p8:
+        ops.gemm_tune.b16_bits |= 1 << 14
     if a.fuse_mid >= 0:
         ops.FUSE_MID = a.fuse_mid
     if a.no_pair_launches:

@@ -673,8 +673,10 @@ using G256 = Geo<256, 256, 2, 2>;
 // for a bf16-only destination); `slots` workgroups run at a time; a split costs the partial planes' round trip at ~3 TB/s + a launch.
 struct Plan { int big; int splits; double cost; };            // big: 0 = 128 x 128 ring, 1 = 256 x 256 ring, 2 = 256 x 256 eight-phase (gemm_bf16_p8.h)
 // Round 6: the eight-phase form.  Measured (tools/p8_probe.py, tools/gemm_bf16_sweep.py): 1.37 us per 64-deep K-tile and workgroup with all CUs
-// busy (0.685 per 32 deep; 1.56 when B is K-major: its sub-tile images are 64-byte row pieces), 19 us per tile round outside the K loop
-// with an fp32 destination, 16 with bf16 only.
+// busy (0.685 per 32 deep; 1.56 when B is K-major: its sub-tile images are 64-byte row pieces), 20 us per tile round outside the K loop
+// with an fp32 destination, 17 with bf16 only -- and 10 us once per launch that only shows INSIDE a train step (tools/gemm_insitu_ab.py): a
+// lone 128 KiB workgroup per CU starts on operands the step left in HBM, and one round of K <= 1024 (the GCN products) then runs slower than the
+// ring forms although the warm stand-alone sweep says the opposite.
 inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool out32 = true, int nprob = 1, bool allow_p8 = false, bool b_km_only = false) {
     const int kt = (int)subgc::cdiv(K, BK);
     Plan best{0, 1, 1e30};
@@ -682,13 +684,14 @@ inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool 
         const int64_t tiles = nprob * (big ? subgc::cdiv(M, 256) * subgc::cdiv(N, 256) : subgc::cdiv(M, 128) * subgc::cdiv(N, 128));
         const int slots = big ? 256 : 512;
         const double c = big == 2 ? (b_km_only ? 0.78 : 0.685) : big ? 0.85 : 0.67;
-        const double e = big == 2 ? (out32 ? 19.0 : 16.0) : (big ? 24.0 : 12.0) * (out32 ? 1.0 : 0.55);
+        const double e = big == 2 ? (out32 ? 20.0 : 17.0) : (big ? 24.0 : 12.0) * (out32 ? 1.0 : 0.55);
+        const double once = big == 2 ? 10.0 : 0.0;
         for (int s = 1; s <= 8; ++s) {
             if (s > 1 && (!may_split || (kt + s - 1) / s < 12 || (size_t)nprob * s * M * N * sizeof(float) > ws_bytes)) break;
             const int per = (kt + s - 1) / s;
             const int64_t rounds = (tiles * s + slots - 1) / slots;
             const double tail = s > 1 ? 3.0 + (double)nprob * (s + 1) * M * N * 4.0 / 3.0e6 : 0.0;       // us: planes written + read back
-            const double cost = rounds * (per * c + (s > 1 ? e * 0.7 : e)) + tail;
+            const double cost = rounds * (per * c + (s > 1 ? e * 0.7 : e)) + tail + once;
             if (cost < best.cost - 1e-9) best = Plan{big, s, cost};
         }
     }

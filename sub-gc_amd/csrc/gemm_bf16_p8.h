@@ -19,7 +19,8 @@
 //   MFMA    P%4 = 0: A0 x B0;  1: A0 x B1;  2: A1 x B1;  3: A1 x B0 (B0 is kept in registers for the whole K-tile)
 //   DMA     one sub-tile image per phase, three in flight:  P0 -> O.A1 (tile t+1) | P1 E.B0, P2 E.A0, P3 E.B1, P4 E.A1 (tile t+2) |
 //           P5 O.B0, P6 O.A0, P7 O.B1 (tile t+3)
-//   waits   vmcnt(6) in P3 (retires O: read in P4..P6) and in P7 (retires E: read in P0..P2 of the next iteration)
+//   waits   vmcnt(10) in every phase but P%4 = 2: the image the NEXT phase reads was issued six sub-tiles ago, so five younger ones (80 KiB
+//           per CU) stay in flight; an image has five phases (~1.7 us) to land
 // Every image is re-staged two phases after the phase that read it (B0: one phase after, its four reads are retired by the lgkmcnt in front
 // of P0's first barrier), and read one phase after the wait that retires it; with the two wave groups half a phase apart both rules hold for
 // either group (the later group's reads are issued before the barrier that the earlier group's next DMA follows).
@@ -264,7 +265,10 @@ __device__ __forceinline__ void mainloop(const Args& p, unsigned char* smem, int
         if constexpr (P == 5) db.template issue<1, 0>(smem, kE + 3 * KT, kend);
         if constexpr (P == 6) da.template issue<1, 0>(smem, kE + 3 * KT, kend);
         if constexpr (P == 7) db.template issue<1, 1>(smem, kE + 3 * KT, kend);
-        if constexpr (PH == 3) wait_vmcnt<6>();
+        // what the NEXT phase reads must have landed: the image issued six sub-tiles ago (five younger ones = 10 instructions stay in flight).
+        // P%4 = 2 has nothing to wait for (the next phase reads nothing).  [First version: vmcnt(6) in P%4 = 3 only -- every image then had to
+        // land within three phases (~1 us) of its issue, which L2-warm operands do and HBM-cold ones (a train step's weights) do not.]
+        if constexpr (PH != 2) wait_vmcnt<10>();
         if constexpr (PH == 0) {                                // B0's reads are done: its image may be re-staged next phase
             if (CS && do_cs) wait_lgkm<(A_EARLY + 2 > 15 ? 15 : A_EARLY + 2)>();
             else wait_lgkm<(A_EARLY > 15 ? 15 : A_EARLY)>();
@@ -298,7 +302,7 @@ __device__ __forceinline__ void mainloop(const Args& p, unsigned char* smem, int
     db.template issue<1, 0>(smem, kbeg + KT, kend);
     da.template issue<1, 0>(smem, kbeg + KT, kend);
     db.template issue<1, 1>(smem, kbeg + KT, kend);
-    wait_vmcnt<6>();
+    wait_vmcnt<10>();                                           // E.B0 and E.A0 (phase 0's reads) have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) __builtin_amdgcn_s_barrier();                  // the second wave row runs half a phase behind the first

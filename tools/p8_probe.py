@@ -52,7 +52,30 @@ def operands(mode, M, N, K, pad):
     return a, b
 
 
+COLD = {"on": False, "buf": None}
+
+
+def timeit_cold(fn, iters):
+    """each timed call behind a 1 GiB fill: operands come from HBM, not from the Infinity Cache the previous call left them in"""
+    if COLD["buf"] is None:
+        COLD["buf"] = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)
+    tot = 0.0
+    for i in range(iters + 2):
+        COLD["buf"].fill_(i & 255)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            tot += a.elapsed_time(b)
+    return tot / iters * 1e3
+
+
 def run(mode, M, N, K, pad, iters, out16, forms):
+    global timeit
+    if COLD["on"]:
+        timeit = timeit_cold
     a, b = operands(mode, M, N, K, pad)
     out = torch.empty(M, N, device=DEV, dtype=BF if out16 else torch.float32)
     o16 = torch.empty(M, N, device=DEV, dtype=BF)
@@ -84,7 +107,9 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--out16", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--cold", action="store_true", help="flush the caches (1 GiB fill) before every timed call")
     a = ap.parse_args()
+    COLD["on"] = a.cold
     forms = [("auto", dict(no_p8=True)), ("r256", dict(tile=256)), ("p8", dict(tile="p8")), ("p8x2", dict(tile="p8", splits=2)), ("p8x4", dict(tile="p8", splits=4))]
     print("# us per launch (TF/s); fp32 destination unless --out16; `pad` = row pitch multiple in elements")
     print(f"{'mode':4s} {'M':>6s} {'N':>6s} {'K':>6s} {'pad':>3s} " + " ".join(f"{n:>14s}" for n, _ in forms) + f" {'torch(bf16 out)':>16s}")
