@@ -515,6 +515,44 @@ def grd_cases(meta):
     save("grd", out=out)
 
 
+def restore_cases(meta):
+    """models/__init__.py:14-41 `optimistic_restore` run on fabricated checkpoints: (a) a "COCO" checkpoint with a larger vocabulary, one
+    unknown key and one key missing, into a smaller-vocabulary network through a word map with kept (-1) rows -> False; (b) a same-shape
+    checkpoint through a permuting word map -> True.  Saved: the network's values before, the checkpoint, the word map, the values after."""
+    import models as ref_models
+    out = {}
+    np.save("data/restore_obj_names.npy", np.array(["__background__"] + ["obj%d" % i for i in range(11)]))
+    np.save("data/restore_rel_names.npy", np.array(["__background__"] + ["rel%d" % i for i in range(5)]))
+    small = dict(rnn_size=16, input_encoding_size=16, att_feat_size=24, gcn_dim=12, fc_feat_size=10, att_hid_size=8, gcn_layers=1,
+                 obj_name_path="data/restore_obj_names.npy", rel_name_path="data/restore_rel_names.npy")
+    for case, (v_net, v_ckpt, tamper) in dict(a=(30, 50, True), b=(50, 50, False)).items():
+        torch.manual_seed(100 + v_net)
+        net = ref_models.setup(ref_opt(vocab_size=v_net, **small))
+        torch.manual_seed(200 + v_ckpt)
+        ck = {k: v.clone() for k, v in ref_models.setup(ref_opt(vocab_size=v_ckpt, **small)).state_dict().items()}
+        if tamper:
+            ck["not_in_the_network.weight"] = torch.randn(3, 5)
+            del ck["ctx2att.bias"]
+        rs = np.random.RandomState(7 + v_net)
+        wm = rs.randint(0, v_ckpt + 1, size=v_net + 1).astype(np.int64)
+        wm[rs.rand(v_net + 1) < 0.3] = -1
+        np.save("data/word_mapping.npy", wm)
+        before = {k: np_(v) for k, v in net.state_dict().items()}
+        ok = ref_models.optimistic_restore(net, ck)
+        for k, v in before.items():
+            out[f"{case}.before.{k}"] = v
+        for k, v in ck.items():
+            out[f"{case}.ckpt.{k}"] = np_(v)
+        for k, v in net.state_dict().items():                   # only what the restore changed: the rest must equal `before`
+            if not np.array_equal(np_(v), before[k]):
+                out[f"{case}.after.{k}"] = np_(v)
+        out[f"{case}.word_map"] = wm
+        out[f"{case}.ok"] = np.array(int(ok))
+        o = {k: v for k, v in vars(ref_opt(vocab_size=v_net, **small)).items() if not k.endswith("_name_path")}
+        meta[f"restore_{case}"] = dict(opt=dict(o, sg_obj_cnt=12, sg_pred_cnt=6), ckpt_vocab=v_ckpt, returned=bool(ok))
+    np.savez_compressed(os.path.join(HERE, "restore_out.npz"), **out)
+
+
 def main():
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     enter_scratch()
@@ -530,6 +568,13 @@ def main():
         with open(os.path.join(HERE, "meta.json")) as f:
             meta = json.load(f)
         grd_cases(meta)
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        return
+    if "--only-restore" in sys.argv:
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        restore_cases(meta)
         with open(os.path.join(HERE, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, sort_keys=True, default=str)
         return
@@ -584,6 +629,7 @@ def main():
     ss_case(w, meta)
     loader_cases(meta)
     grd_cases(meta)
+    restore_cases(meta)
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True, default=str)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
