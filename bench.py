@@ -310,25 +310,17 @@ def gemm_roofline_of(fn, leg, note):
             "gemm_ms": round(gemm_ms, 3), "gemm_gflop": round(flops / 1e9, 2), "note": note}
 
 
-def roofline_block(cfg, batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm_ms, ms_per_step, traffic, traffic_note, steps, busy_ms=None):
-    """`gemm_ms`: SUM of the GEMM launches' durations over the sampled steps; `busy_ms`: the length of the UNION of their intervals
-    (subgc_prof_last_busy).  The two are equal while the launches run one after the other; with the recurrence cut into two chains on
-    two streams (ops.RECURRENCE_CHAINS) two products overlap, each takes longer for sharing the chip and the sum counts that time
-    twice -- the roofline's denominator is the wall time the GEMM family held the device, i.e. the union; the per-launch average (what a
-    rocprofv3 --stats row shows) stays the sum / launches, and both are reported."""
-    busy_ms = gemm_ms if not busy_ms else busy_ms
-    achieved = flops_step * n_s / (busy_ms * 1e-3) / 1e12 if busy_ms > 0 else 0.0
-    extra = {} if abs(busy_ms - gemm_ms) < 1e-6 * max(gemm_ms, 1e-9) else {
-        "gemm_kernel_ms_sum_per_step": round(gemm_ms / n_s, 3), "gemm_overlap": round(gemm_ms / busy_ms, 3),
-        "overlap_note": "two-chain recurrence: launches of two streams overlap; gemm_ms_per_step = union of the launch intervals (wall time the "
-                        "family held the device), gemm_kernel_ms_sum_per_step = sum of the per-launch durations (what rocprofv3 --stats adds up)"}
-    return {"bound": "mfma", "kernel": cfg["kernel"], "achieved": round(achieved, 2), **extra,
+def roofline_block(cfg, batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm_ms, ms_per_step, traffic, traffic_note, steps):
+    """`gemm_ms`: SUM of the GEMM launches' durations over the sampled steps (HIP events on the stream the launches run on; one queue, so the
+    sum is also the wall time the family held the device)."""
+    achieved = flops_step * n_s / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": cfg["kernel"], "achieved": round(achieved, 2),
             "peak": cfg["peak"], "unit": "TFLOP/s", "frac": round(achieved / cfg["peak"], 4),
             "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": round(alg_bytes_launch), "launches_per_step": n_launch // n_s,
             "event_sampled_steps": f"{n_s} of the {steps} timed steps ({n_launch} launches)",
             "avg_launch_us": round(1e3 * gemm_ms / max(n_launch, 1), 2),
-            "gemm_ms_per_step": round(busy_ms / n_s, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
+            "gemm_ms_per_step": round(gemm_ms / n_s, 3), "gemm_gflop_per_step": round(flops_step / 1e9, 2),
             # whole step (all kernels + gaps) against the MFMA peak, with the GEMM FLOPs the step actually EXECUTES (the reference's
             # nominal live-graph FLOPs include masked-out decoder steps the packed path never computes: not a roofline figure)
             "whole_step_frac_executed": round(flops_step / (ms_per_step * 1e-3) / 1e12 / cfg["peak"], 4)}
@@ -367,7 +359,6 @@ def train_config_leg(name, dev, steps=8, warmup=3, opt_over=None):
     dt = time.perf_counter() - t0
     _lib.prof_enable("gemm", False)
     n_launch, gemm_ms, _ = _lib.prof_collect("gemm")
-    busy_ms = _lib.prof_last_busy("gemm")
     ops.FLOPS.update(on=True, gemm=0.0, gemm_bytes=0.0, gemm_calls=0)
     step()
     torch.cuda.synchronize()
@@ -378,7 +369,7 @@ def train_config_leg(name, dev, steps=8, warmup=3, opt_over=None):
     res = {"metric": cfg["metric"], "value": round(B * steps / dt, 2), "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": round(ms, 3), "dtype": cfg["dtype"], "data": "synthetic",
            "config": {"workload": cfg["workload"], "images_per_gpu": B, "decoder": "packed", "includes": "fwd + bwd + fused clip+Adam"},
-           "roofline": roofline_block(cfg, B, flops_step, ops.FLOPS["gemm_bytes"] / calls, n_launch, len(smp), gemm_ms, ms, traffic, note, steps, busy_ms),
+           "roofline": roofline_block(cfg, B, flops_step, ops.FLOPS["gemm_bytes"] / calls, n_launch, len(smp), gemm_ms, ms, traffic, note, steps),
            "final_loss": round(float(loss.item()), 4)}
     del model, lw, batch, adam, step
     torch.cuda.empty_cache()
@@ -499,16 +490,10 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true", help="accepted for older command lines: the optimizer step is on by default")
     ap.add_argument("--pitch-f32", type=int, default=-1, help="experiment: row pitch (elements) of the fp32 recurrent operands (ops.PITCH['f32']; 32 = 128 bytes)")
     ap.add_argument("--no-fold-bias", action="store_true", help="experiment: bias gradients as separate column-sum launches (functions.FOLD_BIAS_SUMS = False)")
-    ap.add_argument("--fork-wgrads", action="store_true", help="experiment: the encoder's weight-gradient products on side streams beside the backward chain (ops.FORK_WGRADS = True)")
     ap.add_argument("--no-pair-launches", action="store_true", help="experiment: the two same-shape products of a GCN unit pair as two launches (ops.PAIR_LAUNCHES = False)")
     ap.add_argument("--share-attention-sets", type=int, default=-1, help="Full-GC configs: 1 = attention sets once per image (ties the att_embed dropout mask "
                     "across an image's sentences: NOT the reference's semantics), 0 = the reference's independent masks on replicated rows (model default)")
-    ap.add_argument("--plan-side-stream", action="store_true", help="experiment: declare the batch resident (model.inputs_resident): the packed decoder's row "
-                    "plan runs on a side stream instead of queueing behind the previous step (measured: no gain, round 5)")
     ap.add_argument("--dedup", type=int, default=-1, help="experiment (Full-GC): opt.dedup_att_embed (1 = att_embed once per node row + masked gather per copy, 0 = on the replicated rows)")
-    ap.add_argument("--chains", type=int, default=-1, help="experiment: ops.RECURRENCE_CHAINS (2 = the recurrence as two interleaved chains on two streams, 0 = one chain)")
-    ap.add_argument("--fuse-mid", type=int, default=-1, help="experiment: ops.FUSE_MID (1 = cell 1 + query product + attention of a decoder step as one launch per direction, "
-                    "3 = one workgroup per CU, 0 = the three launches)")
     ap.add_argument("--no-p8", action="store_true", help="experiment (bf16 configs): SUBGC_GEMM_NO_P8 on every subgc_gemm_bf16 call -- the ring forms only (A/B of the eight-phase form)")
     ap.add_argument("--ss-prob", type=float, default=0.0, help="scheduled-sampling probability (train.py raises it from epoch 5; the headline workload is 0)")
     a = ap.parse_args()
@@ -536,17 +521,10 @@ def main():
     model = models.setup(opt).to(dev).train()
     if a.pitch_f32 >= 0:
         ops.PITCH["f32"] = a.pitch_f32
-    model.inputs_resident = bool(a.plan_side_stream)
-    if a.chains >= 0:
-        ops.RECURRENCE_CHAINS = a.chains
     if a.no_p8:
         ops.gemm_tune.b16_bits |= 1 << 14
-    if a.fuse_mid >= 0:
-        ops.FUSE_MID = a.fuse_mid
     if a.no_pair_launches:
         ops.PAIR_LAUNCHES = False
-    if a.fork_wgrads:
-        ops.FORK_WGRADS = True
     if a.no_fold_bias:
         import subgc.functions as F_
         F_.FOLD_BIAS_SUMS = False
@@ -579,7 +557,7 @@ def main():
         dt_ = time.perf_counter() - t0_
         _lib.prof_enable("gemm", False)
         _, ms_, _ = _lib.prof_collect("gemm")
-        return dt_, len(smp), _lib.prof_last_busy("gemm") or ms_, last
+        return dt_, len(smp), ms_, last
 
     def fence():
         torch.cuda.synchronize()
@@ -617,7 +595,6 @@ def main():
     ops.FLOPS["on"] = False
     if rank == 0:
         n_launch, gemm_ms, _nominal = _lib.prof_collect("gemm")
-        busy_ms = _lib.prof_last_busy("gemm")
         flops_step = ops.FLOPS["gemm"]
         alg_bytes_launch = ops.FLOPS["gemm_bytes"] / max(ops.FLOPS["gemm_calls"], 1)
         n_s = max(len(sampled), 1)
@@ -633,7 +610,7 @@ def main():
                        "decoder": "packed (length-sorted, loss-only: masked-out steps skipped; identical loss and gradients)",
                        "includes": "fwd + bwd" + (" + RCCL grad all-reduce" if world > 1 else "") + (" + fused clip+Adam" if adam else "")
                                    + (f" + scheduled sampling p={a.ss_prob} (per-step logits and draws)" if a.ss_prob > 0 else "")},
-            "roofline": roofline_block(cfg, a.batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm_ms, ms_per_step, traffic, traffic_note, a.steps, busy_ms),
+            "roofline": roofline_block(cfg, a.batch, flops_step, alg_bytes_launch, n_launch, n_s, gemm_ms, ms_per_step, traffic, traffic_note, a.steps),
             "final_loss": round(final_loss, 4),
         }
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_gemm_f32.json")

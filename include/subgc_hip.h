@@ -38,13 +38,17 @@ extern "C" {
 
 #define SUBGC_ABI_VERSION 1
 int subgc_version(void);
-/* Stream ordering without a host round trip: everything enqueued on `signaller` so far completes before anything enqueued on `waiter`
- * from now on starts (hipEventRecord + hipStreamWaitEvent on a pooled event).  Used to run a layer's weight-gradient product on a side
- * stream beside the data-gradient chain of the backward (ops.wgrad_forked) and to join the side streams again.                        */
-int subgc_stream_wait(void* waiter, void* signaller);
 const char* subgc_last_error(void);
 /* name of the gfx target the kernels were compiled for ("gfx950") */
 const char* subgc_arch(void);
+/* Debug bounds mode (off by default; returns the previous setting).  While on, every entry point that consumes an index tensor it did not
+ * produce itself -- rel_ind (csr_build, gcn_*), gpn_obj_ind (gpn_prep / gpn_test_prep / gpn_select, with the reference's node-list-vs-mask
+ * consistency assert, gpn.py:117-118), sub-graph node lists (subgraph_pool_*, subgraph_nms*, pack_rows), token ids (embed_*, token_rows),
+ * criterion targets (masked_nll_*, nll_logsoftmax_bwd), class ids (class_partials) -- validates it on the device BEFORE launching its
+ * kernels and returns SUBGC_EINVAL with the tensor's name, the first offending position and value in subgc_last_error(), as the
+ * reference fails with an IndexError / AssertionError on a bad loader tensor.  Costs one launch and one stream synchronisation per
+ * checked tensor; skipped on a capturing stream.  With the mode off the kernels keep their documented clamping behaviour.           */
+int subgc_debug_bounds(int on);
 
 /* ---- profiling hook used by bench.py (HIP events on the launch stream) -------------------
  * While enabled, every launch of kernel family `family` (see SUBGC_FAM_*) is bracketed by a
@@ -57,13 +61,8 @@ const char* subgc_arch(void);
 #define SUBGC_FAM_GCN 4
 #define SUBGC_FAM_POOL 5
 #define SUBGC_FAM_SOFTMAX 6
-#define SUBGC_FAM_MID 7       /* the fused row-local middle of a train-decoder step: subgc_mid_fwd / subgc_mid_bwd (work = the query product's flops) */
 int subgc_prof_enable(int family, int on);
 int subgc_prof_collect(int family, int64_t* launches, double* total_ms, double* total_work);
-/* busy_ms of the LAST subgc_prof_collect(family): the length of the union of the launches' [start, stop] intervals (events of all
- * streams on one clock).  Equals total_ms while the family's launches run one after the other; smaller when launches of two streams
- * overlap (subgc_recurrence_*_pair) -- the wall time during which the family held the device, the denominator of a roofline.     */
-int subgc_prof_last_busy(int family, double* busy_ms);
 /* bytes the family's launches of the LAST subgc_prof_collect actually moved, where an entry point reports them separately from its
  * algorithmic `work` (the LSTM cell kernels: split-K planes of the gate products, additive gate terms and saved gates included) */
 int subgc_prof_last_moved(int family, double* moved_bytes);
@@ -365,15 +364,6 @@ int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, 
                         int rows_h, int rows_h2, int bf16_bits, int gemm_flags, void* workspace, size_t ws_bytes,
                         void* stream);
 
-/* ... with a hipEvent_t (may be NULL) that `stream` waits for BETWEEN the product and the cell update: the g1 rows (x -> gates) may still
- * be in production on another stream while the product runs (scheduled sampling, AttModel.py:157-167: the sampled words' embedding and
- * x -> gates rows are computed beside the recurrent product instead of in front of it).                                                */
-int subgc_lstm_fwd_gemm_ev(const void* x, int64_t ldx, const void* w, int64_t ldw, int K, float* pre, int64_t ldpre,
-                           const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1,
-                           const float* c_prev, float* c, void* h, int64_t ldh, void* h2, int64_t ldh2,
-                           const uint8_t* keep, float keep_scale, void* hdrop, int64_t ldhd, float* gates, int S, int R,
-                           int rows_h, int rows_h2, int bf16_bits, int gemm_flags, void* workspace, size_t ws_bytes,
-                           void* event_before_cell, void* stream);
 
 /* dh (up to two sources summed: dh_a, dh_b, either may be NULL) and dc (may be NULL) ->
  * dpre [S,4R] and dc_prev.  dh_drop (optional) is a gradient that arrives through the dropout
@@ -704,8 +694,6 @@ int subgc_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, i
                         const int32_t* m_dev, void* stream);
 /* y[c, r] = bf16(x[r, c]) (the W^T snapshots: every data-gradient product becomes an x W^T one) */
 int subgc_transpose_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, void* stream);
-/* y[c, r] = x[r, c], fp32 (the K-major copy of the h2att weight that subgc_mid_fwd streams under fp32 operands) */
-int subgc_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, void* stream);
 int subgc_copy2d_b16(const uint16_t* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int cols, void* stream);
 
 /* ---- on-device batch assembly (dataloaders/dataloader.py:269-367) ----------------------------------------
@@ -734,13 +722,6 @@ int subgc_caption_labels(const int64_t* captions, int64_t ld, int S, int seq_len
  * tok[r * tok_stride] = inverse-CDF draw (index order, u[r]) from softmax(logits[r, :V]); other rows keep their word.
  * `logits` may be raw or log-normalised (the draw is shift-invariant).                                              */
 int subgc_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
-/* scheduled sampling on the rows that FIRE only: ss_plan lists, per step t >= 1, the rows r < live[t] whose selector uniform is below
- * prob (fired [T, S] int32, ascending; count [T]; step 0 fires nothing); multinomial_rows_list draws for row rows[i] (i < *count) from the
- * COMPACT logits row i -- with a gathered GEMM (subgc_gemm_f32 a_rows / m_dev) the previous step's logits exist only for those rows.   */
-int subgc_ss_plan(const float* sel_u, int64_t ld_sel, const int32_t* live, float prob, int T, int S, int32_t* fired, int32_t* count,
-                  void* stream);
-int subgc_multinomial_rows_list(const float* logits, int64_t ld, int max_rows, int V, const int32_t* rows, const int32_t* count,
-                                const float* u, int64_t* tok, int64_t tok_stride, void* stream);
 int subgc_multinomial_rows(const float* logits, int64_t ld, int rows, int V, const float* u, const float* sel_u,
                            float prob, int64_t* tok, int64_t tok_stride, void* stream);
 
@@ -800,24 +781,6 @@ int subgc_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, cons
 int subgc_clip_adam_step_zero(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
                               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                               int step, float grad_scale, uint16_t* p_bf16, void* stream);
-
-/* ---- the row-local middle of a train-decoder step as one launch (csrc/recurrent_mid.hip) ----------------------------------------------
- * replaces, per step: subgc_lstm_fwd (attention LSTM cell, AttModel.py:411-413) + the h2att product (:453) + subgc_attn_fwd_q (:453-466).
- * Between the two gate products of a step everything is local to a sentence row, so a workgroup that owns a few rows runs cell update,
- * query product (matrix pipe, Wq streamed from L2) and attention back to back with the rows' h1 / query / scores in LDS.
- * Cell arguments as subgc_lstm_fwd (g0 = `parts` pre-activation planes `plane_stride` floats apart, e.g. the split-K planes of the gate
- * product; g1 / g2 / b0 / b1 additive terms; h, h2 destinations with row limits; gates = the saved activated gates), query arguments
- * Wq = the h2att weight as the product streams it: bf16 operands -> [A, R] (rows K-contiguous, matrix pipe), fp32 operands -> its
- * TRANSPOSE [R, A] (K-major, VALU form: subgc_transpose_f32); bq [A], q_out [m, A] (the summed query rows, read by the backward),
- * attention arguments as subgc_attn_fwd.  fp32 operands: m <= 1024.
- * bf16_bits: bit 0 = h / h2 / ctx destinations and Wq are bf16, bit 1 = u and v are bf16 (both or neither).  flags: bit 0 = one
- * workgroup per CU (LDS request above half a CU).  debug_stamps (NULL in
- * production): [workgroups][8] int64 wall-clock stamps at the phase boundaries (tools/mid_probe.py).  Needs R % 8 == 0, A % 4 == 0, A <= 512, m <= 4096, 16-byte aligned rows.        */
-int subgc_mid_fwd(const float* g0, int64_t ld0, int parts, int64_t plane_stride, const float* g1, int64_t ld1, const float* g2, int64_t ld2,
-                  const float* b0, const float* b1, const float* c_prev, float* c, void* h, int64_t ldh, int rows_h, void* h2, int64_t ldh2,
-                  int rows_h2, float* gates, const void* Wq, int64_t ldWq, const float* bq, float* q_out, const void* u, const void* v,
-                  const float* w_a, const float* b_a, const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha,
-                  int n_stride, int m, int R, int A, int bf16_bits, int flags, int64_t* debug_stamps, void* stream);
 
 /* ======================================================================================
  * The teacher-forced recurrence as ONE call per direction (AttModel.py:157-175: the T-step loop around TopDownCore, :400-431).
@@ -914,11 +877,6 @@ typedef struct SubgcRecurrence {
     float* dC1_out;
     float* dC2_in;
     float* dC2_out;
-    int32_t fuse_mid;            /* bit 0: cell 1 + query product + attention of a FORWARD step as ONE launch (subgc_mid_fwd; per-sentence attention
-                                    sets only -- shared sets keep the three launches; opt-in: measured slower, ops.FUSE_MID); bit 1: one workgroup per CU */
-    int32_t pad_;
-    const void* WqT;             /* fuse_mid with fp32 operands: the TRANSPOSED query weight [R, A] (K-major, subgc_transpose_f32); unused under bf16 */
-    int64_t ldWqT;
 } SubgcRecurrence;
 int subgc_recurrence_sizeof(void);      /* sizeof(SubgcRecurrence): bindings that mirror the struct check their layout against it */
 /* forward: steps 0 .. T-1 in order.  workspace / ws_bytes: the split-K scratch of the cell products (as subgc_lstm_fwd_gemm). */
@@ -927,16 +885,6 @@ int subgc_recurrence_fwd(const SubgcRecurrence* a, void* workspace, size_t ws_by
  * swap roles every step.  dv != NULL: d(v) accumulates per step (dCtx unused); dv == NULL: this step's d(ctx) rows are kept in dCtx
  * for one subgc_attn_dv_accum* after the loop (always so for shared sets). */
 int subgc_recurrence_bwd(const SubgcRecurrence* a, void* stream);
-/* TWO independent chains of the same recurrence on two streams, their steps interleaved in issue order (a, b, a, b, ...).  The rows of a
- * decoder batch are independent of each other (AttModel.py:157-175 is row-wise throughout), so a batch cut at a row boundary h is two
- * recurrences: chain a = rows [0, h) of every step, chain b = rows [h, m[t]) -- block b is block a with its row pointers advanced by h
- * (row0[t] + h, Gf / pre / lens / off / C1 / C2 / k_out / the dC ping-pong by h rows, Hout / dHout offsets by h rows), its own plane
- * buffers (QP; PA, PB, PC), its own workspace, and m_b[t] = m[t] - h while positive.  While one chain sits in a cell / attention
- * kernel (bandwidth- or latency-bound, a few microseconds) the other's product has the matrix pipes, and a kernel boundary of one chain
- * is covered by the other's running kernel.  Ordering against the caller's stream (fork before, join after) is the caller's job. */
-int subgc_recurrence_fwd_pair(const SubgcRecurrence* a, void* ws_a, size_t ws_a_bytes, void* stream_a, const SubgcRecurrence* b,
-                              void* ws_b, size_t ws_b_bytes, void* stream_b);
-int subgc_recurrence_bwd_pair(const SubgcRecurrence* a, void* stream_a, const SubgcRecurrence* b, void* stream_b);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,18 @@ inline int check_launch(const char* what) {
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Debug bounds mode (subgc_debug_bounds(1); off by default): every entry point that consumes an index tensor it did not produce -- rel_ind,
+// gpn_obj_ind, token / label / target ids, class ids -- validates it BEFORE its kernels run and returns SUBGC_EINVAL naming the tensor, the
+// first bad position and its value, the way the reference fails on a bad loader tensor (an IndexError from torch, the asserts of
+// gpn.py:117-118) instead of clamping or reading out of range.  One extra launch + a stream synchronisation per checked tensor: a
+// debugging aid, never on in the timed paths; inside a stream capture the checks are skipped (a synchronisation is illegal there).
+bool debug_bounds();
+// every x[r * ld + c], r < rows, c < cols (elem = 4: int32, 8: int64) must lie in [lo, hi] or equal `also_ok` (pass lo - 1 for "nothing else")
+int debug_check_range(const void* x, int elem, int64_t rows, int64_t cols, int64_t ld, int64_t lo, int64_t hi, int64_t also_ok, const char* what,
+                      hipStream_t s);
+// gpn.py:117-118: a sub-graph's node list holds the dummy node (N - 1) exactly where its attention mask is zero
+int debug_check_mask_agrees(const int64_t* obj_ind, const float* mask, int64_t n, int64_t dummy, const char* what, hipStream_t s);
 // bytes an LSTM cell forward launch over n = rows x R hidden units moves: `parts` pre-activation planes + the additive gate terms (4 floats
 // per unit each), c_prev, c, the h destinations (fp32 or bf16) and the saved gates -- against the 12 floats per unit of the algorithmic count
 inline double lstm_fwd_moved_bytes(int64_t n, int parts, bool g1, bool g2, bool c_prev, bool h2, bool hdrop, bool gates, int h_bf16) {
@@ -83,13 +95,6 @@ int attn_du_accum_vec(const void* u, int uv_b16, const float* ah, const float* d
 int attn_dv_accum_vec(const float* alpha, int n_stride, const float* dctx, int64_t lddctx, const int32_t* step_off, int T, const int32_t* off,
                       const int32_t* len, float* dv, int S, int R, hipStream_t s);
 
-// recurrent_mid.hip: cell 1 + query product + attention of a step's rows in one launch (and its backward); -100 = shape not covered
-int mid_fwd(const float* g0, int64_t ld0, int parts, int64_t plane, const float* g1, int64_t ld1, const float* g2, int64_t ld2, const float* b0,
-            const float* b1, const float* c_prev, float* c, void* h, int64_t ldh, int rows_h, void* h2, int64_t ldh2, int rows_h2, float* gates,
-            const void* Wq, int64_t ldw, const float* bq, float* q_out, const void* u, const void* v, const float* w_a, const float* b_a,
-            const int32_t* off, const int32_t* len, void* ctx, int64_t ldctx, float* alpha, int n_stride, int m, int R, int A, int b16, int uv16,
-            int flags, hipStream_t s, long long* stamps = nullptr);
-
 }  // namespace subgc
 
 // query chunk (four columns at `idx` = row * A + column) of a QSrc: planes summed in order, bias last
@@ -115,6 +120,12 @@ __device__ __forceinline__ float4 subgc_load_q(const float* __restrict__ ah, con
     }
     return a;
 }
+
+#define SUBGC_DEBUG_RANGE(x, elem, rows, cols, ld, lo, hi, also_ok, what, s)                                                       \
+    do {                                                                                                                        \
+        if (subgc::debug_bounds())                                                                                             \
+            if (int rc_ = subgc::debug_check_range(x, elem, rows, cols, ld, lo, hi, also_ok, what, (hipStream_t)(s))) return rc_; \
+    } while (0)
 
 #define SUBGC_REQUIRE(cond, ...)          \
     do {                                  \

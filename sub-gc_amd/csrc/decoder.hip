@@ -711,6 +711,7 @@ SUBGC_API int subgc_pack_rows(const int32_t* len, const int64_t* idx, int64_t id
                               int32_t* off, int32_t* total, int32_t* src_row, int32_t* sent_of, void* stream) {
     SUBGC_REQUIRE(S >= 0 && N > 0, "pack_rows: bad sizes");
     SUBGC_REQUIRE(off && total && src_row && sent_of && (S == 0 || (len && idx && img)), "pack_rows: null pointer");
+    SUBGC_DEBUG_RANGE(idx, 8, S, N, idx_stride, 0, N - 1, -1, "pack_rows: idx (node lists of the selected sub-graphs)", stream);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, len, idx, idx_stride, img, S, N, off, total,
                        src_row, sent_of);
     return subgc::check_launch("subgc_pack_rows");
@@ -721,6 +722,7 @@ SUBGC_API int subgc_embed_fwd(const float* table, const int64_t* tok, int64_t to
     SUBGC_REQUIRE(n >= 0 && E > 0 && vocab_rows > 0, "embed_fwd: bad sizes");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(table && tok && out, "embed_fwd: null pointer");
+    SUBGC_DEBUG_RANGE(tok, 8, n, 1, tok_stride, 0, vocab_rows - 1, -1, "embed_fwd: tok (word ids)", stream);
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, tok, tok_stride, keep, keep_scale, out, n,
                        E, vocab_rows, out_bf16);
     return subgc::check_launch("subgc_embed_fwd");
@@ -730,6 +732,7 @@ SUBGC_API int subgc_token_rows_f32(const float* table, int64_t ldt, const int64_
     SUBGC_REQUIRE(n >= 0 && C > 0 && vocab_rows > 0 && ldt >= C && ldo >= C, "token_rows: bad sizes");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(table && tok && out, "token_rows: null pointer");
+    SUBGC_DEBUG_RANGE(tok, 8, n, 1, tok_stride, 0, vocab_rows - 1, -1, "token_rows: tok (word ids)", stream);
     const int vec = (C % 4 == 0 && ldt % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
     hipLaunchKernelGGL(token_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, ldt, tok, tok_stride, out, ldo, C,
                        vocab_rows, vec);
@@ -740,6 +743,7 @@ SUBGC_API int subgc_embed_bwd(const float* table, const int64_t* tok, int64_t to
     SUBGC_REQUIRE(n >= 0 && E > 0 && vocab_rows > 0, "embed_bwd: bad sizes");
     if (n == 0) return SUBGC_OK;
     SUBGC_REQUIRE(table && tok && dout && dtable, "embed_bwd: null pointer");
+    SUBGC_DEBUG_RANGE(tok, 8, n, 1, tok_stride, 0, vocab_rows - 1, -1, "embed_bwd: tok (word ids)", stream);
     // (a four-columns-per-lane form was measured: 114 -> 215 us on Full_GC_Kar -- a lane's four atomics land on one line back to back)
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, tok, tok_stride, keep, keep_scale, dout,
                        dtable, n, E, vocab_rows);
@@ -776,16 +780,6 @@ SUBGC_API int subgc_lstm_fwd_gemm(const void* x, int64_t ldx, const void* w, int
                                   void* h, int64_t ldh, void* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, void* hdrop,
                                   int64_t ldhd, float* gates, int S, int R, int rows_h, int rows_h2, int bf16_bits, int gemm_flags,
                                   void* workspace, size_t ws_bytes, void* stream) {
-    return subgc_lstm_fwd_gemm_ev(x, ldx, w, ldw, K, pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd,
-                                  gates, S, R, rows_h, rows_h2, bf16_bits, gemm_flags, workspace, ws_bytes, nullptr, stream);
-}
-// ... with a hipEvent the stream waits for BETWEEN the product and the cell update: g1 (the x->gates rows) may still be in production on
-// another stream while the product runs (scheduled sampling: the sampled words' rows, functions_packed.py)
-SUBGC_API int subgc_lstm_fwd_gemm_ev(const void* x, int64_t ldx, const void* w, int64_t ldw, int K, float* pre, int64_t ldpre, const float* g1,
-                                     int64_t ld1, const float* g2, int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c,
-                                     void* h, int64_t ldh, void* h2, int64_t ldh2, const uint8_t* keep, float keep_scale, void* hdrop,
-                                     int64_t ldhd, float* gates, int S, int R, int rows_h, int rows_h2, int bf16_bits, int gemm_flags,
-                                     void* workspace, size_t ws_bytes, void* event_before_cell, void* stream) {
     // bf16_bits: bit 0 = x and w are bf16 (subgc_gemm_bf16 arithmetic), bit 1 = the h destinations are bf16
     SUBGC_REQUIRE(S >= 0 && R > 0 && K > 0, "lstm_fwd_gemm: bad sizes");
     if (S == 0) return SUBGC_OK;
@@ -806,18 +800,10 @@ SUBGC_API int subgc_lstm_fwd_gemm_ev(const void* x, int64_t ldx, const void* w, 
                   : subgc_gemm_f32(0, 1, S, 4 * R, K, static_cast<const float*>(x), ldx, static_cast<const float*>(w), ldw, pre, ldpre, nullptr, nullptr, 0,
                                    nullptr, 1.f, gemm_flags & ~15, nullptr, nullptr, nullptr, workspace, ws_bytes, stream);
         if (rc != SUBGC_OK) return rc;
-        if (event_before_cell && hipStreamWaitEvent(s, (hipEvent_t)event_before_cell, 0) != hipSuccess) {
-            subgc::set_error("lstm_fwd_gemm: hipStreamWaitEvent failed");
-            return SUBGC_ELAUNCH;
-        }
         return subgc_lstm_fwd(pre, ldpre, g1, ld1, g2, ld2, b0, b1, c_prev, c, h, ldh, h2, ldh2, keep, keep_scale, hdrop, ldhd, gates, S, R, rows_h, rows_h2,
                               h_bf16, stream);
     }
     if (rc != SUBGC_OK) return rc;
-    if (event_before_cell && hipStreamWaitEvent(s, (hipEvent_t)event_before_cell, 0) != hipSuccess) {
-        subgc::set_error("lstm_fwd_gemm: hipStreamWaitEvent failed");
-        return SUBGC_ELAUNCH;
-    }
     if (rows_h <= 0 || rows_h > S) rows_h = S;
     if (rows_h2 <= 0 || rows_h2 > S) rows_h2 = S;
     const int64_t n = (int64_t)S * R;
@@ -1025,6 +1011,7 @@ SUBGC_API int subgc_masked_nll_fwd(const float* logp, const int64_t* target, int
                                    void* stream) {
     SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "masked_nll_fwd: bad sizes");
     SUBGC_REQUIRE(logp && target && mask && loss && scratch2, "masked_nll_fwd: null pointer");
+    SUBGC_DEBUG_RANGE(target, 8, S, T, t_stride, 0, V - 1, -1, "masked_nll_fwd: target (word ids)", stream);
     hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, target, t_stride, mask, m_stride, loss,
                        scratch2, S, T, V, den_override, lse);
     return subgc::check_launch("subgc_masked_nll_fwd");
@@ -1033,6 +1020,7 @@ SUBGC_API int subgc_masked_nll_bwd(const int64_t* target, int64_t t_stride, cons
                                    const float* dloss, float* dlogp, int S, int T, int V, void* stream) {
     SUBGC_REQUIRE(S > 0 && T > 0 && V > 0, "masked_nll_bwd: bad sizes");
     SUBGC_REQUIRE(target && mask && scratch2 && dloss && dlogp, "masked_nll_bwd: null pointer");
+    SUBGC_DEBUG_RANGE(target, 8, S, T, t_stride, 0, V - 1, -1, "masked_nll_bwd: target (word ids)", stream);
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)S * T * V;
     hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, s, dlogp, n, 0.f);
@@ -1045,6 +1033,7 @@ SUBGC_API int subgc_nll_logsoftmax_bwd(const float* logp, const int64_t* target,
                                        const int32_t* active, int out_bf16, const float* lse, void* stream) {
     SUBGC_REQUIRE(S > 0 && T > 0 && V > 0 && ld_out >= V, "nll_logsoftmax_bwd: bad sizes");
     SUBGC_REQUIRE(logp && target && mask && scratch2 && dloss && dlogits, "nll_logsoftmax_bwd: null pointer");
+    SUBGC_DEBUG_RANGE(target, 8, S, T, t_stride, 0, V - 1, -1, "nll_logsoftmax_bwd: target (word ids)", stream);
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_SOFTMAX, s, 4.0 * S * T * (double)V * 2);
     const int vec = V % 4 == 0 && ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(logp) & 15) == 0 &&

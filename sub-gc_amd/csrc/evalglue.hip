@@ -7,7 +7,8 @@
 namespace {
 
 // One workgroup per image.  order[seg+r] = image-local index of the r-th best row: score descending, equal scores keep their input
-// order (the same total order as rank_desc_kernel, beam.hip); identity: no sorting (Full-GC, eval_utils.py:112-115).
+// order (the same total order as rank_desc_kernel, beam.hip); identity: no sorting (Full-GC, eval_utils.py:112-115).  A NaN score ranks
+// as -inf (with the index as tie-break the order stays TOTAL: every rank is taken exactly once, ord[] holds no unwritten slot).
 __global__ __launch_bounds__(256) void eval_rank_rows_kernel(const float* __restrict__ score, const int64_t* __restrict__ keep,
                                                              const int64_t* __restrict__ seq, int T, const int32_t* __restrict__ seg,
                                                              int identity, int32_t* __restrict__ order, float* __restrict__ score_sorted,
@@ -19,13 +20,14 @@ __global__ __launch_bounds__(256) void eval_rank_rows_kernel(const float* __rest
     float* sc = sh + n;
     for (int r = threadIdx.x; r < n; r += blockDim.x) sc[r] = score[a + r];
     __syncthreads();
+    auto key = [](float x) { return x != x ? -INFINITY : x; };
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
         int rank = r;
         if (!identity) {
-            const float v = sc[r];
+            const float v = key(sc[r]);
             rank = 0;
             for (int j = 0; j < n; ++j) {
-                const float u = sc[j];
+                const float u = key(sc[j]);
                 rank += (u > v) || (u == v && j < r);
             }
         }
@@ -103,7 +105,9 @@ SUBGC_API int subgc_eval_rank_rows(const float* score, const int64_t* keep, cons
     SUBGC_REQUIRE(I >= 0 && T >= 0 && max_rows >= 0 && max_rows <= 8192, "eval_rank_rows: I, T >= 0, rows per image <= 8192");
     if (I == 0) return SUBGC_OK;
     SUBGC_REQUIRE(score && keep && seq && seg && order && score_sorted && keep_sorted && seq_sorted, "eval_rank_rows: null pointer");
-    hipLaunchKernelGGL(eval_rank_rows_kernel, dim3(I), dim3(256), (size_t)(2 * max_rows + 2) * sizeof(float), (hipStream_t)stream, score,
+    const size_t lds = (size_t)(2 * max_rows + 2) * sizeof(float);          // 65 544 bytes at the 8192-row limit: above the 64 KiB default
+    if (int rc = subgc::raise_lds_cached((const void*)eval_rank_rows_kernel, lds, "eval_rank_rows")) return rc;
+    hipLaunchKernelGGL(eval_rank_rows_kernel, dim3(I), dim3(256), lds, (hipStream_t)stream, score,
                        keep, seq, T, seg, identity, order, score_sorted, keep_sorted, seq_sorted);
     return subgc::check_launch("subgc_eval_rank_rows");
 }

@@ -658,6 +658,7 @@ SUBGC_API int subgc_gcn_edges_fwd_bn(const void* F2, const void* F3, int f_bf16,
     SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0 && L % 4 == 0, "gcn_edges_fwd_bn: bad sizes (L must be a multiple of 4)");
     if (B == 0) return SUBGC_OK;
     SUBGC_REQUIRE(F2 && F3 && rel_ind && Pout, "gcn_edges_fwd_bn: null pointer");
+    SUBGC_DEBUG_RANGE(rel_ind, 8, (int64_t)B * K, 2, 2, 0, N - 1, -1, "gcn_edges_fwd_bn: rel_ind", stream);
     SUBGC_REQUIRE((f_bf16 ? (al8(F2) && al8(F3)) : (al16(F2) && al16(F3))) && al16(aff2) && al16(aff3), "gcn_edges_fwd_bn: misaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float) * 2 * (size_t)N * TC + sizeof(int) * 2 * K;

@@ -667,6 +667,7 @@ SUBGC_API int subgc_csr_build(const int64_t* rel_ind, int B, int K, int N, int32
     SUBGC_REQUIRE(B >= 0 && K > 0 && N > 0, "csr_build: bad sizes");
     if (B == 0) return SUBGC_OK;
     SUBGC_REQUIRE(rel_ind && ptr && edges, "csr_build: null pointer");
+    SUBGC_DEBUG_RANGE(rel_ind, 8, (int64_t)B * K, 2, 2, 0, N - 1, -1, "csr_build: rel_ind (node ids of the relations)", stream);
     const size_t lds = sizeof(int) * (K + N + 1);
     hipLaunchKernelGGL(csr_build_kernel, dim3(B, 2), dim3(128), lds, (hipStream_t)stream, rel_ind, B, K, N, ptr, edges);
     return subgc::check_launch("subgc_csr_build");
@@ -692,6 +693,7 @@ SUBGC_API int subgc_gcn_nodes_bwd(const float* dX, const uint8_t* act, const int
     SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0, "gcn_nodes_bwd: bad sizes");
     if (B == 0) return SUBGC_OK;
     SUBGC_REQUIRE(dX && act && rel_ind && ptr && dF0 && dF1, "gcn_nodes_bwd: null pointer");
+    SUBGC_DEBUG_RANGE(rel_ind, 8, (int64_t)B * K, 2, 2, 0, N - 1, -1, "gcn_nodes_bwd: rel_ind", stream);
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_GCN, s, 4.0 * B * L * (2.0 * K + 2.0 * K));
     const size_t lds = sizeof(int) * (2 * K) + sizeof(float) * 2 * N;
@@ -710,6 +712,7 @@ SUBGC_API int subgc_gcn_edges_fwd(const float* F2, const float* F3, const int64_
     SUBGC_REQUIRE(B >= 0 && N > 0 && K > 0 && L > 0, "gcn_edges_fwd: bad sizes");
     if (B == 0) return SUBGC_OK;
     SUBGC_REQUIRE(F2 && F3 && rel_ind && Pout, "gcn_edges_fwd: null pointer");
+    SUBGC_DEBUG_RANGE(rel_ind, 8, (int64_t)B * K, 2, 2, 0, N - 1, -1, "gcn_edges_fwd: rel_ind", stream);
     SUBGC_REQUIRE(L % 4 == 0, "gcn_edges_fwd: L must be a multiple of 4 (got %d)", L);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float) * 2 * (size_t)N * TC + sizeof(int) * 2 * K;

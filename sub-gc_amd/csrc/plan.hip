@@ -11,6 +11,8 @@
 // Everything here is integer / copy work on a few thousand elements: latency-bound single launches, threads along rows.
 #include "common.h"
 
+#include <vector>
+
 #include <algorithm>
 
 namespace {
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256) void class_partials_kernel(const float* __rest
 SUBGC_API int subgc_class_partials(const float* X, int64_t ldx, const int32_t* cls, int M, int L, int C, int slabs, float* part, void* stream) {
     SUBGC_REQUIRE(M > 0 && L > 0 && C > 0 && C <= 64 && slabs > 0 && ldx >= L, "class_partials: bad sizes (at most 64 classes)");
     SUBGC_REQUIRE(X && cls && part, "class_partials: null pointer");
+    SUBGC_DEBUG_RANGE(cls, 4, M, 1, 1, 0, C - 1, -1, "class_partials: cls (class ids)", stream);
     const int rpb = (M + slabs - 1) / slabs;
     const size_t lds = (size_t)C * 256 * sizeof(float);
     if (int rc = subgc::raise_lds_cached((const void*)class_partials_kernel, lds, "class_partials")) return rc;
@@ -302,6 +305,9 @@ SUBGC_API int subgc_gpn_prep(const int64_t* gpn_obj_ind, const float* gpn_pool_m
                              int sentences_per_image, int64_t* idx, float* w, float* denom, int32_t* img, void* stream) {
     SUBGC_REQUIRE(b5 > 0 && hb > 0 && N > 0 && sentences_per_image > 0, "gpn_prep: bad sizes");
     SUBGC_REQUIRE(gpn_obj_ind && gpn_pool_mtx && att_masks && idx && w && denom && img, "gpn_prep: null pointer");
+    SUBGC_DEBUG_RANGE(gpn_obj_ind, 8, (int64_t)b5 * 2 * hb, N, N, 0, N - 1, -1, "gpn_prep: gpn_obj_ind (node lists of the sampled sub-graphs)", stream);
+    if (subgc::debug_bounds())
+        if (int rc = subgc::debug_check_mask_agrees(gpn_obj_ind, att_masks, (int64_t)b5 * 2 * hb * N, N - 1, "gpn_prep: gpn_obj_ind vs att_masks", (hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(gpn_prep_kernel, dim3(2 * b5 * hb), dim3(64), 0, (hipStream_t)stream, gpn_obj_ind, gpn_pool_mtx, att_masks, b5, hb, N,
                        sentences_per_image, idx, w, denom, img);
     return subgc::check_launch("subgc_gpn_prep");
@@ -369,6 +375,23 @@ SUBGC_API int subgc_gpn_test_prep(const int64_t* table, int images, int total, i
                                   int32_t* img, int32_t* offsets32, void* stream) {
     SUBGC_REQUIRE(images > 0 && total >= 0 && N > 0, "gpn_test_prep: bad sizes");
     SUBGC_REQUIRE(table && (total == 0 || (idx && w && denom && lens && img)), "gpn_test_prep: null pointer");
+    if (subgc::debug_bounds() && total > 0) {
+        // the table lives on the device: bring it over and check every image's candidate node lists (counterpart 0, what the kernel reads)
+        std::vector<int64_t> t((size_t)images * 5 + 1);
+        if (hipMemcpyAsync(t.data(), table, t.size() * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+            hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+            subgc::set_error("gpn_test_prep: debug check cannot read the address table");
+            return SUBGC_ELAUNCH;
+        }
+        for (int b = 0; b < images; ++b) {
+            const int64_t mb = t[b + 1] - t[b];
+            SUBGC_REQUIRE(mb >= 0 && t[images] <= total, "gpn_test_prep: candidate offsets are not ascending / exceed `total` [debug bounds mode]");
+            const int64_t* obj = reinterpret_cast<const int64_t*>(t[images + 1 + 4 * (size_t)b]);
+            const float* msk = reinterpret_cast<const float*>(t[images + 1 + 4 * (size_t)b + 2]);
+            if (int rc = subgc::debug_check_range(obj, 8, mb, N, N, 0, N - 1, -1, "gpn_test_prep: gpn_obj_ind (candidate node lists)", (hipStream_t)stream)) return rc;
+            if (int rc = subgc::debug_check_mask_agrees(obj, msk, mb * N, N - 1, "gpn_test_prep: gpn_obj_ind vs att_masks", (hipStream_t)stream)) return rc;
+        }
+    }
     hipLaunchKernelGGL(gpn_test_prep_kernel, dim3(std::max(total, images + 1)), dim3(64), 0, (hipStream_t)stream, table, images, N, idx, w, denom,
                        lens, img, offsets32);
     return subgc::check_launch("subgc_gpn_test_prep");
@@ -379,6 +402,7 @@ SUBGC_API int subgc_gpn_select(const float* score, const int64_t* gpn_obj_ind, c
                                int sentences_per_image, int32_t* img_s, void* stream) {
     SUBGC_REQUIRE(b5 > 0 && hb > 0 && N > 0 && read_out_cols >= 0 && sentences_per_image > 0, "gpn_select: bad sizes");
     SUBGC_REQUIRE(score && gpn_obj_ind && att_masks && sel_idx && lens && (!ro_sel || read_out), "gpn_select: null pointer");
+    SUBGC_DEBUG_RANGE(gpn_obj_ind, 8, (int64_t)b5 * 2 * hb, N, N, 0, N - 1, -1, "gpn_select: gpn_obj_ind", stream);
     hipLaunchKernelGGL(gpn_select_kernel, dim3(b5), dim3(256), 0, (hipStream_t)stream, score, gpn_obj_ind, att_masks, read_out, b5, hb, N,
                        read_out_cols, sel_idx, lens, ro_sel, sel, sentences_per_image, img_s);
     return subgc::check_launch("subgc_gpn_select");

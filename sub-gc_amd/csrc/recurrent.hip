@@ -45,54 +45,6 @@ int check_fwd(const SubgcRecurrence* a) {
     return SUBGC_OK;
 }
 
-// step t with the row-local middle as one launch; -100 (before anything was enqueued): not covered, issue the plain sequence
-int fwd_step_fused(const SubgcRecurrence* a, int t, void* workspace, size_t ws_bytes, void* stream) {
-    const int R = a->R, A = a->A, S = a->S, esz = a->bf16 ? 2 : 4;
-    const int64_t R4 = 4 * (int64_t)R;
-    // the query weight as the fused product streams it: bf16 -> Wq [A, R] (matrix pipe), fp32 -> WqT [R, A] (K-major, VALU form, <= 1024 rows)
-    const void* const wq = a->bf16 ? a->Wq : a->WqT;
-    const int64_t ldq = a->bf16 ? a->ldWq : a->ldWqT;
-    if ((a->bf16 != 0) != (a->uv_b16 != 0) || R % 8 || A % 4 || A > 512 || a->n_alpha > 512 || a->m[t] > (a->bf16 ? 4096 : 1024) || !wq) return -100;
-    hipStream_t s = (hipStream_t)stream;
-    const int cell_bits = (a->bf16 ? 1 : 0) | (a->bf16 ? 2 : 0);
-    const int m = a->m[t];
-    const int mn = a->m[t + 1] > 0 ? a->m[t + 1] : 1;
-    const int64_t o = a->row0[t], o1 = a->row0[t + 1];
-    char* const H1t = at(a->H1, o * a->ldH1, esz);
-    char* const H2t = at(a->H2, o * a->ldH2, esz);
-    char* const H1n = at(a->H1, o1 * a->ldH1, esz);
-    char* const H2n = at(a->H2, o1 * a->ldH2, esz);
-    float* const C1p = a->C1 + (int64_t)t * S * R;
-    float* const C2p = a->C2 + (int64_t)t * S * R;
-    // gate product 1 as split-K planes in the workspace (or one plain plane in `pre`)
-    int parts = 0;
-    const float* g0 = static_cast<const float*>(workspace);
-    int64_t ld0 = R4, plane = (int64_t)m * R4;
-    int rc = a->bf16 ? subgc::gemm_bf16_nt_partials(reinterpret_cast<const uint16_t*>(H1t), a->ldH1, static_cast<const uint16_t*>(a->Wc1), a->ldW1, m, (int)R4,
-                                                     2 * R, static_cast<float*>(workspace), ws_bytes, s, &parts)
-                     : subgc::gemm_nt_partials(reinterpret_cast<const float*>(H1t), a->ldH1, static_cast<const float*>(a->Wc1), a->ldW1, m, (int)R4, 2 * R,
-                                               a->gemm_flags, static_cast<float*>(workspace), ws_bytes, s, &parts);
-    if (rc == -100) {                                                   // not the split-K shape: the plain product into `pre`
-        rc = a->bf16 ? subgc_gemm_bf16(0, 1, m, (int)R4, 2 * R, reinterpret_cast<const uint16_t*>(H1t), a->ldH1, static_cast<const uint16_t*>(a->Wc1), a->ldW1,
-                                       a->pre, R4, nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, 0, nullptr, workspace, ws_bytes, stream)
-                     : subgc_gemm_f32(0, 1, m, (int)R4, 2 * R, reinterpret_cast<const float*>(H1t), a->ldH1, static_cast<const float*>(a->Wc1), a->ldW1, a->pre,
-                                      R4, nullptr, nullptr, 0, nullptr, 1.f, a->gemm_flags & ~15, nullptr, nullptr, nullptr, workspace, ws_bytes, stream);
-        g0 = a->pre; parts = 1; plane = 0;
-    }
-    if (rc != SUBGC_OK) return rc;
-    rc = subgc::mid_fwd(g0, ld0, parts, plane, a->Gx + o * R4, R4, a->Gf, R4, a->b1i, a->b1h, C1p, C1p + (int64_t)S * R, H2t + (int64_t)R * esz, a->ldH2, m,
-                        H1n + (int64_t)R * esz, a->ldH1, mn, a->G1 + o * R4, wq, ldq, a->bq, a->AH + o * A, a->u, a->v, a->w_a, a->b_a, a->off, a->lens,
-                        H2t, a->ldH2, a->AL + o * a->n_alpha, a->n_alpha, m, R, A, a->bf16 ? 1 : 0, a->uv_b16 ? 1 : 0, (a->fuse_mid >> 1) & 1, s);
-    if (rc == -100) {                                                   // (alignment) the three launches on the planes already computed
-        subgc::set_error("recurrence_fwd: fuse_mid set but the fused middle does not cover this shape");
-        return SUBGC_EINVAL;
-    }
-    if (rc != SUBGC_OK) return rc;
-    return subgc_lstm_fwd_gemm(H2t, a->ldH2, a->Wc2, a->ldW2, 3 * R, a->pre, R4, nullptr, 0, nullptr, 0, a->b2i, a->b2h, C2p, C2p + (int64_t)S * R, H1n,
-                               a->ldH1, H2n + 2 * (int64_t)R * esz, a->ldH2, a->k_out ? a->k_out + (int64_t)t * S * R : nullptr, a->keep_scale,
-                               at(a->Hout, a->hout_off[t], esz), a->ld_hout, a->G2 + o * R4, m, R, mn, mn, cell_bits, a->gemm_flags, workspace, ws_bytes, stream);
-}
-
 // one time step of the forward recurrence (all launches of step t on `stream`)
 int fwd_step(const SubgcRecurrence* a, int t, void* workspace, size_t ws_bytes, void* stream) {
     const int R = a->R, A = a->A, S = a->S, esz = a->bf16 ? 2 : 4;
@@ -108,11 +60,6 @@ int fwd_step(const SubgcRecurrence* a, int t, void* workspace, size_t ws_bytes, 
     char* const H2n = at(a->H2, o1 * a->ldH2, esz);
     float* const C1p = a->C1 + (int64_t)t * S * R;
     float* const C2p = a->C2 + (int64_t)t * S * R;
-    if ((a->fuse_mid & 1) && !a->shared) {
-        // the fused middle (recurrent_mid.hip): gate product 1 as planes -> ONE launch for cell 1 + query + attention -> gate product 2 + cell 2
-        int rc = fwd_step_fused(a, t, workspace, ws_bytes, stream);
-        if (rc != -100) return rc;
-    }
     // attention LSTM: [h2_{t-1} | h1_{t-1}] . Wc1^T + x->gates + fc->gates; h1_t -> H2[t][:, R:2R] and the next step's H1[:, R:]
     int rc = subgc_lstm_fwd_gemm(H1t, a->ldH1, a->Wc1, a->ldW1, 2 * R, a->pre, R4, a->Gx + o * R4, R4, a->Gf, R4, a->b1i, a->b1h, C1p,
                                  C1p + (int64_t)S * R, H2t + (int64_t)R * esz, a->ldH2, H1n + (int64_t)R * esz, a->ldH1, nullptr, 1.f, nullptr, 0,
@@ -148,20 +95,6 @@ SUBGC_API int subgc_recurrence_fwd(const SubgcRecurrence* a, void* workspace, si
     return SUBGC_OK;
 }
 
-SUBGC_API int subgc_recurrence_fwd_pair(const SubgcRecurrence* a, void* ws_a, size_t ws_a_bytes, void* stream_a, const SubgcRecurrence* b, void* ws_b,
-                                        size_t ws_b_bytes, void* stream_b) {
-    if (int rc = check_fwd(a)) return rc;
-    if (int rc = check_fwd(b)) return rc;
-    SUBGC_REQUIRE(stream_a != stream_b, "recurrence_fwd_pair: the two chains need two streams");
-    const int T = a->T > b->T ? a->T : b->T;
-    for (int t = 0; t < T; ++t) {                       // steps interleaved in issue order: neither chain's queue runs dry behind the other's
-        if (t < a->T)
-            if (int rc = fwd_step(a, t, ws_a, ws_a_bytes, stream_a)) return rc;
-        if (t < b->T)
-            if (int rc = fwd_step(b, t, ws_b, ws_b_bytes, stream_b)) return rc;
-    }
-    return SUBGC_OK;
-}
 
 namespace {
 int check_bwd(const SubgcRecurrence* a) {
@@ -264,17 +197,3 @@ SUBGC_API int subgc_recurrence_bwd(const SubgcRecurrence* a, void* stream) {
     return SUBGC_OK;
 }
 
-SUBGC_API int subgc_recurrence_bwd_pair(const SubgcRecurrence* a, void* stream_a, const SubgcRecurrence* b, void* stream_b) {
-    if (int rc = check_bwd(a)) return rc;
-    if (int rc = check_bwd(b)) return rc;
-    SUBGC_REQUIRE(stream_a != stream_b, "recurrence_bwd_pair: the two chains need two streams");
-    BwdState sa = bwd_begin(a), sb = bwd_begin(b);
-    const int T = a->T > b->T ? a->T : b->T;
-    for (int t = T - 1; t >= 0; --t) {
-        if (t < a->T)
-            if (int rc = bwd_step(a, sa, t, stream_a)) return rc;
-        if (t < b->T)
-            if (int rc = bwd_step(b, sb, t, stream_b)) return rc;
-    }
-    return SUBGC_OK;
-}

@@ -31,22 +31,15 @@ __global__ __launch_bounds__(256) void uniform_kernel(float* __restrict__ out, i
 // from memory ONCE, coalesced (thread t takes columns t, t+256, ...), and exp(x - max) is staged in LDS; the chunk sums and the final scan
 // then run on LDS in exactly the order of additions the first version used (it read each thread's 152-byte chunk straight from memory,
 // three times, 64 cache lines per wave load: 28 us for 160 rows of 9488) -- same picks, bit for bit.
-template <bool LIST>
-__global__ __launch_bounds__(256) void multinomial_kernel(const float* __restrict__ logits, int64_t ld, int V, const int32_t* __restrict__ rows,
-                                                          const int32_t* __restrict__ count, const float* __restrict__ u,
+__global__ __launch_bounds__(256) void multinomial_kernel(const float* __restrict__ logits, int64_t ld, int V, const float* __restrict__ u,
                                                           const float* __restrict__ sel_u, float prob, int64_t* __restrict__ tok, int64_t tok_stride) {
     extern __shared__ float ex[];                                  // [V] exp(x - max)
     __shared__ float part[256];
     __shared__ float smf[16];
     __shared__ int pick_s;
-    int r = blockIdx.x;
-    if (LIST) {
-        if ((int)blockIdx.x >= *count) return;
-        r = rows[blockIdx.x];
-    } else if (!(sel_u[r] < prob)) {
-        return;                                                    // workgroup-uniform: this row keeps its ground-truth word
-    }
-    const float* p = logits + (int64_t)blockIdx.x * ld;            // LIST: compact logits row i; else row r == blockIdx.x
+    const int r = blockIdx.x;
+    if (!(sel_u[r] < prob)) return;                                // workgroup-uniform: this row keeps its ground-truth word
+    const float* p = logits + (int64_t)r * ld;
     float mx = -INFINITY;
     for (int c = threadIdx.x; c < V; c += 256) { const float x = p[c]; ex[c] = x; mx = fmaxf(mx, x); }
     mx = block_max(mx, smf);                                       // (barriers inside: ex[] is complete afterwards)
@@ -81,55 +74,7 @@ __global__ __launch_bounds__(256) void multinomial_kernel(const float* __restric
     if (threadIdx.x == 0) tok[(int64_t)r * tok_stride] = pick_s;
 }
 
-// (LIST = true: the same draw for a LIST of rows -- workgroup i < *count draws for sentence row rows[i] from the COMPACT logits row i; the
-// fired-rows form of scheduled sampling, subgc_ss_plan + a gathered GEMM)
-
-// fired[t][0 .. count[t]) = the rows r < live[t] with sel[t][r] < prob, ascending (AttModel.py:158-160: sample_mask = uniform < ss_prob): one
-// workgroup per step, ordered compaction by wave ballots
-__global__ __launch_bounds__(256) void ss_plan_kernel(const float* __restrict__ sel, int64_t ld_sel, const int32_t* __restrict__ live, float prob, int S,
-                                                      int32_t* __restrict__ fired, int32_t* __restrict__ count) {
-    __shared__ int wave_base[4], total_s;
-    const int t = blockIdx.x, m = min(live[t], S), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) total_s = 0;
-    __syncthreads();
-    for (int r0 = 0; r0 < m; r0 += 256) {
-        const int r = r0 + threadIdx.x;
-        const bool hit = t > 0 && r < m && sel[(int64_t)t * ld_sel + r] < prob;       // step 0 always takes <bos>
-        const unsigned long long b = __ballot(hit);
-        if (lane == 0) wave_base[wave] = __popcll(b);
-        __syncthreads();
-        int base = total_s;
-        for (int w = 0; w < wave; ++w) base += wave_base[w];
-        if (hit) fired[(int64_t)t * S + base + __popcll(b & ((1ull << lane) - 1ull))] = r;
-        __syncthreads();
-        if (threadIdx.x == 0) total_s += wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) count[t] = total_s;
-}
-
 }  // namespace
-
-SUBGC_API int subgc_ss_plan(const float* sel_u, int64_t ld_sel, const int32_t* live, float prob, int T, int S, int32_t* fired, int32_t* count,
-                            void* stream) {
-    SUBGC_REQUIRE(T >= 0 && S > 0 && ld_sel >= S, "ss_plan: bad sizes");
-    if (T == 0) return SUBGC_OK;
-    SUBGC_REQUIRE(sel_u && live && fired && count, "ss_plan: null pointer");
-    hipLaunchKernelGGL(ss_plan_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, sel_u, ld_sel, live, prob, S, fired, count);
-    return subgc::check_launch("subgc_ss_plan");
-}
-
-SUBGC_API int subgc_multinomial_rows_list(const float* logits, int64_t ld, int max_rows, int V, const int32_t* rows, const int32_t* count, const float* u,
-                                          int64_t* tok, int64_t tok_stride, void* stream) {
-    SUBGC_REQUIRE(max_rows >= 0 && V > 0 && ld >= V && tok_stride >= 1, "multinomial_rows_list: bad sizes");
-    if (max_rows == 0) return SUBGC_OK;
-    SUBGC_REQUIRE(logits && rows && count && u && tok, "multinomial_rows_list: null pointer");
-    SUBGC_REQUIRE(V <= 36000, "multinomial_rows_list: at most 36000 columns (the row is staged in LDS)");
-    if (int rc = subgc::raise_lds_cached((const void*)multinomial_kernel<true>, (size_t)V * sizeof(float), "multinomial_rows_list")) return rc;
-    hipLaunchKernelGGL(multinomial_kernel<true>, dim3(max_rows), dim3(256), (size_t)V * sizeof(float), (hipStream_t)stream, logits, ld, V, rows, count, u,
-                       (const float*)nullptr, 0.f, tok, tok_stride);
-    return subgc::check_launch("subgc_multinomial_rows_list");
-}
 
 SUBGC_API int subgc_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
     SUBGC_REQUIRE(n >= 0 && offset % 4 == 0, "uniform: bad arguments");
@@ -147,8 +92,8 @@ SUBGC_API int subgc_multinomial_rows(const float* logits, int64_t ld, int rows, 
     if (rows == 0) return SUBGC_OK;
     SUBGC_REQUIRE(logits && u && sel_u && tok, "multinomial_rows: null pointer");
     SUBGC_REQUIRE(V <= 36000, "multinomial_rows: at most 36000 columns (the row is staged in LDS)");
-    if (int rc = subgc::raise_lds_cached((const void*)multinomial_kernel<false>, (size_t)V * sizeof(float), "multinomial_rows")) return rc;
-    hipLaunchKernelGGL(multinomial_kernel<false>, dim3(rows), dim3(256), (size_t)V * sizeof(float), (hipStream_t)stream, logits, ld, V,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, u, sel_u, prob, tok, tok_stride);
+    if (int rc = subgc::raise_lds_cached((const void*)multinomial_kernel, (size_t)V * sizeof(float), "multinomial_rows")) return rc;
+    hipLaunchKernelGGL(multinomial_kernel, dim3(rows), dim3(256), (size_t)V * sizeof(float), (hipStream_t)stream, logits, ld, V, u,
+                       sel_u, prob, tok, tok_stride);
     return subgc::check_launch("subgc_multinomial_rows");
 }

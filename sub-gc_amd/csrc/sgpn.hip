@@ -215,6 +215,7 @@ SUBGC_API int subgc_subgraph_pool_fwd(const float* X, const int64_t* idx, int64_
     SUBGC_REQUIRE(G >= 0 && N > 0 && N <= MAXN && L > 0, "subgraph_pool_fwd: bad sizes G=%d N=%d L=%d", G, N, L);
     if (G == 0) return SUBGC_OK;
     SUBGC_REQUIRE(X && idx && w && denom && img && out, "subgraph_pool_fwd: null pointer");
+    SUBGC_DEBUG_RANGE(idx, 8, G, N, idx_stride, 0, N - 1, -1, "subgraph_pool_fwd: idx (node lists of the sub-graphs)", stream);
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_POOL, s, 4.0 * G * L * 3.0);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3((L + 255) / 256, G), dim3(256), 0, s, X, idx, idx_stride, w, w_gstride, w_istride,
@@ -228,6 +229,7 @@ SUBGC_API int subgc_subgraph_pool_bwd(const float* dout, const int64_t* idx, int
     SUBGC_REQUIRE(G >= 0 && N > 0 && N <= MAXN && L > 0, "subgraph_pool_bwd: bad sizes");
     if (G == 0) return SUBGC_OK;
     SUBGC_REQUIRE(dout && idx && w && denom && img && argmax && dX, "subgraph_pool_bwd: null pointer");
+    SUBGC_DEBUG_RANGE(idx, 8, G, N, idx_stride, 0, N - 1, -1, "subgraph_pool_bwd: idx", stream);
     hipStream_t s = (hipStream_t)stream;
     subgc::ProfScope prof(SUBGC_FAM_POOL, s, 4.0 * G * L * 3.0);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((L + 255) / 256, G), dim3(256), 0, s, dout, idx, idx_stride, w, w_gstride, w_istride,
@@ -267,6 +269,7 @@ SUBGC_API int subgc_subgraph_nms(const float* score, const int64_t* idx, int64_t
     // of 64 * SUBGC_NMS_WORDS bits: more nodes than that would silently drop ids from the masks and change the kept set
     SUBGC_REQUIRE(N <= 64 * W, "subgraph_nms: node ids must be < %d (64 * SUBGC_NMS_WORDS), got %d nodes per image", 64 * W, N);
     SUBGC_REQUIRE(keep && n_keep, "subgraph_nms: null output");
+    SUBGC_DEBUG_RANGE(idx, 8, M, N, idx_stride, 0, N - 1, -1, "subgraph_nms: idx (candidate node lists)", stream);
     hipStream_t s = (hipStream_t)stream;
     SUBGC_REQUIRE(M == 0 || (score && idx && len && scratch), "subgraph_nms: null pointer");
     const size_t need = (size_t)M * (W * 8 + 8);
@@ -321,6 +324,7 @@ SUBGC_API int subgc_subgraph_nms_batched(const float* score, const int64_t* idx,
     if (images == 0) return SUBGC_OK;
     SUBGC_REQUIRE(offsets && keep && n_keep, "subgraph_nms_batched: null pointer");
     SUBGC_REQUIRE(total == 0 || (score && idx && len && scratch), "subgraph_nms_batched: null pointer");
+    SUBGC_DEBUG_RANGE(idx, 8, total, N, idx_stride, 0, N - 1, -1, "subgraph_nms_batched: idx (candidate node lists)", stream);
     const size_t need = (size_t)total * (W * 8 + 8);
     SUBGC_REQUIRE(scratch_bytes >= need, "subgraph_nms_batched: scratch too small (%zu < %zu)", scratch_bytes, need);
     uint64_t* masks = (uint64_t*)scratch;

@@ -124,13 +124,6 @@ def prof_collect(family):
     return n.value, ms.value, work.value
 
 
-def prof_last_busy(family):
-    """Busy (interval-union) milliseconds of the family's launches at the last prof_collect: the wall time they held the device."""
-    ms = ctypes.c_double(0)
-    call("subgc_prof_last_busy", FAM[family], ctypes.byref(ms))
-    return ms.value
-
-
 def prof_last_moved(family):
     """Bytes the family's launches at the last prof_collect actually moved (LSTM cells: split-K planes, gate terms, saved gates included)."""
     b = ctypes.c_double(0)

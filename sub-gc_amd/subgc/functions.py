@@ -9,6 +9,8 @@ ragged attention sets are packed once (reference: AttModel.py:122-177,328-368,40
 """
 from __future__ import annotations
 
+import math
+
 import torch
 from torch.autograd import Function
 
@@ -34,8 +36,7 @@ def _weight_bias_grads(dz, x, w_shape, gW, gb, need_w, need_b):
     if need_w and need_b and FOLD_BIAS_SUMS:
         oW = gW if gW is not None else torch.empty(w_shape, device=dev, dtype=torch.float32)
         ob = gb if gb is not None else torch.empty(w_shape[0], device=dev, dtype=torch.float32)
-        # both destinations are .grad views: nothing reads them before the slice is announced -> beside the chain, on a side stream
-        (ops.wgrad_forked if (gW is not None and gb is not None) else ops.wgrad)(dz, x, oW, ob.view(-1), accum=gW is not None, db_accum=gb is not None)
+        ops.wgrad(dz, x, oW, ob.view(-1), accum=gW is not None, db_accum=gb is not None)
         return (None if gW is not None else oW), (None if gb is not None else ob)
     if need_w:
         if gW is not None:                # accumulate in the GEMM epilogue: no temporary, no separate `+=` pass by autograd
@@ -642,7 +643,6 @@ def note(*event):
 
 def grads_ready(stage):
     """Called by the decoder backwards when every kernel that writes the gradient slice `stage` has been enqueued."""
-    ops.join_forks()                                         # weight-gradient products that ran beside the chain (ops.wgrad_forked)
     note("ready", stage)
     if on_grads_ready is not None:
         on_grads_ready(stage)
@@ -714,9 +714,13 @@ class Prepared:
             self.v16 = ops.empty_b16(MR, att_w.size(0), dev, zero=True)
             if self.dedup:
                 self.Xu16 = ops.as_b16(X_nodes)                # the unique node rows
-                r16 = ops.empty_b16(X_nodes.size(0), att_w.size(0), dev)
-                ops.gemm(self.Xu16, wa, r16, tb=True, bias=att_b, relu=True)
-                ops.gather_rows_keep(r16, self.src_row, keep_att, scale, self.v16, m_dev=self.total)
+                # ONE rounding, like the replicated path (its GEMM epilogue rounds relu(.) * keep * scale from the fp32 accumulator): a bf16
+                # intermediate is exact only when the scale is a power of two (drop_prob_lm = 0.5, the presets' value) -- otherwise the
+                # unique rows stay fp32 until the masked gather rounds them
+                exact16 = keep_att is None or math.frexp(float(scale))[0] == 0.5
+                r_u = ops.empty_b16(X_nodes.size(0), att_w.size(0), dev) if exact16 else new(X_nodes.size(0), att_w.size(0))
+                ops.gemm(self.Xu16, wa, r_u, tb=True, bias=att_b, relu=True)
+                ops.gather_rows_keep(r_u, self.src_row, keep_att, scale, self.v16, m_dev=self.total)
             else:
                 ops.gemm(self.Xg16, wa, self.v16, tb=True, bias=att_b, relu=True, keep=keep_att, keep_scale=scale, m_dev=self.total)
             self.v = self.v16
@@ -758,9 +762,9 @@ class Prepared:
         """deferred d(u): one pass over the kept d(e) / query rows of all steps (subgc_attn_du_accum), every d(u) row written once"""
         ops.attn_du_accum(self.u, ah, de, step_off, T, self.off, lens, w_a, du, S, A)
 
-    def recur_fields(self, r0=0):
-        """The attention-set fields of ops.Recurrence (per-sentence sets); r0: first sentence row of the chain the block is for."""
-        return dict(shared=0, u=self.u, v=self.v, off=self.off[r0:], uv_b16=int(ops.is_b16(self.u)), fuse_mid=int(ops.FUSE_MID))
+    def recur_fields(self):
+        """The attention-set fields of ops.Recurrence (per-sentence sets)."""
+        return dict(shared=0, u=self.u, v=self.v, off=self.off, uv_b16=int(ops.is_b16(self.u)))
 
     def new_du(self, A):
         """Zeroed accumulator of d(u) for the backward's time loop."""
@@ -827,9 +831,7 @@ class PreparedShared(Prepared):
     def dv_accum(self, alpha, dctx, step_off, T, lens, dv, S, R):
         ops.attn_dv_accum_group(alpha, dctx, step_off, T, self.rows, self.B, self.g, self.N, dv, R)
 
-    def recur_fields(self, r0=0):
-        if r0:
-            raise ops.SubgcError("shared attention sets run as one chain (an image's sentences share d(u) planes)")
+    def recur_fields(self):
         return dict(shared=1, u=self.u, v=self.v, rows_map=self.rows, B=self.B, g=self.g, Nn=self.N, uv_b16=int(ops.is_b16(self.u)))
 
     def new_du(self, A):
@@ -856,15 +858,6 @@ def make_prepared(meta, fc_in, X_nodes, lens, idx, img, N, P, k_fc, k_att, scale
     if rows is None:
         rows = sh["rows"]
     return PreparedShared(fc_in, X_nodes, lens, rows, sh["B"], sh["g"], N, P, k_fc, k_att, scale, W)
-
-
-def fused_mid_weights(pr, wq, bf, forward):
-    """SubgcRecurrence fields of the fused middle (ops.FUSE_MID, csrc/recurrent_mid.hip; forward only): under fp32 operands the K-major
-    TRANSPOSE `WqT` [R, A] of the h2att weight `wq` [A, R] that the fused launch streams (one 2 MB transpose per forward call)."""
-    if not (ops.FUSE_MID & 1) or pr.shared or bf or not forward:
-        return {}
-    wt = ops.transpose_f32(wq)
-    return dict(WqT=wt, ldWqT=ops.ld(wt))
 
 
 def _cat_weights(w_ih_part, w_hh):
@@ -972,7 +965,7 @@ class DecoderFn(Function):
                                  H1=H1, ldH1=H1.stride(1), H2=H2, ldH2=H2.stride(1), Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2),
                                  Wq=W[17], ldWq=ops.ld(W[17]), b1i=b1i, b1h=b1h, b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre, Gx=Gx, Gf=Gf, C1=C1, C2=C2,
                                  G1=G1, G2=G2, AH=AH, AL=AL, k_out=k_out, QP=QP, qp_bytes=QP.numel() * 4, w_a=an_w, b_a=an_b, lens=lens,
-                                 **pr.recur_fields(), **fused_mid_weights(pr, h2a_w, bf, True))
+                                 **pr.recur_fields())
             ops.recurrence_fwd(rec, H1)
         for t in range(T if rec is None else 0):
             if ss is not None:
@@ -1138,9 +1131,10 @@ class DecoderFn(Function):
 
         if defer_dv:
             pr.dv_accum(AL[:T].view(T * S, AL.size(2)), dCtx.view(T * S, R), _step_offsets(T, S, dev), T, lens, dv, S, R)
+            del dCtx                                             # [T, S, R] fp32: not kept alive through the weight-gradient products
         if defer_du:
             pr.du_accum(AH[:T].view(T * S, A), dE.view(T * S, dE.size(2)), _step_offsets(T, S, dev), T, lens, an_w, du, S, A)
-            del dCtx
+            del dE
         P1, P2 = dP1.view(T * S, 4 * R), dP2.view(T * S, 4 * R)
         H1a, H2a = ops.flat_rows(H1[:T]), ops.flat_rows(H2[:T])
         wgrad(13, P2, H2a[:, :2 * R], bias=15)             # b_ih and b_hh have the same gradient: one sum rides each product

@@ -25,44 +25,15 @@ from . import functions as F_
 from . import ops
 
 
-# Scheduled sampling, second form (opt-in): the draw chain on the FIRED rows only (gathered logits product, list multinomial, gathered /
-# scattered x -> gates product) on a side stream beside the attention LSTM's recurrent product.  Built because round 3's review asked for
-# it; measured SLOWER than the in-line all-rows form and therefore off: 22.47 vs 21.61 ms per step at p = 0.25 (p = 0: 20.39).  Why
-# (tools/ss_probe.py, 161 fired rows of 640): the chain is 49 + 21 + 6 + 28 us of small launches per step on top of the complete batched
-# p = 0 work, against +76 us net for the in-line form, whose full-row products REPLACE their batched counterparts at ~80 % of their
-# efficiency; and the side stream buys nothing, because the recurrent product's 480 workgroups hold every CU slot until it ends.
-SS_FIRED_ROWS_ONLY = False
-
-
 class Plan:
     """The packed decoder's row plan, built by ONE launch (subgc_live_plan): sentences ordered by live steps (a step t of sentence s
     is live iff mask_t[s, t'] > 0 for some t' >= t and the reference's early break, AttModel.py:171-172, has not happened), the
     live-row counts per step and their prefix, the criterion's denominator.  The T counts are the one thing the HOST needs (launch
     dimensions); they travel to pinned memory behind an event."""
 
-    def __init__(self, labels, mask_t, ahead=False):
-        """`ahead` (AttModel.inputs_resident, opt-in): the plan kernel and its copy run on a SIDE stream that does not wait for the
-        caller's stream.  The plan depends on the label / mask INPUTS alone; on the caller's stream it queues behind the whole previous
-        train step, so the host -- which must read the T counts before it can size the decoder's launches -- drains the GPU once per
-        step.  Only legal when the caller guarantees that `labels` / `mask_t` are complete in device memory when forward is called
-        (a prefetching loader that synchronises its copy stream; bench.py's resident batch); the plan's device outputs are handed back to
-        the caller's stream through an event."""
+    def __init__(self, labels, mask_t):
         S, T = mask_t.shape
         self.T = T
-        if ahead and labels.is_cuda:
-            main = torch.cuda.current_stream(labels.device)
-            side = ops.plan_stream(labels.device)
-            with torch.cuda.stream(side):
-                self.perm32, self.perm, self.inv32, self.plan, self.den = ops.live_plan(labels, mask_t)
-                self.host = _pinned_counts(T)
-                self.host.copy_(self.plan[:T], non_blocking=True)
-                self.event = torch.cuda.Event()
-                self.event.record(side)
-            main.wait_event(self.event)                                         # the decoder's kernels read perm / offs / den on the caller's stream
-            for t_ in (self.perm32, self.perm, self.inv32, self.plan, self.den):
-                t_.record_stream(main)
-            self.offs = self.plan[T:]
-            return
         self.perm32, self.perm, self.inv32, self.plan, self.den = ops.live_plan(labels, mask_t)
         self.offs = self.plan[T:]                                              # int32 [T+1] on the device
         self.host = torch.empty(T, dtype=torch.int32).pin_memory()
@@ -74,16 +45,6 @@ class Plan:
         """-> list of live rows per step (blocks until the counts have arrived)."""
         self.event.synchronize()
         return [int(c) for c in self.host.tolist()]
-
-
-_PINNED_COUNTS = {}
-
-
-def _pinned_counts(T):
-    """Two alternating pinned [T] buffers (a fresh pin_memory() per step costs ~30 us of host time)."""
-    ring = _PINNED_COUNTS.setdefault(T, [[torch.empty(T, dtype=torch.int32).pin_memory() for _ in range(2)], 0])
-    ring[1] ^= 1
-    return ring[0][ring[1]]
 
 
 # `Plan` issued at the START of the model's forward: the counts travel while the host is still enqueueing the encoder, so the decoder
@@ -133,29 +94,19 @@ class PackedDecoderLossFn(Function):
         pr = F_.make_prepared(meta, fc_p, X_nodes, lens_p, idx_p, img_p, N, P, k_fc, k_att, scale, W if bf else None, rows=plan.inv32)
 
         # scheduled sampling (AttModel.py:157-167; see functions.DecoderFn): input words, x->gates and logits go step by step
-        # Two forms.  `fast_ss` (fp32 operands): everything is first computed teacher-forced in the batched launches of the p = 0 path;
-        # at step t >= 1 only the rows whose selector FIRED (subgc_ss_plan: ~p of the live rows) get the previous step's logits (a
-        # gathered GEMM), a draw, a new embedding row and a new x -> gates row (gathered / scattered GEMM) -- and that chain runs on a
-        # SIDE stream beside the attention LSTM's recurrent product, which does not need x_t; only the cell update waits for it
-        # (subgc_lstm_fwd_gemm_ev).  The per-step form below (all live rows, in line) remains for bf16 operands.
         ss = meta.get("ss")
         tokens_p = labels_p
-        fast_ss = ss is not None and not bf and rows > 0 and T_live > 0 and SS_FIRED_ROWS_ONLY
         if ss is not None:
             sel_p, u_p = ss[1].index_select(1, perm).contiguous(), ss[2].index_select(1, perm).contiguous()
         xt = act(max(rows, 1), E)
         Gx = new(max(rows, 1), 4 * R)
         tok_flat = k_flat = None
-        if fast_ss:
-            fired, fcnt = ops.ss_plan(sel_p, plan.plan[:T], ss[0])
-            lg_c = new(S, V1)                                   # the fired rows' logits of the previous step, compact
-            side, ev_lang = ops.side_stream(dev), torch.cuda.Event()
         if rows > 0:
             # the words actually fed, in packed order (ground truth; scheduled sampling overwrites the drawn ones in place) and the
             # keep-mask rows that go with them: the backward's embedding gradient is ONE launch over them in every mode
             tok_flat = tok_all[:rows]
             k_flat = None if k_xt is None else k_xt.view(-1, E)[:rows]
-        if (ss is None or fast_ss) and rows > 0:
+        if ss is None and rows > 0:
             # all T steps' input words in packed order -> ONE embedding launch (and one in the backward) instead of one per step;
             # the dropout keep-mask is random, so its first `rows` rows serve the packed rows as they are (GENERATED masks only: a
             # caller that injects masks -- the parity tests -- never gets here, AttModel._forward runs the unpacked decoder for them,
@@ -184,49 +135,21 @@ class PackedDecoderLossFn(Function):
         # arithmetic); the Python loop below remains for scheduled sampling (per-step logits / draws / embeddings) and for the bench's
         # FLOP-accounting pass.
         rec = None
-        h_cut = 0
         if ss is None and T_live > 0 and ops.recurrence_ok():
-            def fwd_block(r0, Mc, QPc):
-                """Argument block of the chain that owns rows [r0, r0 + Mc[t]) of every step (r0 = 0: the whole batch or chain a)."""
-                Tc = sum(1 for m_ in Mc if m_ > 0)
-                # the entry after the last step: where that step's state rows go.  A chain that ends before the batch does has no next
-                # rows of its own: its one dummy row goes to the slack behind the last step, never into the other chain's rows
-                nxt_m = Mc[Tc] if Tc < len(Mc) else 0
-                nxt_row = (ot[Tc] + r0) if nxt_m > 0 else rows
-                return ops.Recurrence(S=S, T=Tc, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
-                                      keep_scale=float(scale), m=list(Mc[:Tc]) + [nxt_m], row0=[o_ + r0 for o_ in ot[:Tc]] + [nxt_row],
-                                      hout_off=[(o_ + r0) * ops.ld(Hout) for o_ in ot[:Tc]], ld_hout=ops.ld(Hout), H1=H1, ldH1=ops.ld(H1), H2=H2,
-                                      ldH2=ops.ld(H2), Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]),
-                                      b1i=b1i, b1h=b1h, b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre[r0:], Gx=Gx, Gf=Gf[r0:], C1=C1[:, r0:], C2=C2[:, r0:],
-                                      G1=G1, G2=G2, AH=AH, AL=AL, k_out=None if k_out is None else k_out[:, r0:], QP=QPc, qp_bytes=QPc.numel() * 4,
-                                      w_a=an_w, b_a=an_b, lens=lens_p[r0:], **pr.recur_fields(r0), **F_.fused_mid_weights(pr, h2a_w, bf, True))
-            h_cut = 0 if pr.shared else ops.chain_cut(M[:T_live])
-            if h_cut:
-                # two chains (ops.RECURRENCE_CHAINS): rows [0, h) and [h, m[t]) of every step as independent recurrences on two streams
-                Ma = [min(m_, h_cut) for m_ in M] 
-                Mb = [max(m_ - h_cut, 0) for m_ in M]
-                rec = fwd_block(0, Ma, QP)
-                ops.recurrence_pair("subgc_recurrence_fwd_pair", rec, fwd_block(h_cut, Mb, new(8 * S * A)), H1, True)
-            else:
-                rec = fwd_block(0, list(M), QP)
-                ops.recurrence_fwd(rec, H1)
+            # the entry after the last step: where that step's state rows go (one dummy row in the slack when no row is live there)
+            nxt_m = M[T_live] if T_live < len(M) else 0
+            rec = ops.Recurrence(S=S, T=T_live, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
+                                 keep_scale=float(scale), m=list(M[:T_live]) + [nxt_m], row0=list(ot[:T_live]) + [ot[T_live] if nxt_m > 0 else rows],
+                                 hout_off=[o_ * ops.ld(Hout) for o_ in ot[:T_live]], ld_hout=ops.ld(Hout), H1=H1, ldH1=ops.ld(H1), H2=H2,
+                                 ldH2=ops.ld(H2), Hout=Hout, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2), Wq=W[17], ldWq=ops.ld(W[17]),
+                                 b1i=b1i, b1h=b1h, b2i=b2i, b2h=b2h, bq=h2a_b, pre=pre, Gx=Gx, Gf=Gf, C1=C1, C2=C2, G1=G1, G2=G2, AH=AH, AL=AL,
+                                 k_out=k_out, QP=QP, qp_bytes=QP.numel() * 4, w_a=an_w, b_a=an_b, lens=lens_p, **pr.recur_fields())
+            ops.recurrence_fwd(rec, H1)
         for t in range(T_live if rec is None else 0):
             m, o, mn = M[t], ot[t], (M[t + 1] if t + 1 < T else 0)
             o1 = ot[t + 1]
             mn_ = max(mn, 1)                                    # row limit 0 means "all" in the C ABI: write 1 dummy row into the slack
-            ev_ss = None
-            if fast_ss and t >= 1:
-                op, mp = ot[t - 1], M[t - 1]
-                side.wait_event(ev_lang)                        # h2_{t-1} (Hout) is there
-                with torch.cuda.stream(side):
-                    ft, ct = fired[t], fcnt[t:t + 1]
-                    ops.gemm(Hout[op:op + mp], W[21], lg_c[:mp], tb=True, bias=lg_b, a_rows=ft[:mp], m_dev=ct)
-                    ops.multinomial_rows_list_(lg_c[:mp], ft, ct, u_p[t], tok_flat[o:o + m])
-                    ops.embed_fwd(emb, tok_flat[o:o + m], 1, None if k_flat is None else k_flat[o:o + m], scale, xt[o:o + m])
-                    ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True, a_rows=ft[:m], c_rows=ft[:m], m_dev=ct)
-                    ev_ss = torch.cuda.Event()
-                    ev_ss.record(side)
-            elif ss is not None and not fast_ss:
+            if ss is not None:
                 if t >= 1:                                      # raw logits of every row live at step t-1; draws for the rows still live now
                     op, mp = ot[t - 1], M[t - 1]
                     ops.gemm(Hout[op:op + mp], W[21], logits[op:op + mp], tb=True, bias=lg_b)
@@ -234,17 +157,14 @@ class PackedDecoderLossFn(Function):
                 ops.embed_fwd(emb, tok_flat[o:o + m], 1, None if k_flat is None else k_flat[o:o + m], scale, xt[o:o + m])
                 ops.gemm(xt[o:o + m], W[9][:, 2 * R:], Gx[o:o + m], tb=True)
             ops.lstm_fwd_gemm(H1[o:o + m], Wc1, pre[:m], Gx[o:o + m], Gf[:m], b1i, b1h, C1[t][:m], C1[t + 1][:m], H2[o:o + m, R:2 * R],
-                              H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_, event=ev_ss)
+                              H1[o1:o1 + mn_, R:], None, 1.0, None, G1[o:o + m], m, R, rows_h=m, rows_h2=mn_)
             nq, sq = ops.gemm_planes(H2[o:o + m, R:2 * R], W[17], QP, tb=True)   # the query product stays as split-K planes: the attention
             pr.attn_fwd(AH[o:o + m], an_w, an_b, lens_p, H2[o:o + m, :R], AL[o:o + m], m, A, R, q=(QP, nq, sq, h2a_b))   # kernel sums them (+ bias) into AH
 
             ops.lstm_fwd_gemm(H2[o:o + m], Wc2, pre[:m], None, None, b2i, b2h, C2[t][:m], C2[t + 1][:m], H1[o1:o1 + mn_, :R],
                               H2[o1:o1 + mn_, 2 * R:], None if k_out is None else k_out[t], scale, Hout[o:o + m], G2[o:o + m], m, R,
                               rows_h=mn_, rows_h2=mn_)
-            if fast_ss:
-                ev_lang = torch.cuda.Event()
-                ev_lang.record()
-        if ss is None or fast_ss:
+        if ss is None:
             ops.gemm(Hout[:rows], W[21], logits[:rows], tb=True, bias=lg_b)
         elif T_live > 0:
             op = ot[T_live - 1]
@@ -256,7 +176,6 @@ class PackedDecoderLossFn(Function):
         loss, nll = ops.masked_nll_fwd(logits[:rows].view(rows, 1, V1), tgt_p, msk_p, den=plan.den, lse=lse)
 
         ctx.meta = (N, scale, S, T, T_live, R, E, A, V1, M, ot, rows)
-        ctx.h_cut = h_cut
         ctx.masks = (k_xt, k_out)
         ctx.flat_tokens = (tok_flat, k_flat)
         ctx.W, ctx.bf = W, bf
@@ -338,29 +257,15 @@ class PackedDecoderLossFn(Function):
         F_.note("bptt_begin", T_live)
         rec = None
         if T_live > 0 and ops.recurrence_ok():
-            def bwd_block(r0, Mc, planes, cells):
-                Tc = sum(1 for m_ in Mc if m_ > 0)
-                PA_, PB_, PC_ = planes
-                c1, c2 = cells
-                return ops.Recurrence(S=S, T=Tc, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
-                                      keep_scale=float(scale), m=list(Mc[:Tc]) + [0], row0=[o_ + r0 for o_ in ot[:Tc]] + [rows],
-                                      dhout_off=[(o_ + r0) * R for o_ in ot[:Tc]], ld_dhout=R, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2),
-                                      Wq=W[17], ldWq=ops.ld(W[17]), C1=C1[:, r0:], C2=C2[:, r0:], G1=G1, G2=G2, AH=AH, AL=AL,
-                                      k_out=None if k_out is None else k_out[:, r0:], w_a=an_w, lens=lens_p[r0:], dHout=dHout, dP1=dP1, dP2=dP2,
-                                      dAH=dAH, du=du, du_planes=du.size(0) if du.dim() == 3 else 1, du_plane_stride=du.stride(0) if du.dim() == 3 else 0,
-                                      dv=None if defer_dv else dv, dWa=dWa, dBa=dBa, dCtx=dCtx if defer_dv else None, dE=dE, PA=PA_, pa_bytes=PA_.numel() * 4,
-                                      PB=PB_, pb_bytes=PB_.numel() * 4, PC=PC_, pc_bytes=PC_.numel() * 4, dC1_in=c1[0][r0:], dC1_out=c1[1][r0:],
-                                      dC2_in=c2[0][r0:], dC2_out=c2[1][r0:], **pr.recur_fields(r0))
-            h_cut = getattr(ctx, "h_cut", 0) if ops.RECURRENCE_CHAINS >= 2 else 0
-            if h_cut:
-                Ma = [min(m_, h_cut) for m_ in M]
-                Mb = [max(m_ - h_cut, 0) for m_ in M]
-                rec = bwd_block(0, Ma, (PA, PB, PC), (dC1, dC2))
-                rec_b = bwd_block(h_cut, Mb, (new(8 * S * 3 * R), new(8 * S * R), new(8 * S * 2 * R)), (dC1, dC2))
-                ops.recurrence_pair("subgc_recurrence_bwd_pair", rec, rec_b, dHout, False)
-            else:
-                rec = bwd_block(0, list(M), (PA, PB, PC), (dC1, dC2))
-                ops.recurrence_bwd(rec)
+            rec = ops.Recurrence(S=S, T=T_live, R=R, A=A, n_alpha=AL.size(1), bf16=int(bf), gemm_flags=ops.GEMM_MODES[ops.gemm_mode.current],
+                                 keep_scale=float(scale), m=list(M[:T_live]) + [0], row0=list(ot[:T_live]) + [rows],
+                                 dhout_off=[o_ * R for o_ in ot[:T_live]], ld_dhout=R, Wc1=Wc1, ldW1=ops.ld(Wc1), Wc2=Wc2, ldW2=ops.ld(Wc2),
+                                 Wq=W[17], ldWq=ops.ld(W[17]), C1=C1, C2=C2, G1=G1, G2=G2, AH=AH, AL=AL, k_out=k_out, w_a=an_w, lens=lens_p, dHout=dHout,
+                                 dP1=dP1, dP2=dP2, dAH=dAH, du=du, du_planes=du.size(0) if du.dim() == 3 else 1,
+                                 du_plane_stride=du.stride(0) if du.dim() == 3 else 0, dv=None if defer_dv else dv, dWa=dWa, dBa=dBa,
+                                 dCtx=dCtx if defer_dv else None, dE=dE, PA=PA, pa_bytes=PA.numel() * 4, PB=PB, pb_bytes=PB.numel() * 4, PC=PC,
+                                 pc_bytes=PC.numel() * 4, dC1_in=dC1[0], dC1_out=dC1[1], dC2_in=dC2[0], dC2_out=dC2[1], **pr.recur_fields())
+            ops.recurrence_bwd(rec)
         for t in range(T_live - 1, -1, -1):
             if rec is not None:
                 break
@@ -390,6 +295,7 @@ class PackedDecoderLossFn(Function):
             del dCtx
         if defer_du:
             pr.du_accum(AH, dE, step_off, max(T_live, 1), lens_p, an_w, du, S, A)
+            del dE
         dGf = new(S, 4 * R)                                     # d(fc->gates) = sum over each sentence's live steps of dP1: one launch
         ops.packed_time_sum(dP1, step_off, T_live, S, dGf)
         dGf = opnd(dGf)

@@ -124,8 +124,6 @@ class AttModel(CaptionModel):
         # marginal is unchanged, the joint distribution is not the reference's; 7-8 % faster on Full_GC_Kar, reported beside the
         # default by bench.py); 0: never.  Not a reference option.
         self.share_attention_sets = int(g("share_attention_sets", -1))
-        if g("recurrence_chains") is not None:                       # opt-in: the packed recurrence as two interleaved chains (ops.RECURRENCE_CHAINS)
-            ops.RECURRENCE_CHAINS = int(g("recurrence_chains"))
         self.dedup_att_embed = g("dedup_att_embed", 1) != 0          # 0: att_embed on the replicated rows themselves (measurement / tests)
         # the two GCN units that read the same source run as one paired Function (concatenated fc_lft; functions.UnitPairFn); 0 = one by one
         self.pair_gcn_units = g("pair_gcn_units", 1) != 0
@@ -138,10 +136,6 @@ class AttModel(CaptionModel):
         # step_{h_att,c_att,h_lang,c_lang,alpha,ctx,logp}); None (default): no cost.  The train forward then runs the unpacked
         # decoder, the decode the eager (not graph-replayed) loop -- same kernels.
         self.__dict__["tap"] = None
-        # opt-in: the caller guarantees that the tensors handed to forward are complete in device memory when the call is made (a loader
-        # that synchronises its upload stream; a resident batch).  The packed decoder's row plan then runs on a side stream instead of
-        # queueing behind the previous train step, and the host no longer drains the GPU once per step (functions_packed.Plan).
-        self.__dict__["inputs_resident"] = False
         self.__dict__["_nbt_pending"] = {}
         self._build_parameters()
 
@@ -261,7 +255,6 @@ class AttModel(CaptionModel):
 
     def flatten_grads(self):
         """Point every .grad into one flat fp32 buffer (zeroed); dead parameters contribute zeros."""
-        ops.join_forks()                  # no weight-gradient product of an earlier backward may still be writing the buffer
         fresh = self.flat_grads is None or self.flat_grads.device != self.flat_params.device
         if fresh:
             self.flat_grads = torch.zeros_like(self.flat_params)
@@ -717,7 +710,7 @@ class AttModel(CaptionModel):
         plan = None
         if packed:                                                                        # the packed decoder's row plan, read behind an event
             from ..functions_packed import PlanAhead
-            plan = PlanAhead(seq.contiguous(), fused_crit[1], ahead=bool(self.__dict__.get("inputs_resident", False)))
+            plan = PlanAhead(seq.contiguous(), fused_crit[1])
         masks = self._masks({"fc": ((b5, R), p), "att": ((b5 * N, R), p), "xt": ((T, b5, E), p), "out": ((T, b5, R), p),
                              "gpn_hid": ((2 * b5 * hb, self.att_hid_size), self.gpn_drop_prob if (self.gpn and self.use_sGPN_score) else 0.0)}, dev)
         X = self._encode(att_feats, obj_dist, pred_dist, rel_ind)

@@ -22,18 +22,11 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
-_OVERRIDE = [None]        # raw handle of the side stream a forked call runs on (wgrad_forked); None: the caller's current stream
-
-
 def _stream_of(idx):
-    if _OVERRIDE[0] is not None:
-        return _OVERRIDE[0]
     return _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(idx).cuda_stream
 
 
 def _stream():
-    if _OVERRIDE[0] is not None:
-        return _OVERRIDE[0]
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
@@ -74,20 +67,6 @@ def _ws(t):
 
 
 _CAPTURE_STREAMS = {}
-_SIDE_STREAMS = {}
-
-
-def side_stream(device):
-    """One extra HIP stream per device for work that runs BESIDE the main launch sequence (scheduled sampling's per-step draw chain
-    next to the recurrent product); it gets its own split-K workspace like any stream (ensure_workspace)."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(idx)
-    if st is None:
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
-    return st
-
-
 class graph_capture:
     """`with ops.graph_capture(graph, device): ...` = torch.cuda.graph on a dedicated capture stream of that device whose
     split-K workspace was allocated EAGERLY (outside any graph's private pool), so the addresses a captured GEMM bakes in stay
@@ -156,6 +135,23 @@ def set_gemm_mode(mode):
     if mode not in GEMM_MODES:
         raise SubgcError(f"unknown GEMM mode {mode!r}")
     gemm_mode.current = mode
+
+
+class debug_bounds:
+    """`with ops.debug_bounds(): ...` -- the library's debug bounds mode (subgc_debug_bounds): every entry point that consumes an index
+    tensor it did not produce (rel_ind, gpn_obj_ind, node lists, word ids, criterion targets, class ids) validates it on the device before
+    its kernels run and raises SubgcError naming the tensor, the first bad position and its value -- the way the reference fails on a bad
+    loader tensor (IndexError; the asserts of gpn.py:117-118).  One launch + one stream synchronisation per checked tensor: debugging only."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = lib().subgc_debug_bounds(int(self.on))
+        return self
+
+    def __exit__(self, *exc):
+        lib().subgc_debug_bounds(int(self.prev))
 
 
 class gemm_tune:
@@ -270,15 +266,6 @@ def transpose_bf16(x, out=None):
     if out is None:
         out = torch.zeros(cols, (rows + 7) // 8 * 8, device=x.device, dtype=BF16)[:, :rows]
     call("subgc_transpose_f32_bf16", _ptr(x, torch.float32), ld(x), _ptr(out, BF16), ld(out), rows, cols, _stream())
-    return out
-
-
-def transpose_f32(x, out=None):
-    """out[c, r] = x[r, c], fp32 (subgc_transpose_f32)."""
-    rows, cols = x.shape
-    if out is None:
-        out = torch.empty(cols, rows, device=x.device, dtype=torch.float32)
-    call("subgc_transpose_f32", _ptr(x, torch.float32), ld(x), _ptr(out, torch.float32), ld(out), rows, cols, _stream())
     return out
 
 
@@ -421,73 +408,6 @@ def wgrad(dy, x, dW, db, accum=False, db_accum=False, m_dev=None):
              _ptr(db, torch.float32), (ACCUM if accum else 0) | GEMM_MODES[gemm_mode.current] | gemm_tune.f32_bits, int(db_accum),
              _ptr(m_dev, torch.int32), *_ws(dy), _stream())
     return dW, db
-
-
-# ---- weight gradients beside the backward's data-gradient chain (opt-in; measured, no gain -- DESIGN 8.0) -----------------------------------
-# Nothing downstream of a layer's backward reads its parameter gradients before the slice they live in is announced (functions.grads_ready)
-# or the backward returns, while the NEXT kernel of the chain needs only the data gradient.  The weight-gradient products of the encoder are
-# short, half-filling launches (32 tiles x 8 K parts of 512 workgroup slots for a 1024 x 512 GCN matrix); FORK_WGRADS = True runs them on one
-# of two side streams BESIDE the chain.  Stand-alone that pays (12 x (dx product + weight gradient), bf16: 1072 -> 765 us); inside the real
-# backward 1.7 ms per Full_GC_Kar step run two kernels deep (tools/overlap_report.py) and the step does not get shorter -- the chain's own
-# kernels (add_n, the BatchNorm and aggregation backwards) already fill the memory system, the co-running kernels just share it -- while
-# the two extra stream-ordering calls per product cost the host-bound configs 0.1 ms.  Off.
-FORK_WGRADS = False
-_FORK_SIDES = 2
-_FORKS = {}               # device index -> {"sides": [(torch stream, raw handle)], "next": i, "used": {raw handles}, "held": [tensors], "armed": bool}
-
-
-def _fork_state(idx):
-    st = _FORKS.get(idx)
-    if st is None:
-        sides = []
-        for _ in range(_FORK_SIDES):
-            ts = torch.cuda.Stream(device=idx)
-            with torch.cuda.stream(ts):
-                ensure_workspace(torch.device("cuda", idx))        # its own split-K scratch, allocated before any fork
-            sides.append((ts, ts.cuda_stream))
-        st = _FORKS[idx] = {"sides": sides, "next": 0, "used": set(), "held": [], "armed": False}
-    return st
-
-
-def join_forks(device=None):
-    """The caller's current stream waits for every weight-gradient product forked since the last join (functions.grads_ready, the end of the
-    backward, FlatAdam.step, flatten_grads): after it, the parameter gradients are ordered like any other result of the stream."""
-    for idx, st in _FORKS.items():
-        if device is not None and torch.device(device).index not in (None, idx):
-            continue
-        if st["used"]:
-            main = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(idx).cuda_stream
-            for raw in st["used"]:
-                call("subgc_stream_wait", main, raw)
-            st["used"] = set()
-        st["held"] = []
-        st["armed"] = False
-
-
-def wgrad_forked(dy, x, dW, db, accum=False, db_accum=False, m_dev=None):
-    """ops.wgrad on a side stream (two per device, alternating), ordered behind everything the current stream has enqueued so far.  Only
-    inside a running backward (the engine's end-of-pass callback is the last join); the operands stay referenced until the join so that
-    the allocator cannot hand their memory to a later kernel of the main stream.  Destinations must not be read before `join_forks`."""
-    if not FORK_WGRADS or _OVERRIDE[0] is not None:
-        return wgrad(dy, x, dW, db, accum=accum, db_accum=db_accum, m_dev=m_dev)
-    idx = dy.device.index
-    st = _fork_state(idx)
-    if not st["armed"]:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join_forks)
-        except RuntimeError:                                   # not inside a backward pass: nothing would join
-            return wgrad(dy, x, dW, db, accum=accum, db_accum=db_accum, m_dev=m_dev)
-        st["armed"] = True
-    _, raw = st["sides"][st["next"]]
-    st["next"] = (st["next"] + 1) % len(st["sides"])
-    call("subgc_stream_wait", raw, _stream_of(idx))
-    st["used"].add(raw)
-    st["held"].append((dy, x, m_dev))
-    _OVERRIDE[0] = raw
-    try:
-        return wgrad(dy, x, dW, db, accum=accum, db_accum=db_accum, m_dev=m_dev)
-    finally:
-        _OVERRIDE[0] = None
 
 
 def colsum_set(xs, outs, accumulate=False):
@@ -1014,10 +934,9 @@ def lstm_fwd(g0, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S,
          int(rows_h2), _same_storage(h, h2, hdrop), _stream())
 
 
-def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0, event=None):
+def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdrop, gates, S, R, rows_h=0, rows_h2=0):
     """gemm(x, w^T) + lstm_fwd with the split-K reduce folded into the cell kernel (subgc_lstm_fwd_gemm); `pre` [S, 4R] is scratch.
-    x, w both fp32 or both bf16; h / h2 / hdrop all fp32 or all bf16.  `event` (torch.cuda.Event): the stream waits for it between the
-    product and the cell update (g1 may still be in production on another stream while the product runs)."""
+    x, w both fp32 or both bf16; h / h2 / hdrop all fp32 or all bf16."""
     L = lambda t: ld(t) if t is not None else 0
     K = x.size(1)
     xb = int(is_b16(x))
@@ -1028,37 +947,10 @@ def lstm_fwd_gemm(x, w, pre, g1, g2, b0, b1, c_prev, c, h, h2, keep, scale, hdro
         FLOPS["gemm"] += 2.0 * S * 4 * R * K
         FLOPS["gemm_bytes"] += eb * (S * K + K * 4 * R) + 4.0 * S * 4 * R
         FLOPS["gemm_calls"] += 1
-    call("subgc_lstm_fwd_gemm_ev", _ptr(x), ld(x), _ptr(w), ld(w), K, _ptr(pre, torch.float32), ld(pre),
+    call("subgc_lstm_fwd_gemm", _ptr(x), ld(x), _ptr(w), ld(w), K, _ptr(pre, torch.float32), ld(pre),
          _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev), _ptr(c), _ptr(h), L(h), _ptr(h2), L(h2),
          _ptr(keep, torch.uint8), float(scale), _ptr(hdrop), L(hdrop), _ptr(gates), S, R, int(rows_h), int(rows_h2),
-         xb | (_same_storage(h, h2, hdrop) << 1), GEMM_MODES[gemm_mode.current], *_ws(x), None if event is None else event.cuda_event, _stream())
-
-
-# The row-local middle of a train-decoder step -- attention-LSTM cell update, h2att query product, attention -- as ONE launch per step
-# (csrc/recurrent_mid.hip; SubgcRecurrence.fuse_mid).  Bit 0: on (per-sentence attention sets, forward), bit 1: one workgroup per CU.
-# OPT-IN (bench.py --fuse-mid 1): built for round 4's review (item 1: fuse the recurrence's cell / attention work into fewer launches),
-# correct (tests/test_mid_gpu.py, test_packed_gpu.py), and SLOWER than the three launches it replaces -- measured with in-kernel stamps
-# (tools/mid_probe.py, profiles/r05_mid_probe.txt): Kar 640 rows 57 us against 42-46, Full_GC_Kar 1280 rows 97 against 75-79, Flickr 47
-# against 43-47.  Why: (1) the cell phase is bound by the CHIP's memory bandwidth (159 MB of planes / gate terms per step: 28 us fused or
-# not); (2) every workgroup has to stream the whole query weight (1 MB bf16 / 2 MB fp32) for its 3-5 rows: 256 CUs reading the same
-# megabytes saturate the L2s at ~13 TB/s aggregate = 20 us (bf16) / 33 us (fp32), against 15 / 19 us for the chip-wide split-K product;
-# (3) a workgroup alone on its CU walks its phases serially, so the attention part (25 + 5 + 11 us on Full-GC) is no faster than the
-# 1280-workgroup launch (36 us).  DESIGN 8.
-FUSE_MID = 0
-
-
-def mid_fwd(g0, parts, plane, g1, g2, b0, b1, c_prev, c, h, h2, gates, wq, bq, q_out, u, v, w_a, b_a, off, lens, ctx, alpha, m, R, A,
-            rows_h=0, rows_h2=0, flags=0, stamps=None):
-    """subgc_mid_fwd: lstm_fwd (g0 = `parts` planes `plane` floats apart) + q = h wq^T + bq (-> q_out) + attn_fwd in one launch."""
-    L = lambda t: ld(t) if t is not None else 0
-    if FLOPS["on"]:
-        FLOPS["gemm"] += 2.0 * m * A * R
-        FLOPS["gemm_bytes"] += (2.0 if is_b16(wq) else 4.0) * (m * R + A * R) + 4.0 * m * A
-    call("subgc_mid_fwd", _ptr(g0, torch.float32), ld(g0), int(parts), int(plane), _ptr(g1), L(g1), _ptr(g2), L(g2), _ptr(b0), _ptr(b1), _ptr(c_prev),
-         _ptr(c), _ptr(h), ld(h), int(rows_h), _ptr(h2), L(h2), int(rows_h2), _ptr(gates), _ptr(wq), ld(wq), _ptr(bq, torch.float32),
-         _ptr(q_out, torch.float32), _ptr(u), _ptr(v), _ptr(w_a), _ptr(b_a), _ptr(off, torch.int32), _ptr(lens, torch.int32), _ptr(ctx), ld(ctx),
-         _ptr(alpha), alpha.size(1) if alpha is not None else 0, int(m), int(R), int(A), int(is_b16(ctx)) | (_uv_b16(u, v, A, R) << 1), int(flags),
-         _ptr(stamps, torch.int64), _stream())
+         xb | (_same_storage(h, h2, hdrop) << 1), GEMM_MODES[gemm_mode.current], *_ws(x), _stream())
 
 
 def gemm_planes(a, b, planes, *, ta=False, tb=False):
@@ -1178,72 +1070,6 @@ def recurrence_bwd(rec):
     import ctypes
     call("subgc_recurrence_bwd", ctypes.addressof(rec.st), _stream())
 
-
-# Two interleaved chains of the train decoder's recurrence (subgc_recurrence_*_pair): rows [0, h) of every step on the caller's stream,
-# rows [h, m[t]) on a side stream.  0 = one chain (every launch of the loop in one queue).
-# OPT-IN (opt.recurrence_chains = 2 / bench.py --chains 2).  Measured (round 5, A/B in one job, two repeats): Sub_GC_Kar 19.90 -> 19.70 ms
-# (-1.0 %), Full_GC_Kar 16.05 -> 15.76 (-1.8 %), Flickr (320 rows) +0.6 % -- the step gets a little shorter because one chain's cell /
-# attention kernels run under the other's product, but every overlapped product takes longer (the chip's memory system is shared: GEMM
-# launch durations sum to 20.5 ms instead of 17.3), so the GEMM family holds the device for 18.1 ms instead of 17.4 and the roofline
-# fraction of the dominant kernel DROPS (0.669 -> 0.643) while the value rises 1 %.  Off by default: the contract line keeps one queue and
-# clean per-launch durations; DESIGN 8.
-RECURRENCE_CHAINS = 0
-_CHAIN_STREAMS = {}
-
-
-def chain_stream(device):
-    """The second chain's stream of `device` (its own split-K workspace, like any stream)."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _CHAIN_STREAMS.get(idx)
-    if st is None:
-        st = _CHAIN_STREAMS[idx] = torch.cuda.Stream(device=idx)
-    return st
-
-
-_PLAN_STREAMS = {}
-
-
-def plan_stream(device):
-    """The stream the packed decoder's row plan runs on when the caller vouches for resident inputs (functions_packed.Plan(ahead=True))."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _PLAN_STREAMS.get(idx)
-    if st is None:
-        st = _PLAN_STREAMS[idx] = torch.cuda.Stream(device=idx)
-    return st
-
-
-def chain_cut(M, tile=128):
-    """Row boundary h of the two chains for the live-row counts M[t] of a packed recurrence (0: one chain).  A multiple of the GEMM's
-    row tile, so the two products of a step cover the tiles of the one they replace, near half of the first step's rows; small
-    batches stay whole (two half-empty tile rows would cost more than the overlap returns)."""
-    if RECURRENCE_CHAINS < 2 or not M or M[0] < 4 * tile:        # measured (round 5): 640 / 1280 rows gain 1-2 %, 320 rows lose 0.6 %
-        return 0
-    h = tile * max(1, round(M[0] / (2.0 * tile)))
-    return h if M[0] - h >= tile // 2 else 0
-
-
-def recurrence_pair(fn, rec_a, rec_b, like, with_ws):
-    """Issue the two chains: a on the current stream, b on the chain stream, forked after everything queued so far and joined before
-    anything queued later (events).  fn = "subgc_recurrence_fwd_pair" / "subgc_recurrence_bwd_pair"."""
-    import ctypes
-    dev = like.device
-    main = torch.cuda.current_stream(dev)
-    side = chain_stream(dev)
-    fork = torch.cuda.Event()
-    fork.record(main)
-    side.wait_event(fork)
-    ws_a = _ws(like)
-    with torch.cuda.stream(side):
-        ws_b = _ws(like)
-    if with_ws:
-        call(fn, ctypes.addressof(rec_a.st), ws_a[0], ws_a[1], main.cuda_stream, ctypes.addressof(rec_b.st), ws_b[0], ws_b[1], side.cuda_stream)
-    else:
-        call(fn, ctypes.addressof(rec_a.st), main.cuda_stream, ctypes.addressof(rec_b.st), side.cuda_stream)
-    join = torch.cuda.Event()
-    join.record(side)
-    main.wait_event(join)
 
 
 def recurrence_ok():
@@ -1568,23 +1394,6 @@ def multinomial_rows_(logits, u, sel_u, prob, tok):
     rows, V = logits.shape
     call("subgc_multinomial_rows", _ptr(logits, torch.float32), ld(logits), rows, V, _ptr(u, torch.float32), _ptr(sel_u, torch.float32),
          float(prob), _ptr(tok, torch.int64), tok.stride(0) if tok.dim() else 1, _stream())
-    return tok
-
-
-def ss_plan(sel_u, live, prob):
-    """Scheduled sampling's fired rows per step (subgc_ss_plan): sel_u fp32 [T, S] selector uniforms, live int32 [T] (device) live rows per
-    step.  -> (fired int32 [T, S], count int32 [T]): fired[t][:count[t]] = rows r < live[t] with sel_u[t][r] < prob (none at t = 0)."""
-    T, S = sel_u.shape
-    fired = torch.empty(T, S, device=sel_u.device, dtype=torch.int32)
-    count = torch.empty(T, device=sel_u.device, dtype=torch.int32)
-    call("subgc_ss_plan", _ptr(sel_u, torch.float32), sel_u.stride(0), _ptr(live, torch.int32), float(prob), T, S, _ptr(fired), _ptr(count), _stream())
-    return fired, count
-
-
-def multinomial_rows_list_(logits, rows, count, u, tok):
-    """tok[rows[i]] <- draw from softmax(logits[i]) for i < *count (compact logits rows; subgc_multinomial_rows_list)."""
-    call("subgc_multinomial_rows_list", _ptr(logits, torch.float32), ld(logits), logits.size(0), logits.size(1), _ptr(rows, torch.int32),
-         _ptr(count, torch.int32), _ptr(u, torch.float32), _ptr(tok, torch.int64), tok.stride(0) if tok.dim() else 1, _stream())
     return tok
 
 

@@ -203,8 +203,6 @@ class GradBucketReducer:
         never re-sorted -- every rank then issues the five slices with the same sizes; a rank that announced a slice early has
         merely issued it sooner.  With overlap on, the early order IS the canonical order (logit, recurrent, prepare, gcn), so a
         rank that missed an announcement still lines up (`_ready` holds a slice back until its predecessors are out)."""
-        from . import ops
-        ops.join_forks()
         if not self.active:
             return self.model.flat_grads
         g = self.model.flat_grads
@@ -269,7 +267,6 @@ class FlatAdam:
         the buffer.  Default: torch's semantics, the (scaled, clipped) gradients stay readable after the step."""
         from . import ops
         self.t += 1
-        ops.join_forks()
         ops.fill_(self.sumsq, 0.0)
         ops.sumsq(self.model.flat_grads, self.sumsq)
         m = self.model

@@ -161,3 +161,28 @@ def test_grounding_argmax_kernel_equals_oracle_on_other_shapes(N, I):
             np.testing.assert_array_equal(h["att2"][i, :w], att2)
             np.testing.assert_array_equal(h["node"][i, :w], node)
             assert (h["att2"][i, w:] == -1).all() and (h["node"][i, w:] == -1).all()
+
+
+@pytest.mark.gpu
+def test_eval_rank_rows_nan_scores_and_row_limit():
+    """subgc_eval_rank_rows at its advertised limit (8192 rows of one image: 65 544 bytes of dynamic LDS, above the 64 KiB default) and
+    with NaN scores: NaN ranks as -inf with the index as tie-break, so the order is a permutation (no rank taken twice, none left out)."""
+    from subgc import ops
+    rng = np.random.default_rng(5)
+    rows, T = 8192 + 300, 4
+    bounds = [0, 8192, rows]
+    score = rng.random(rows).astype(np.float32)
+    score[[3, 100, 8191, 8200, 8201]] = np.nan
+    score[50] = score[49]
+    seq = rng.integers(1, 50, size=(rows, T))
+    keep = np.arange(rows)
+    dev = "cuda:0"
+    out = ops.eval_collect(torch.from_numpy(score).to(dev), torch.from_numpy(keep).to(dev), torch.from_numpy(seq).to(dev), bounds)
+    for a, b in zip(bounds, bounds[1:]):
+        key = np.where(np.isnan(score[a:b]), -np.inf, score[a:b])
+        want = np.argsort(-key, kind="stable")
+        np.testing.assert_array_equal(out["order"][a:b], want)
+        np.testing.assert_array_equal(out["keep"][a:b], keep[a:b][want])
+        np.testing.assert_array_equal(out["seq"][a:b], seq[a:b][want])
+    with pytest.raises(ops.SubgcError):
+        ops.eval_collect(torch.zeros(8193, device=dev), torch.zeros(8193, device=dev, dtype=torch.int64), torch.zeros(8193, T, device=dev, dtype=torch.int64), [0, 8193])

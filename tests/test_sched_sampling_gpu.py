@@ -114,61 +114,3 @@ def test_scheduled_sampling_matches_the_reference_golden(golden, packed):
         m.injected_ss = inj
         outputs, _, _ = m(*__import__("subgc").synthetic.forward_args({k: v.to(DEV) for k, v in batch.items()}))
         close(outputs, ref["outputs"], "outputs")
-
-
-def test_ss_plan_and_list_multinomial_kernels():
-    """subgc_ss_plan: fired[t] = ascending rows r < live[t] with sel[t][r] < prob, nothing at t = 0; subgc_multinomial_rows_list draws for
-    exactly those rows from COMPACT logits rows and equals the all-rows kernel (subgc_multinomial_rows) on the same logits."""
-    g = torch.Generator().manual_seed(7)
-    T, S, V, prob = 9, 700, 333, 0.3
-    sel = torch.rand(T, S, generator=g).to(DEV)
-    live = torch.tensor([700, 700, 650, 400, 257, 256, 64, 1, 0], dtype=torch.int32).to(DEV)
-    fired, cnt = ops.ss_plan(sel, live, prob)
-    cnt_h, fired_h, sel_h, live_h = cnt.cpu(), fired.cpu(), sel.cpu(), live.cpu()
-    assert int(cnt_h[0]) == 0 and int(cnt_h[8]) == 0
-    for t in range(1, T):
-        want = [r for r in range(int(live_h[t])) if float(sel_h[t, r]) < prob]
-        assert fired_h[t, :int(cnt_h[t])].tolist() == want, t
-    t = 2
-    m = int(live_h[t])
-    logits = (torch.randn(m, V, generator=g) * 3).to(DEV)
-    u = torch.rand(S, generator=g).to(DEV)
-    base = torch.randint(0, V, (m,), generator=g).to(DEV)
-    a, b = base.clone(), base.clone()
-    ops.multinomial_rows_(logits, u[:m].contiguous(), sel[t][:m].contiguous(), prob, a)
-    compact = logits[fired[t][:int(cnt_h[t])].long()].contiguous()
-    pad = torch.zeros(m - compact.size(0), V, device=DEV)
-    ops.multinomial_rows_list_(torch.cat([compact, pad]), fired[t], cnt[t:t + 1], u, b)
-    assert torch.equal(a, b) and not torch.equal(a, base)
-
-
-@pytest.mark.parametrize("drop", [0.0])          # (with dropout the two forms assign the random x_t keep-mask rows differently: both valid, not comparable)
-def test_fired_rows_side_stream_form_equals_the_in_line_form(drop):
-    """The packed decoder's two scheduled-sampling forms on the same Philox stream: draw chain on the fired rows only, on a side stream
-    beside the recurrent product (default) vs. every live row in line (functions_packed.SS_FIRED_ROWS_ONLY = False).  Same words fed,
-    same loss and gradients up to the rounding of the differently tiled logit products."""
-    import argparse
-    from subgc import functions_packed as FP, synthetic
-    from test_packed_gpu import OPT
-    torch.manual_seed(1)
-    m = models.setup(argparse.Namespace(**dict(OPT, sampling_prob=0.35, drop_prob_lm=drop))).to(DEV).train()
-    batch = synthetic.make_train_batch(24, D=256, vocab=300, n_obj_cls=60, seed=3, fc_size=256, min_len=3, max_len=16)
-    res = {}
-    for fast in (False, True):
-        FP.SS_FIRED_ROWS_ONLY = fast
-        try:
-            m._dropout_calls = 0
-            lw = models.LossWrapper(m, None)
-            b = {k: v.to(DEV) for k, v in batch.items()}
-            m.flatten_grads()
-            out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
-                     None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
-            models.total_loss(out).backward()
-            torch.cuda.synchronize()
-            res[fast] = (float(out["lang_loss"]), m.flat_grads.clone())
-        finally:
-            FP.SS_FIRED_ROWS_ONLY = False
-    (l0, g0), (l1, g1) = res[False], res[True]
-    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)), (l0, l1)
-    scale = float(g0.abs().max())
-    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=2e-5 * scale + 1e-8, rtol=2e-4)

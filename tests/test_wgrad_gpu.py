@@ -146,39 +146,6 @@ def test_wgrad_rejects_mismatched_operands():
         ops.wgrad(dy, x, torch.empty(64, 32, device=DEV), torch.empty(32, device=DEV))
 
 
-def test_forked_weight_gradients_equal_the_in_line_ones():
-    """ops.FORK_WGRADS (opt-in): the encoder's weight-gradient products on side streams beside the backward chain, joined when the slice is
-    announced / the backward returns -- same kernels, same operands: every gradient bit for bit (the atomically accumulated embedding rows: to 1e-9), and ready on the caller's stream."""
-    import argparse
-    import bench
-    import subgc.models as models
-    from subgc import synthetic
-    cfg = bench.CONFIGS["full_gc_kar"]
-    grads = {}
-    for fork in (False, True):
-        torch.manual_seed(5)
-        m = models.setup(argparse.Namespace(**dict(cfg["opt"], drop_prob_lm=0.0))).to(DEV).train()
-        lw = models.LossWrapper(m, None)
-        b = {k: v.to(DEV) for k, v in synthetic.make_train_batch(8, seed=3, **cfg["data"]).items()}
-        ops.FORK_WGRADS = fork
-        try:
-            for _ in range(2):                                  # second pass: the side streams and their workspaces exist
-                m.flatten_grads()
-                models.total_loss(lw(*bench.lw_args(b))).backward()
-                g = m.flat_grads.clone()                        # on the caller's stream, no synchronize: the end-of-backward join orders it
-        finally:
-            ops.FORK_WGRADS = False
-        grads[fork] = g
-        emb = m.P("embed.0.weight").grad
-        lo = (emb.data_ptr() - m.flat_grads.data_ptr()) // 4
-    a, b = grads[False].clone(), grads[True].clone()
-    assert float((a - b).abs().max()) < 1e-9                   # the embedding rows are accumulated with float atomics (order varies run to run) ...
-    a[lo:lo + emb.numel()] = 0
-    b[lo:lo + emb.numel()] = 0
-    assert torch.equal(a, b)                                   # ... everything else is bit for bit the same
-    assert float(b.abs().max()) > 0
-
-
 @pytest.mark.parametrize("K,M,N,splits", [(7000, 9488, 1000, 0), (7000, 4000, 1000, 3), (16640, 1024, 512, 8), (333, 200, 72, 0), (2176, 4000, 2000, 2),
                                             (12001, 1024, 1024, 4), (65, 264, 40, 0)])
 def test_wgrad_eight_phase_form(K, M, N, splits):

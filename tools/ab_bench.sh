@@ -1,4 +1,4 @@
-# A/B of one bench.py switch over the three train configs in ONE job (same box): tools/ab_bench.sh "--fuse-mid 0" "--fuse-mid 1" ...
+# A/B of one bench.py switch over the three train configs in ONE job (same box): tools/ab_bench.sh "--no-p8" " " ...
 R=${GRAFT_REPO_ROOT:-.}
 for C in ${CONFIGS:-kar full_gc_kar flickr}; do
   for V in "$@"; do

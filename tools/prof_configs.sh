@@ -1,5 +1,5 @@
 # rocprofv3 kernel stats (and optionally the idle-gap report) of the train configs in one job:
-#   CONFIGS="kar full_gc_kar flickr" TAG=r05x [GAPS=1] [GREP="attn_|lstm_"] [EXTRA="--fuse-mid 1"] bash tools/prof_configs.sh
+#   CONFIGS="kar full_gc_kar flickr" TAG=r05x [GAPS=1] [GREP="attn_|lstm_"] [EXTRA="--no-p8"] bash tools/prof_configs.sh
 # -> gpurun_out/${TAG}_${config}_kernel_stats.txt (tools/rocprof_summary.py), gpurun_out/${TAG}_${config}_gaps.txt (tools/gap_report.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${TAG:-prof}
