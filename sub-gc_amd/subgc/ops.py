@@ -10,7 +10,7 @@ import gc
 
 import torch
 
-from ._lib import SubgcError, call
+from ._lib import SubgcError, call, lib
 
 RELU, ACCUM = 1, 2
 FLOPS = {"on": False, "gemm": 0.0, "gemm_bytes": 0.0, "gemm_calls": 0}
