@@ -532,8 +532,8 @@ def main():
         model.ss_prob = a.ss_prob
     lw = models.LossWrapper(model, None)
     batch = {k: v.to(dev) for k, v in synthetic.make_train_batch(a.batch, seed=1000 + rank, **cfg["data"]).items()}
-    red = parallel.GradBucketReducer(model)
     adam = None if a.no_optimizer else parallel.FlatAdam(model)      # a training step ends with the parameter update (misc/utils.py:174-200 + Adam)
+    red = parallel.GradBucketReducer(model, optimizer=adam)          # the clip norm is accumulated slice by slice as the slices become final
     one = ops.fill_(torch.empty((), device=dev, dtype=torch.float32), 1.0)
 
     def step():

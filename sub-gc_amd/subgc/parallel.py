@@ -122,12 +122,21 @@ class GradBucketReducer:
     enqueued behind the kernels already on the compute stream (torch.distributed's stream hand-off) and runs on RCCL's own stream.
     Reference semantics: nn.DataParallel's gradient reduce-add, train.py:96-98,154-164."""
 
-    def __init__(self, model, group=None, overlap=True, always_reduce=False, timing=False):
+    def __init__(self, model, group=None, overlap=True, always_reduce=False, timing=False, optimizer=None):
         """`always_reduce`: issue the collectives even in a one-rank group (a one-GPU box can then exercise RCCL itself and
         the stream ordering between the backward kernels and the all-reduce; the sum over one rank is the identity).
         `timing`: bracket the step with HIP events on the compute stream (`report()`): when each slice's collective could start,
-        and how long the compute stream then WAITED for the collectives after the backward's last kernel = the exposed communication."""
+        and how long the compute stream then WAITED for the collectives after the backward's last kernel = the exposed communication.
+        `optimizer` (a FlatAdam): the squared gradient norm its global-norm clip needs is accumulated BUCKET BY BUCKET as each slice
+        becomes final -- one rank: right behind the slice's last gradient kernel; several ranks: behind the slice's all-reduce, on a side
+        stream, so neither the backward nor the later collectives wait for it -- instead of one pass over the whole 280 MB buffer after
+        the last collective.  What cannot move is the clip + Adam sweep itself: the clip coefficient is a function of the norm of ALL
+        reduced gradients (misc/utils.py:174-200 computes the total norm before it scales any gradient), so no parameter can be
+        updated before the last slice has been reduced; the exposed tail of a step is therefore the last (fusion, 13 MB) collective,
+        that slice's norm and the sweep."""
         self.model, self.group = model, group
+        self.optimizer = optimizer
+        self._side = None
         self.timing = bool(timing)
         self._ev = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -139,7 +148,9 @@ class GradBucketReducer:
         self._handles = []
         self.issued = []                                        # (stage, bytes) of every collective of the current step, in issue order
         self._need = {}
-        if self.overlap:
+        if optimizer is not None:
+            optimizer.reducer = self
+        if self.overlap or (optimizer is not None and overlap):
             from . import functions as F_
             F_.on_grads_ready = self._ready
             early = [(st, lo, hi) for st, lo, hi in self.buckets if st != "fusion"]
@@ -164,14 +175,30 @@ class GradBucketReducer:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self._ev["issue"].append(e)
-        self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append(work)
+        if self.optimizer is not None and g.is_cuda:
+            # the slice's share of the clip norm behind ITS collective, beside everything else (the compute stream never waits for it
+            # before `finish`; a host-side backend -- gloo on CPU tensors -- has no stream to put it on: `finish` adds it after the wait)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=g.device)
+            with torch.cuda.stream(self._side):
+                work.wait()
+                self.optimizer.accumulate(stage, lo, hi)
 
     def _ready(self, stage):
         """The gradient slice `stage` is final.  Its all-reduce starts now IF every slice before it in the canonical order
         (`self.buckets`) is already out; otherwise it is only marked and goes out when its predecessors have (or in `finish`).
         RCCL pairs collectives across ranks by issue order, so the sequence has to be rank-invariant: always the canonical one,
         whatever subset of the announcements a rank's backward happened to make (advisor finding, round 4)."""
-        if not self.active or self.model.flat_grads is None or stage in self._launched:
+        if self.model.flat_grads is None or stage in self._launched:
+            return
+        if not self.active:                                     # one rank, no collectives: the slice's norm right behind its last gradient kernel
+            if self.optimizer is not None and stage != "fusion":
+                for st, lo, hi in self.buckets:
+                    if st == stage and hi > lo:
+                        self._launched.append(st)
+                        self.optimizer.accumulate(st, lo, hi)
             return
         self._announced.add(stage)
         for st, lo, hi in self.buckets:
@@ -187,6 +214,8 @@ class GradBucketReducer:
         """Call before forward: (re)binds every .grad into the zeroed flat bucket."""
         self._fired, self._pending, self._launched, self.issued, self._announced = {}, [], [], [], set()
         flat = self.model.flatten_grads()
+        if self.optimizer is not None:
+            self.optimizer.begin_step()
         if self.timing and self.active and flat.is_cuda:
             self._ev = {"start": torch.cuda.Event(enable_timing=True), "issue": [], "bwd_end": None, "waited": []}
             self._ev["start"].record()
@@ -205,6 +234,9 @@ class GradBucketReducer:
         rank that missed an announcement still lines up (`_ready` holds a slice back until its predecessors are out)."""
         if not self.active:
             return self.model.flat_grads
+        if self.optimizer is not None and average and self.world > 1:
+            raise RuntimeError("an attached optimizer accumulates the norm of the SUMMED slices: call finish(average=False) and hand 1 / world "
+                               "to FlatAdam.step(grad_scale=...)")
         g = self.model.flat_grads
         for st, lo, hi in self.buckets:
             if st not in self._launched and hi > lo:
@@ -220,6 +252,8 @@ class GradBucketReducer:
                 e.record()
                 self._ev["waited"].append(e)
         self._pending = []
+        if self._side is not None:                              # the per-slice norms accumulated beside the backward
+            torch.cuda.current_stream(g.device).wait_stream(self._side)
         if average and self.world > 1:
             g.mul_(1.0 / self.world)
         return g
@@ -235,7 +269,12 @@ class GradBucketReducer:
         t = lambda e: round(ev["start"].elapsed_time(e), 3)
         rows = [{"stage": st, "bytes": nb, "issue_ms": t(ei), "done_by_ms": t(ew)} for (st, nb), ei, ew in zip(self.issued, ev["issue"], ev["waited"])]
         end = t(ev["bwd_end"])
-        return {"buckets": rows, "backward_end_ms": end, "exposed_ms": round((rows[-1]["done_by_ms"] if rows else end) - end, 3)}
+        rep = {"buckets": rows, "backward_end_ms": end, "exposed_ms": round((rows[-1]["done_by_ms"] if rows else end) - end, 3)}
+        if self.optimizer is not None:
+            rep["optimizer_tail"] = ("clip norm accumulated per slice behind its collective (side stream); after the last collective: the fusion "
+                                     "slice's norm + ONE clip/Adam sweep (the clip coefficient needs the norm of ALL reduced slices, so no sweep can "
+                                     "start earlier)")
+        return rep
 
     def close(self):
         from . import functions as F_
@@ -260,6 +299,22 @@ class FlatAdam:
         self.v = torch.zeros_like(model.flat_params)
         self.sumsq = torch.zeros(1, device=model.flat_params.device)
         self.t = 0
+        self.reducer = None            # a GradBucketReducer(optimizer=self) accumulates the clip norm slice by slice (begin_step / accumulate)
+        self._have = None              # stages whose squared norm is already in self.sumsq for the gradients of the current step
+
+    def begin_step(self):
+        """(reducer.prepare) a new set of gradients: the norm accumulator starts from zero."""
+        from . import ops
+        ops.fill_(self.sumsq, 0.0)
+        self._have = set()
+
+    def accumulate(self, stage, lo, hi):
+        """sumsq += |flat_grads[lo:hi]|^2 on the CURRENT stream (the slice is final -- and, with several ranks, reduced -- there)."""
+        from . import ops
+        if self._have is None or stage in self._have:
+            return
+        self._have.add(stage)
+        ops.sumsq(self.model.flat_grads[lo:hi], self.sumsq)
 
     def step(self, grad_scale=1.0, zero_grad=False):
         """`zero_grad`: leave the gradient buffer ZEROED by the sweep itself (= this step followed by the `optimizer.zero_grad()` every
@@ -267,8 +322,14 @@ class FlatAdam:
         the buffer.  Default: torch's semantics, the (scaled, clipped) gradients stay readable after the step."""
         from . import ops
         self.t += 1
-        ops.fill_(self.sumsq, 0.0)
-        ops.sumsq(self.model.flat_grads, self.sumsq)
+        if self._have is not None and self.reducer is not None:
+            for st, lo, hi in self.reducer.buckets:             # whatever was not announced early (always the fusion slice)
+                if hi > lo:
+                    self.accumulate(st, lo, hi)
+            self._have = None
+        else:
+            ops.fill_(self.sumsq, 0.0)
+            ops.sumsq(self.model.flat_grads, self.sumsq)
         m = self.model
         snap = m.weights_b16() if getattr(m, "bf16_storage", False) else None     # compute_dtype = bf16: refreshed in the same sweep
         ops.clip_adam_step(m.flat_params, m.flat_grads, self.m, self.v, self.sumsq, self.clip, self.lr,
