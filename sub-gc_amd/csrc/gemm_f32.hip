@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -368,35 +369,43 @@ __device__ __forceinline__ void colsum_store(float* smem, const float4& cs, int 
 // CONSECUTIVE columns per register quad = one 16-byte store (with the column-per-lane layout a lane issued 64 scalar stores per
 // 128x128 tile and the store issue of a K = 1000 product rivalled its K loop).  f(m, n, quad) is called per whole / partial quad.
 struct Quad { float v[4]; };
-template <int BM, int BN, int MT, int NT, typename F>
+// WAVES_N: waves along N (the wave owns MT x NT tiles of 32 x 32 at row (wave / WAVES_N) * 32 MT, column (wave % WAVES_N) * 32 NT): 2 for the
+// 2 x 2 waves of the 128 x 128 / 64 x 64 loops, 4 for the 2 x 4 waves of the eight-phase loop.  One instantiation per tile row `a` (a fold):
+// the accumulator index stays a constant whatever the unroller decides.
+template <int MT, int NT, int WAVES_N, int A, typename F>
+__device__ __forceinline__ void quads_of_row(const f32x16 (&acc)[MT][NT], int m0, int n0, int M, int N, F& f) {
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 7;
+    const int wm = (wave / WAVES_N) * (32 * MT), wn = (wave % WAVES_N) * (32 * NT);
+    const int m = m0 + wm + A * 32 + (lane & 31);
+    if (m >= M) return;
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn + b * 32 + 8 * q + 4 * (lane >> 5);
+            if (n >= N) continue;
+            Quad x{{acc[A][b][4 * q], acc[A][b][4 * q + 1], acc[A][b][4 * q + 2], acc[A][b][4 * q + 3]}};
+            f(m, n, x);
+        }
+}
+template <int MT, int NT, int WAVES_N, typename F, int... As>
+__device__ __forceinline__ void for_each_quad_seq(const f32x16 (&acc)[MT][NT], int m0, int n0, int M, int N, F& f, std::integer_sequence<int, As...>) {
+    (quads_of_row<MT, NT, WAVES_N, As>(acc, m0, n0, M, N, f), ...);
+}
+template <int BM, int BN, int MT, int NT, int WAVES_N = 2, typename F>
 __device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[MT][NT], int m0, int n0, int M, int N, F&& f) {
-    constexpr int WM = BM / 2, WN = BN / 2;
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
-    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-        const int m = m0 + wm + a * 32 + (lane & 31);
-        if (m >= M) continue;
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn + b * 32 + 8 * q + 4 * (lane >> 5);
-                if (n >= N) continue;
-                Quad x{{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]}};
-                f(m, n, x);
-            }
-    }
+    static_assert(BM == (WAVES_N == 2 ? 2 : 2) * 32 * MT && BN == WAVES_N * 32 * NT, "two wave rows x WAVES_N wave columns cover the tile");
+    for_each_quad_seq<MT, NT, WAVES_N>(acc, m0, n0, M, N, f, std::make_integer_sequence<int, MT>{});
 }
 
 __device__ __forceinline__ bool dev_aligned(const void* p, unsigned mask) { return (reinterpret_cast<uintptr_t>(p) & mask) == 0; }
 
-template <int BM, int BN, int MT, int NT>
+template <int BM, int BN, int MT, int NT, int WAVES_N = 2>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, int M, int m0, int n0, f32x16 (&acc)[MT][NT]) {
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
     const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && dev_aligned(p.C, 15) && (!p.bias || dev_aligned(p.bias, 15)) &&
                      (!p.add || (p.ldadd % 4 == 0 && dev_aligned(p.add, 15))) && (!p.keep || dev_aligned(p.keep, 3));
-    for_each_quad<BM, BN, MT, NT>(acc, m0, n0, M, p.N, [&](int m, int n, Quad& x) {
+    for_each_quad<BM, BN, MT, NT, WAVES_N>(acc, m0, n0, M, p.N, [&](int m, int n, Quad& x) {
         int64_t row = m;
         if (p.c_rows) {
             const int g = p.c_rows[m];

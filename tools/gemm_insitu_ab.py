@@ -27,13 +27,14 @@ VARIANTS = {"plan": 0, "no_p8": 1 << 14, "p8": 1 << 13, "r256": 128, "r128": 64}
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="full_gc_kar", choices=["full_gc_kar", "flickr"])
+    ap.add_argument("--config", default="full_gc_kar", choices=["full_gc_kar", "flickr", "kar"])
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--min-us", type=float, default=15.0)
     ap.add_argument("--variants", default="plan,no_p8")
     a = ap.parse_args()
     names = a.variants.split(",")
     cfg = bench.CONFIGS[a.config]
+    f32 = cfg["dtype"] == "f32"
     torch.manual_seed(1234)
     model = models.setup(argparse.Namespace(**cfg["opt"])).to(DEV).train()
     b = {k: v.to(DEV) for k, v in synthetic.make_train_batch(cfg["batch"], seed=1000, **cfg["data"]).items()}
@@ -50,16 +51,21 @@ def main():
     rec = []
 
     def spy(name, *args):
-        if name not in ("subgc_gemm_bf16", "subgc_gemm_bf16_pair", "subgc_gemm_bf16_wgrad"):
+        if name not in ("subgc_gemm_bf16", "subgc_gemm_bf16_pair", "subgc_gemm_bf16_wgrad", "subgc_gemm_f32", "subgc_gemm_f32_pair", "subgc_gemm_f32_wgrad"):
             return real(name, *args)
         if name == "subgc_gemm_bf16":
             ta, tb, M, N, K = args[:5]
             c32, c16, bias, add, keep, flags, m_dev = args[9], args[11], args[13], args[14], args[16], args[18], args[19]
             key = ("tn" if ta else "nt" if tb else "nn", M, N, K, ("f" if c32 is not None else "") + ("h" if c16 is not None else "") + ("b" if bias is not None else "") +
                    ("+" if add is not None else "") + ("d" if keep is not None else "") + ("r" if flags & 1 else "") + ("A" if flags & 2 else "") + ("~" if m_dev is not None else ""))
-        elif name == "subgc_gemm_bf16_pair":
+        elif name == "subgc_gemm_f32":
             ta, tb, M, N, K = args[:5]
-            key = ("tn" if ta else "nt" if tb else "nn", M, N, K, "PAIR" + ("f" if args[11] is not None else "h"))
+            bias, add, keep, flags, a_rows, c_rows, m_dev = args[11], args[12], args[14], args[16], args[17], args[18], args[19]
+            key = ("tn" if ta else "nt" if tb else "nn", M, N, K, ("b" if bias is not None else "") + ("+" if add is not None else "") + ("d" if keep is not None else "") +
+                   ("r" if flags & 1 else "") + ("A" if flags & 2 else "") + ("g" if a_rows is not None else "") + ("s" if c_rows is not None else "") + ("~" if m_dev is not None else ""))
+        elif name.endswith("_pair"):
+            ta, tb, M, N, K = args[:5]
+            key = ("tn" if ta else "nt" if tb else "nn", M, N, K, "PAIR")
         else:
             M, N, K = args[:3]
             key = ("tn", M, N, K, "W" + ("~" if args[12] is not None else ""))
@@ -75,7 +81,7 @@ def main():
     steps = {n: 0.0 for n in names}
     for rep in range(a.reps):
         for n in names:
-            ops.gemm_tune.b16_bits = VARIANTS[n]
+            ops.gemm_tune.b16_bits = ops.gemm_tune.f32_bits = VARIANTS[n] if n in ('plan', 'no_p8', 'p8') or not f32 else 0
             rec.clear()
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
@@ -88,7 +94,7 @@ def main():
                 d[0] += 1
                 d[1] += e0.elapsed_time(e1) * 1e3
     ops.call = real
-    ops.gemm_tune.b16_bits = 0
+    ops.gemm_tune.b16_bits = ops.gemm_tune.f32_bits = 0
     base = res[names[0]]
     print(f"# {a.config}: in-situ us per call (mean over {a.reps} steps, with per-call events), calls per step, per-step total per variant")
     print("# step ms: " + "  ".join(f"{n} {steps[n] / a.reps:.2f}" for n in names))
