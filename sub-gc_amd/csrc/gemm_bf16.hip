@@ -854,6 +854,20 @@ int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_
             if (c < best) { best = c; pl.splits = sp; }
         }
         if (pl.splits <= 1 || tiles >= 448) return -100;
+        // Round 6: from 1024 rows up (Full_GC_Kar's first steps: 5 x 16 tiles of 256 x 256) the planes come from the eight-phase form, K parts
+        // chosen to fill whole rounds of the 256 CUs -- in situ (A/B in one job, two repeats) the GEMM family 8.82 -> 8.61 ms per step, the step
+        // 15.10 -> 15.03 (one more plane for the cell kernels to add eats two thirds of it); below 1024 rows: no gain, the 128 x 128 form stays.
+        if (p8_able && a.M >= 1024) {
+            const int64_t t256 = subgc::cdiv(a.M, 256) * subgc::cdiv(a.N, 256);
+            const int kt64 = (int)subgc::cdiv(a.K, 64);
+            double bestc = 1e30;
+            int bs = 0;
+            for (int sp = 2; sp <= 8 && (kt64 + sp - 1) / sp >= 6 && (size_t)sp * a.M * a.N * sizeof(float) <= ws_bytes; ++sp) {
+                const double c = (double)((t256 * sp + 255) / 256) * ((kt64 + sp - 1) / sp * 1.4 + 14.0) + 0.8 * sp;
+                if (c < bestc) { bestc = c; bs = sp; }
+            }
+            if (bs > 1) { pl.big = 2; pl.splits = bs; }
+        }
     } else if (force == 128 || force == 256) {
         pl.big = force == 256;
         if (pl.big) pl.splits = 1;
