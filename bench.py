@@ -179,7 +179,7 @@ def decode_bench(model_sd, dev, images, M):
         us_step = 1e3 * e0.elapsed_time(e1) / 20 / steps
         gbps = bytes_step / (us_step * 1e-6) / 1e9
         traffic, pmc_name = None, None
-        for rnd in ("r05", "r04", "r03", "r02"):                # committed PMC passes over the same loop (tools/pmc_decode.sh)
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):         # committed PMC passes over the same loop (tools/pmc_decode.sh)
             pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_decode.json")
             if not os.path.exists(pmc_path):
                 continue
@@ -250,7 +250,7 @@ def pmc_traffic(config, batch, world, launches_per_step):
     if world != 1 or batch != CONFIGS[config]["batch"]:
         return None, "no PMC profile for this configuration"
     note = "no PMC profile for this configuration"
-    for rnd in ("r05", "r04", "r03", "r02"):                               # newest committed pass whose launch count matches this build
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):                        # newest committed pass whose launch count matches this build
         name = f"{rnd}_pmc_traffic.json" if config == "kar" else f"{rnd}_pmc_traffic_{config}.json"
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -271,7 +271,7 @@ def pmc_traffic(config, batch, world, launches_per_step):
 
 def decode_pmc(leg):
     """HBM bytes per GEMM launch of a decode leg from the committed PMC passes (tools/pmc_decode_legs.sh -> profiles/rNN_pmc_decode_legs.json)."""
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_decode_legs.json")
         if os.path.exists(path):
             with open(path) as f:

@@ -21,7 +21,8 @@ import json
 
 FETCH_FACTOR = 2.0          # profiles/r02_pmc_calibration.txt
 FAMILY = ("gemm_f32_kernel", "gemm_f32_splitk_kernel", "splitk_reduce_kernel", "gemm_skinny",
-          "gemm_bf16_kernel", "gemm_bf16_splitk_kernel", "splitk_reduce_b16_kernel")          # bf16 configs: both GEMM families run
+          "gemm_bf16_kernel", "gemm_bf16_splitk_kernel", "gemm_bf16_p8_kernel", "gemm_bf16_p8_splitk_kernel",
+          "splitk_reduce_b16_kernel")                                                          # bf16 configs: both GEMM families run
 REDUCE = ("splitk_reduce_kernel", "splitk_reduce_b16_kernel")
 STEP_MARK = "live_plan_kernel"      # launched exactly once per (packed) train step: counts the profiled steps when one call may be two kernels
 
