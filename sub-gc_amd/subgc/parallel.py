@@ -127,10 +127,10 @@ class GradBucketReducer:
         the stream ordering between the backward kernels and the all-reduce; the sum over one rank is the identity).
         `timing`: bracket the step with HIP events on the compute stream (`report()`): when each slice's collective could start,
         and how long the compute stream then WAITED for the collectives after the backward's last kernel = the exposed communication.
-        `optimizer` (a FlatAdam): the squared gradient norm its global-norm clip needs is accumulated BUCKET BY BUCKET as each slice
-        becomes final -- one rank: right behind the slice's last gradient kernel; several ranks: behind the slice's all-reduce, on a side
+        `optimizer` (a FlatAdam): with several ranks the squared gradient norm its global-norm clip needs is accumulated BUCKET BY BUCKET
+        as each slice becomes final -- behind the slice's all-reduce, on a side
         stream, so neither the backward nor the later collectives wait for it -- instead of one pass over the whole 280 MB buffer after
-        the last collective.  What cannot move is the clip + Adam sweep itself: the clip coefficient is a function of the norm of ALL
+        the last collective.  (One rank has nothing to hide it behind: the whole-buffer pass in `FlatAdam.step` stays.)  What cannot move is the clip + Adam sweep itself: the clip coefficient is a function of the norm of ALL
         reduced gradients (misc/utils.py:174-200 computes the total norm before it scales any gradient), so no parameter can be
         updated before the last slice has been reduced; the exposed tail of a step is therefore the last (fusion, 13 MB) collective,
         that slice's norm and the sweep."""
@@ -146,6 +146,7 @@ class GradBucketReducer:
         self.overlap = overlap and self.active
         self._pending, self._launched, self._fired, self._announced = [], [], {}, set()
         self._handles = []
+        self._slices = []
         self.issued = []                                        # (stage, bytes) of every collective of the current step, in issue order
         self._need = {}
         if optimizer is not None:
@@ -177,6 +178,7 @@ class GradBucketReducer:
             self._ev["issue"].append(e)
         work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append(work)
+        self._slices.append((stage, lo, hi))
         if self.optimizer is not None and g.is_cuda:
             # the slice's share of the clip norm behind ITS collective, beside everything else (the compute stream never waits for it
             # before `finish`; a host-side backend -- gloo on CPU tensors -- has no stream to put it on: `finish` adds it after the wait)
@@ -193,13 +195,8 @@ class GradBucketReducer:
         whatever subset of the announcements a rank's backward happened to make (advisor finding, round 4)."""
         if self.model.flat_grads is None or stage in self._launched:
             return
-        if not self.active:                                     # one rank, no collectives: the slice's norm right behind its last gradient kernel
-            if self.optimizer is not None and stage != "fusion":
-                for st, lo, hi in self.buckets:
-                    if st == stage and hi > lo:
-                        self._launched.append(st)
-                        self.optimizer.accumulate(st, lo, hi)
-            return
+        if not self.active:                                     # one rank: no collective to hide a slice's norm behind -- on the one compute stream five
+            return                                              # small norm launches cost MORE than one pass over the buffer (measured: 5 x 36 us vs 65-74)
         self._announced.add(stage)
         for st, lo, hi in self.buckets:
             if st in self._launched:
@@ -213,6 +210,7 @@ class GradBucketReducer:
     def prepare(self):
         """Call before forward: (re)binds every .grad into the zeroed flat bucket."""
         self._fired, self._pending, self._launched, self.issued, self._announced = {}, [], [], [], set()
+        self._slices = []
         flat = self.model.flatten_grads()
         if self.optimizer is not None:
             self.optimizer.begin_step()
@@ -245,13 +243,15 @@ class GradBucketReducer:
         if self._ev is not None:                                # the backward's last kernel (and the last slice's issue point)
             self._ev["bwd_end"] = torch.cuda.Event(enable_timing=True)
             self._ev["bwd_end"].record()
-        for w in self._pending:
+        for w, (st, lo, hi) in zip(self._pending, self._slices):
             w.wait()
+            if self.optimizer is not None and not g.is_cuda:    # host-side backend: the slice's norm right behind its (blocking) wait
+                self.optimizer.accumulate(st, lo, hi)
             if self._ev is not None:                            # the compute stream is past this collective
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 self._ev["waited"].append(e)
-        self._pending = []
+        self._pending, self._slices = [], []
         if self._side is not None:                              # the per-slice norms accumulated beside the backward
             torch.cuda.current_stream(g.device).wait_stream(self._side)
         if average and self.world > 1:
@@ -322,12 +322,13 @@ class FlatAdam:
         the buffer.  Default: torch's semantics, the (scaled, clipped) gradients stay readable after the step."""
         from . import ops
         self.t += 1
-        if self._have is not None and self.reducer is not None:
-            for st, lo, hi in self.reducer.buckets:             # whatever was not announced early (always the fusion slice)
+        if self._have:                                          # some slices are in already: add whatever was not announced early (always the fusion slice)
+            for st, lo, hi in self.reducer.buckets:
                 if hi > lo:
                     self.accumulate(st, lo, hi)
             self._have = None
-        else:
+        else:                                                   # nothing accumulated (one rank, or no reducer): one pass over the whole buffer
+            self._have = None
             ops.fill_(self.sumsq, 0.0)
             ops.sumsq(self.model.flat_grads, self.sumsq)
         m = self.model
