@@ -186,8 +186,8 @@ def decode_bench(model_sd, dev, images, M):
             with open(pmc_path) as f:
                 kk = json.load(f)["kernels"]
             per = lambda k_: kk[k_]["hbm_fetch_bytes_per_launch"] + kk[k_]["hbm_write_bytes_per_launch"]
-            if "logits_pick" in kk:                      # r03 loop: 2 LSTM launches, h2att (plain) and the logits launch with the pick epilogue
-                traffic, pmc_name = 2 * per("lstm") + per("plain_1tile") + per("logits_pick"), f"{rnd}_pmc_decode.json"
+            if "dual_pick" in kk and getattr(m, "decode_fused_pick", True):    # round-6 loop: [logits | att gates], cell + pick, [h2att | lang hidden part], lang ctx part
+                traffic, pmc_name = per("dual_pick") + per("cell_pick") + per("dual") + per("lstm"), f"{rnd}_pmc_decode.json"
                 break
             if not getattr(m, "decode_fused_pick", True):
                 traffic, pmc_name = 2 * per("lstm") + 2 * per("plain_1tile"), f"{rnd}_pmc_decode.json"
@@ -197,8 +197,9 @@ def decode_bench(model_sd, dev, images, M):
                                   "traffic_unit": (f"bytes fetched + written past L2 per token step (profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_decode.sh)"
                                                    if pmc_name else "no committed PMC pass over this loop (tools/pmc_decode.sh)"),
                                   "bytes_per_step": round(bytes_step), "us_per_step": round(us_step, 2), "steps_per_replay": steps,
-                                  "note": "whole replayed token loop of one image (10 sub-graphs; 5 launches per step -- att-LSTM (files the previous pick), h2att, "
-                                          "attention, lang-LSTM, logits with the arg-max epilogue -- + the in-graph survivor gathers) / 21 steps; "
+                                  "note": "whole replayed token loop of one image (10 sub-graphs; 5 launches per step -- att-LSTM cell (files the previous pick), "
+                                          "[h2att | hidden part of the lang-LSTM gates], attention, lang-LSTM (context part + cell), [logits with the arg-max epilogue | "
+                                          "next step's att-LSTM gates] -- + the in-graph survivor gathers) / 21 steps; "
                                           "the 120 MB of weights fit the 256 MiB Infinity Cache, so the HBM roof is generous"}
     # the same images, decoded `group` at a time as one batch (sample_images): same tokens per image, weights streamed once per step
     group = min(256, images)                              # sized for 288 GB: 2560 sub-graph rows per decode step

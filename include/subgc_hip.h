@@ -541,30 +541,41 @@ int subgc_row_count_f32(const float* x, int64_t ld, int rows, int cols, int32_t*
  * Greedy pick folded into the decode step's launches (csrc/gemm_skinny.hip; AttModel.py:295-319 with sample_max, <= 16 rows).
  * `best` buffers: uint64 [16 rows][8 slots][16] (16 KB; slot (m, x) at element (m*8 + x)*16, its own 128-byte line), all zero
  * before the logits launch that fills them.
- *   subgc_logits_pick  -- logits = x W^T + bias WITHOUT writing them (logits may be NULL): slot (m, workgroup & 7) <- atomicMax of
- *       (ordered logit bits << 32 | ~column): the row's arg-max with ties to the smaller column (torch.max's first max);
+ *   subgc_skinny_dual with `best` -- problem 1 = the logits x W^T + bias WITHOUT writing them (C1 may be NULL): slot (m, workgroup & 7) <-
+ *       atomicMax of (ordered logit bits << 32 | ~column): the row's arg-max with ties to the smaller column (torch.max's first max);
  *       lse_part[(wg*16 + m)*2 + {0,1}] = (max, sum exp(. - max)) over the 16 vocabulary rows of workgroup wg (ceil(V/16) of them).
- *   subgc_lstm_step_pick -- subgc_lstm_step_skinny whose input word of row m is that arg-max (finished rows feed 0; the word selects
+ *   subgc_lstm_cell_pick -- the attention LSTM's cell whose input word of row m is that arg-max (finished rows feed 0; the word selects
  *       row add1[word] of the per-token x->gates table); workgroup 0 files the pick of step t_prev exactly once: seq[m, t_prev],
  *       unf_out[m] (= unf_in[m] && word > 0; word > 0 at t_prev = 0), count_out += live rows; nothing is written when *prev_count
  *       == 0 (the reference has left its loop); `best_reset` (the other buffer) is cleared for this step's logits launch (NULL: none).
  *   subgc_pick_file    -- that bookkeeping alone (after the last pick).
  *   subgc_pick_lse_finish -- seqlp[m, t] = -log sum_wg sum_wg exp(max_wg - max) for every step the loop reached, from
- *       lse_part [T][ceil(V/16)][16][2]: one pass after the loop instead of a vocabulary reduction per step.                      */
-int subgc_logits_pick(const float* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
-                      int64_t ldl, uint64_t* best, float* lse_part, int w_bf16, void* stream);
-int subgc_lstm_step_pick(const float* x, int64_t ldx, const void* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
-                         int64_t ld1, int tok_rows, const float* add2, int64_t ld2, const float* b0, const float* b1,
-                         const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2,
-                         const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int T, int t_prev,
-                         int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, int w_bf16, void* stream);
+ *       lse_part [T][ceil(V/16)][16][2]: one pass after the loop instead of a vocabulary reduction per step.
+ * (Rounds 3-5 had the pick in a logits-only launch, subgc_logits_pick, and in the fused attention-LSTM launch, subgc_lstm_step_pick;
+ * round 6 replaced both by the two entry points below.)                                                                          */
 /* C[M,N] = act(A[M,K] W[N,K]^T + bias), M <= 16, with bf16-STORED W (raw uint16) and fp32 activations / results: the weight-streaming
- * products of a decode step under compute_dtype = bf16 (w_bf16 != 0 in the three entry points above selects the same for them:
+ * products of a decode step under compute_dtype = bf16 (w_bf16 != 0 in subgc_lstm_step_skinny / subgc_skinny_dual selects the same for them:
  * half the bytes of the 120 MB a token step streams; accumulation and everything downstream stay fp32). */
 int subgc_gemm_skinny_wb16(const float* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc, const float* bias, int M,
                            int N, int K, int relu, void* stream);
 int subgc_pick_file(const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int S, int T, int t_prev,
                     int32_t* count_out, const int32_t* prev_count, void* stream);
+/* Round 6 -- the independent weight streams of a one-image token step share launches (the dependent chain keeps five launches, the
+ * attention LSTM's 32 MB and two thirds of the language LSTM's 48 MB leave it):
+ * subgc_skinny_dual: two weight-streaming products of S <= 16 rows in ONE launch -- problem 1 with the fused arg-max / log-sum-exp
+ *   epilogue described above when `best` != NULL (C1 may then be NULL), problem 2 plain.  unperm*_R != 0: that problem's W rows are in
+ *   the LSTM forms' permuted gate order and its result is written gate-major [S, 4R].  The decode step uses it for
+ *   [logits(h_lang) | H1 . Wc1^T] and for [h2att(h_att) | [h_att, h_lang_prev] . Wc2[:, R:]^T]  (AttModel.py:411-413, 421-423, 453, 336).
+ * subgc_lstm_cell_pick: the attention LSTM's cell from those pre-activations + the picked word's x -> gates table row (add1) + the fc term
+ *   (add2) + biases; the word is the previous step's fused arg-max (best_prev; the pick is filed as described above) or tok[m].          */
+int subgc_skinny_dual(int S, const float* x1, int64_t ldx1, const void* W1, int64_t ldw1, const float* bias1, int N1, int K1, float* C1,
+                      int64_t ldc1, int unperm1_R, uint64_t* best, float* lse_part, const float* x2, int64_t ldx2, const void* W2,
+                      int64_t ldw2, const float* bias2, int N2, int K2, float* C2, int64_t ldc2, int unperm2_R, int w_bf16, void* stream);
+int subgc_lstm_cell_pick(const float* pre, int64_t ldpre, int S, int R, const float* add1, int64_t ld1, const int64_t* tok, int tok_rows,
+                         const float* add2, int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c, float* h0,
+                         int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2, const uint64_t* best_prev, const int32_t* unf_in,
+                         int32_t* unf_out, int64_t* seq, int T, int t_prev, int32_t* count_out, const int32_t* prev_count,
+                         uint64_t* best_reset, void* stream);
 int subgc_pick_lse_finish(const float* lse_part, int V, int S, int T, const int32_t* counts, float* seqlp, void* stream);
 
 /* ======================================================================================

@@ -65,6 +65,13 @@ struct LstmEpi {
     PickIn pk;
 };
 struct PickOut { unsigned long long* best; float* lse_part; };              // logits launch: slots as above, [workgroups][16][2] partials
+// A SECOND product in the same launch (DUAL): workgroups [first_blocks, gridDim.x) stream W2 [N2, K2] against A2 [M, K2] and store
+// plainly (bias2 optional).  Round 6, one-image decode: the products of a token step that share no data dependence share a launch --
+// [logits (+ pick) | attention-LSTM gate product] and [h2att | the language LSTM's h_att / h_lang part] -- so a weight stream that used to
+// sit on the step's dependent chain runs beside one that has to.  unperm_R (either problem's plain store): W's rows are in the LSTM
+// forms' permuted gate order (row 16 b + 4 g + u = gate g of unit 4 b + u); the result column goes to g * R + 4 b + u, the order the
+// cell kernels' additive terms use.
+struct Second { const float* A; int64_t lda; const void* W; int64_t ldb; float* C; int64_t ldc; const float* bias; int N; int K; int first_blocks; int unperm_R; };
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {                 // monotone float -> uint32
     const uint32_t u = __float_as_uint(f);
@@ -86,18 +93,28 @@ __device__ __forceinline__ int picked_word(const PickIn& pk, int m, bool& unf) {
 constexpr int PICK_WAVES = 8, PLAIN_WAVES = 8;      // 16 measured: no gain (593 logits workgroups are 2-3 per CU already)
 constexpr int LSTM_WAVES = 16;                                                // waves per workgroup of the fused LSTM-step launches
 
-template <int WAVES, int D, bool LSTM, int MT, bool PICK = false, bool WB16 = false>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* __restrict__ A, int64_t lda, const void* __restrict__ W,
-                                                                      int64_t ldb, float* __restrict__ C, int64_t ldc,
-                                                                      const float* __restrict__ bias, int M, int N, int K, int relu,
-                                                                      LstmEpi ep, const float* __restrict__ add, int64_t ldadd, PickOut po = PickOut{}) {
+template <int WAVES, int D, bool LSTM, int MT, bool PICK = false, bool WB16 = false, bool DUAL = false>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const float* A, int64_t lda, const void* W,
+                                                                      int64_t ldb, float* C, int64_t ldc,
+                                                                      const float* bias, int M, int N, int K, int relu,
+                                                                      LstmEpi ep, const float* __restrict__ add, int64_t ldadd, PickOut po = PickOut{},
+                                                                      Second sec = Second{}, int unperm_R = 0) {
     static_assert(!LSTM || MT <= 2, "the fused cell update handles up to two 16-row activation tiles (wave mt owns tile mt)");
     static_assert(!PICK || (!LSTM && MT == 1), "the arg-max epilogue belongs to the plain one-tile form (the logits launch)");
+    static_assert(!DUAL || (!LSTM && MT == 1), "a second product rides the plain one-tile forms");
     __shared__ float part[WAVES][MT * 256];
     __shared__ float tile[(LSTM || PICK) ? 256 * MT : 1];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: uniform loop control
     const int r16 = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    int bx = blockIdx.x;
+    bool second = false;                                                    // workgroup-uniform
+    if (DUAL && bx >= sec.first_blocks) {
+        second = true;
+        bx -= sec.first_blocks;
+        A = sec.A; lda = sec.lda; W = sec.W; ldb = sec.ldb; C = sec.C; ldc = sec.ldc; bias = sec.bias; N = sec.N; K = sec.K; unperm_R = sec.unperm_R;
+        relu = 0;
+    }
+    const int n0 = bx * 16;
     const float* wrow = static_cast<const float*>(W) + (WB16 ? 0 : (int64_t)min(n0 + r16, N - 1) * ldb);   // rows past N: clamped, their results are not stored
     const uint16_t* wrow16 = static_cast<const uint16_t*>(W) + (WB16 ? (int64_t)min(n0 + r16, N - 1) * ldb : 0);
     const float* arow[MT];                                                 // columns m >= M of a tile: garbage, never stored
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 wq[D], aq[D][MT];
     float gadd[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;                        // LSTM: wave mt < MT, lane (u = lane/16, m = 16*mt + lane%16)
-    const int eu = lane >> 4, em = wave * 16 + (lane & 15), ej = blockIdx.x * 4 + eu;
+    const int eu = lane >> 4, em = wave * 16 + (lane & 15), ej = bx * 4 + eu;
     const bool elive = LSTM && wave < MT && em < M && ej < ep.R;
     if (LSTM && ep.pk.best && blockIdx.x == 0 && t < 128) {                   // the previous step's pick, filed once (workgroup 0)
         if (ep.pk.best_reset) ep.pk.best_reset[t * PICK_LINE] = 0ull;
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
         for (int w = 0; w < WAVES; ++w) sum += part[w][e];
         const int n = n0 + 4 * (l >> 4) + v, m = mt * 16 + (l & 15);
         if (LSTM) tile[(4 * (l >> 4) + v) * (16 * MT) + m] = sum;             // row 4*g + u of this workgroup, column m
-        else if (PICK) {
+        else if (PICK && !second) {
             // (e == t < 256 here: waves 0..3, all lanes.)  Online (max, arg, sum exp) merge: two shuffles fold the four lanes that
             // hold a decode row inside this wave, the four waves' results meet in LDS -- a short chain instead of a 16-step scan
             const float o = n < N ? sum + (bias ? bias[n] : 0.f) : -INFINITY;
@@ -216,12 +233,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
             if (l < 16) { tile[(v * 16 + l) * 4] = mx; tile[(v * 16 + l) * 4 + 1] = se; tile[(v * 16 + l) * 4 + 2] = __int_as_float(arg); }
         } else if (m < M && n < N) {
             float o = sum + (bias ? bias[n] : 0.f);
-            if (add) o += add[(int64_t)m * ldadd + n];
+            if (add && !second) o += add[(int64_t)m * ldadd + n];
             if (relu) o = fmaxf(o, 0.f);
-            C[(int64_t)m * ldc + n] = o;
+            const int nc = unperm_R ? ((n & 15) >> 2) * unperm_R + (n >> 4) * 4 + (n & 3) : n;     // permuted gate row -> gate-major column
+            C[(int64_t)m * ldc + nc] = o;
         }
     }
-    if (PICK) {
+    if (PICK && !second) {
         __syncthreads();
         if (t < M) {                                                          // thread = decode row: merge the four waves' results
             float mx = tile[t * 4], se = tile[t * 4 + 1];
@@ -235,9 +253,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mfma_kernel(const floa
                 if (om > mx || (om == mx && oa < arg)) arg = oa;
                 mx = big;
             }
-            atomicMax(po.best + (t * PICK_SLOTS + (blockIdx.x & (PICK_SLOTS - 1))) * PICK_LINE,
+            atomicMax(po.best + (t * PICK_SLOTS + (bx & (PICK_SLOTS - 1))) * PICK_LINE,
                       ((unsigned long long)ordered_bits(mx) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)arg));
-            float* lp = po.lse_part + ((int64_t)blockIdx.x * 16 + t) * 2;
+            float* lp = po.lse_part + ((int64_t)bx * 16 + t) * 2;
             lp[0] = mx; lp[1] = se;
         }
     }
@@ -327,53 +345,111 @@ SUBGC_API int subgc_lstm_step_skinny(const float* x, int64_t ldx, const void* w_
     return subgc::check_launch("subgc_lstm_step_skinny");
 }
 
-// ---- C ABI: the greedy pick folded into the decode step's launches (see PickIn above) ------------------------------------------
-// `best` buffers: 16 rows x 8 slots x 16 uint64 (16 KB), zero before the logits launch that fills them.
-// subgc_lstm_step_pick: subgc_lstm_step_skinny whose input word of row m is the arg-max `best_prev` that the previous step's
-//   subgc_logits_pick left (finished rows feed word 0; the table row add1[word] is the x->gates term); workgroup 0 files that pick:
-//   seq[m, t_prev], unf_out[m], counts[t_prev], and clears `best_reset` (the other buffer) for this step's logits launch.  S <= 16.
-SUBGC_API int subgc_lstm_step_pick(const float* x, int64_t ldx, const void* w_perm, int64_t ldw, int K, int S, int R, const float* add1,
-                                   int64_t ld1, int tok_rows, const float* add2, int64_t ld2, const float* b0, const float* b1,
-                                   const float* c_prev, float* c, float* h0, int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2,
-                                   const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int T, int t_prev,
-                                   int32_t* count_out, const int32_t* prev_count, uint64_t* best_reset, int w_bf16, void* stream) {
-    SUBGC_REQUIRE(S >= 1 && S <= 16 && R > 0 && R % 4 == 0 && K > 0 && K % 4 == 0, "lstm_step_pick: need 1 <= S <= 16, R % 4 == 0, K % 4 == 0");
-    SUBGC_REQUIRE(x && w_perm && c && (h0 || h1 || h2) && add1 && tok_rows > 0, "lstm_step_pick: null pointer");
-    SUBGC_REQUIRE(best_prev && unf_out && seq && count_out && t_prev >= 0 && t_prev < T && (t_prev == 0 || unf_in), "lstm_step_pick: pick arguments");
-    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_perm % (w_bf16 ? 8 : 16)) == 0,
-                  "lstm_step_pick: x / w_perm rows must be 16-byte aligned float4 rows (8-byte aligned bf16 rows)");
-    hipStream_t s = (hipStream_t)stream;
-    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * 4.0 * R * K);
-    PickIn pk{reinterpret_cast<const unsigned long long*>(best_prev), unf_in, unf_out, seq, T, t_prev, count_out, prev_count,
-              reinterpret_cast<unsigned long long*>(best_reset)};
-    LstmEpi ep{add1, ld1, nullptr, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, pk};
-    if (w_bf16)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<LSTM_WAVES, 2, true, 1, false, true>), dim3(4 * R / 16), dim3(LSTM_WAVES * 64), 0, s, x, ldx, w_perm, ldw, nullptr, 0,
-                           nullptr, S, 4 * R, K, 0, ep, nullptr, 0, PickOut{});
-    else
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<LSTM_WAVES, 2, true, 1>), dim3(4 * R / 16), dim3(LSTM_WAVES * 64), 0, s, x, ldx, w_perm, ldw, nullptr, 0, nullptr, S,
-                           4 * R, K, 0, ep, nullptr, 0, PickOut{});
-    return subgc::check_launch("subgc_lstm_step_pick");
+// ---- round 6: the token step's independent weight streams share launches ---------------------------------------------------------------
+namespace {
+// The attention LSTM's cell update of a greedy decode step as its own small launch: the gate PRODUCT no longer waits for the pick (it
+// streams beside the logits, subgc_skinny_dual), only this kernel does.  pre [S, 4R] = H1 . Wc1^T in gate-major column order; everything
+// else -- the word's x -> gates table row, the fc term, biases, c_prev, the three h destinations, and workgroup 0's filing of the pick --
+// as in the LSTM form of gemm_skinny_mfma_kernel, in the same order of additions.
+__global__ __launch_bounds__(256) void lstm_cell_pick_kernel(const float* __restrict__ pre, int64_t ldpre, LstmEpi ep, int M) {
+    const int t = threadIdx.x;
+    if (ep.pk.best && blockIdx.x == 0 && t < 128) {
+        if (ep.pk.best_reset) ep.pk.best_reset[t * PICK_LINE] = 0ull;
+        if (t < M) {
+            bool unf;
+            const int w = picked_word(ep.pk, t, unf);
+            const bool alive = !(ep.pk.prev_count && *ep.pk.prev_count == 0);
+            if (alive) {
+                ep.pk.seq[(int64_t)t * ep.pk.T + ep.pk.t_prev] = w;
+                if (unf) atomicAdd(ep.pk.count_out, 1);
+            }
+            ep.pk.unf_out[t] = alive && unf;
+        }
+    }
+    const int idx = blockIdx.x * 256 + t;
+    if (idx >= M * ep.R) return;
+    const int em = idx / ep.R, ej = idx - em * ep.R;
+    // two dependent memory latencies (the pick's slots, then the word's table row) bound this launch: everything that does not depend on
+    // the word is requested BEFORE the slots are read
+    float pv[4], bs[4], a2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = g * ep.R + ej;
+        pv[g] = pre[(int64_t)em * ldpre + col];
+        bs[g] = (ep.b0 ? ep.b0[col] : 0.f) + (ep.b1 ? ep.b1[col] : 0.f);              // (0 + b0) + b1, as the LSTM form adds them
+        a2[g] = ep.add2 ? ep.add2[(int64_t)em * ep.ld2 + col] : 0.f;
+    }
+    const float cprev = ep.c_prev ? ep.c_prev[(int64_t)em * ep.R + ej] : 0.f;
+    int64_t row1 = em;
+    if (ep.pk.best) { bool unf; const int w = picked_word(ep.pk, em, unf); row1 = w >= ep.tok_rows ? ep.tok_rows - 1 : w; }
+    else if (ep.tok) { const int64_t w = ep.tok[em]; row1 = w < 0 ? 0 : (w >= ep.tok_rows ? ep.tok_rows - 1 : w); }
+    float g4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v = bs[g];
+        if (ep.add1) v += ep.add1[row1 * ep.ld1 + g * ep.R + ej];
+        if (ep.add2) v += a2[g];
+        g4[g] = pv[g] + v;
+    }
+    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+    const float cn = fg * cprev + ig * gg, hn = og * tanhf(cn);
+    ep.c[(int64_t)em * ep.R + ej] = cn;
+    if (ep.h0) ep.h0[(int64_t)em * ep.ldh0 + ej] = hn;
+    if (ep.h1) ep.h1[(int64_t)em * ep.ldh1 + ej] = hn;
+    if (ep.h2) ep.h2[(int64_t)em * ep.ldh2 + ej] = hn;
+}
+}  // namespace
+
+// subgc_lstm_cell_pick: c, h <- LSTMCell pointwise from pre-activations `pre` [S, 4R] (gate-major columns: what subgc_skinny_dual leaves
+// with unperm_R) + add1[word] + add2 + b0 + b1.  word of row m = the previous step's fused arg-max when best_prev != NULL (then the pick
+// is filed: seq[m, t_prev], unf_out[m], counts[t_prev]; `best_reset`, the other buffer, is cleared for this step's logits launch), else tok[m] (tok may be NULL: add1 row m).  S <= 16.
+SUBGC_API int subgc_lstm_cell_pick(const float* pre, int64_t ldpre, int S, int R, const float* add1, int64_t ld1, const int64_t* tok, int tok_rows,
+                                   const float* add2, int64_t ld2, const float* b0, const float* b1, const float* c_prev, float* c, float* h0,
+                                   int64_t ldh0, float* h1, int64_t ldh1, float* h2, int64_t ldh2, const uint64_t* best_prev, const int32_t* unf_in,
+                                   int32_t* unf_out, int64_t* seq, int T, int t_prev, int32_t* count_out, const int32_t* prev_count,
+                                   uint64_t* best_reset, void* stream) {
+    SUBGC_REQUIRE(S >= 1 && S <= 16 && R > 0 && ldpre >= 4 * R, "lstm_cell_pick: need 1 <= S <= 16 and ldpre >= 4 R");
+    SUBGC_REQUIRE(pre && c && (h0 || h1 || h2), "lstm_cell_pick: null pointer");
+    SUBGC_REQUIRE(!(tok || best_prev) || (add1 && tok_rows > 0), "lstm_cell_pick: a word needs its table in add1");
+    SUBGC_REQUIRE(!best_prev || (unf_out && seq && count_out && t_prev >= 0 && t_prev < T && (t_prev == 0 || unf_in)), "lstm_cell_pick: pick arguments");
+    SUBGC_DEBUG_RANGE(tok, 8, S, 1, 1, 0, tok_rows - 1, -1, "lstm_cell_pick: tok (word ids)", stream);
+    PickIn pk{};
+    if (best_prev)
+        pk = PickIn{reinterpret_cast<const unsigned long long*>(best_prev), unf_in, unf_out, seq, T, t_prev, count_out, prev_count,
+                    reinterpret_cast<unsigned long long*>(best_reset)};
+    LstmEpi ep{add1, ld1, tok, tok_rows, add2, ld2, b0, b1, c_prev, c, h0, ldh0, h1, ldh1, h2, ldh2, R, pk};
+    hipLaunchKernelGGL(lstm_cell_pick_kernel, dim3((S * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pre, ldpre, ep, S);
+    return subgc::check_launch("subgc_lstm_cell_pick");
 }
 
-// subgc_logits_pick: logits = x W^T + bias for S <= 16 rows WITHOUT writing them (logits may be NULL): `best` slots <- packed arg-max
-//   (64-bit atomicMax; zero before the launch), lse_part[(wg * 16 + m) * 2 + {0, 1}] = (max, sum exp(. - max)) over the 16 vocabulary
-//   rows of workgroup wg = 0 .. ceil(V/16)-1.
-SUBGC_API int subgc_logits_pick(const float* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, int S, int V, int K, float* logits,
-                                int64_t ldl, uint64_t* best, float* lse_part, int w_bf16, void* stream) {
-    SUBGC_REQUIRE(S >= 1 && S <= 16 && V > 0 && K > 0 && K % 4 == 0, "logits_pick: need 1 <= S <= 16 and K % 4 == 0");
-    SUBGC_REQUIRE(x && W && best && lse_part && (!logits || ldl >= V), "logits_pick: null pointer");
-    SUBGC_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= K && ldw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)W % (w_bf16 ? 8 : 16)) == 0,
-                  "logits_pick: x / W rows must be 16-byte aligned float4 rows (8-byte aligned bf16 rows)");
+// subgc_skinny_dual: TWO weight-streaming products of one decode step in one launch, S <= 16 rows each:
+//   problem 1: C1 = x1 W1^T + bias1 (C1 may be NULL with `best`), and with best != NULL the fused arg-max / log-sum-exp partials of
+//              the greedy pick (W1 = the logit matrix; `best` slots as PickIn describes, zero before the launch; lse_part[(wg * 16 + m) * 2 + {0, 1}]);
+//   problem 2: C2 = x2 W2^T (+ bias2), plain.
+// unperm1_R / unperm2_R != 0: that problem's W rows are in the permuted gate order of the LSTM forms and its result columns are written
+// gate-major (column g R + j).  Both weight matrices fp32 or both bf16 (w_bf16).
+SUBGC_API int subgc_skinny_dual(int S, const float* x1, int64_t ldx1, const void* W1, int64_t ldw1, const float* bias1, int N1, int K1, float* C1,
+                                int64_t ldc1, int unperm1_R, uint64_t* best, float* lse_part, const float* x2, int64_t ldx2, const void* W2,
+                                int64_t ldw2, const float* bias2, int N2, int K2, float* C2, int64_t ldc2, int unperm2_R, int w_bf16, void* stream) {
+    SUBGC_REQUIRE(S >= 1 && S <= 16 && N1 > 0 && N2 > 0 && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0, "skinny_dual: need 1 <= S <= 16 and K %% 4 == 0");
+    SUBGC_REQUIRE(x1 && W1 && x2 && W2 && C2 && (C1 || best) && (!best || lse_part), "skinny_dual: null pointer");
+    SUBGC_REQUIRE(ldx1 >= K1 && ldx1 % 4 == 0 && ldw1 >= K1 && ldw1 % 4 == 0 && ldx2 >= K2 && ldx2 % 4 == 0 && ldw2 >= K2 && ldw2 % 4 == 0 &&
+                      ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)x2 % 16) == 0 && ((uintptr_t)W1 % (w_bf16 ? 8 : 16)) == 0 && ((uintptr_t)W2 % (w_bf16 ? 8 : 16)) == 0,
+                  "skinny_dual: x / W rows must be 16-byte aligned float4 rows (8-byte aligned bf16 rows)");
+    SUBGC_REQUIRE((!unperm1_R || N1 == 4 * unperm1_R) && (!unperm2_R || N2 == 4 * unperm2_R) && (!C1 || ldc1 >= N1) && ldc2 >= N2, "skinny_dual: destination / permutation sizes");
+    SUBGC_REQUIRE(!(best && unperm1_R), "skinny_dual: the pick epilogue belongs to the logit matrix");
     hipStream_t s = (hipStream_t)stream;
-    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * (double)V * K);
-    if (w_bf16)
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<PICK_WAVES, 2, false, 1, true, true>), dim3((V + 15) / 16), dim3(PICK_WAVES * 64), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
-                           LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
-    else
-        hipLaunchKernelGGL((gemm_skinny_mfma_kernel<PICK_WAVES, 2, false, 1, true>), dim3((V + 15) / 16), dim3(PICK_WAVES * 64), 0, s, x, ldx, W, ldw, logits, ldl, bias, S, V, K, 0,
-                           LstmEpi{}, nullptr, 0, PickOut{reinterpret_cast<unsigned long long*>(best), lse_part});
-    return subgc::check_launch("subgc_logits_pick");
+    subgc::ProfScope prof(SUBGC_FAM_GEMM, s, 2.0 * S * ((double)N1 * K1 + (double)N2 * K2));
+    const int nb1 = (N1 + 15) / 16, nb2 = (N2 + 15) / 16;
+    Second sec{x2, ldx2, W2, ldw2, C2, ldc2, bias2, N2, K2, nb1, unperm2_R};
+    PickOut po{reinterpret_cast<unsigned long long*>(best), lse_part};
+#define SUBGC_DUAL_GO(PICK_, W16_) \
+    hipLaunchKernelGGL((gemm_skinny_mfma_kernel<PLAIN_WAVES, 2, false, 1, PICK_, W16_, true>), dim3(nb1 + nb2), dim3(PLAIN_WAVES * 64), 0, s, x1, ldx1, W1, ldw1, C1, ldc1, \
+                       bias1, S, N1, K1, 0, LstmEpi{}, nullptr, 0, po, sec, unperm1_R)
+    if (best) { if (w_bf16) SUBGC_DUAL_GO(true, true); else SUBGC_DUAL_GO(true, false); }
+    else { if (w_bf16) SUBGC_DUAL_GO(false, true); else SUBGC_DUAL_GO(false, false); }
+#undef SUBGC_DUAL_GO
+    return subgc::check_launch("subgc_skinny_dual");
 }
 
 namespace {
@@ -406,7 +482,7 @@ __global__ __launch_bounds__(256) void pick_lse_finish_kernel(const float* __res
 }
 }  // namespace
 
-// subgc_pick_file: the bookkeeping of subgc_lstm_step_pick alone (the LAST pick of a loop has no following LSTM launch)
+// subgc_pick_file: the bookkeeping of subgc_lstm_cell_pick alone (the LAST pick of a loop has no following cell launch)
 SUBGC_API int subgc_pick_file(const uint64_t* best_prev, const int32_t* unf_in, int32_t* unf_out, int64_t* seq, int S, int T, int t_prev,
                               int32_t* count_out, const int32_t* prev_count, void* stream) {
     SUBGC_REQUIRE(S >= 1 && S <= 16 && t_prev >= 0 && t_prev < T, "pick_file: bad sizes");

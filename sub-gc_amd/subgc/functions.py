@@ -1355,13 +1355,22 @@ class DecodeState:
         return self.logits
 
     def greedy_loop(self, T, seq, seqlp, counts, AL, it0):
-        """The whole greedy token loop (AttModel.py:282-319 with sample_max) for <= 16 rows on the fused state, with the PICK folded
-        into the step's launches: the logits launch leaves the packed arg-max and log-sum-exp partials (subgc_logits_pick), the next
-        step's attention-LSTM launch reads its input word from there and files seq / unfinished / the live count
-        (subgc_lstm_step_pick), the log-probabilities are formed once after the loop (subgc_pick_lse_finish).  Five launches per
-        token (att-LSTM, h2att, attention, lang-LSTM, logits) instead of six, no [n, V+1] logits in memory; the last core step, whose
-        logits the reference never reads, runs only as far as its attention weights are wanted (`AL`).
-        seq [S,T] / counts [T] zeroed by the caller, `it0` = S zeros (the <bos> input of step 0)."""
+        """The whole greedy token loop (AttModel.py:282-319 with sample_max) for <= 16 rows on the fused state, with the PICK folded into
+        the step's launches and -- round 6 -- the weight streams that do not depend on each other sharing launches, so that only what
+        must wait sits on the step's dependent chain.  Five launches per token:
+
+          1. [ logits(h_lang) + packed arg-max / log-sum-exp partials  |  attention-LSTM gate product H1 . Wc1^T ]   (subgc_skinny_dual)
+             -- the gate product needs step t's STATE, not the word: it used to wait for the pick inside the att-LSTM launch;
+          2. attention-LSTM cell: reads the pick (files seq / unfinished / the live count), adds the word's x -> gates table row
+             (subgc_lstm_cell_pick);
+          3. [ h2att(h_att)  |  the language LSTM's (h_att, h_lang_prev) part  [h_att, h_lang] . Wc2[:, R:]^T ]            (subgc_skinny_dual)
+          4. attention;
+          5. language LSTM: ctx . Wc2[:, :R]^T + the part from 3 + cell (subgc_lstm_step_skinny, K = R).
+
+        The 32 MB of the attention LSTM and 32 of the language LSTM's 48 MB leave the chain pick -> cell -> query -> attention -> cell.
+        The log-probabilities are formed once after the loop (subgc_pick_lse_finish); the last core step, whose logits the reference never
+        reads, runs only as far as its attention weights are wanted (`AL`).  seq [S,T] / counts [T] zeroed by the caller, `it0` = S zeros
+        (the <bos> input of step 0)."""
         if not (self.fused and self.xt_table is not None and self.S <= 16):
             raise ops.SubgcError("greedy_loop needs the fused decode state with the x->gates table and <= 16 rows")
         S, R, A, V1 = self.S, self.R, self.A, self.V1
@@ -1369,31 +1378,37 @@ class DecodeState:
         if getattr(self, "_pick", None) is None or self._pick[2].size(0) != T:
             self._pick = (torch.zeros(2, ops.PICK_BEST_ELEMS, device=dev, dtype=torch.int64), torch.zeros(2, S, device=dev, dtype=torch.int32),
                           torch.empty(T, (V1 + 15) // 16, 16, 2, device=dev, dtype=torch.float32))
+            self._preL = torch.empty(S, 4 * R, device=dev, dtype=torch.float32)
         best, unf, lse = self._pick
+        preA, preL = self.pre, self._preL
+        h2a_w = self.w16[17] if self.w16 is not None else self.h2a_w
         ops.zero_(best)
+        # step 0's gate product has no logits launch to ride in: alone (H1 is the zero state, but the launch keeps the loop uniform)
+        ops.skinny_dual(self.H2[:, R:2 * R], h2a_w, self.ah, self.H1, self.Wc1, preA, bias1=self.h2a_b, unperm2_R=R)
         for t in range(T + 1):
             last = t == T
             hs = [self.H2[:, R:2 * R], self.H1n[:, R:]]
             if t == 0:
-                ops.lstm_step_skinny(self.H1, self.Wc1, self.C1[0], self.C1[1], hs, self.b1i, self.b1h, self.xt_table, it0, self.Gf)
+                ops.lstm_cell_pick(preA, self.C1[0], self.C1[1], hs, self.b1i, self.b1h, self.xt_table, self.Gf, tok=it0)
             else:
                 pick = (best[(t - 1) & 1], unf[(t - 2) & 1] if t >= 2 else None, unf[(t - 1) & 1], seq, t - 1, counts[t - 1:t],
                         counts[t - 2:t - 1] if t >= 2 else None)
                 if last and AL is None:
                     ops.pick_file(*pick)
                     break
-                ops.lstm_step_pick(self.H1, self.Wc1, self.C1[0], self.C1[1], hs, self.b1i, self.b1h, self.xt_table, self.Gf, *pick,
-                                   None if last else best[t & 1])
+                ops.lstm_cell_pick(preA, self.C1[0], self.C1[1], hs, self.b1i, self.b1h, self.xt_table, self.Gf, pick=pick,
+                                   best_reset=None if last else best[t & 1])
             self.C1.reverse()
-            self._h2att()
+            ops.skinny_dual(self.H2[:, R:2 * R], h2a_w, self.ah, self.H2[:, R:], self.Wc2[:, R:], preL, bias1=self.h2a_b, unperm2_R=R)
             ops.attn_fwd(pr.u, pr.v, self.ah, self.an_w, self.an_b, pr.off, pr.lens, self.H2[:, :R], None if AL is None else AL[t], S, A, R)
             if last:
                 break
-            ops.lstm_step_skinny(self.H2, self.Wc2, self.C2[0], self.C2[1], [self.H1n[:, :R], self.H2n[:, 2 * R:], self.hout], self.b2i, self.b2h)
+            ops.lstm_step_skinny(self.H2[:, :R], self.Wc2[:, :R], self.C2[0], self.C2[1], [self.H1n[:, :R], self.H2n[:, 2 * R:], self.hout], self.b2i,
+                                 self.b2h, add2=preL)
             self.C2.reverse()
             self.H1, self.H1n = self.H1n, self.H1
             self.H2, self.H2n = self.H2n, self.H2
-            ops.logits_pick(self.hout, self.lg_op, self.lg_b, best[t & 1], lse[t])
+            ops.skinny_dual(self.hout, self.lg_op, None, self.H1, self.Wc1, preA, bias1=self.lg_b, unperm2_R=R, best=best[t & 1], lse_part=lse[t])
         ops.pick_lse_finish(lse, V1, counts, seqlp)
 
     def step(self, it, alpha_out, normalize=True):

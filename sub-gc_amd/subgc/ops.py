@@ -871,35 +871,37 @@ def lstm_step_skinny(x, w_perm, c_prev, c, hs, b0=None, b1=None, add1=None, tok=
 PICK_BEST_ELEMS = 16 * 8 * 16       # uint64 slots of one `best` buffer of the fused greedy pick (subgc_hip.h)
 
 
-def logits_pick(x, W, bias, best, lse_part, logits=None):
-    """Logits launch of a greedy decode step with the arg-max / log-sum-exp partials in its epilogue (subgc_logits_pick)."""
-    S, K = x.shape
-    V = W.size(0)
-    call("subgc_logits_pick", _ptr(x, torch.float32), ld(x), _ptr(W), ld(W), _ptr(bias, torch.float32), S, V, K, _ptr(logits),
-         ld(logits) if logits is not None else 0, _ptr(best, torch.int64), _ptr(lse_part, torch.float32), int(is_b16(W)), _stream())
+def skinny_dual(x1, W1, out1, x2, W2, out2, bias1=None, bias2=None, unperm1_R=0, unperm2_R=0, best=None, lse_part=None):
+    """Two weight-streaming products of <= 16 rows in one launch (subgc_skinny_dual): out1 = x1 W1^T (+ bias1) -- or, with `best`, the fused
+    arg-max / log-sum-exp partials (packed arg-max by 64-bit atomicMax into `best`, per-workgroup (max, sum exp) into `lse_part`) instead of (or beside) out1 -- and out2 = x2 W2^T (+ bias2).  unperm*_R: W's rows are
+    in the permuted LSTM gate order, the result is written gate-major."""
+    S = x1.size(0)
+    b16 = is_b16(W1)
+    if is_b16(W2) != b16:
+        raise SubgcError("skinny_dual: both weight matrices fp32 or both bf16")
+    call("subgc_skinny_dual", S, _ptr(x1, torch.float32), ld(x1), _ptr(W1), ld(W1), _ptr(bias1, torch.float32), W1.size(0), x1.size(1),
+         _ptr(out1, torch.float32), ld(out1) if out1 is not None else 0, int(unperm1_R), _ptr(best, torch.int64), _ptr(lse_part, torch.float32),
+         _ptr(x2, torch.float32), ld(x2), _ptr(W2), ld(W2), _ptr(bias2, torch.float32), W2.size(0), x2.size(1), _ptr(out2, torch.float32), ld(out2),
+         int(unperm2_R), int(b16), _stream())
 
 
-def lstm_step_pick(x, w_perm, c_prev, c, hs, b0, b1, table, add2, best_prev, unf_in, unf_out, seq, t_prev, count_out, prev_count, best_reset):
-    """lstm_step_skinny fed by the previous step's fused arg-max (subgc_lstm_step_pick)."""
-    S, K = x.shape
-    R = c.size(1)
+def lstm_cell_pick(pre, c_prev, c, hs, b0, b1, table, add2, tok=None, pick=None, best_reset=None):
+    """The attention LSTM's cell of a greedy decode step from gate-major pre-activations (subgc_lstm_cell_pick).  `pick` = (best_prev,
+    unf_in, unf_out, seq, t_prev, count_out, prev_count), or None with `tok` [S] int64 (step 0)."""
+    S, R = c.shape
     hs = list(hs) + [None] * (3 - len(hs))
     hp = []
     for h_ in hs:
         hp += [_ptr(h_, torch.float32), ld(h_) if h_ is not None else 0]
-    call("subgc_lstm_step_pick", _ptr(x, torch.float32), ld(x), _ptr(w_perm), ld(w_perm), K, S, R, _ptr(table, torch.float32), ld(table),
-         table.size(0), _ptr(add2, torch.float32), ld(add2) if add2 is not None else 0, _ptr(b0, torch.float32), _ptr(b1, torch.float32),
-         _ptr(c_prev, torch.float32), _ptr(c, torch.float32), *hp, _ptr(best_prev, torch.int64), _ptr(unf_in, torch.int32), _ptr(unf_out, torch.int32),
-         _ptr(seq, torch.int64), seq.size(1), int(t_prev), _ptr(count_out, torch.int32), _ptr(prev_count, torch.int32), _ptr(best_reset, torch.int64),
-         int(is_b16(w_perm)), _stream())
-
-
-def gemm_skinny_wb16(x, w16, out, bias=None, relu=False):
-    """out = act(x w16^T + bias): fp32 rows (<= 16) against a bf16-STORED weight matrix (subgc_gemm_skinny_wb16)."""
-    M, K = x.shape
-    call("subgc_gemm_skinny_wb16", _ptr(x, torch.float32), ld(x), _ptr(w16, BF16), ld(w16), _ptr(out, torch.float32), ld(out), _ptr(bias, torch.float32),
-         M, w16.size(0), K, int(relu), _stream())
-    return out
+    if pick is not None:
+        best_prev, unf_in, unf_out, seq, t_prev, count_out, prev_count = pick
+        pk = [_ptr(best_prev, torch.int64), _ptr(unf_in, torch.int32), _ptr(unf_out, torch.int32), _ptr(seq, torch.int64), seq.size(1), int(t_prev),
+              _ptr(count_out, torch.int32), _ptr(prev_count, torch.int32), _ptr(best_reset, torch.int64)]
+    else:
+        pk = [None, None, None, None, 0, 0, None, None, None]
+    call("subgc_lstm_cell_pick", _ptr(pre, torch.float32), ld(pre), S, R, _ptr(table, torch.float32), ld(table), _ptr(tok, torch.int64), table.size(0),
+         _ptr(add2, torch.float32), ld(add2) if add2 is not None else 0, _ptr(b0, torch.float32), _ptr(b1, torch.float32), _ptr(c_prev, torch.float32),
+         _ptr(c, torch.float32), *hp, *pk, _stream())
 
 
 def pick_file(best_prev, unf_in, unf_out, seq, t_prev, count_out, prev_count):

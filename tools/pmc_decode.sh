@@ -1,8 +1,8 @@
-# FETCH_SIZE / WRITE_SIZE of the one-image decode loop's weight-streaming kernels -> gpurun_out/${ROUND}_pmc_decode.json (ROUND=r03 by default)
+# FETCH_SIZE / WRITE_SIZE of the one-image decode loop's weight-streaming kernels -> gpurun_out/${ROUND}_pmc_decode.json (ROUND=r06 by default)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r06}
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmcd_$C
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmcd_$C -- python $R/tools/decode_bench.py 16 50 > $O/pmcd_$C.log 2>&1
@@ -14,12 +14,16 @@ def load(c):
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "gemm_skinny_mfma_kernel" not in k:
-            continue
         import re
-        a = [x.strip() for x in re.search(r"gemm_skinny_mfma_kernel<([^>]*)>", k).group(1).split(",")]     # WAVES, D, LSTM, MT, PICK, WB16
-        lstm, mt, pick = a[2] == "true", a[3], len(a) > 4 and a[4] == "true"
-        key = "lstm" if lstm else ("logits_pick" if pick else ("plain_1tile" if mt == "1" else "other"))
+        if "lstm_cell_pick_kernel" in k:
+            key = "cell_pick"
+        elif "gemm_skinny_mfma_kernel" in k:
+            a = [x.strip() for x in re.search(r"gemm_skinny_mfma_kernel<([^>]*)>", k).group(1).split(",")]     # WAVES, D, LSTM, MT, PICK, WB16, DUAL
+            flag = lambda i: len(a) > i and a[i] == "true"
+            lstm, mt, pick, dual = flag(2), a[3], flag(4), flag(6)
+            key = ("dual_pick" if pick else "dual") if dual else ("lstm" if lstm else ("plain_1tile" if mt == "1" else "other"))
+        else:
+            continue
         d[key][0] += 1; d[key][1] += float(r["Counter_Value"])
     return d
 f, w = load("FETCH_SIZE"), load("WRITE_SIZE")

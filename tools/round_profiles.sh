@@ -42,3 +42,4 @@ done
 cut -c1-700 $R/profiles/${ROUND}_bench_n1.json; cut -c1-400 $O/${ROUND}_bench_full_gc_kar.json; cut -c1-400 $O/${ROUND}_bench_flickr.json
 head -14 $O/${ROUND}_train_kernel_stats.txt | cut -c1-150; head -12 $O/${ROUND}_full_gc_kar_kernel_stats.txt | cut -c1-150; cat $O/${ROUND}_pmc_traffic.json | head -20
 ROUND=$ROUND bash $R/tools/pmc_decode_legs.sh > $O/${ROUND}_pmc_decode_legs.log 2>&1      # GEMM traffic + kernel stats of the three throughput decode legs
+ROUND=$ROUND bash $R/tools/pmc_decode.sh > $O/${ROUND}_pmc_decode.log 2>&1                # FETCH / WRITE of the one-image greedy loop -> ${ROUND}_pmc_decode.json
