@@ -24,6 +24,20 @@ __device__ __forceinline__ float4 ldx(const void* base, int64_t i) {
     return UV16 ? subgc_load4_bf(static_cast<const uint16_t*>(base) + i) : ld4(static_cast<const float*>(base) + i);
 }
 
+// the same four elements as they lie in memory (a uint2 of bf16 pairs, or the float4 itself): what a thread holds while several rows are
+// in flight -- the conversion happens when a row is used, so a bf16 row in flight costs two registers, not four
+template <bool UV16> struct RawOf { using type = float4; };
+template <> struct RawOf<true> { using type = uint2; };
+template <bool UV16>
+__device__ __forceinline__ typename RawOf<UV16>::type ldraw(const void* base, int64_t i) {
+    if constexpr (UV16) return *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + i);
+    else return ld4(static_cast<const float*>(base) + i);
+}
+__device__ __forceinline__ float4 cvt4(const float4& r) { return r; }
+__device__ __forceinline__ float4 cvt4(const uint2& q) {
+    return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+}
+
 // CA = ceil(A/4 / 64): float4 chunks of a score row per lane;  CR = ceil(R/4 / 256): float4 chunks of a value row per thread
 template <int CA, int CR, bool UV16>
 __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restrict__ u, const void* __restrict__ v,
@@ -117,8 +131,10 @@ __global__ __launch_bounds__(256) void attn_fwd_vec_kernel(const void* __restric
     }
 }
 
-template <int CA, int CR64, bool UV16>
-__global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restrict__ u, const void* __restrict__ v,
+// LEAN: d(u) and d(v) are both deferred (du == dv == NULL: every launch of the product) -- their read-modify-write paths are compiled out
+// and their registers with them
+template <int CA, int CR64, bool UV16, bool LEAN>
+__device__ __forceinline__ void attn_bwd_vec_body(const void* __restrict__ u, const void* __restrict__ v,
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
                                                            const int32_t* __restrict__ off, const int32_t* __restrict__ len,
                                                            const float* __restrict__ alpha, int n_stride,
@@ -168,21 +184,21 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
     }
     __syncthreads();
     // NCH of this wave's nodes at a time: rows requested together, the NCH dot products reduced over the lanes together
-    constexpr int NCH = CR64 <= 2 ? 4 : (CR64 <= 4 ? 3 : 1);
+    constexpr int NCH = CR64 <= 2 ? 4 : (CR64 <= 4 ? (UV16 ? 3 : 2) : 1);
     for (int i0 = wave; i0 < l; i0 += 4 * NCH) {
-        float4 x[NCH][CR64];
+        typename RawOf<UV16>::type x[NCH][CR64];
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
 #pragma unroll
             for (int c = 0; c < CR64; ++c)
-                x[k][c] = (i0 + 4 * k < l && lane + c * 64 < R4) ? ldx<UV16>(v, (int64_t)(m0 + i0 + 4 * k) * R + (lane + c * 64) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[k][c] = ldraw<UV16>(v, (int64_t)(m0 + min(i0 + 4 * k, l - 1)) * R + min(lane + c * 64, R4 - 1) * 4);
         float sc[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int i = i0 + 4 * k;
             float acc = 0.f;
             if (i < l) {
-                if (dv) {
+                if (!LEAN && dv) {
                     const float a_i = al_s[i];
                     float* dvr = dv + (int64_t)(m0 + i) * R;
                     float4 y[CR64];
@@ -195,7 +211,10 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < CR64; ++c) acc += g[c].x * x[k][c].x + g[c].y * x[k][c].y + g[c].z * x[k][c].z + g[c].w * x[k][c].w;
+                for (int c = 0; c < CR64; ++c) {
+                    const float4 xv = cvt4(x[k][c]);            // g is zero in the chunks past R: a clamped load there adds nothing
+                    acc += g[c].x * xv.x + g[c].y * xv.y + g[c].z * xv.z + g[c].w * xv.w;
+                }
             }
             sc[k] = acc;
         }
@@ -205,6 +224,14 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
             for (int k = 0; k < NCH; ++k)
                 if (i0 + 4 * k < l) da_s[i0 + 4 * k] = sc[k];
         }
+    }
+    constexpr int UN = LEAN ? (UV16 ? 8 : 6) : 4;
+    const int grp = t >> 7;
+    typename RawOf<UV16>::type xu[UN] = {};
+    if (l > 0) {                                            // (an empty set has no row to request)
+        const int a40 = min(t & 127, A4 - 1);
+#pragma unroll
+        for (int k = 0; k < UN; ++k) xu[k] = ldraw<UV16>(u, (int64_t)(m0 + min(grp + 2 * k, l - 1)) * A + a40 * 4);
     }
     __syncthreads();
     float dot = 0.f;
@@ -222,34 +249,40 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
         db_a[s] = desum;
     }
     // through tanh: 2 thread groups x 128 float4 chunks of the hidden dimension; group g takes nodes i = g, g+2, ...
+    // UN of a group's nodes at a time: their u (and d(u)) rows are requested together, the sums keep the node order.  LEAN (nothing of
+    // d(u) is touched here): the rows stay in memory format until used, so eight bf16 / six fp32 rows are in flight -- and the first batch
+    // was requested before the softmax backward above (it depends on nothing that section computes)
 #pragma unroll
     for (int c = 0; c < CA; ++c) {
-        const int a4 = (t & 127) + c * 128, grp = t >> 7;
+        const int a4 = (t & 127) + c * 128;
         float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f), wsum = dsum;
         if (a4 < A4) {
             const float4 wa = ld4(w_a + a4 * 4), ha = ld4(ah + (int64_t)s * A + a4 * 4);
-            // four of this group's nodes at a time: their u (and d(u)) rows are requested together, the sums keep the node order
-            constexpr int UN = 4;
             for (int i0 = grp; i0 < l; i0 += 2 * UN) {
-                float4 x[UN], d[UN];
+                float4 d[LEAN ? 1 : UN];
+                if (c > 0 || i0 > grp) {
 #pragma unroll
-                for (int k = 0; k < UN; ++k) {
-                    const int i = i0 + 2 * k;
-                    const int64_t o = (int64_t)(m0 + (i < l ? i : grp)) * A + a4 * 4;      // past the end: a valid row, its result is dropped
-                    x[k] = ldx<UV16>(u, o);
-                    d[k] = du ? ld4(du + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < UN; ++k) xu[k] = ldraw<UV16>(u, (int64_t)(m0 + min(i0 + 2 * k, l - 1)) * A + a4 * 4);
+                }
+                if constexpr (!LEAN) {
+#pragma unroll
+                    for (int k = 0; k < UN; ++k)
+                        d[k] = du ? ld4(du + (int64_t)(m0 + min(i0 + 2 * k, l - 1)) * A + a4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int k = 0; k < UN; ++k) {
                     const int i = i0 + 2 * k;
                     if (i >= l) break;
+                    const float4 x = cvt4(xu[k]);
                     const float de = al_s[i];
-                    const float t0 = subgc_tanh(x[k].x + ha.x), t1 = subgc_tanh(x[k].y + ha.y), t2 = subgc_tanh(x[k].z + ha.z), t3 = subgc_tanh(x[k].w + ha.w);
+                    const float t0 = subgc_tanh(x.x + ha.x), t1 = subgc_tanh(x.y + ha.y), t2 = subgc_tanh(x.z + ha.z), t3 = subgc_tanh(x.w + ha.w);
                     const float p0 = de * wa.x * (1.f - t0 * t0), p1 = de * wa.y * (1.f - t1 * t1);
                     const float p2 = de * wa.z * (1.f - t2 * t2), p3 = de * wa.w * (1.f - t3 * t3);
-                    if (du) {
-                        d[k].x += p0; d[k].y += p1; d[k].z += p2; d[k].w += p3;
-                        st4(du + (int64_t)(m0 + i) * A + a4 * 4, d[k]);
+                    if constexpr (!LEAN) {
+                        if (du) {
+                            d[k].x += p0; d[k].y += p1; d[k].z += p2; d[k].w += p3;
+                            st4(du + (int64_t)(m0 + i) * A + a4 * 4, d[k]);
+                        }
                     }
                     dsum.x += p0; dsum.y += p1; dsum.z += p2; dsum.w += p3;
                     wsum.x += de * t0; wsum.y += de * t1; wsum.z += de * t2; wsum.w += de * t3;
@@ -268,6 +301,33 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
             st4(dw_a + (int64_t)s * A + a4 * 4, wsum);      // per-sentence partial; the caller column-sums once over all steps
         }
     }
+}
+
+// fp32 sets: as the compiler allots registers (118-124 with 1000-wide value rows: four workgroups per CU).  bf16 sets: held to 96 registers
+// so that FIVE workgroups share a CU -- Full-GC's 1280 sentence rows are then resident at once instead of 1024 + a second round.
+template <int CA, int CR64, bool UV16, bool LEAN>
+__global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restrict__ u, const void* __restrict__ v,
+                                                           const float* __restrict__ ah, const float* __restrict__ w_a,
+                                                           const int32_t* __restrict__ off, const int32_t* __restrict__ len,
+                                                           const float* __restrict__ alpha, int n_stride,
+                                                           const float* __restrict__ dctx, int64_t lddctx, void* __restrict__ dah,
+                                                           float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
+                                                           float* __restrict__ db_a, int A, int R, int dah_b16,
+                                                           float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride,
+                                                           float* __restrict__ de_keep) {
+    attn_bwd_vec_body<CA, CR64, UV16, LEAN>(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep);
+}
+template <int CA, int CR64, bool LEAN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void attn_bwd_vec_b16_kernel(const void* __restrict__ u, const void* __restrict__ v,
+                                                           const float* __restrict__ ah, const float* __restrict__ w_a,
+                                                           const int32_t* __restrict__ off, const int32_t* __restrict__ len,
+                                                           const float* __restrict__ alpha, int n_stride,
+                                                           const float* __restrict__ dctx, int64_t lddctx, void* __restrict__ dah,
+                                                           float* __restrict__ du, float* __restrict__ dv, float* __restrict__ dw_a,
+                                                           float* __restrict__ db_a, int A, int R, int dah_b16,
+                                                           float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride,
+                                                           float* __restrict__ de_keep) {
+    attn_bwd_vec_body<CA, CR64, true, LEAN>(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep);
 }
 
 // d(v) of ALL time steps in one pass: dv[m0 + i, :] = sum over the steps t at which sentence s is live of alpha_t[s, i] *
@@ -431,12 +491,14 @@ int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a
         return -100;
     const int ca = (A / 4 + 127) / 128, cr = (R / 4 + 63) / 64;
     if (ca > 2 || cr > 8) return -100;
+    const bool lean = !du && !dv;
+#define SUBGC_ATT_BWD2(K_, ...)                                                                                                           \
+    hipLaunchKernelGGL((K_<__VA_ARGS__>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, A, \
+                       R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep)
 #define SUBGC_ATT_BWD(CA_, CR_)                                                                                                          \
     do {                                                                                                                                   \
-        if (uv_b16) hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, true>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
-                                       dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep); \
-        else hipLaunchKernelGGL((attn_bwd_vec_kernel<CA_, CR_, false>), dim3(S), dim3(256), 0, s, u, v, ah, w_a, off, len, alpha, n_stride, \
-                                dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep); \
+        if (uv_b16) { if (lean) SUBGC_ATT_BWD2(attn_bwd_vec_b16_kernel, CA_, CR_, true); else SUBGC_ATT_BWD2(attn_bwd_vec_b16_kernel, CA_, CR_, false); } \
+        else { if (lean) SUBGC_ATT_BWD2(attn_bwd_vec_kernel, CA_, CR_, false, true); else SUBGC_ATT_BWD2(attn_bwd_vec_kernel, CA_, CR_, false, false); } \
     } while (0)
     if (ca == 1) {
         if (cr <= 1) SUBGC_ATT_BWD(1, 1); else if (cr <= 2) SUBGC_ATT_BWD(1, 2); else if (cr <= 4) SUBGC_ATT_BWD(1, 4); else SUBGC_ATT_BWD(1, 8);
@@ -444,6 +506,7 @@ int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a
         if (cr <= 1) SUBGC_ATT_BWD(2, 1); else if (cr <= 2) SUBGC_ATT_BWD(2, 2); else if (cr <= 4) SUBGC_ATT_BWD(2, 4); else SUBGC_ATT_BWD(2, 8);
     }
 #undef SUBGC_ATT_BWD
+#undef SUBGC_ATT_BWD2
     return check_launch("subgc_attn_bwd(vec)");
 }
 
