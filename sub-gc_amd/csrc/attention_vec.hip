@@ -303,8 +303,9 @@ __device__ __forceinline__ void attn_bwd_vec_body(const void* __restrict__ u, co
     }
 }
 
-// fp32 sets: as the compiler allots registers (118-124 with 1000-wide value rows: four workgroups per CU).  bf16 sets: held to 96 registers
-// so that FIVE workgroups share a CU -- Full-GC's 1280 sentence rows are then resident at once instead of 1024 + a second round.
+// The general form, as the compiler allots registers (114-124 with 1000-wide value rows and the read-modify-write paths: four workgroups
+// per CU); the deferred form over bf16 sets is additionally held to 96 registers so that FIVE workgroups share a CU -- Full-GC's 1280
+// sentence rows are then resident at once instead of 1024 + a second round (fp32, deferred: 73 registers without being asked).
 template <int CA, int CR64, bool UV16, bool LEAN>
 __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restrict__ u, const void* __restrict__ v,
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_vec_kernel(const void* __restric
                                                            float* __restrict__ de_keep) {
     attn_bwd_vec_body<CA, CR64, UV16, LEAN>(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep);
 }
-template <int CA, int CR64, bool LEAN>
+template <int CA, int CR64>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void attn_bwd_vec_b16_kernel(const void* __restrict__ u, const void* __restrict__ v,
                                                            const float* __restrict__ ah, const float* __restrict__ w_a,
                                                            const int32_t* __restrict__ off, const int32_t* __restrict__ len,
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void a
                                                            float* __restrict__ db_a, int A, int R, int dah_b16,
                                                            float* __restrict__ dctx_keep, int64_t ldkeep, int n_planes, int64_t plane_stride,
                                                            float* __restrict__ de_keep) {
-    attn_bwd_vec_body<CA, CR64, true, LEAN>(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep);
+    attn_bwd_vec_body<CA, CR64, true, true>(u, v, ah, w_a, off, len, alpha, n_stride, dctx, lddctx, dah, du, dv, dw_a, db_a, A, R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep);
 }
 
 // d(v) of ALL time steps in one pass: dv[m0 + i, :] = sum over the steps t at which sentence s is live of alpha_t[s, i] *
@@ -497,7 +498,7 @@ int attn_bwd_vec(const void* u, const void* v, const float* ah, const float* w_a
                        R, dah_b16, dctx_keep, ldkeep, n_planes, plane_stride, de_keep)
 #define SUBGC_ATT_BWD(CA_, CR_)                                                                                                          \
     do {                                                                                                                                   \
-        if (uv_b16) { if (lean) SUBGC_ATT_BWD2(attn_bwd_vec_b16_kernel, CA_, CR_, true); else SUBGC_ATT_BWD2(attn_bwd_vec_b16_kernel, CA_, CR_, false); } \
+        if (uv_b16) { if (lean) SUBGC_ATT_BWD2(attn_bwd_vec_b16_kernel, CA_, CR_); else SUBGC_ATT_BWD2(attn_bwd_vec_kernel, CA_, CR_, true, false); } \
         else { if (lean) SUBGC_ATT_BWD2(attn_bwd_vec_kernel, CA_, CR_, false, true); else SUBGC_ATT_BWD2(attn_bwd_vec_kernel, CA_, CR_, false, false); } \
     } while (0)
     if (ca == 1) {
