@@ -323,3 +323,70 @@ def test_no_garbage_collection_inside_a_graph_capture(golden):
         sampling._GraphedLoop._loop = real
     assert seen == [False] and gc.isenabled()
     assert torch.equal(out[0].cpu(), torch.from_numpy(g.group("out")["seq"]))
+
+
+@pytest.mark.parametrize("S,R,V,K1,K2,wb16", [(10, 1000, 9488, 1000, 2000, False), (16, 48, 150, 96, 144, False), (1, 52, 1003, 100, 104, False),
+                                              (10, 1000, 9488, 1000, 2000, True), (7, 48, 77, 96, 48, True)])
+def test_dual_weight_stream_and_cell_pick_kernels(S, R, V, K1, K2, wb16):
+    """Round 6's greedy step, kernel by kernel against torch: subgc_skinny_dual = [logits with the arg-max / log-sum-exp epilogue | a
+    gate product in the permuted row order, written gate-major], then subgc_lstm_cell_pick = the attention LSTM's cell whose word is
+    that arg-max, with the bookkeeping of AttModel.py:295-319 (finished rows feed 0, seq / unfinished / live count)."""
+    g = torch.Generator().manual_seed(S * 131 + R)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    h, Wl, bl = rnd(S, K1), rnd(V, K1, sc=K1 ** -0.5), rnd(V, sc=0.2)
+    Wl[5] = Wl[3]; bl[5] = bl[3]                                                    # an exact tie: the smaller column must win
+    x2, Wg = rnd(S, K2), rnd(4 * R, K2, sc=K2 ** -0.5)
+    Wgp = Wg[ops.lstm_gate_perm(R, DEV)].contiguous()
+    if wb16:
+        Wl, Wgp, Wg = Wl.bfloat16(), Wgp.bfloat16(), Wg.bfloat16()
+    logits_ref = h.double() @ Wl.double().t() + bl.double()
+    gates_ref = x2.double() @ Wg.double().t()
+    # (a) plain dual: both results written
+    out1, out2 = torch.empty(S, V, device=DEV), torch.full((S, 4 * R + 8), 7.0, device=DEV)
+    ops.skinny_dual(h, Wl, out1, x2, Wgp, out2[:, :4 * R], bias1=bl, unperm2_R=R)
+    torch.testing.assert_close(out1.double(), logits_ref, atol=3e-5, rtol=1e-5)
+    torch.testing.assert_close(out2[:, :4 * R].double(), gates_ref, atol=3e-5, rtol=1e-5)
+    assert float(out2[:, 4 * R:].min()) == 7.0                                      # nothing past the gate columns
+    # (b) with the pick epilogue: no logits in memory, arg-max of out1's own bits, log-sum-exp partials
+    wgs = (V + 15) // 16
+    best = torch.zeros(2, 16 * 8 * 16, dtype=torch.int64, device=DEV)
+    lse = torch.zeros(1, wgs * 16 * 2, device=DEV)
+    pre = torch.empty(S, 4 * R, device=DEV)
+    ops.skinny_dual(h, Wl, None, x2, Wgp, pre, bias1=bl, unperm2_R=R, best=best[0], lse_part=lse[0])
+    assert torch.equal(pre, out2[:, :4 * R])
+    word = out1.argmax(1)                                                           # torch: the first maximum
+    # the cell: table row of the picked word (finished rows feed word 0), fc term, two biases
+    T, t_prev = 5, 2
+    table, add2, b0, b1, cp = rnd(V, 4 * R, sc=0.3), rnd(S, 4 * R, sc=0.3), rnd(4 * R, sc=0.2), rnd(4 * R, sc=0.2), rnd(S, R)
+    unf_in = (torch.arange(S) % 3 != 1).int().to(DEV)
+    unf_out, seq = torch.full((S,), -5, dtype=torch.int32, device=DEV), torch.full((S, T), -1, dtype=torch.int64, device=DEV)
+    count, prev = torch.zeros(1, dtype=torch.int32, device=DEV), torch.ones(1, dtype=torch.int32, device=DEV)
+    best[1].fill_(3)
+    c, h0, hw = torch.empty(S, R, device=DEV), torch.empty(S, R, device=DEV), torch.full((S, 3 * R), 9.0, device=DEV)
+    ops.lstm_cell_pick(pre, cp, c, [h0, hw[:, R:2 * R]], b0, b1, table, add2, pick=(best[0], unf_in, unf_out, seq, t_prev, count, prev), best_reset=best[1])
+    fed = word * unf_in.long()
+    assert torch.equal(seq[:, t_prev], fed) and int(seq[:, :t_prev].max()) == -1 and int(seq[:, t_prev + 1:].max()) == -1
+    assert torch.equal(unf_out, (unf_in.bool() & (fed > 0)).int()) and int(count) == int(unf_out.sum())
+    assert int(best[1].abs().max()) == 0                                            # the other buffer is ready for this step's logits
+    p = pre.double() + table[fed].double() + add2.double() + b0.double() + b1.double()
+    i, f, gg, o = p[:, :R].sigmoid(), p[:, R:2 * R].sigmoid(), p[:, 2 * R:3 * R].tanh(), p[:, 3 * R:].sigmoid()
+    cn = f * cp.double() + i * gg
+    torch.testing.assert_close(c.double(), cn, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(h0.double(), o * cn.tanh(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(hw[:, R:2 * R], h0) and float(hw[:, :R].min()) == 9.0 and float(hw[:, 2 * R:].min()) == 9.0
+    # a loop the reference has already left (*prev_count == 0) files nothing
+    seq2, cnt2 = seq.clone(), torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.lstm_cell_pick(pre, cp, c, [h0], b0, b1, table, add2, pick=(best[0], unf_in, unf_out.clone(), seq2, t_prev + 1, cnt2, cnt2.clone()), best_reset=None)
+    assert torch.equal(seq2, seq) and int(cnt2) == 0
+    # the word given directly (step 0)
+    tok = torch.randint(0, V, (S,), generator=g).to(DEV)
+    ops.lstm_cell_pick(pre, cp, c, [h0], b0, b1, table, add2, tok=tok)
+    p = pre.double() + table[tok].double() + add2.double() + b0.double() + b1.double()
+    cn = p[:, R:2 * R].sigmoid() * cp.double() + p[:, :R].sigmoid() * p[:, 2 * R:3 * R].tanh()
+    torch.testing.assert_close(c.double(), cn, atol=2e-5, rtol=1e-5)
+    # the log-probability of the picked word from the per-workgroup (max, sum exp) partials
+    counts = torch.full((1,), S, dtype=torch.int32, device=DEV)
+    seqlp = torch.zeros(S, 1, device=DEV)
+    ops.pick_lse_finish(lse, V, counts, seqlp)
+    want = out1.double().max(1).values - torch.logsumexp(out1.double(), 1)
+    torch.testing.assert_close(seqlp[:, 0].double(), want, atol=2e-5, rtol=1e-5)
