@@ -264,3 +264,70 @@ def test_one_rank_keeps_the_whole_buffer_norm_pass():
     # (the two backward passes differ in the last bits -- embed_bwd / pool_bwd accumulate with float atomics -- and Adam's first step turns a
     # near-zero gradient's last bit into a visible fraction of lr = 1e-2: measured 9e-6)
     assert float((pa - pu).abs().max()) <= 1e-4 and float((pu - start).abs().max()) > 1e-3
+
+
+def _nccl_adam_worker(port, q):
+    """world size 1, backend nccl, `always_reduce`: the code path of an N > 1 run with the optimizer attached -- every slice's clip-norm
+    share is accumulated on the reducer's side stream behind ITS collective's work handle, the compute stream joins it in finish()."""
+    _setup_paths()
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from subgc import ops, parallel
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    m, batch, models = _model_and_batch()
+    start = m.flat_params.detach().clone()
+    res = {}
+    real = ops.sumsq
+    for attached in (True, False):
+        m.flat_params.data.copy_(start)
+        m.invalidate_decode_caches()
+        adam = parallel.FlatAdam(m, lr=1e-2, clip_norm=0.05)            # the clip is active: a wrong or unfinished norm moves the parameters
+        red = parallel.GradBucketReducer(m, always_reduce=True, optimizer=adam if attached else None)
+        seen = []
+        ops.sumsq = lambda g, out: (seen.append((g.numel(), torch.cuda.current_stream().cuda_stream)), real(g, out))[1]
+        try:
+            for _ in range(2):                                          # two steps: the accumulator is re-armed by prepare()
+                seen.clear()
+                _shard_step_sum(m, models, batch, red)
+                adam.step(grad_scale=1.0)
+            torch.cuda.synchronize()
+        finally:
+            ops.sumsq = real
+        side = red._side.cuda_stream if red._side is not None else None
+        res[attached] = (m.flat_params.detach().cpu(), list(seen), float(adam.sumsq), side, [hi - lo for _, lo, hi in red.buckets if hi > lo])
+        red.close()
+    q.put((res, torch.cuda.current_stream().cuda_stream, dist.get_backend(), float((res[False][0] - start.cpu()).abs().max())))
+    dist.destroy_process_group()
+
+
+def _shard_step_sum(m, models, shard, reducer):
+    lw = models.LossWrapper(m, None)
+    b = {k: v.to(m.flat_params.device) for k, v in shard.items()}
+    reducer.prepare()
+    out = lw(b["fc_feats"], b["att_feats"], b["labels"], b["masks"], b["att_masks"], None, None, None, b["obj_dist"], None, b["rel_ind"],
+             None, b["pred_dist"], b["gpn_obj_ind"], b["gpn_pred_ind"], b["gpn_nrel_ind"], b["gpn_pool_mtx"])
+    (out["lang_loss"] + out["gpn_loss"]).backward()
+    return reducer.finish(average=False)
+
+
+@pytest.mark.timeout(600)
+def test_rccl_slices_carry_their_clip_norm_on_the_side_stream():
+    """The N > 1 step tail over the real `nccl` backend (world size 1 on the one-GPU box, `always_reduce`): with the optimizer attached
+    each of the five slices adds its squared norm right behind its own collective on the reducer's side stream, FlatAdam.step finds all
+    of them in and launches no norm pass of its own; the parameters after two clipped steps equal those of the detached order
+    (collectives, then one whole-buffer norm pass)."""
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_adam_worker, args=(_free_port(), q))
+    p.start()
+    res, main_stream, backend, moved = q.get(timeout=500)
+    p.join(120)
+    assert p.exitcode == 0 and backend == "nccl"
+    (pa, seen_a, na, side, sizes), (pu, seen_u, nu, side_u, _) = res[True], res[False]
+    assert side is not None and side != main_stream and side_u is None
+    assert [n for n, _ in seen_a] == sizes and all(st == side for _, st in seen_a)         # five slice passes, all on the side stream
+    assert len(seen_u) == 1 and seen_u[0][0] == sum(sizes) and seen_u[0][1] == main_stream    # detached: one pass over the whole buffer
+    assert abs(na - nu) <= 1e-5 * nu and nu ** 0.5 > 0.05
+    assert float((pa - pu).abs().max()) <= 2e-4 and moved > 1e-3
