@@ -411,10 +411,19 @@ def test_bf16_training_trajectory_follows_the_fp32_hip_path(golden, shape):
     assert (rel < bound).all(), (worst, float(rel[worst]), float(bound[worst]))
     assert len(stats["fp32"]) >= 8                                # 4 layers x 4 units x (mean, var)
     # Running statistics.  What they are FOR is the eval-mode forward: its loss on the same batch agrees like the training losses do.
+    # Two fp32 samples do not pin the width of the fp32 path's OWN eval-mode distribution either (20 fp32 runs each, round 6: golden dims
+    # 2.220 ... 2.329 with the bf16 run at 2.2372 every time; full width 5.467 ... 6.107 -- the near-constant columns of the first layers
+    # make the fp32 running statistics themselves irreproducible -- with the bf16 run at 5.561 ... 5.565): the bound is at least the
+    # measured half-width of that distribution around the bf16 value, 6 % / 15 %.
     e_rel, e_own = abs(evals["bf16"] - evals["fp32"]) / evals["fp32"], abs(evals["fp32_again"] - evals["fp32"]) / evals["fp32"]
-    assert e_rel < 2e-2 + 2.0 * max(e_own, float(own.max())), (evals, e_rel, e_own)
+    e_floor = 6e-2 if shape == "golden_dims" else 15e-2
+    assert e_rel < max(2e-2 + 2.0 * max(e_own, float(own.max())), e_floor), (evals, e_rel, e_own)
     # Element-wise they are a soft spot of bf16 storage and the test says how soft: a unit output whose column mean exceeds its spread is
     # stored with 2^-9 |mean| of rounding per element, so the one-pass statistics of the bf16 rows move by a fraction of the layer's
     # standard deviation -- measured 1.6 layer-std on the golden dims (x50 GCN weights; fp32 against itself: 0.07-0.19) -- while at full
     # width the near-constant columns of the first layers make even two fp32 runs differ by 20-30 layer-std, bf16 no more than they do.
-    assert bm < max(2.5, 2.0 * om) and bv < max(1.5, 2.0 * ov), (bm, bv, om, ov)
+    # (ten jobs, round 6, full width: bf16 20.9-29.5 layer-std / 7.5-19.6 layer-var, fp32 against itself 16.0-34.2 / 4.4-24.1 -- one
+    # fp32 pair is a noisy yardstick there, so the bound is at least twice the largest fp32 self-deviation seen; golden dims: bf16
+    # 1.57-1.61 / 0.93-0.95 every time, fp32 against itself 0.04-0.22 / 0.03-0.11)
+    wide_m, wide_v = (0.0, 0.0) if shape == "golden_dims" else (70.0, 50.0)
+    assert bm < max(2.5, 2.0 * om, wide_m) and bv < max(1.5, 2.0 * ov, wide_v), (bm, bv, om, ov)
