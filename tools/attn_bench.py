@@ -16,7 +16,7 @@ from subgc import ops  # noqa: E402
 CONFIGS = {           # rows, (min, max) set length, A, R, bf16 sets
     "fgk": (1280, (37, 37), 512, 1000, True),
     "flickr": (640, (2, 30), 512, 1000, True),
-    "kar": (1280, (2, 11), 512, 1000, False),
+    "kar": (640, (2, 11), 512, 1000, False),        # 128 images x 5 sentences
 }
 
 
