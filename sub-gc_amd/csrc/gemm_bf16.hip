@@ -446,6 +446,93 @@ __device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[G::MA][G::NB],
     for_each_quad_seq<G>(acc, m0, n0, M, N, f, std::make_integer_sequence<int, G::MA>{});
 }
 
+// The same walk with the accumulators TRANSPOSED THROUGH LDS first (round 6).  In the register layout above one store instruction
+// touches 32 different rows and writes 32 (fp32) or 16 (bf16) bytes of each -- every 128-byte line of C is written in four separate
+// instructions, and a 256 x 256 tile's epilogue ran at 1.9 TB/s (bf16 result) / 2.9 TB/s (fp32) when the whole chip stored at once:
+// 16-20 us appended to every round of the one-workgroup-per-CU form.  Here each wave writes a 32-row slab of its sub-tile into its
+// own LDS region (row pitch + 4 floats: the 16-byte writes of 16 lanes fall on 64 distinct banks), reads it back row-major and hands
+// f() quads whose lanes are CONSECUTIVE along a row: one store instruction = 4 (or 2) whole row segments of 256 (512) bytes.  The
+// stages are dead by then (one barrier); a wave only ever touches its own region, in program order, so no further barrier is needed.
+template <typename G, int A, typename F>
+__device__ __forceinline__ void quads_of_row_lds(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, float* mine, F& f) {
+    constexpr int WC = 32 * G::NB, PITCH = WC + 4, LPR = WC / 4, RPI = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave / G::WN) * (32 * G::MA), wn = (wave % G::WN) * (32 * G::NB);
+    float* wr = mine + (lane & 31) * PITCH + 4 * (lane >> 5);
+#pragma unroll
+    for (int b = 0; b < G::NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(wr + b * 32 + 8 * q) = make_float4(acc[A][b][4 * q], acc[A][b][4 * q + 1], acc[A][b][4 * q + 2], acc[A][b][4 * q + 3]);
+    const int c = 4 * (lane % LPR), n = n0 + wn + c;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = RPI * i + lane / LPR;
+        const float4 t = *reinterpret_cast<const float4*>(mine + r * PITCH + c);
+        const int m = m0 + wm + A * 32 + r;
+        if (m < M && n < N) {
+            Quad x{{t.x, t.y, t.z, t.w}};
+            f(m, n, x);
+        }
+    }
+}
+template <typename G, typename F, int... As>
+__device__ __forceinline__ void for_each_quad_lds_seq(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, float* mine, F& f,
+                                                      std::integer_sequence<int, As...>) {
+    (quads_of_row_lds<G, As>(acc, m0, n0, M, N, mine, f), ...);
+}
+// N % 4 == 0 (whole quads).  `smem`: the workgroup's dynamic LDS (>= NW * 32 * (32 NB + 4) floats: 35 / 68 / 70 KB of the 64 / 128 / 128 the forms own)
+template <typename G, typename F>
+__device__ __forceinline__ void for_each_quad_lds(const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, int N, unsigned char* smem, F&& f) {
+    constexpr int PITCH = 32 * G::NB + 4;
+    if constexpr ((size_t)G::NW * 32 * PITCH * 4 <= G::LDS || G::NW == 8) {
+        float* mine = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * (32 * PITCH);
+        __syncthreads();                                        // every wave is past its last stage read
+        for_each_quad_lds_seq<G>(acc, m0, n0, M, N, mine, f, std::make_integer_sequence<int, G::MA>{});
+    } else for_each_quad<G>(acc, m0, n0, M, N, f);              // the 16-wave form: its slabs would not fit (139 KB), it keeps the register walk
+}
+
+// A bf16-ONLY destination with nothing but bias / ReLU in the epilogue: the quads are finished and packed in registers, the slab holds
+// bf16 (row pitch + 16 bytes), a lane reads 16 bytes = EIGHT columns back and one store instruction writes 8 whole 128-byte row
+// segments -- half the LDS traffic and half the store instructions of the fp32 slab (a bf16 result through the fp32 slab stored
+// 8 bytes per lane and took LONGER than an fp32 result of twice the bytes).
+template <typename G, int A>
+__device__ __forceinline__ void quads_of_row_lds_b16(const Args& p, const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, unsigned char* mine, bool relu) {
+    constexpr int WC = 32 * G::NB, PITCH = WC * 2 + 16, LPR = WC / 8, RPI = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave / G::WN) * (32 * G::MA), wn = (wave % G::WN) * (32 * G::NB);
+    unsigned char* wr = mine + (lane & 31) * PITCH + 8 * (lane >> 5);
+#pragma unroll
+    for (int b = 0; b < G::NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4] = {acc[A][b][4 * q], acc[A][b][4 * q + 1], acc[A][b][4 * q + 2], acc[A][b][4 * q + 3]};
+            const int n = n0 + wn + b * 32 + 8 * q + 4 * (lane >> 5);
+            if (p.bias && n < p.N) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            uint2 o;
+            o.x = f2bf(v[0]) | (f2bf(v[1]) << 16);
+            o.y = f2bf(v[2]) | (f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(wr + (b * 32 + 8 * q) * 2) = o;
+        }
+    const int c = 8 * (lane % LPR), n = n0 + wn + c;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = RPI * i + lane / LPR;
+        const uint4 t = *reinterpret_cast<const uint4*>(mine + r * PITCH + c * 2);
+        const int m = m0 + wm + A * 32 + r;
+        if (m < M && n < p.N) *reinterpret_cast<uint4*>(p.C16 + (int64_t)m * p.ldc16 + n) = t;
+    }
+}
+template <typename G, int... As>
+__device__ __forceinline__ void store_tile_b16_lds_seq(const Args& p, const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, unsigned char* mine, bool relu,
+                                                       std::integer_sequence<int, As...>) {
+    (quads_of_row_lds_b16<G, As>(p, acc, m0, n0, M, mine, relu), ...);
+}
+
 // The column sums a workgroup's threads hold after mainloop_dma<.., CS = true>: thread t has columns 8 (t % (TBM/8)) .. +7 over its k-rows;
 // the NT / (TBM/8) row groups meet in LDS (everybody is past the last stage read after the barrier) and thread m < TBM stores column
 // m0 + m.  Fixed summation order.
@@ -468,12 +555,12 @@ __device__ __forceinline__ void colsum_store(unsigned char* smem, const float (&
 
 // bias / residual / ReLU / keep-mask / accumulate, results to fp32 and / or bf16 (one 16-byte / 8-byte store per accumulator quad)
 template <typename G>
-__device__ __forceinline__ void store_tile(const Args& p, const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M) {
+__device__ __forceinline__ void store_tile(const Args& p, const f32x16 (&acc)[G::MA][G::NB], int m0, int n0, int M, unsigned char* smem) {
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
     // vector form: every quad is whole (N % 4 == 0) and every row start 16 / 8 bytes aligned
     const bool vec = p.N % 4 == 0 && (!p.C32 || (p.ldc32 % 4 == 0 && aligned16(p.C32))) && (!p.C16 || (p.ldc16 % 4 == 0 && aligned8(p.C16))) &&
                      (!p.bias || aligned16(p.bias)) && (!p.add || (p.ldadd % 4 == 0 && aligned16(p.add))) && (!p.keep || aligned4(p.keep));
-    for_each_quad<G>(acc, m0, n0, M, p.N, [&](int m, int n, Quad& x) {
+    auto body = [&](int m, int n, Quad& x) {
         const int64_t row = m;
         if (vec) {
             if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); x.v[0] += t.x; x.v[1] += t.y; x.v[2] += t.z; x.v[3] += t.w; }
@@ -515,7 +602,15 @@ __device__ __forceinline__ void store_tile(const Args& p, const f32x16 (&acc)[G:
             }
             if (p.C16) p.C16[row * p.ldc16 + col] = (uint16_t)f2bf(v);
         }
-    });
+    };
+    constexpr bool slabs = (size_t)G::NW * 32 * (32 * G::NB + 4) * 4 <= G::LDS || G::NW == 8;
+    // (all three conditions are workgroup-uniform)
+    if (slabs && vec && p.C16 && !p.C32 && !p.add && !p.keep && p.N % 8 == 0 && p.ldc16 % 8 == 0 && aligned16(p.C16)) {
+        unsigned char* mine = smem + (threadIdx.x >> 6) * (32 * (32 * G::NB * 2 + 16));
+        __syncthreads();                                        // every wave is past its last stage read
+        store_tile_b16_lds_seq<G>(p, acc, m0, n0, M, mine, relu, std::make_integer_sequence<int, G::MA>{});
+    } else if (vec) for_each_quad_lds<G>(acc, m0, n0, M, p.N, smem, body);
+    else for_each_quad<G>(acc, m0, n0, M, p.N, body);
 }
 
 template <typename G, bool A_KM, bool B_KM, bool CS = false>
@@ -538,7 +633,7 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
         mainloop_dma<G, A_KM, B_KM, true>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc, cs, n0 == 0);
         if (n0 == 0) colsum_store<G>(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);
     } else mainloop_dma<G, A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
-    store_tile<G>(p, acc, m0, n0, M);
+    store_tile<G>(p, acc, m0, n0, M, smem);
 }
 
 template <typename G, bool A_KM, bool B_KM, bool CS = false>
@@ -565,7 +660,7 @@ __global__ __launch_bounds__(G::NT, (G::NT == 256 ? 2 : G::NT / 256)) void gemm_
         if (n0 == 0) colsum_store<G>(smem, cs, m0, p.M, p.cs_part + (size_t)part * p.M, false);    // an empty part stores zeros
     } else mainloop_dma<G, A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     float* out = ws + (size_t)part * p.M * p.N;                 // raw partial plane [M][N]; N % 4 == 0 on this path
-    for_each_quad<G>(acc, m0, n0, p.M, p.N, [&](int m, int n, Quad& x) {
+    for_each_quad_lds<G>(acc, m0, n0, p.M, p.N, smem, [&](int m, int n, Quad& x) {
         *reinterpret_cast<float4*>(out + (size_t)m * p.N + n) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
     });
 }
@@ -633,7 +728,7 @@ __global__ __launch_bounds__(p8::NT) void gemm_bf16_p8_kernel(const Args p_in) {
         p8::mainloop<A_KM, B_KM, true>(p, smem, M, K, m0, n0, 0, (K + p8::KT - 1) / p8::KT, acc, cs, n0 == 0);
         if (n0 == 0) p8::colsum_store(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);
     } else p8::mainloop<A_KM, B_KM>(p, smem, M, K, m0, n0, 0, (K + p8::KT - 1) / p8::KT, acc);
-    store_tile<GP8>(p, acc, m0, n0, M);
+    store_tile<GP8>(p, acc, m0, n0, M, smem);
 }
 
 template <bool A_KM, bool B_KM, bool CS = false>
@@ -660,7 +755,7 @@ __global__ __launch_bounds__(p8::NT) void gemm_bf16_p8_splitk_kernel(const Args 
         if (n0 == 0) p8::colsum_store(smem, cs, m0, p.M, p.cs_part + (size_t)part * p.M, false);   // an empty part stores zeros
     } else p8::mainloop<A_KM, B_KM>(p, smem, p.M, K, m0, n0, kt0, kt1, acc);
     float* out = ws + (size_t)part * p.M * p.N;
-    for_each_quad<GP8>(acc, m0, n0, p.M, p.N, [&](int m, int n, Quad& x) {
+    for_each_quad_lds<GP8>(acc, m0, n0, p.M, p.N, smem, [&](int m, int n, Quad& x) {
         *reinterpret_cast<float4*>(out + (size_t)m * p.N + n) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
     });
 }
@@ -676,7 +771,9 @@ struct Plan { int big; int splits; double cost; };            // big: 0 = 128 x 
 // busy (0.685 per 32 deep; 1.56 when B is K-major: its sub-tile images are 64-byte row pieces), 20 us per tile round outside the K loop
 // with an fp32 destination, 17 with bf16 only -- and 10 us once per launch that only shows INSIDE a train step (tools/gemm_insitu_ab.py): a
 // lone 128 KiB workgroup per CU starts on operands the step left in HBM, and one round of K <= 1024 (the GCN products) then runs slower than the
-// ring forms although the warm stand-alone sweep says the opposite.
+// ring forms although the warm stand-alone sweep says the opposite.  With the LDS-transposed epilogue (for_each_quad_lds) the per-round cost fell to
+// 14 / 13 us (16384 x 1024 x 1024: 47 -> 41 us with an fp32 result, the store phase now at the HBM write rate), which moves the 9472-row GCN
+// products and the heads of the 16640-row ones to this form.
 inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool out32 = true, int nprob = 1, bool allow_p8 = false, bool b_km_only = false) {
     const int kt = (int)subgc::cdiv(K, BK);
     Plan best{0, 1, 1e30};
@@ -684,8 +781,8 @@ inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool 
         const int64_t tiles = nprob * (big ? subgc::cdiv(M, 256) * subgc::cdiv(N, 256) : subgc::cdiv(M, 128) * subgc::cdiv(N, 128));
         const int slots = big ? 256 : 512;
         const double c = big == 2 ? (b_km_only ? 0.78 : 0.685) : big ? 0.85 : 0.67;
-        const double e = big == 2 ? (out32 ? 20.0 : 17.0) : (big ? 24.0 : 12.0) * (out32 ? 1.0 : 0.55);
-        const double once = big == 2 ? 10.0 : 0.0;
+        const double e = big == 2 ? (out32 ? 14.0 : 13.0) : (big ? 24.0 * (out32 ? 1.0 : 0.8) : 12.0 * (out32 ? 1.0 : 0.55));    // eight-phase: 20 / 17 before its results went through LDS
+        const double once = big == 2 ? 6.0 : 0.0;
         for (int s = 1; s <= 8; ++s) {
             if (s > 1 && (!may_split || (kt + s - 1) / s < 12 || (size_t)nprob * s * M * N * sizeof(float) > ws_bytes)) break;
             const int per = (kt + s - 1) / s;

@@ -60,8 +60,10 @@ def main():
     ap.add_argument("--out16", action="store_true", help="bf16 destination (what torch.mm on bf16 tensors writes) instead of fp32")
     ap.add_argument("--tile", default="0", choices=("0", "128", "256", "p8"), help="force the workgroup form (SUBGC_GEMM_TILE128 / TILE256 / TILE_P8 flag bits)")
     ap.add_argument("--no-p8", action="store_true", help="forbid the eight-phase form (SUBGC_GEMM_NO_P8)")
+    ap.add_argument("--splits", type=int, default=0, help="force this many K parts (SUBGC_GEMM_SPLITS(n); 0 = the cost model decides)")
     a = ap.parse_args()
-    ops.gemm_tune.b16_bits = ops.gemm_tune.TILE_BITS[a.tile if a.tile == "p8" else int(a.tile)] | ((1 << 14) if a.no_p8 else 0)
+    ops.WS_MBYTES = max(ops.WS_MBYTES, 1024)
+    ops.gemm_tune.b16_bits = ops.gemm_tune.TILE_BITS[a.tile if a.tile == "p8" else int(a.tile)] | ((1 << 14) if a.no_p8 else 0) | ((a.splits & 15) << 8)
     sh = shapes(a.config)
     if a.shape:
         sh = [("custom",) + tuple(int(x) if i else x for i, x in enumerate(s.split(","))) + (1,) for s in a.shape.split(";")]
