@@ -398,14 +398,54 @@ __device__ __forceinline__ void for_each_quad(const f32x16 (&acc)[MT][NT], int m
     for_each_quad_seq<MT, NT, WAVES_N>(acc, m0, n0, M, N, f, std::make_integer_sequence<int, MT>{});
 }
 
+// The same walk with the accumulators TRANSPOSED THROUGH LDS first (round 6; the bf16 kernels' for_each_quad_lds has the measurements): in the
+// register layout one store instruction touches 32 rows and writes 32 bytes of each; here every wave writes a 32-row slab of its sub-tile
+// into its own LDS region (row pitch + 4 floats), reads it back row-major and hands f() quads whose lanes are consecutive along a row --
+// one store instruction = whole row segments of 128 / 256 bytes.  The stages are dead (the main loop ends with a barrier, so does the
+// column-sum exchange); a wave only touches its own region, in program order.  N % 4 == 0.
+template <int MT, int NT, int WAVES_N, int A, typename F>
+__device__ __forceinline__ void quads_of_row_lds(const f32x16 (&acc)[MT][NT], int m0, int n0, int M, int N, float* mine, F& f) {
+    constexpr int WC = 32 * NT, PITCH = WC + 4, LPR = WC / 4, RPI = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 7;
+    const int wm = (wave / WAVES_N) * (32 * MT), wn = (wave % WAVES_N) * (32 * NT);
+    float* wr = mine + (lane & 31) * PITCH + 4 * (lane >> 5);
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(wr + b * 32 + 8 * q) = make_float4(acc[A][b][4 * q], acc[A][b][4 * q + 1], acc[A][b][4 * q + 2], acc[A][b][4 * q + 3]);
+    const int c = 4 * (lane % LPR), n = n0 + wn + c;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = RPI * i + lane / LPR;
+        const float4 t = *reinterpret_cast<const float4*>(mine + r * PITCH + c);
+        const int m = m0 + wm + A * 32 + r;
+        if (m < M && n < N) {
+            Quad x{{t.x, t.y, t.z, t.w}};
+            f(m, n, x);
+        }
+    }
+}
+template <int MT, int NT, int WAVES_N, typename F, int... As>
+__device__ __forceinline__ void for_each_quad_lds_seq(const f32x16 (&acc)[MT][NT], int m0, int n0, int M, int N, float* mine, F& f, std::integer_sequence<int, As...>) {
+    (quads_of_row_lds<MT, NT, WAVES_N, As>(acc, m0, n0, M, N, mine, f), ...);
+}
+// `smem`: the workgroup's stages (4 waves x 32 rows x (32 NT + 4) floats = 35 KB of the 74 KB of a 128 x 128 tile, 18 of 37 KB for 64 x 64)
+template <int BM, int BN, int MT, int NT, typename F>
+__device__ __forceinline__ void for_each_quad_lds(const f32x16 (&acc)[MT][NT], int m0, int n0, int M, int N, float* smem, F&& f) {
+    static_assert(BM == 2 * 32 * MT && BN == 2 * 32 * NT, "2 x 2 waves cover the tile");
+    float* mine = smem + ((threadIdx.x >> 6) & 3) * (32 * (32 * NT + 4));
+    for_each_quad_lds_seq<MT, NT, 2>(acc, m0, n0, M, N, mine, f, std::make_integer_sequence<int, MT>{});
+}
+
 __device__ __forceinline__ bool dev_aligned(const void* p, unsigned mask) { return (reinterpret_cast<uintptr_t>(p) & mask) == 0; }
 
 template <int BM, int BN, int MT, int NT, int WAVES_N = 2>
-__device__ __forceinline__ void epilogue(const GemmArgs& p, int M, int m0, int n0, f32x16 (&acc)[MT][NT]) {
+__device__ __forceinline__ void epilogue(const GemmArgs& p, int M, int m0, int n0, f32x16 (&acc)[MT][NT], float* smem = nullptr) {
     const bool relu = p.flags & SUBGC_GEMM_RELU, accum = p.flags & SUBGC_GEMM_ACCUM;
     const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && dev_aligned(p.C, 15) && (!p.bias || dev_aligned(p.bias, 15)) &&
                      (!p.add || (p.ldadd % 4 == 0 && dev_aligned(p.add, 15))) && (!p.keep || dev_aligned(p.keep, 3));
-    for_each_quad<BM, BN, MT, NT, WAVES_N>(acc, m0, n0, M, p.N, [&](int m, int n, Quad& x) {
+    auto body = [&](int m, int n, Quad& x) {
         int64_t row = m;
         if (p.c_rows) {
             const int g = p.c_rows[m];
@@ -441,7 +481,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int M, int m0, int n
             if (accum) v += *dst;
             *dst = v;
         }
-    });
+    };
+    if constexpr (WAVES_N == 2) {
+        if (smem != nullptr && vec) { for_each_quad_lds<BM, BN, MT, NT>(acc, m0, n0, M, p.N, smem, body); return; }      // (workgroup-uniform)
+    }
+    for_each_quad<BM, BN, MT, NT, WAVES_N>(acc, m0, n0, M, p.N, body);
 }
 
 // ---- workgroup -> tile mapping for L2 locality ------------------------------------------------------
@@ -504,7 +548,7 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_kern
         mainloop<BM, BN, TA, TB, VEC, MT, NT, true>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc, &cs);
         if (n0 == 0) colsum_store<BM>(smem, cs, m0, M, p.cs_out, p.cs_accum != 0);           // workgroup-uniform
     } else mainloop<BM, BN, TA, TB, VEC, MT, NT>(p, smem, M, K, m0, n0, 0, (K + BK - 1) / BK, acc);
-    epilogue<BM, BN, MT, NT>(p, M, m0, n0, acc);
+    epilogue<BM, BN, MT, NT>(p, M, m0, n0, acc, XM == 0 ? smem : nullptr);       // (the staging-wave forms have left half the workgroup behind)
 }
 
 // split-K form for shapes whose tile count cannot fill 256 CUs (the per-step recurrent GEMMs, M = 640:
@@ -549,13 +593,15 @@ __global__ __launch_bounds__(XM ? 512 : 256, XM >= 3 ? 2 : 1) void gemm_f32_spli
     // raw partial tile -> ws[part][m][n] (accumulators hold C^T quads, see epilogue)
     float* out = ws + (size_t)part * p.M * p.N;
     const bool vec = p.N % 4 == 0;                               // ws planes are 16-byte aligned
-    for_each_quad<BM, BN, MT, NT>(acc, m0, n0, p.M, p.N, [&](int m, int n, Quad& x) {
+    auto body = [&](int m, int n, Quad& x) {
         float* d = out + (size_t)m * p.N + n;
         if (vec) { *reinterpret_cast<float4*>(d) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]); return; }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (n + e < p.N) d[e] = x.v[e];
-    });
+    };
+    if (XM == 0 && vec) for_each_quad_lds<BM, BN, MT, NT>(acc, m0, n0, p.M, p.N, smem, body);
+    else for_each_quad<BM, BN, MT, NT>(acc, m0, n0, p.M, p.N, body);
 }
 
 // C = [C +] bias + sum_parts ws[part]   (float4 along N when N % 4 == 0 and C is 16-byte aligned)
