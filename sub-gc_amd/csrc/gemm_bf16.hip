@@ -783,7 +783,7 @@ inline Plan plan_for(int M, int N, int K, bool may_split, size_t ws_bytes, bool 
         const double c = big == 2 ? (b_km_only ? 0.78 : 0.685) : big ? 0.85 : 0.67;
         const double e = big == 2 ? (out32 ? 14.0 : 13.0) : (big ? 24.0 * (out32 ? 1.0 : 0.8) : 12.0 * (out32 ? 1.0 : 0.55));    // eight-phase: 20 / 17 before its results went through LDS
         const double once = big == 2 ? 6.0 : 0.0;
-        for (int s = 1; s <= 8; ++s) {
+        for (int s = 1; s <= (big == 2 ? 15 : 8); ++s) {        // 15: what SUBGC_GEMM_SPLITS can name; ~1024-deep parts of the GCN weight gradients (16 tiles, K = 16640) fill the chip
             if (s > 1 && (!may_split || (kt + s - 1) / s < 12 || (size_t)nprob * s * M * N * sizeof(float) > ws_bytes)) break;
             const int per = (kt + s - 1) / s;
             const int64_t rounds = (tiles * s + slots - 1) / slots;
@@ -1011,7 +1011,7 @@ SUBGC_API int subgc_gemm_bf16_workspace_bytes(int M, int N, int K, size_t* bytes
     // scratch the split-K form of this shape wants (its fp32 partial planes); 0 when the shape never splits.  A smaller
     // (or no) workspace is legal: the dispatch then splits less (or not at all).
     SUBGC_REQUIRE(M >= 0 && N >= 0 && K >= 0 && bytes, "gemm_bf16_workspace_bytes: bad arguments");
-    const Plan pl = plan_for(M, N, K, true, (size_t)8 * M * N * sizeof(float));
+    const Plan pl = plan_for(M, N, K, true, (size_t)15 * M * N * sizeof(float), true, 1, K % 8 == 0);
     *bytes = pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
     return SUBGC_OK;
 }
@@ -1051,7 +1051,7 @@ SUBGC_API int subgc_gemm_bf16_wgrad(int M, int N, int K, const uint16_t* dY, int
     Args a{dY, X, dW, nullptr, nullptr, nullptr, nullptr, m_dev, lddy, ldx, lddw, 0, 0, M, N, K, flags, 1.f};
     a.cs_out = db; a.cs_accum = db_accumulate ? 1 : 0;
     float* ws = static_cast<float*>(workspace);
-    const size_t cs_bytes = ((size_t)8 * M * sizeof(float) + 15) & ~(size_t)15;
+    const size_t cs_bytes = ((size_t)15 * M * sizeof(float) + 15) & ~(size_t)15;
     if (ws && ws_bytes > cs_bytes) {                            // the split-K form's partial sums live behind its planes
         ws_bytes = (ws_bytes - cs_bytes) & ~(size_t)15;
         a.cs_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_bytes);
