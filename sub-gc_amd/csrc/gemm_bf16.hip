@@ -671,7 +671,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __r
                                                                 const float* __restrict__ bias, int accum, int relu,
                                                                 const float* __restrict__ cs_part = nullptr, float* __restrict__ cs_out = nullptr,
                                                                 int cs_accum = 0, float* __restrict__ C32b = nullptr, uint16_t* __restrict__ C16b = nullptr,
-                                                                const float* __restrict__ bias2 = nullptr) {
+                                                                const float* __restrict__ bias2 = nullptr, const uint8_t* __restrict__ keep = nullptr,
+                                                                float keep_scale = 1.f) {
     const size_t plane = (size_t)M * N;
     if (blockIdx.y == 1) { ws += (size_t)splits * plane; C32 = C32b; C16 = C16b; bias = bias2; }     // pair launch: grid.y = problem
     if (cs_part != nullptr)                                     // column sums of A that came with a weight gradient: parts added in order
@@ -690,6 +691,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __r
             v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (keep) {                                             // dense [M, N] dropout mask, after the ReLU like in store_tile (single-problem launches only)
+            const uint32_t k4 = *reinterpret_cast<const uint32_t*>(keep + row * N + c4);
+            v.x = (k4 & 0xffu) ? v.x * keep_scale : 0.f; v.y = ((k4 >> 8) & 0xffu) ? v.y * keep_scale : 0.f;
+            v.z = ((k4 >> 16) & 0xffu) ? v.z * keep_scale : 0.f; v.w = (k4 >> 24) ? v.w * keep_scale : 0.f;
+        }
         if (C32) {
             float4* d = reinterpret_cast<float4*>(C32 + row * ldc32 + c4);
             if (accum) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
@@ -849,7 +855,7 @@ int launch(const Args& a, float* ws, int splits, bool partials_only, hipStream_t
     const int64_t n = (int64_t)a.M * a.N / 4;
     hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048), (unsigned)a.nprob), dim3(256), 0, s, (const float*)ws,
                        splits, a.M, a.N, a.C32, a.ldc32, a.C16, a.ldc16, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0,
-                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum, a.C32b, a.C16b, a.bias2);
+                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum, a.C32b, a.C16b, a.bias2, a.keep, a.keep_scale);
     return subgc::check_launch("subgc_gemm_bf16(split-K)");
 }
 
@@ -892,7 +898,7 @@ int launch_p8(const Args& a, float* ws, int splits, bool partials_only, hipStrea
     const int64_t n = (int64_t)a.M * a.N / 4;
     hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048), (unsigned)a.nprob), dim3(256), 0, s, (const float*)ws,
                        splits, a.M, a.N, a.C32, a.ldc32, a.C16, a.ldc16, a.bias, (a.flags & SUBGC_GEMM_ACCUM) ? 1 : 0,
-                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum, a.C32b, a.C16b, a.bias2);
+                       (a.flags & SUBGC_GEMM_RELU) ? 1 : 0, with_cs ? (const float*)a.cs_part : nullptr, a.cs_out, a.cs_accum, a.C32b, a.C16b, a.bias2, a.keep, a.keep_scale);
     return subgc::check_launch("subgc_gemm_bf16(p8, split-K)");
 }
 
@@ -905,7 +911,8 @@ inline bool p8_ok(const Args& a, bool a_km, bool b_km) {
 
 template <bool A_KM, bool B_KM>
 int run(const Args& a, float* ws, size_t ws_bytes, hipStream_t s, bool partials_only, int* splits_out, bool may_cut_rows = true) {
-    const bool plain = !a.add && !a.keep && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
+    // (a dropout mask rides the reduce pass of a single-problem launch: the 320-row fc projection of the Flickr shape, K = 4096, is 24 tiles)
+    const bool plain = !a.add && (!a.keep || (a.nprob == 1 && aligned4(a.keep))) && (!a.m_dev || A_KM) && a.N % 4 == 0 && (!a.C32 || (a.ldc32 % 4 == 0 && aligned16(a.C32))) &&
                        (!a.C16 || (a.ldc16 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C16) & 7) == 0)) && (!a.bias || aligned16(a.bias)) &&
                        (a.nprob == 1 || ((!a.C32b || aligned16(a.C32b)) && (!a.C16b || (reinterpret_cast<uintptr_t>(a.C16b) & 7) == 0) &&
                                          (!a.bias2 || aligned16(a.bias2))));

@@ -258,6 +258,24 @@ def test_gemm_bf16_eight_phase_split_k(mode, M, N, K, splits):
     assert float((out.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("tile,splits", [(128, 4), ("p8", 3), (0, 0)])
+def test_gemm_bf16_split_k_with_relu_and_dropout_mask(tile, splits):
+    """The reduce pass of a split product applies bias -> ReLU -> keep mask like the tile epilogue does (round 6: the 320-row fc projection
+    of the Flickr shape, K = 4096, is 24 tiles of 128 x 128 and used to run unsplit because of its mask); fp32 and bf16 destinations of one
+    call agree; tile = 0: the dispatch's own choice for this shape."""
+    M, N, K = 320, 1000, 4096
+    a, b, ref = operands("nt", M, N, K, seed=11)
+    bias = rnd(N, seed=5)
+    keep = (torch.rand(M, N, generator=torch.Generator().manual_seed(7)) < 0.5).to(torch.uint8).to(DEV)
+    want = torch.relu(ref + bias.double()) * keep.double() * 2.0
+    out, o16 = torch.full((M, N), float("nan"), device=DEV), torch.empty(M, N, device=DEV, dtype=BF)
+    with ops.gemm_tune(tile=tile, splits=splits):
+        ops.gemm(a, b, out, tb=True, bias=bias, relu=True, keep=keep, keep_scale=2.0, out16=o16)
+    assert float((out.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+    assert torch.equal(o16, out.to(BF))
+    assert float(out[keep == 0].abs().max()) == 0.0
+
+
 def test_gemm_bf16_eight_phase_epilogues_row_count_and_repeatability():
     M, N, K = 700, 1000, 512
     a, b, ref = operands("nt", M, N, K, seed=3)
